@@ -1,0 +1,180 @@
+"""ELBO-steps/sec of the fused HIP step (BASELINE.json metric), with the kernel roofline and the CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): MNIST shapes, model "h2,s2,e2", learnable curvature, MLP h_dim 400, batch 128 per
+GPU, float32, epoch >= 10 state (radii 2.0, curvature SGD active).  One "step" = ModelVAE.train_step: forward, ELBO,
+backward, Adam + SGD on the radii (+ gradient all-reduce when N > 1).  Inputs (binarised x, eps) are synthetic
+(mvae_amd/synthetic.py) and resident in HBM before the timed region; weights are the synthetic init.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL = "h2,s2,e2"
+COMPS = [("h", 2), ("s", 2), ("e", 2)]
+B, D, H = 128, 784, 400
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+
+
+def algorithmic_per_launch(P):
+    """Algorithmic bytes / flops of each launch of one step at B=128 (each tensor once)."""
+    NH, Z = 12, 8
+    f4 = 4.0
+    return {
+        "enc_fwd": dict(flops=2.0 * B * D * H, bytes=f4 * (B * D + H * D + H + B * H)),
+        "latent_fwd": dict(flops=2.0 * B * H * NH + 2.0 * B * Z * H,
+                           bytes=f4 * (B * H + NH * H + NH + B * 6 + H * Z + H + B * Z + B * H)),
+        "dec1_fwd": dict(flops=2.0 * B * H * D, bytes=f4 * (B * H + D * H + D + 2 * B * D)),
+        "dec1_bwd": dict(flops=4.0 * B * H * D, bytes=f4 * (B * D + B * H + D * H + D * H + D + B * H)),
+        "latent_bwd": dict(flops=4.0 * B * H * Z + 2.0 * B * NH * H,
+                           bytes=f4 * (2 * B * H + H * Z + NH * H + B * H + H * Z + H)),
+        "enc_bwd": dict(flops=2.0 * B * H * D + 2.0 * B * NH * H, bytes=f4 * (B * H + B * D + H * D + NH * H + B * H)),
+        "optim": dict(flops=12.0 * P, bytes=f4 * 7 * P),  # read p,g,m,v ; write p,m,v
+    }
+
+
+def cpu_baseline(seconds_budget=15.0):
+    """The oracle (CPU restatement of the reference path, validated against golden vectors) timed on this box's host
+    cores: same model, same synthetic inputs, same step (fwd, ELBO, bwd, Adam + curvature SGD)."""
+    from mvae_amd import synthetic
+    from oracle import model as M
+    spec = M.Spec(MODEL, in_dim=D, h_dim=H, fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    n_data = 16
+    xs = synthetic.binary_batches(n_data, B, D)
+    eps = synthetic.eps_batches(n_data, B, spec.total_true_dim)
+    orc = M.StepOracle(spec, state0)
+    for s in range(5):
+        orc.train_step(xs[s % n_data], eps[s % n_data], 1.0, epoch=12)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        orc.train_step(xs[n % n_data], eps[n % n_data], 1.0, epoch=12)
+        n += 1
+        if n >= 50 and time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ELBO-steps/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of the same h2,s2,e2 B=128 workload in {dt:.1f}s (oracle = CPU restatement of "
+                      "ModelVAE.train_step, float32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--graph-steps", type=int, default=50,
+                    help="steps captured per HIP graph (0 = eager launches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import StepRunner
+
+    eng = StepEngine(COMPS, D, H, dev, radius_trainable=[True, True, False], lr=1e-3)
+    shapes = [(n, s) for n, _, s in eng.flat.entries]
+    eng.load_state(synthetic.synthetic_state(shapes, radius=2.0))
+    n_data = max(args.graph_steps, 1) * 4  # distinct resident batches, cycled
+    xs = synthetic.binary_batches(n_data, B, D, seed=4321 + rank).to(dev)
+    eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
+    runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=True, graph_steps=args.graph_steps,
+                        world_size=world)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    runner.run(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = eng.read_stats()
+    assert stats["sum"]["steps"] == args.warmup + args.steps, stats["sum"]["steps"]
+    assert all(map(lambda v: v == v and abs(v) != float("inf"), [stats["last"]["elbo"]])), "non-finite ELBO"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # per-launch durations measured live with HIP events on the launch stream (mvae_step_profile)
+    prof = eng.profile_step(xs[0], eps[0], 1.0, True, iters=200)
+    alg = algorithmic_per_launch(eng.flat.n_logical_params())
+    dom = max(prof, key=prof.get)
+    dur_s = prof[dom] * 1e-3
+    hbm_gbs = alg[dom]["bytes"] / dur_s / 1e9
+    mfma_tf = alg[dom]["flops"] / dur_s / 1e12
+    # the bound that is closer to its peak is the one that limits this launch
+    if hbm_gbs / HBM_PEAK_GBS >= mfma_tf / F32_MFMA_PEAK_TF:
+        roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hbm_gbs / HBM_PEAK_GBS}
+    else:
+        roof = {"bound": "mfma", "achieved": mfma_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": mfma_tf / F32_MFMA_PEAK_TF}
+    roof.update({"kernel": dom, "traffic": None, "kernel_ms": prof,
+                 "step_bytes": sum(v["bytes"] for v in alg.values()),
+                 "step_flops": sum(v["flops"] for v in alg.values())})
+
+    line = {
+        "metric": "ELBO-steps/sec (batch 128) MNIST h2,s2,e2",
+        "value": args.steps * world / dt,
+        "unit": "ELBO-steps/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: MNIST shapes (D=784), model h2,s2,e2, learnable curvature, "
+                               "MLP h_dim=400, batch 128 per GPU, epoch>=10 state",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "graph_steps": args.graph_steps,
+                   "final_elbo_per_sample": stats["last"]["elbo"] / B},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

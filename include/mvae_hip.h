@@ -1,0 +1,208 @@
+/*
+ * mvae_hip.h -- C ABI of libmvae_hip.so: the MI355X (gfx950) implementation of the per-batch hot path of
+ * oskopek/mvae (ModelVAE.train_step and the Riemannian latent-space operators under it).
+ *
+ * The reference has no FFI: its "operator API" is a set of Python classes.  Each entry point
+ * below therefore cites the reference Python interface it stands behind (file:line under /root/reference); the
+ * Python host layer in mvae_amd/ binds these with ctypes and re-exposes them under the reference's class/method
+ * names (see INTEGRATION.md for the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing synchronises, nothing allocates:
+ *     every call is legal inside a HIP graph capture;
+ *   - tensors are row-major, coordinates in the last dim, leading dims flattened to `rows`;
+ *   - return value: 0 on success, MVAE_E_* (<0) for argument errors, a positive hipError_t for runtime errors;
+ *     mvae_last_error() returns a message for the calling thread's last failure;
+ *   - manifold `kind`: the four latent component types of the reference's model-string grammar
+ *     (mt/mvae/utils.py:30-38): e, h, s, p.
+ */
+#ifndef MVAE_HIP_H
+#define MVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVAE_ABI_VERSION 1
+
+enum { MVAE_EUCLIDEAN = 0, MVAE_HYPERBOLOID = 1, MVAE_SPHERE = 2, MVAE_POINCARE = 3 };
+
+enum {
+  MVAE_OK = 0,
+  MVAE_E_BADARG = -1,     /* null pointer, negative size, unknown kind */
+  MVAE_E_UNSUPPORTED = -2,/* shape outside what the kernels were built for (e.g. true_dim > MVAE_MAX_TRUE_DIM) */
+  MVAE_E_ALIGN = -3       /* a matrix whose row stride is not a multiple of 4 floats / base not 16-byte aligned */
+};
+
+#define MVAE_MAX_TRUE_DIM 64
+#define MVAE_MAX_COMPONENTS 64
+
+int mvae_abi_version(void);
+const char* mvae_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Manifold primitives (forward).  Manifold interface: mt/mvae/ops/manifold.py:22-75.
+ * `radius_param` points at ONE float: the raw nn.Parameter (_nradius / _pradius, component.py:123,142,160); the
+ * kernels apply radius = clamp(relu(p), 1e-8, 1e8) themselves (manifold.py:73-75).  Ignored for MVAE_EUCLIDEAN.
+ * `d` is the TRUE dimension; ambient A = d+1 for h/s, d for e/p.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Manifold.exp_map_mu0: x[rows,d] -> out[rows,A].   hyperbolics.py:28-29,114-121 | spherical.py:28-29,94-101 |
+ * euclidean.py:78-79 | poincare.py:132-137 */
+int mvae_exp_map_mu0(int kind, const float* x, float* out, int64_t rows, int d, const float* radius_param,
+                     void* stream);
+
+/* Manifold.inverse_exp_map_mu0: x[rows,A] -> out[rows,A].   hyperbolics.py:131-135 | spherical.py:112-116 |
+ * euclidean.py:86-87 | poincare.py:148-149 */
+int mvae_inverse_exp_map_mu0(int kind, const float* x, float* out, int64_t rows, int d, const float* radius_param,
+                             void* stream);
+
+/* Manifold.parallel_transport_mu0(x, dst): x[rows,A], dst[rows,A] -> out[rows,A].
+ * hyperbolics.py:87-93 | spherical.py:74-77 | euclidean.py:66-67 | poincare.py:116-117 */
+int mvae_parallel_transport_mu0(int kind, const float* x, const float* dst, float* out, int64_t rows, int d,
+                                const float* radius_param, void* stream);
+
+/* Manifold.inverse_parallel_transport_mu0(x, src).   hyperbolics.py:96-103 | spherical.py:80-83 | euclidean.py:70-71 |
+ * poincare.py:120-121 */
+int mvae_inverse_parallel_transport_mu0(int kind, const float* x, const float* src, float* out, int64_t rows, int d,
+                                        const float* radius_param, void* stream);
+
+/* Manifold.sample_projection_mu0(v, at_point) -> (z, (u, v)): v[rows,d]; at[at_rows,A] is broadcast over leading
+ * sample dims (row r uses at[r % at_rows]); z[rows,A], u[rows,A].
+ * hyperbolics.py:138-142 | spherical.py:119-123 | euclidean.py:90-93 | poincare.py:152-157 */
+int mvae_sample_projection_mu0(int kind, const float* v, const float* at, float* z, float* u, int64_t rows,
+                               int64_t at_rows, int d, const float* radius_param, void* stream);
+
+/* Manifold.inverse_sample_projection_mu0(z, at_point) -> (u, v).   hyperbolics.py:145-148 | spherical.py:126-129 |
+ * euclidean.py:96-99 | poincare.py:160-164 */
+int mvae_inverse_sample_projection_mu0(int kind, const float* z, const float* at, float* u, float* v, int64_t rows,
+                                       int64_t at_rows, int d, const float* radius_param, void* stream);
+
+/* Manifold.logdet(mu, std, z, data): h/s take u = data[0] ([rows,A]); p takes (mu, z) (poincare.py:55-89); e writes
+ * zeros.  out[rows].   hyperbolics.py:49-51,58-65 | spherical.py:49-51,58-67 */
+int mvae_logdet(int kind, const float* u, const float* mu, const float* z, float* out, int64_t rows, int64_t at_rows,
+                int d, const float* radius_param, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One latent component end to end:  Component.encode (component.py:63-75, given the two Linear-head outputs) ->
+ * SamplingProcedure.reparametrize (sampling_procedures.py:93-99 | 147-151) -> q_z.rsample_with_parts
+ * (wrapped_normal.py:70-78) -> SamplingProcedure.kl_loss (sampling_procedures.py:101-116 | 153-155).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct mvae_component_desc {
+  int32_t kind;       /* MVAE_* */
+  int32_t true_dim;   /* d */
+  int32_t mean_col;   /* first column of this component's fc_mean output inside a `heads` row   */
+  int32_t logvar_col; /* first column of its fc_logvar output inside a `heads` row               */
+  int32_t logvar_dim; /* d, or 1 under --scalar_parametrization (component.py:54-57)             */
+  int32_t eps_col;    /* first column inside an `eps` row (eps rows are [sum true_dim])          */
+  int32_t z_col;      /* first column inside a `concat_z` row (rows are [sum ambient dim])       */
+  int32_t radius_idx; /* index into `radii` (one raw radius parameter per component; unused: e)  */
+} mvae_component_desc;
+
+/* heads[head_rows, heads_ld], eps[rows, eps_ld] (rows = n_samples * head_rows; row r uses heads[r % head_rows]),
+ * radii[ncomp] raw parameters.  Outputs: z[rows, z_ld]; kl[ncomp, rows] (may be NULL); log_q / log_p [ncomp, rows]
+ * (may be NULL: the importance-sampling path of ModelVAE.log_likelihood, vae.py:82-123, via rsample_log_probs
+ * sampling_procedures.py:46-50,106-110); mu[head_rows, z_ld] and std[head_rows, eps_ld] (may be NULL; q_z.loc and
+ * q_z.scale as the reference exposes them). */
+int mvae_component_forward(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                           const float* eps, int eps_ld, const float* radii, float* z, int z_ld, float* kl,
+                           float* log_q, float* log_p, float* mu, float* std, int64_t rows, int64_t head_rows,
+                           void* stream);
+
+/* Backward of the above for the training path (rows == head_rows): given dz[rows, z_ld] and dkl[ncomp, rows]
+ * (NULL = the scalar `dkl_scalar` for every entry), writes dheads[rows, heads_ld] and ACCUMULATES (atomicAdd) into
+ * dradii[ncomp] (zero it first).  Gradient rules include the reference's non-standard ones (common.py:28-94). */
+int mvae_component_backward(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                            const float* eps, int eps_ld, const float* radii, const float* dz, int z_ld,
+                            const float* dkl, float dkl_scalar, float* dheads, float* dradii, int64_t rows,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dense layers (torch.nn.Linear semantics: y = x W^T + b, W is [N, K]).  FeedForwardVAE.encode / decode,
+ * ffnn_vae.py:42-60; Component heads, component.py:52-57.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int mvae_linear_forward(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K, int relu,
+                        void* stream);
+/* dW[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] = dy W  (dx may be NULL).  With relu_in != 0, x is the output of a
+ * ReLU and dx is additionally masked by x > 0 (folds the previous activation's backward into this call). */
+int mvae_linear_backward(const float* x, const float* W, const float* dy, int relu_in, float* dW, float* db, float* dx,
+                         int64_t M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The whole step.  ModelVAE.train_step, vae.py:149-166; BatchStats, stats.py:144-212; CurvatureOptimizer.step,
+ * mt/mvae/utils.py:174-180 with the routing of Trainer.build_optimizer, train.py:327-360.
+ * All buffers are allocated by the host layer (torch) and only referenced here.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct mvae_model_desc {
+  int32_t abi_version;  /* MVAE_ABI_VERSION */
+  int32_t arch;         /* 0 = feed-forward MLP (FeedForwardVAE, ffnn_vae.py:27-60) */
+  int32_t batch;        /* B: rows per step */
+  int32_t in_dim;       /* D */
+  int32_t h_dim;        /* H */
+  int32_t ncomp;
+  int32_t heads_dim;    /* NH = sum true_dim + sum logvar_dim: rows of the fused head matrix */
+  int32_t z_dim;        /* Z  = sum ambient dims */
+  int32_t eps_dim;      /* sum true_dim */
+  int32_t n_params;     /* P: floats in each of params/grads/adam_m/adam_v (flat layout below) */
+  const mvae_component_desc* comps; /* HOST pointer, copied */
+  /* offsets (in floats) into the flat buffers; every matrix row-major, torch.nn.Linear layout [out, in] */
+  int64_t off_radii;    /* MUST be 0: the first 64 floats hold the raw radius parameters, entry i = component i
+                           (components.{i}._nradius/_pradius); comps[i].radius_idx == i                         */
+  int64_t off_w_heads;  /* [NH, H]            fc_mean rows of every component, then fc_logvar rows             */
+  int64_t off_b_heads;  /* [NH]                                                                                */
+  int64_t off_w_e0;     /* [H, D]             fc_e0                                                            */
+  int64_t off_b_e0;     /* [H]                                                                                 */
+  int64_t off_w_d0;     /* [H, Z]             fc_d0                                                            */
+  int64_t off_b_d0;     /* [H]                                                                                 */
+  int64_t off_w_logits; /* [D, H]             fc_logits                                                        */
+  int64_t off_b_logits; /* [D]                                                                                 */
+  float* params;        /* [P] */
+  float* grads;         /* [P]  dense gradient of (-ELBO) after mvae_step_forward_backward                     */
+  float* adam_m;        /* [P] */
+  float* adam_v;        /* [P] */
+  int32_t* step_count;  /* [2]  {Adam step counter, scratch}; device-side so that a captured graph advances it; zeroed
+                           by the host at creation                                                              */
+  float* workspace;     /* [mvae_workspace_floats(desc)] activations + partial sums                            */
+  float* stats;         /* [2 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
+                           same record for the LAST step only (stats.py:120-127 without the per-step .item() syncs:
+                           the host reads it when it wants to, e.g. once per epoch)                             */
+  uint8_t* radius_trainable; /* [ncomp] host pointer, copied: 0 = fixed curvature (requires_grad False)        */
+  double lr;            /* Adam learning rate (run.py:33); betas (0.9, 0.999), eps 1e-8 = torch defaults        */
+  double curvature_lr;  /* SGD lr on radii, 1e-4 (train.py:346,351)                                            */
+} mvae_model_desc;
+
+typedef struct mvae_ctx mvae_ctx;
+
+int64_t mvae_workspace_floats(const mvae_model_desc* desc);
+int mvae_create(const mvae_model_desc* desc, mvae_ctx** out);
+void mvae_destroy(mvae_ctx* ctx);
+
+/* forward -> ELBO -> backward: fills `grads` (all P entries are written, nothing accumulates) and adds this step's
+ * bce / kl / elbo sums to `stats`.  x[B, D] (binarised or soft targets), eps[B, eps_dim] ~ N(0,1).
+ * With want_outputs != 0 also writes logits[B,D], concat_z[B,Z], bce[B], kl[ncomp,B] (any may be NULL). */
+int mvae_step_forward_backward(mvae_ctx* ctx, const float* x, const float* eps, float beta, int want_outputs,
+                               float* logits, float* concat_z, float* bce, float* kl, void* stream);
+
+/* optimizer: fused Adam over the flat buffer (radii excluded) + SGD(lr=curvature_lr) on trainable radii iff
+ * do_curvature_step (the reference's `not fixed_curvature and epoch >= 10`, train.py:357-358).  In data-parallel runs
+ * the host all-reduces `grads` (SUM) between the two calls. */
+int mvae_step_optimizer(mvae_ctx* ctx, int do_curvature_step, void* stream);
+
+/* Both of the above back to back (single-GPU ModelVAE.train_step). */
+int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, void* stream);
+
+/* Measurement aid (never captured into a graph, synchronises): runs `iters` full steps on `stream` with a HIP event
+ * between consecutive launches and writes the average duration of each of the MVAE_STEP_KERNELS launches, in
+ * milliseconds, to the HOST array ms_out[MVAE_STEP_KERNELS] (order: enc_fwd, latent_fwd, dec1_fwd, dec1_bwd,
+ * latent_bwd, enc_bwd, optim).  Parameters and optimizer state advance exactly as in mvae_train_step. */
+#define MVAE_STEP_KERNELS 7
+int mvae_step_profile(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, int iters,
+                      float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVAE_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libmvae_hip.so (C ABI: include/mvae_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or an entry point fails, the product path raises.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmvae_hip.so")
+
+EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE = 0, 1, 2, 3
+ABI_VERSION = 1
+MAX_TRUE_DIM = 64
+MAX_COMPONENTS = 64
+RADII_REGION = 64
+
+
+class ComponentDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("true_dim", C.c_int32), ("mean_col", C.c_int32), ("logvar_col", C.c_int32),
+                ("logvar_dim", C.c_int32), ("eps_col", C.c_int32), ("z_col", C.c_int32), ("radius_idx", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("arch", C.c_int32), ("batch", C.c_int32), ("in_dim", C.c_int32),
+                ("h_dim", C.c_int32), ("ncomp", C.c_int32), ("heads_dim", C.c_int32), ("z_dim", C.c_int32),
+                ("eps_dim", C.c_int32), ("n_params", C.c_int32), ("comps", C.POINTER(ComponentDesc)),
+                ("off_radii", C.c_int64), ("off_w_heads", C.c_int64), ("off_b_heads", C.c_int64),
+                ("off_w_e0", C.c_int64), ("off_b_e0", C.c_int64), ("off_w_d0", C.c_int64), ("off_b_d0", C.c_int64),
+                ("off_w_logits", C.c_int64), ("off_b_logits", C.c_int64), ("params", C.c_void_p),
+                ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("step_count", C.c_void_p),
+                ("workspace", C.c_void_p), ("stats", C.c_void_p), ("radius_trainable", C.POINTER(C.c_uint8)),
+                ("lr", C.c_double), ("curvature_lr", C.c_double)]
+
+
+# name -> (restype, argtypes): every symbol include/mvae_hip.h declares
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+PROTOTYPES = {
+    "mvae_abi_version": (C.c_int, []),
+    "mvae_last_error": (C.c_char_p, []),
+    "mvae_exp_map_mu0": (C.c_int, [_I, _P, _P, _L, _I, _P, _P]),
+    "mvae_inverse_exp_map_mu0": (C.c_int, [_I, _P, _P, _L, _I, _P, _P]),
+    "mvae_parallel_transport_mu0": (C.c_int, [_I, _P, _P, _P, _L, _I, _P, _P]),
+    "mvae_inverse_parallel_transport_mu0": (C.c_int, [_I, _P, _P, _P, _L, _I, _P, _P]),
+    "mvae_sample_projection_mu0": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_inverse_sample_projection_mu0": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_logdet": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_component_forward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
+                                         _L, _L, _P]),
+    "mvae_component_backward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _F, _P, _P,
+                                          _L, _P]),
+    "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),
+    "mvae_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "mvae_destroy": (None, [C.c_void_p]),
+    "mvae_step_forward_backward": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
+    "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
+    "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
+    "mvae_step_profile": (C.c_int, [_P, _P, _P, _F, _I, _I, C.POINTER(C.c_float), _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class MvaeHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Loads the library once; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvaeHipError(f"{LIB_PATH} is missing: build it with `python -m mvae_amd.build` "
+                           "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvae_abi_version() != ABI_VERSION:
+        raise MvaeHipError("libmvae_hip.so ABI version mismatch: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().mvae_last_error().decode(errors="replace")
+        raise MvaeHipError(f"libmvae_hip error {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvaeHipError("mvae_amd ops need tensors on a HIP device (there is no CPU path)")
+    if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+        raise MvaeHipError(f"unsupported dtype {t.dtype}: the HIP path computes in float32")
+    if not t.is_contiguous():
+        raise MvaeHipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,33 @@
+"""Builds libmvae_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "mvae_kernels.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "mvae_math.hpp"), os.path.join(HERE, "csrc", "mvae_gemm.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "mvae_hip.h")]
+LIB = os.path.join(HERE, "libmvae_hip.so")
+
+
+def lib_is_fresh() -> bool:
+    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and lib_is_fresh():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libmvae_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
+           "-o", LIB + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,495 @@
+// mvae_math.hpp -- per-row Riemannian latent-space arithmetic for gfx950, written once over a scalar type T:
+//   T = float        -> forward kernels
+//   T = Dual         -> forward-mode derivative along ONE input direction (backward kernels run one thread per
+//                       (row, component, input direction); every thread re-evaluates the primal in registers)
+//
+// The arithmetic follows the reference operator by operator, INCLUDING its guarded functions and their non-standard
+// derivative rules (all under /root/reference/mt/mvae/ops/):
+//   common.py:28-39   LeakyClamp   value: hard clamp; derivative: 1 inside [lo,hi] (inclusive), 1e-8 outside
+//   common.py:76-94   Acosh        x<-max(x,1+1e-8); z=sqrt(max(x^2-1,1e-9)); log(x+z); derivative 1/z
+//   common.py:46-63   Atanh        clamp +-(1-4e-8); derivative 1/(1-x^2) on the clamped x
+//   common.py:107-119 cosh/sinh    leaky clamp +-85;  sqrt: leaky clamp min 1e-9
+//   common.py:122-147 logsinh      x + signed-logsumexp([0,-2x],[+1,-1]) - ln2, inner clamp(.,1e-8) leaky
+//   torch.clamp / relu / abs / norm / F.normalize / softplus: ATen's derivative rules (hard masks, norm'(0)=0)
+// Summation orders follow the reference too (index order; <x,y>_L = sum(all) - 2*x0*y0, hyperbolics.py:72-78), so
+// the f32 results differ from the CPU reference only through libm-vs-ocml transcendentals.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace mv {
+
+constexpr float kEps = 1e-8f;                      // common.py:21
+constexpr float kMaxNorm = 85.0f;                  // common.py:22
+constexpr float kLn2 = 0.6931471805599453f;        // common.py:23
+constexpr float kLogSqrt2Pi = 0.9189385332046727f; // math.log(math.sqrt(2*pi)) in torch Normal.log_prob
+
+struct Dual {
+  float v, d;
+};
+
+// ---- value access / construction
+__device__ __forceinline__ float val(float x) { return x; }
+__device__ __forceinline__ float val(Dual x) { return x.v; }
+template <typename T> __device__ __forceinline__ T make(float v, float d);
+template <> __device__ __forceinline__ float make<float>(float v, float) { return v; }
+template <> __device__ __forceinline__ Dual make<Dual>(float v, float d) { return Dual{v, d}; }
+template <typename T> __device__ __forceinline__ T cst(float v) { return make<T>(v, 0.0f); }
+__device__ __forceinline__ float tan_of(float) { return 0.0f; }
+__device__ __forceinline__ float tan_of(Dual x) { return x.d; }
+
+// ---- arithmetic on Dual (float overloads are the builtin operators)
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+  float q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, float b) { return {a.v / b, a.d / b}; }
+__device__ __forceinline__ Dual operator/(float a, Dual b) {
+  float q = a / b.v;
+  return {q, -q * b.d / b.v};
+}
+
+// ---- elementary functions with ATen's derivative rules
+__device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ Dual t_sqrt(Dual x) {
+  float s = sqrtf(x.v);
+  return {s, x.d / (2.0f * s)};
+}
+__device__ __forceinline__ float t_exp(float x) { return expf(x); }
+__device__ __forceinline__ Dual t_exp(Dual x) {
+  float e = expf(x.v);
+  return {e, e * x.d};
+}
+__device__ __forceinline__ float t_log(float x) { return logf(x); }
+__device__ __forceinline__ Dual t_log(Dual x) { return {logf(x.v), x.d / x.v}; }
+__device__ __forceinline__ float t_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ Dual t_cosh(Dual x) { return {coshf(x.v), sinhf(x.v) * x.d}; }
+__device__ __forceinline__ float t_sinh(float x) { return sinhf(x); }
+__device__ __forceinline__ Dual t_sinh(Dual x) { return {sinhf(x.v), coshf(x.v) * x.d}; }
+__device__ __forceinline__ float t_cos(float x) { return cosf(x); }
+__device__ __forceinline__ Dual t_cos(Dual x) { return {cosf(x.v), -sinf(x.v) * x.d}; }
+__device__ __forceinline__ float t_sin(float x) { return sinf(x); }
+__device__ __forceinline__ Dual t_sin(Dual x) { return {sinf(x.v), cosf(x.v) * x.d}; }
+__device__ __forceinline__ float t_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ Dual t_tanh(Dual x) {
+  float t = tanhf(x.v);
+  return {t, (1.0f - t * t) * x.d};
+}
+__device__ __forceinline__ float t_acos(float x) { return acosf(x); }
+__device__ __forceinline__ Dual t_acos(Dual x) { return {acosf(x.v), x.d * -rsqrtf(1.0f - x.v * x.v)}; }
+__device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ Dual t_abs(Dual x) {
+  float s = (x.v > 0.0f) ? 1.0f : ((x.v < 0.0f) ? -1.0f : 0.0f);
+  return {fabsf(x.v), x.d * s};
+}
+__device__ __forceinline__ float t_relu(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __forceinline__ Dual t_relu(Dual x) { return x.v > 0.0f ? x : Dual{0.0f, 0.0f}; }
+
+// torch.clamp (hard): derivative 1 inside [lo,hi] inclusive, 0 outside
+__device__ __forceinline__ float hard_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ Dual hard_clamp(Dual x, float lo, float hi) {
+  bool in = (x.v >= lo) && (x.v <= hi);
+  return {fminf(fmaxf(x.v, lo), hi), in ? x.d : 0.0f};
+}
+// LeakyClamp (common.py:28-39)
+__device__ __forceinline__ float leaky_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ Dual leaky_clamp(Dual x, float lo, float hi) {
+  bool in = (x.v >= lo) && (x.v <= hi);
+  return {fminf(fmaxf(x.v, lo), hi), in ? x.d : x.d * kEps};
+}
+// F.softplus(beta=1, threshold=20)
+__device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ Dual t_softplus(Dual x) {
+  if (x.v > 20.0f) return x;
+  float e = expf(x.v);
+  return {log1pf(e), x.d * e / (e + 1.0f)};
+}
+
+// ---- the reference's guarded functions
+template <typename T> __device__ __forceinline__ T g_sqrt(T x) { return t_sqrt(leaky_clamp(x, 1e-9f, INFINITY)); }
+template <typename T> __device__ __forceinline__ T g_cosh(T x) { return t_cosh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
+template <typename T> __device__ __forceinline__ T g_sinh(T x) { return t_sinh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
+
+__device__ __forceinline__ float g_acosh_parts(float x, float* z_out) {
+  float xc = fmaxf(x, 1.0f + kEps);  // == 1.0f in f32, as in the reference's f32 path
+  float z = sqrtf(fmaxf(xc * xc - 1.0f, 1e-9f));
+  *z_out = z;
+  return logf(xc + z);
+}
+__device__ __forceinline__ float g_acosh(float x) {
+  float z;
+  return g_acosh_parts(x, &z);
+}
+__device__ __forceinline__ Dual g_acosh(Dual x) {
+  float z;
+  float y = g_acosh_parts(x.v, &z);
+  return {y, x.d / z};
+}
+__device__ __forceinline__ float g_atanh(float x) {
+  float xc = fminf(fmaxf(x, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
+  return (logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f;
+}
+__device__ __forceinline__ Dual g_atanh(Dual x) {
+  float xc = fminf(fmaxf(x.v, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
+  return {(logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
+}
+// logsinh (common.py:122-128 via logsumexp_signs :139-147); torch.max sends the derivative to the arg-max entry
+// (first entry on ties)
+template <typename T> __device__ __forceinline__ T g_logsinh(T x) {
+  T a = cst<T>(0.0f);
+  T b = -2.0f * x;
+  T m = (val(a) >= val(b)) ? a : b;
+  T s = 1.0f * t_exp(a - m) + (-1.0f) * t_exp(b - m);
+  return x + (m + t_log(leaky_clamp(s, kEps, INFINITY))) - kLn2;
+}
+template <typename T> __device__ __forceinline__ T g_logcosh(T x) {  // common.py:131-136 (torch.logsumexp)
+  T a = cst<T>(0.0f);
+  T b = -2.0f * x;
+  T m = (val(a) >= val(b)) ? a : b;
+  float mv = val(m);  // torch.logsumexp detaches the max
+  T s = t_exp(a - mv) + t_exp(b - mv);
+  return x + (t_log(s) + mv) - kLn2;
+}
+
+// RadiusManifold.radius (manifold.py:73-75)
+template <typename T> __device__ __forceinline__ T radius_of(T p) { return hard_clamp(t_relu(p), 1e-8f, 1e8f); }
+
+// torch.norm(p=2) over n entries, derivative 0 at the origin
+template <typename T> __device__ __forceinline__ T norm2(const T* x, int n) {
+  T s = x[0] * x[0];
+  for (int i = 1; i < n; ++i) s = s + x[i] * x[i];
+  return t_sqrt(s);
+}
+template <> __device__ __forceinline__ Dual norm2<Dual>(const Dual* x, int n) {
+  float s = x[0].v * x[0].v;
+  float sd = x[0].v * x[0].d;
+  for (int i = 1; i < n; ++i) {
+    s = s + x[i].v * x[i].v;
+    sd += x[i].v * x[i].d;
+  }
+  float nv = sqrtf(s);
+  return {nv, nv == 0.0f ? 0.0f : sd / nv};
+}
+
+// <x,y>_L  (hyperbolics.py:72-78): sum of all products, minus twice the first
+template <typename T> __device__ __forceinline__ T lorentz_product(const T* x, const T* y, int A) {
+  T m0 = x[0] * y[0];
+  T s = m0;
+  for (int i = 1; i < A; ++i) s = s + x[i] * y[i];
+  return s - 2.0f * m0;
+}
+template <typename T> __device__ __forceinline__ T dot(const T* x, const T* y, int A) {
+  T s = x[0] * y[0];
+  for (int i = 1; i < A; ++i) s = s + x[i] * y[i];
+  return s;
+}
+
+// sum_i log N(v_i; 0, sigma_i) as torch.distributions.Normal.log_prob evaluates it, summed in index order
+template <typename T> __device__ __forceinline__ T normal_logprob_term(T v, T sigma) {
+  T var = sigma * sigma;
+  return -(v * v) / (2.0f * var) - t_log(sigma) - kLogSqrt2Pi;
+}
+
+// =================================================================================================== manifolds
+enum Kind : int { kEuclidean = 0, kHyperboloid = 1, kSphere = 2, kPoincare = 3 };
+
+__host__ __device__ inline int ambient_dim(int kind, int d) {
+  return (kind == kHyperboloid || kind == kSphere) ? d + 1 : d;
+}
+
+// ---- exp_map_mu0 on the true-dim tangent vector x[d] -> mu[A]
+template <int KIND, typename T> __device__ __forceinline__ void exp_map_mu0(const T* x, int d, T R, T* mu) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < d; ++i) mu[i] = x[i] / 2.0f;  // euclidean.py:78-79
+  } else if constexpr (KIND == kPoincare) {
+    // poincare.py:132-137 -> geoopt 0.1.0 expmap0 (PARITY UNPINNED, see oracle/__init__.py)
+    T c = 1.0f / (R * R);
+    T sc = t_sqrt(c);
+    T n = hard_clamp(norm2(x, d), 1e-15f, INFINITY);
+    T t = t_tanh(hard_clamp(sc * n, -15.0f, 15.0f));
+    for (int i = 0; i < d; ++i) mu[i] = t * x[i] / (sc * n);
+  } else {
+    // hyperbolics.py:114-121 | spherical.py:94-101
+    T n = norm2(x, d);
+    T xn = n / R;
+    T nc = hard_clamp(n, 1e-12f, INFINITY);  // F.normalize(eps=1e-12)
+    T c, s;
+    if constexpr (KIND == kHyperboloid) {
+      c = g_cosh(xn);
+      s = g_sinh(xn);
+    } else {
+      c = t_cos(xn);
+      s = t_sin(xn);
+    }
+    mu[0] = c * R;
+    for (int i = 0; i < d; ++i) mu[i + 1] = s * ((x[i] / nc) * R);
+  }
+}
+
+// ---- parallel_transport_mu0(x, dst) on ambient vectors
+template <int KIND, typename T> __device__ __forceinline__ void pt_mu0(const T* x, const T* dst, int A, T R, T* out) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < A; ++i) out[i] = x[i];
+  } else if constexpr (KIND == kPoincare) {
+    T c = 1.0f / (R * R);  // geoopt parallel_transport0: v * clamp_min(1 - c|y|^2, MIN_NORM)
+    T f = hard_clamp(1.0f - c * dot(dst, dst, A), 1e-15f, INFINITY);
+    for (int i = 0; i < A; ++i) out[i] = x[i] * f;
+  } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:87-93
+    T coef = lorentz_product(dst, x, A) / (R * (R + dst[0]));
+    out[0] = x[0] + coef * (dst[0] + R);
+    for (int i = 1; i < A; ++i) out[i] = x[i] + coef * dst[i];
+  } else {  // spherical.py:74-77
+    T coef = dot(dst, x, A) / (R * (R + dst[0]));
+    out[0] = x[0] - coef * (dst[0] + R);
+    for (int i = 1; i < A; ++i) out[i] = x[i] - coef * dst[i];
+  }
+}
+
+template <int KIND, typename T>
+__device__ __forceinline__ void inv_pt_mu0(const T* x, const T* src, int A, T R, T* out) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < A; ++i) out[i] = x[i];
+  } else if constexpr (KIND == kPoincare) {
+    T c = 1.0f / (R * R);
+    T f = hard_clamp(1.0f - c * dot(src, src, A), 1e-15f, INFINITY);
+    for (int i = 0; i < A; ++i) out[i] = x[i] / f;
+  } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:96-103
+    T coef = (-x[0]) / (R + src[0]);
+    out[0] = x[0] + coef * (src[0] + R);
+    for (int i = 1; i < A; ++i) out[i] = x[i] + coef * src[i];
+  } else {  // spherical.py:80-83
+    T coef = x[0] / (R + src[0]);
+    out[0] = x[0] - coef * (src[0] + R);
+    for (int i = 1; i < A; ++i) out[i] = x[i] - coef * src[i];
+  }
+}
+
+// ---- Poincare helpers (geoopt 0.1.0 as best known; PARITY UNPINNED)
+template <typename T> __device__ __forceinline__ T p_lambda(const T* x, int A, T c) {
+  return 2.0f / (1.0f - c * dot(x, x, A));
+}
+template <typename T> __device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c, T* out) {
+  T x2 = dot(x, x, A), y2 = dot(y, y, A), xy = dot(x, y, A);
+  T fa = 1.0f + 2.0f * c * xy + c * y2;
+  T fb = 1.0f - c * x2;
+  T den = (1.0f + 2.0f * c * xy + c * c * x2 * y2) + 1e-5f;
+  for (int i = 0; i < A; ++i) out[i] = (fa * x[i] + fb * y[i]) / den;
+}
+__device__ __forceinline__ float p_artanh(float x) {
+  float xc = fminf(fmaxf(x, -1.0f + 1e-5f), 1.0f - 1e-5f);
+  return (logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f;
+}
+__device__ __forceinline__ Dual p_artanh(Dual x) {
+  float xc = fminf(fmaxf(x.v, -1.0f + 1e-5f), 1.0f - 1e-5f);
+  return {(logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
+}
+
+// ---- exp_map(u, at) / inverse_exp_map(z, at) on ambient vectors
+template <int KIND, int AMAX, typename T>
+__device__ __forceinline__ void exp_map(const T* u, const T* at, int A, T R, T* z) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < A; ++i) z[i] = at[i] + u[i] / 2.0f;  // euclidean.py:74-75
+  } else if constexpr (KIND == kPoincare) {  // poincare.py:124-129 -> geoopt expmap
+    T c = 1.0f / (R * R);
+    T sc = t_sqrt(c);
+    T n = hard_clamp(norm2(u, A), 1e-15f, INFINITY);
+    T t = t_tanh(hard_clamp(sc / 2.0f * p_lambda(at, A, c) * n, -15.0f, 15.0f));
+    T second[AMAX];
+    for (int i = 0; i < A; ++i) second[i] = t * u[i] / (sc * n);
+    p_mobius_add(at, second, A, c, z);
+  } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:106-111
+    T n = g_sqrt(lorentz_product(u, u, A)) / R;
+    T c = g_cosh(n), s = g_sinh(n);
+    for (int i = 0; i < A; ++i) z[i] = c * at[i] + s * (u[i] / n);
+  } else {  // spherical.py:86-91
+    T n = norm2(u, A) / R;
+    T c = t_cos(n), s = t_sin(n);
+    for (int i = 0; i < A; ++i) z[i] = c * at[i] + s * (u[i] / n);
+  }
+}
+
+template <int KIND, int AMAX, typename T>
+__device__ __forceinline__ void log_map(const T* z, const T* at, int A, T R, T* u) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < A; ++i) u[i] = 2.0f * (z[i] - at[i]);  // euclidean.py:82-83
+  } else if constexpr (KIND == kPoincare) {  // poincare.py:140-145 -> geoopt logmap
+    T c = 1.0f / (R * R);
+    T sc = t_sqrt(c);
+    T neg[AMAX], sub[AMAX];
+    for (int i = 0; i < A; ++i) neg[i] = -at[i];
+    p_mobius_add(neg, z, A, c, sub);
+    T sn = hard_clamp(norm2(sub, A), 1e-15f, INFINITY);
+    T f = 2.0f / sc / p_lambda(at, A, c) * p_artanh(sc * sn);
+    for (int i = 0; i < A; ++i) u[i] = f * sub[i] / sn;
+  } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:124-128
+    T alpha = -lorentz_product(at, z, A) / (R * R);
+    T coef = g_acosh(alpha) / g_sqrt(alpha * alpha - 1.0f);
+    for (int i = 0; i < A; ++i) u[i] = coef * (z[i] - alpha * at[i]);
+  } else {  // spherical.py:104-109
+    T alpha = dot(at, z, A) / (R * R);
+    T coef = t_acos(hard_clamp(alpha, -1.0f, 1.0f)) / g_sqrt(1.0f - alpha * alpha);
+    for (int i = 0; i < A; ++i) u[i] = coef * (z[i] - alpha * at[i]);
+  }
+}
+
+// inverse_exp_map_mu0 (hyperbolics.py:131-135 | spherical.py:112-116 | euclidean.py:86-87 | geoopt logmap0)
+template <int KIND, typename T> __device__ __forceinline__ void log_map_mu0(const T* x, int A, T R, T* out) {
+  if constexpr (KIND == kEuclidean) {
+    for (int i = 0; i < A; ++i) out[i] = 2.0f * x[i];
+  } else if constexpr (KIND == kPoincare) {
+    T c = 1.0f / (R * R);
+    T sc = t_sqrt(c);
+    T n = hard_clamp(norm2(x, A), 1e-15f, INFINITY);
+    T f = p_artanh(sc * n);
+    for (int i = 0; i < A; ++i) out[i] = x[i] / n / sc * f;
+  } else {
+    T alpha = x[0] / R;
+    T coef;
+    if constexpr (KIND == kHyperboloid) coef = g_acosh(alpha) / g_sqrt(alpha * alpha - 1.0f);
+    else coef = t_acos(hard_clamp(alpha, -1.0f, 1.0f)) / g_sqrt(1.0f - alpha * alpha);
+    out[0] = coef * (x[0] - alpha * R);
+    for (int i = 1; i < A; ++i) out[i] = coef * x[i];
+  }
+}
+
+// ---- logdet of the projection Jacobian from the tangent vector u (hyperbolics.py:58-65 | spherical.py:58-67)
+template <int KIND, typename T> __device__ __forceinline__ T logdet_u(const T* u, int A, T R) {
+  float nm1 = (float)(A - 1 - 1);  // (n - 1) with n = A - 1
+  if constexpr (KIND == kHyperboloid) {
+    T r = g_sqrt(lorentz_product(u, u, A)) / R;
+    return nm1 * (t_log(R) + g_logsinh(r) - t_log(r));
+  } else {
+    T r = norm2(u, A) / R;
+    return nm1 * (t_log(R) + t_log(hard_clamp(t_abs(t_sin(r)), 1e-5f, INFINITY)) -
+                  t_log(hard_clamp(r, 1e-5f, INFINITY)));
+  }
+}
+
+// poincare_to_lorentz (poincare.py:167-170): y[A] -> out[A+1]
+template <typename T> __device__ __forceinline__ void poincare_to_lorentz(const T* y, int A, T R, T* out) {
+  T n = norm2(y, A);
+  T n2 = n * n;
+  T den = R * R - n2;
+  out[0] = (R * (R * R + n2)) / den;
+  for (int i = 0; i < A; ++i) out[i + 1] = (2.0f * (R * R) * y[i]) / den;
+}
+
+// PoincareBall.logdet (poincare.py:55-89): via the Lorentz model
+template <int AMAX, typename T> __device__ __forceinline__ T p_logdet(const T* mu, const T* z, int A, T R) {
+  T zl[AMAX + 1], ml[AMAX + 1], u[AMAX + 1];
+  poincare_to_lorentz(z, A, R, zl);
+  poincare_to_lorentz(mu, A, R, ml);
+  log_map<kHyperboloid, AMAX + 1>(zl, ml, A + 1, R, u);
+  return logdet_u<kHyperboloid>(u, A + 1, R);
+}
+
+// =================================================================================================== component
+// One latent component for one row, from the two head outputs to (z, kl | log q, log p).
+//   mraw[d], lraw[lvd] (lvd = d or 1), eps[d], rp = raw radius parameter.
+// component.py:63-75 -> sampling_procedures.py:93-99|147-151 -> wrapped_normal.py:70-78 -> :84-103 -> kl_loss.
+template <int KIND, int DMAX, typename T>
+__device__ __forceinline__ void component_forward(const T* mraw, const T* lraw, int lvd, const float* eps, int d,
+                                                  T rp, T* z, T* kl, T* log_q_out, T* log_p_out, T* mu_out,
+                                                  T* sigma_out) {
+  constexpr int AMAX = DMAX + 1;
+  T sigma[DMAX];
+  for (int i = 0; i < lvd; ++i) sigma[i] = t_softplus(lraw[i]) + 1e-5f;  // component.py:72
+  if (sigma_out)
+    for (int i = 0; i < lvd; ++i) sigma_out[i] = sigma[i];
+  if (lvd == 1)
+    for (int i = 1; i < d; ++i) sigma[i] = sigma[0];  // wrapped_normal.py:46-49 / Normal broadcasting
+
+  if constexpr (KIND == kEuclidean) {
+    T mu[DMAX];
+    exp_map_mu0<kEuclidean>(mraw, d, cst<T>(0.0f), mu);
+    for (int i = 0; i < d; ++i) z[i] = mu[i] + eps[i] * sigma[i];  // Normal.rsample
+    if (mu_out)
+      for (int i = 0; i < d; ++i) mu_out[i] = mu[i];
+    if (kl) {  // kl_divergence(N(mu,sigma), N(0,1)).sum(-1), sampling_procedures.py:153-155
+      T s = cst<T>(0.0f);
+      for (int i = 0; i < d; ++i) {
+        T var_ratio = (sigma[i] / 1.0f) * (sigma[i] / 1.0f);
+        T t1 = ((mu[i] - 0.0f) / 1.0f) * ((mu[i] - 0.0f) / 1.0f);
+        T term = 0.5f * (var_ratio + t1 - 1.0f - t_log(var_ratio));
+        s = (i == 0) ? term : s + term;
+      }
+      *kl = s;
+    }
+    if (log_q_out) {  // EuclideanNormal.log_prob (wrapped_distributions.py:39-42)
+      T lq = cst<T>(0.0f), lp = cst<T>(0.0f);
+      for (int i = 0; i < d; ++i) {
+        T a = normal_logprob_term(z[i] - mu[i], sigma[i]);
+        T b = normal_logprob_term(z[i], cst<T>(1.0f));
+        lq = (i == 0) ? a : lq + a;
+        lp = (i == 0) ? b : lp + b;
+      }
+      *log_q_out = lq;
+      *log_p_out = lp;
+    }
+    return;
+  } else {
+    const int A = ambient_dim(KIND, d);
+    T R = radius_of(rp);
+    T mu[AMAX], v[DMAX], x[AMAX], u[AMAX];
+    exp_map_mu0<KIND>(mraw, d, R, mu);
+    if (mu_out)
+      for (int i = 0; i < A; ++i) mu_out[i] = mu[i];
+    for (int i = 0; i < d; ++i) v[i] = eps[i] * sigma[i];  // Normal(0, sigma).rsample
+
+    T logdet_q, logdet_p;
+    T v0[DMAX];
+    if constexpr (KIND == kPoincare) {
+      T c = 1.0f / (R * R);
+      T lam = p_lambda(mu, A, c);
+      for (int i = 0; i < A; ++i) u[i] = v[i] / lam;  // poincare.py:152-157
+      exp_map<KIND, AMAX>(u, mu, A, R, z);
+      logdet_q = p_logdet<AMAX>(mu, z, A, R);
+      T mu0[AMAX], u0[AMAX];
+      for (int i = 0; i < A; ++i) mu0[i] = cst<T>(0.0f);
+      log_map<KIND, AMAX>(z, mu0, A, R, u0);
+      T lam0 = p_lambda(mu0, A, c);
+      for (int i = 0; i < A; ++i) v0[i] = u0[i] * lam0;  // poincare.py:160-164
+      logdet_p = p_logdet<AMAX>(mu0, z, A, R);
+    } else {
+      x[0] = cst<T>(0.0f);  // expand_proj_dims (common.py:156-158)
+      for (int i = 0; i < d; ++i) x[i + 1] = v[i];
+      pt_mu0<KIND>(x, mu, A, R, u);
+      exp_map<KIND, AMAX>(u, mu, A, R, z);
+      logdet_q = logdet_u<KIND>(u, A, R);
+      // prior p_z = WrappedNormal(mu0, 1): log_prob(z) via inverse_sample_projection_mu0 (wrapped_normal.py:99-103)
+      T mu0[AMAX], u0[AMAX], w[AMAX];
+      mu0[0] = 1.0f * R;
+      for (int i = 1; i < A; ++i) mu0[i] = 0.0f * R;
+      log_map<KIND, AMAX>(z, mu0, A, R, u0);
+      inv_pt_mu0<KIND>(u0, mu0, A, R, w);
+      for (int i = 0; i < d; ++i) v0[i] = w[i + 1];
+      logdet_p = logdet_u<KIND>(u0, A, R);
+    }
+    T nq = cst<T>(0.0f), np = cst<T>(0.0f);
+    for (int i = 0; i < d; ++i) {
+      T a = normal_logprob_term(v[i], sigma[i]);
+      T b = normal_logprob_term(v0[i], cst<T>(1.0f));
+      nq = (i == 0) ? a : nq + a;
+      np = (i == 0) ? b : np + b;
+    }
+    T lq = nq - logdet_q;  // wrapped_normal.py:84-97
+    T lp = np - logdet_p;
+    if (kl) *kl = lq - lp;  // sampling_procedures.py:101-104
+    if (log_q_out) {
+      *log_q_out = lq;
+      *log_p_out = lp;
+    }
+  }
+}
+
+}  // namespace mv

@@ -1,0 +1,236 @@
+"""StepEngine: owns the flat device buffers of one model and drives the fused HIP step (include/mvae_hip.h,
+`mvae_step_forward_backward` / `mvae_step_optimizer`).
+
+HBM layout (float32; every segment starts on a 64-float boundary so matrix rows are 16-byte aligned):
+
+    [0, 64)          raw radius parameters, entry i = component i   (components.{i}._nradius / _pradius)
+    W_heads [NH, H]  fc_mean rows of every component, then fc_logvar rows     (component.py:52-57)
+    b_heads [NH]
+    W_e0 [H, D], b_e0 [H]            fc_e0        (ffnn_vae.py:36)
+    W_d0 [H, Z], b_d0 [H]            fc_d0        (ffnn_vae.py:39)
+    W_logits [D, H], b_logits [D]    fc_logits    (ffnn_vae.py:40)
+
+`params`, `grads`, `adam_m`, `adam_v` share this layout, so the optimizer is one streaming pass and a data-parallel
+run all-reduces ONE contiguous gradient buffer.  nn.Parameters of the host-side model are views into `params`
+(state-dict keys and shapes are the reference's).
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ModelDesc, check, load, ptr, stream_ptr
+from .functional import ComponentLayout
+
+
+def _up64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class FlatLayout:
+    """Offsets of every named tensor of a FeedForwardVAE inside the flat buffers."""
+
+    def __init__(self, layout: ComponentLayout, in_dim: int, h_dim: int, scalar_parametrization: bool):
+        self.comp_layout = layout
+        self.in_dim, self.h_dim = in_dim, h_dim
+        NH, Z, H, D = layout.heads_dim, layout.z_dim, h_dim, in_dim
+        o = _lib.RADII_REGION
+        self.off_w_heads = o; o += _up64(NH * H)
+        self.off_b_heads = o; o += _up64(NH)
+        self.off_w_e0 = o; o += _up64(H * D)
+        self.off_b_e0 = o; o += _up64(H)
+        self.off_w_d0 = o; o += _up64(H * Z)
+        self.off_b_d0 = o; o += _up64(H)
+        self.off_w_logits = o; o += _up64(D * H)
+        self.off_b_logits = o; o += _up64(D)
+        self.n_params = o
+        # name -> (offset, shape), reference state-dict names and registration order
+        self.entries: List[Tuple[str, int, Tuple[int, ...]]] = []
+        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius"}
+        for i, (letter, d) in enumerate(layout.comps):
+            desc = layout.descs[i]
+            pre = f"components.{i}."
+            if letter in radius_name:
+                self.entries.append((pre + radius_name[letter], i, ()))
+            self.entries.append((pre + "fc_mean.weight", self.off_w_heads + desc.mean_col * H, (d, H)))
+            self.entries.append((pre + "fc_mean.bias", self.off_b_heads + desc.mean_col, (d,)))
+            self.entries.append((pre + "fc_logvar.weight", self.off_w_heads + desc.logvar_col * H,
+                                 (desc.logvar_dim, H)))
+            self.entries.append((pre + "fc_logvar.bias", self.off_b_heads + desc.logvar_col, (desc.logvar_dim,)))
+        self.entries += [("fc_e0.weight", self.off_w_e0, (H, D)), ("fc_e0.bias", self.off_b_e0, (H,)),
+                         ("fc_d0.weight", self.off_w_d0, (H, Z)), ("fc_d0.bias", self.off_b_d0, (H,)),
+                         ("fc_logits.weight", self.off_w_logits, (D, H)), ("fc_logits.bias", self.off_b_logits, (D,))]
+
+    def views(self, flat: Tensor) -> Dict[str, Tensor]:
+        out = {}
+        for name, off, shape in self.entries:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = flat[off:off + n].view(shape)
+        return out
+
+    def n_logical_params(self) -> int:
+        t = 0
+        for _, _, shape in self.entries:
+            n = 1
+            for s in shape:
+                n *= s
+            t += n
+        return t
+
+
+class StepEngine:
+
+    def __init__(self, comps: Sequence[Tuple[str, int]], in_dim: int, h_dim: int, device,
+                 scalar_parametrization: bool = False, radius_trainable: Optional[Sequence[bool]] = None,
+                 lr: float = 1e-3, curvature_lr: float = 1e-4):
+        load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MvaeHipError("StepEngine needs a HIP device: the product path has no CPU fallback")
+        self.layout = ComponentLayout(comps, scalar_parametrization)
+        self.flat = FlatLayout(self.layout, in_dim, h_dim, scalar_parametrization)
+        self.in_dim, self.h_dim = in_dim, h_dim
+        self.lr, self.curvature_lr = float(lr), float(curvature_lr)
+        n = self.layout.n
+        tr = [False] * n if radius_trainable is None else [bool(t) for t in radius_trainable]
+        self.radius_trainable = [t and letter != "e" for t, (letter, _) in zip(tr, self.layout.comps)]
+        P = self.flat.n_params
+        z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
+        self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
+        self.counters = z(4, torch.int32)
+        self.stats = z(2 * (4 + n))
+        self._ctx: Dict[int, Tuple[int, Tensor]] = {}
+        self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
+
+    # ---- state
+    def param_views(self) -> Dict[str, Tensor]:
+        return self.flat.views(self.params)
+
+    def grad_views(self) -> Dict[str, Tensor]:
+        return self.flat.views(self.grads)
+
+    def load_state(self, state: Dict[str, Tensor]) -> None:
+        views = self.param_views()
+        for name, v in views.items():
+            v.copy_(state[name].to(device=self.device, dtype=torch.float32))
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        return {k: v.detach().clone() for k, v in self.param_views().items()}
+
+    def set_radii(self, value: float) -> None:
+        """Trainer._train_epoch warm-up override (train.py:189-194): every h/p/s radius <- value."""
+        for i, (letter, _) in enumerate(self.layout.comps):
+            if letter != "e":
+                self.params[i] = value
+
+    def set_lr(self, lr: float, curvature_lr: Optional[float] = None) -> None:
+        self.lr = float(lr)
+        if curvature_lr is not None:
+            self.curvature_lr = float(curvature_lr)
+        self._drop_contexts()
+
+    def reset_optimizer(self) -> None:
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.counters.zero_()
+
+    def _drop_contexts(self) -> None:
+        for h, _ in self._ctx.values():
+            load().mvae_destroy(h)
+        self._ctx.clear()
+
+    def __del__(self):
+        try:
+            self._drop_contexts()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # ---- contexts (one per batch size; they share params / grads / optimizer state / stats)
+    def _context(self, batch: int) -> int:
+        hit = self._ctx.get(batch)
+        if hit is not None:
+            return hit[0]
+        d = ModelDesc()
+        d.abi_version = _lib.ABI_VERSION
+        d.arch = 0
+        d.batch, d.in_dim, d.h_dim = batch, self.in_dim, self.h_dim
+        d.ncomp = self.layout.n
+        d.heads_dim, d.z_dim, d.eps_dim = self.layout.heads_dim, self.layout.z_dim, self.layout.eps_dim
+        d.n_params = self.flat.n_params
+        d.comps = self.layout.descs
+        d.off_radii = 0
+        for f in ("off_w_heads", "off_b_heads", "off_w_e0", "off_b_e0", "off_w_d0", "off_b_d0", "off_w_logits",
+                  "off_b_logits"):
+            setattr(d, f, getattr(self.flat, f))
+        d.params, d.grads = self.params.data_ptr(), self.grads.data_ptr()
+        d.adam_m, d.adam_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        d.step_count = self.counters.data_ptr()
+        d.stats = self.stats.data_ptr()
+        d.radius_trainable = self._trainable_arr
+        d.lr, d.curvature_lr = self.lr, self.curvature_lr
+        nws = load().mvae_workspace_floats(C.byref(d))
+        ws = torch.zeros(int(nws), dtype=torch.float32, device=self.device)
+        d.workspace = ws.data_ptr()
+        handle = C.c_void_p()
+        check(load().mvae_create(C.byref(d), C.byref(handle)))
+        self._ctx[batch] = (handle.value, ws)
+        return handle.value
+
+    # ---- the step
+    def _check_inputs(self, x: Tensor, eps: Tensor) -> int:
+        if x.dim() != 2 or x.shape[1] != self.in_dim:
+            raise ValueError(f"x must be [B, {self.in_dim}], got {tuple(x.shape)}")
+        if tuple(eps.shape) != (x.shape[0], self.layout.eps_dim):
+            raise ValueError(f"eps must be [{x.shape[0]}, {self.layout.eps_dim}], got {tuple(eps.shape)}")
+        return x.shape[0]
+
+    def forward_backward(self, x: Tensor, eps: Tensor, beta: float = 1.0, want_outputs: bool = False):
+        """forward -> ELBO -> backward.  Fills self.grads with d(-ELBO)/d(theta); adds to self.stats."""
+        B = self._check_inputs(x, eps)
+        ctx = self._context(B)
+        out = None
+        lo = cz = bce = kl = None
+        if want_outputs:
+            lo = x.new_empty(B, self.in_dim)
+            cz = x.new_empty(B, self.layout.z_dim)
+            bce = x.new_empty(B)
+            kl = x.new_empty(self.layout.n, B)
+            out = {"logits": lo, "concat_z": cz, "bce": bce, "kl": kl}
+        check(load().mvae_step_forward_backward(ctx, ptr(x), ptr(eps), float(beta), 1 if want_outputs else 0, ptr(lo),
+                                                ptr(cz), ptr(bce), ptr(kl), stream_ptr(self.device)))
+        return out
+
+    def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
+        ctx = self._context(batch if batch is not None else next(iter(self._ctx)))
+        check(load().mvae_step_optimizer(ctx, 1 if do_curvature_step else 0, stream_ptr(self.device)))
+
+    def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
+        B = self._check_inputs(x, eps)
+        check(load().mvae_train_step(self._context(B), ptr(x), ptr(eps), float(beta),
+                                     1 if do_curvature_step else 0, stream_ptr(self.device)))
+
+    STEP_KERNELS = ("enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd", "optim")
+
+    def profile_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
+                     iters: int = 50) -> Dict[str, float]:
+        """Average duration (ms) of each launch of the step, HIP events on the launch stream (mvae_step_profile)."""
+        B = self._check_inputs(x, eps)
+        ms = (C.c_float * len(self.STEP_KERNELS))()
+        check(load().mvae_step_profile(self._context(B), ptr(x), ptr(eps), float(beta), 1 if do_curvature_step else 0,
+                                       int(iters), ms, stream_ptr(self.device)))
+        return dict(zip(self.STEP_KERNELS, [float(v) for v in ms]))
+
+    # ---- statistics (stats.py:120-127 semantics, read when the host wants them)
+    def read_stats(self, reset: bool = False) -> Dict[str, object]:
+        s = self.stats.cpu()  # one sync
+        n = 4 + self.layout.n
+        rec = lambda v: {"bce": float(v[0]), "kl": float(v[1]), "elbo": float(v[2]), "steps": int(v[3]),  # noqa: E731
+                         "component_kl": [float(t) for t in v[4:n]]}
+        out = {"sum": rec(s[:n]), "last": rec(s[n:2 * n])}
+        if reset:
+            self.stats.zero_()
+        return out

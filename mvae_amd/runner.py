@@ -1,0 +1,73 @@
+"""StepRunner: drives many fused steps over HBM-resident batches, optionally as HIP graphs, optionally data-parallel.
+
+Data parallelism (new functionality -- the reference is single-device): samples are independent given the parameters
+and the loss is a batch SUM (stats.py:200-202), so each rank runs forward/backward on its own rows and ONE all-reduce
+(SUM) of the flat gradient buffer over RCCL/xGMI precedes the (replicated, identical) optimizer step.
+"""
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from .engine import StepEngine
+
+
+class StepRunner:
+
+    def __init__(self, eng: StepEngine, xs: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
+                 graph_steps: int = 0, world_size: int = 1):
+        assert xs.shape[0] == eps.shape[0] and xs.shape[0] >= 1
+        self.eng, self.xs, self.eps = eng, xs, eps
+        self.beta, self.do_curv = float(beta), bool(do_curvature_step)
+        self.world = int(world_size)
+        self.n_data = xs.shape[0]
+        self.gs = int(graph_steps)
+        self.cursor = 0  # index of the next resident batch
+        self.graphs: List[torch.cuda.CUDAGraph] = []
+        if self.gs > 0:
+            if self.n_data % self.gs != 0:
+                raise ValueError("the number of resident batches must be a multiple of graph_steps")
+            self._capture()
+
+    def _one(self, i: int) -> None:
+        if self.world == 1:
+            self.eng.train_step(self.xs[i], self.eps[i], self.beta, self.do_curv)
+        else:
+            import torch.distributed as dist
+            self.eng.forward_backward(self.xs[i], self.eps[i], self.beta)
+            dist.all_reduce(self.eng.grads, op=dist.ReduceOp.SUM)
+            self.eng.optimizer_step(self.do_curv, batch=self.xs.shape[1])
+
+    def _capture(self) -> None:
+        # snapshot the state the warm-up launches below will advance, so that capturing has no net effect
+        eng = self.eng
+        keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(min(3, self.n_data)):  # library / RCCL warm-up outside capture
+                self._one(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for gi in range(self.n_data // self.gs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(gi * self.gs, (gi + 1) * self.gs):
+                    self._one(i)
+            self.graphs.append(g)
+        torch.cuda.synchronize()
+        for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
+            dst.copy_(src)
+
+    def run(self, n_steps: int) -> None:
+        """Advance exactly n_steps steps (graph replays where a whole graph fits, eager launches otherwise)."""
+        left = int(n_steps)
+        while left > 0:
+            if self.gs > 0 and self.cursor % self.gs == 0 and left >= self.gs:
+                self.graphs[self.cursor // self.gs].replay()
+                self.cursor = (self.cursor + self.gs) % self.n_data
+                left -= self.gs
+            else:
+                self._one(self.cursor)
+                self.cursor = (self.cursor + 1) % self.n_data
+                left -= 1

@@ -1,0 +1,360 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Bar (BASELINE.json north_star): 1e-4 relative, float32, fixed seeds.  `assert_close` is element-wise
+|a-b| <= rtol*|b| + atol with atol = rtol/10 * max|b| unless stated.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, load_json, load_npz, summary_of
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from mvae_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _cpu(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("d", [2, 5, 40])
+@pytest.mark.parametrize("R", [0.5, 1.0, 2.0, 11.0])
+@pytest.mark.parametrize("man", ["H", "S", "E"])
+def test_primitives_vs_golden(dev, man, R, d):
+    from mvae_amd import functional as Fn
+    g = load_npz("g1_primitives.npz")
+    k = f"{man}/R{R:g}/d{d}/f32/"
+    kind = {"H": 1, "S": 2, "E": 0}[man]
+    x, v = T(g[k + "x"]).to(dev), T(g[k + "v"]).to(dev)
+    Rt = torch.tensor(R, device=dev)
+    mu = Fn.exp_map_mu0(kind, x, Rt)
+    assert_close(_cpu(mu), g[k + "mu"], RTOL, k + "mu")
+    mu_ref = T(g[k + "mu"]).to(dev)
+    z, (u, _) = Fn.sample_projection_mu0(kind, v, mu_ref, Rt)
+    assert_close(_cpu(z), g[k + "z"], RTOL, k + "z")
+    assert_close(_cpu(u), g[k + "u"], RTOL, k + "u")
+    z_ref = T(g[k + "z"]).to(dev)
+    iu, iv = Fn.inverse_sample_projection_mu0(kind, z_ref, mu_ref, Rt)
+    # the inverse maps cancel catastrophically for points far from the origin (alpha^2 - 1); both sides evaluate
+    # the same expression, differences come from cosh/sinh/log ulps upstream
+    assert_close(_cpu(iu), g[k + "inv_u"], 5 * RTOL, k + "inv_u", atol_frac=5 * RTOL)
+    assert_close(_cpu(iv), g[k + "inv_v"], 5 * RTOL, k + "inv_v", atol_frac=5 * RTOL)
+    assert_close(_cpu(Fn.inverse_exp_map_mu0(kind, mu_ref, Rt)), g[k + "log_mu0"], 5 * RTOL, k + "log_mu0",
+                 atol_frac=5 * RTOL)
+    if man == "E":
+        return
+    u_ref = T(g[k + "u"]).to(dev)
+    assert_close(_cpu(Fn.logdet(kind, u_ref, None, None, Rt)), g[k + "logdet_u"], RTOL, k + "logdet_u", atol_frac=1e-4)
+    vz = torch.cat([torch.zeros_like(v[..., :1]), v], dim=-1)
+    assert_close(_cpu(Fn.parallel_transport_mu0(kind, vz, mu_ref, Rt)), g[k + "pt"], RTOL, k + "pt")
+    assert_close(_cpu(Fn.inverse_parallel_transport_mu0(kind, u_ref, mu_ref, Rt)), g[k + "ipt"], RTOL, k + "ipt",
+                 atol_frac=1e-4)
+    mu0 = torch.zeros_like(mu_ref)
+    mu0[..., 0] = R
+    iu0, iv0 = Fn.inverse_sample_projection_mu0(kind, z_ref, mu0, Rt)
+    assert_close(_cpu(iu0), g[k + "inv0_u"], 5 * RTOL, k + "inv0_u", atol_frac=5 * RTOL)
+    assert_close(_cpu(iv0), g[k + "inv0_v"], 5 * RTOL, k + "inv0_v", atol_frac=5 * RTOL)
+
+
+@pytest.mark.parametrize("kind,name", [(1, "h"), (2, "s"), (0, "e"), (3, "p")])
+def test_primitive_round_trips_large(dev, kind, name):
+    """Size-independent properties on 1M rows: sample_projection o inverse = id, exp_mu0 o log_mu0 = id, points stay on
+    the manifold (reference tests: test_hyperbolics.py:220-241, test_spherical.py, test_poincare.py:147-148)."""
+    from mvae_amd import functional as Fn
+    rows, d, R = 1 << 20, 3, 2.0
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(rows, d, generator=g) * 0.5).to(dev)
+    v = (torch.randn(rows, d, generator=g) * 0.4).to(dev)
+    Rt = torch.tensor(R, device=dev)
+    mu = Fn.exp_map_mu0(kind, x, Rt)
+    z, (u, _) = Fn.sample_projection_mu0(kind, v, mu, Rt)
+    assert torch.isfinite(z).all()
+    _, v_back = Fn.inverse_sample_projection_mu0(kind, z, mu, Rt)
+    assert float((v_back - v).abs().max()) < 5e-4
+    back = Fn.inverse_exp_map_mu0(kind, mu, Rt)
+    x_back = back[..., 1:] if kind in (1, 2) else back
+    assert float((x_back - x).abs().max()) < 5e-4
+    if kind == 1:
+        lp = (z[..., 1:]**2).sum(-1) - z[..., 0]**2
+        assert float((lp + R * R).abs().max()) < 2e-3 * R * R
+    if kind == 2:
+        assert float(((z**2).sum(-1) - R * R).abs().max()) < 1e-4 * R * R
+    if kind == 3:
+        assert float((z**2).sum(-1).max()) < R * R
+
+
+def test_poincare_agrees_with_hyperboloid(dev):
+    """PARITY UNPINNED for p (geoopt absent): cross-model identity instead -- mapping the hyperboloid results to the
+    ball (hyperbolics.py:151-152) must give the ball results."""
+    from mvae_amd import functional as Fn
+    R = 2.0
+    Rt = torch.tensor(R, device=dev)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(4096, 2, generator=g) * 0.7).to(dev)
+    v = (torch.randn(4096, 2, generator=g) * 0.5).to(dev)
+    mu_h = Fn.exp_map_mu0(1, x, Rt)
+    to_ball = lambda t: R * t[..., 1:] / (R + t[..., :1])  # noqa: E731
+    mu_p = Fn.exp_map_mu0(3, x / 2, Rt)  # expmap0 on the ball of a tangent vector x/2 == projection of exp_mu0(x)
+    assert float((to_ball(mu_h) - mu_p).abs().max()) < 5e-4
+    z_h, _ = Fn.sample_projection_mu0(1, v, mu_h, Rt)
+    z_p, _ = Fn.sample_projection_mu0(3, v, mu_p, Rt)
+    # same sample in both models: the ball's tangent vector at 0 is v/2 * ... only directions/lengths along geodesics
+    # agree, so compare geodesic distance from mu instead of coordinates
+    d_h = R * torch.acosh(torch.clamp(-((z_h[..., 1:] * mu_h[..., 1:]).sum(-1) - z_h[..., 0] * mu_h[..., 0]) / R**2,
+                                      min=1.0))
+    zl = torch.cat([(R * (R**2 + (z_p**2).sum(-1, keepdim=True))), 2 * R**2 * z_p], -1) / \
+        (R**2 - (z_p**2).sum(-1, keepdim=True))
+    ml = torch.cat([(R * (R**2 + (mu_p**2).sum(-1, keepdim=True))), 2 * R**2 * mu_p], -1) / \
+        (R**2 - (mu_p**2).sum(-1, keepdim=True))
+    d_p = R * torch.acosh(torch.clamp(-((zl[..., 1:] * ml[..., 1:]).sum(-1) - zl[..., 0] * ml[..., 0]) / R**2, min=1.0))
+    assert float((d_h - d_p).abs().max()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ components
+def _g2_keys():
+    g = load_npz("g2_component.npz")
+    return sorted({k.rsplit("/", 1)[0] for k in g if k.rsplit("/", 1)[0].endswith("f32")})
+
+
+@pytest.mark.parametrize("key", _g2_keys())
+def test_component_forward_backward_vs_golden(dev, key):
+    from mvae_amd import functional as Fn
+    g = load_npz("g2_component.npz")
+    comp, Rs, par, _ = key.split("/")
+    letter, d = comp[0], int(comp[1:])
+    scalar = par == "scalar"
+    lay = Fn.ComponentLayout([(letter, d)], scalar_parametrization=scalar)
+    heads = torch.cat([T(g[key + "/mean_raw"]), T(g[key + "/logvar_raw"])], dim=-1).to(dev)
+    eps = T(g[key + "/eps"]).to(dev)
+    radii = torch.tensor([float(Rs[1:])], device=dev)
+    out = Fn.component_forward(lay, heads, eps, radii, want_kl=True, want_log_probs=True, want_params=True)
+    assert_close(_cpu(out["z"]), g[key + "/z"], RTOL, "z")
+    assert_close(_cpu(out["kl"][0]), g[key + "/kl"], RTOL, "kl", atol_frac=1e-4)
+    assert_close(_cpu(out["mu"]), g[key + "/mu"], RTOL, "mu")
+    assert_close(_cpu(out["std"][:, :(1 if scalar else d)]), g[key + "/std"], RTOL, "std")
+    if letter != "e":
+        assert_close(_cpu(out["log_q"][0]), g[key + "/logq"], RTOL, "logq", atol_frac=1e-4)
+        assert_close(_cpu(out["log_p"][0]), g[key + "/logp"], RTOL, "logp", atol_frac=1e-4)
+    dz, dkl = T(g[key + "/wz"]).to(dev), T(g[key + "/wkl"]).to(dev).reshape(1, -1)
+    dheads, dradii = Fn.component_backward(lay, heads, eps, radii, dz, dkl)
+    assert_close(_cpu(dheads[:, :d]), g[key + "/d_mean_raw"], RTOL, "d_mean_raw", atol_frac=1e-4)
+    assert_close(_cpu(dheads[:, d:]), g[key + "/d_logvar_raw"], RTOL, "d_logvar_raw", atol_frac=1e-4)
+    if letter != "e":
+        assert_close(float(dradii[0]), float(g[key + "/d_radius"]), 2 * RTOL, "d_radius")
+
+
+def test_component_sample_dims_vs_oracle(dev):
+    """Leading sample dim (ModelVAE.log_likelihood path): eps [n, B, sum d] against the oracle's log q / log p."""
+    from mvae_amd import functional as Fn
+    from oracle import model as M
+    comps = [("h", 2), ("s", 3), ("e", 2), ("p", 2)]
+    lay = Fn.ComponentLayout(comps)
+    g = torch.Generator().manual_seed(3)
+    B, n = 16, 5
+    heads = torch.randn(B, lay.heads_dim, generator=g) * 0.6
+    eps = torch.randn(n, B, lay.eps_dim, generator=g)
+    radii = torch.tensor([2.0, 1.5, 0.0, 2.5])
+    out = Fn.component_forward(lay, heads.to(dev), eps.to(dev), radii.to(dev), want_kl=False, want_log_probs=True)
+    for i, (letter, d) in enumerate(comps):
+        c = M.ComponentSpec(letter, d)
+        desc = lay.descs[i]
+        o = M.component_forward(c, heads[:, desc.mean_col:desc.mean_col + d],
+                                heads[:, desc.logvar_col:desc.logvar_col + d],
+                                eps[..., desc.eps_col:desc.eps_col + d], radii[i], want_log_probs=True)
+        A = c.dim
+        assert_close(_cpu(out["z"][..., desc.z_col:desc.z_col + A]), o.z.numpy(), RTOL, f"z {letter}")
+        assert_close(_cpu(out["log_q"][i]), o.log_q.numpy(), RTOL, f"log_q {letter}", atol_frac=1e-4)
+        assert_close(_cpu(out["log_p"][i]), o.log_p.numpy(), RTOL, f"log_p {letter}", atol_frac=1e-4)
+
+
+def test_component_backward_poincare_vs_oracle(dev):
+    from mvae_amd import functional as Fn
+    from oracle import model as M
+    lay = Fn.ComponentLayout([("p", 3)])
+    g = torch.Generator().manual_seed(11)
+    B = 32
+    heads = (torch.randn(B, 6, generator=g) * 0.5)
+    eps = torch.randn(B, 3, generator=g)
+    wz, wkl = torch.randn(B, 3, generator=g), torch.rand(B, generator=g) + 0.5
+    rp = torch.tensor(2.0, requires_grad=True)
+    m = heads[:, :3].clone().requires_grad_(True)
+    l = heads[:, 3:].clone().requires_grad_(True)
+    o = M.component_forward(M.ComponentSpec("p", 3), m, l, eps, rp)
+    loss = (wz * o.z).sum() + (wkl * o.kl).sum()
+    gm, gl, gr = torch.autograd.grad(loss, [m, l, rp])
+    out = Fn.component_forward(lay, heads.to(dev), eps.to(dev), torch.tensor([2.0], device=dev))
+    assert_close(_cpu(out["z"]), o.z.detach().numpy(), RTOL, "z")
+    assert_close(_cpu(out["kl"][0]), o.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    dheads, dr = Fn.component_backward(lay, heads.to(dev), eps.to(dev), torch.tensor([2.0], device=dev), wz.to(dev),
+                                       wkl.reshape(1, -1).to(dev))
+    assert_close(_cpu(dheads[:, :3]), gm.numpy(), RTOL, "d_mean", atol_frac=1e-4)
+    assert_close(_cpu(dheads[:, 3:]), gl.numpy(), RTOL, "d_logvar", atol_frac=1e-4)
+    assert_close(float(dr[0]), float(gr), 2 * RTOL, "d_radius")
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+@pytest.mark.parametrize("M_,N,K", [(128, 400, 784), (128, 12, 400), (128, 784, 400), (128, 400, 8), (37, 50, 23),
+                                    (1, 1, 1), (256, 400, 48)])
+def test_linear_forward_backward(dev, M_, N, K):
+    from mvae_amd import functional as Fn
+    g = torch.Generator().manual_seed(M_ * 7 + N)
+    x = torch.relu(torch.randn(M_, K, generator=g))
+    W = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M_, N, generator=g)
+    for relu in (False, True):
+        y = Fn.linear_forward(x.to(dev), W.to(dev), b.to(dev), relu=relu)
+        ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+        ref = torch.relu(ref) if relu else ref
+        assert_close(_cpu(y), ref.numpy(), 2e-5, f"linear fwd relu={relu}", atol_frac=1e-5)
+    dW, db, dx = Fn.linear_backward(x.to(dev), W.to(dev), dy.to(dev), relu_in=True)
+    assert_close(_cpu(dW), (dy.double().t() @ x.double()).numpy(), 2e-5, "dW", atol_frac=1e-5)
+    assert_close(_cpu(db), dy.double().sum(0).numpy(), 2e-5, "db", atol_frac=1e-5)
+    assert_close(_cpu(dx), ((dy.double() @ W.double()) * (x > 0)).numpy(), 2e-5, "dx", atol_frac=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ the fused step
+SMALL = load_json("g3_step_small.json")
+
+
+def _engine(dev, meta, lr=1e-3):
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    comps = [(c.letter, c.true_dim) for c in M.parse_components(meta["model"])]
+    trainable = [not meta["fixed_curvature"]] * len(comps)
+    return StepEngine(comps, meta["in_dim"], meta["h_dim"], dev,
+                      scalar_parametrization=meta.get("scalar_parametrization", False), radius_trainable=trainable,
+                      lr=lr)
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_fused_step_small_vs_golden(dev, name):
+    g = load_npz("g3_step_small.npz")
+    meta = SMALL[name]
+    eng = _engine(dev, meta)
+    key = f"{name}/f32/steps1/"
+    state0 = {k[len(key + "state0/"):]: T(v) for k, v in g.items() if k.startswith(key + "state0/")}
+    eng.load_state(state0)
+    if meta["epoch"] < 10:
+        eng.set_radii(11 - meta["epoch"])
+    do_curv = (not meta["fixed_curvature"]) and meta["epoch"] >= 10
+    x = T(g[key + "x"], torch.float32)[0].to(dev)
+    eps = T(g[key + "eps"])[0].to(dev)
+    out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
+    assert_close(_cpu(out["logits"]), g[key + "logits"], RTOL, "logits")
+    assert_close(_cpu(out["concat_z"]), g[key + "concat_z"], RTOL, "concat_z")
+    assert_close(_cpu(out["bce"]), g[key + "bce_rows"], RTOL, "bce")
+    assert_close(_cpu(out["kl"]), g[key + "kl_rows"], RTOL, "kl", atol_frac=1e-4)
+    gv = eng.grad_views()
+    for n, t in gv.items():
+        if key + "grad/" + n in g:
+            assert_close(_cpu(t), g[key + "grad/" + n], RTOL, "grad " + n, atol_frac=1e-4)
+    eng.optimizer_step(do_curv)
+    for n, t in eng.param_views().items():
+        assert_close(_cpu(t), g[key + "state1/" + n], RTOL, "state1 " + n)
+    st = eng.read_stats()["last"]
+    ref = g[key + "stats"][0]
+    assert_close(st["bce"], ref[0], RTOL, "bce sum")
+    assert_close(st["kl"], ref[1], RTOL, "kl sum")
+    assert_close(st["elbo"], ref[2], RTOL, "elbo")
+    assert_close(st["component_kl"], ref[3:], RTOL, "component kl", atol_frac=1e-4)
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_fused_step_small_five_steps(dev, name):
+    g = load_npz("g3_step_small.npz")
+    meta = SMALL[name]
+    eng = _engine(dev, meta)
+    key1 = f"{name}/f32/steps1/"
+    key = f"{name}/f32/steps5/"
+    eng.load_state({k[len(key1 + "state0/"):]: T(v) for k, v in g.items() if k.startswith(key1 + "state0/")})
+    if meta["epoch"] < 10:
+        eng.set_radii(11 - meta["epoch"])
+    do_curv = (not meta["fixed_curvature"]) and meta["epoch"] >= 10
+    xs, eps = T(g[key + "x"], torch.float32).to(dev), T(g[key + "eps"]).to(dev)
+    for s in range(5):
+        eng.train_step(xs[s], eps[s], 1.0, do_curv)
+        st = eng.read_stats()["last"]
+        ref = g[key + "stats"][s]
+        assert_close([st["bce"], st["kl"], st["elbo"]], ref[:3], 2 * RTOL, f"stats step {s}", atol_frac=2e-4)
+    for n, t in eng.param_views().items():
+        assert_close(_cpu(t), g[key + "state_final/" + n], 2 * RTOL, "state_final " + n, atol_frac=2e-4)
+    tot = eng.read_stats()["sum"]
+    assert tot["steps"] == 5
+    assert_close(tot["elbo"], g[key + "stats"][:, 2].sum(), 2 * RTOL, "elbo sum over steps")
+
+
+FULL = load_json("g3_step_full.json")
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(FULL) if FULL[n]["arch"] == "ff"])
+def test_fused_step_full_size_vs_golden(dev, name):
+    """BASELINE.json configs [0], [1], [3] at their full sizes (B=128, h=400, D=784)."""
+    from mvae_amd import synthetic
+    from oracle import model as M
+    g = load_npz("g3_step_full.npz")
+    meta = FULL[name]
+    spec = M.Spec(meta["model"], in_dim=meta["in_dim"], h_dim=meta["h_dim"], fixed_curvature=meta["fixed_curvature"])
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    do_curv = (not meta["fixed_curvature"]) and meta["epoch"] >= 10
+    for steps in (1, 5):
+        key = f"{name}/f32/steps{steps}/"
+        eng = _engine(dev, meta)
+        eng.load_state(state0)
+        xs = synthetic.binary_batches(steps, meta["batch"], meta["in_dim"]).to(dev)
+        eps = synthetic.eps_batches(steps, meta["batch"], spec.total_true_dim).to(dev)
+        for s in range(steps):
+            out = eng.forward_backward(xs[s], eps[s], 1.0, want_outputs=(steps == 1))
+            if steps == 1:
+                assert_close(_cpu(out["concat_z"]), g[key + "concat_z"], RTOL, "concat_z")
+                assert_close(_cpu(out["bce"]), g[key + "bce_rows"], RTOL, "bce rows")
+                assert_close(_cpu(out["kl"]), g[key + "kl_rows"], RTOL, "kl rows", atol_frac=1e-4)
+                ref = g[key + "logits_summary"]
+                assert_close(summary_of(_cpu(out["logits"]), ref), ref, RTOL, "logits summary")
+                for n, t in eng.grad_views().items():
+                    if key + "grad_summary/" + n in g:
+                        ref = g[key + "grad_summary/" + n]
+                        assert_close(summary_of(_cpu(t), ref), ref, RTOL, "grad " + n, atol_frac=1e-4)
+            eng.optimizer_step(do_curv)
+            st = eng.read_stats()["last"]
+            ref = g[key + "stats"][s]
+            for got, want, nm in zip([st["bce"], st["kl"], st["elbo"]], ref[:3], ["bce", "kl", "elbo"]):
+                assert_close(got, want, RTOL, f"{nm} step {s}")
+        for n, t in eng.param_views().items():
+            ref = g[key + "state_final_summary/" + n]
+            assert_close(summary_of(_cpu(t), ref), ref, RTOL, "final " + n, atol_frac=1e-4)
+
+
+def test_fused_step_matches_oracle_other_batch_sizes(dev):
+    """Ragged last batch (B not a multiple of 16) and B=256, against the oracle on the same seeded inputs."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    for B in (96, 37, 256):
+        spec = M.Spec("h2,s2,e2,p2", in_dim=784, h_dim=400, fixed_curvature=False)
+        state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+        x = synthetic.binary_batches(1, B, 784)[0]
+        eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+        orc = M.StepOracle(spec, state0)
+        ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+        eng = StepEngine([(c.letter, c.true_dim) for c in spec.components], 784, 400, dev,
+                         radius_trainable=[True] * 4)
+        eng.load_state(state0)
+        out = eng.forward_backward(x.to(dev), eps.to(dev), 0.7, want_outputs=True)
+        eng.optimizer_step(True)
+        assert_close(_cpu(out["bce"]), ref.bce.detach().numpy(), RTOL, f"bce B={B}")
+        assert_close(_cpu(out["kl"]), ref.kl.detach().numpy(), RTOL, f"kl B={B}", atol_frac=1e-4)
+        assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, f"elbo B={B}")
+        for n, t in eng.param_views().items():
+            assert_close(_cpu(t), orc.P[n].detach().numpy(), RTOL, f"param {n} B={B}")

@@ -1,0 +1,122 @@
+"""CPU-side checks of the host layer: the C-ABI library loads and exports every declared symbol, argument validation
+works without a GPU, the flat layout reproduces the reference's state-dict contract, and the product path refuses
+to run without a HIP device (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import load_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from mvae_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "mvae_hip.h")).read()
+    declared = set(re.findall(r"\b(mvae_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mvae_ctx"}
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mvae_abi_version() == L.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    L = _lib()
+    lib = L.load()
+    # NULL pointers / bad kinds are rejected before anything touches the device
+    assert lib.mvae_exp_map_mu0(1, None, None, 4, 2, None, None) == -1
+    assert lib.mvae_exp_map_mu0(9, 1, 1, 4, 2, 1, None) == -1
+    assert b"kind" in lib.mvae_last_error()
+    assert lib.mvae_exp_map_mu0(1, 16, 16, 4, 100, 16, None) == -2  # true_dim > MVAE_MAX_TRUE_DIM
+    assert lib.mvae_linear_forward(None, None, None, None, 4, 4, 4, 0, None) == -1
+    with pytest.raises(L.MvaeHipError):
+        L.check(-1)
+
+
+def test_model_desc_validation_without_gpu():
+    L = _lib()
+    lib = L.load()
+    from mvae_amd.engine import FlatLayout
+    from mvae_amd.functional import ComponentLayout
+    lay = ComponentLayout([("h", 2), ("s", 2), ("e", 2)])
+    flat = FlatLayout(lay, 784, 400, False)
+    d = L.ModelDesc()
+    d.abi_version, d.arch, d.batch, d.in_dim, d.h_dim = L.ABI_VERSION, 0, 128, 784, 400
+    d.ncomp, d.heads_dim, d.z_dim, d.eps_dim = 3, lay.heads_dim, lay.z_dim, lay.eps_dim
+    d.n_params = flat.n_params
+    d.comps = lay.descs
+    for f in ("off_w_heads", "off_b_heads", "off_w_e0", "off_b_e0", "off_w_d0", "off_b_d0", "off_w_logits",
+              "off_b_logits"):
+        setattr(d, f, getattr(flat, f))
+    assert lib.mvae_workspace_floats(C.byref(d)) > 128 * 784
+    h = C.c_void_p()
+    assert lib.mvae_create(C.byref(d), C.byref(h)) == -1  # null buffers
+    fake = 0x10000  # never dereferenced by create
+    for f in ("params", "grads", "adam_m", "adam_v", "step_count", "workspace", "stats"):
+        setattr(d, f, fake)
+    assert lib.mvae_create(C.byref(d), C.byref(h)) == 0
+    lib.mvae_destroy(h)
+    d.heads_dim += 1
+    assert lib.mvae_create(C.byref(d), C.byref(h)) == -1  # inconsistent with the component table
+    d.heads_dim -= 1
+    d.off_w_e0 += 2
+    assert lib.mvae_create(C.byref(d), C.byref(h)) == -3  # misaligned segment
+
+
+def test_layouts_match_reference_state_dict_contract():
+    from mvae_amd.engine import FlatLayout
+    from mvae_amd.functional import ComponentLayout
+    tab = load_json("g5_parser.json")["state_shapes"]
+    for key, comps in [("h2,s2,e2|ff", [("h", 2), ("s", 2), ("e", 2)]),
+                       ("6h2,6s2,6e2|ff", [("h", 2)] * 6 + [("s", 2)] * 6 + [("e", 2)] * 6), ("e6|ff", [("e", 6)])]:
+        lay = ComponentLayout(comps)
+        flat = FlatLayout(lay, 784, 400, False)
+        assert [[n, list(s)] for n, _, s in flat.entries] == tab[key]
+        views = flat.views(torch.zeros(flat.n_params))
+        # views tile the head matrix without overlap: writing ones everywhere covers exactly the logical count
+        for v in views.values():
+            v.fill_(1.0)
+        assert int(sum(v.numel() for v in views.values())) == flat.n_logical_params()
+    lay = ComponentLayout([("h", 2), ("s", 2), ("e", 2)])
+    assert (lay.heads_dim, lay.z_dim, lay.eps_dim) == (12, 8, 6)
+    flat = FlatLayout(lay, 784, 400, False)
+    assert flat.n_logical_params() == 636798  # P for h2,s2,e2
+    d = lay.descs[1]
+    assert (d.kind, d.mean_col, d.logvar_col, d.eps_col, d.z_col) == (2, 2, 8, 2, 3)
+
+
+def test_no_cpu_fallback():
+    _lib()
+    from mvae_amd import functional as Fn
+    from mvae_amd._lib import MvaeHipError
+    from mvae_amd.engine import StepEngine
+    with pytest.raises(MvaeHipError):
+        Fn.exp_map_mu0(1, torch.zeros(4, 2), torch.tensor(1.0))
+    with pytest.raises(MvaeHipError):
+        Fn.linear_forward(torch.zeros(4, 4), torch.zeros(4, 4), None)
+    with pytest.raises(MvaeHipError):
+        StepEngine([("h", 2)], 8, 8, "cpu")
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "mvae_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src or f.endswith((".hip", ".hpp", ".py")) and \
+                    not re.search(r"open\(.*/root/reference", src), f
