@@ -30,19 +30,21 @@ F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
 
 
 def algorithmic_per_launch(P):
-    """Algorithmic bytes / flops of each launch of one step at B=128 (each tensor once)."""
-    NH, Z = 12, 8
+    """Algorithmic bytes / flops of each of the six launches of one fused step at B=128: every
+    tensor a launch consumes or produces counted once; a weight updated in a gradient epilogue costs 7 floats per
+    element (read p, m, v; write g, p, m, v)."""
+    NH, Z, E = 12, 8, 6
     f4 = 4.0
     return {
         "enc_fwd": dict(flops=2.0 * B * D * H, bytes=f4 * (B * D + H * D + H + B * H)),
         "latent_fwd": dict(flops=2.0 * B * H * NH + 2.0 * B * Z * H,
-                           bytes=f4 * (B * H + NH * H + NH + B * 6 + H * Z + H + B * Z + B * H)),
+                           bytes=f4 * (B * H + NH * H + NH + B * E + H * Z + H + B * Z + B * NH + B * H)),
         "dec1_fwd": dict(flops=2.0 * B * H * D, bytes=f4 * (B * H + D * H + D + 2 * B * D)),
-        "dec1_bwd": dict(flops=4.0 * B * H * D, bytes=f4 * (B * D + B * H + D * H + D * H + D + B * H)),
-        "latent_bwd": dict(flops=4.0 * B * H * Z + 2.0 * B * NH * H,
-                           bytes=f4 * (2 * B * H + H * Z + NH * H + B * H + H * Z + H)),
-        "enc_bwd": dict(flops=2.0 * B * H * D + 2.0 * B * NH * H, bytes=f4 * (B * H + B * D + H * D + NH * H + B * H)),
-        "optim": dict(flops=12.0 * P, bytes=f4 * 7 * P),  # read p,g,m,v ; write p,m,v
+        "dec1_bwd": dict(flops=2.0 * B * H * D, bytes=f4 * (B * D + D * H + 2 * B * H + 7 * D)),
+        "latent_bwd": dict(flops=2.0 * B * H * D + 2.0 * B * H * Z + 2.0 * B * NH * H,
+                           bytes=f4 * (3 * B * H + H * Z + 2 * B * NH + B * E + NH * H + B * D + B * H + 7 * D * H)),
+        "enc_bwd": dict(flops=2.0 * B * H * D + 2.0 * B * NH * H + 2.0 * B * H * Z,
+                        bytes=f4 * (2 * B * H + B * D + B * NH + B * H + B * Z + 7 * (H * D + NH * H + H * Z + 2 * H + NH))),
     }
 
 

@@ -163,8 +163,8 @@ typedef struct mvae_model_desc {
   float* grads;         /* [P]  dense gradient of (-ELBO) after mvae_step_forward_backward                     */
   float* adam_m;        /* [P] */
   float* adam_v;        /* [P] */
-  int32_t* step_count;  /* [2]  {Adam step counter, scratch}; device-side so that a captured graph advances it; zeroed
-                           by the host at creation                                                              */
+  int32_t* step_count;  /* [32] {Adam step counter, arrival scratch...}; device-side so that a captured graph advances
+                           it; zeroed by the host at creation                                                   */
   float* workspace;     /* [mvae_workspace_floats(desc)] activations + partial sums                            */
   float* stats;         /* [2 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
                            same record for the LAST step only (stats.py:120-127 without the per-step .item() syncs:
@@ -197,8 +197,9 @@ int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta,
 /* Measurement aid (never captured into a graph, synchronises): runs `iters` full steps on `stream` with a HIP event
  * between consecutive launches and writes the average duration of each of the MVAE_STEP_KERNELS launches, in
  * milliseconds, to the HOST array ms_out[MVAE_STEP_KERNELS] (order: enc_fwd, latent_fwd, dec1_fwd, dec1_bwd,
- * latent_bwd, enc_bwd, optim).  Parameters and optimizer state advance exactly as in mvae_train_step. */
-#define MVAE_STEP_KERNELS 7
+ * latent_bwd, enc_bwd -- the six launches of mvae_train_step, whose gradient epilogues carry the optimizer).
+ * Parameters and optimizer state advance exactly as in mvae_train_step. */
+#define MVAE_STEP_KERNELS 6
 int mvae_step_profile(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, int iters,
                       float* ms_out, void* stream);
 

@@ -32,8 +32,13 @@ __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ row, i
   return r;
 }
 
+// The K loops below issue the operand loads of G consecutive k-chunks before any MFMA consumes them (the loads are
+// independent of the accumulator, so G L2/HBM round trips overlap), and alternate between two accumulators so that
+// consecutive MFMAs do not wait on the 40-cycle dependent-accumulator latency.
+
 // NT:  acc[i][j] += sum_{k in chunks} A[m0+i][k] * W[n0+j][k]      (y = x W^T: both operands K-contiguous)
 // The wave processes the 16-wide k-chunks c = chunk0, chunk0+stride, ... < nchunks.
+template <int G = 4>
 __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, int M, int m0,
                                          const float* __restrict__ W, int ldw, int N, int n0, int K, int chunk0,
                                          int stride, bool vecA, bool vecW, f32x4 acc) {
@@ -43,21 +48,31 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
   const float* arow = A + (size_t)(a_ok ? m0 + i : 0) * lda;
   const float* wrow = W + (size_t)(w_ok ? n0 + i : 0) * ldw;
   const int nchunks = (K + 15) >> 4;
-#pragma unroll 4
-  for (int c = chunk0; c < nchunks; c += stride) {
-    const int k = (c << 4) + (q << 2);
-    float4 a = load4_guarded(arow, k, K, a_ok, vecA);
-    float4 b = load4_guarded(wrow, k, K, w_ok, vecW);
-    acc = mfma16(a.x, b.x, acc);
-    acc = mfma16(a.y, b.y, acc);
-    acc = mfma16(a.z, b.z, acc);
-    acc = mfma16(a.w, b.w, acc);
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int c = chunk0; c < nchunks; c += stride * G) {
+    float4 a[G], b[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int cc = c + g * stride;
+      const int k = (cc << 4) + (q << 2);
+      const bool ok = cc < nchunks;
+      a[g] = load4_guarded(arow, k, K, a_ok && ok, vecA);
+      b[g] = load4_guarded(wrow, k, K, w_ok && ok, vecW);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      acc = mfma16(a[g].x, b[g].x, acc);
+      acc2 = mfma16(a[g].y, b[g].y, acc2);
+      acc = mfma16(a[g].z, b[g].z, acc);
+      acc2 = mfma16(a[g].w, b[g].w, acc2);
+    }
   }
-  return acc;
+  return acc + acc2;
 }
 
 // TN:  acc[i][j] += sum_{m} P[m][p0+i] * Q[m][q0+j]     (dW = dy^T x: contraction over the batch rows)
-// The wave processes rows m = 4*(s) + q for steps s = step0, step0+stride, ... ; 4 rows per MFMA.
+// The wave processes rows m = 4*s + q for steps s = step0, step0+stride, ... ; 4 rows per MFMA.
+template <int G = 8>
 __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, int NP, int p0,
                                          const float* __restrict__ Q, int ldq, int NQ, int q0, int Mrows, int step0,
                                          int stride, f32x4 acc) {
@@ -65,40 +80,58 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
   const int i = lane & 15, q = lane >> 4;
   const bool p_ok = (p0 + i) < NP, q_ok = (q0 + i) < NQ;
   const int nsteps = (Mrows + 3) >> 2;
-#pragma unroll 8
-  for (int s = step0; s < nsteps; s += stride) {
-    const int m = (s << 2) + q;
-    const bool m_ok = m < Mrows;
-    float a = (p_ok && m_ok) ? P[(size_t)m * ldp + p0 + i] : 0.f;
-    float b = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
-    acc = mfma16(a, b, acc);
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int s = step0; s < nsteps; s += stride * G) {
+    float a[G], b[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int m = ((s + g * stride) << 2) + q;
+      const bool m_ok = m < Mrows;
+      a[g] = (p_ok && m_ok) ? P[(size_t)m * ldp + p0 + i] : 0.f;
+      b[g] = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+      acc = mfma16(a[g], b[g], acc);
+      if (g + 1 < G) acc2 = mfma16(a[g + 1], b[g + 1], acc2);
+    }
   }
-  return acc;
+  return acc + acc2;
 }
 
 // NN:  acc[i][j] += sum_{k} G[m0+i][k] * W[k][n0+j]      (dx = dy W: G is K-contiguous, W is N-contiguous)
-__device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ G, int ldg, int M, int m0,
+template <int G = 4>
+__device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, int M, int m0,
                                          const float* __restrict__ W, int ldw, int N, int n0, int K, int chunk0,
                                          int stride, bool vecG, f32x4 acc) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, q = lane >> 4;
   const bool g_ok = (m0 + i) < M, w_ok = (n0 + i) < N;
-  const float* grow = G + (size_t)(g_ok ? m0 + i : 0) * ldg;
+  const float* grow = Gm + (size_t)(g_ok ? m0 + i : 0) * ldg;
+  const float* wcol = W + (w_ok ? n0 + i : 0);
   const int nchunks = (K + 15) >> 4;
-#pragma unroll 2
-  for (int c = chunk0; c < nchunks; c += stride) {
-    const int k = (c << 4) + (q << 2);
-    float4 a = load4_guarded(grow, k, K, g_ok, vecG);
-    float b0 = (w_ok && k < K) ? W[(size_t)k * ldw + n0 + i] : 0.f;
-    float b1 = (w_ok && k + 1 < K) ? W[(size_t)(k + 1) * ldw + n0 + i] : 0.f;
-    float b2 = (w_ok && k + 2 < K) ? W[(size_t)(k + 2) * ldw + n0 + i] : 0.f;
-    float b3 = (w_ok && k + 3 < K) ? W[(size_t)(k + 3) * ldw + n0 + i] : 0.f;
-    acc = mfma16(a.x, b0, acc);
-    acc = mfma16(a.y, b1, acc);
-    acc = mfma16(a.z, b2, acc);
-    acc = mfma16(a.w, b3, acc);
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int c = chunk0; c < nchunks; c += stride * G) {
+    float4 a[G];
+    float b[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int cc = c + g * stride;
+      const int k = (cc << 4) + (q << 2);
+      const bool ok = cc < nchunks;
+      a[g] = load4_guarded(grow, k, K, g_ok && ok, vecG);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[g][t] = (w_ok && ok && k + t < K) ? wcol[(size_t)(k + t) * ldw] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      acc = mfma16(a[g].x, b[g][0], acc);
+      acc2 = mfma16(a[g].y, b[g][1], acc2);
+      acc = mfma16(a[g].z, b[g][2], acc);
+      acc2 = mfma16(a[g].w, b[g][3], acc2);
+    }
   }
-  return acc;
+  return acc + acc2;
 }
 
 // Combine the four waves' partial tiles.  red is float[4][16][17] in LDS (row padded: the epilogue reads a column of

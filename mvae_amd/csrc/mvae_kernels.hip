@@ -110,30 +110,34 @@ template <int DMAX>
 __device__ __forceinline__ void comp_fwd_row(const mvae_component_desc& c, const float* heads_row, const float* eps_row,
                                              const float* radii, float* z_row, float* z_row2, float* kl, float* lq,
                                              float* lp, float* mu_row, float* std_row) {
-  float m[DMAX], l[DMAX], e[DMAX], z[DMAX + 1], mu[DMAX + 1], sg[DMAX];
+  MV_BOUNDS(DMAX + 1);
+  float m[kN], l[kN], e[kN], z[kN], mu[kN], sg[kN];
   const int d = c.true_dim, lvd = c.logvar_dim;
-  for (int i = 0; i < d; ++i) {
+  MV_FOR(i, 0, d) {
     m[i] = heads_row[c.mean_col + i];
     e[i] = eps_row[c.eps_col + i];
   }
-  for (int i = 0; i < lvd; ++i) l[i] = heads_row[c.logvar_col + i];
+  MV_FOR(i, 0, lvd) l[i] = heads_row[c.logvar_col + i];
   float rp = (c.kind == kEuclidean) ? 0.f : radii[c.radius_idx];
   float klv = 0.f, lqv = 0.f, lpv = 0.f;
   comp_eval<DMAX, float>(c.kind, m, l, lvd, e, d, rp, z, kl ? &klv : nullptr, lq ? &lqv : nullptr,
                          lq ? &lpv : nullptr, mu_row ? mu : nullptr, std_row ? sg : nullptr);
   const int A = ambient_dim(c.kind, d);
-  for (int i = 0; i < A; ++i) z_row[c.z_col + i] = z[i];
-  if (z_row2)
-    for (int i = 0; i < A; ++i) z_row2[c.z_col + i] = z[i];
+  MV_FOR(i, 0, A) z_row[c.z_col + i] = z[i];
+  if (z_row2) {
+    MV_FOR(i, 0, A) z_row2[c.z_col + i] = z[i];
+  }
   if (kl) *kl = klv;
   if (lq) {
     *lq = lqv;
     *lp = lpv;
   }
-  if (mu_row)
-    for (int i = 0; i < A; ++i) mu_row[c.z_col + i] = mu[i];
-  if (std_row)
-    for (int i = 0; i < lvd; ++i) std_row[c.eps_col + i] = sg[i];
+  if (mu_row) {
+    MV_FOR(i, 0, A) mu_row[c.z_col + i] = mu[i];
+  }
+  if (std_row) {
+    MV_FOR(i, 0, lvd) std_row[c.eps_col + i] = sg[i];
+  }
 }
 
 // d(loss)/d(input direction `dir`) for one (row, component): loss = <dz, z> + dkl * kl
@@ -141,20 +145,21 @@ template <int DMAX>
 __device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, const float* heads_row,
                                               const float* eps_row, const float* radii, const float* dz_row, float dkl,
                                               int dir) {
-  Dual m[DMAX], l[DMAX], z[DMAX + 1];
-  float e[DMAX];
+  MV_BOUNDS(DMAX + 1);
+  Dual m[kN], l[kN], z[kN];
+  float e[kN];
   const int d = c.true_dim, lvd = c.logvar_dim;
-  for (int i = 0; i < d; ++i) {
+  MV_FOR(i, 0, d) {
     m[i] = Dual{heads_row[c.mean_col + i], (dir == i) ? 1.f : 0.f};
     e[i] = eps_row[c.eps_col + i];
   }
-  for (int i = 0; i < lvd; ++i) l[i] = Dual{heads_row[c.logvar_col + i], (dir == d + i) ? 1.f : 0.f};
+  MV_FOR(i, 0, lvd) l[i] = Dual{heads_row[c.logvar_col + i], (dir == d + i) ? 1.f : 0.f};
   Dual rp = Dual{(c.kind == kEuclidean) ? 0.f : radii[c.radius_idx], (dir == d + lvd) ? 1.f : 0.f};
   Dual kl;
   comp_eval<DMAX, Dual>(c.kind, m, l, lvd, e, d, rp, z, &kl, nullptr, nullptr, nullptr, nullptr);
   const int A = ambient_dim(c.kind, d);
   float g = dkl * kl.d;
-  for (int i = 0; i < A; ++i) g += dz_row[c.z_col + i] * z[i].d;
+  MV_FOR(i, 0, A) g += dz_row[c.z_col + i] * z[i].d;
   return g;
 }
 
@@ -203,16 +208,33 @@ __device__ __forceinline__ void job_nn(float (*red)[16][17], const float* G, int
   }
 }
 
-// out[c] = sum_m Gm[m][c] for the 64 columns starting at c0 (rows added in index order within 4 interleaved groups)
-__device__ __forceinline__ void job_colsum(float* lds /*[4][64]*/, const float* Gm, int ld, int Mrows, int ncols,
-                                           int c0, float* out) {
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+// out[c] = sum_m Gm[m][c] for the 16 columns starting at c0: thread (g = tid>>4, c = tid&15) adds rows g, g+16, ...
+// (loads issued in batches of 8), the 16 row-groups meet in LDS and are added in index order.
+constexpr int kColsPerBlock = 16;
+__device__ __forceinline__ void job_colsum(float* lds /*>= 16*17 floats*/, const float* Gm, int ld, int Mrows,
+                                           int ncols, int c0, float* out) {
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   float s = 0.f;
-  if (c0 + c < ncols)
-    for (int m = g; m < Mrows; m += 4) s += Gm[(size_t)m * ld + c0 + c];
-  lds[g * 64 + c] = s;
+  if (c0 + c < ncols) {
+    const float* col = Gm + c0 + c;
+    int m = g;
+    for (; m + 16 * 7 < Mrows; m += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(m + 16 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; m < Mrows; m += 16) s += col[(size_t)m * ld];
+  }
+  lds[g * 17 + c] = s;
   __syncthreads();
-  if (g == 0 && c0 + c < ncols) out[c0 + c] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
+  if (g == 0 && c0 + c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += lds[q * 17 + c];
+    out[c0 + c] = t;
+  }
   __syncthreads();
 }
 
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float* x, const float*
   b -= n_dw;
   (void)ntM;
   (void)ntN;
-  job_colsum(&red[0][0][0], dy, N, M, N, b * 64, db);
+  job_colsum(&red[0][0][0], dy, N, M, N, b * kColsPerBlock, db);
 }
 
 // ------------------------------------------------------------------------------------------------ primitives (API)
@@ -252,73 +274,74 @@ template <int OP, int KIND, int DMAX>
 __device__ __forceinline__ void prim_row(const float* a, const float* b, const float* c3, float* o1, float* o2, int d,
                                          float rp, int64_t r, int64_t at_rows) {
   constexpr int AMAX = DMAX + 1;
+  MV_BOUNDS(AMAX);
   const int A = ambient_dim(KIND, d);
   float R = (KIND == kEuclidean) ? 0.f : radius_of(rp);
   float t0[AMAX], t1[AMAX], t2[AMAX], t3[AMAX];
   if constexpr (OP == OP_EXP0) {
-    for (int i = 0; i < d; ++i) t0[i] = a[r * d + i];
-    exp_map_mu0<KIND>(t0, d, R, t1);
-    for (int i = 0; i < A; ++i) o1[r * A + i] = t1[i];
+    MV_FOR(i, 0, d) t0[i] = a[r * d + i];
+    exp_map_mu0<KIND, AMAX>(t0, d, R, t1);
+    MV_FOR(i, 0, A) o1[r * A + i] = t1[i];
   } else if constexpr (OP == OP_LOG0) {
-    for (int i = 0; i < A; ++i) t0[i] = a[r * A + i];
-    log_map_mu0<KIND>(t0, A, R, t1);
-    for (int i = 0; i < A; ++i) o1[r * A + i] = t1[i];
+    MV_FOR(i, 0, A) t0[i] = a[r * A + i];
+    log_map_mu0<KIND, AMAX>(t0, A, R, t1);
+    MV_FOR(i, 0, A) o1[r * A + i] = t1[i];
   } else if constexpr (OP == OP_PT0 || OP == OP_IPT0) {
-    for (int i = 0; i < A; ++i) {
+    MV_FOR(i, 0, A) {
       t0[i] = a[r * A + i];
       t1[i] = b[r * A + i];
     }
-    if constexpr (OP == OP_PT0) pt_mu0<KIND>(t0, t1, A, R, t2);
-    else inv_pt_mu0<KIND>(t0, t1, A, R, t2);
-    for (int i = 0; i < A; ++i) o1[r * A + i] = t2[i];
+    if constexpr (OP == OP_PT0) pt_mu0<KIND, AMAX>(t0, t1, A, R, t2);
+    else inv_pt_mu0<KIND, AMAX>(t0, t1, A, R, t2);
+    MV_FOR(i, 0, A) o1[r * A + i] = t2[i];
   } else if constexpr (OP == OP_SAMPLE) {  // a = v[rows,d], b = at[at_rows,A] -> o1 = z, o2 = u
     const int64_t ar = r % at_rows;
-    for (int i = 0; i < A; ++i) t1[i] = b[ar * A + i];
+    MV_FOR(i, 0, A) t1[i] = b[ar * A + i];
     if constexpr (KIND == kEuclidean) {
-      for (int i = 0; i < d; ++i) t2[i] = a[r * d + i];
+      MV_FOR(i, 0, d) t2[i] = a[r * d + i];
     } else if constexpr (KIND == kPoincare) {
-      float lam = p_lambda(t1, A, 1.0f / (R * R));
-      for (int i = 0; i < d; ++i) t2[i] = a[r * d + i] / lam;
+      float lam = p_lambda<AMAX>(t1, A, 1.0f / (R * R));
+      MV_FOR(i, 0, d) t2[i] = a[r * d + i] / lam;
     } else {
       t0[0] = 0.f;
-      for (int i = 0; i < d; ++i) t0[i + 1] = a[r * d + i];
-      pt_mu0<KIND>(t0, t1, A, R, t2);
+      MV_FOR(i, 1, A) t0[i] = a[r * d + i - 1];
+      pt_mu0<KIND, AMAX>(t0, t1, A, R, t2);
     }
     exp_map<KIND, AMAX>(t2, t1, A, R, t3);
-    for (int i = 0; i < A; ++i) {
+    MV_FOR(i, 0, A) {
       o1[r * A + i] = t3[i];
       if (o2) o2[r * A + i] = t2[i];
     }
   } else if constexpr (OP == OP_ISAMPLE) {  // a = z[rows,A], b = at -> o1 = u[rows,A], o2 = v[rows,d]
     const int64_t ar = r % at_rows;
-    for (int i = 0; i < A; ++i) {
+    MV_FOR(i, 0, A) {
       t0[i] = a[r * A + i];
       t1[i] = b[ar * A + i];
     }
     log_map<KIND, AMAX>(t0, t1, A, R, t2);
-    for (int i = 0; i < A; ++i) o1[r * A + i] = t2[i];
+    MV_FOR(i, 0, A) o1[r * A + i] = t2[i];
     if constexpr (KIND == kEuclidean) {
-      for (int i = 0; i < d; ++i) o2[r * d + i] = t2[i];
+      MV_FOR(i, 0, d) o2[r * d + i] = t2[i];
     } else if constexpr (KIND == kPoincare) {
-      float lam = p_lambda(t1, A, 1.0f / (R * R));
-      for (int i = 0; i < d; ++i) o2[r * d + i] = t2[i] * lam;
+      float lam = p_lambda<AMAX>(t1, A, 1.0f / (R * R));
+      MV_FOR(i, 0, d) o2[r * d + i] = t2[i] * lam;
     } else {
-      inv_pt_mu0<KIND>(t2, t1, A, R, t3);
-      for (int i = 0; i < d; ++i) o2[r * d + i] = t3[i + 1];
+      inv_pt_mu0<KIND, AMAX>(t2, t1, A, R, t3);
+      MV_FOR(i, 1, A) o2[r * d + i - 1] = t3[i];
     }
   } else {  // OP_LOGDET: a = u (h,s) ; b = mu, c3 = z (p)
     if constexpr (KIND == kEuclidean) {
       o1[r] = 0.f;
     } else if constexpr (KIND == kPoincare) {
       const int64_t ar = r % at_rows;
-      for (int i = 0; i < A; ++i) {
+      MV_FOR(i, 0, A) {
         t0[i] = b[ar * A + i];
         t1[i] = c3[r * A + i];
       }
       o1[r] = p_logdet<AMAX>(t0, t1, A, R);
     } else {
-      for (int i = 0; i < A; ++i) t0[i] = a[r * A + i];
-      o1[r] = logdet_u<KIND>(t0, A, R);
+      MV_FOR(i, 0, A) t0[i] = a[r * A + i];
+      o1[r] = logdet_u<KIND, AMAX>(t0, A, R);
     }
   }
 }
@@ -511,7 +534,7 @@ extern "C" int mvae_linear_backward(const float* x, const float* W, const float*
   if (!x || !W || !dy || !dW || !db || M < 1 || N < 1 || K < 1)
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   const int ntN = (N + 15) / 16, ntK = (K + 15) / 16, ntM = (int)((M + 15) / 16);
-  const int n_dx = dx ? ntM * ntK : 0, n_dw = ntN * ntK, n_db = (N + 63) / 64;
+  const int n_dx = dx ? ntM * ntK : 0, n_dw = ntN * ntK, n_db = (N + kColsPerBlock - 1) / kColsPerBlock;
   hipLaunchKernelGGL(k_linear_bwd, dim3(n_dx + n_dw + n_db), dim3(256), 0, (hipStream_t)stream, x, W, dy, dW, db, dx,
                      (int)M, N, K, relu_in, n_dw, n_dx);
   LAUNCH_CHECK("linear backward launch");
@@ -554,7 +577,7 @@ static void carve(mvae_ctx* c) {
   c->o_dz = take(B * c->ldz);
   c->o_dheads = take(B * c->ldh);
   c->o_dh = take(B * H);
-  c->o_drpart = take((int64_t)c->nt_b * kMaxComp);
+  c->o_drpart = take(B * kMaxComp);  // [comp][B]
   c->o_total = o;
 }
 
@@ -616,85 +639,342 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
 
 extern "C" void mvae_destroy(mvae_ctx* ctx) { delete ctx; }
 
-// ---- 1: encoder layer
-__global__ __launch_bounds__(256) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
-                                                 int D) {
-  __shared__ float red[4][16][17];
-  job_linear_fwd<true>(red, x, D, W, D, b, h, H, B, H, D, blockIdx.y, blockIdx.x);
+// ---------------------------------------------------------------------------------------------- Adam in the epilogue
+// torch.optim.Adam, single-tensor CPU formulas, defaults betas=(0.9, 0.999), eps=1e-8:
+//   m <- m + (1-b1)(g - m) ; v <- v*b2 + ((1-b2) g) g ; p <- p + (-lr/bc1 * m) / (sqrt(v)/sqrt(bc2) + eps)
+// In the single-GPU step the update is applied by the workgroup that produced the gradient tile, in its epilogue,
+// one launch after the last read of that weight (see the launch list at the top); a data-parallel run applies it in
+// k_optim after the gradient all-reduce instead.
+struct AdamArgs {
+  float* p;
+  float* m;
+  float* v;
+  const int* counters;  // counters[0] = number of this step (already advanced by launch 1)
+  double lr;
+};
+
+__device__ __forceinline__ double pow_int(double base, int e) {  // base^e by squaring (e >= 0)
+  double r = 1.0, b = base;
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
 }
 
-// ---- 2: heads GEMM + latent components + first decoder layer, 16 batch rows per workgroup
-template <int DMAX>
+// thread 0 writes {-lr/bc1, sqrt(bc2)} to sh[0..1]; the caller's next __syncthreads publishes it
+__device__ __forceinline__ void adam_consts(float* sh, const int* counters, double lr, int step_offset) {
+  if (threadIdx.x == 0) {
+    const int step = *(volatile const int*)&counters[0] + step_offset;
+    const double bc1 = 1.0 - pow_int(0.9, step);
+    const double bc2 = 1.0 - pow_int(0.999, step);
+    sh[0] = (float)(-(lr / bc1));
+    sh[1] = (float)sqrt(bc2);
+  }
+}
+
+__device__ __forceinline__ void adam1(float& P, float G, float& M, float& V, float neg_step, float bc2s) {
+  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999);
+  M = M + w1 * (G - M);
+  V = V * b2 + (w2 * G) * G;
+  P = P + (neg_step * M) / (sqrtf(V) / bc2s + 1e-8f);
+}
+
+// ---------------------------------------------------------------------------------------------- step tile jobs
+// 8-wave (512-thread) variants for the long contractions (K = 784 / 400): every wave issues ALL of its operand loads
+// up front (<= 7 k-chunks per wave) and the eight partial tiles meet in LDS.
+constexpr int kW8 = 8;
+__device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, rbase = (lane >> 4) << 2;
+  red[wave][rbase + 0][col] = acc[0];
+  red[wave][rbase + 1][col] = acc[1];
+  red[wave][rbase + 2][col] = acc[2];
+  red[wave][rbase + 3][col] = acc[3];
+  __syncthreads();
+  float s = 0.f;
+  if (tid < 256) {
+    const int r = tid >> 4, c = tid & 15;
+    s = ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) +
+        ((red[4][r][c] + red[5][r][c]) + (red[6][r][c] + red[7][r][c]));
+  }
+  return s;
+}
+
+// dW tile (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q]; 256 threads
+template <bool ADAM>
+__device__ __forceinline__ void job_tn_opt(float (*red)[16][17], float* sh, const float* P, int ldp, int NP, int pt,
+                                           const float* Q, int ldq, int NQ, int qt, int Mrows, float* out, int ldo,
+                                           const AdamArgs& aa) {
+  const int wave = threadIdx.x >> 6;
+  const int pr = pt * 16 + (threadIdx.x >> 4), qc = qt * 16 + (threadIdx.x & 15);
+  const bool ok = pr < NP && qc < NQ;
+  const size_t idx = (size_t)pr * ldo + qc;
+  float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+  if (ADAM) {
+    if (ok) {  // issued before the contraction: the round trip overlaps it
+      p0 = aa.p[idx];
+      m0 = aa.m[idx];
+      v0 = aa.v[idx];
+    }
+    adam_consts(sh, aa.counters, aa.lr, 0);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_tn(P, ldp, NP, pt * 16, Q, ldq, NQ, qt * 16, Mrows, wave, 4, acc);
+  const float s = reduce_tiles(red, acc);
+  if (ok) {
+    out[idx] = s;
+    if (ADAM) {
+      adam1(p0, s, m0, v0, sh[0], sh[1]);
+      aa.p[idx] = p0;
+      aa.m[idx] = m0;
+      aa.v[idx] = v0;
+    }
+  }
+}
+
+// bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16
+template <bool ADAM>
+__device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/, const float* Gm, int ld, int Mrows,
+                                               int ncols, int c0, float* out, const AdamArgs& aa) {
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4, ng = blockDim.x >> 4;
+  float* sh = lds + 32 * 17;
+  float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+  const bool fin = (g == 0) && (c0 + c < ncols);
+  if (ADAM) {
+    if (fin) {
+      p0 = aa.p[c0 + c];
+      m0 = aa.m[c0 + c];
+      v0 = aa.v[c0 + c];
+    }
+    adam_consts(sh, aa.counters, aa.lr, 0);
+  }
+  float s = 0.f;
+  if (c0 + c < ncols) {
+    const float* col = Gm + c0 + c;
+    int m = g;
+    for (; m + ng * 3 < Mrows; m += ng * 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = col[(size_t)(m + ng * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; m < Mrows; m += ng) s += col[(size_t)m * ld];
+  }
+  lds[g * 17 + c] = s;
+  __syncthreads();
+  if (fin) {
+    float t = 0.f;
+    for (int q = 0; q < ng; ++q) t += lds[q * 17 + c];
+    out[c0 + c] = t;
+    if (ADAM) {
+      adam1(p0, t, m0, v0, sh[0], sh[1]);
+      aa.p[c0 + c] = p0;
+      aa.m[c0 + c] = m0;
+      aa.v[c0 + c] = v0;
+    }
+  }
+}
+
+// ---- 1: encoder layer (512 threads).  In the fused single-GPU step, workgroup (0,0) also advances the step counter.
+__global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
+                                                 int D, int* counters, int bump_step) {
+  __shared__ float red[kW8][16][17];
+  const int wave = threadIdx.x >> 6;
+  const int mt = blockIdx.y, nt = blockIdx.x;
+  if (bump_step && mt == 0 && nt == 0 && threadIdx.x == 0) counters[0] = counters[0] + 1;
+  const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_nt<7>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
+  const float s = reduce_tiles8(red, acc);
+  if (threadIdx.x < 256) {
+    const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+    if (m < B && n < H) {
+      const float v = s + b[n];
+      h[(size_t)m * H + n] = v > 0.f ? v : 0.f;
+    }
+  }
+}
+
+// wave-level sum (all 64 lanes end up with the total)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- 2: heads + latent components + first decoder layer; ONE batch row per workgroup.  The phases are short and
+// latency-bound, so rows are spread over as many CUs as possible, every global operand is requested in the first
+// instructions of the kernel (one memory round trip), and the small reductions are wavefront shuffles.
+// FAST: NH <= 16, Z <= 8, H <= 512 (operands of all phases are held in registers from the start).
+template <int DMAX, bool FAST>
 __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h, const float* Wh, const float* bh,
                                                     const float* eps, int eps_ld, const float* radii, const float* Wd0,
                                                     const float* bd0, float* heads, int ldh, float* z, int ldz,
                                                     float* z_user, float* kl, float* kl_user, float* hd, int B, int H,
                                                     int NH, int Z) {
-  __shared__ float red[4][16][17];
-  __shared__ float heads_s[kRows][kHeadsMax];
-  __shared__ float z_s[kRows][kHeadsMax];
-  const int tid = threadIdx.x, m0 = blockIdx.x * kRows;
-  const int wave = tid >> 6;
-  const bool vh = aligned16(h) && (H & 3) == 0, vw = aligned16(Wh) && (H & 3) == 0;
-  // heads tile(s): [16 rows] x [NH] = h W_heads^T + b
-  for (int nt = 0; nt * 16 < NH; ++nt) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_nt(h, H, B, m0, Wh, H, NH, nt * 16, H, wave, 4, vh, vw, acc);
-    float s = reduce_tiles(red, acc);
-    const int r = tid >> 4, n = nt * 16 + (tid & 15);
-    if (n < NH) {
-      float v = s + bh[n];
-      heads_s[r][n] = v;
-      if (m0 + r < B) heads[(size_t)(m0 + r) * ldh + n] = v;
-    }
-  }
-  __syncthreads();
-  // latent components: one thread per (row, component)
-  for (int it = tid; it < kRows * t.n; it += 256) {
-    const int r = it % kRows, ci = it / kRows;
-    if (m0 + r < B) {
-      const size_t row = m0 + r;
-      float klv;
-      comp_fwd_row<DMAX>(t.c[ci], heads_s[r], eps + row * eps_ld, radii, z_s[r], z + row * ldz, &klv, nullptr, nullptr,
-                         nullptr, nullptr);
-      kl[(size_t)ci * B + row] = klv;
-      if (kl_user) kl_user[(size_t)ci * B + row] = klv;
-      if (z_user) {
-        const mvae_component_desc& c = t.c[ci];
-        const int A = ambient_dim(c.kind, c.true_dim);
-        for (int i = 0; i < A; ++i) z_user[row * Z + c.z_col + i] = z_s[r][c.z_col + i];
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] the row of h, then [eps_dim] the row of eps
+  __shared__ __attribute__((aligned(16))) float heads_s[kHeadsMax];
+  __shared__ __attribute__((aligned(16))) float z_s[kHeadsMax];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const size_t row = blockIdx.x;
+  float* h_s = dyn;
+  float* eps_s = dyn + ((H + 3) & ~3);
+  const bool vec = aligned16(Wh) && (H & 3) == 0;
+
+  // ---- request everything
+  float hv[2] = {0.f, 0.f};
+  float4 wf[4][2];
+  float wd[2][8], bd[2] = {0.f, 0.f};
+  float bhv = 0.f;
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + 256 * u < H) hv[u] = h[row * H + tid + 256 * u];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = wave + 4 * q;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = lane * 4 + 256 * u;
+        wf[q][u] = (n < NH && k < H) ? *reinterpret_cast<const float4*>(Wh + (size_t)n * H + k)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        bd[u] = bd0[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wd[u][j] = (j < Z) ? Wd0[(size_t)c * Z + j] : 0.f;
+      }
+    }
+    if (tid < NH) bhv = bh[tid];
+  }
+  if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
+  for (int k = tid + (FAST ? 512 : 0); k < H; k += 256) h_s[k] = h[row * H + k];
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + 256 * u < H) h_s[tid + 256 * u] = hv[u];
   }
   __syncthreads();
-  // first decoder layer: hd = relu(z W_d0^T + b)   (K = Z is tiny: plain FMAs, one output per thread-iteration)
-  for (int idx = tid; idx < kRows * H; idx += 256) {
-    const int r = idx / H, c = idx - r * H;
-    if (m0 + r < B) {
+
+  // ---- heads = h W_heads^T + b
+  if (FAST) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = wave + 4 * q;
+      if (n < NH) {  // wave-uniform
+        float p = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = lane * 4 + 256 * u;
+          if (k < H) {
+            const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
+            p = fmaf(xv.x, wf[q][u].x, p);
+            p = fmaf(xv.y, wf[q][u].y, p);
+            p = fmaf(xv.z, wf[q][u].z, p);
+            p = fmaf(xv.w, wf[q][u].w, p);
+          }
+        }
+        p = wave_sum(p);
+        if (lane == 0) heads_s[n] = p;
+      }
+    }
+    __syncthreads();
+    if (tid < NH) {
+      const float v = heads_s[tid] + bhv;
+      heads[row * ldh + tid] = v;
+      heads_s[tid] = v;  // same thread wrote nothing else here; published by the barrier below
+    }
+  } else {
+#pragma unroll 4
+    for (int n = wave; n < NH; n += 4) {
+      float p = 0.f;
+      if (vec) {
+        for (int k = lane * 4; k < H; k += 256) {
+          const float4 wv = *reinterpret_cast<const float4*>(Wh + (size_t)n * H + k);
+          const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
+          p = fmaf(xv.x, wv.x, p);
+          p = fmaf(xv.y, wv.y, p);
+          p = fmaf(xv.z, wv.z, p);
+          p = fmaf(xv.w, wv.w, p);
+        }
+      } else {
+        for (int k = lane; k < H; k += 64) p = fmaf(h_s[k], Wh[(size_t)n * H + k], p);
+      }
+      p = wave_sum(p);
+      if (lane == 0) heads_s[n] = p + bh[n];
+    }
+    __syncthreads();
+    if (tid < NH) heads[row * ldh + tid] = heads_s[tid];
+  }
+  __syncthreads();
+
+  // ---- latent components: component ci runs on wave ci&3, lane ci>>2 (different manifolds land on different waves)
+  {
+    const int ci = lane * 4 + wave;
+    if (ci < t.n) {
+      float klv;
+      comp_fwd_row<DMAX>(t.c[ci], heads_s, eps_s, radii, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr, nullptr);
+      kl[(size_t)ci * B + row] = klv;
+      if (kl_user) kl_user[(size_t)ci * B + row] = klv;
+    }
+  }
+  __syncthreads();
+  if (z_user && tid < Z) z_user[row * Z + tid] = z_s[tid];
+
+  // ---- first decoder layer: hd = relu(z W_d0^T + b)   (K = Z is tiny)
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < Z) acc = fmaf(z_s[j], wd[u][j], acc);
+        acc += bd[u];
+        hd[row * H + c] = acc > 0.f ? acc : 0.f;
+      }
+    }
+  } else {
+    for (int c = tid; c < H; c += 256) {
       const float* w = Wd0 + (size_t)c * Z;
       float acc = 0.f;
-      for (int j = 0; j < Z; ++j) acc = fmaf(z_s[r][j], w[j], acc);
+      for (int j = 0; j < Z; ++j) acc = fmaf(z_s[j], w[j], acc);
       acc += bd0[c];
-      hd[(size_t)(m0 + r) * H + c] = acc > 0.f ? acc : 0.f;
+      hd[row * H + c] = acc > 0.f ? acc : 0.f;
     }
   }
 }
 
-// ---- 3: output layer + BCE-with-logits + its gradient
-__global__ __launch_bounds__(256) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
+// ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
+__global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
                                                   float* g, float* bce_part, float* logits_user, int B, int H, int D) {
-  __shared__ float red[4][16][17];
+  __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
   const int mt = blockIdx.y, nt = blockIdx.x;
+  const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
+  const bool ok = threadIdx.x < 256 && m < B && n < D;
+  float t = 0.f, bias = 0.f;
+  if (ok) {  // epilogue operands requested up front
+    t = x[(size_t)m * D + n];
+    bias = b[n];
+  }
   const bool v1 = aligned16(hd) && (H & 3) == 0, v2 = aligned16(W) && (H & 3) == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_nt(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, 4, v1, v2, acc);
-  float s = reduce_tiles(red, acc);
-  const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+  acc = tile_nt<4>(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, kW8, v1, v2, acc);
+  const float s = reduce_tiles8(red, acc);
+  if (threadIdx.x >= 256) return;
   float loss = 0.f;
-  if (m < B && n < D) {
-    const float y = s + b[n];
-    const float t = x[(size_t)m * D + n];
+  if (ok) {
+    const float y = s + bias;
     // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
     const float e = expf(-fabsf(y));
     const float log_sig = fminf(y, 0.f) - log1pf(e);
@@ -711,35 +991,49 @@ __global__ __launch_bounds__(256) void k_dec1_fwd(const float* hd, const float* 
   if ((threadIdx.x & 15) == 0 && m < B) bce_part[(size_t)nt * B + m] = loss;
 }
 
-// ---- 4: backward of the output layer + statistics
-__global__ __launch_bounds__(256) void k_dec1_bwd(const float* g, const float* hd, const float* W, float* dW, float* db,
+// ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
+template <bool ADAM>
+__global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
-                                                  int n_dw, int n_db) {
-  __shared__ float red[4][16][17];
+                                                  int n_db, AdamArgs ab) {
+  __shared__ float red[kW8][16][17];
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
-  if (b < n_dhd) {  // dhd = (g W) * [hd > 0]
-    job_nn(red, g, D, B, b / ntH, W, H, H, b % ntH, D, hd, H, dhd, H);
+  if (b < n_dhd) {
+    const int mt = b / ntH, nt = b % ntH;
+    const int wave = threadIdx.x >> 6;
+    const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
+    const bool ok = threadIdx.x < 256 && m < B && n < H;
+    float mask = 0.f;
+    if (ok) mask = hd[(size_t)m * H + n];
+    const bool vg = aligned16(g) && (D & 3) == 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_nn<7>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
+    const float s = reduce_tiles8(red, acc);
+    if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
     return;
   }
   b -= n_dhd;
-  if (b < n_dw) {  // dW_logits[D,H] = g^T hd
-    job_tn(red, g, D, D, b / ntH, hd, H, H, b % ntH, B, dW, H);
-    return;
-  }
-  b -= n_dw;
   if (b < n_db) {
-    job_colsum(&red[0][0][0], g, D, B, D, b * 64, db);
+    job_colsum_opt<ADAM>(&red[0][0][0], g, D, B, D, b * kColsPerBlock, db, ab);
     return;
   }
   // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo
-  float* sm = &red[0][0][0];  // >= 256 floats
-  const int tid = threadIdx.x;
+  float* sm = &red[0][0][0];  // >= 512 floats
+  const int tid = threadIdx.x, nthr = blockDim.x;
   float bce_acc = 0.f, elbo_acc = 0.f;
-  for (int r = tid; r < B; r += 256) {
+  for (int r = tid; r < B; r += nthr) {
     float bce = 0.f;
-    for (int nt = 0; nt < ntD; ++nt) bce += bce_part[(size_t)nt * B + r];
+    int nt = 0;
+    for (; nt + 7 < ntD; nt += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = bce_part[(size_t)(nt + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bce += v[u];
+    }
+    for (; nt < ntD; ++nt) bce += bce_part[(size_t)nt * B + r];
     if (bce_user) bce_user[r] = bce;
     float klr = 0.f;
     for (int i = 0; i < ncomp; ++i) klr = (i == 0) ? kl[r] : klr + kl[(size_t)i * B + r];
@@ -749,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_dec1_bwd(const float* g, const float* h
   auto block_sum = [&](float v) -> float {
     sm[tid] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = nthr >> 1; s > 0; s >>= 1) {
       if (tid < s) sm[tid] += sm[tid + s];
       __syncthreads();
     }
@@ -763,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_dec1_bwd(const float* g, const float* h
   const int last = 4 + ncomp;
   for (int i = 0; i < ncomp; ++i) {
     float a = 0.f;
-    for (int r = tid; r < B; r += 256) a += kl[(size_t)i * B + r];
+    for (int r = tid; r < B; r += nthr) a += kl[(size_t)i * B + r];
     const float s = block_sum(a);
     kl_total += s;
     if (tid == 0) {
@@ -783,148 +1077,207 @@ __global__ __launch_bounds__(256) void k_dec1_bwd(const float* g, const float* h
   }
 }
 
-// ---- 5: backward through the first decoder layer, the latent components and the heads
-template <int DMAX>
+// ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
+// workgroup) ; dW_logits = g^T hd (+Adam: W_logits was last read by launch 4)
+template <int DMAX, bool FAST, bool ADAM>
 __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, const float* heads,
                                                     int ldh, const float* eps, int eps_ld, const float* radii,
-                                                    const float* z, int ldz, const float* h, const float* Wh,
-                                                    float* dheads, float* dh, float* dWd0, float* dbd0, float* drpart,
-                                                    float beta, int B, int H, int NH, int Z, int n_rows, int n_dw) {
+                                                    const float* h, const float* Wh, float* dheads, float* dh,
+                                                    float* drpart, const float* g, const float* hd, float* dWl,
+                                                    float beta, int B, int H, int D, int NH, int Z, int n_rows,
+                                                    AdamArgs awl) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [256] partials | [NH] heads | [eps]
   __shared__ float red[4][16][17];
-  __shared__ float dz_s[kRows][kHeadsMax];
-  __shared__ float dheads_s[kRows][kHeadsMax];
-  __shared__ float dr_s[kMaxComp][kRows];
+  __shared__ float sh2[2];
+  __shared__ float dz_s[kHeadsMax];
+  __shared__ float dheads_s[kHeadsMax];
   int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  if (b >= n_rows) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
-    if (b < n_dw) {  // dW_d0[H,Z] = dhd^T z
-      const int ntZ = (Z + 15) / 16;
-      job_tn(red, dhd, H, H, b / ntZ, z, ldz, Z, b % ntZ, B, dWd0, Z);
-      return;
-    }
-    b -= n_dw;
-    job_colsum(&red[0][0][0], dhd, H, B, H, b * 64, dbd0);
+    const int ntH = (H + 15) / 16;
+    job_tn_opt<ADAM>(red, sh2, g, D, D, b / ntH, hd, H, H, b % ntH, B, dWl, H, awl);
     return;
   }
-  const int m0 = b * kRows, wave = tid >> 6;
-  const bool vg = aligned16(dhd) && (H & 3) == 0;
-  // dz tile(s) = dhd[16 rows] W_d0
-  for (int nt = 0; nt * 16 < Z; ++nt) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_nn(dhd, H, B, m0, Wd0, Z, Z, nt * 16, H, wave, 4, vg, acc);
-    float s = reduce_tiles(red, acc);
-    const int r = tid >> 4, n = nt * 16 + (tid & 15);
-    if (n < Z) dz_s[r][n] = s;
+  const size_t row = b;
+  const int H4 = (H + 3) & ~3;
+  float* dhd_s = dyn;
+  float* part = dyn + H4;
+  float* heads_s = part + 256;
+  float* eps_s = heads_s + ((NH + 3) & ~3);
+
+  // ---- request everything
+  int ZP = 1;
+  while (ZP < Z) ZP <<= 1;
+  const int nsl = 256 / ZP;
+  const int zj = tid % ZP, sl = tid / ZP;
+  float wz[16];   // FAST: this thread's W_d0 column slice (H/nsl <= 16 entries)
+  float wh[2][16];  // FAST: W_heads[:, c] for the two columns c of this thread
+  float hm[2] = {0.f, 0.f};
+  if (FAST) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = sl + q * nsl;
+      wz[q] = (zj < Z && c < H) ? Wd0[(size_t)c * Z + zj] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        hm[u] = h[row * H + c];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) wh[u][n] = (n < NH) ? Wh[(size_t)n * H + c] : 0.f;
+      }
+    }
   }
-  for (int i = tid; i < kMaxComp * kRows; i += 256) (&dr_s[0][0])[i] = 0.f;
+  for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
+  if (tid < NH) heads_s[tid] = heads[row * ldh + tid];
+  if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
   __syncthreads();
-  // component backward: one thread per (row, component, input direction)
-  for (int it = tid; it < kRows * t.total_dirs; it += 256) {
-    const int r = it % kRows, gd = it / kRows;
-    if (m0 + r >= B) continue;
-    int ci = 0;
-    while (gd >= t.dir_off[ci + 1]) ++ci;
-    const int dir = gd - t.dir_off[ci];
+
+  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c, slices meet in LDS
+  {
+    float p = 0.f;
+    if (FAST) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int c = sl + q * nsl;
+        if (c < H) p = fmaf(dhd_s[c], wz[q], p);
+      }
+    } else if (zj < Z) {
+      for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
+    }
+    part[tid] = p;
+    __syncthreads();
+    if (tid < Z) {
+      float sum = 0.f;
+      for (int q = 0; q < nsl; ++q) sum += part[q * ZP + tid];
+      dz_s[tid] = sum;
+    }
+    __syncthreads();
+  }
+  // ---- component backward: wave w takes components w, w+4, ...; lane = input direction (forward-mode duals)
+  for (int ci = wave; ci < t.n; ci += 4) {
     const mvae_component_desc& c = t.c[ci];
-    const size_t row = m0 + r;
-    float gv = comp_bwd_dir<DMAX>(c, heads + row * ldh, eps + row * eps_ld, radii, dz_s[r], beta, dir);
-    if (dir < c.true_dim) dheads_s[r][c.mean_col + dir] = gv;
-    else if (dir < c.true_dim + c.logvar_dim) dheads_s[r][c.logvar_col + (dir - c.true_dim)] = gv;
-    else dr_s[ci][r] = gv;
+    const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
+    for (int dir = lane; dir < ndir; dir += 64) {
+      const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, radii, dz_s, beta, dir);
+      if (dir < c.true_dim) dheads_s[c.mean_col + dir] = gv;
+      else if (dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (dir - c.true_dim)] = gv;
+      else drpart[(size_t)ci * B + row] = gv;
+    }
   }
   __syncthreads();
-  if (tid < t.n) {
-    float s = 0.f;
-    for (int r = 0; r < kRows; ++r) s += dr_s[tid][r];
-    drpart[(size_t)b * kMaxComp + tid] = s;
-  }
-  for (int idx = tid; idx < kRows * NH; idx += 256) {
-    const int r = idx / NH, n = idx - r * NH;
-    if (m0 + r < B) dheads[(size_t)(m0 + r) * ldh + n] = dheads_s[r][n];
-  }
-  // dh = (dheads W_heads) * [h > 0]   (K = NH is small: plain FMAs)
-  for (int idx = tid; idx < kRows * H; idx += 256) {
-    const int r = idx / H, c = idx - r * H;
-    if (m0 + r < B) {
+  if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
+  // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n)
+          if (n < NH) acc = fmaf(dheads_s[n], wh[u][n], acc);
+        dh[row * H + c] = (hm[u] > 0.f) ? acc : 0.f;
+      }
+    }
+  } else {
+    for (int c = tid; c < H; c += 256) {
       float acc = 0.f;
-      for (int n = 0; n < NH; ++n) acc = fmaf(dheads_s[r][n], Wh[(size_t)n * H + c], acc);
-      const size_t o = (size_t)(m0 + r) * H + c;
+      for (int n = 0; n < NH; ++n) acc = fmaf(dheads_s[n], Wh[(size_t)n * H + c], acc);
+      const size_t o = row * H + c;
       dh[o] = (h[o] > 0.f) ? acc : 0.f;
     }
   }
 }
 
-// ---- 6: encoder / heads weight gradients + radius gradients
+// ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
+template <bool ADAM>
 __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
-                                                 int ldh, const float* h, const float* drpart, float* dWe0,
-                                                 float* dbe0, float* dWh, float* dbh, float* dradii, int B, int H,
-                                                 int D, int NH, int n_we0, int n_wh, int n_be0, int n_bh, int nt_b) {
+                                                 int ldh, const float* h, const float* dhd, const float* z, int ldz,
+                                                 const float* drpart, float* G, float* P, int B, int H, int D, int NH,
+                                                 int Z, int n_we0, int n_wh, int n_wd0, int n_be0, int n_bh, int n_bd0,
+                                                 int64_t off_w_e0, int64_t off_b_e0, int64_t off_w_heads,
+                                                 int64_t off_b_heads, int64_t off_w_d0, int64_t off_b_d0, AdamArgs base,
+                                                 double curv_lr, int do_curv) {
   __shared__ float red[4][16][17];
+  __shared__ float sh2[2];
   int b = blockIdx.x;
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
   if (b < n_we0) {  // dW_e0[H,D] = dh^T x
     const int ntD = (D + 15) / 16;
-    job_tn(red, dh, H, H, b / ntD, x, D, D, b % ntD, B, dWe0, D);
+    job_tn_opt<ADAM>(red, sh2, dh, H, H, b / ntD, x, D, D, b % ntD, B, G + off_w_e0, D, at(off_w_e0));
     return;
   }
   b -= n_we0;
   if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
     const int ntH = (H + 15) / 16;
-    job_tn(red, dheads, ldh, NH, b / ntH, h, H, H, b % ntH, B, dWh, H);
+    job_tn_opt<ADAM>(red, sh2, dheads, ldh, NH, b / ntH, h, H, H, b % ntH, B, G + off_w_heads, H, at(off_w_heads));
     return;
   }
   b -= n_wh;
+  if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
+    const int ntZ = (Z + 15) / 16;
+    job_tn_opt<ADAM>(red, sh2, dhd, H, H, b / ntZ, z, ldz, Z, b % ntZ, B, G + off_w_d0, Z, at(off_w_d0));
+    return;
+  }
+  b -= n_wd0;
   if (b < n_be0) {
-    job_colsum(&red[0][0][0], dh, H, B, H, b * 64, dbe0);
+    job_colsum_opt<ADAM>(&red[0][0][0], dh, H, B, H, b * kColsPerBlock, G + off_b_e0, at(off_b_e0));
     return;
   }
   b -= n_be0;
   if (b < n_bh) {
-    job_colsum(&red[0][0][0], dheads, ldh, B, NH, b * 64, dbh);
+    job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, b * kColsPerBlock, G + off_b_heads, at(off_b_heads));
     return;
   }
-  // radius gradients: fixed-order sum of the per-workgroup partials of launch 5
-  const int tid = threadIdx.x;
-  if (tid < kRadiiRegion) {
+  b -= n_bh;
+  if (b < n_bd0) {
+    job_colsum_opt<ADAM>(&red[0][0][0], dhd, H, B, H, b * kColsPerBlock, G + off_b_d0, at(off_b_d0));
+    return;
+  }
+  // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
+  // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < kRadiiRegion) G[tid] = 0.f;
+  __syncthreads();
+  for (int ci = wave; ci < t.n; ci += 4) {
+    if (!t.trainable[ci]) continue;
     float s = 0.f;
-    if (tid < t.n && t.trainable[tid])
-      for (int w = 0; w < nt_b; ++w) s += drpart[(size_t)w * kMaxComp + tid];
-    // radius_idx == component index in the flat layout
-    dradii[tid] = s;
+    for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
+    s = wave_sum(s);
+    if (lane == 0) {
+      G[ci] = s;
+      if (ADAM && do_curv) P[ci] = P[ci] + (float)(-curv_lr) * s;
+    }
   }
 }
 
-// ---- 7: fused optimizer.  torch.optim.Adam (single-tensor CPU formulas, defaults betas=(0.9,0.999), eps=1e-8) over
-// every float of the flat buffer past the radii region; torch.optim.SGD(lr=curvature_lr) on trainable radii.
+// ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
 __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const float* g, float* m, float* v, int n4,
                                                int* counters, double lr, double curv_lr, int do_curv) {
   __shared__ float sh[2];
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    const int step = *(volatile int*)&counters[0] + 1;
-    const double bc1 = 1.0 - pow(0.9, (double)step);
-    const double bc2 = 1.0 - pow(0.999, (double)step);
-    sh[0] = (float)(-(lr / bc1));  // addcdiv_(exp_avg, denom, value=-step_size)
-    sh[1] = (float)sqrt(bc2);
-  }
+  adam_consts(sh, counters, lr, 1);
   __syncthreads();
   const float neg_step = sh[0], bc2s = sh[1];
-  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999);
   const int i4 = blockIdx.x * 256 + tid + kRadiiRegion / 4;
   if (i4 < n4) {
     float4 pp = reinterpret_cast<float4*>(p)[i4];
     const float4 gg = reinterpret_cast<const float4*>(g)[i4];
     float4 mm = reinterpret_cast<float4*>(m)[i4];
     float4 vv = reinterpret_cast<float4*>(v)[i4];
-#define ADAM1(P, G, M, V)                         \
-  M = M + w1 * (G - M);                           \
-  V = V * b2 + (w2 * G) * G;                      \
-  P = P + (neg_step * M) / (sqrtf(V) / bc2s + 1e-8f);
-    ADAM1(pp.x, gg.x, mm.x, vv.x)
-    ADAM1(pp.y, gg.y, mm.y, vv.y)
-    ADAM1(pp.z, gg.z, mm.z, vv.z)
-    ADAM1(pp.w, gg.w, mm.w, vv.w)
-#undef ADAM1
+    adam1(pp.x, gg.x, mm.x, vv.x, neg_step, bc2s);
+    adam1(pp.y, gg.y, mm.y, vv.y, neg_step, bc2s);
+    adam1(pp.z, gg.z, mm.z, vv.z, neg_step, bc2s);
+    adam1(pp.w, gg.w, mm.w, vv.w, neg_step, bc2s);
     reinterpret_cast<float4*>(p)[i4] = pp;
     reinterpret_cast<float4*>(m)[i4] = mm;
     reinterpret_cast<float4*>(v)[i4] = vv;
@@ -932,22 +1285,30 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const floa
   if (blockIdx.x == 0 && do_curv && tid < t.n && t.trainable[tid]) {
     p[tid] = p[tid] + (float)(-curv_lr) * g[tid];  // SGD: param.add_(grad, alpha=-lr)
   }
-  // the last workgroup to finish advances the step counter (every other workgroup has read it by then)
-  __syncthreads();
+  // The last workgroup to arrive advances the step counter.  Every other workgroup consumed counters[0] before its
+  // own arrival (the value fed the __syncthreads above), so no fence is needed: the plain stores below only have to
+  // be visible to the NEXT launch.  Arrivals are counted on 16 group words first (one hot word would serialise
+  // ~600 device-scope atomics at ~12 ns each), the group-completing workgroups then meet on counters[1].
   if (tid == 0) {
-    __threadfence();
-    const int done = atomicAdd(&counters[1], 1);
-    if (done == (int)gridDim.x - 1) {
-      counters[1] = 0;
-      counters[0] = counters[0] + 1;
-      __threadfence();
+    constexpr int NG = 16;
+    const int grp = blockIdx.x % NG;
+    const int gsize = ((int)gridDim.x - grp + NG - 1) / NG;
+    if (atomicAdd(&counters[4 + grp], 1) == gsize - 1) {
+      counters[4 + grp] = 0;
+      const int ngroups = (int)gridDim.x < NG ? (int)gridDim.x : NG;
+      if (atomicAdd(&counters[1], 1) == ngroups - 1) {
+        counters[1] = 0;
+        counters[0] = counters[0] + 1;
+      }
     }
   }
 }
 
-static int step_fwd_bwd_impl(mvae_ctx* c, const float* x, const float* eps, float beta, int want_outputs,
-                             float* logits, float* concat_z, float* bce, float* kl, void* stream, hipEvent_t* ev) {
-#define MARK() do { if (ev) hipEventRecord(*ev++, s); } while (0)
+// fused = single-GPU step (Adam/SGD in the gradient epilogues, no k_optim); otherwise gradients only.
+static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
+                     int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
+                     hipEvent_t* ev) {
+#define MARK() do { if (ev) (void)hipEventRecord(*ev++, s); } while (0)
   if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const mvae_model_desc& d = c->d;
   const int B = d.batch, H = d.h_dim, D = d.in_dim, NH = d.heads_dim, Z = d.z_dim;
@@ -956,51 +1317,88 @@ static int step_fwd_bwd_impl(mvae_ctx* c, const float* x, const float* eps, floa
   float *h = ws + c->o_h, *heads = ws + c->o_heads, *z = ws + c->o_z, *hd = ws + c->o_hd, *g = ws + c->o_g,
         *bce_part = ws + c->o_bce_part, *klw = ws + c->o_kl, *dhd = ws + c->o_dhd, *dheads = ws + c->o_dheads,
         *dh = ws + c->o_dh, *drpart = ws + c->o_drpart;
-  const float* P = d.params;
+  float* P = d.params;
   float* G = d.grads;
   if (!want_outputs) logits = concat_z = bce = kl = nullptr;
+  const AdamArgs base = {d.params, d.adam_m, d.adam_v, d.step_count, d.lr};
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
+  // register-resident fast paths of the latent kernels (the BASELINE MLP configs with few components qualify)
+  const bool fast = NH <= 16 && Z <= 8 && H <= 512 && (H & 3) == 0 && aligned16(P + d.off_w_heads);
+  int zp = 1;
+  while (zp < Z) zp <<= 1;
+  const bool fast_b = fast && (H + 256 / zp - 1) / (256 / zp) <= 16;
 
-  hipLaunchKernelGGL(k_enc_fwd, dim3(c->nt_h, c->nt_b), dim3(256), 0, s, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D);
+  hipLaunchKernelGGL(k_enc_fwd, dim3(c->nt_h, c->nt_b), dim3(512), 0, s, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
+                     d.step_count, fused ? 1 : 0);
   MARK();
-  DMAX_SWITCH(c->dmax, hipLaunchKernelGGL((k_latent_fwd<DM>), dim3(c->nt_b), dim3(256), 0, s, c->t, h,
-                                          P + d.off_w_heads, P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii,
-                                          P + d.off_w_d0, P + d.off_b_d0, heads, c->ldh, z, c->ldz, concat_z, klw, kl,
-                                          hd, B, H, NH, Z));
+  {
+    const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
+#define LF(DM, FA)                                                                                                   \
+  hipLaunchKernelGGL((k_latent_fwd<DM, FA>), dim3(B), dim3(256), lds, s, c->t, h, P + d.off_w_heads,                 \
+                     P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
+                     c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z)
+    if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
+#undef LF
+  }
   MARK();
-  hipLaunchKernelGGL(k_dec1_fwd, dim3(c->nt_d, c->nt_b), dim3(256), 0, s, hd, P + d.off_w_logits, P + d.off_b_logits,
+  hipLaunchKernelGGL(k_dec1_fwd, dim3(c->nt_d, c->nt_b), dim3(512), 0, s, hd, P + d.off_w_logits, P + d.off_b_logits,
                      x, g, bce_part, logits, B, H, D);
   MARK();
   {
-    const int n_dhd = c->nt_b * c->nt_h, n_dw = c->nt_d * c->nt_h, n_db = (D + 63) / 64;
-    hipLaunchKernelGGL(k_dec1_bwd, dim3(n_dhd + n_dw + n_db + 1), dim3(256), 0, s, g, hd, P + d.off_w_logits,
-                       G + d.off_w_logits, G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D,
-                       d.ncomp, n_dhd, n_dw, n_db);
-    MARK();
+    const int n_dhd = c->nt_b * c->nt_h, n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
+    if (fused)
+      hipLaunchKernelGGL(k_dec1_bwd<true>, dim3(n_dhd + n_db + 1), dim3(512), 0, s, g, hd, P + d.off_w_logits,
+                         G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
+                         at(d.off_b_logits));
+    else
+      hipLaunchKernelGGL(k_dec1_bwd<false>, dim3(n_dhd + n_db + 1), dim3(512), 0, s, g, hd, P + d.off_w_logits,
+                         G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
+                         at(d.off_b_logits));
   }
+  MARK();
   {
-    const int n_dw = c->nt_h * ((Z + 15) / 16), n_db = (H + 63) / 64;
-    DMAX_SWITCH(c->dmax, hipLaunchKernelGGL((k_latent_bwd<DM>), dim3(c->nt_b + n_dw + n_db), dim3(256), 0, s, c->t,
-                                            dhd, P + d.off_w_d0, heads, c->ldh, eps, d.eps_dim, P + d.off_radii, z,
-                                            c->ldz, h, P + d.off_w_heads, dheads, dh, G + d.off_w_d0, G + d.off_b_d0,
-                                            drpart, beta, B, H, NH, Z, c->nt_b, n_dw));
-    MARK();
+    const int n_dwl = c->nt_d * c->nt_h;
+    const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 256 + (((size_t)NH + 3) & ~(size_t)3) + d.eps_dim + 4) *
+                       sizeof(float);
+#define LB(DM, FA, AD)                                                                                              \
+  hipLaunchKernelGGL((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, s, c->t, dhd, P + d.off_w_d0,      \
+                     heads, c->ldh, eps, d.eps_dim, P + d.off_radii, h, P + d.off_w_heads, dheads, dh, drpart, g,   \
+                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits))
+    if (fast_b) {
+      if (fused) { DMAX_SWITCH(c->dmax, LB(DM, true, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, true, false)); }
+    } else {
+      if (fused) { DMAX_SWITCH(c->dmax, LB(DM, false, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, false, false)); }
+    }
+#undef LB
   }
+  MARK();
   {
-    const int n_we0 = c->nt_h * c->nt_d, n_wh = ((NH + 15) / 16) * c->nt_h, n_be0 = (H + 63) / 64,
-              n_bh = (NH + 63) / 64;
-    hipLaunchKernelGGL(k_enc_bwd, dim3(n_we0 + n_wh + n_be0 + n_bh + 1), dim3(256), 0, s, c->t, dh, x, dheads, c->ldh,
-                       h, drpart, G + d.off_w_e0, G + d.off_b_e0, G + d.off_w_heads, G + d.off_b_heads,
-                       G + d.off_radii, B, H, D, NH, n_we0, n_wh, n_be0, n_bh, c->nt_b);
-    MARK();
+    const int n_we0 = c->nt_h * c->nt_d, n_wh = ((NH + 15) / 16) * c->nt_h, n_wd0 = c->nt_h * ((Z + 15) / 16);
+    const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
+              n_bd0 = n_be0;
+    const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
+#define EB(AD)                                                                                                       \
+  hipLaunchKernelGGL(k_enc_bwd<AD>, dim3(grid), dim3(256), 0, s, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
+                     drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
+                     d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+    if (fused) EB(true); else EB(false);
+#undef EB
   }
+  MARK();
 #undef MARK
-  LAUNCH_CHECK("step forward/backward launch");
+  LAUNCH_CHECK("step launch");
   return 0;
 }
 
 extern "C" int mvae_step_forward_backward(mvae_ctx* c, const float* x, const float* eps, float beta, int want_outputs,
                                           float* logits, float* concat_z, float* bce, float* kl, void* stream) {
-  return step_fwd_bwd_impl(c, x, eps, beta, want_outputs, logits, concat_z, bce, kl, stream, nullptr);
+  return step_impl(c, x, eps, beta, false, 0, want_outputs, logits, concat_z, bce, kl, stream, nullptr);
 }
 
 extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* stream) {
@@ -1016,9 +1414,7 @@ extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* str
 
 extern "C" int mvae_train_step(mvae_ctx* c, const float* x, const float* eps, float beta, int do_curvature_step,
                                void* stream) {
-  int rc = mvae_step_forward_backward(c, x, eps, beta, 0, nullptr, nullptr, nullptr, nullptr, stream);
-  if (rc) return rc;
-  return mvae_step_optimizer(c, do_curvature_step, stream);
+  return step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
 }
 
 extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, float beta, int do_curvature_step,
@@ -1034,20 +1430,18 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
   double acc[NK] = {0};
   int rc = 0;
   for (int it = 0; it < iters && rc == 0; ++it) {
-    hipEventRecord(ev[0], s);
-    rc = step_fwd_bwd_impl(c, x, eps, beta, 0, nullptr, nullptr, nullptr, nullptr, stream, &ev[1]);
+    (void)hipEventRecord(ev[0], s);
+    rc = step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, &ev[1]);
     if (rc) break;
-    rc = mvae_step_optimizer(c, do_curvature_step, stream);
-    hipEventRecord(ev[NK], s);
     hipError_t e = hipEventSynchronize(ev[NK]);
     if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
     for (int k = 0; k < NK; ++k) {
       float ms = 0.f;
-      hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
       acc[k] += ms;
     }
   }
-  for (auto& e : ev) hipEventDestroy(e);
+  for (auto& e : ev) (void)hipEventDestroy(e);
   if (rc) return rc;
   for (int k = 0; k < NK; ++k) ms_out[k] = (float)(acc[k] / iters);
   return 0;

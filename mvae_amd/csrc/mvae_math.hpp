@@ -17,6 +17,14 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// Small-vector loops: arrays are sized by a compile-time bound and every loop is written over that bound with a
+// runtime guard, fully unrolled for bounds <= 9 so that all indices are compile-time constants and the vectors live in
+// VGPRs (a runtime-indexed array would be placed in scratch memory).
+#define MV_BOUNDS(NMAX)        \
+  constexpr int kN = (NMAX);   \
+  constexpr int kU = ((NMAX) <= 9 ? (NMAX) : 1)
+#define MV_FOR(i, from, n) _Pragma("unroll (kU)") for (int i = (from); i < kN; ++i) if (i < (n))
+
 namespace mv {
 
 constexpr float kEps = 1e-8f;                      // common.py:21
@@ -165,15 +173,17 @@ template <typename T> __device__ __forceinline__ T g_logcosh(T x) {  // common.p
 template <typename T> __device__ __forceinline__ T radius_of(T p) { return hard_clamp(t_relu(p), 1e-8f, 1e8f); }
 
 // torch.norm(p=2) over n entries, derivative 0 at the origin
-template <typename T> __device__ __forceinline__ T norm2(const T* x, int n) {
-  T s = x[0] * x[0];
-  for (int i = 1; i < n; ++i) s = s + x[i] * x[i];
-  return t_sqrt(s);
+template <int NMAX> __device__ __forceinline__ float norm2(const float* x, int n) {
+  MV_BOUNDS(NMAX);
+  float s = x[0] * x[0];
+  MV_FOR(i, 1, n) s = s + x[i] * x[i];
+  return sqrtf(s);
 }
-template <> __device__ __forceinline__ Dual norm2<Dual>(const Dual* x, int n) {
+template <int NMAX> __device__ __forceinline__ Dual norm2(const Dual* x, int n) {
+  MV_BOUNDS(NMAX);
   float s = x[0].v * x[0].v;
   float sd = x[0].v * x[0].d;
-  for (int i = 1; i < n; ++i) {
+  MV_FOR(i, 1, n) {
     s = s + x[i].v * x[i].v;
     sd += x[i].v * x[i].d;
   }
@@ -182,15 +192,17 @@ template <> __device__ __forceinline__ Dual norm2<Dual>(const Dual* x, int n) {
 }
 
 // <x,y>_L  (hyperbolics.py:72-78): sum of all products, minus twice the first
-template <typename T> __device__ __forceinline__ T lorentz_product(const T* x, const T* y, int A) {
+template <int NMAX, typename T> __device__ __forceinline__ T lorentz_product(const T* x, const T* y, int A) {
+  MV_BOUNDS(NMAX);
   T m0 = x[0] * y[0];
   T s = m0;
-  for (int i = 1; i < A; ++i) s = s + x[i] * y[i];
+  MV_FOR(i, 1, A) s = s + x[i] * y[i];
   return s - 2.0f * m0;
 }
-template <typename T> __device__ __forceinline__ T dot(const T* x, const T* y, int A) {
+template <int NMAX, typename T> __device__ __forceinline__ T dot(const T* x, const T* y, int A) {
+  MV_BOUNDS(NMAX);
   T s = x[0] * y[0];
-  for (int i = 1; i < A; ++i) s = s + x[i] * y[i];
+  MV_FOR(i, 1, A) s = s + x[i] * y[i];
   return s;
 }
 
@@ -207,20 +219,23 @@ __host__ __device__ inline int ambient_dim(int kind, int d) {
   return (kind == kHyperboloid || kind == kSphere) ? d + 1 : d;
 }
 
+// All functions below take AMAX = compile-time bound on the AMBIENT dimension of their vector arguments.
+
 // ---- exp_map_mu0 on the true-dim tangent vector x[d] -> mu[A]
-template <int KIND, typename T> __device__ __forceinline__ void exp_map_mu0(const T* x, int d, T R, T* mu) {
+template <int KIND, int AMAX, typename T> __device__ __forceinline__ void exp_map_mu0(const T* x, int d, T R, T* mu) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < d; ++i) mu[i] = x[i] / 2.0f;  // euclidean.py:78-79
+    MV_FOR(i, 0, d) mu[i] = x[i] / 2.0f;  // euclidean.py:78-79
   } else if constexpr (KIND == kPoincare) {
     // poincare.py:132-137 -> geoopt 0.1.0 expmap0 (PARITY UNPINNED, see oracle/__init__.py)
     T c = 1.0f / (R * R);
     T sc = t_sqrt(c);
-    T n = hard_clamp(norm2(x, d), 1e-15f, INFINITY);
+    T n = hard_clamp(norm2<AMAX>(x, d), 1e-15f, INFINITY);
     T t = t_tanh(hard_clamp(sc * n, -15.0f, 15.0f));
-    for (int i = 0; i < d; ++i) mu[i] = t * x[i] / (sc * n);
+    MV_FOR(i, 0, d) mu[i] = t * x[i] / (sc * n);
   } else {
     // hyperbolics.py:114-121 | spherical.py:94-101
-    T n = norm2(x, d);
+    T n = norm2<AMAX>(x, d);
     T xn = n / R;
     T nc = hard_clamp(n, 1e-12f, INFINITY);  // F.normalize(eps=1e-12)
     T c, s;
@@ -232,58 +247,63 @@ template <int KIND, typename T> __device__ __forceinline__ void exp_map_mu0(cons
       s = t_sin(xn);
     }
     mu[0] = c * R;
-    for (int i = 0; i < d; ++i) mu[i + 1] = s * ((x[i] / nc) * R);
+    MV_FOR(i, 1, d + 1) mu[i] = s * ((x[i - 1] / nc) * R);
   }
 }
 
 // ---- parallel_transport_mu0(x, dst) on ambient vectors
-template <int KIND, typename T> __device__ __forceinline__ void pt_mu0(const T* x, const T* dst, int A, T R, T* out) {
+template <int KIND, int AMAX, typename T>
+__device__ __forceinline__ void pt_mu0(const T* x, const T* dst, int A, T R, T* out) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < A; ++i) out[i] = x[i];
+    MV_FOR(i, 0, A) out[i] = x[i];
   } else if constexpr (KIND == kPoincare) {
     T c = 1.0f / (R * R);  // geoopt parallel_transport0: v * clamp_min(1 - c|y|^2, MIN_NORM)
-    T f = hard_clamp(1.0f - c * dot(dst, dst, A), 1e-15f, INFINITY);
-    for (int i = 0; i < A; ++i) out[i] = x[i] * f;
+    T f = hard_clamp(1.0f - c * dot<AMAX>(dst, dst, A), 1e-15f, INFINITY);
+    MV_FOR(i, 0, A) out[i] = x[i] * f;
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:87-93
-    T coef = lorentz_product(dst, x, A) / (R * (R + dst[0]));
+    T coef = lorentz_product<AMAX>(dst, x, A) / (R * (R + dst[0]));
     out[0] = x[0] + coef * (dst[0] + R);
-    for (int i = 1; i < A; ++i) out[i] = x[i] + coef * dst[i];
+    MV_FOR(i, 1, A) out[i] = x[i] + coef * dst[i];
   } else {  // spherical.py:74-77
-    T coef = dot(dst, x, A) / (R * (R + dst[0]));
+    T coef = dot<AMAX>(dst, x, A) / (R * (R + dst[0]));
     out[0] = x[0] - coef * (dst[0] + R);
-    for (int i = 1; i < A; ++i) out[i] = x[i] - coef * dst[i];
+    MV_FOR(i, 1, A) out[i] = x[i] - coef * dst[i];
   }
 }
 
-template <int KIND, typename T>
+template <int KIND, int AMAX, typename T>
 __device__ __forceinline__ void inv_pt_mu0(const T* x, const T* src, int A, T R, T* out) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < A; ++i) out[i] = x[i];
+    MV_FOR(i, 0, A) out[i] = x[i];
   } else if constexpr (KIND == kPoincare) {
     T c = 1.0f / (R * R);
-    T f = hard_clamp(1.0f - c * dot(src, src, A), 1e-15f, INFINITY);
-    for (int i = 0; i < A; ++i) out[i] = x[i] / f;
+    T f = hard_clamp(1.0f - c * dot<AMAX>(src, src, A), 1e-15f, INFINITY);
+    MV_FOR(i, 0, A) out[i] = x[i] / f;
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:96-103
     T coef = (-x[0]) / (R + src[0]);
     out[0] = x[0] + coef * (src[0] + R);
-    for (int i = 1; i < A; ++i) out[i] = x[i] + coef * src[i];
+    MV_FOR(i, 1, A) out[i] = x[i] + coef * src[i];
   } else {  // spherical.py:80-83
     T coef = x[0] / (R + src[0]);
     out[0] = x[0] - coef * (src[0] + R);
-    for (int i = 1; i < A; ++i) out[i] = x[i] - coef * src[i];
+    MV_FOR(i, 1, A) out[i] = x[i] - coef * src[i];
   }
 }
 
 // ---- Poincare helpers (geoopt 0.1.0 as best known; PARITY UNPINNED)
-template <typename T> __device__ __forceinline__ T p_lambda(const T* x, int A, T c) {
-  return 2.0f / (1.0f - c * dot(x, x, A));
+template <int AMAX, typename T> __device__ __forceinline__ T p_lambda(const T* x, int A, T c) {
+  return 2.0f / (1.0f - c * dot<AMAX>(x, x, A));
 }
-template <typename T> __device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c, T* out) {
-  T x2 = dot(x, x, A), y2 = dot(y, y, A), xy = dot(x, y, A);
+template <int AMAX, typename T>
+__device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c, T* out) {
+  MV_BOUNDS(AMAX);
+  T x2 = dot<AMAX>(x, x, A), y2 = dot<AMAX>(y, y, A), xy = dot<AMAX>(x, y, A);
   T fa = 1.0f + 2.0f * c * xy + c * y2;
   T fb = 1.0f - c * x2;
   T den = (1.0f + 2.0f * c * xy + c * c * x2 * y2) + 1e-5f;
-  for (int i = 0; i < A; ++i) out[i] = (fa * x[i] + fb * y[i]) / den;
+  MV_FOR(i, 0, A) out[i] = (fa * x[i] + fb * y[i]) / den;
 }
 __device__ __forceinline__ float p_artanh(float x) {
   float xc = fminf(fmaxf(x, -1.0f + 1e-5f), 1.0f - 1e-5f);
@@ -297,100 +317,104 @@ __device__ __forceinline__ Dual p_artanh(Dual x) {
 // ---- exp_map(u, at) / inverse_exp_map(z, at) on ambient vectors
 template <int KIND, int AMAX, typename T>
 __device__ __forceinline__ void exp_map(const T* u, const T* at, int A, T R, T* z) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < A; ++i) z[i] = at[i] + u[i] / 2.0f;  // euclidean.py:74-75
+    MV_FOR(i, 0, A) z[i] = at[i] + u[i] / 2.0f;  // euclidean.py:74-75
   } else if constexpr (KIND == kPoincare) {  // poincare.py:124-129 -> geoopt expmap
     T c = 1.0f / (R * R);
     T sc = t_sqrt(c);
-    T n = hard_clamp(norm2(u, A), 1e-15f, INFINITY);
-    T t = t_tanh(hard_clamp(sc / 2.0f * p_lambda(at, A, c) * n, -15.0f, 15.0f));
+    T n = hard_clamp(norm2<AMAX>(u, A), 1e-15f, INFINITY);
+    T t = t_tanh(hard_clamp(sc / 2.0f * p_lambda<AMAX>(at, A, c) * n, -15.0f, 15.0f));
     T second[AMAX];
-    for (int i = 0; i < A; ++i) second[i] = t * u[i] / (sc * n);
-    p_mobius_add(at, second, A, c, z);
+    MV_FOR(i, 0, A) second[i] = t * u[i] / (sc * n);
+    p_mobius_add<AMAX>(at, second, A, c, z);
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:106-111
-    T n = g_sqrt(lorentz_product(u, u, A)) / R;
+    T n = g_sqrt(lorentz_product<AMAX>(u, u, A)) / R;
     T c = g_cosh(n), s = g_sinh(n);
-    for (int i = 0; i < A; ++i) z[i] = c * at[i] + s * (u[i] / n);
+    MV_FOR(i, 0, A) z[i] = c * at[i] + s * (u[i] / n);
   } else {  // spherical.py:86-91
-    T n = norm2(u, A) / R;
+    T n = norm2<AMAX>(u, A) / R;
     T c = t_cos(n), s = t_sin(n);
-    for (int i = 0; i < A; ++i) z[i] = c * at[i] + s * (u[i] / n);
+    MV_FOR(i, 0, A) z[i] = c * at[i] + s * (u[i] / n);
   }
 }
 
 template <int KIND, int AMAX, typename T>
 __device__ __forceinline__ void log_map(const T* z, const T* at, int A, T R, T* u) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < A; ++i) u[i] = 2.0f * (z[i] - at[i]);  // euclidean.py:82-83
+    MV_FOR(i, 0, A) u[i] = 2.0f * (z[i] - at[i]);  // euclidean.py:82-83
   } else if constexpr (KIND == kPoincare) {  // poincare.py:140-145 -> geoopt logmap
     T c = 1.0f / (R * R);
     T sc = t_sqrt(c);
     T neg[AMAX], sub[AMAX];
-    for (int i = 0; i < A; ++i) neg[i] = -at[i];
-    p_mobius_add(neg, z, A, c, sub);
-    T sn = hard_clamp(norm2(sub, A), 1e-15f, INFINITY);
-    T f = 2.0f / sc / p_lambda(at, A, c) * p_artanh(sc * sn);
-    for (int i = 0; i < A; ++i) u[i] = f * sub[i] / sn;
+    MV_FOR(i, 0, A) neg[i] = -at[i];
+    p_mobius_add<AMAX>(neg, z, A, c, sub);
+    T sn = hard_clamp(norm2<AMAX>(sub, A), 1e-15f, INFINITY);
+    T f = 2.0f / sc / p_lambda<AMAX>(at, A, c) * p_artanh(sc * sn);
+    MV_FOR(i, 0, A) u[i] = f * sub[i] / sn;
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:124-128
-    T alpha = -lorentz_product(at, z, A) / (R * R);
+    T alpha = -lorentz_product<AMAX>(at, z, A) / (R * R);
     T coef = g_acosh(alpha) / g_sqrt(alpha * alpha - 1.0f);
-    for (int i = 0; i < A; ++i) u[i] = coef * (z[i] - alpha * at[i]);
+    MV_FOR(i, 0, A) u[i] = coef * (z[i] - alpha * at[i]);
   } else {  // spherical.py:104-109
-    T alpha = dot(at, z, A) / (R * R);
+    T alpha = dot<AMAX>(at, z, A) / (R * R);
     T coef = t_acos(hard_clamp(alpha, -1.0f, 1.0f)) / g_sqrt(1.0f - alpha * alpha);
-    for (int i = 0; i < A; ++i) u[i] = coef * (z[i] - alpha * at[i]);
+    MV_FOR(i, 0, A) u[i] = coef * (z[i] - alpha * at[i]);
   }
 }
 
 // inverse_exp_map_mu0 (hyperbolics.py:131-135 | spherical.py:112-116 | euclidean.py:86-87 | geoopt logmap0)
-template <int KIND, typename T> __device__ __forceinline__ void log_map_mu0(const T* x, int A, T R, T* out) {
+template <int KIND, int AMAX, typename T> __device__ __forceinline__ void log_map_mu0(const T* x, int A, T R, T* out) {
+  MV_BOUNDS(AMAX);
   if constexpr (KIND == kEuclidean) {
-    for (int i = 0; i < A; ++i) out[i] = 2.0f * x[i];
+    MV_FOR(i, 0, A) out[i] = 2.0f * x[i];
   } else if constexpr (KIND == kPoincare) {
     T c = 1.0f / (R * R);
     T sc = t_sqrt(c);
-    T n = hard_clamp(norm2(x, A), 1e-15f, INFINITY);
+    T n = hard_clamp(norm2<AMAX>(x, A), 1e-15f, INFINITY);
     T f = p_artanh(sc * n);
-    for (int i = 0; i < A; ++i) out[i] = x[i] / n / sc * f;
+    MV_FOR(i, 0, A) out[i] = x[i] / n / sc * f;
   } else {
     T alpha = x[0] / R;
     T coef;
     if constexpr (KIND == kHyperboloid) coef = g_acosh(alpha) / g_sqrt(alpha * alpha - 1.0f);
     else coef = t_acos(hard_clamp(alpha, -1.0f, 1.0f)) / g_sqrt(1.0f - alpha * alpha);
     out[0] = coef * (x[0] - alpha * R);
-    for (int i = 1; i < A; ++i) out[i] = coef * x[i];
+    MV_FOR(i, 1, A) out[i] = coef * x[i];
   }
 }
 
 // ---- logdet of the projection Jacobian from the tangent vector u (hyperbolics.py:58-65 | spherical.py:58-67)
-template <int KIND, typename T> __device__ __forceinline__ T logdet_u(const T* u, int A, T R) {
+template <int KIND, int AMAX, typename T> __device__ __forceinline__ T logdet_u(const T* u, int A, T R) {
   float nm1 = (float)(A - 1 - 1);  // (n - 1) with n = A - 1
   if constexpr (KIND == kHyperboloid) {
-    T r = g_sqrt(lorentz_product(u, u, A)) / R;
+    T r = g_sqrt(lorentz_product<AMAX>(u, u, A)) / R;
     return nm1 * (t_log(R) + g_logsinh(r) - t_log(r));
   } else {
-    T r = norm2(u, A) / R;
+    T r = norm2<AMAX>(u, A) / R;
     return nm1 * (t_log(R) + t_log(hard_clamp(t_abs(t_sin(r)), 1e-5f, INFINITY)) -
                   t_log(hard_clamp(r, 1e-5f, INFINITY)));
   }
 }
 
-// poincare_to_lorentz (poincare.py:167-170): y[A] -> out[A+1]
-template <typename T> __device__ __forceinline__ void poincare_to_lorentz(const T* y, int A, T R, T* out) {
-  T n = norm2(y, A);
+// poincare_to_lorentz (poincare.py:167-170): y[A] -> out[A+1]   (AMAX bounds the OUTPUT)
+template <int AMAX, typename T> __device__ __forceinline__ void poincare_to_lorentz(const T* y, int A, T R, T* out) {
+  MV_BOUNDS(AMAX);
+  T n = norm2<AMAX>(y, A);
   T n2 = n * n;
   T den = R * R - n2;
   out[0] = (R * (R * R + n2)) / den;
-  for (int i = 0; i < A; ++i) out[i + 1] = (2.0f * (R * R) * y[i]) / den;
+  MV_FOR(i, 1, A + 1) out[i] = (2.0f * (R * R) * y[i - 1]) / den;
 }
 
-// PoincareBall.logdet (poincare.py:55-89): via the Lorentz model
+// PoincareBall.logdet (poincare.py:55-89): via the Lorentz model.  AMAX bounds the ball dimension.
 template <int AMAX, typename T> __device__ __forceinline__ T p_logdet(const T* mu, const T* z, int A, T R) {
   T zl[AMAX + 1], ml[AMAX + 1], u[AMAX + 1];
-  poincare_to_lorentz(z, A, R, zl);
-  poincare_to_lorentz(mu, A, R, ml);
+  poincare_to_lorentz<AMAX + 1>(z, A, R, zl);
+  poincare_to_lorentz<AMAX + 1>(mu, A, R, ml);
   log_map<kHyperboloid, AMAX + 1>(zl, ml, A + 1, R, u);
-  return logdet_u<kHyperboloid>(u, A + 1, R);
+  return logdet_u<kHyperboloid, AMAX + 1>(u, A + 1, R);
 }
 
 // =================================================================================================== component
@@ -402,22 +426,26 @@ __device__ __forceinline__ void component_forward(const T* mraw, const T* lraw, 
                                                   T rp, T* z, T* kl, T* log_q_out, T* log_p_out, T* mu_out,
                                                   T* sigma_out) {
   constexpr int AMAX = DMAX + 1;
-  T sigma[DMAX];
-  for (int i = 0; i < lvd; ++i) sigma[i] = t_softplus(lraw[i]) + 1e-5f;  // component.py:72
-  if (sigma_out)
-    for (int i = 0; i < lvd; ++i) sigma_out[i] = sigma[i];
-  if (lvd == 1)
-    for (int i = 1; i < d; ++i) sigma[i] = sigma[0];  // wrapped_normal.py:46-49 / Normal broadcasting
+  MV_BOUNDS(AMAX);
+  T sigma[AMAX];
+  MV_FOR(i, 0, lvd) sigma[i] = t_softplus(lraw[i]) + 1e-5f;  // component.py:72
+  if (sigma_out) {
+    MV_FOR(i, 0, lvd) sigma_out[i] = sigma[i];
+  }
+  if (lvd == 1) {  // wrapped_normal.py:46-49 / Normal broadcasting
+    MV_FOR(i, 1, d) sigma[i] = sigma[0];
+  }
 
   if constexpr (KIND == kEuclidean) {
-    T mu[DMAX];
-    exp_map_mu0<kEuclidean>(mraw, d, cst<T>(0.0f), mu);
-    for (int i = 0; i < d; ++i) z[i] = mu[i] + eps[i] * sigma[i];  // Normal.rsample
-    if (mu_out)
-      for (int i = 0; i < d; ++i) mu_out[i] = mu[i];
+    T mu[AMAX];
+    exp_map_mu0<kEuclidean, AMAX>(mraw, d, cst<T>(0.0f), mu);
+    MV_FOR(i, 0, d) z[i] = mu[i] + eps[i] * sigma[i];  // Normal.rsample
+    if (mu_out) {
+      MV_FOR(i, 0, d) mu_out[i] = mu[i];
+    }
     if (kl) {  // kl_divergence(N(mu,sigma), N(0,1)).sum(-1), sampling_procedures.py:153-155
       T s = cst<T>(0.0f);
-      for (int i = 0; i < d; ++i) {
+      MV_FOR(i, 0, d) {
         T var_ratio = (sigma[i] / 1.0f) * (sigma[i] / 1.0f);
         T t1 = ((mu[i] - 0.0f) / 1.0f) * ((mu[i] - 0.0f) / 1.0f);
         T term = 0.5f * (var_ratio + t1 - 1.0f - t_log(var_ratio));
@@ -427,7 +455,7 @@ __device__ __forceinline__ void component_forward(const T* mraw, const T* lraw, 
     }
     if (log_q_out) {  // EuclideanNormal.log_prob (wrapped_distributions.py:39-42)
       T lq = cst<T>(0.0f), lp = cst<T>(0.0f);
-      for (int i = 0; i < d; ++i) {
+      MV_FOR(i, 0, d) {
         T a = normal_logprob_term(z[i] - mu[i], sigma[i]);
         T b = normal_logprob_term(z[i], cst<T>(1.0f));
         lq = (i == 0) ? a : lq + a;
@@ -440,43 +468,44 @@ __device__ __forceinline__ void component_forward(const T* mraw, const T* lraw, 
   } else {
     const int A = ambient_dim(KIND, d);
     T R = radius_of(rp);
-    T mu[AMAX], v[DMAX], x[AMAX], u[AMAX];
-    exp_map_mu0<KIND>(mraw, d, R, mu);
-    if (mu_out)
-      for (int i = 0; i < A; ++i) mu_out[i] = mu[i];
-    for (int i = 0; i < d; ++i) v[i] = eps[i] * sigma[i];  // Normal(0, sigma).rsample
+    T mu[AMAX], v[AMAX], x[AMAX], u[AMAX];
+    exp_map_mu0<KIND, AMAX>(mraw, d, R, mu);
+    if (mu_out) {
+      MV_FOR(i, 0, A) mu_out[i] = mu[i];
+    }
+    MV_FOR(i, 0, d) v[i] = eps[i] * sigma[i];  // Normal(0, sigma).rsample
 
     T logdet_q, logdet_p;
-    T v0[DMAX];
+    T v0[AMAX];
     if constexpr (KIND == kPoincare) {
       T c = 1.0f / (R * R);
-      T lam = p_lambda(mu, A, c);
-      for (int i = 0; i < A; ++i) u[i] = v[i] / lam;  // poincare.py:152-157
+      T lam = p_lambda<AMAX>(mu, A, c);
+      MV_FOR(i, 0, A) u[i] = v[i] / lam;  // poincare.py:152-157
       exp_map<KIND, AMAX>(u, mu, A, R, z);
       logdet_q = p_logdet<AMAX>(mu, z, A, R);
       T mu0[AMAX], u0[AMAX];
-      for (int i = 0; i < A; ++i) mu0[i] = cst<T>(0.0f);
+      MV_FOR(i, 0, A) mu0[i] = cst<T>(0.0f);
       log_map<KIND, AMAX>(z, mu0, A, R, u0);
-      T lam0 = p_lambda(mu0, A, c);
-      for (int i = 0; i < A; ++i) v0[i] = u0[i] * lam0;  // poincare.py:160-164
+      T lam0 = p_lambda<AMAX>(mu0, A, c);
+      MV_FOR(i, 0, A) v0[i] = u0[i] * lam0;  // poincare.py:160-164
       logdet_p = p_logdet<AMAX>(mu0, z, A, R);
     } else {
       x[0] = cst<T>(0.0f);  // expand_proj_dims (common.py:156-158)
-      for (int i = 0; i < d; ++i) x[i + 1] = v[i];
-      pt_mu0<KIND>(x, mu, A, R, u);
+      MV_FOR(i, 1, A) x[i] = v[i - 1];
+      pt_mu0<KIND, AMAX>(x, mu, A, R, u);
       exp_map<KIND, AMAX>(u, mu, A, R, z);
-      logdet_q = logdet_u<KIND>(u, A, R);
+      logdet_q = logdet_u<KIND, AMAX>(u, A, R);
       // prior p_z = WrappedNormal(mu0, 1): log_prob(z) via inverse_sample_projection_mu0 (wrapped_normal.py:99-103)
       T mu0[AMAX], u0[AMAX], w[AMAX];
       mu0[0] = 1.0f * R;
-      for (int i = 1; i < A; ++i) mu0[i] = 0.0f * R;
+      MV_FOR(i, 1, A) mu0[i] = 0.0f * R;
       log_map<KIND, AMAX>(z, mu0, A, R, u0);
-      inv_pt_mu0<KIND>(u0, mu0, A, R, w);
-      for (int i = 0; i < d; ++i) v0[i] = w[i + 1];
-      logdet_p = logdet_u<KIND>(u0, A, R);
+      inv_pt_mu0<KIND, AMAX>(u0, mu0, A, R, w);
+      MV_FOR(i, 1, A) v0[i - 1] = w[i];
+      logdet_p = logdet_u<KIND, AMAX>(u0, A, R);
     }
     T nq = cst<T>(0.0f), np = cst<T>(0.0f);
-    for (int i = 0; i < d; ++i) {
+    MV_FOR(i, 0, d) {
       T a = normal_logprob_term(v[i], sigma[i]);
       T b = normal_logprob_term(v0[i], cst<T>(1.0f));
       nq = (i == 0) ? a : nq + a;

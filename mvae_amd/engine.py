@@ -101,7 +101,7 @@ class StepEngine:
         P = self.flat.n_params
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
         self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
-        self.counters = z(4, torch.int32)
+        self.counters = z(32, torch.int32)
         self.stats = z(2 * (4 + n))
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
         self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
@@ -116,7 +116,7 @@ class StepEngine:
     def load_state(self, state: Dict[str, Tensor]) -> None:
         views = self.param_views()
         for name, v in views.items():
-            v.copy_(state[name].to(device=self.device, dtype=torch.float32))
+            v.copy_(state[name].to(device=self.device, dtype=torch.float32).reshape(v.shape))
 
     def state_dict(self) -> Dict[str, Tensor]:
         return {k: v.detach().clone() for k, v in self.param_views().items()}
@@ -213,7 +213,7 @@ class StepEngine:
         check(load().mvae_train_step(self._context(B), ptr(x), ptr(eps), float(beta),
                                      1 if do_curvature_step else 0, stream_ptr(self.device)))
 
-    STEP_KERNELS = ("enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd", "optim")
+    STEP_KERNELS = ("enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")
 
     def profile_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
                      iters: int = 50) -> Dict[str, float]:

@@ -30,6 +30,39 @@ def binary_batches(steps: int, batch: int, in_dim: int, seed: int = 4321, dtype=
     return (u < pixel_probs(in_dim)).to(dtype)
 
 
+def digits_like_batches(steps: int, batch: int, side: int = 28, n_classes: int = 10, seed: int = 4321,
+                        dtype=torch.float32) -> torch.Tensor:
+    """[steps, batch, side*side] {0,1} images with MNIST-like latent structure: every sample picks one of `n_classes`
+    stroke-like prototypes (a few anisotropic Gaussian blobs on the pixel grid), a random sub-pixel shift and a random
+    stroke thickness, and is then binarised dynamically, x = (p > U(0,1)) as in image_reconstruction.py:44-53.
+    Unlike i.i.d. pixels this gives the posterior something to encode, so long training runs behave like the
+    reference's MNIST runs (no posterior collapse)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(side, dtype=torch.float64), torch.arange(side, dtype=torch.float64),
+                            indexing="ij")
+    n_blobs = 4
+    cx = 6 + 16 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
+    cy = 6 + 16 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
+    sx = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
+    sy = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
+    n = steps * batch
+    cls = torch.randint(0, n_classes, (n,), generator=g)
+    shift = (torch.rand(n, 2, generator=g, dtype=torch.float64) - 0.5) * 3.0
+    thick = 0.8 + 0.5 * torch.rand(n, 1, 1, generator=g, dtype=torch.float64)
+    out = torch.empty(n, side * side, dtype=dtype)
+    chunk = 4096
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        c = cls[lo:hi]
+        dx = xx[None, None] - (cx[c] + shift[lo:hi, 0:1])[:, :, None, None]
+        dy = yy[None, None] - (cy[c] + shift[lo:hi, 1:2])[:, :, None, None]
+        e = torch.exp(-0.5 * ((dx / sx[c][:, :, None, None])**2 + (dy / sy[c][:, :, None, None])**2)).sum(dim=1)
+        prob = (0.02 + 0.95 * torch.clamp(e * thick[lo:hi], max=1.0)).reshape(hi - lo, -1)
+        u = torch.rand(hi - lo, side * side, generator=g, dtype=torch.float64)
+        out[lo:hi] = (u < prob).to(dtype)
+    return out.reshape(steps, batch, side * side)
+
+
 def uniform_batches(steps: int, batch: int, in_dim: int, seed: int = 4321, dtype=torch.float32) -> torch.Tensor:
     """[steps, batch, in_dim] tensor in [0,1) -- a stand-in for CIFAR pixels (BCE with soft targets)."""
     g = torch.Generator().manual_seed(seed)
