@@ -132,6 +132,17 @@ int mvae_linear_backward(const float* x, const float* W, const float* dy, int re
                          int64_t M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Importance-sampled log-likelihood pieces.  ModelVAE.log_likelihood, vae.py:82-123 ("next" row f-1 of the scope table).
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* out[r] = sum_j binary_cross_entropy_with_logits(logits[r][j], x[r % x_rows][j])   (vae.py:108-109 without
+ * materialising x.repeat((n,1,1))).  logits[rows, D], x[x_rows, D]. */
+int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows, int64_t x_rows, int D, void* stream);
+/* log_px[b] = logsumexp_n(-bce + log_p - log_q) - log n ; mi[b] = logsumexp_n(log_q - log_p) - log n   (vae.py:113-117)
+ * bce, log_p, log_q: [n, B]. */
+int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi, int n,
+                       int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * The whole step.  ModelVAE.train_step, vae.py:149-166; BatchStats, stats.py:144-212; CurvatureOptimizer.step,
  * mt/mvae/utils.py:174-180 with the routing of Trainer.build_optimizer, train.py:327-360.
  * All buffers are allocated by the host layer (torch) and only referenced here.

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmvae_hip.so")
+LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE = 0, 1, 2, 3
 ABI_VERSION = 1
@@ -53,6 +53,8 @@ PROTOTYPES = {
                                           _L, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "mvae_loglik_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),
     "mvae_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "mvae_destroy": (None, [C.c_void_p]),

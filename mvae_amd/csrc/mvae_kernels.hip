@@ -25,6 +25,18 @@
 
 using namespace mv;
 
+// ------------------------------------------------------------------------------------------------ dev timing hooks
+// -DMV_DBG_TIMING: workgroup 0 of the latent kernels stamps wall_clock64() (100 MHz) at phase boundaries.
+#ifdef MV_DBG_TIMING
+__device__ unsigned long long g_dbg[64];
+#define MV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+extern "C" int mvae_debug_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
+}
+#else
+#define MV_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
@@ -97,12 +109,21 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
 template <int DMAX, typename T>
 __device__ __forceinline__ void comp_eval(int kind, const T* m, const T* l, int lvd, const float* e, int d, T rp, T* z,
                                           T* kl, T* lq, T* lp, T* mu, T* sg) {
-  switch (kind) {
-    case kEuclidean: component_forward<kEuclidean, DMAX, T>(m, l, lvd, e, d, rp, z, kl, lq, lp, mu, sg); break;
-    case kHyperboloid: component_forward<kHyperboloid, DMAX, T>(m, l, lvd, e, d, rp, z, kl, lq, lp, mu, sg); break;
-    case kSphere: component_forward<kSphere, DMAX, T>(m, l, lvd, e, d, rp, z, kl, lq, lp, mu, sg); break;
-    default: component_forward<kPoincare, DMAX, T>(m, l, lvd, e, d, rp, z, kl, lq, lp, mu, sg); break;
+#define MV_KIND_SWITCH(DD, LL)                                                                              \
+  switch (kind) {                                                                                           \
+    case kEuclidean: component_forward<kEuclidean, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;     \
+    case kHyperboloid: component_forward<kHyperboloid, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break; \
+    case kSphere: component_forward<kSphere, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;           \
+    default: component_forward<kPoincare, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;              \
   }
+  // the common case (every dimension equals the bucket bound) is instantiated with compile-time dimensions, which
+  // folds away every loop guard of the small-vector code
+  if (d == DMAX && lvd == DMAX) {
+    MV_KIND_SWITCH(DMAX, DMAX)
+  } else {
+    MV_KIND_SWITCH(d, lvd)
+  }
+#undef MV_KIND_SWITCH
 }
 
 // forward for one (row, component); pointers are to the start of the row
@@ -541,6 +562,69 @@ extern "C" int mvae_linear_backward(const float* x, const float* W, const float*
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ log-likelihood helpers (API)
+// bce[r] = sum_j BCE-with-logits(logits[r][j], x[r % x_rows][j]); one wavefront per row.
+__global__ __launch_bounds__(256) void k_bce_rows(const float* logits, const float* x, float* out, int64_t rows,
+                                                  int64_t x_rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* lr = logits + r * D;
+  const float* xr = x + (r % x_rows) * D;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float y = lr[j], t = xr[j];
+    const float e = expf(-fabsf(y));
+    s += (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[r] = s;
+}
+
+// log p(x)[b] = logsumexp_n(-bce[n][b] + log_p[n][b] - log_q[n][b]) - log n ;
+// mi[b] = logsumexp_n(log_q[n][b] - log_p[n][b]) - log n        (vae.py:113-117)
+__global__ __launch_bounds__(256) void k_loglik_reduce(const float* bce, const float* log_p, const float* log_q,
+                                                       float* log_px, float* mi, int n, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float m1 = -INFINITY, m2 = -INFINITY;
+  for (int i = 0; i < n; ++i) {
+    const size_t o = (size_t)i * B + b;
+    m1 = fmaxf(m1, -bce[o] + log_p[o] - log_q[o]);
+    m2 = fmaxf(m2, log_q[o] - log_p[o]);
+  }
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const size_t o = (size_t)i * B + b;
+    s1 += expf((-bce[o] + log_p[o] - log_q[o]) - m1);
+    s2 += expf((log_q[o] - log_p[o]) - m2);
+  }
+  const float ln = logf((float)n);
+  log_px[b] = m1 + logf(s1) - ln;
+  mi[b] = m2 + logf(s2) - ln;
+}
+
+extern "C" int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows, int64_t x_rows, int D,
+                             void* stream) {
+  if (!logits || !x || !out || rows < 0 || x_rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_bce_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, x, out,
+                     rows, x_rows, D);
+  LAUNCH_CHECK("bce rows launch");
+  return 0;
+}
+
+extern "C" int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi,
+                                  int n, int B, void* stream) {
+  if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_loglik_reduce, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q,
+                     log_px, mi, n, B);
+  LAUNCH_CHECK("loglik reduce launch");
+  return 0;
+}
+
 // ================================================================================================ the fused step
 struct mvae_ctx {
   mvae_model_desc d;
@@ -824,6 +908,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
   float* h_s = dyn;
   float* eps_s = dyn + ((H + 3) & ~3);
   const bool vec = aligned16(Wh) && (H & 3) == 0;
+  MV_STAMP(0);
 
   // ---- request everything
   float hv[2] = {0.f, 0.f};
@@ -863,6 +948,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
       if (tid + 256 * u < H) h_s[tid + 256 * u] = hv[u];
   }
   __syncthreads();
+  MV_STAMP(1);
 
   // ---- heads = h W_heads^T + b
   if (FAST) {
@@ -915,11 +1001,17 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
     if (tid < NH) heads[row * ldh + tid] = heads_s[tid];
   }
   __syncthreads();
+  MV_STAMP(2);
 
   // ---- latent components: component ci runs on wave ci&3, lane ci>>2 (different manifolds land on different waves)
   {
     const int ci = lane * 4 + wave;
+#ifdef MV_DBG_SKIP_COMP
+    if (ci < t.n) { kl[(size_t)ci * B + row] = heads_s[0]; z_s[t.c[ci].z_col] = eps_s[0]; z_s[t.c[ci].z_col+1] = radii[0]; }
+    if (false) {
+#else
     if (ci < t.n) {
+#endif
       float klv;
       comp_fwd_row<DMAX>(t.c[ci], heads_s, eps_s, radii, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr, nullptr);
       kl[(size_t)ci * B + row] = klv;
@@ -927,6 +1019,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
     }
   }
   __syncthreads();
+  MV_STAMP(3);
   if (z_user && tid < Z) z_user[row * Z + tid] = z_s[tid];
 
   // ---- first decoder layer: hd = relu(z W_d0^T + b)   (K = Z is tiny)
@@ -952,6 +1045,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
       hd[row * H + c] = acc > 0.f ? acc : 0.f;
     }
   }
+  MV_STAMP(4);
 }
 
 // ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
@@ -977,7 +1071,7 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
     const float y = s + bias;
     // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
     const float e = expf(-fabsf(y));
-    const float log_sig = fminf(y, 0.f) - log1pf(e);
+    const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
     loss = (1.f - t) * y - log_sig;
     const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
     g[(size_t)m * D + n] = sig - t;  // d(sum bce)/d(logit)
@@ -1100,6 +1194,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     return;
   }
   const size_t row = b;
+  MV_STAMP(8);
   const int H4 = (H + 3) & ~3;
   float* dhd_s = dyn;
   float* part = dyn + H4;
@@ -1134,6 +1229,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   if (tid < NH) heads_s[tid] = heads[row * ldh + tid];
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
   __syncthreads();
+  MV_STAMP(9);
 
   // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c, slices meet in LDS
   {
@@ -1156,6 +1252,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     }
     __syncthreads();
   }
+  MV_STAMP(10);
   // ---- component backward: wave w takes components w, w+4, ...; lane = input direction (forward-mode duals)
   for (int ci = wave; ci < t.n; ci += 4) {
     const mvae_component_desc& c = t.c[ci];
@@ -1168,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     }
   }
   __syncthreads();
+  MV_STAMP(11);
   if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
   // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
   if (FAST) {
@@ -1190,6 +1288,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       dh[o] = (h[o] > 0.f) ? acc : 0.f;
     }
   }
+  MV_STAMP(12);
 }
 
 // ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)

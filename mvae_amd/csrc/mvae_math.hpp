@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "mvae_fastmath.hpp"
+
 // Small-vector loops: arrays are sized by a compile-time bound and every loop is written over that bound with a
 // runtime guard, fully unrolled for bounds <= 9 so that all indices are compile-time constants and the vectors live in
 // VGPRs (a runtime-indexed array would be placed in scratch memory).
@@ -116,17 +118,41 @@ __device__ __forceinline__ Dual leaky_clamp(Dual x, float lo, float hi) {
   return {fminf(fmaxf(x.v, lo), hi), in ? x.d : x.d * kEps};
 }
 // F.softplus(beta=1, threshold=20)
-__device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : mvf::log1p_pos(expf(x)); }
 __device__ __forceinline__ Dual t_softplus(Dual x) {
-  if (x.v > 20.0f) return x;
-  float e = expf(x.v);
-  return {log1pf(e), x.d * e / (e + 1.0f)};
+  const float e = expf(fminf(x.v, 20.0f));
+  const bool lin = x.v > 20.0f;
+  return {lin ? x.v : mvf::log1p_pos(e), lin ? x.d : x.d * e / (e + 1.0f)};
 }
 
 // ---- the reference's guarded functions
 template <typename T> __device__ __forceinline__ T g_sqrt(T x) { return t_sqrt(leaky_clamp(x, 1e-9f, INFINITY)); }
 template <typename T> __device__ __forceinline__ T g_cosh(T x) { return t_cosh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
 template <typename T> __device__ __forceinline__ T g_sinh(T x) { return t_sinh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
+// cosh and sinh of the same (leaky-clamped) argument, one exp (common.py:107-114)
+__device__ __forceinline__ void g_cosh_sinh(float x, float* c, float* s) {
+  mvf::sinhcosh(fminf(fmaxf(x, -kMaxNorm), kMaxNorm), s, c);
+}
+__device__ __forceinline__ void g_cosh_sinh(Dual x, Dual* c, Dual* s) {
+  const Dual xc = leaky_clamp(x, -kMaxNorm, kMaxNorm);
+  float sh, ch;
+  mvf::sinhcosh(xc.v, &sh, &ch);
+  *c = Dual{ch, sh * xc.d};
+  *s = Dual{sh, ch * xc.d};
+}
+// cos and sin of the same argument
+__device__ __forceinline__ void t_cos_sin(float x, float* c, float* s) {
+  if (!mvf::sincos_fast(x, s, c)) {  // |x| >= 8192: full-range reduction
+    *s = sinf(x);
+    *c = cosf(x);
+  }
+}
+__device__ __forceinline__ void t_cos_sin(Dual x, Dual* c, Dual* s) {
+  float sv, cv;
+  t_cos_sin(x.v, &cv, &sv);
+  *c = Dual{cv, -sv * x.d};
+  *s = Dual{sv, cv * x.d};
+}
 
 __device__ __forceinline__ float g_acosh_parts(float x, float* z_out) {
   float xc = fmaxf(x, 1.0f + kEps);  // == 1.0f in f32, as in the reference's f32 path
@@ -239,13 +265,8 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ void exp_ma
     T xn = n / R;
     T nc = hard_clamp(n, 1e-12f, INFINITY);  // F.normalize(eps=1e-12)
     T c, s;
-    if constexpr (KIND == kHyperboloid) {
-      c = g_cosh(xn);
-      s = g_sinh(xn);
-    } else {
-      c = t_cos(xn);
-      s = t_sin(xn);
-    }
+    if constexpr (KIND == kHyperboloid) g_cosh_sinh(xn, &c, &s);
+    else t_cos_sin(xn, &c, &s);
     mu[0] = c * R;
     MV_FOR(i, 1, d + 1) mu[i] = s * ((x[i - 1] / nc) * R);
   }
@@ -330,11 +351,13 @@ __device__ __forceinline__ void exp_map(const T* u, const T* at, int A, T R, T* 
     p_mobius_add<AMAX>(at, second, A, c, z);
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:106-111
     T n = g_sqrt(lorentz_product<AMAX>(u, u, A)) / R;
-    T c = g_cosh(n), s = g_sinh(n);
+    T c, s;
+    g_cosh_sinh(n, &c, &s);
     MV_FOR(i, 0, A) z[i] = c * at[i] + s * (u[i] / n);
   } else {  // spherical.py:86-91
     T n = norm2<AMAX>(u, A) / R;
-    T c = t_cos(n), s = t_sin(n);
+    T c, s;
+    t_cos_sin(n, &c, &s);
     MV_FOR(i, 0, A) z[i] = c * at[i] + s * (u[i] / n);
   }
 }
@@ -393,8 +416,9 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ T logdet_u(
     return nm1 * (t_log(R) + g_logsinh(r) - t_log(r));
   } else {
     T r = norm2<AMAX>(u, A) / R;
-    return nm1 * (t_log(R) + t_log(hard_clamp(t_abs(t_sin(r)), 1e-5f, INFINITY)) -
-                  t_log(hard_clamp(r, 1e-5f, INFINITY)));
+    T cr, sr;
+    t_cos_sin(r, &cr, &sr);
+    return nm1 * (t_log(R) + t_log(hard_clamp(t_abs(sr), 1e-5f, INFINITY)) - t_log(hard_clamp(r, 1e-5f, INFINITY)));
   }
 }
 

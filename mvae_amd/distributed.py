@@ -1,0 +1,56 @@
+"""Data-parallel step over torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+New functionality (the reference is single-device).  Samples are independent given the
+parameters and the loss is a batch SUM (stats.py:200-202), so:
+  * batch rows are split contiguously across ranks (`shard_rows`), every rank draws / receives its own eps rows;
+  * parameters, optimizer state and radii are replicated;
+  * ONE exchange per step: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2), after which
+    every rank applies the identical optimizer step;
+  * the epoch >= 10 gate and the radius warm-up are functions of the epoch only: no communication;
+  * statistics are summed across ranks only when somebody reads them (`reduce_stats`).
+`engine` is anything with `.grads` (flat tensor), `.stats`, `forward_backward(x, eps, beta)` and
+`optimizer_step(do_curvature_step, batch=...)` -- the StepEngine on the GPU.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of the rows owned by `rank` (earlier ranks take the remainder)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DataParallelStep:
+
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None) -> None:
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def broadcast_state(self, src: int = 0) -> None:
+        """Make every rank start from rank `src`'s parameters / optimizer state."""
+        if self.world > 1:
+            for t in (self.engine.params, self.engine.adam_m, self.engine.adam_v, self.engine.counters):
+                dist.broadcast(t, src=src, group=self.group)
+
+    def train_step(self, x_local: Tensor, eps_local: Tensor, beta: float, do_curvature_step: bool) -> None:
+        eng = self.engine
+        if self.world == 1:
+            eng.train_step(x_local, eps_local, beta, do_curvature_step)
+            return
+        eng.forward_backward(x_local, eps_local, beta)
+        dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.group)
+        eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
+
+    def reduce_stats(self) -> Tensor:
+        """Global sums of the running statistics (one small all-reduce, when the host wants to log)."""
+        s = self.engine.stats.clone()
+        if self.world > 1:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return s

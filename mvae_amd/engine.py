@@ -110,6 +110,12 @@ class StepEngine:
     def param_views(self) -> Dict[str, Tensor]:
         return self.flat.views(self.params)
 
+    def param_views_raw(self) -> Dict[str, Tensor]:
+        """The fused matrices as the kernels see them (all heads of all components stacked)."""
+        f, NH, H = self.flat, self.layout.heads_dim, self.h_dim
+        return {"w_heads": self.params[f.off_w_heads:f.off_w_heads + NH * H].view(NH, H),
+                "b_heads": self.params[f.off_b_heads:f.off_b_heads + NH]}
+
     def grad_views(self) -> Dict[str, Tensor]:
         return self.flat.views(self.grads)
 

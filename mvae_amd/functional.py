@@ -38,6 +38,8 @@ def _radius_arg(kind: int, radius: Optional[Tensor], like: Tensor) -> Optional[T
 
 
 def _no_grad_inputs(*ts) -> None:
+    """The radius is exempt: it is the live nn.Parameter by construction (RadiusManifold takes a callable returning
+    it), while a tensor argument that requires grad means the caller expects autograd to flow through."""
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts):
         raise NotImplementedError(
             "the standalone manifold primitives are forward-only; differentiable paths go through the fused "
@@ -46,7 +48,7 @@ def _no_grad_inputs(*ts) -> None:
 
 # --------------------------------------------------------------------------------------------- primitives
 def exp_map_mu0(kind: int, x: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(x, radius)
+    _no_grad_inputs(x)
     x = _f32c(x)
     d = x.shape[-1]
     out = x.new_empty(x.shape[:-1] + (ambient_dim(kind, d),))
@@ -60,7 +62,7 @@ def _true_dim(kind: int, ambient: int) -> int:
 
 
 def inverse_exp_map_mu0(kind: int, x: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(x, radius)
+    _no_grad_inputs(x)
     x = _f32c(x)
     A = x.shape[-1]
     out = torch.empty_like(x)
@@ -71,7 +73,7 @@ def inverse_exp_map_mu0(kind: int, x: Tensor, radius: Optional[Tensor] = None) -
 
 
 def _pt(fn_name: str, kind: int, x: Tensor, other: Tensor, radius: Optional[Tensor]) -> Tensor:
-    _no_grad_inputs(x, other, radius)
+    _no_grad_inputs(x, other)
     x, other = torch.broadcast_tensors(x, other)
     x, other = _f32c(x), _f32c(other)
     A = x.shape[-1]
@@ -103,7 +105,7 @@ def _at_rows(x: Tensor, at: Tensor, last: int) -> Tuple[Tensor, int]:
 
 
 def sample_projection_mu0(kind: int, v: Tensor, at_point: Tensor, radius: Optional[Tensor] = None):
-    _no_grad_inputs(v, at_point, radius)
+    _no_grad_inputs(v, at_point)
     v = _f32c(v)
     d = v.shape[-1]
     A = ambient_dim(kind, d)
@@ -117,7 +119,7 @@ def sample_projection_mu0(kind: int, v: Tensor, at_point: Tensor, radius: Option
 
 
 def inverse_sample_projection_mu0(kind: int, z: Tensor, at_point: Tensor, radius: Optional[Tensor] = None):
-    _no_grad_inputs(z, at_point, radius)
+    _no_grad_inputs(z, at_point)
     z = _f32c(z)
     A = z.shape[-1]
     d = _true_dim(kind, A)
@@ -132,7 +134,7 @@ def inverse_sample_projection_mu0(kind: int, z: Tensor, at_point: Tensor, radius
 
 def logdet(kind: int, u: Optional[Tensor], mu: Optional[Tensor], z: Optional[Tensor],
            radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(u, mu, z, radius)
+    _no_grad_inputs(u, mu, z)
     ref = _f32c(u if kind in (_lib.HYPERBOLOID, _lib.SPHERE) else z)
     A = ref.shape[-1]
     rows = ref.numel() // A
@@ -234,3 +236,23 @@ def linear_backward(x: Tensor, W: Tensor, dy: Tensor, relu_in: bool = False, nee
     check(load().mvae_linear_backward(ptr(x), ptr(W), ptr(dy), 1 if relu_in else 0, ptr(dW), ptr(db), ptr(dx), M, N, K,
                                       stream_ptr(x.device)))
     return dW, db, dx
+
+
+# --------------------------------------------------------------------------------------------- log-likelihood pieces
+def bce_rows(logits: Tensor, x: Tensor) -> Tensor:
+    """sum_j BCE-with-logits(logits[..., j], x[..., j]) with x broadcast over leading sample dims of logits."""
+    logits, x = _f32c(logits), _f32c(x)
+    D = logits.shape[-1]
+    rows, x_rows = logits.numel() // D, x.numel() // D
+    out = logits.new_empty(logits.shape[:-1])
+    check(load().mvae_bce_rows(ptr(logits), ptr(x), ptr(out), rows, x_rows, D, stream_ptr(logits.device)))
+    return out
+
+
+def loglik_reduce(bce: Tensor, log_p: Tensor, log_q: Tensor):
+    bce, log_p, log_q = _f32c(bce), _f32c(log_p), _f32c(log_q)
+    n, B = bce.shape
+    log_px, mi = bce.new_empty(B), bce.new_empty(B)
+    check(load().mvae_loglik_reduce(ptr(bce), ptr(log_p), ptr(log_q), ptr(log_px), ptr(mi), n, B,
+                                    stream_ptr(bce.device)))
+    return log_px, mi

@@ -1,0 +1,252 @@
+"""ModelVAE / FeedForwardVAE of the reference (mt/mvae/models/vae.py:29-166, ffnn_vae.py:27-60) on the fused HIP step.
+
+Same constructor signatures, attribute names (`components`, `fc_e0`, `fc_d0`, `fc_logits`, `total_z_dim`, `device`),
+state-dict keys and method names.  After `.to(device)` every nn.Parameter is a view into the StepEngine's flat HBM
+buffer, so `state_dict()` / `load_state_dict()` / checkpoints keep working while the kernels see one contiguous
+parameter / gradient / optimizer-state layout.  float32 only (`--doubles=False`); there is no CPU execution path.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as Fn
+from ._lib import MvaeHipError
+from .components import Component
+from .distributions import FusedParts, FusedPosterior, FusedPrior
+from .engine import StepEngine
+from .stats import BatchStatsFloat
+
+
+class Reparametrized:  # vae.py:29-35
+
+    def __init__(self, q_z, p_z, z: Tensor, data: Tuple) -> None:
+        self.q_z = q_z
+        self.p_z = p_z
+        self.z = z
+        self.data = data
+
+
+class _SlicedPosterior:
+    """q_z of one component inside a fused forward: loc/scale are slices of the tensors the kernel produced."""
+
+    def __init__(self, loc: Tensor, scale: Tensor, manifold):
+        self.loc = self.mean = loc
+        self.scale = self.stddev = scale
+        self.manifold = manifold
+
+
+class BatchStats:
+    """stats.py:144-212 over tensors the fused kernels produced ([B] bce, [ncomp, B] kl)."""
+
+    def __init__(self, bce: Tensor, component_kl: Tensor, beta: float, log_likelihood: Optional[Tensor] = None,
+                 mutual_info: Optional[Tensor] = None, cov_norm: Optional[Tensor] = None) -> None:
+        self._bce, self._component_kl, self._beta = bce, component_kl, beta
+        self._log_likelihood, self._mutual_info, self._cov_norm = log_likelihood, mutual_info, cov_norm
+
+    @property
+    def bce(self) -> Tensor:
+        return self._bce.sum(dim=0)
+
+    @property
+    def component_kl(self) -> List[Tensor]:
+        return [k.sum(dim=0) for k in self._component_kl]
+
+    @property
+    def kl(self) -> Tensor:
+        return self._component_kl.sum(dim=0).sum(dim=-1)
+
+    @property
+    def elbo(self) -> Tensor:
+        return (-self._bce - self._beta * self._component_kl.sum(dim=0)).sum(dim=0)
+
+    @property
+    def beta(self) -> float:
+        return self._beta
+
+    @property
+    def log_likelihood(self) -> Optional[Tensor]:
+        return None if self._log_likelihood is None else self._log_likelihood.sum(dim=0)
+
+    @property
+    def mutual_info(self) -> Optional[Tensor]:
+        return None if self._mutual_info is None else self._mutual_info.sum(dim=0)
+
+    @property
+    def cov_norm(self) -> Optional[Tensor]:
+        return None if self._cov_norm is None else self._cov_norm.sum(dim=0)
+
+    def convert_to_float(self) -> "EagerBatchStatsFloat":
+        return EagerBatchStatsFloat(self)
+
+
+class EagerBatchStatsFloat:  # stats.py:115-127 (eval path: syncs, like the reference)
+
+    def __init__(self, bs: BatchStats) -> None:
+        self.bce, self.kl, self.elbo = bs.bce.item(), bs.kl.item(), bs.elbo.item()
+        self.log_likelihood = None if bs.log_likelihood is None else bs.log_likelihood.item()
+        self.mutual_info = None if bs.mutual_info is None else bs.mutual_info.item()
+        self.cov_norm = None if bs.cov_norm is None else bs.cov_norm.item()
+        self.component_kl = [x.item() for x in bs.component_kl]
+        self.beta = bs.beta
+
+
+Outputs = Tuple[List[Reparametrized], Tensor, Tensor]
+
+
+class ModelVAE(nn.Module):
+
+    def __init__(self, h_dim: int, components: List[Component], dataset, scalar_parametrization: bool) -> None:
+        super().__init__()
+        self.device = torch.device("cpu")
+        self.components = nn.ModuleList(components)
+        self.reconstruction_loss = dataset.reconstruction_loss
+        self.total_z_dim = sum(component.dim for component in components)
+        for component in components:
+            component.init_layers(h_dim, scalar_parametrization=scalar_parametrization)
+        self._h_dim = h_dim
+        self._scalar_parametrization = scalar_parametrization
+        self.engine: Optional[StepEngine] = None
+        self._generator: Optional[torch.Generator] = None
+
+    # ---- device placement: build the StepEngine and alias every parameter into its flat buffer
+    def to(self, device) -> "ModelVAE":
+        self.device = torch.device(device)
+        super().to(self.device)
+        if self.device.type == "cuda":
+            self._bind_engine()
+        return self
+
+    def _comps_desc(self):
+        return [(c.LETTER, c.true_dim) for c in self.components]
+
+    def _bind_engine(self, lr: float = 1e-3) -> None:
+        raise NotImplementedError
+
+    def _alias_parameters(self, eng: StepEngine) -> None:
+        views, gviews = eng.param_views(), eng.grad_views()
+        for name, p in self.named_parameters():
+            views[name].copy_(p.data)
+            p.data = views[name]
+            if p.requires_grad:
+                p.grad = gviews[name]
+        self.engine = eng
+
+    def _need_engine(self) -> StepEngine:
+        if self.engine is None:
+            raise MvaeHipError("the model is not on a HIP device: call model.to('cuda') (there is no CPU path)")
+        return self.engine
+
+    def seed_sampler(self, seed: int) -> None:
+        self._generator = torch.Generator(device=self.device).manual_seed(seed)
+
+    def _eps(self, *lead: int) -> Tensor:
+        return torch.randn(*lead, self._need_engine().layout.eps_dim, device=self.device, generator=self._generator)
+
+    # ---- reference API
+    def encode(self, x: Tensor) -> Tensor:
+        raise NotImplementedError
+
+    def decode(self, concat_z: Tensor) -> Tensor:
+        raise NotImplementedError
+
+    def _wrap_outputs(self, out, heads: Optional[Tensor] = None) -> Outputs:
+        eng = self._need_engine()
+        reps = []
+        B = out["concat_z"].shape[0]
+        for i, c in enumerate(self.components):
+            d = eng.layout.descs[i]
+            A = c.dim
+            z = out["concat_z"][:, d.z_col:d.z_col + A]
+            q = _SlicedPosterior(out["mu"][:, d.z_col:d.z_col + A] if "mu" in out else None,
+                                 out["std"][:, d.eps_col:d.eps_col + d.logvar_dim] if "std" in out else None,
+                                 c.manifold)
+            reps.append(Reparametrized(q, FusedPrior(c, B, self.device), z, (FusedParts(kl=out["kl"][i]),)))
+        return reps, out["concat_z"], out["logits"]
+
+    def forward(self, x: Tensor, eps: Optional[Tensor] = None) -> Outputs:  # vae.py:69-80
+        eng = self._need_engine()
+        x = x.to(self.device, torch.float32)
+        eps = self._eps(x.shape[0]) if eps is None else eps
+        h = self.encode(x)
+        P = eng.param_views_raw()
+        heads = Fn.linear_forward(h, P["w_heads"], P["b_heads"])
+        co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=True, want_params=True)
+        x_ = self.decode(co["z"])
+        out = {"concat_z": co["z"], "kl": co["kl"], "mu": co["mu"], "std": co["std"], "logits": x_}
+        self._last_forward = (x, out)
+        return self._wrap_outputs(out)
+
+    def log_likelihood(self, x: Tensor, n: int = 500, eps: Optional[Tensor] = None):  # vae.py:82-123
+        eng = self._need_engine()
+        x = x.to(self.device, torch.float32)
+        B = x.shape[0]
+        eps = self._eps(n, B) if eps is None else eps
+        h = self.encode(x)
+        P = eng.param_views_raw()
+        heads = Fn.linear_forward(h, P["w_heads"], P["b_heads"])
+        co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=False, want_log_probs=True)
+        concat_z = co["z"]  # [n, B, Z]
+        logits = self.decode(concat_z)  # [n, B, D]
+        bce = Fn.bce_rows(logits, x)  # [n, B] without materialising x.repeat
+        log_p_z, log_q_z_x = co["log_p"].sum(dim=0), co["log_q"].sum(dim=0)
+        log_p_x, mi = Fn.loglik_reduce(bce, log_p_z, log_q_z_x)
+        # cov_norm (vae.py:119-121): mean_n[(x - mean_x)^T (z_n - mean_z_n)] = (x - mean_x)^T mean_n(z_n - mean_z_n)
+        zc = (concat_z - concat_z.mean(dim=1, keepdim=True)).mean(dim=0)
+        xc = x - x.mean(dim=0, keepdim=True)
+        cov, _, _ = Fn.linear_backward(xc, torch.zeros(zc.shape[1], xc.shape[1], device=self.device), zc,
+                                       need_dx=False)
+        return log_p_x, mi, cov.norm()
+
+    def compute_batch_stats(self, x_mb: Tensor, x_mb_: Tensor, reparametrized: List[Reparametrized], beta: float,
+                            likelihood_n: int = 0) -> BatchStats:  # vae.py:125-147
+        bce = Fn.bce_rows(x_mb_, x_mb.to(self.device, torch.float32))
+        kl = torch.stack([c.kl_loss(r.q_z, r.p_z, r.z, r.data) for c, r in zip(self.components, reparametrized)])
+        ll = mi = cn = None
+        if likelihood_n:
+            ll, mi, cn = self.log_likelihood(x_mb, n=likelihood_n)
+        return BatchStats(bce, kl, beta, ll, mi, cn)
+
+    def train_step(self, optimizer, x_mb: Tensor, beta: float, eps: Optional[Tensor] = None):  # vae.py:149-166
+        """zero_grad -> forward -> ELBO -> backward -> optimizer.step as ONE fused launch sequence.  Returns a lazy
+        BatchStatsFloat (no device sync until a field is read) and an empty outputs tuple."""
+        eng = self._need_engine()
+        x = x_mb.to(self.device, torch.float32)
+        eps = self._eps(x.shape[0]) if eps is None else eps
+        optimizer.bind(self)
+        eng.train_step(x, eps, float(beta), optimizer.curv_condition())
+        return BatchStatsFloat(eng, beta), (None, None, None)
+
+
+class FeedForwardVAE(ModelVAE):
+
+    def __init__(self, h_dim: int, components: List[Component], dataset, scalar_parametrization: bool) -> None:
+        super().__init__(h_dim, components, dataset, scalar_parametrization)
+        self.in_dim = dataset.in_dim
+        self.fc_e0 = nn.Linear(dataset.in_dim, h_dim)  # ffnn_vae.py:36
+        self.fc_d0 = nn.Linear(self.total_z_dim, h_dim)  # :39
+        self.fc_logits = nn.Linear(h_dim, dataset.in_dim)  # :40
+
+    def _bind_engine(self, lr: float = 1e-3) -> None:
+        trainable = [bool(getattr(c._radius_param(), "requires_grad", False)) for c in self.components]
+        eng = StepEngine(self._comps_desc(), self.in_dim, self._h_dim, self.device,
+                         scalar_parametrization=self._scalar_parametrization, radius_trainable=trainable, lr=lr)
+        self._alias_parameters(eng)
+
+    def encode(self, x: Tensor) -> Tensor:  # ffnn_vae.py:42-50
+        assert x.dim() == 2 and x.shape[1] == self.in_dim
+        return Fn.linear_forward(x, self.fc_e0.weight.detach(), self.fc_e0.bias.detach(), relu=True)
+
+    def decode(self, concat_z: Tensor) -> Tensor:  # ffnn_vae.py:52-60
+        assert concat_z.dim() >= 2
+        h = Fn.linear_forward(concat_z, self.fc_d0.weight.detach(), self.fc_d0.bias.detach(), relu=True)
+        return Fn.linear_forward(h, self.fc_logits.weight.detach(), self.fc_logits.bias.detach())
+
+
+class ConvolutionalVAE(ModelVAE):
+    """conv_vae.py:28-79 -- the CIFAR conv architecture (BASELINE config [4]) is the next row of the scope table
+    (SURVEY.md section 8, a-18); it is not built on the HIP path yet."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        raise NotImplementedError("architecture 'conv' is not part of the MI355X hot-path build yet (MLP only)")

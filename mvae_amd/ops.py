@@ -1,0 +1,129 @@
+"""Manifold interface of the reference (mt/mvae/ops/manifold.py:22-75) backed by the HIP primitives.
+
+Same class names, method names, argument meaning and conventions: tensors are [..., A] with coordinates last and
+arbitrary leading dims; RadiusManifold takes a callable returning the live radius parameter
+(component.py:125-126 `Hyperboloid(lambda: self._nradius)`); Hyperboloid / PoincareBall negate the curvature.
+The standalone primitives are forward-only (see functional._no_grad_inputs); training differentiates through the
+fused component / step operators.
+"""
+from typing import Any, Callable, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from . import functional as Fn
+
+
+class Manifold:
+    KIND = -1
+
+    def _r(self):
+        return None
+
+    def exp_map_mu0(self, x: Tensor) -> Tensor:
+        return Fn.exp_map_mu0(self.KIND, x, self._r())
+
+    def inverse_exp_map_mu0(self, x: Tensor) -> Tensor:
+        return Fn.inverse_exp_map_mu0(self.KIND, x, self._r())
+
+    def parallel_transport_mu0(self, x: Tensor, dst: Tensor) -> Tensor:
+        return Fn.parallel_transport_mu0(self.KIND, x, dst, self._r())
+
+    def inverse_parallel_transport_mu0(self, x: Tensor, src: Tensor) -> Tensor:
+        return Fn.inverse_parallel_transport_mu0(self.KIND, x, src, self._r())
+
+    def sample_projection_mu0(self, x: Tensor, at_point: Tensor) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+        return Fn.sample_projection_mu0(self.KIND, x, at_point, self._r())
+
+    def inverse_sample_projection_mu0(self, x_proj: Tensor, at_point: Tensor) -> Tuple[Tensor, Tensor]:
+        return Fn.inverse_sample_projection_mu0(self.KIND, x_proj, at_point, self._r())
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
+        raise NotImplementedError
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:
+        raise NotImplementedError
+
+    @property
+    def radius(self) -> Tensor:
+        raise NotImplementedError
+
+    @property
+    def curvature(self) -> Tensor:
+        raise NotImplementedError
+
+
+class RadiusManifold(Manifold):
+
+    def __init__(self, radius: Callable[[], Tensor]):
+        super().__init__()
+        self._radius = radius
+
+    def _r(self):
+        return self._radius()
+
+    @property
+    def radius(self) -> Tensor:  # manifold.py:73-75
+        return torch.clamp(torch.relu(self._radius().detach()), min=1e-8, max=1e8)
+
+    @property
+    def curvature(self) -> Tensor:  # manifold.py:69-71
+        return 1.0 / self.radius.pow(2)
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:  # hyperbolics.py:68-69 | spherical.py:70-71
+        e0 = torch.zeros(shape, **kwargs)
+        e0[..., 0] = 1
+        return e0 * self.radius.to(e0.device)
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
+        return Fn.logdet(self.KIND, data[0], None, None, self._r())
+
+
+class Hyperboloid(RadiusManifold):
+    KIND = _lib.HYPERBOLOID
+
+    @property
+    def curvature(self) -> Tensor:  # hyperbolics.py:53-55
+        return -super().curvature
+
+
+class Sphere(RadiusManifold):
+    KIND = _lib.SPHERE
+
+
+class PoincareBall(RadiusManifold):
+    KIND = _lib.POINCARE
+
+    @property
+    def curvature(self) -> Tensor:  # poincare.py:30-32
+        return -super().curvature
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:  # poincare.py:112-113
+        return torch.zeros(shape, **kwargs)
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:  # poincare.py:55-89
+        return Fn.logdet(self.KIND, None, mu, z, self._r())
+
+
+class Euclidean(Manifold):
+    KIND = _lib.EUCLIDEAN
+
+    @property
+    def radius(self):  # euclidean.py:26-32
+        return 0
+
+    @property
+    def curvature(self):
+        return 0
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:
+        return torch.zeros(shape, **kwargs)
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
+        return torch.zeros_like(mu)  # euclidean.py:58-59
+
+
+def lorentz_to_poincare(x: Tensor, radius: Tensor) -> Tensor:
+    """hyperbolics.py:151-152 (used by the embedding export, train.py:271); a two-op torch expression on purpose."""
+    return radius * x[..., 1:] / (radius + x[..., 0:1])

@@ -1,0 +1,97 @@
+"""`python -m mvae_amd.run` -- the reference's `python -m mt.examples.run` (run.py:28-186) on the MI355X path.
+Same flags, same header / epoch log lines; `--doubles` defaults to False here (the HIP path computes in float32)."""
+import argparse
+import datetime
+import os
+
+import torch
+
+from . import utils
+from .data import create_dataset
+from .models import ConvolutionalVAE, FeedForwardVAE
+from .trainer import Trainer
+
+
+def str2bool(v: str) -> bool:  # mt/utils.py:19-26
+    v = v.lower()
+    if v == "true":
+        return True
+    if v == "false":
+        return False
+    raise argparse.ArgumentTypeError(f"Boolean value expected, got '{v}'.")
+
+
+def main(argv=None) -> None:
+    p = argparse.ArgumentParser(description="M-VAE runner (MI355X).")
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--data", type=str, default="./data")
+    p.add_argument("--batch_size", type=int, default=100)
+    p.add_argument("--learning_rate", type=float, default=1e-3)
+    p.add_argument("--epochs", type=int, default=500)
+    p.add_argument("--warmup", type=int, default=100)
+    p.add_argument("--lookahead", type=int, default=50)
+    p.add_argument("--model", type=str, default="h2,s2,e2")
+    p.add_argument("--architecture", type=str, default="ff")
+    p.add_argument("--universal", type=str2bool, default=False)
+    p.add_argument("--dataset", type=str, default="mnist")
+    p.add_argument("--h_dim", type=int, default=400)
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--show_embeddings", type=int, default=0)
+    p.add_argument("--export_embeddings", type=int, default=0)
+    p.add_argument("--test_every", type=int, default=0)
+    p.add_argument("--train_statistics", type=str2bool, default=False)
+    p.add_argument("--scalar_parametrization", type=str2bool, default=False)
+    p.add_argument("--fixed_curvature", type=str2bool, default=True)
+    p.add_argument("--doubles", type=str2bool, default=False)
+    p.add_argument("--beta_start", type=float, default=1.0)
+    p.add_argument("--beta_end", type=float, default=1.0)
+    p.add_argument("--beta_end_epoch", type=int, default=1)
+    p.add_argument("--likelihood_n", type=int, default=500)
+    args = p.parse_args(argv)
+
+    if args.seed:
+        print("Using pre-set random seed:", args.seed)
+        utils.set_seeds(args.seed)
+    if not torch.cuda.is_available():
+        raise SystemExit("mvae_amd needs a HIP device: the MI355X path has no CPU fallback "
+                         "(the reference falls back to cpu here, run.py:91-93).")
+    if args.doubles:
+        raise SystemExit("--doubles=True is not supported: the HIP path computes in float32.")
+    if args.universal:
+        raise SystemExit("--universal needs the 'u' component, which is not part of this build yet.")
+    device = torch.device(args.device)
+    print("Running on:", device, flush=True)
+
+    dataset = create_dataset(args.dataset, args.batch_size, args.data, device=device)
+    print("#####")
+    cur_time = datetime.datetime.utcnow().isoformat()
+    components = utils.parse_components(args.model, args.fixed_curvature)
+    model_name = utils.canonical_name(components)
+    print(f"VAE Model: {model_name}; Epochs: {args.epochs}; Time: {cur_time}; Fixed curvature: {args.fixed_curvature}; "
+          f"Dataset: {args.dataset}")
+    print("#####", flush=True)
+    chkpt_dir = f"./chkpt/vae-{args.dataset}-{model_name}-{cur_time}"
+    os.makedirs(chkpt_dir)
+    if args.architecture == "ff":
+        model_cls = FeedForwardVAE
+    elif args.architecture == "conv":
+        model_cls = ConvolutionalVAE
+    else:
+        raise ValueError(f"Unknown --architecture='{args.architecture}'. Possible options: 'ff', 'conv'.")
+    model = model_cls(h_dim=args.h_dim, components=components, dataset=dataset,
+                      scalar_parametrization=args.scalar_parametrization).to(device)
+    if args.seed:
+        model.seed_sampler(args.seed)
+    trainer = Trainer(model, img_dims=dataset.img_dims, chkpt_dir=chkpt_dir, test_every=args.test_every)
+    optimizer = trainer.build_optimizer(learning_rate=args.learning_rate, fixed_curvature=args.fixed_curvature)
+    train_loader, test_loader = dataset.create_loaders(seed=args.seed)
+    betas = utils.linear_betas(args.beta_start, args.beta_end, end_epoch=args.beta_end_epoch, epochs=args.epochs)
+    trainer.train_stopping(optimizer=optimizer, train_data=train_loader, eval_data=test_loader, warmup=args.warmup,
+                           lookahead=args.lookahead, betas=betas, likelihood_n=args.likelihood_n,
+                           max_epochs=args.epochs)
+    print(flush=True)
+    print("Done.", flush=True)
+
+
+if __name__ == "__main__":
+    main()

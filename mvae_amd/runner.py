@@ -9,6 +9,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
+from .distributed import DataParallelStep
 from .engine import StepEngine
 
 
@@ -24,19 +25,17 @@ class StepRunner:
         self.gs = int(graph_steps)
         self.cursor = 0  # index of the next resident batch
         self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.dp = DataParallelStep(eng) if self.world > 1 else None
         if self.gs > 0:
             if self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
             self._capture()
 
     def _one(self, i: int) -> None:
-        if self.world == 1:
+        if self.dp is None:
             self.eng.train_step(self.xs[i], self.eps[i], self.beta, self.do_curv)
         else:
-            import torch.distributed as dist
-            self.eng.forward_backward(self.xs[i], self.eps[i], self.beta)
-            dist.all_reduce(self.eng.grads, op=dist.ReduceOp.SUM)
-            self.eng.optimizer_step(self.do_curv, batch=self.xs.shape[1])
+            self.dp.train_step(self.xs[i], self.eps[i], self.beta, self.do_curv)
 
     def _capture(self) -> None:
         # snapshot the state the warm-up launches below will advance, so that capturing has no net effect

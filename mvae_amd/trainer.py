@@ -1,0 +1,189 @@
+"""Trainer shell of the reference (mt/mvae/models/train.py:34-360) around the fused HIP step: epoch loop, radius
+warm-up, beta schedule, early stopping, rolling checkpoints (reference-compatible state-dict files), stdout format."""
+import os
+import warnings
+from typing import Any, Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .components import HyperbolicComponent, PoincareComponent, SphericalComponent
+from .models import ModelVAE
+from .stats import EpochStats
+
+
+class CurvatureOptimizer:
+    """mt/mvae/utils.py:148-180 + Trainer.build_optimizer (train.py:327-360): Adam(lr) on the network parameters,
+    SGD(1e-4) on `_nradius` / `_pradius` when `should_do_curvature_step()`.  The arithmetic runs inside the fused
+    step (gradient epilogues) or in `mvae_step_optimizer`; this object carries the hyper-parameters and the gate."""
+
+    def __init__(self, learning_rate: float, curvature_lr: float, should_do_curvature_step) -> None:
+        self.learning_rate, self.curvature_lr = float(learning_rate), float(curvature_lr)
+        self.curv_condition = should_do_curvature_step
+        self._model: Optional[ModelVAE] = None
+
+    def bind(self, model: ModelVAE) -> None:
+        if self._model is not model:
+            eng = model._need_engine()
+            if eng.lr != self.learning_rate or eng.curvature_lr != self.curvature_lr:
+                eng.set_lr(self.learning_rate, self.curvature_lr)
+            self._model = model
+
+    def zero_grad(self) -> None:  # gradients are overwritten, never accumulated
+        pass
+
+    def step(self, closure: Optional[Any] = None) -> None:
+        self._model._need_engine().optimizer_step(self.curv_condition())
+
+
+class Trainer:
+
+    def __init__(self, model: ModelVAE, img_dims=None, chkpt_dir: str = "./chkpt", train_statistics: bool = False,
+                 show_embeddings: int = 0, export_embeddings: int = 0, test_every: int = 0) -> None:
+        self.model = model
+        self.chkpt_dir = chkpt_dir
+        self.epoch = 0
+        self.global_step = 0
+        self.test_every = test_every
+        os.makedirs(chkpt_dir, exist_ok=True)
+
+    # ---- checkpoints (train.py:57-77): model weights only, `{epoch}.chkpt`
+    def _path(self, epoch: int) -> str:
+        return os.path.join(self.chkpt_dir, f"{epoch}.chkpt")
+
+    def _load_epoch(self, epoch: int) -> None:
+        self.model.load_state_dict(torch.load(self._path(epoch), map_location=self.model.device))
+
+    def _save_epoch(self, epoch: int) -> None:
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, self._path(epoch))
+
+    def _delete_epoch(self, epoch: int) -> None:
+        if os.path.isfile(self._path(epoch)):
+            os.remove(self._path(epoch))
+
+    def _update_checkpoints(self, lookahead: int) -> None:
+        if self.epoch - lookahead - 1 >= 0:
+            self._delete_epoch(self.epoch - lookahead - 1)
+        self._save_epoch(self.epoch)
+
+    @staticmethod
+    def _should_stop(results: Dict[int, EpochStats], epoch: int, lookahead: int, max_epoch: int) -> Optional[int]:
+        """train.py:79-95."""
+        stop = epoch - lookahead
+        elbos = np.asarray([float(results[i].elbo) for i in range(stop + 1, epoch + 1)])
+        best = int(np.argmax(elbos))
+        if elbos[best] < float(results[stop].elbo):
+            return stop
+        if epoch == max_epoch:
+            return stop + 1 + best
+        return None
+
+    def get_beta(self, betas: Optional[Sequence[float]]) -> float:
+        if betas is None:
+            return 1.0
+        return float(betas[-1] if self.epoch >= len(betas) else betas[self.epoch])
+
+    def build_optimizer(self, learning_rate: float, fixed_curvature: bool) -> CurvatureOptimizer:
+        def condition() -> bool:  # train.py:357-358
+            return (not fixed_curvature) and (self.epoch >= 10)
+        has_radii = any(c._radius_param() is not None for c in self.model.components)
+        if not fixed_curvature and not has_radii:
+            warnings.warn("Fixed curvature disabled, but found no curvature parameters. Did you mean to set "
+                          "fixed=True, or not?")
+        return CurvatureOptimizer(learning_rate, 1e-4, condition)
+
+    # ---- epochs
+    def _train_epoch(self, optimizer: CurvatureOptimizer, train_data, beta: float) -> EpochStats:
+        print(f"\tTrainEpoch {self.epoch}:\t", end="")
+        self.model.train()
+        eng = self.model._need_engine()
+        if self.epoch < 10:  # train.py:189-194 (applies to fixed-curvature models too)
+            if any(isinstance(c, (SphericalComponent, PoincareComponent, HyperbolicComponent))
+                   for c in self.model.components):
+                eng.set_radii(11 - self.epoch)
+        eng.read_stats(reset=True)
+        for x_mb, _ in train_data:
+            self.model.train_step(optimizer, x_mb, beta=beta)
+            self.global_step += 1
+        sums = eng.read_stats(reset=True)["sum"]  # the only device sync of the epoch
+        epoch_stats = EpochStats(sums, length=len(train_data.dataset), beta=beta)
+        print(self._epoch_dict(epoch_stats), flush=True)
+        return epoch_stats
+
+    def _epoch_dict(self, epoch_stats: EpochStats) -> Dict[str, float]:
+        d = epoch_stats.to_print()
+        for i, component in enumerate(self.model.components):
+            d[f"{component.summary_name(i)}/curvature"] = float(component.manifold.curvature)
+        return d
+
+    def _test_epoch(self, test_data, likelihood_n: int, beta: float) -> EpochStats:
+        print(f"\tEpoch {self.epoch}:\t", end="")
+        self.model.eval()
+        sums = {"bce": 0.0, "kl": 0.0, "elbo": 0.0, "component_kl": [0.0] * len(self.model.components)}
+        ll = mi = cn = 0.0
+        with torch.no_grad():
+            for x_mb, _ in test_data:
+                reps, _, x_ = self.model(x_mb)
+                st = self.model.compute_batch_stats(x_mb, x_, reps, likelihood_n=likelihood_n, beta=beta)
+                f = st.convert_to_float()
+                sums["bce"] += f.bce
+                sums["kl"] += f.kl
+                sums["elbo"] += f.elbo
+                sums["component_kl"] = [a + b for a, b in zip(sums["component_kl"], f.component_kl)]
+                ll += f.log_likelihood or 0.0
+                mi += f.mutual_info or 0.0
+                cn += f.cov_norm or 0.0
+        epoch_stats = EpochStats(sums, length=len(test_data.dataset), beta=beta, log_likelihood=ll, mutual_info=mi,
+                                 cov_norm=cn)
+        print(self._epoch_dict(epoch_stats), flush=True)
+        self.model.train()
+        return epoch_stats
+
+    def _try_test_during_train(self, test_results, eval_data, likelihood_n, betas) -> None:
+        if self.test_every > 0 and self.epoch % self.test_every == 0:
+            test_results[self.epoch - 1] = self._test_epoch(eval_data, likelihood_n, self.get_beta(betas))
+
+    def train_epochs(self, optimizer, train_data, eval_data, betas, epochs: int = 300, likelihood_n: int = 500):
+        test_results: Dict[int, EpochStats] = {}
+        for _ in range(epochs):
+            self._train_epoch(optimizer, train_data, beta=self.get_beta(betas))
+            self.epoch += 1
+            self._try_test_during_train(test_results, eval_data, likelihood_n, betas)
+        test_results[self.epoch - 1] = self._test_epoch(eval_data, likelihood_n, self.get_beta(betas))
+        self._save_epoch(self.epoch)
+        return test_results
+
+    def train_stopping(self, optimizer, train_data, eval_data, betas, warmup: int = 5, lookahead: int = 2,
+                       likelihood_n: int = 500, max_epochs: int = 1000):
+        """train.py:105-154."""
+        assert warmup >= lookahead
+        train_results: Dict[int, EpochStats] = {}
+        test_results: Dict[int, EpochStats] = {}
+        for _ in range(warmup):
+            train_results[self.epoch] = self._train_epoch(optimizer, train_data, beta=self.get_beta(betas))
+            self._update_checkpoints(lookahead)
+            self.epoch += 1
+            self._try_test_during_train(test_results, eval_data, likelihood_n, betas)
+        stop_epoch = None
+        for _ in range(warmup, max_epochs):
+            train_results[self.epoch] = self._train_epoch(optimizer, train_data, beta=self.get_beta(betas))
+            stop_epoch = Trainer._should_stop(train_results, self.epoch, lookahead, max_epoch=max_epochs - 1)
+            self._update_checkpoints(lookahead)
+            if stop_epoch:
+                break
+            self.epoch += 1
+            self._try_test_during_train(test_results, eval_data, likelihood_n, betas)
+        if not stop_epoch:
+            warnings.warn("Did not stop using early stopping.")
+            stop_epoch = self.epoch - 1 if not os.path.isfile(self._path(self.epoch)) else self.epoch
+        self._load_epoch(stop_epoch)
+        last_epoch = self.epoch
+        self.epoch = stop_epoch
+        print(f"Stopped at epoch: {stop_epoch}. Deleting epochs [{stop_epoch + 1}, {last_epoch}] and "
+              f"[{last_epoch - lookahead},{stop_epoch - 1}].")
+        for e in range(stop_epoch + 1, last_epoch + 1):
+            self._delete_epoch(e)
+        for e in range(last_epoch - lookahead, stop_epoch):
+            self._delete_epoch(e)
+        test_results[stop_epoch] = self._test_epoch(eval_data, likelihood_n, self.get_beta(betas))
+        return test_results

@@ -1,0 +1,99 @@
+"""CPU tests of the host-side mirror of the reference API: model-string grammar, parameter naming/counting, the
+early-stopping rule, the CLI surface -- everything that does not need a kernel launch."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_json
+from mvae_amd import utils
+from mvae_amd._lib import MvaeHipError
+from mvae_amd.models import ConvolutionalVAE, FeedForwardVAE
+from mvae_amd.trainer import Trainer
+
+
+class _DS:
+    in_dim = 784
+
+    def reconstruction_loss(self, a, b):
+        raise AssertionError
+
+
+def test_parse_components_table():
+    """Reference tests/mvae/test_utils.py + golden table recorded from the reference parser."""
+    tab = load_json("g5_parser.json")
+    for s, ref in tab["parse"].items():
+        if any(c["shortcut"][0] in "udc" for c in ref["components"]):
+            with pytest.raises(NotImplementedError):
+                utils.parse_components(s, False)
+            continue
+        comps = utils.parse_components(s, fixed_curvature=False)
+        assert utils.canonical_name(comps) == ref["canonical"]
+        for c, r in zip(comps, ref["components"]):
+            assert type(c).__name__ == r["class"]
+            assert (c.dim, c.true_dim, c._shortcut()) == (r["dim"], r["true_dim"], r["shortcut"])
+            assert [n for n, _ in c.named_parameters()] == r["params"]
+    for s, err in tab["errors"].items():
+        with pytest.raises({"ValueError": ValueError, "NotImplementedError": NotImplementedError}[err]):
+            utils.parse_components(s, False)
+    assert utils.parse_components("", False) == []
+    for k, v in tab["linear_betas"].items():
+        a, b, c, d = k.split(",")
+        got = utils.linear_betas(float(a), float(b), int(c), int(d))
+        assert np.allclose(got[:len(v)], v)
+
+
+def test_fixed_curvature_freezes_radii():
+    comps = utils.parse_components("h2,s2,p2,e2", fixed_curvature=True)
+    assert [c._radius_param().requires_grad for c in comps[:3]] == [False] * 3
+    assert comps[3]._radius_param() is None
+    comps = utils.parse_components("h2,s2", fixed_curvature=False)
+    assert all(c._radius_param().requires_grad for c in comps)
+    for c in comps:
+        c.init_layers(8, scalar_parametrization=False)  # the manifold is created here, as in the reference
+    assert float(comps[0].manifold.curvature) == -1.0 and float(comps[1].manifold.curvature) == 1.0
+
+
+@pytest.mark.parametrize("model", ["h2,s2,e2", "6h2,6s2,6e2", "e6"])
+def test_state_dict_contract(model):
+    """Parameter names, shapes and registration order are the reference's (checkpoint compatibility)."""
+    tab = load_json("g5_parser.json")["state_shapes"]
+    torch.manual_seed(0)
+    m = FeedForwardVAE(400, utils.parse_components(model, False), _DS(), False)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == tab[f"{model}|ff"]
+    assert m.total_z_dim == sum(c.dim for c in m.components)
+
+
+def test_no_cpu_execution_path():
+    m = FeedForwardVAE(16, utils.parse_components("h2,e2", False), _DS(), False)
+    with pytest.raises(MvaeHipError):
+        m(torch.zeros(2, 784))
+    with pytest.raises(NotImplementedError):
+        ConvolutionalVAE(8192, [], _DS(), False)
+
+
+def test_should_stop_rule():
+    """train.py:79-95 restated: stop when no epoch in the lookahead window beats the window start."""
+    class R:
+        def __init__(self, e):
+            self.elbo = e
+    res = {i: R(v) for i, v in enumerate([-10, -9, -8, -8.5, -8.6, -8.7])}
+    assert Trainer._should_stop(res, 5, 3, 100) == 2
+    assert Trainer._should_stop(res, 4, 3, 100) is None
+    assert Trainer._should_stop(res, 4, 3, 4) == 2
+    res2 = {i: R(v) for i, v in enumerate([-10, -9, -8, -7])}
+    assert Trainer._should_stop(res2, 3, 2, 3) == 3
+
+
+def test_cli_flags_match_reference():
+    import argparse
+    from mvae_amd import run
+    flags = ("--device --data --batch_size --learning_rate --epochs --warmup --lookahead --model --architecture "
+             "--universal --dataset --h_dim --seed --show_embeddings --export_embeddings --test_every "
+             "--train_statistics --scalar_parametrization --fixed_curvature --doubles --beta_start --beta_end "
+             "--beta_end_epoch --likelihood_n").split()
+    src = open(run.__file__).read()
+    for f in flags:  # mt/examples/run.py:30-84
+        assert f'"{f}"' in src, f
+    assert run.str2bool("True") is True and run.str2bool("false") is False
+    with pytest.raises(argparse.ArgumentTypeError):
+        run.str2bool("maybe")

@@ -1,0 +1,213 @@
+"""GPU tests of the host-side mirror: the reference's class API (Manifold / Component / ModelVAE / Trainer) driving the
+HIP kernels, against the oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, assert_close_after_adam, load_npz
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+class _DS:
+    in_dim = 784
+
+    def __init__(self, in_dim=784):
+        self.in_dim = in_dim
+
+    def reconstruction_loss(self, x_, x):
+        from mvae_amd import functional as Fn
+        return Fn.bce_rows(x_, x)
+
+
+def _cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def test_manifold_classes_vs_golden(dev):
+    from mvae_amd.ops import Euclidean, Hyperboloid, Sphere
+    g = load_npz("g1_primitives.npz")
+    R = torch.nn.Parameter(torch.tensor(2.0, device=dev))
+    for name, man in [("H", Hyperboloid(lambda: R)), ("S", Sphere(lambda: R)), ("E", Euclidean())]:
+        k = f"{name}/R2/d5/f32/"
+        x, v = T(g[k + "x"]).to(dev), T(g[k + "v"]).to(dev)
+        with torch.no_grad():
+            mu = man.exp_map_mu0(x)
+            z, (u, v_) = man.sample_projection_mu0(v, at_point=mu)
+        assert_close(_cpu(mu), g[k + "mu"], RTOL, name + " mu")
+        assert_close(_cpu(z), g[k + "z"], RTOL, name + " z")
+        if name != "E":
+            assert_close(_cpu(man.logdet(mu, None, z, (u, v_))), g[k + "logdet_u"], RTOL, name + " logdet", atol_frac=1e-4)
+            assert float(man.radius) == 2.0
+    assert float(Hyperboloid(lambda: R).curvature) == -0.25 and float(Sphere(lambda: R).curvature) == 0.25
+    with pytest.raises(NotImplementedError):  # differentiable use goes through the fused operators
+        Hyperboloid(lambda: R).exp_map_mu0(torch.zeros(2, 2, device=dev, requires_grad=True))
+
+
+def test_component_api(dev):
+    """Component.forward -> q.rsample_with_parts -> kl_loss, the reference's call sequence (vae.py:73-76,137)."""
+    from mvae_amd import utils
+    from oracle import model as M
+    comp = utils.parse_components("h3", fixed_curvature=False)[0]
+    comp.init_layers(16, scalar_parametrization=False)
+    comp.to(dev)
+    comp._nradius.data.fill_(2.0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 16, generator=g)
+    eps = torch.randn(8, 3, generator=g)
+    q_z, p_z, (loc, scale) = comp(x.to(dev))
+    z, data = q_z.rsample_with_parts(eps=eps.to(dev))
+    kl = comp.kl_loss(q_z, p_z, z, data)
+    mean_raw = torch.nn.functional.linear(x, comp.fc_mean.weight.cpu(), comp.fc_mean.bias.cpu())
+    lv_raw = torch.nn.functional.linear(x, comp.fc_logvar.weight.cpu(), comp.fc_logvar.bias.cpu())
+    o = M.component_forward(M.ComponentSpec("h", 3), mean_raw, lv_raw, eps, torch.tensor(2.0))
+    assert_close(_cpu(z), o.z.detach().numpy(), RTOL, "z")
+    assert_close(_cpu(kl), o.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    assert_close(_cpu(loc), o.mu.detach().numpy(), RTOL, "loc")
+    assert_close(_cpu(scale), o.std.detach().numpy(), RTOL, "scale")
+    assert tuple(p_z.loc.shape) == (8, 4) and float(p_z.loc[0, 0]) == 2.0
+
+
+def _model(dev, model_str, in_dim, h_dim, fixed=False, scalar=False):
+    from mvae_amd import synthetic, utils
+    from mvae_amd.models import FeedForwardVAE
+    from oracle import model as M
+    spec = M.Spec(model_str, in_dim=in_dim, h_dim=h_dim, fixed_curvature=fixed, scalar_parametrization=scalar)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    m = FeedForwardVAE(h_dim, utils.parse_components(model_str, fixed), _DS(in_dim), scalar)
+    m.load_state_dict(state0)
+    m.to(dev)
+    return m, spec, state0
+
+
+def test_model_train_step_vs_oracle(dev):
+    """ModelVAE.train_step through the class API (parameters aliased into the flat HBM buffer) == the oracle."""
+    from mvae_amd import synthetic
+    from mvae_amd.trainer import Trainer
+    from oracle import model as M
+    m, spec, state0 = _model(dev, "h2,s2,e2", 784, 400)
+    assert list(m.state_dict().keys()) == [n for n, _ in spec.named_shapes()]
+    trainer = Trainer(m, chkpt_dir="/tmp/mvae_test_chkpt")
+    trainer.epoch = 12
+    opt = trainer.build_optimizer(learning_rate=1e-3, fixed_curvature=False)
+    orc = M.StepOracle(spec, state0)
+    xs = synthetic.binary_batches(3, 128, 784)
+    eps = synthetic.eps_batches(3, 128, 6)
+    for s in range(3):
+        ref = orc.train_step(xs[s], eps[s], 1.0, epoch=12)
+        stats, _ = m.train_step(opt, xs[s], beta=1.0, eps=eps[s].to(dev))
+        assert_close(stats.elbo, float(ref.elbo.detach()), RTOL, f"elbo step {s}")
+        assert_close(stats.component_kl, ref.kl.sum(1).detach().numpy(), RTOL, "component kl", atol_frac=1e-4)
+    for n, p in m.named_parameters():
+        assert p.data_ptr() >= m.engine.params.data_ptr()  # still a view of the flat buffer
+        assert_close_after_adam(_cpu(p), orc.P[n].detach().numpy(), 1e-3, 3, "param " + n)
+
+
+def test_model_forward_and_batch_stats(dev):
+    from mvae_amd import synthetic
+    from oracle import model as M
+    m, spec, state0 = _model(dev, "h2,s2,e2,p2", 784, 64)
+    x = synthetic.binary_batches(1, 32, 784)[0]
+    eps = synthetic.eps_batches(1, 32, 8)[0]
+    P = {k: v.clone() for k, v in state0.items()}
+    ref = M.forward(spec, P, x, eps, beta=0.5)
+    with torch.no_grad():
+        reps, concat_z, x_ = m(x.to(dev), eps=eps.to(dev))
+        bs = m.compute_batch_stats(x.to(dev), x_, reps, beta=0.5)
+    assert_close(_cpu(x_), ref.logits.numpy(), RTOL, "logits")
+    assert_close(_cpu(concat_z), ref.concat_z.numpy(), RTOL, "concat_z")
+    assert_close(float(bs.elbo), float(ref.elbo), RTOL, "elbo")
+    assert_close(float(bs.bce), float(ref.bce.sum()), RTOL, "bce")
+    for i, r in enumerate(reps):
+        assert_close(_cpu(r.q_z.loc), ref.comps[i].mu.numpy(), RTOL, f"loc {i}")
+        assert_close(_cpu(m.components[i].kl_loss(r.q_z, r.p_z, r.z, r.data)), ref.kl[i].numpy(), RTOL, f"kl {i}",
+                     atol_frac=1e-4)
+
+
+@pytest.mark.parametrize("name,model", [("h2s2e2", "h2,s2,e2"), ("e6", "e6"), ("h5s3e4", "h5,s3,e4")])
+def test_log_likelihood_vs_golden(dev, name, model):
+    """ModelVAE.log_likelihood (vae.py:82-123) against the reference's own output (n=8 importance samples)."""
+    g = load_npz("g4_loglik.npz")
+    m, spec, _ = _model(dev, model, 32, 16)
+    key = f"{name}/f32/"
+    with torch.no_grad():
+        lp, mi, cn = m.log_likelihood(T(g[key + "x"], torch.float32).to(dev), n=8, eps=T(g[key + "eps"]).to(dev))
+    assert_close(_cpu(lp), g[key + "log_px"], RTOL, "log_px")
+    assert_close(_cpu(mi), g[key + "mi"], RTOL, "mi", atol_frac=1e-4)
+    assert_close(float(cn), float(g[key + "cov_norm"]), 5 * RTOL, "cov_norm")
+
+
+def test_log_likelihood_full_size_properties(dev):
+    """n=500, B=128 (the reference's eval setting): finite, log p(x) <= 0 for binary data, IWAE bound >= ELBO-ish,
+    and independent of how the sample dim is chunked."""
+    from mvae_amd import synthetic
+    m, spec, _ = _model(dev, "h2,s2,e2", 784, 400)
+    x = synthetic.binary_batches(1, 128, 784)[0].to(dev)
+    eps = torch.randn(500, 128, 6, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        lp, mi, cn = m.log_likelihood(x, n=500, eps=eps)
+        lp_a, _, _ = m.log_likelihood(x, n=250, eps=eps[:250])
+        lp_b, _, _ = m.log_likelihood(x, n=250, eps=eps[250:])
+    assert torch.isfinite(lp).all() and torch.isfinite(mi).all() and torch.isfinite(cn)
+    assert (lp <= 0).all()
+    merged = torch.logsumexp(torch.stack([lp_a, lp_b]), dim=0) - np.log(2.0)
+    assert float((merged - lp).abs().max()) < 1e-3 * float(lp.abs().max())
+
+
+def test_trainer_epochs_and_checkpoints(dev, tmp_path):
+    """Two tiny epochs through Trainer.train_stopping-style calls: finite stats, warm-up radii (train.py:189-194:
+    K = +-1/(11-epoch)^2 even for fixed curvature, reference test_vae.py:296-300), reference-compatible checkpoint."""
+    from mvae_amd import utils
+    from mvae_amd.data import DeviceLoader
+    from mvae_amd.models import FeedForwardVAE
+    from mvae_amd.trainer import Trainer
+    from mvae_amd import synthetic
+    x = (synthetic.digits_like_batches(4, 64).reshape(-1, 784) * 255).to(torch.uint8).to(dev)
+    y = torch.zeros(256, dtype=torch.int64, device=dev)
+    train = DeviceLoader(x, y, 64, train=True, binarize=True, seed=1)
+    test = DeviceLoader(x[:64], y[:64], 64, train=False, binarize=True)
+    torch.manual_seed(0)
+    m = FeedForwardVAE(32, utils.parse_components("h2,s2,e2", True), _DS(), False).to(dev)
+    m.seed_sampler(3)
+    tr = Trainer(m, chkpt_dir=str(tmp_path))
+    opt = tr.build_optimizer(1e-3, fixed_curvature=True)
+    res = tr.train_epochs(opt, train, test, betas=None, epochs=2, likelihood_n=4)
+    st = res[1]
+    assert np.isfinite([st.bce, st.kl, st.elbo, st.log_likelihood]).all()
+    assert st.log_likelihood < 10 and st.log_likelihood > -1e4  # reference test_vae.py:285-304 bounds
+    assert abs(float(m.components[0].manifold.curvature) + 0.01) < 1e-6  # R = 11 - 1 = 10 after 2 epochs
+    assert abs(float(m.components[1].manifold.curvature) - 0.01) < 1e-6
+    sd = torch.load(os.path.join(str(tmp_path), "2.chkpt"))
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m2 = FeedForwardVAE(32, utils.parse_components("h2,s2,e2", True), _DS(), False)
+    m2.load_state_dict(sd)
+    m2.to(dev)
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+
+
+def test_training_improves_elbo(dev):
+    """A few hundred steps on structured synthetic images: the ELBO per sample goes up substantially."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    xs = synthetic.digits_like_batches(50, 128).to(dev)
+    eps = synthetic.eps_batches(50, 128, 6).to(dev)
+    first = None
+    for it in range(400):
+        eng.train_step(xs[it % 50], eps[it % 50], 1.0, it >= 100)
+        if it == 0:
+            first = eng.read_stats()["last"]["elbo"] / 128
+    last = eng.read_stats()["last"]["elbo"] / 128
+    assert np.isfinite(last) and last > first + 100, (first, last)

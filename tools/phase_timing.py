@@ -1,0 +1,27 @@
+"""Dev tool: phase timestamps of the latent kernels (needs a -DMV_DBG_TIMING build passed via MVAE_HIP_LIB)."""
+import ctypes as C
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvae_amd import _lib, synthetic
+from mvae_amd.engine import StepEngine
+lib = _lib.load()
+dev = torch.device("cuda:0")
+eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+xs = synthetic.binary_batches(8, 128, 784).to(dev); eps = synthetic.eps_batches(8, 128, 6).to(dev)
+for i in range(20): eng.train_step(xs[i % 8], eps[i % 8], 1.0, True)
+torch.cuda.synchronize()
+acc = None
+N = 50
+for i in range(N):
+    eng.train_step(xs[i % 8], eps[i % 8], 1.0, True)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    lib.mvae_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    lib.mvae_debug_read(buf, 16)
+    v = [int(x) for x in buf]
+    d = [(v[1]-v[0]), (v[2]-v[1]), (v[3]-v[2]), (v[4]-v[3]), (v[9]-v[8]), (v[10]-v[9]), (v[11]-v[10]), (v[12]-v[11])]
+    acc = d if acc is None else [a + b for a, b in zip(acc, d)]
+names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:comps", "bwd:dh"]
+for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
