@@ -7,7 +7,8 @@
 Workload (BASELINE.json configs[1]): MNIST shapes, model "h2,s2,e2", learnable curvature, MLP h_dim 400, batch 128 per
 GPU, float32, epoch >= 10 state (radii 2.0, curvature SGD active).  One "step" = ModelVAE.train_step: forward, ELBO,
 backward, Adam + SGD on the radii (+ gradient all-reduce when N > 1).  Inputs (binarised x, eps) are synthetic
-(mvae_amd/synthetic.py) and resident in HBM before the timed region; weights are the synthetic init.
+(mvae_amd/synthetic.py: MNIST-shaped stroke images, dynamically binarised) and resident in HBM before the timed
+region; weights are the synthetic init.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -48,30 +49,49 @@ def algorithmic_per_launch(P):
     }
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The oracle (CPU restatement of the reference path, validated against golden vectors) timed on this box's host
-    cores: same model, same synthetic inputs, same step (fwd, ELBO, bwd, Adam + curvature SGD)."""
+def cpu_baseline(seconds_budget=12.0):
+    """The oracle (CPU restatement of the reference path, pinned to golden vectors recorded from the reference) timed
+    on this box's host cores: same model, same synthetic inputs, same step (fwd, ELBO, bwd, Adam + curvature SGD).
+    torch's default (one thread per core) oversubscribes this op-dispatch-bound workload badly on a many-core host,
+    so a short probe picks the fastest intra-op thread count and that one is timed and reported."""
     from mvae_amd import synthetic
     from oracle import model as M
     spec = M.Spec(MODEL, in_dim=D, h_dim=H, fixed_curvature=False)
     state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
     n_data = 16
-    xs = synthetic.binary_batches(n_data, B, D)
+    xs = synthetic.digits_like_batches(n_data, B)
     eps = synthetic.eps_batches(n_data, B, spec.total_true_dim)
-    orc = M.StepOracle(spec, state0)
-    for s in range(5):
-        orc.train_step(xs[s % n_data], eps[s % n_data], 1.0, epoch=12)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        orc.train_step(xs[n % n_data], eps[n % n_data], 1.0, epoch=12)
-        n += 1
-        if n >= 50 and time.perf_counter() - t0 > seconds_budget:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "ELBO-steps/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of the same h2,s2,e2 B=128 workload in {dt:.1f}s (oracle = CPU restatement of "
-                      "ModelVAE.train_step, float32)"}
+
+    def run(seconds, min_steps):
+        orc = M.StepOracle(spec, state0)
+        for s in range(3):
+            orc.train_step(xs[s % n_data], eps[s % n_data], 1.0, epoch=12)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            orc.train_step(xs[n % n_data], eps[n % n_data], 1.0, epoch=12)
+            n += 1
+            if n >= min_steps and time.perf_counter() - t0 > seconds:
+                break
+        return n, time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    probe = {}
+    for t in sorted({1, 4, 8, 16, min(32, ncpu)}):
+        if t <= ncpu:
+            torch.set_num_threads(t)
+            n, dt = run(1.5, 5)
+            probe[t] = n / dt
+    best = max(probe, key=probe.get)
+    torch.set_num_threads(best)
+    n, dt = run(seconds_budget, 50)
+    torch.set_num_threads(default_threads)
+    return {"value": n / dt, "unit": "ELBO-steps/sec", "cores": best, "kind": "port",
+            "sample": f"{n} steps of the same h2,s2,e2 B=128 workload in {dt:.1f}s with {best} intra-op threads "
+                      f"(best of a probe over {sorted(probe)} threads: "
+                      f"{', '.join(f'{k}: {v:.0f}/s' for k, v in sorted(probe.items()))}; host has {ncpu} logical "
+                      "cores); oracle = CPU restatement of ModelVAE.train_step, float32"}
 
 
 def main():
@@ -81,6 +101,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--graph-steps", type=int, default=50,
                     help="steps captured per HIP graph (0 = eager launches)")
+    ap.add_argument("--reset-every", type=int, default=5000,
+                    help="restore the initial parameters / optimizer state every N steps: the reference's learnable-"
+                         "curvature training (batch-summed SGD on the radii) goes non-finite after ~1e4 steps on a "
+                         "small cycled data set -- the oracle does too -- and a benchmark should not time NaNs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,10 +128,10 @@ def main():
     shapes = [(n, s) for n, _, s in eng.flat.entries]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0))
     n_data = max(args.graph_steps, 1) * 4  # distinct resident batches, cycled
-    xs = synthetic.binary_batches(n_data, B, D, seed=4321 + rank).to(dev)
+    xs = synthetic.digits_like_batches(n_data, B, seed=4321 + rank).to(dev)
     eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
     runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=True, graph_steps=args.graph_steps,
-                        world_size=world)
+                        world_size=world, reset_every=args.reset_every)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -126,7 +150,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = eng.read_stats()
-    assert stats["sum"]["steps"] == args.warmup + args.steps, stats["sum"]["steps"]
+    assert stats["sum"]["steps"] == args.warmup + args.steps + runner.capture_steps, stats["sum"]["steps"]
     finite = stats["last"]["elbo"] == stats["last"]["elbo"] and abs(stats["last"]["elbo"]) != float("inf")
     assert finite or os.environ.get("MVAE_BENCH_ALLOW_NONFINITE"), "non-finite ELBO"
 
@@ -169,6 +193,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: MNIST shapes (D=784), model h2,s2,e2, learnable curvature, "
                                "MLP h_dim=400, batch 128 per GPU, epoch>=10 state",
                    "global_batch": B * world, "parallelism": f"dp{world}", "graph_steps": args.graph_steps,
+                   "state_reset_every": args.reset_every,
                    "final_elbo_per_sample": stats["last"]["elbo"] / B},
         "roofline": roof,
     }

@@ -15,6 +15,7 @@
 //
 // Nothing here synchronises or allocates, so the host layer can capture any number of steps into one HIP graph.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1407,7 +1408,13 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const floa
 static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
                      int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
                      hipEvent_t* ev) {
-#define MARK() do { if (ev) (void)hipEventRecord(*ev++, s); } while (0)
+  int ki = 0;  // launch index; with `ev` != NULL launch k is bracketed by ev[2k] (start) / ev[2k+1] (stop)
+#define STEP_LAUNCH(KERN, GRID, BLOCK, LDS, ...)                                                              \
+  do {                                                                                                         \
+    if (ev) hipExtLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, ev[2 * ki], ev[2 * ki + 1], 0, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, __VA_ARGS__);                                          \
+    ++ki;                                                                                                      \
+  } while (0)
   if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const mvae_model_desc& d = c->d;
   const int B = d.batch, H = d.h_dim, D = d.in_dim, NH = d.heads_dim, Z = d.z_dim;
@@ -1433,40 +1440,36 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   while (zp < Z) zp <<= 1;
   const bool fast_b = fast && (H + 256 / zp - 1) / (256 / zp) <= 16;
 
-  hipLaunchKernelGGL(k_enc_fwd, dim3(c->nt_h, c->nt_b), dim3(512), 0, s, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
+  STEP_LAUNCH(k_enc_fwd, dim3(c->nt_h, c->nt_b), dim3(512), 0, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
                      d.step_count, fused ? 1 : 0);
-  MARK();
   {
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
 #define LF(DM, FA)                                                                                                   \
-  hipLaunchKernelGGL((k_latent_fwd<DM, FA>), dim3(B), dim3(256), lds, s, c->t, h, P + d.off_w_heads,                 \
+  STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(256), lds, c->t, h, P + d.off_w_heads,                 \
                      P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
                      c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z)
     if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
 #undef LF
   }
-  MARK();
-  hipLaunchKernelGGL(k_dec1_fwd, dim3(c->nt_d, c->nt_b), dim3(512), 0, s, hd, P + d.off_w_logits, P + d.off_b_logits,
+  STEP_LAUNCH(k_dec1_fwd, dim3(c->nt_d, c->nt_b), dim3(512), 0, hd, P + d.off_w_logits, P + d.off_b_logits,
                      x, g, bce_part, logits, B, H, D);
-  MARK();
   {
     const int n_dhd = c->nt_b * c->nt_h, n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
     if (fused)
-      hipLaunchKernelGGL(k_dec1_bwd<true>, dim3(n_dhd + n_db + 1), dim3(512), 0, s, g, hd, P + d.off_w_logits,
+      STEP_LAUNCH(k_dec1_bwd<true>, dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,
                          G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
                          at(d.off_b_logits));
     else
-      hipLaunchKernelGGL(k_dec1_bwd<false>, dim3(n_dhd + n_db + 1), dim3(512), 0, s, g, hd, P + d.off_w_logits,
+      STEP_LAUNCH(k_dec1_bwd<false>, dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,
                          G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
                          at(d.off_b_logits));
   }
-  MARK();
   {
     const int n_dwl = c->nt_d * c->nt_h;
     const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 256 + (((size_t)NH + 3) & ~(size_t)3) + d.eps_dim + 4) *
                        sizeof(float);
 #define LB(DM, FA, AD)                                                                                              \
-  hipLaunchKernelGGL((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, s, c->t, dhd, P + d.off_w_d0,      \
+  STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, c->t, dhd, P + d.off_w_d0,      \
                      heads, c->ldh, eps, d.eps_dim, P + d.off_radii, h, P + d.off_w_heads, dheads, dh, drpart, g,   \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits))
     if (fast_b) {
@@ -1476,21 +1479,19 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     }
 #undef LB
   }
-  MARK();
   {
     const int n_we0 = c->nt_h * c->nt_d, n_wh = ((NH + 15) / 16) * c->nt_h, n_wd0 = c->nt_h * ((Z + 15) / 16);
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
 #define EB(AD)                                                                                                       \
-  hipLaunchKernelGGL(k_enc_bwd<AD>, dim3(grid), dim3(256), 0, s, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
+  STEP_LAUNCH(k_enc_bwd<AD>, dim3(grid), dim3(256), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
                      drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
                      d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
     if (fused) EB(true); else EB(false);
 #undef EB
   }
-  MARK();
-#undef MARK
+#undef STEP_LAUNCH
   LAUNCH_CHECK("step launch");
   return 0;
 }
@@ -1520,8 +1521,7 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
                                  int iters, float* ms_out, void* stream) {
   if (!c || !x || !eps || !ms_out || iters < 1) return fail(MVAE_E_BADARG, "null pointer / iters < 1%s", "");
   constexpr int NK = MVAE_STEP_KERNELS;
-  hipStream_t s = (hipStream_t)stream;
-  hipEvent_t ev[NK + 1];
+  hipEvent_t ev[2 * NK];
   for (auto& e : ev) {
     hipError_t rc = hipEventCreate(&e);
     if (rc != hipSuccess) return hip_fail(rc, "hipEventCreate");
@@ -1529,14 +1529,15 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
   double acc[NK] = {0};
   int rc = 0;
   for (int it = 0; it < iters && rc == 0; ++it) {
-    (void)hipEventRecord(ev[0], s);
-    rc = step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, &ev[1]);
+    // every launch carries its own start/stop event (hipExtLaunchKernelGGL): the difference is the execution time
+    // of that dispatch alone, the quantity rocprofv3 --kernel-trace reports
+    rc = step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, ev);
     if (rc) break;
-    hipError_t e = hipEventSynchronize(ev[NK]);
+    hipError_t e = hipEventSynchronize(ev[2 * NK - 1]);
     if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
     for (int k = 0; k < NK; ++k) {
       float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      (void)hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
       acc[k] += ms;
     }
   }

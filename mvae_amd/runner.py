@@ -16,7 +16,7 @@ from .engine import StepEngine
 class StepRunner:
 
     def __init__(self, eng: StepEngine, xs: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
-                 graph_steps: int = 0, world_size: int = 1):
+                 graph_steps: int = 0, world_size: int = 1, reset_every: int = 0):
         assert xs.shape[0] == eps.shape[0] and xs.shape[0] >= 1
         self.eng, self.xs, self.eps = eng, xs, eps
         self.beta, self.do_curv = float(beta), bool(do_curvature_step)
@@ -24,6 +24,10 @@ class StepRunner:
         self.n_data = xs.shape[0]
         self.gs = int(graph_steps)
         self.cursor = 0  # index of the next resident batch
+        self.reset_every = int(reset_every)
+        self.since_reset = 0
+        self.capture_steps = 0  # steps executed while warming up / capturing (they only touch the statistics)
+        self._snapshot = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.dp = DataParallelStep(eng) if self.world > 1 else None
         if self.gs > 0:
@@ -58,15 +62,27 @@ class StepRunner:
         for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
             dst.copy_(src)
 
+    def _state(self):
+        e = self.eng
+        return (e.params, e.adam_m, e.adam_v, e.counters)
+
     def run(self, n_steps: int) -> None:
         """Advance exactly n_steps steps (graph replays where a whole graph fits, eager launches otherwise)."""
+        if self.reset_every > 0 and self._snapshot is None:
+            self._snapshot = [t.clone() for t in self._state()]
         left = int(n_steps)
         while left > 0:
+            if self.reset_every > 0 and self.since_reset >= self.reset_every:
+                for dst, src in zip(self._state(), self._snapshot):
+                    dst.copy_(src)
+                self.since_reset = 0
             if self.gs > 0 and self.cursor % self.gs == 0 and left >= self.gs:
                 self.graphs[self.cursor // self.gs].replay()
                 self.cursor = (self.cursor + self.gs) % self.n_data
                 left -= self.gs
+                self.since_reset += self.gs
             else:
                 self._one(self.cursor)
                 self.cursor = (self.cursor + 1) % self.n_data
                 left -= 1
+                self.since_reset += 1
