@@ -25,6 +25,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
            # a/b and sqrt lower to v_rcp_f32 / v_sqrt_f32 sequences (<= 2.5 ulp) instead of the ~10-instruction
            # correctly-rounded expansions: the manifold chain is latency-bound and the parity bar is 1e-4
            "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+           # subnormal f32 inputs/outputs of VALU ops flush to zero (MFMA C/D never flush): removes the frexp/ldexp
+           # range scaling around every v_rcp_f32 / v_exp_f32 / v_log_f32; and a/b may become a * (1/b)
+           "-fgpu-flush-denormals-to-zero", "-freciprocal-math",
            "-o", LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -820,6 +820,73 @@ __device__ __forceinline__ void job_tn_opt(float (*red)[16][17], float* sh, cons
   }
 }
 
+// dW tile per WAVE (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q].  The batch contraction (K = B = 128) is short
+// enough for one wave: 32 MFMA steps on two accumulators, all operand loads in flight at once, no LDS, no barrier.
+// The four waves of a workgroup take four neighbouring q-tiles (they share the P operand through L1).
+// The MFMA is issued with the operand roles swapped (A <- Q, B <- P), so that lane l ends up with the four
+// CONSECUTIVE outputs out[p0 + (l&15)][q0 + 4*(l>>4) + 0..3]: gradient, parameter and both Adam moments move as one
+// 16-byte access per lane each.
+template <bool ADAM>
+__device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int pt, const float* Q, int ldq, int NQ,
+                                            int qt, int Mrows, float* out, int ldo, const AdamArgs& aa) {
+  if (qt * 16 >= NQ) return;
+  const int lane = threadIdx.x & 63;
+  const int pr = pt * 16 + (lane & 15), qc0 = qt * 16 + ((lane >> 4) << 2);
+  const bool pok = pr < NP;
+  const size_t idx = (size_t)pr * ldo + qc0;
+  const bool vec = pok && (qc0 + 3 < NQ) && (ldo & 3) == 0 && aligned16(out) && (!ADAM || aligned16(aa.p));
+  float p0[4] = {0.f, 0.f, 0.f, 0.f}, m0[4] = {0.f, 0.f, 0.f, 0.f}, v0[4] = {0.f, 0.f, 0.f, 0.f};
+  float neg_step = 0.f, bc2s = 1.f;
+  if (ADAM) {
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(aa.p + idx);
+      const float4 b = *reinterpret_cast<const float4*>(aa.m + idx);
+      const float4 c = *reinterpret_cast<const float4*>(aa.v + idx);
+      p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p0[3] = a.w;
+      m0[0] = b.x; m0[1] = b.y; m0[2] = b.z; m0[3] = b.w;
+      v0[0] = c.x; v0[1] = c.y; v0[2] = c.z; v0[3] = c.w;
+    } else if (pok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (qc0 + r < NQ) {
+          p0[r] = aa.p[idx + r];
+          m0[r] = aa.m[idx + r];
+          v0[r] = aa.v[idx + r];
+        }
+    }
+    const int step = *(volatile const int*)&aa.counters[0];
+    const double bc1 = 1.0 - pow_int(0.9, step);
+    const double bc2 = 1.0 - pow_int(0.999, step);
+    neg_step = (float)(-(aa.lr / bc1));
+    bc2s = (float)sqrt(bc2);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_tn<32>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
+  if (ADAM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
+  }
+  if (vec) {
+    *reinterpret_cast<float4*>(out + idx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (ADAM) {
+      *reinterpret_cast<float4*>(aa.p + idx) = make_float4(p0[0], p0[1], p0[2], p0[3]);
+      *reinterpret_cast<float4*>(aa.m + idx) = make_float4(m0[0], m0[1], m0[2], m0[3]);
+      *reinterpret_cast<float4*>(aa.v + idx) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    }
+  } else if (pok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (qc0 + r < NQ) {
+        out[idx + r] = acc[r];
+        if (ADAM) {
+          aa.p[idx + r] = p0[r];
+          aa.m[idx + r] = m0[r];
+          aa.v[idx + r] = v0[r];
+        }
+      }
+  }
+}
+
 // bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16
 template <bool ADAM>
 __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/, const float* Gm, int ld, int Mrows,
@@ -1135,14 +1202,13 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     bce_acc += bce;
     elbo_acc += (-bce - beta * klr);
   }
+  // block-wide sum: wavefront shuffles, then the (<= 8) wave totals meet in LDS -- two barriers per reduction
   auto block_sum = [&](float v) -> float {
-    sm[tid] = v;
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
     __syncthreads();
-    for (int s = nthr >> 1; s > 0; s >>= 1) {
-      if (tid < s) sm[tid] += sm[tid + s];
-      __syncthreads();
-    }
-    float r = sm[0];
+    float r = 0.f;
+    for (int w = 0; w < (nthr >> 6); ++w) r += sm[w];
     __syncthreads();
     return r;
   };
@@ -1190,8 +1256,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
-    const int ntH = (H + 15) / 16;
-    job_tn_opt<ADAM>(red, sh2, g, D, D, b / ntH, hd, H, H, b % ntH, B, dWl, H, awl);
+    const int ntH4 = ((H + 15) / 16 + 3) / 4;
+    job_tn_wave<ADAM>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
     return;
   }
   const size_t row = b;
@@ -1312,20 +1378,23 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
     return a;
   };
   if (b < n_we0) {  // dW_e0[H,D] = dh^T x
-    const int ntD = (D + 15) / 16;
-    job_tn_opt<ADAM>(red, sh2, dh, H, H, b / ntD, x, D, D, b % ntD, B, G + off_w_e0, D, at(off_w_e0));
+    const int ntD4 = ((D + 15) / 16 + 3) / 4;
+    job_tn_wave<ADAM>(dh, H, H, b / ntD4, x, D, D, (b % ntD4) * 4 + (threadIdx.x >> 6), B, G + off_w_e0, D,
+                      at(off_w_e0));
     return;
   }
   b -= n_we0;
   if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
-    const int ntH = (H + 15) / 16;
-    job_tn_opt<ADAM>(red, sh2, dheads, ldh, NH, b / ntH, h, H, H, b % ntH, B, G + off_w_heads, H, at(off_w_heads));
+    const int ntH4 = ((H + 15) / 16 + 3) / 4;
+    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntH4, h, H, H, (b % ntH4) * 4 + (threadIdx.x >> 6), B, G + off_w_heads, H,
+                      at(off_w_heads));
     return;
   }
   b -= n_wh;
   if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
-    const int ntZ = (Z + 15) / 16;
-    job_tn_opt<ADAM>(red, sh2, dhd, H, H, b / ntZ, z, ldz, Z, b % ntZ, B, G + off_w_d0, Z, at(off_w_d0));
+    const int ntZ4 = ((Z + 15) / 16 + 3) / 4;
+    job_tn_wave<ADAM>(dhd, H, H, b / ntZ4, z, ldz, Z, (b % ntZ4) * 4 + (threadIdx.x >> 6), B, G + off_w_d0, Z,
+                      at(off_w_d0));
     return;
   }
   b -= n_wd0;
@@ -1465,7 +1534,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
                          at(d.off_b_logits));
   }
   {
-    const int n_dwl = c->nt_d * c->nt_h;
+    const int n_dwl = c->nt_d * ((c->nt_h + 3) / 4);
     const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 256 + (((size_t)NH + 3) & ~(size_t)3) + d.eps_dim + 4) *
                        sizeof(float);
 #define LB(DM, FA, AD)                                                                                              \
@@ -1480,7 +1549,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #undef LB
   }
   {
-    const int n_we0 = c->nt_h * c->nt_d, n_wh = ((NH + 15) / 16) * c->nt_h, n_wd0 = c->nt_h * ((Z + 15) / 16);
+    const int n_we0 = c->nt_h * ((c->nt_d + 3) / 4), n_wh = ((NH + 15) / 16) * ((c->nt_h + 3) / 4),
+              n_wd0 = c->nt_h * (((Z + 15) / 16 + 3) / 4);
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;

@@ -75,13 +75,13 @@ __device__ __forceinline__ Dual t_sqrt(Dual x) {
   float s = sqrtf(x.v);
   return {s, x.d / (2.0f * s)};
 }
-__device__ __forceinline__ float t_exp(float x) { return expf(x); }
+__device__ __forceinline__ float t_exp(float x) { return mvf::fexp(x); }
 __device__ __forceinline__ Dual t_exp(Dual x) {
-  float e = expf(x.v);
+  float e = mvf::fexp(x.v);
   return {e, e * x.d};
 }
-__device__ __forceinline__ float t_log(float x) { return logf(x); }
-__device__ __forceinline__ Dual t_log(Dual x) { return {logf(x.v), x.d / x.v}; }
+__device__ __forceinline__ float t_log(float x) { return mvf::flog(x); }
+__device__ __forceinline__ Dual t_log(Dual x) { return {mvf::flog(x.v), x.d / x.v}; }
 __device__ __forceinline__ float t_cosh(float x) { return coshf(x); }
 __device__ __forceinline__ Dual t_cosh(Dual x) { return {coshf(x.v), sinhf(x.v) * x.d}; }
 __device__ __forceinline__ float t_sinh(float x) { return sinhf(x); }
@@ -118,9 +118,9 @@ __device__ __forceinline__ Dual leaky_clamp(Dual x, float lo, float hi) {
   return {fminf(fmaxf(x.v, lo), hi), in ? x.d : x.d * kEps};
 }
 // F.softplus(beta=1, threshold=20)
-__device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : mvf::log1p_pos(expf(x)); }
+__device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : mvf::log1p_pos(mvf::fexp(x)); }
 __device__ __forceinline__ Dual t_softplus(Dual x) {
-  const float e = expf(fminf(x.v, 20.0f));
+  const float e = mvf::fexp(fminf(x.v, 20.0f));
   const bool lin = x.v > 20.0f;
   return {lin ? x.v : mvf::log1p_pos(e), lin ? x.d : x.d * e / (e + 1.0f)};
 }
@@ -158,7 +158,7 @@ __device__ __forceinline__ float g_acosh_parts(float x, float* z_out) {
   float xc = fmaxf(x, 1.0f + kEps);  // == 1.0f in f32, as in the reference's f32 path
   float z = sqrtf(fmaxf(xc * xc - 1.0f, 1e-9f));
   *z_out = z;
-  return logf(xc + z);
+  return mvf::flog(xc + z);
 }
 __device__ __forceinline__ float g_acosh(float x) {
   float z;
@@ -171,11 +171,11 @@ __device__ __forceinline__ Dual g_acosh(Dual x) {
 }
 __device__ __forceinline__ float g_atanh(float x) {
   float xc = fminf(fmaxf(x, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
-  return (logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f;
+  return (mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f;
 }
 __device__ __forceinline__ Dual g_atanh(Dual x) {
   float xc = fminf(fmaxf(x.v, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
-  return {(logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
+  return {(mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
 }
 // logsinh (common.py:122-128 via logsumexp_signs :139-147); torch.max sends the derivative to the arg-max entry
 // (first entry on ties)
@@ -328,11 +328,11 @@ __device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c,
 }
 __device__ __forceinline__ float p_artanh(float x) {
   float xc = fminf(fmaxf(x, -1.0f + 1e-5f), 1.0f - 1e-5f);
-  return (logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f;
+  return (mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f;
 }
 __device__ __forceinline__ Dual p_artanh(Dual x) {
   float xc = fminf(fmaxf(x.v, -1.0f + 1e-5f), 1.0f - 1e-5f);
-  return {(logf(1.0f + xc) - logf(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
+  return {(mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
 }
 
 // ---- exp_map(u, at) / inverse_exp_map(z, at) on ambient vectors
