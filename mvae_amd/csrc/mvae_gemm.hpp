@@ -134,6 +134,14 @@ __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, 
   return acc + acc2;
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic (lgkmcnt) and NOT for its
+// outstanding global loads/stores.  __syncthreads() also drains vmcnt, i.e. it stalls every wave until prefetches issued
+// for later phases have landed and earlier global stores have been acknowledged -- a full memory round trip per barrier
+// in kernels whose phases are ~1 us long.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Combine the four waves' partial tiles.  red is float[4][16][17] in LDS (row padded: the epilogue reads a column of
 // the wave dimension).  Returns the full sum for element (row = tid>>4, col = tid&15) of the 16x16 tile.
 __device__ __forceinline__ float reduce_tiles(float (*red)[16][17], f32x4 acc) {
@@ -144,10 +152,10 @@ __device__ __forceinline__ float reduce_tiles(float (*red)[16][17], f32x4 acc) {
   red[wave][rbase + 1][col] = acc[1];
   red[wave][rbase + 2][col] = acc[2];
   red[wave][rbase + 3][col] = acc[3];
-  __syncthreads();
+  lds_barrier();
   const int r = tid >> 4, c = tid & 15;
   float s = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
-  __syncthreads();
+  lds_barrier();
   return s;
 }
 

@@ -778,7 +778,7 @@ __device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) 
   red[wave][rbase + 1][col] = acc[1];
   red[wave][rbase + 2][col] = acc[2];
   red[wave][rbase + 3][col] = acc[3];
-  __syncthreads();
+  lds_barrier();
   float s = 0.f;
   if (tid < 256) {
     const int r = tid >> 4, c = tid & 15;
@@ -951,11 +951,21 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
   }
 }
 
-// wave-level sum (all 64 lanes end up with the total)
+// wave-level sum (all 64 lanes end up with the total): DPP row operations + one readlane, ~50 cycles, instead of six
+// dependent ds_bpermute round trips through the LDS crossbar (~130 cycles each) that __shfl_xor lowers to.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  int x = __float_as_int(v);
+#define MV_DPP_ADD(CTRL, ROWMASK)                                                                       \
+  x = __float_as_int(__int_as_float(x) +                                                                \
+                     __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, true)));
+  MV_DPP_ADD(0xB1, 0xF)   // quad_perm [1,0,3,2]
+  MV_DPP_ADD(0x4E, 0xF)   // quad_perm [2,3,0,1]
+  MV_DPP_ADD(0x141, 0xF)  // row_half_mirror
+  MV_DPP_ADD(0x140, 0xF)  // row_mirror: every lane of a 16-lane row now holds the row sum
+  MV_DPP_ADD(0x142, 0xA)  // row_bcast15 into rows 1 and 3
+  MV_DPP_ADD(0x143, 0xC)  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef MV_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
 // ---- 2: heads + latent components + first decoder layer; ONE batch row per workgroup.  The phases are short and
@@ -971,6 +981,8 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] the row of h, then [eps_dim] the row of eps
   __shared__ __attribute__((aligned(16))) float heads_s[kHeadsMax];
   __shared__ __attribute__((aligned(16))) float z_s[kHeadsMax];
+  __shared__ mvae_component_desc desc_s[kMaxComp];  // per-lane indexed below: LDS, not the kernarg segment
+  __shared__ float rad_s[kMaxComp];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t row = blockIdx.x;
   float* h_s = dyn;
@@ -1009,38 +1021,44 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
     if (tid < NH) bhv = bh[tid];
   }
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
-  for (int k = tid + (FAST ? 512 : 0); k < H; k += 256) h_s[k] = h[row * H + k];
+  if (tid < t.n) {  // staged last so that its wait does not delay the issue of the loads above
+    desc_s[tid] = t.c[tid];
+    rad_s[tid] = radii[tid];
+  }
+  if (!FAST)
+    for (int k = tid; k < H; k += 256) h_s[k] = h[row * H + k];
   if (FAST) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       if (tid + 256 * u < H) h_s[tid + 256 * u] = hv[u];
   }
-  __syncthreads();
+  lds_barrier();
   MV_STAMP(1);
 
   // ---- heads = h W_heads^T + b
   if (FAST) {
+    float part[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = wave + 4 * q;
-      if (n < NH) {  // wave-uniform
-        float p = 0.f;
+    for (int q = 0; q < 4; ++q) {  // rows past NH were loaded as zeros: no branch, the four reductions interleave
+      float p = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = lane * 4 + 256 * u;
-          if (k < H) {
-            const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
-            p = fmaf(xv.x, wf[q][u].x, p);
-            p = fmaf(xv.y, wf[q][u].y, p);
-            p = fmaf(xv.z, wf[q][u].z, p);
-            p = fmaf(xv.w, wf[q][u].w, p);
-          }
+      for (int u = 0; u < 2; ++u) {
+        const int k = lane * 4 + 256 * u;
+        if (k < H) {
+          const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
+          p = fmaf(xv.x, wf[q][u].x, p);
+          p = fmaf(xv.y, wf[q][u].y, p);
+          p = fmaf(xv.z, wf[q][u].z, p);
+          p = fmaf(xv.w, wf[q][u].w, p);
         }
-        p = wave_sum(p);
-        if (lane == 0) heads_s[n] = p;
       }
+      part[q] = p;
     }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[q] = wave_sum(part[q]);
+    const float mine = lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3];
+    if (lane < 4 && wave + 4 * lane < NH) heads_s[wave + 4 * lane] = mine;
+    lds_barrier();
     if (tid < NH) {
       const float v = heads_s[tid] + bhv;
       heads[row * ldh + tid] = v;
@@ -1065,10 +1083,10 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
       p = wave_sum(p);
       if (lane == 0) heads_s[n] = p + bh[n];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < NH) heads[row * ldh + tid] = heads_s[tid];
   }
-  __syncthreads();
+  lds_barrier();
   MV_STAMP(2);
 
   // ---- latent components: component ci runs on wave ci&3, lane ci>>2 (different manifolds land on different waves)
@@ -1081,12 +1099,13 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
     if (ci < t.n) {
 #endif
       float klv;
-      comp_fwd_row<DMAX>(t.c[ci], heads_s, eps_s, radii, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr, nullptr);
+      comp_fwd_row<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr,
+                         nullptr);
       kl[(size_t)ci * B + row] = klv;
       if (kl_user) kl_user[(size_t)ci * B + row] = klv;
     }
   }
-  __syncthreads();
+  lds_barrier();
   MV_STAMP(3);
   if (z_user && tid < Z) z_user[row * Z + tid] = z_s[tid];
 
@@ -1252,6 +1271,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   __shared__ float sh2[2];
   __shared__ float dz_s[kHeadsMax];
   __shared__ float dheads_s[kHeadsMax];
+  __shared__ float rad_s[kMaxComp];
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (b >= n_rows) {  // dW_logits[D,H] tile
@@ -1293,9 +1313,10 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     }
   }
   for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
+  if (tid < t.n) rad_s[tid] = radii[tid];
   if (tid < NH) heads_s[tid] = heads[row * ldh + tid];
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
-  __syncthreads();
+  lds_barrier();
   MV_STAMP(9);
 
   // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c, slices meet in LDS
@@ -1311,13 +1332,23 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
     part[tid] = p;
-    __syncthreads();
-    if (tid < Z) {
-      float sum = 0.f;
-      for (int q = 0; q < nsl; ++q) sum += part[q * ZP + tid];
-      dz_s[tid] = sum;
+    lds_barrier();
+    // two short stages instead of one nsl-long dependent chain of LDS reads
+    const int nq = nsl >= 4 ? 4 : 1, per = nsl / nq;
+    float sum = 0.f;
+    if (tid < nq * ZP) {
+      const int qq = tid / ZP, jj = tid % ZP;
+      for (int q = 0; q < per; ++q) sum += part[(qq * per + q) * ZP + jj];
     }
-    __syncthreads();
+    lds_barrier();
+    if (tid < nq * ZP) part[tid] = sum;
+    lds_barrier();
+    if (tid < Z) {
+      float tot = 0.f;
+      for (int q = 0; q < nq; ++q) tot += part[q * ZP + tid];
+      dz_s[tid] = tot;
+    }
+    lds_barrier();
   }
   MV_STAMP(10);
   // ---- component backward: wave w takes components w, w+4, ...; lane = input direction (forward-mode duals)
@@ -1325,13 +1356,13 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     const mvae_component_desc& c = t.c[ci];
     const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
     for (int dir = lane; dir < ndir; dir += 64) {
-      const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, radii, dz_s, beta, dir);
+      const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, rad_s, dz_s, beta, dir);
       if (dir < c.true_dim) dheads_s[c.mean_col + dir] = gv;
       else if (dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (dir - c.true_dim)] = gv;
       else drpart[(size_t)ci * B + row] = gv;
     }
   }
-  __syncthreads();
+  lds_barrier();
   MV_STAMP(11);
   if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
   // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
