@@ -132,6 +132,48 @@ int mvae_linear_backward(const float* x, const float* W, const float* dy, int re
                          int64_t M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Building blocks of the convolutional architecture.  ConvolutionalVAE, conv_vae.py:28-79: every Conv2d /
+ * ConvTranspose2d there has kernel 4, stride 2, padding 1; both run on the MFMA contractions through a patch matrix.
+ * (b, c, y, x) element strides are explicit, so NCHW and channel-last activations share the kernels.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* col[(b,oy,ox), (c,ky,kx)] = src[b, c, 2oy-1+ky, 2ox-1+kx] (0 outside; with mask != NULL also 0 where mask <= 0).
+ * col is [B*IH/2*IW/2, C*16].  Forward of Conv2d (conv_vae.py:47-49,60-62) and backward of ConvTranspose2d. */
+int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, int C, int IH, int IW, int64_t sb,
+                       int64_t sc, int64_t sy, int64_t sx, void* stream);
+/* dst[b,c,y,x] = act(bias[c] + sum of the (<= 4) entries col[(b,py,px),(c,ky,kx)] with y = 2py-1+ky, x = 2px-1+kx);
+ * col is [B*H/2*W/2, C*16].  Forward of ConvTranspose2d (conv_vae.py:52-55,72-74) and backward-data of Conv2d.
+ * relu != 0: act = ReLU; mask != NULL: the result is zeroed where mask[b,c,y,x] <= 0 (backward through a ReLU). */
+int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C, int H, int W,
+                       int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, void* stream);
+/* out[b][c][r] = in[b][r][c]: the `.view(bs, -1)` / `.view(-1, 128, 4, 4)` re-flattenings of conv_vae.py:65,71. */
+int mvae_permute_rc(const float* in, float* out, int64_t B, int R, int Cc, void* stream);
+/* out[NP, NQ] = P[M, NP]^T Q[M, NQ]  (weight gradients).  For M > 256 the rows are processed in slices whose partial
+ * products are added in index order: `workspace` must then hold mvae_gemm_tn_workspace_floats(M, NP, NQ) floats. */
+int64_t mvae_gemm_tn_workspace_floats(int64_t M, int NP, int NQ);
+int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t M, int NP, int NQ, float* workspace,
+                 void* stream);
+/* dy[i] = 0 where y[i] <= 0  (backward through a ReLU whose output is y). */
+int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream);
+/* out[M, N] = G[M, K] W[K, N], optionally zeroed where mask[M, N] <= 0. */
+int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N, void* stream);
+/* out[N] = column sums of G[M, N]  (bias gradients); for M > 512 `workspace` must hold
+ * mvae_colsum_workspace_floats(M, N) floats (row slices are summed separately, then added in index order). */
+int64_t mvae_colsum_workspace_floats(int64_t M, int N);
+int mvae_colsum(const float* G, float* out, int64_t M, int N, float* workspace, void* stream);
+/* bce[r] = sum_j BCE-with-logits(logits[r][j], x[r][j]) and g = d(sum bce)/d(logits) = sigmoid(logits) - x
+ * (image_reconstruction.py:142-143 with soft targets; vae.py:131). */
+int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, float* g, int64_t rows, int D,
+                              void* stream);
+/* BatchStats (stats.py:144-212): adds sum_b bce, sum_b kl_i, sum_b(-bce - beta*sum_i kl_i) to the statistics record
+ * (same layout as mvae_model_desc.stats). */
+int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp, void* stream);
+/* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable
+ * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180. */
+int mvae_optimizer_step_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n_params,
+                             int32_t* counters, int ncomp, const uint8_t* radius_trainable, double lr,
+                             double curvature_lr, int do_curvature_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Importance-sampled log-likelihood pieces.  ModelVAE.log_likelihood, vae.py:82-123 ("next" row f-1 of the scope table).
  * ------------------------------------------------------------------------------------------------------------------ */
 /* out[r] = sum_j binary_cross_entropy_with_logits(logits[r][j], x[r % x_rows][j])   (vae.py:108-109 without

@@ -53,6 +53,19 @@ PROTOTYPES = {
                                           _L, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P]),
+    "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),
+    "mvae_permute_rc": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "mvae_gemm_tn_workspace_floats": (C.c_int64, [_L, _I, _I]),
+    "mvae_gemm_tn": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "mvae_relu_mask": (C.c_int, [_P, _P, _L, _P]),
+    "mvae_gemm_nn": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_colsum_workspace_floats": (C.c_int64, [_L, _I]),
+    "mvae_colsum": (C.c_int, [_P, _P, _L, _I, _P, _P]),
+    "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
+    "mvae_batch_stats": (C.c_int, [_P, _P, _P, _F, _I, _I, _P]),
+    "mvae_optimizer_step_flat": (C.c_int, [_P, _P, _P, _P, _L, _P, _I, C.POINTER(C.c_uint8), C.c_double, C.c_double,
+                                           _I, _P]),
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "mvae_loglik_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),

@@ -1,0 +1,314 @@
+"""ConvEngine: the CIFAR conv architecture of the reference (mt/mvae/models/conv_vae.py:28-79) on the HIP kernels.
+
+Layers (conv_vae.py:47-55): e0 Conv(3->64) e1 Conv(64->128) e2 Conv(128->512), all k4 s2 p1 + ReLU -> flatten 8192 ->
+component heads -> latent components -> d0 Linear(Z->2048)+ReLU -> view [128,4,4] -> d1 ConvT(128->256) d2 ConvT(256->64)
+(+ReLU) d3 ConvT(64->3) -> flatten 3072 -> BCE-with-logits (soft targets).
+
+Every Conv2d / ConvTranspose2d is a patch-matrix gather (`mvae_im2col_k4s2p1` / `mvae_col2im_k4s2p1`) around one of the
+f32-MFMA contractions of the Linear layers; activations between layers are channel-last ([B*H*W, C]) so that they are
+directly the row-major operands of those contractions; weights stay in the reference's layouts ([OC, IC*16] for Conv2d,
+[IC, OC*16] for ConvTranspose2d are exactly the matrices the contractions need).  Backward of a ConvTranspose2d is the
+im2col of the incoming gradient; backward-data of a Conv2d is a col2im.  Parameters, gradients and optimizer state live
+in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming kernel and
+data-parallel training all-reduces one buffer.
+
+First version: correctness and a complete path (BASELINE config [4]); the contractions use the small-batch tile
+kernels (no LDS-tiled large-M GEMM yet), so this path is far from the MFMA roofline.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from . import functional as Fn
+from ._lib import check, load, ptr, stream_ptr
+from .functional import ComponentLayout
+
+H_DIM = 8192  # conv_vae.py: the encoder output is 512*4*4
+
+
+def _up64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class ConvFlatLayout:
+
+    def __init__(self, layout: ComponentLayout):
+        NH, Z = layout.heads_dim, layout.z_dim
+        self.comp_layout = layout
+        o = _lib.RADII_REGION
+        self.off: Dict[str, int] = {}
+
+        def take(name, n):
+            nonlocal o
+            self.off[name] = o
+            o += _up64(n)
+
+        take("w_heads", NH * H_DIM)
+        take("b_heads", NH)
+        shapes = [("e0", (64, 3, 4, 4)), ("e1", (128, 64, 4, 4)), ("e2", (512, 128, 4, 4)), ("d0", (2048, Z)),
+                  ("d1", (128, 256, 4, 4)), ("d2", (256, 64, 4, 4)), ("d3", (64, 3, 4, 4))]
+        bias = {"e0": 64, "e1": 128, "e2": 512, "d0": 2048, "d1": 256, "d2": 64, "d3": 3}
+        self.shapes = dict(shapes)
+        for name, shp in shapes:
+            n = 1
+            for v in shp:
+                n *= v
+            take(name + ".weight", n)
+            take(name + ".bias", bias[name])
+        self.n_params = o
+        self.entries: List[Tuple[str, int, Tuple[int, ...]]] = []
+        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius"}
+        for i, (letter, d) in enumerate(layout.comps):
+            desc = layout.descs[i]
+            pre = f"components.{i}."
+            if letter in radius_name:
+                self.entries.append((pre + radius_name[letter], i, ()))
+            self.entries.append((pre + "fc_mean.weight", self.off["w_heads"] + desc.mean_col * H_DIM, (d, H_DIM)))
+            self.entries.append((pre + "fc_mean.bias", self.off["b_heads"] + desc.mean_col, (d,)))
+            self.entries.append((pre + "fc_logvar.weight", self.off["w_heads"] + desc.logvar_col * H_DIM,
+                                 (desc.logvar_dim, H_DIM)))
+            self.entries.append((pre + "fc_logvar.bias", self.off["b_heads"] + desc.logvar_col, (desc.logvar_dim,)))
+        for name, shp in shapes:
+            self.entries.append((name + ".weight", self.off[name + ".weight"], shp))
+            self.entries.append((name + ".bias", self.off[name + ".bias"], (bias[name],)))
+
+    def views(self, flat: Tensor) -> Dict[str, Tensor]:
+        out = {}
+        for name, off, shape in self.entries:
+            n = 1
+            for v in shape:
+                n *= v
+            out[name] = flat[off:off + n].view(shape)
+        return out
+
+
+def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strides) -> Tensor:
+    col = src.new_empty(B * (IH // 2) * (IH // 2), Cc * 16)
+    check(load().mvae_im2col_k4s2p1(ptr(src), ptr(mask), ptr(col), B, Cc, IH, IH, *strides, stream_ptr(src.device)))
+    return col
+
+
+def _col2im(col: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, Hh: int, strides, relu: bool,
+            out_shape) -> Tensor:
+    dst = col.new_empty(out_shape)
+    check(load().mvae_col2im_k4s2p1(ptr(col), ptr(bias), ptr(mask), ptr(dst), B, Cc, Hh, Hh, *strides,
+                                    1 if relu else 0, stream_ptr(col.device)))
+    return dst
+
+
+def _nhwc(Hh: int, Cc: int):
+    return (Hh * Hh * Cc, 1, Hh * Cc, Cc)  # (sb, sc, sy, sx)
+
+
+def _nchw(Hh: int, Cc: int):
+    return (Cc * Hh * Hh, Hh * Hh, Hh, 1)
+
+
+def _permute_rc(x: Tensor, B: int, R: int, Cc: int) -> Tensor:
+    out = torch.empty_like(x)
+    check(load().mvae_permute_rc(ptr(x), ptr(out), B, R, Cc, stream_ptr(x.device)))
+    return out
+
+
+def _gemm_tn(P: Tensor, Q: Tensor) -> Tensor:
+    M, NP = P.shape
+    NQ = Q.shape[1]
+    out = P.new_empty(NP, NQ)
+    nws = load().mvae_gemm_tn_workspace_floats(M, NP, NQ)
+    ws = P.new_empty(int(nws)) if nws > 0 else None
+    check(load().mvae_gemm_tn(ptr(P), ptr(Q), ptr(out), M, NP, NQ, ptr(ws), stream_ptr(P.device)))
+    return out
+
+
+def _gemm_nn(G: Tensor, W: Tensor) -> Tensor:
+    M, K = G.shape
+    N = W.shape[1]
+    out = G.new_empty(M, N)
+    check(load().mvae_gemm_nn(ptr(G), ptr(W), None, ptr(out), M, K, N, stream_ptr(G.device)))
+    return out
+
+
+def _colsum(G: Tensor) -> Tensor:
+    out = G.new_empty(G.shape[1])
+    nws = load().mvae_colsum_workspace_floats(G.shape[0], G.shape[1])
+    ws = G.new_empty(int(nws)) if nws > 0 else None
+    check(load().mvae_colsum(ptr(G), ptr(out), G.shape[0], G.shape[1], ptr(ws), stream_ptr(G.device)))
+    return out
+
+
+def _relu_mask_(dy: Tensor, y: Tensor) -> Tensor:
+    check(load().mvae_relu_mask(ptr(dy), ptr(y), dy.numel(), stream_ptr(dy.device)))
+    return dy
+
+
+class ConvEngine:
+    in_dim = 3072
+
+    def __init__(self, comps: Sequence[Tuple[str, int]], device, scalar_parametrization: bool = False,
+                 radius_trainable: Optional[Sequence[bool]] = None, lr: float = 1e-3, curvature_lr: float = 1e-4):
+        load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MvaeHipError("ConvEngine needs a HIP device: the product path has no CPU fallback")
+        self.layout = ComponentLayout(comps, scalar_parametrization)
+        self.flat = ConvFlatLayout(self.layout)
+        self.lr, self.curvature_lr = float(lr), float(curvature_lr)
+        n = self.layout.n
+        tr = [False] * n if radius_trainable is None else [bool(t) for t in radius_trainable]
+        self.radius_trainable = [t and letter != "e" for t, (letter, _) in zip(tr, self.layout.comps)]
+        self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
+        P = self.flat.n_params
+        z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
+        self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
+        self.counters = z(32, torch.int32)
+        self.stats = z(2 * (4 + n))
+
+    # ---- state (same surface as StepEngine)
+    def param_views(self) -> Dict[str, Tensor]:
+        return self.flat.views(self.params)
+
+    def grad_views(self) -> Dict[str, Tensor]:
+        return self.flat.views(self.grads)
+
+    def load_state(self, state: Dict[str, Tensor]) -> None:
+        for name, v in self.param_views().items():
+            v.copy_(state[name].to(device=self.device, dtype=torch.float32).reshape(v.shape))
+
+    def set_radii(self, value: float) -> None:
+        for i, (letter, _) in enumerate(self.layout.comps):
+            if letter != "e":
+                self.params[i] = value
+
+    def set_lr(self, lr: float, curvature_lr: Optional[float] = None) -> None:
+        self.lr = float(lr)
+        if curvature_lr is not None:
+            self.curvature_lr = float(curvature_lr)
+
+    def _w(self, name: str) -> Tensor:
+        return self.param_views()[name]
+
+    # ---- forward (keeps what backward needs)
+    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True):
+        PV = self.param_views()
+        lay = self.layout
+        B = x.shape[0]
+        NH = lay.heads_dim
+        c = {}
+        c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
+        c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
+        c["col1"] = _im2col(c["a0"], None, B, 64, 16, _nhwc(16, 64))
+        c["a1"] = Fn.linear_forward(c["col1"], PV["e1.weight"].view(128, 1024), PV["e1.bias"], relu=True)
+        c["col2"] = _im2col(c["a1"], None, B, 128, 8, _nhwc(8, 128))
+        c["a2"] = Fn.linear_forward(c["col2"], PV["e2.weight"].view(512, 2048), PV["e2.bias"], relu=True)
+        c["hflat"] = _permute_rc(c["a2"], B, 16, 512).view(B, H_DIM)  # NCHW flatten (conv_vae.py:65)
+        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
+        b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
+        c["heads"] = Fn.linear_forward(c["hflat"], w_heads, b_heads)
+        co = Fn.component_forward(lay, c["heads"], eps, self.params[:lay.n], want_kl=want_kl,
+                                  want_log_probs=not want_kl, want_params=False)
+        c["z"], c["kl"], c["co"] = co["z"], co["kl"], co
+        zz = co["z"].reshape(-1, lay.z_dim)
+        R = zz.shape[0]
+        c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
+        c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
+        c["cT1"] = _gemm_nn(c["t0"], PV["d1.weight"].view(128, 256 * 16))
+        c["b1"] = _col2im(c["cT1"], PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True, (R * 64, 256))
+        c["cT2"] = _gemm_nn(c["b1"], PV["d2.weight"].view(256, 64 * 16))
+        c["b2"] = _col2im(c["cT2"], PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64))
+        c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
+        c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
+        return c
+
+    def decode(self, z: Tensor) -> Tensor:
+        """[..., B, Z] -> [..., B, 3072] (conv_vae.py:68-79)."""
+        PV = self.param_views()
+        zz = z.reshape(-1, self.layout.z_dim).contiguous()
+        R = zz.shape[0]
+        d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
+        t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
+        b1 = _col2im(_gemm_nn(t0, PV["d1.weight"].view(128, 4096)), PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True,
+                     (R * 64, 256))
+        b2 = _col2im(_gemm_nn(b1, PV["d2.weight"].view(256, 1024)), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
+                     (R * 256, 64))
+        lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
+                     (R, 3072))
+        return lo.view(z.shape[:-1] + (3072,))
+
+    def forward_backward(self, x: Tensor, eps: Tensor, beta: float = 1.0, want_outputs: bool = False):
+        x = x.contiguous()
+        B = x.shape[0]
+        lay = self.layout
+        c = self._forward(x, eps)
+        bce = x.new_empty(B)
+        g = torch.empty_like(c["logits"])
+        check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
+                                               stream_ptr(self.device)))
+        check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
+                                      stream_ptr(self.device)))
+        PV, GV = self.param_views(), self.grad_views()
+        # ---- decoder backward
+        dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
+        GV["d3.weight"].view(64, 48).copy_(_gemm_tn(c["b2"], dcol3))
+        GV["d3.bias"].copy_(_colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3)))
+        db2 = _relu_mask_(Fn.linear_forward(dcol3, PV["d3.weight"].view(64, 48), None), c["b2"])
+        dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64))
+        GV["d2.weight"].view(256, 1024).copy_(_gemm_tn(c["b1"], dcol2))
+        GV["d2.bias"].copy_(_colsum(db2))
+        db1 = _relu_mask_(Fn.linear_forward(dcol2, PV["d2.weight"].view(256, 1024), None), c["b1"])
+        dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256))
+        GV["d1.weight"].view(128, 4096).copy_(_gemm_tn(c["t0"], dcol1))
+        GV["d1.bias"].copy_(_colsum(db1))
+        dt0 = Fn.linear_forward(dcol1, PV["d1.weight"].view(128, 4096), None)  # [B*16, 128]
+        dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
+        dW, db, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True)
+        GV["d0.weight"].copy_(dW)
+        GV["d0.bias"].copy_(db)
+        # ---- latent components
+        dheads, dradii = Fn.component_backward(lay, c["heads"], eps, self.params[:lay.n], dz, None, float(beta))
+        self.grads[:_lib.RADII_REGION].zero_()
+        for i, t in enumerate(self.radius_trainable):
+            if t:
+                self.grads[i:i + 1].copy_(dradii[i:i + 1])
+        NH = lay.heads_dim
+        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
+        dWh, dbh, dhflat = Fn.linear_backward(c["hflat"], w_heads, dheads, relu_in=True, need_dx=True)
+        self.grads[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM).copy_(dWh)
+        self.grads[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH].copy_(dbh)
+        # ---- encoder backward (Conv2d backward-data = col2im)
+        da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
+        GV["e2.weight"].view(512, 2048).copy_(_gemm_tn(da2, c["col2"]))
+        GV["e2.bias"].copy_(_colsum(da2))
+        da1 = _col2im(_gemm_nn(da2, PV["e2.weight"].view(512, 2048)), None, c["a1"], B, 128, 8, _nhwc(8, 128), False,
+                      (B * 64, 128))
+        GV["e1.weight"].view(128, 1024).copy_(_gemm_tn(da1, c["col1"]))
+        GV["e1.bias"].copy_(_colsum(da1))
+        da0 = _col2im(_gemm_nn(da1, PV["e1.weight"].view(128, 1024)), None, c["a0"], B, 64, 16, _nhwc(16, 64), False,
+                      (B * 256, 64))
+        GV["e0.weight"].view(64, 48).copy_(_gemm_tn(da0, c["col0"]))
+        GV["e0.bias"].copy_(_colsum(da0))
+        if want_outputs:
+            return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
+        return None
+
+    def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
+        check(load().mvae_optimizer_step_flat(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                                              self.flat.n_params, ptr(self.counters), self.layout.n,
+                                              self._trainable_arr, self.lr, self.curvature_lr,
+                                              1 if do_curvature_step else 0, stream_ptr(self.device)))
+
+    def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
+        self.forward_backward(x, eps, beta)
+        self.optimizer_step(do_curvature_step)
+
+    def read_stats(self, reset: bool = False):
+        s = self.stats.cpu()
+        n = 4 + self.layout.n
+        rec = lambda v: {"bce": float(v[0]), "kl": float(v[1]), "elbo": float(v[2]), "steps": int(v[3]),  # noqa: E731
+                         "component_kl": [float(t) for t in v[4:n]]}
+        out = {"sum": rec(s[:n]), "last": rec(s[n:2 * n])}
+        if reset:
+            self.stats.zero_()
+        return out

@@ -1647,3 +1647,325 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
   for (int k = 0; k < NK; ++k) ms_out[k] = (float)(acc[k] / iters);
   return 0;
 }
+
+// Adam over a flat parameter buffer whose first 64 floats are the raw radii (SGD on the trainable ones): the optimizer
+// of any architecture laid out like StepEngine's buffers (used by the conv path).
+extern "C" int mvae_optimizer_step_flat(float* params, const float* grads, float* adam_m, float* adam_v,
+                                        int64_t n_params, int32_t* counters, int ncomp,
+                                        const uint8_t* radius_trainable, double lr, double curvature_lr,
+                                        int do_curvature_step, void* stream) {
+  if (!params || !grads || !adam_m || !adam_v || !counters || n_params < kRadiiRegion || (n_params & 3) ||
+      ncomp < 0 || ncomp > kMaxComp)
+    return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
+  CompTable t;
+  memset(&t, 0, sizeof(t));
+  t.n = ncomp;
+  for (int i = 0; i < ncomp; ++i) t.trainable[i] = radius_trainable ? radius_trainable[i] : 0;
+  const int n4 = (int)(n_params / 4);
+  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_optim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v, n4,
+                     counters, lr, curvature_lr, do_curvature_step);
+  LAUNCH_CHECK("flat optimizer launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ conv building blocks (API)
+// The reference's conv architecture (conv_vae.py:28-79) uses only Conv2d / ConvTranspose2d with kernel 4, stride 2,
+// padding 1.  Both are expressed on the dense MFMA contractions above through a patch matrix:
+//   Conv2d forward          y[(b,oy,ox), oc]       = im2col(x)[(b,oy,ox), (ic,ky,kx)] . W[oc, (ic,ky,kx)]^T      (NT)
+//   ConvTranspose2d forward col[(b,iy,ix),(oc,ky,kx)] = x[(b,iy,ix), ic] . W[ic, (oc,ky,kx)]  then y = col2im(col)   (NN)
+// and their backward passes are the same two gathers with the roles of input and output exchanged.
+// Activations are addressed through explicit (batch, channel, y, x) strides, so NCHW tensors at the model boundary
+// and channel-last tensors between layers use the same kernels.
+
+// col[(b,oy,ox), (c,ky,kx)] = src[b, c, 2oy-1+ky, 2ox-1+kx]  (0 outside), optionally masked by mask[...same index] > 0
+__global__ __launch_bounds__(256) void k_im2col(const float* src, const float* mask, float* col, int B, int C, int IH,
+                                                int IW, int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+  const int OH = IH / 2, OW = IW / 2, K = C * 16;
+  const int64_t total = (int64_t)B * OH * OW * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int64_t m = i / K;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((int64_t)OW * OH));
+    const int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    float v = 0.f;
+    if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+      const int64_t o = b * sb + c * sc + iy * sy + ix * sx;
+      v = src[o];
+      if (mask && !(mask[o] > 0.f)) v = 0.f;
+    }
+    col[i] = v;
+  }
+}
+
+// dst[b, c, y, x] = act(bias[c] + sum over the (ky,kx) with y = 2*py-1+ky, x = 2*px-1+kx of col[(b,py,px), (c,ky,kx)])
+// (PH = H/2 patch rows).  With mask != NULL the result is multiplied by [mask[b,c,y,x] > 0] (backward through a ReLU).
+__global__ __launch_bounds__(256) void k_col2im(const float* col, const float* bias, const float* mask, float* dst,
+                                                int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sy,
+                                                int64_t sx, int relu) {
+  const int PH = H / 2, PW = W / 2, K = C * 16;
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // enumerate with the channel fastest so that consecutive threads read consecutive (c,ky,kx) groups
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((y + 1) & 1) + 2 * a;  // ky with the parity of y+1
+      const int py = (y + 1 - ky) / 2;
+      if (py < 0 || py >= PH) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kx = ((x + 1) & 1) + 2 * e;
+        const int px = (x + 1 - kx) / 2;
+        if (px < 0 || px >= PW) continue;
+        acc += col[(((int64_t)b * PH + py) * PW + px) * K + c * 16 + ky * 4 + kx];
+      }
+    }
+    const int64_t o = b * sb + c * sc + y * sy + x * sx;
+    if (relu) acc = acc > 0.f ? acc : 0.f;
+    if (mask && !(mask[o] > 0.f)) acc = 0.f;
+    dst[o] = acc;
+  }
+}
+
+// out[b][c][r] = in[b][r][c]   (channel-last <-> channel-first flattening of a small activation)
+__global__ __launch_bounds__(256) void k_permute_rc(const float* in, float* out, int64_t B, int R, int Cc) {
+  const int64_t total = B * R * Cc;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i % R);
+    const int c = (int)((i / R) % Cc);
+    const int64_t b = i / ((int64_t)R * Cc);
+    out[i] = in[(b * R + r) * Cc + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* P, const float* Q, float* out, int M, int NP, int NQ) {
+  const int ntQ4 = ((NQ + 15) / 16 + 3) / 4;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_tn_wave<false>(P, NP, NP, blockIdx.x / ntQ4, Q, NQ, NQ, (blockIdx.x % ntQ4) * 4 + (threadIdx.x >> 6), M, out, NQ,
+                     none);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nn(const float* G, const float* W, const float* mask, float* out, int M,
+                                                 int K, int N) {
+  __shared__ float red[4][16][17];
+  const int ntN = (N + 15) / 16;
+  job_nn(red, G, K, M, blockIdx.x / ntN, W, N, N, blockIdx.x % ntN, K, mask, N, out, N);
+}
+
+__global__ __launch_bounds__(256) void k_colsum(const float* G, float* out, int M, int N) {
+  __shared__ float lds[32 * 17 + 2];
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_colsum_opt<false>(lds, G, N, M, N, blockIdx.x * kColsPerBlock, out, none);
+}
+
+// g[r][j] = sigmoid(logits[r][j]) - x[r][j];  bce[r] = sum_j BCE-with-logits   (one wavefront per row)
+__global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* logits, const float* x, float* bce, float* g,
+                                                     int64_t rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float y = logits[r * D + j], t = x[r * D + j];
+    const float e = mvf::fexp(-fabsf(y));
+    s += (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
+    g[r * D + j] = ((y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t;
+  }
+  s = wave_sum(s);
+  if (lane == 0) bce[r] = s;
+}
+
+// BatchStats (stats.py:144-212) for paths that do not run the fused MLP step: one workgroup
+__global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B,
+                                                     int ncomp) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+  };
+  float b = 0.f, e = 0.f;
+  for (int r = tid; r < B; r += 256) {
+    float klr = 0.f;
+    for (int i = 0; i < ncomp; ++i) klr = (i == 0) ? kl[r] : klr + kl[(size_t)i * B + r];
+    b += bce[r];
+    e += (-bce[r] - beta * klr);
+  }
+  const float bs = block_sum(b), es = block_sum(e);
+  const int last = 4 + ncomp;
+  float kt = 0.f;
+  for (int i = 0; i < ncomp; ++i) {
+    float a = 0.f;
+    for (int r = tid; r < B; r += 256) a += kl[(size_t)i * B + r];
+    const float sres = block_sum(a);
+    kt += sres;
+    if (tid == 0) {
+      stats[4 + i] += sres;
+      stats[last + 4 + i] = sres;
+    }
+  }
+  if (tid == 0) {
+    stats[0] += bs; stats[1] += kt; stats[2] += es; stats[3] += 1.f;
+    stats[last] = bs; stats[last + 1] = kt; stats[last + 2] = es; stats[last + 3] = 1.f;
+  }
+}
+
+static int grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+extern "C" int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, int C, int IH, int IW,
+                                  int64_t sb, int64_t sc, int64_t sy, int64_t sx, void* stream) {
+  if (!src || !col || B < 1 || C < 1 || IH < 2 || IW < 2 || (IH & 1) || (IW & 1))
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_im2col, dim3(grid_for((int64_t)B * (IH / 2) * (IW / 2) * C * 16)), dim3(256), 0,
+                     (hipStream_t)stream, src, mask, col, B, C, IH, IW, sb, sc, sy, sx);
+  LAUNCH_CHECK("im2col launch");
+  return 0;
+}
+
+extern "C" int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C,
+                                  int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu,
+                                  void* stream) {
+  if (!col || !dst || B < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_col2im, dim3(grid_for((int64_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, col, bias,
+                     mask, dst, B, C, H, W, sb, sc, sy, sx, relu);
+  LAUNCH_CHECK("col2im launch");
+  return 0;
+}
+
+extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, int Cc, void* stream) {
+  if (!in || !out || B < 1 || R < 1 || Cc < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_permute_rc, dim3(grid_for(B * R * Cc)), dim3(256), 0, (hipStream_t)stream, in, out, B, R, Cc);
+  LAUNCH_CHECK("permute launch");
+  return 0;
+}
+
+// Long batch contractions (conv layers: M = B*OH*OW up to 65536 rows): the rows are cut into slices of kTnSlice, one
+// workgroup-row of tiles per slice writes its partial [NP, NQ] product, and a second launch adds the slices in index
+// order (deterministic; no float atomics).
+constexpr int kTnSlice = 256;
+__global__ __launch_bounds__(256) void k_gemm_tn_sliced(const float* P, const float* Q, float* part, int M, int NP,
+                                                        int NQ, int tiles) {
+  const int slice = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int ntQ4 = ((NQ + 15) / 16 + 3) / 4;
+  const int m0 = slice * kTnSlice;
+  const int rows = (M - m0) < kTnSlice ? (M - m0) : kTnSlice;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_tn_wave<false>(P + (size_t)m0 * NP, NP, NP, tile / ntQ4, Q + (size_t)m0 * NQ, NQ, NQ,
+                     (tile % ntQ4) * 4 + (threadIdx.x >> 6), rows, part + (size_t)slice * NP * NQ, NQ, none);
+}
+__global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* out, int64_t n, int slices) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_relu_mask(float* dy, const float* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+extern "C" int64_t mvae_gemm_tn_workspace_floats(int64_t M, int NP, int NQ) {
+  if (M <= kTnSlice) return 0;
+  return ((M + kTnSlice - 1) / kTnSlice) * (int64_t)NP * NQ;
+}
+
+extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t M, int NP, int NQ, float* workspace,
+                            void* stream) {
+  if (!P || !Q || !out || M < 1 || NP < 1 || NQ < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int tiles = ((NP + 15) / 16) * (((NQ + 15) / 16 + 3) / 4);
+  if (M <= kTnSlice) {
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles), dim3(256), 0, (hipStream_t)stream, P, Q, out, (int)M, NP, NQ);
+  } else {
+    if (!workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
+    const int slices = (int)((M + kTnSlice - 1) / kTnSlice);
+    hipLaunchKernelGGL(k_gemm_tn_sliced, dim3((unsigned)(tiles * slices)), dim3(256), 0, (hipStream_t)stream, P, Q,
+                       workspace, (int)M, NP, NQ, tiles);
+    const int64_t n = (int64_t)NP * NQ;
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+  }
+  LAUNCH_CHECK("gemm_tn launch");
+  return 0;
+}
+
+extern "C" int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream) {
+  if (!dy || !y || n < 0) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_relu_mask, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n);
+  LAUNCH_CHECK("relu mask launch");
+  return 0;
+}
+
+extern "C" int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N,
+                            void* stream) {
+  if (!G || !W || !out || M < 1 || K < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int64_t grid = ((M + 15) / 16) * ((N + 15) / 16);
+  if (grid > 0x7fffffff) return fail(MVAE_E_UNSUPPORTED, "grid too large%s", "");
+  hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, G, W, mask, out, (int)M, K, N);
+  LAUNCH_CHECK("gemm_nn launch");
+  return 0;
+}
+
+// tall matrices (conv activations: up to 65536 rows): row slices of kColSlice are summed by separate workgroups, the
+// slice totals are then added in index order
+constexpr int kColSlice = 512;
+__global__ __launch_bounds__(256) void k_colsum_sliced(const float* G, float* part, int M, int N, int ncb) {
+  __shared__ float lds[32 * 17 + 2];
+  const int slice = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+  const int m0 = slice * kColSlice;
+  const int rows = (M - m0) < kColSlice ? (M - m0) : kColSlice;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_colsum_opt<false>(lds, G + (size_t)m0 * N, N, rows, N, cb * kColsPerBlock, part + (size_t)slice * N, none);
+}
+
+extern "C" int64_t mvae_colsum_workspace_floats(int64_t M, int N) {
+  return M <= kColSlice ? 0 : ((M + kColSlice - 1) / kColSlice) * (int64_t)N;
+}
+
+extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* workspace, void* stream) {
+  if (!G || !out || M < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int ncb = (N + kColsPerBlock - 1) / kColsPerBlock;
+  if (M <= kColSlice) {
+    hipLaunchKernelGGL(k_colsum, dim3(ncb), dim3(256), 0, (hipStream_t)stream, G, out, (int)M, N);
+  } else {
+    if (!workspace) return fail(MVAE_E_BADARG, "mvae_colsum needs a workspace for M > 512%s", "");
+    const int slices = (int)((M + kColSlice - 1) / kColSlice);
+    hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
+                       workspace, (int)M, N, ncb);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)stream, workspace, out, (int64_t)N,
+                       slices);
+  }
+  LAUNCH_CHECK("colsum launch");
+  return 0;
+}
+
+extern "C" int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, float* g, int64_t rows,
+                                         int D, void* stream) {
+  if (!logits || !x || !bce || !g || rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_bce_fwd_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, x,
+                     bce, g, rows, D);
+  LAUNCH_CHECK("bce launch");
+  return 0;
+}
+
+extern "C" int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp,
+                                void* stream) {
+  if (!bce || !kl || !stats || B < 1 || ncomp < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, bce, kl, stats, beta, B, ncomp);
+  LAUNCH_CHECK("batch stats launch");
+  return 0;
+}
+

@@ -15,7 +15,7 @@ from . import functional as Fn
 from ._lib import MvaeHipError
 from .components import Component
 from .distributions import FusedParts, FusedPosterior, FusedPrior
-from .engine import StepEngine
+from .engine import StepEngine  # noqa: F401  (ConvEngine has the same surface)
 from .stats import BatchStatsFloat
 
 
@@ -245,8 +245,42 @@ class FeedForwardVAE(ModelVAE):
 
 
 class ConvolutionalVAE(ModelVAE):
-    """conv_vae.py:28-79 -- the CIFAR conv architecture (BASELINE config [4]) is the next row of the scope table
-    (SURVEY.md section 8, a-18); it is not built on the HIP path yet."""
+    """conv_vae.py:28-79 (BASELINE config [4], CIFAR shapes): 3 x Conv(k4,s2,p1) encoder, Linear + 3 x ConvTranspose
+    decoder, `h_dim` must be 8192 as in the reference.  Runs on mvae_amd.conv.ConvEngine."""
 
-    def __init__(self, *args, **kwargs) -> None:
-        raise NotImplementedError("architecture 'conv' is not part of the MI355X hot-path build yet (MLP only)")
+    def __init__(self, h_dim: int, components: List[Component], dataset, scalar_parametrization: bool,
+                 img_dims: Tuple[int, int, int] = (3, 32, 32)) -> None:
+        if h_dim != 8192 or tuple(img_dims) != (3, 32, 32):
+            raise ValueError("'conv' architecture only works with --h_dim=8192 and 3x32x32 images (as in the reference)")
+        super().__init__(h_dim, components, dataset, scalar_parametrization)
+        self.img_dims = img_dims
+        self.img_dims_flat = 3072
+        self.in_dim = 3072
+        self.e0 = nn.Conv2d(3, 64, kernel_size=4, stride=2, padding=1)
+        self.e1 = nn.Conv2d(64, 128, kernel_size=4, stride=2, padding=1)
+        self.e2 = nn.Conv2d(128, 512, kernel_size=4, stride=2, padding=1)
+        self.d0 = nn.Linear(self.total_z_dim, 2048)
+        self.d1 = nn.ConvTranspose2d(128, 256, kernel_size=4, stride=2, padding=1)
+        self.d2 = nn.ConvTranspose2d(256, 64, kernel_size=4, stride=2, padding=1)
+        self.d3 = nn.ConvTranspose2d(64, 3, kernel_size=4, stride=2, padding=1)
+
+    def _bind_engine(self, lr: float = 1e-3) -> None:
+        from .conv import ConvEngine
+        trainable = [bool(getattr(c._radius_param(), "requires_grad", False)) for c in self.components]
+        eng = ConvEngine(self._comps_desc(), self.device, scalar_parametrization=self._scalar_parametrization,
+                         radius_trainable=trainable, lr=lr)
+        self._alias_parameters(eng)
+
+    def forward(self, x: Tensor, eps: Optional[Tensor] = None) -> Outputs:
+        eng = self._need_engine()
+        x = x.to(self.device, torch.float32).contiguous()
+        eps = self._eps(x.shape[0]) if eps is None else eps
+        c = eng._forward(x, eps)
+        out = {"concat_z": c["z"], "kl": c["kl"], "logits": c["logits"]}
+        return self._wrap_outputs(out)
+
+    def decode(self, concat_z: Tensor) -> Tensor:
+        return self._need_engine().decode(concat_z)
+
+    def log_likelihood(self, x: Tensor, n: int = 500, eps: Optional[Tensor] = None):
+        raise NotImplementedError("log_likelihood on the conv architecture is not built yet")

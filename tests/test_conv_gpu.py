@@ -1,0 +1,108 @@
+"""GPU tests of the conv architecture (BASELINE config [4], conv_vae.py:28-79) against the golden vectors recorded from
+the reference (B=4, CIFAR shapes, soft targets) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_after_adam, load_json, load_npz, summary_of
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def _cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def test_conv_layers_vs_torch(dev):
+    """The two patch-matrix gathers + contractions against torch.nn.functional.conv2d / conv_transpose2d (float64)."""
+    import torch.nn.functional as F
+    from mvae_amd import functional as Fn
+    from mvae_amd.conv import _col2im, _gemm_nn, _im2col, _nchw, _nhwc
+    g = torch.Generator().manual_seed(0)
+    B = 3
+    x = torch.randn(B, 5, 8, 8, generator=g)
+    W = torch.randn(7, 5, 4, 4, generator=g) * 0.2
+    b = torch.randn(7, generator=g)
+    ref = F.conv2d(x.double(), W.double(), b.double(), stride=2, padding=1)  # [B,7,4,4]
+    col = _im2col(x.to(dev).contiguous(), None, B, 5, 8, _nchw(8, 5))
+    y = Fn.linear_forward(col, W.view(7, 80).to(dev), b.to(dev))  # [(b,oy,ox), oc]
+    assert_close(_cpu(y.view(B, 4, 4, 7).permute(0, 3, 1, 2)), ref.numpy(), 2e-5, "conv2d", atol_frac=1e-5)
+    Wt = torch.randn(5, 6, 4, 4, generator=g) * 0.2
+    bt = torch.randn(6, generator=g)
+    reft = F.conv_transpose2d(x.double(), Wt.double(), bt.double(), stride=2, padding=1)  # [B,6,16,16]
+    x_cl = x.permute(0, 2, 3, 1).contiguous().view(B * 64, 5).to(dev)
+    colT = _gemm_nn(x_cl, Wt.view(5, 96).to(dev))
+    yt = _col2im(colT, bt.to(dev), None, B, 6, 16, _nchw(16, 6), False, (B, 6 * 256))
+    assert_close(_cpu(yt.view(B, 6, 16, 16)), reft.numpy(), 2e-5, "conv_transpose2d", atol_frac=1e-5)
+    yt2 = _col2im(colT, bt.to(dev), None, B, 6, 16, _nhwc(16, 6), True, (B * 256, 6))
+    assert_close(_cpu(yt2.view(B, 16, 16, 6).permute(0, 3, 1, 2)), torch.relu(reft).numpy(), 2e-5, "convT nhwc relu",
+                 atol_frac=1e-5)
+
+
+def test_conv_step_vs_golden(dev):
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from oracle import model as M
+    g = load_npz("g3_step_full.npz")
+    meta = load_json("g3_step_full.json")["cifar_conv_h2s2e2_learn"]
+    spec = M.Spec(meta["model"], in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    B = meta["batch"]
+    for steps in (1, 5):
+        key = f"cifar_conv_h2s2e2_learn/f32/steps{steps}/"
+        eng = ConvEngine([(c.letter, c.true_dim) for c in spec.components], dev, radius_trainable=[True] * 3)
+        eng.load_state(state0)
+        xs = synthetic.uniform_batches(steps, B, 3072).to(dev)
+        eps = synthetic.eps_batches(steps, B, spec.total_true_dim).to(dev)
+        for s in range(steps):
+            out = eng.forward_backward(xs[s], eps[s], 1.0, want_outputs=(steps == 1))
+            if steps == 1:
+                assert_close(_cpu(out["concat_z"]), g[key + "concat_z"], RTOL, "concat_z")
+                assert_close(_cpu(out["bce"]), g[key + "bce_rows"], RTOL, "bce rows")
+                assert_close(_cpu(out["kl"]), g[key + "kl_rows"], RTOL, "kl rows", atol_frac=1e-4)
+                ref = g[key + "logits_summary"]
+                assert_close(summary_of(_cpu(out["logits"]), ref), ref, RTOL, "logits summary")
+                for n, t in eng.grad_views().items():
+                    if key + "grad_summary/" + n in g:
+                        ref = g[key + "grad_summary/" + n]
+                        assert_close(summary_of(_cpu(t), ref), ref, 2 * RTOL, "grad " + n, atol_frac=2e-4)
+            eng.optimizer_step(True)
+            st = eng.read_stats()["last"]
+            ref = g[key + "stats"][s]
+            for got, want, nm in zip([st["bce"], st["kl"], st["elbo"]], ref[:3], ["bce", "kl", "elbo"]):
+                assert_close(got, want, RTOL if nm != "kl" else 5 * RTOL, f"{nm} step {s}")
+        for n, t in eng.param_views().items():
+            ref = g[key + "state_final_summary/" + n]
+            got = summary_of(_cpu(t), ref)
+            assert_close_after_adam(got[:3], ref[:3], 1e-3, steps, "final (sum, L2, max) " + n, rtol=5e-4)
+
+
+def test_conv_step_full_batch_vs_oracle(dev):
+    """B=32 of the BASELINE config [4] shapes: per-sample statistics and every gradient against the oracle."""
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from oracle import model as M
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    B = 32
+    x = synthetic.uniform_batches(1, B, 3072)[0]
+    eps = synthetic.eps_batches(1, B, 6)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=1.0, epoch=12)
+    eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True] * 3)
+    eng.load_state(state0)
+    out = eng.forward_backward(x.to(dev), eps.to(dev), 1.0, want_outputs=True)
+    assert_close(_cpu(out["logits"]), ref.logits.detach().numpy(), RTOL, "logits")
+    assert_close(_cpu(out["bce"]), ref.bce.detach().numpy(), RTOL, "bce")
+    assert_close(_cpu(out["kl"]), ref.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    for n, t in eng.grad_views().items():
+        if orc.P[n].grad is not None:
+            assert_close(_cpu(t), orc.P[n].grad.numpy(), 2 * RTOL, "grad " + n, atol_frac=2e-4)

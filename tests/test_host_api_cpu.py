@@ -53,6 +53,17 @@ def test_fixed_curvature_freezes_radii():
     assert float(comps[0].manifold.curvature) == -1.0 and float(comps[1].manifold.curvature) == 1.0
 
 
+def test_state_dict_contract_conv():
+    tab = load_json("g5_parser.json")["state_shapes"]
+    m = ConvolutionalVAE(8192, utils.parse_components("h2,s2,e2", False), _DS(), False)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == tab["h2,s2,e2|conv"]
+    from mvae_amd.conv import ConvFlatLayout
+    from mvae_amd.functional import ComponentLayout
+    flat = ConvFlatLayout(ComponentLayout([("h", 2), ("s", 2), ("e", 2)]))
+    assert [[n, list(s)] for n, _, s in flat.entries] == tab["h2,s2,e2|conv"]
+    assert sum(int(torch.tensor(s).prod()) if s else 1 for _, _, s in flat.entries) == 2090001
+
+
 @pytest.mark.parametrize("model", ["h2,s2,e2", "6h2,6s2,6e2", "e6"])
 def test_state_dict_contract(model):
     """Parameter names, shapes and registration order are the reference's (checkpoint compatibility)."""
@@ -67,8 +78,8 @@ def test_no_cpu_execution_path():
     m = FeedForwardVAE(16, utils.parse_components("h2,e2", False), _DS(), False)
     with pytest.raises(MvaeHipError):
         m(torch.zeros(2, 784))
-    with pytest.raises(NotImplementedError):
-        ConvolutionalVAE(8192, [], _DS(), False)
+    with pytest.raises(ValueError):  # the reference only warns (run.py:117-119); a wrong h_dim cannot work
+        ConvolutionalVAE(400, utils.parse_components("e2", False), _DS(), False)
 
 
 def test_should_stop_rule():
