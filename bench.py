@@ -173,7 +173,13 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": mfma_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": mfma_tf / F32_MFMA_PEAK_TF}
-    roof.update({"kernel": dom, "traffic": None, "kernel_ms": prof,
+    traffic = None  # fabric bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["kernels"]["k_" + dom]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    roof.update({"kernel": dom, "traffic": traffic, "kernel_ms": prof,
                  "step_bytes": sum(v["bytes"] for v in alg.values()),
                  "step_flops": sum(v["flops"] for v in alg.values())})
 
