@@ -38,7 +38,9 @@ __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ row, i
 
 // NT:  acc[i][j] += sum_{k in chunks} A[m0+i][k] * W[n0+j][k]      (y = x W^T: both operands K-contiguous)
 // The wave processes the 16-wide k-chunks c = chunk0, chunk0+stride, ... < nchunks.
-template <int G = 4>
+// FULL: every row of the tile exists, K is a multiple of 16 and both operands are 16-byte aligned -- the loads are
+// then plain dwordx4 without per-load branches (a chunk index past the end is clamped and its values zeroed).
+template <int G = 4, bool FULL = false>
 __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, int M, int m0,
                                          const float* __restrict__ W, int ldw, int N, int n0, int K, int chunk0,
                                          int stride, bool vecA, bool vecW, f32x4 acc) {
@@ -56,8 +58,17 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
       const int cc = c + g * stride;
       const int k = (cc << 4) + (q << 2);
       const bool ok = cc < nchunks;
-      a[g] = load4_guarded(arow, k, K, a_ok && ok, vecA);
-      b[g] = load4_guarded(wrow, k, K, w_ok && ok, vecW);
+      if (FULL) {
+        const int kk = ok ? k : 0;
+        float4 av = *reinterpret_cast<const float4*>(arow + kk);
+        const float4 bv = *reinterpret_cast<const float4*>(wrow + kk);
+        if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[g] = av;
+        b[g] = bv;
+      } else {
+        a[g] = load4_guarded(arow, k, K, a_ok && ok, vecA);
+        b[g] = load4_guarded(wrow, k, K, w_ok && ok, vecW);
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -72,7 +83,7 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
 
 // TN:  acc[i][j] += sum_{m} P[m][p0+i] * Q[m][q0+j]     (dW = dy^T x: contraction over the batch rows)
 // The wave processes rows m = 4*s + q for steps s = step0, step0+stride, ... ; 4 rows per MFMA.
-template <int G = 8>
+template <int G = 8, bool FULL = false>
 __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, int NP, int p0,
                                          const float* __restrict__ Q, int ldq, int NQ, int q0, int Mrows, int step0,
                                          int stride, f32x4 acc) {
@@ -87,8 +98,15 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
     for (int g = 0; g < G; ++g) {
       const int m = ((s + g * stride) << 2) + q;
       const bool m_ok = m < Mrows;
-      a[g] = (p_ok && m_ok) ? P[(size_t)m * ldp + p0 + i] : 0.f;
-      b[g] = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
+      if (FULL) {  // all columns exist; a row past the end is clamped and zeroed
+        const int mm = m_ok ? m : 0;
+        const float av = P[(size_t)mm * ldp + p0 + i];
+        b[g] = Q[(size_t)mm * ldq + q0 + i];
+        a[g] = m_ok ? av : 0.f;
+      } else {
+        a[g] = (p_ok && m_ok) ? P[(size_t)m * ldp + p0 + i] : 0.f;
+        b[g] = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; g += 2) {
@@ -100,7 +118,7 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
 }
 
 // NN:  acc[i][j] += sum_{k} G[m0+i][k] * W[k][n0+j]      (dx = dy W: G is K-contiguous, W is N-contiguous)
-template <int G = 4>
+template <int G = 4, bool FULL = false>
 __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, int M, int m0,
                                          const float* __restrict__ W, int ldw, int N, int n0, int K, int chunk0,
                                          int stride, bool vecG, f32x4 acc) {
@@ -119,6 +137,15 @@ __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, 
       const int cc = c + g * stride;
       const int k = (cc << 4) + (q << 2);
       const bool ok = cc < nchunks;
+      if (FULL) {
+        const int kk = ok ? k : 0;
+        float4 av = *reinterpret_cast<const float4*>(grow + kk);
+        if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[g] = av;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[g][t] = wcol[(size_t)(kk + t) * ldw];
+        continue;
+      }
       a[g] = load4_guarded(grow, k, K, g_ok && ok, vecG);
 #pragma unroll
       for (int t = 0; t < 4; ++t) b[g][t] = (w_ok && ok && k + t < K) ? wcol[(size_t)(k + t) * ldw] : 0.f;

@@ -826,7 +826,7 @@ __device__ __forceinline__ void job_tn_opt(float (*red)[16][17], float* sh, cons
 // The MFMA is issued with the operand roles swapped (A <- Q, B <- P), so that lane l ends up with the four
 // CONSECUTIVE outputs out[p0 + (l&15)][q0 + 4*(l>>4) + 0..3]: gradient, parameter and both Adam moments move as one
 // 16-byte access per lane each.
-template <bool ADAM>
+template <bool ADAM, bool FULL = false>
 __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int pt, const float* Q, int ldq, int NQ,
                                             int qt, int Mrows, float* out, int ldo, const AdamArgs& aa) {
   if (qt * 16 >= NQ) return;
@@ -861,7 +861,7 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
     bc2s = (float)sqrt(bc2);
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_tn<32>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
+  acc = tile_tn<32, false>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);  // (unguarded variant measured slower)
   if (ADAM) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
@@ -931,20 +931,34 @@ __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/,
   }
 }
 
+// XCD-aware tile assignment for the NT layers.  Workgroup L is observed to run on XCD L % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"); each XCD has a private L2, so a weight row-block fetched by workgroups on all 8 XCDs crosses
+// the fabric 8 times.  Column tiles (= weight row-blocks) are therefore dealt to XCDs: XCD k owns nt = k, k+8, ... and
+// runs every row tile mt of those; the activation rows are the only operand every XCD fetches.  Placement only
+// changes speed, never results.  Launch with grid = 8 * ceil(NT/8) * MT; returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt) {
+  const int L = blockIdx.x, k = L & 7, s = L >> 3;
+  *nt = k + 8 * (s / MT);
+  *mt = s % MT;
+  return *nt < NT;
+}
+
 // ---- 1: encoder layer (512 threads).  In the fused single-GPU step, workgroup (0,0) also advances the step counter.
+template <bool FULL>
 __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
                                                  int D, int* counters, int bump_step) {
   __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
-  const int mt = blockIdx.y, nt = blockIdx.x;
-  if (bump_step && mt == 0 && nt == 0 && threadIdx.x == 0) counters[0] = counters[0] + 1;
+  int mt, nt;
+  if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) counters[0] = counters[0] + 1;
+  if (!xcd_tile((H + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
   const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_nt<7>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
+  acc = tile_nt<7, FULL>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
   const float s = reduce_tiles8(red, acc);
   if (threadIdx.x < 256) {
     const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
-    if (m < B && n < H) {
+    if (FULL || (m < B && n < H)) {
       const float v = s + b[n];
       h[(size_t)m * H + n] = v > 0.f ? v : 0.f;
     }
@@ -1136,11 +1150,13 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
 }
 
 // ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
+template <bool FULL>
 __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
                                                   float* g, float* bce_part, float* logits_user, int B, int H, int D) {
   __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
-  const int mt = blockIdx.y, nt = blockIdx.x;
+  int mt, nt;
+  if (!xcd_tile((D + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
   const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
   const bool ok = threadIdx.x < 256 && m < B && n < D;
   float t = 0.f, bias = 0.f;
@@ -1150,7 +1166,7 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   }
   const bool v1 = aligned16(hd) && (H & 3) == 0, v2 = aligned16(W) && (H & 3) == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_nt<4>(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, kW8, v1, v2, acc);
+  acc = tile_nt<4, FULL>(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, kW8, v1, v2, acc);
   const float s = reduce_tiles8(red, acc);
   if (threadIdx.x >= 256) return;
   float loss = 0.f;
@@ -1173,7 +1189,7 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
 }
 
 // ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
-template <bool ADAM>
+template <bool ADAM, bool FULL>
 __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
@@ -1190,7 +1206,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     if (ok) mask = hd[(size_t)m * H + n];
     const bool vg = aligned16(g) && (D & 3) == 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_nn<7>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
+    acc = tile_nn<7, false>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);  // (the unguarded variant measured slower)
     const float s = reduce_tiles8(red, acc);
     if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
     return;
@@ -1259,7 +1275,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
 
 // ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
 // workgroup) ; dW_logits = g^T hd (+Adam: W_logits was last read by launch 4)
-template <int DMAX, bool FAST, bool ADAM>
+template <int DMAX, bool FAST, bool ADAM>  // FAST also implies tile-aligned B, H, D (checked on the host)
 __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, const float* heads,
                                                     int ldh, const float* eps, int eps_ld, const float* radii,
                                                     const float* h, const float* Wh, float* dheads, float* dh,
@@ -1277,7 +1293,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
     const int ntH4 = ((H + 15) / 16 + 3) / 4;
-    job_tn_wave<ADAM>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
+    if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
+    else job_tn_wave<ADAM, false>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
     return;
   }
   const size_t row = b;
@@ -1390,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
 }
 
 // ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
-template <bool ADAM>
+template <bool ADAM, bool FULL>
 __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
                                                  int ldh, const float* h, const float* dhd, const float* z, int ldz,
                                                  const float* drpart, float* G, float* P, int B, int H, int D, int NH,
@@ -1410,8 +1427,8 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
   };
   if (b < n_we0) {  // dW_e0[H,D] = dh^T x
     const int ntD4 = ((D + 15) / 16 + 3) / 4;
-    job_tn_wave<ADAM>(dh, H, H, b / ntD4, x, D, D, (b % ntD4) * 4 + (threadIdx.x >> 6), B, G + off_w_e0, D,
-                      at(off_w_e0));
+    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntD4, x, D, D, (b % ntD4) * 4 + (threadIdx.x >> 6), B, G + off_w_e0, D,
+                            at(off_w_e0));
     return;
   }
   b -= n_we0;
@@ -1538,9 +1555,17 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   const bool fast = NH <= 16 && Z <= 8 && H <= 512 && (H & 3) == 0 && aligned16(P + d.off_w_heads);
   int zp = 1;
   while (zp < Z) zp <<= 1;
-  const bool fast_b = fast && (H + 256 / zp - 1) / (256 / zp) <= 16;
+  const bool fast_b = fast && (H + 256 / zp - 1) / (256 / zp) <= 16 && (B % 16 == 0) && (H % 16 == 0) &&
+                      (D % 16 == 0);
 
-  STEP_LAUNCH(k_enc_fwd, dim3(c->nt_h, c->nt_b), dim3(512), 0, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
+  // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
+  const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
+                    aligned16(P + d.off_w_logits) && aligned16(ws);
+  if (full)
+    STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0);
+  else
+  STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
                      d.step_count, fused ? 1 : 0);
   {
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
@@ -1551,18 +1576,21 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
 #undef LF
   }
-  STEP_LAUNCH(k_dec1_fwd, dim3(c->nt_d, c->nt_b), dim3(512), 0, hd, P + d.off_w_logits, P + d.off_b_logits,
-                     x, g, bce_part, logits, B, H, D);
+  if (full)
+    STEP_LAUNCH(k_dec1_fwd<true>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+                P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
+  else
+    STEP_LAUNCH(k_dec1_fwd<false>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+                P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
   {
     const int n_dhd = c->nt_b * c->nt_h, n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
-    if (fused)
-      STEP_LAUNCH(k_dec1_bwd<true>, dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,
-                         G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
-                         at(d.off_b_logits));
-    else
-      STEP_LAUNCH(k_dec1_bwd<false>, dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,
-                         G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,
-                         at(d.off_b_logits));
+#define DB(AD, FU)                                                                                             \
+  STEP_LAUNCH((k_dec1_bwd<AD, FU>), dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,               \
+              G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
+              at(d.off_b_logits))
+    if (fused) { if (full) DB(true, true); else DB(true, false); }
+    else { if (full) DB(false, true); else DB(false, false); }
+#undef DB
   }
   {
     const int n_dwl = c->nt_d * ((c->nt_h + 3) / 4);
@@ -1585,11 +1613,12 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
-#define EB(AD)                                                                                                       \
-  STEP_LAUNCH(k_enc_bwd<AD>, dim3(grid), dim3(256), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
+#define EB(AD, FU)                                                                                                   \
+  STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(256), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
                      drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
                      d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
-    if (fused) EB(true); else EB(false);
+    if (fused) { if (full) EB(true, true); else EB(true, false); }
+    else { if (full) EB(false, true); else EB(false, false); }
 #undef EB
   }
 #undef STEP_LAUNCH
