@@ -1010,29 +1010,46 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
   float wd[2][8], bd[2] = {0.f, 0.f};
   float bhv = 0.f;
   if (FAST) {
+    // Branch-free requests: an index past the end is clamped to a valid address and the value zeroed afterwards
+    // (every `if (cond) load` costs a lone wave a taken/not-taken branch; ~30 of them made this prologue 2.5 us).
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (tid + 256 * u < H) hv[u] = h[row * H + tid + 256 * u];
+    for (int u = 0; u < 2; ++u) {
+      const int k = tid + 256 * u;
+      const float v = h[row * H + (k < H ? k : 0)];
+      hv[u] = k < H ? v : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = wave + 4 * q;
+      const int nn = n < NH ? n : 0;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int k = lane * 4 + 256 * u;
-        wf[q][u] = (n < NH && k < H) ? *reinterpret_cast<const float4*>(Wh + (size_t)n * H + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = n < NH && k < H;
+        float4 v = *reinterpret_cast<const float4*>(Wh + (size_t)nn * H + (k < H ? k : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        wf[q][u] = v;
       }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = tid + 256 * u;
-      if (c < H) {
-        bd[u] = bd0[c];
+      const int cc = c < H ? c : 0;
+      bd[u] = bd0[cc];
+      if (Z == 8) {  // wave-uniform: the row of W_d0 is two 16-byte loads
+        const float4 a = *reinterpret_cast<const float4*>(Wd0 + (size_t)cc * 8);
+        const float4 b4 = *reinterpret_cast<const float4*>(Wd0 + (size_t)cc * 8 + 4);
+        wd[u][0] = a.x; wd[u][1] = a.y; wd[u][2] = a.z; wd[u][3] = a.w;
+        wd[u][4] = b4.x; wd[u][5] = b4.y; wd[u][6] = b4.z; wd[u][7] = b4.w;
+      } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wd[u][j] = (j < Z) ? Wd0[(size_t)c * Z + j] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const float v = Wd0[(size_t)cc * Z + (j < Z ? j : 0)];
+          wd[u][j] = j < Z ? v : 0.f;
+        }
       }
     }
-    if (tid < NH) bhv = bh[tid];
+    bhv = bh[tid < NH ? tid : 0];
   }
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
   if (tid < t.n) {  // staged last so that its wait does not delay the issue of the loads above
