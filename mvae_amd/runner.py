@@ -33,7 +33,19 @@ class StepRunner:
         if self.gs > 0:
             if self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:  # noqa: BLE001
+                if self.world == 1:
+                    raise
+                # a collective that cannot be captured on this stack must not take the run down: fall back to eager
+                # launches (same arithmetic, host launch cost back on the critical path)
+                import sys
+                print(f"[StepRunner] graph capture with the gradient all-reduce failed ({type(e).__name__}: {e}); "
+                      "running eagerly", file=sys.stderr, flush=True)
+                self.graphs = []
+                self.gs = 0
+                torch.cuda.synchronize()
 
     def _one(self, i: int) -> None:
         if self.dp is None:

@@ -1,0 +1,77 @@
+"""Data-parallel step with the REAL engine: two ranks (gloo, both on cuda:0 -- RCCL refuses two ranks on one device)
+each run forward/backward on half of the rows, all-reduce the flat gradient buffer and apply the optimizer; the result
+must equal the single-process step on the full batch (strong-scaling parity)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import assert_close_after_adam
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, steps, q):
+    import torch.distributed as dist
+    from mvae_amd import synthetic
+    from mvae_amd.distributed import DataParallelStep, shard_rows
+    from mvae_amd.engine import StepEngine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    xs = synthetic.digits_like_batches(steps, 128)
+    eps = synthetic.eps_batches(steps, 128, 6)
+    lo, hi = shard_rows(128, rank, world)
+    dp = DataParallelStep(eng)
+    dp.broadcast_state()
+    for s in range(steps):
+        dp.train_step(xs[s, lo:hi].to(dev), eps[s, lo:hi].to(dev), 1.0, True)
+    total = dp.reduce_stats().cpu().numpy().copy()
+    q.put((rank, eng.params.cpu().numpy().copy(), total))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_equals_single_process():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    steps, world = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    xs = synthetic.digits_like_batches(steps, 128).to(dev)
+    eps = synthetic.eps_batches(steps, 128, 6).to(dev)
+    for s in range(steps):
+        eng.train_step(xs[s], eps[s], 1.0, True)  # fused single-GPU path
+    ref = eng.params.cpu().numpy()
+    assert np.array_equal(results[0][1], results[1][1]), "ranks diverged"
+    assert_close_after_adam(results[0][1], ref, 1e-3, steps, "flat parameters, dp2 vs single process")
+    tot = eng.stats.cpu().numpy()
+    n = 4 + 3
+    np.testing.assert_allclose(results[0][2][:3], tot[:3], rtol=2e-4)
+    assert results[0][2][3] == 2 * steps and tot[3] == steps  # every rank counts its own steps
