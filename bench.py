@@ -30,11 +30,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
 
 
-def algorithmic_per_launch(P):
+def algorithmic_per_launch(P, NH=12, Z=8, E=6):
     """Algorithmic bytes / flops of each of the six launches of one fused step at B=128: every
     tensor a launch consumes or produces counted once; a weight updated in a gradient epilogue costs 7 floats per
     element (read p, m, v; write g, p, m, v)."""
-    NH, Z, E = 12, 8, 6
     f4 = 4.0
     return {
         "enc_fwd": dict(flops=2.0 * B * D * H, bytes=f4 * (B * D + H * D + H + B * H)),
@@ -49,14 +48,14 @@ def algorithmic_per_launch(P):
     }
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=12.0, model=MODEL, fixed=False):
     """The oracle (CPU restatement of the reference path, pinned to golden vectors recorded from the reference) timed
     on this box's host cores: same model, same synthetic inputs, same step (fwd, ELBO, bwd, Adam + curvature SGD).
     torch's default (one thread per core) oversubscribes this op-dispatch-bound workload badly on a many-core host,
     so a short probe picks the fastest intra-op thread count and that one is timed and reported."""
     from mvae_amd import synthetic
     from oracle import model as M
-    spec = M.Spec(MODEL, in_dim=D, h_dim=H, fixed_curvature=False)
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=fixed)
     state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
     n_data = 16
     xs = synthetic.digits_like_batches(n_data, B)
@@ -106,6 +105,10 @@ def main():
                          "curvature training (batch-summed SGD on the radii) goes non-finite after ~1e4 steps on a "
                          "small cycled data set -- the oracle does too -- and a benchmark should not time NaNs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", type=str, default=MODEL,
+                    help="latent space string; the driver's metric is the default (BASELINE configs[1]); "
+                         "'e6' = configs[0], '6h2,6s2,6e2' = configs[3]")
+    ap.add_argument("--fixed-curvature", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,13 +127,19 @@ def main():
     from mvae_amd.engine import StepEngine
     from mvae_amd.runner import StepRunner
 
-    eng = StepEngine(COMPS, D, H, dev, radius_trainable=[True, True, False], lr=1e-3)
+    from mvae_amd.utils import parse_component_str
+    comps = []
+    for tok in args.model.lower().split(","):
+        mult, letter, dim = parse_component_str(tok.strip())
+        comps += [(letter, dim)] * mult
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[not args.fixed_curvature] * len(comps), lr=1e-3)
     shapes = [(n, s) for n, _, s in eng.flat.entries]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0))
     n_data = max(args.graph_steps, 1) * 4  # distinct resident batches, cycled
     xs = synthetic.digits_like_batches(n_data, B, seed=4321 + rank).to(dev)
     eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
-    runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=True, graph_steps=args.graph_steps,
+    runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not args.fixed_curvature,
+                        graph_steps=args.graph_steps,
                         world_size=world, reset_every=args.reset_every)
 
     def sync_all():
@@ -160,8 +169,9 @@ def main():
         return
 
     # per-launch durations measured live with HIP events on the launch stream (mvae_step_profile)
-    prof = eng.profile_step(xs[0], eps[0], 1.0, True, iters=200)
-    alg = algorithmic_per_launch(eng.flat.n_logical_params())
+    prof = eng.profile_step(xs[0], eps[0], 1.0, not args.fixed_curvature, iters=200)
+    alg = algorithmic_per_launch(eng.flat.n_logical_params(), eng.layout.heads_dim, eng.layout.z_dim,
+                                 eng.layout.eps_dim)
     dom = max(prof, key=prof.get)
     dur_s = prof[dom] * 1e-3
     hbm_gbs = alg[dom]["bytes"] / dur_s / 1e9
@@ -184,7 +194,7 @@ def main():
                  "step_flops": sum(v["flops"] for v in alg.values())})
 
     line = {
-        "metric": "ELBO-steps/sec (batch 128) MNIST h2,s2,e2",
+        "metric": f"ELBO-steps/sec (batch 128) MNIST {args.model}",
         "value": args.steps * world / dt,
         "unit": "ELBO-steps/sec",
         "n_gpus": world,
@@ -196,7 +206,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: MNIST shapes (D=784), model h2,s2,e2, learnable curvature, "
+        "config": {"workload": ("BASELINE configs[1]: " if args.model == MODEL and not args.fixed_curvature else "") +
+                               f"MNIST shapes (D=784), model {args.model}, "
+                               f"{'fixed' if args.fixed_curvature else 'learnable'} curvature, "
                                "MLP h_dim=400, batch 128 per GPU, epoch>=10 state",
                    "global_batch": B * world, "parallelism": f"dp{world}", "graph_steps": args.graph_steps,
                    "state_reset_every": args.reset_every,
@@ -204,7 +216,7 @@ def main():
         "roofline": roof,
     }
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline"] = cpu_baseline(model=args.model, fixed=args.fixed_curvature)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

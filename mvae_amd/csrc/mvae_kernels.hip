@@ -70,6 +70,10 @@ struct CompTable {
   mvae_component_desc c[kMaxComp];
   int dir_off[kMaxComp + 1];  // prefix sum of derivative directions per component (d + logvar_dim + trainable radius)
   unsigned char trainable[kMaxComp];
+  // Placement of the components on the 4 waves of a latent workgroup: components of the same manifold kind share a
+  // wave (one instruction stream, no divergence), different kinds run on different waves.
+  unsigned char wave_of[kMaxComp];
+  unsigned char lane_of[kMaxComp];
 };
 
 static int bucket_of(int dmax) {
@@ -103,6 +107,24 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
   t->dir_off[ncomp] = off;
   t->total_dirs = off;
   *dmax_out = dmax;
+  // wave placement: the kinds present split the 4 waves between them; a kind's components go round-robin over its waves
+  int kinds[4], nk = 0;
+  for (int k = 0; k < 4; ++k) {
+    bool present = false;
+    for (int i = 0; i < ncomp; ++i) present |= (comps[i].kind == k);
+    if (present) kinds[nk++] = k;
+  }
+  const int wpk = nk ? (4 / nk > 0 ? 4 / nk : 1) : 1;
+  int fill[4] = {0, 0, 0, 0};
+  for (int ki = 0; ki < nk; ++ki) {
+    int rr = 0;
+    for (int i = 0; i < ncomp; ++i)
+      if (comps[i].kind == kinds[ki]) {
+        const int w = (ki * wpk + (rr++ % wpk)) & 3;
+        t->wave_of[i] = (unsigned char)w;
+        t->lane_of[i] = (unsigned char)fill[w]++;
+      }
+  }
   return 0;
 }
 
@@ -997,6 +1019,7 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
   __shared__ __attribute__((aligned(16))) float z_s[kHeadsMax];
   __shared__ mvae_component_desc desc_s[kMaxComp];  // per-lane indexed below: LDS, not the kernarg segment
   __shared__ float rad_s[kMaxComp];
+  __shared__ signed char comp_at_s[4][kMaxComp];  // [wave][lane] -> component (or -1)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t row = blockIdx.x;
   float* h_s = dyn;
@@ -1052,9 +1075,12 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
     bhv = bh[tid < NH ? tid : 0];
   }
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
+  comp_at_s[tid >> 6][tid & 63] = -1;
+  lds_barrier();
   if (tid < t.n) {  // staged last so that its wait does not delay the issue of the loads above
     desc_s[tid] = t.c[tid];
     rad_s[tid] = radii[tid];
+    comp_at_s[t.wave_of[tid]][t.lane_of[tid]] = (signed char)tid;
   }
   if (!FAST)
     for (int k = tid; k < H; k += 256) h_s[k] = h[row * H + k];
@@ -1122,12 +1148,12 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
 
   // ---- latent components: component ci runs on wave ci&3, lane ci>>2 (different manifolds land on different waves)
   {
-    const int ci = lane * 4 + wave;
+    const int ci = comp_at_s[wave][lane];
 #ifdef MV_DBG_SKIP_COMP
-    if (ci < t.n) { kl[(size_t)ci * B + row] = heads_s[0]; z_s[t.c[ci].z_col] = eps_s[0]; z_s[t.c[ci].z_col+1] = radii[0]; }
+    if (ci >= 0) { kl[(size_t)ci * B + row] = heads_s[0]; z_s[t.c[ci].z_col] = eps_s[0]; z_s[t.c[ci].z_col+1] = radii[0]; }
     if (false) {
 #else
-    if (ci < t.n) {
+    if (ci >= 0) {
 #endif
       float klv;
       comp_fwd_row<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr,
@@ -1266,19 +1292,25 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
   };
   const float bce_sum = block_sum(bce_acc);
   const float elbo_sum = block_sum(elbo_acc);
-  float kl_total = 0.f;
   const int last = 4 + ncomp;
-  for (int i = 0; i < ncomp; ++i) {
-    float a = 0.f;
-    for (int r = tid; r < B; r += nthr) a += kl[(size_t)i * B + r];
-    const float s = block_sum(a);
-    kl_total += s;
-    if (tid == 0) {
-      stats[4 + i] += s;
-      stats[last + 4 + i] = s;
+  // per-component KL sums: one wave per component (waves take components round-robin), rows summed in lane order
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    for (int i = wave; i < ncomp; i += nw) {
+      float a = 0.f;
+      for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
+      a = wave_sum(a);
+      if (lane == 0) {
+        stats[4 + i] += a;
+        stats[last + 4 + i] = a;
+        sm[16 + i] = a;
+      }
     }
   }
+  __syncthreads();
+  float kl_total = 0.f;
   if (tid == 0) {
+    for (int i = 0; i < ncomp; ++i) kl_total += sm[16 + i];
     stats[0] += bce_sum;
     stats[1] += kl_total;
     stats[2] += elbo_sum;
@@ -1305,6 +1337,9 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   __shared__ float dz_s[kHeadsMax];
   __shared__ float dheads_s[kHeadsMax];
   __shared__ float rad_s[kMaxComp];
+  __shared__ signed char comp_at_s[4][kMaxComp];  // [wave][slot] -> component (or -1), slots in lane_of order
+  __shared__ mvae_component_desc desc_s[kMaxComp];
+  __shared__ int ndir_s[kMaxComp];
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (b >= n_rows) {  // dW_logits[D,H] tile
@@ -1347,7 +1382,14 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     }
   }
   for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
-  if (tid < t.n) rad_s[tid] = radii[tid];
+  comp_at_s[tid >> 6][tid & 63] = -1;
+  lds_barrier();
+  if (tid < t.n) {
+    rad_s[tid] = radii[tid];
+    desc_s[tid] = t.c[tid];
+    ndir_s[tid] = t.dir_off[tid + 1] - t.dir_off[tid];
+    comp_at_s[t.wave_of[tid]][t.lane_of[tid]] = (signed char)tid;
+  }
   if (tid < NH) heads_s[tid] = heads[row * ldh + tid];
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
   lds_barrier();
@@ -1385,15 +1427,30 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     lds_barrier();
   }
   MV_STAMP(10);
-  // ---- component backward: wave w takes components w, w+4, ...; lane = input direction (forward-mode duals)
-  for (int ci = wave; ci < t.n; ci += 4) {
-    const mvae_component_desc& c = t.c[ci];
-    const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
-    for (int dir = lane; dir < ndir; dir += 64) {
-      const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, rad_s, dz_s, beta, dir);
-      if (dir < c.true_dim) dheads_s[c.mean_col + dir] = gv;
-      else if (dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (dir - c.true_dim)] = gv;
-      else drpart[(size_t)ci * B + row] = gv;
+  // ---- component backward (forward-mode duals): the wave's components (all of one manifold kind) are flattened into
+  // (component, input direction) items, one lane per item, 64 items per pass
+  {
+    int total = 0;
+    for (int sidx = 0; sidx < kMaxComp; ++sidx) {
+      const int ci = comp_at_s[wave][sidx];
+      if (ci < 0) break;
+      total += ndir_s[ci];
+    }
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      if (item < total) {
+        int rem = item, ci = comp_at_s[wave][0], sidx = 0;
+        while (rem >= ndir_s[ci]) {
+          rem -= ndir_s[ci];
+          ci = comp_at_s[wave][++sidx];
+        }
+        const mvae_component_desc& c = desc_s[ci];
+        const int dir = rem;
+        const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, rad_s, dz_s, beta, dir);
+        if (dir < c.true_dim) dheads_s[c.mean_col + dir] = gv;
+        else if (dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (dir - c.true_dim)] = gv;
+        else drpart[(size_t)ci * B + row] = gv;
+      }
     }
   }
   lds_barrier();

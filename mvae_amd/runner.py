@@ -57,22 +57,24 @@ class StepRunner:
         # snapshot the state the warm-up launches below will advance, so that capturing has no net effect
         eng = self.eng
         keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for i in range(min(3, self.n_data)):  # library / RCCL warm-up outside capture
-                self._one(i)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for gi in range(self.n_data // self.gs):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for i in range(gi * self.gs, (gi + 1) * self.gs):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(min(3, self.n_data)):  # library / RCCL warm-up outside capture
                     self._one(i)
-            self.graphs.append(g)
-        torch.cuda.synchronize()
-        for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
-            dst.copy_(src)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for gi in range(self.n_data // self.gs):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(gi * self.gs, (gi + 1) * self.gs):
+                        self._one(i)
+                self.graphs.append(g)
+            torch.cuda.synchronize()
+        finally:  # capturing (or failing to) must have no net effect on the model
+            for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
+                dst.copy_(src)
 
     def _state(self):
         e = self.eng

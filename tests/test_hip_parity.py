@@ -358,3 +358,40 @@ def test_fused_step_matches_oracle_other_batch_sizes(dev):
         assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, f"elbo B={B}")
         for n, t in eng.param_views().items():
             assert_close(_cpu(t), orc.P[n].detach().numpy(), RTOL, f"param {n} B={B}")
+
+
+# ------------------------------------------------------------------------------------------------ robustness envelope
+@pytest.mark.parametrize("radius", [1e-5, 1.0, 1e5])
+@pytest.mark.parametrize("scale", [100.0, 1.01, 1.0])
+@pytest.mark.parametrize("d", [2, 5, 10, 20, 40])
+def test_wrapped_normal_envelope(dev, d, scale, radius):
+    """Reference tests/mvae/distributions/test_wrapped_normal.py:24-52 restated: WrappedNormal on the hyperboloid at
+    loc = mu_0 with dims {3,6,11,21,41}, scales {100, 1.01, 1}, radii {1e-5, 1, 1e5}: samples and log-probs are finite
+    and log_prob <= 0 -- here through the fused component operator (1000 samples x 2 rows), plus the oracle's values."""
+    import math
+    from mvae_amd import functional as Fn
+    from oracle import model as M
+    lay = Fn.ComponentLayout([("h", d)])
+    B, n = 2, 1000
+    lv_raw = math.log(math.expm1(scale - 1e-5))  # softplus^-1
+    heads = torch.zeros(B, 2 * d)
+    heads[:, d:] = lv_raw
+    eps = torch.randn(n, B, d, generator=torch.Generator().manual_seed(42))
+    out = Fn.component_forward(lay, heads.to(dev), eps.to(dev), torch.tensor([radius], device=dev), want_kl=False,
+                               want_log_probs=True)
+    z, lq = out["z"].cpu(), out["log_q"][0].cpu()
+    assert torch.isfinite(z).all() and torch.isfinite(lq).all()
+    assert (lq <= 0).all(), "Log probs too big."
+    o = M.component_forward(M.ComponentSpec("h", d), heads[:, :d], heads[:, d:], eps, torch.tensor(radius),
+                            want_log_probs=True)
+    # the same guarded arithmetic on both sides: agreement even where clamps are active (R = 1e-5, 1e5).
+    # Exception, stated: the reference's logsinh(r) - log(r) evaluates log(1 - exp(-2r)); for r = |u|/R < 1e-4 (only
+    # reachable at R = 1e5 with an unusually short sample) the float32 cancellation in 1 - exp(-2r) leaves 2-3
+    # significant digits in EITHER implementation, so those entries are compared at the precision the formula has.
+    r = (eps * (scale)).norm(dim=-1) / radius
+    well = (r >= 1e-4).numpy()
+    a, b = lq.numpy(), o.log_q.numpy()
+    if well.any():
+        assert_close(a[well], b[well], 2e-4, f"log_q d={d} scale={scale} R={radius}", atol_frac=2e-4)
+    if (~well).any():
+        assert np.abs(a[~well] - b[~well]).max() < 0.5 * (d - 1) + 1e-3

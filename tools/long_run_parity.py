@@ -18,15 +18,18 @@ ap.add_argument("--every", type=int, default=200)
 ap.add_argument("--curv-after", type=int, default=0, help="curvature SGD starts after this many steps")
 ap.add_argument("--n-data", type=int, default=200)
 ap.add_argument("--no-oracle", action="store_true")
+ap.add_argument("--model", type=str, default="h2,s2,e2")
+ap.add_argument("--digits", action="store_true")
 args = ap.parse_args()
 
 torch.set_num_threads(8)
 dev = torch.device("cuda:0")
-spec = M.Spec("h2,s2,e2", in_dim=784, h_dim=400, fixed_curvature=False)
+spec = M.Spec(args.model, in_dim=784, h_dim=400, fixed_curvature=False)
 state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
-xs = synthetic.binary_batches(args.n_data, 128, 784)
-eps = synthetic.eps_batches(args.n_data, 128, 6)
-eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+xs = synthetic.digits_like_batches(args.n_data, 128) if args.digits else synthetic.binary_batches(args.n_data, 128, 784)
+eps = synthetic.eps_batches(args.n_data, 128, spec.total_true_dim)
+comps = [(c.letter, c.true_dim) for c in spec.components]
+eng = StepEngine(comps, 784, 400, dev, radius_trainable=[True] * len(comps))
 eng.load_state(state0)
 xs_d, eps_d = xs.to(dev), eps.to(dev)
 orc = None if args.no_oracle else M.StepOracle(spec, state0)
@@ -39,11 +42,11 @@ for s in range(args.steps):
     if (s + 1) % args.every == 0 or s == args.steps - 1:
         st = eng.read_stats()["last"]
         pv = eng.param_views()
-        line = f"step {s+1:6d}  hip elbo/sample {st['elbo']/128:10.4f}  R_h {float(pv['components.0._nradius']):.5f} " \
-               f"R_s {float(pv['components.1._pradius']):.5f}"
+        radii = [round(float(v), 4) for k, v in pv.items() if k.endswith("radius")]
+        line = f"step {s+1:6d}  hip elbo/sample {st['elbo']/128:10.4f}  radii {radii}"
         if orc is not None:
             worst = max(float((pv[n].cpu() - orc.P[n].detach()).abs().max() / orc.P[n].detach().abs().max().clamp_min(1e-30))
                         for n in pv)
-            line += f" | oracle elbo/sample {float(out.elbo)/128:10.4f} R_h {float(orc.P['components.0._nradius']):.5f} " \
-                    f"R_s {float(orc.P['components.1._pradius']):.5f} | max param rel diff {worst:.2e}"
+            oradii = [round(float(v), 4) for k, v in orc.P.items() if k.endswith("radius")]
+            line += f" | oracle elbo/sample {float(out.elbo)/128:10.4f} radii {oradii}"
         print(line, flush=True)
