@@ -1,19 +1,22 @@
 // mvae_kernels.hip -- gfx950 kernels + C ABI (include/mvae_hip.h) for the per-batch hot path of mvae.
 //
-// The ELBO step (reference: ModelVAE.train_step, mt/mvae/models/vae.py:149-166) is SEVEN launches; each one is bounded
-// by a grid-wide data dependency (every output of launch k is needed by every workgroup of launch k+1):
+// The ELBO step (reference: ModelVAE.train_step, mt/mvae/models/vae.py:149-166) is SIX launches; each cut is a
+// grid-wide data dependency (every output of launch k is needed by every workgroup of launch k+1):
 //
-//   1 k_enc_fwd     h  = relu(x W_e0^T + b)                                   MFMA NT, 16x16 tiles, 4-way split-K
-//   2 k_latent_fwd  heads = h W_heads^T + b  ->  per-component exp_map_mu0 / softplus / wrapped-normal sample /
-//                   KL  ->  concat_z  ->  hd = relu(z W_d0^T + b)             MFMA NT + per-row manifold math
+//   1 k_enc_fwd     h  = relu(x W_e0^T + b)                      MFMA NT, 16x16 tile / workgroup, 8 waves split K
+//   2 k_latent_fwd  one batch ROW per workgroup: heads = h W_heads^T + b -> per-component exp_map_mu0 / softplus /
+//                   wrapped-normal sample / KL -> concat_z -> hd = relu(z W_d0^T + b)
 //   3 k_dec1_fwd    logits = hd W_logits^T + b ; BCE-with-logits row partials ; g = sigmoid(logits) - x
-//   4 k_dec1_bwd    dW_logits = g^T hd ; db_logits ; dhd = (g W_logits) * [hd>0] ; step statistics
-//   5 k_latent_bwd  dz = dhd W_d0 -> component backward (forward-mode duals, one thread per input direction)
-//                   -> dheads ; dh = (dheads W_heads) * [h>0] ; dW_d0 = dhd^T z ; db_d0
-//   6 k_enc_bwd     dW_e0 = dh^T x ; db_e0 ; dW_heads = dheads^T h ; db_heads ; radius gradients
-//   7 k_optim       fused Adam over the flat parameter buffer + SGD on the radii
+//   4 k_dec1_bwd    dhd = (g W_logits) * [hd>0] ; db_logits (+Adam) ; step statistics (BatchStats)
+//   5 k_latent_bwd  rows: dz = dhd W_d0 -> component backward (forward-mode duals, one lane per input direction)
+//                   -> dheads ; dh = (dheads W_heads) * [h>0]      tiles: dW_logits = g^T hd (+Adam)
+//   6 k_enc_bwd     dW_e0 = dh^T x, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
 //
+// In the single-GPU step the optimizer runs in the gradient epilogues, each weight one launch after its last read;
+// the two-call path (mvae_step_forward_backward -> all-reduce -> mvae_step_optimizer) uses k_optim instead.
 // Nothing here synchronises or allocates, so the host layer can capture any number of steps into one HIP graph.
+// Further down: manifold primitives, component operators, generic dense layers, log-likelihood helpers and the
+// patch-matrix gathers of the conv architecture -- the rest of the C ABI.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -810,38 +813,6 @@ __device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) 
   return s;
 }
 
-// dW tile (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q]; 256 threads
-template <bool ADAM>
-__device__ __forceinline__ void job_tn_opt(float (*red)[16][17], float* sh, const float* P, int ldp, int NP, int pt,
-                                           const float* Q, int ldq, int NQ, int qt, int Mrows, float* out, int ldo,
-                                           const AdamArgs& aa) {
-  const int wave = threadIdx.x >> 6;
-  const int pr = pt * 16 + (threadIdx.x >> 4), qc = qt * 16 + (threadIdx.x & 15);
-  const bool ok = pr < NP && qc < NQ;
-  const size_t idx = (size_t)pr * ldo + qc;
-  float p0 = 0.f, m0 = 0.f, v0 = 0.f;
-  if (ADAM) {
-    if (ok) {  // issued before the contraction: the round trip overlaps it
-      p0 = aa.p[idx];
-      m0 = aa.m[idx];
-      v0 = aa.v[idx];
-    }
-    adam_consts(sh, aa.counters, aa.lr, 0);
-  }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_tn(P, ldp, NP, pt * 16, Q, ldq, NQ, qt * 16, Mrows, wave, 4, acc);
-  const float s = reduce_tiles(red, acc);
-  if (ok) {
-    out[idx] = s;
-    if (ADAM) {
-      adam1(p0, s, m0, v0, sh[0], sh[1]);
-      aa.p[idx] = p0;
-      aa.m[idx] = m0;
-      aa.v[idx] = v0;
-    }
-  }
-}
-
 // dW tile per WAVE (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q].  The batch contraction (K = B = 128) is short
 // enough for one wave: 32 MFMA steps on two accumulators, all operand loads in flight at once, no LDS, no barrier.
 // The four waves of a workgroup take four neighbouring q-tiles (they share the P operand through L1).
@@ -1358,10 +1329,13 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   float* eps_s = heads_s + ((NH + 3) & ~3);
 
   // ---- request everything
-  int ZP = 1;
-  while (ZP < Z) ZP <<= 1;
-  const int nsl = 256 / ZP;
-  const int zj = tid % ZP, sl = tid / ZP;
+  int ZP = 1, zsh = 0;  // ZP = next power of two >= Z: the (slice, j) split of the thread index is shifts and masks
+  while (ZP < Z) {
+    ZP <<= 1;
+    ++zsh;
+  }
+  const int nsl = 256 >> zsh;
+  const int zj = tid & (ZP - 1), sl = tid >> zsh;
   float wz[16];   // FAST: this thread's W_d0 column slice (H/nsl <= 16 entries)
   float wh[2][16];  // FAST: W_heads[:, c] for the two columns c of this thread
   float hm[2] = {0.f, 0.f};
@@ -1413,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     const int nq = nsl >= 4 ? 4 : 1, per = nsl / nq;
     float sum = 0.f;
     if (tid < nq * ZP) {
-      const int qq = tid / ZP, jj = tid % ZP;
+      const int qq = tid >> zsh, jj = tid & (ZP - 1);
       for (int q = 0; q < per; ++q) sum += part[(qq * per + q) * ZP + jj];
     }
     lds_barrier();
