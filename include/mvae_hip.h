@@ -247,6 +247,16 @@ int mvae_step_optimizer(mvae_ctx* ctx, int do_curvature_step, void* stream);
 /* Both of the above back to back (single-GPU ModelVAE.train_step). */
 int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, void* stream);
 
+/* Device-side input pipeline (scope row f-2; reference: DataLoader workers + ImageDynamicBinarization,
+ * mt/data/image_reconstruction.py:44-53,70-74, and the Normal.rsample draw inside the step).  Gathers batch number
+ * (counters[8] % batches_per_epoch) of `images` (uint8 [n_images, D], HBM-resident) through `perm` (device int32
+ * permutation, may be NULL = identity), writes x[B, D] = (pixel/255 > U(0,1)) (train != 0) or (pixel/255 > 0.5), and
+ * eps[B, E] ~ N(0,1); both from Philox4x32-10 keyed by (seed, counters[8]).  counters = mvae_model_desc.step_count;
+ * its entry 8 (the batch cursor) is advanced by the first launch of every step, so [prepare, step] pairs can be
+ * captured into a HIP graph and replayed for a whole epoch without host work. */
+int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E, uint64_t seed,
+                       const int32_t* counters, int batches_per_epoch, int train, float* x, float* eps, void* stream);
+
 /* Measurement aid (never captured into a graph, synchronises): runs `iters` full steps on `stream` with a HIP event
  * between consecutive launches and writes the average duration of each of the MVAE_STEP_KERNELS launches, in
  * milliseconds, to the HOST array ms_out[MVAE_STEP_KERNELS] (order: enc_fwd, latent_fwd, dec1_fwd, dec1_bwd,

@@ -100,3 +100,83 @@ class StepRunner:
                 self.cursor = (self.cursor + 1) % self.n_data
                 left -= 1
                 self.since_reset += 1
+
+
+class EpochRunner:
+    """A training epoch with NO per-step host work: the data set lives in HBM as uint8, every step is the pair
+    [mvae_prepare_batch (gather + dynamic binarisation + eps draw, Philox), fused train step], and the pairs are replayed
+    as HIP graphs of `graph_steps` steps.  The batch cursor and the Adam step counter are device-resident, so one
+    captured graph serves every position of every epoch; only a change of (beta, curvature gate) re-captures.
+    Replaces the reference's DataLoader worker processes + per-step H2D copy + torch RNG draw
+    (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
+
+    def __init__(self, eng: StepEngine, images: Tensor, batch: int, seed: int = 0, graph_steps: int = 32,
+                 shuffle: bool = True):
+        import ctypes as C
+
+        from ._lib import check, load, ptr, stream_ptr
+        assert images.dtype == torch.uint8 and images.dim() == 2 and images.is_cuda
+        self.eng, self.images, self.B = eng, images.contiguous(), int(batch)
+        self.N, self.D = images.shape
+        self.nb = self.N // self.B  # full batches; a ragged tail is the caller's (eager) business
+        if self.nb < 1:
+            raise ValueError("data set smaller than one batch")
+        self.E = eng.layout.eps_dim
+        self.seed, self.shuffle = int(seed), shuffle
+        self.gs = max(1, min(int(graph_steps), self.nb))
+        dev = images.device
+        self.x = torch.zeros(self.B, self.D, device=dev)
+        self.eps = torch.zeros(self.B, self.E, device=dev)
+        self.perm = torch.arange(self.N, device=dev, dtype=torch.int32)
+        self._gen = torch.Generator(device=dev).manual_seed(self.seed)
+        self._graphs = {}
+        self._c = (C, check, load, ptr, stream_ptr)
+
+    def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
+        C, check, load, ptr, stream_ptr = self._c
+        check(load().mvae_prepare_batch(ptr(self.images), ptr(self.perm), self.N, self.D, self.B, self.E,
+                                        C.c_uint64(self.seed), ptr(self.eng.counters), self.nb, 1 if train else 0,
+                                        ptr(self.x), ptr(self.eps), stream_ptr(self.images.device)))
+        self.eng.train_step(self.x, self.eps, beta, do_curv)
+
+    def _graph(self, beta: float, do_curv: bool) -> torch.cuda.CUDAGraph:
+        key = (float(beta), bool(do_curv))
+        g = self._graphs.get(key)
+        if g is None:
+            eng = self.eng
+            keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._pair(beta, do_curv)  # warm-up outside capture
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(self.gs):
+                        self._pair(beta, do_curv)
+                torch.cuda.synchronize()
+            finally:
+                for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
+                    dst.copy_(src)
+            self._graphs[key] = g
+        return g
+
+    def run_epoch(self, beta: float, do_curv: bool, use_graphs: bool = True) -> int:
+        """Runs the `nb` full batches of one epoch; returns the number of steps taken."""
+        if self.shuffle:
+            self.perm.copy_(torch.randperm(self.N, device=self.perm.device, generator=self._gen).to(torch.int32))
+        # epoch-local position = cursor % nb: start every epoch on a multiple of nb
+        cur = int(self.eng.counters[8].item())
+        if cur % self.nb:
+            self.eng.counters[8] = cur + (self.nb - cur % self.nb)
+        left = self.nb
+        if use_graphs:
+            g = self._graph(beta, do_curv)
+            while left >= self.gs:
+                g.replay()
+                left -= self.gs
+        for _ in range(left):
+            self._pair(beta, do_curv)
+        return self.nb

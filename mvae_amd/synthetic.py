@@ -37,14 +37,15 @@ def digits_like_batches(steps: int, batch: int, side: int = 28, n_classes: int =
     stroke thickness, and is then binarised dynamically, x = (p > U(0,1)) as in image_reconstruction.py:44-53.
     Unlike i.i.d. pixels this gives the posterior something to encode, so long training runs behave like the
     reference's MNIST runs (no posterior collapse)."""
+    gp = torch.Generator().manual_seed(777)  # the class prototypes are the same for every seed (train / test splits)
     g = torch.Generator().manual_seed(seed)
     yy, xx = torch.meshgrid(torch.arange(side, dtype=torch.float64), torch.arange(side, dtype=torch.float64),
                             indexing="ij")
     n_blobs = 4
-    cx = 6 + 16 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
-    cy = 6 + 16 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
-    sx = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
-    sy = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=g, dtype=torch.float64)
+    cx = 6 + 16 * torch.rand(n_classes, n_blobs, generator=gp, dtype=torch.float64)
+    cy = 6 + 16 * torch.rand(n_classes, n_blobs, generator=gp, dtype=torch.float64)
+    sx = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=gp, dtype=torch.float64)
+    sy = 1.5 + 3.0 * torch.rand(n_classes, n_blobs, generator=gp, dtype=torch.float64)
     n = steps * batch
     cls = torch.randint(0, n_classes, (n,), generator=g)
     shift = (torch.rand(n, 2, generator=g, dtype=torch.float64) - 0.5) * 3.0

