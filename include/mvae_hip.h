@@ -216,8 +216,9 @@ typedef struct mvae_model_desc {
   float* grads;         /* [P]  dense gradient of (-ELBO) after mvae_step_forward_backward                     */
   float* adam_m;        /* [P] */
   float* adam_v;        /* [P] */
-  int32_t* step_count;  /* [32] {Adam step counter, arrival scratch...}; device-side so that a captured graph advances
-                           it; zeroed by the host at creation                                                   */
+  int32_t* step_count;  /* [32] device-side so that a captured graph advances it; zeroed by the host at creation:
+                           [0] Adam step counter, [1] arrival scratch, [2..3] this step's {-lr/bc1, sqrt(bc2)} as
+                           float bits, [8] batch cursor of mvae_prepare_batch, [16..31] arrival scratch          */
   float* workspace;     /* [mvae_workspace_floats(desc)] activations + partial sums                            */
   float* stats;         /* [2 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
                            same record for the LAST step only (stats.py:120-127 without the per-step .item() syncs:

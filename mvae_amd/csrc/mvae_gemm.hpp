@@ -70,6 +70,9 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
         b[g] = load4_guarded(wrow, k, K, w_ok && ok, vecW);
       }
     }
+    // keep every load of the batch above the first MFMA: without this the scheduler trades registers for a
+    // load -> wait -> MFMA interleaving, i.e. G serialized memory round trips
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       acc = mfma16(a[g].x, b[g].x, acc);
@@ -108,6 +111,7 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
         b[g] = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; g += 2) {
       acc = mfma16(a[g], b[g], acc);
@@ -150,6 +154,7 @@ __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, 
 #pragma unroll
       for (int t = 0; t < 4; ++t) b[g][t] = (w_ok && ok && k + t < K) ? wcol[(size_t)(k + t) * ldw] : 0.f;
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       acc = mfma16(a[g].x, b[g][0], acc);

@@ -847,14 +847,12 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
           v0[r] = aa.v[idx + r];
         }
     }
-    const int step = *(volatile const int*)&aa.counters[0];
-    const double bc1 = 1.0 - pow_int(0.9, step);
-    const double bc2 = 1.0 - pow_int(0.999, step);
-    neg_step = (float)(-(aa.lr / bc1));
-    bc2s = (float)sqrt(bc2);
+    // {-lr/bc1, sqrt(bc2)} of this step, published by launch 1 (k_enc_fwd)
+    neg_step = reinterpret_cast<const float*>(aa.counters)[2];
+    bc2s = reinterpret_cast<const float*>(aa.counters)[3];
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = tile_tn<32, false>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);  // (unguarded variant measured slower)
+  acc = tile_tn<32, FULL>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
   if (ADAM) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
@@ -894,7 +892,10 @@ __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/,
       m0 = aa.m[c0 + c];
       v0 = aa.v[c0 + c];
     }
-    adam_consts(sh, aa.counters, aa.lr, 0);
+    if (threadIdx.x == 0) {  // published by launch 1 (k_enc_fwd)
+      sh[0] = reinterpret_cast<const float*>(aa.counters)[2];
+      sh[1] = reinterpret_cast<const float*>(aa.counters)[3];
+    }
   }
   float s = 0.f;
   if (c0 + c < ncols) {
@@ -939,15 +940,27 @@ __device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt) {
 // ---- 1: encoder layer (512 threads).  In the fused single-GPU step, workgroup (0,0) also advances the step counter.
 template <bool FULL>
 __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
-                                                 int D, int* counters, int bump_step) {
+                                                 int D, int* counters, int bump_step, double lr) {
   __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
   int mt, nt;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (bump_step) counters[0] = counters[0] + 1;
+  // Once per step: advance the counters and publish Adam's bias-correction scalars for the gradient epilogues of
+  // launches 4-6 (double-precision pow / divide / sqrt: ~1 us for one lane -- done here by a padding workgroup of
+  // the XCD-aware grid when there is one, so that it is off every critical path).
+  const bool real = xcd_tile((H + 15) / 16, (B + 15) / 16, &nt, &mt);
+  const bool has_pad = (((H + 15) / 16) & 7) != 0;
+  if (threadIdx.x == 0 && (has_pad ? blockIdx.x == gridDim.x - 1 : blockIdx.x == 0)) {
+    int step = counters[0];
+    if (bump_step) counters[0] = ++step;
     counters[8] = counters[8] + 1;  // batch cursor of the device-side input pipeline (mvae_prepare_batch)
+    if (bump_step) {
+      const double bc1 = 1.0 - pow_int(0.9, step);
+      const double bc2 = 1.0 - pow_int(0.999, step);
+      reinterpret_cast<float*>(counters)[2] = (float)(-(lr / bc1));
+      reinterpret_cast<float*>(counters)[3] = (float)sqrt(bc2);
+    }
   }
-  if (!xcd_tile((H + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
+  if (!real) return;
   const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = tile_nt<7, FULL>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
@@ -1223,7 +1236,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     if (ok) mask = hd[(size_t)m * H + n];
     const bool vg = aligned16(g) && (D & 3) == 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_nn<7, false>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);  // (the unguarded variant measured slower)
+    acc = tile_nn<7, FULL>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
     const float s = reduce_tiles8(red, acc);
     if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
     return;
@@ -1555,14 +1568,14 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const floa
   }
   // The last workgroup to arrive advances the step counter.  Every other workgroup consumed counters[0] before its
   // own arrival (the value fed the __syncthreads above), so no fence is needed: the plain stores below only have to
-  // be visible to the NEXT launch.  Arrivals are counted on 16 group words first (one hot word would serialise
-  // ~600 device-scope atomics at ~12 ns each), the group-completing workgroups then meet on counters[1].
+  // be visible to the NEXT launch.  Arrivals are counted on 16 group words (counters[16..31]) first (one hot word
+  // would serialise ~600 device-scope atomics at ~12 ns each); the group-completing workgroups meet on counters[1].
   if (tid == 0) {
     constexpr int NG = 16;
     const int grp = blockIdx.x % NG;
     const int gsize = ((int)gridDim.x - grp + NG - 1) / NG;
-    if (atomicAdd(&counters[4 + grp], 1) == gsize - 1) {
-      counters[4 + grp] = 0;
+    if (atomicAdd(&counters[16 + grp], 1) == gsize - 1) {
+      counters[16 + grp] = 0;
       const int ngroups = (int)gridDim.x < NG ? (int)gridDim.x : NG;
       if (atomicAdd(&counters[1], 1) == ngroups - 1) {
         counters[1] = 0;
@@ -1614,10 +1627,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
                     aligned16(P + d.off_w_logits) && aligned16(ws);
   if (full)
     STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
-                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0);
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
   else
-  STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0, P + d.off_b_e0, h, B, H, D,
-                     d.step_count, fused ? 1 : 0);
+    STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
   {
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
 #define LF(DM, FA)                                                                                                   \

@@ -97,3 +97,20 @@ def test_epoch_runner_graph_equals_eager(dev):
         results.append((eng.params.clone(), st))
     assert torch.equal(results[0][0], results[1][0])
     assert results[0][1]["sum"]["elbo"] == results[1][1]["sum"]["elbo"]
+
+
+def test_split_step_keeps_cursor_and_counter(dev):
+    """Data-parallel order (gradients, then k_optim): the Adam counter and the batch cursor both advance by one per
+    step -- the arrival scratch words of k_optim must not overlap either of them."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=1.0))
+    x = synthetic.binary_batches(1, 128, 784)[0].to(dev)
+    eps = synthetic.eps_batches(1, 128, 6)[0].to(dev)
+    for k in range(5):
+        eng.forward_backward(x, eps, 1.0)
+        eng.optimizer_step(True)
+        torch.cuda.synchronize()
+        assert int(eng.counters[0]) == k + 1 and int(eng.counters[8]) == k + 1
+        assert int(eng.counters[1]) == 0 and int(eng.counters[16:].abs().sum()) == 0
