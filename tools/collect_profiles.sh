@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect the round's profile artefacts on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh r01b
+# Writes everything under gpurun_out/prof_<tag>/; tools/summarise_profiles.py turns that into profiles/<tag>_*.
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline"
+PMCB="python $ROOT/bench.py --steps 300 --warmup 50 --graph-steps 0 --no-cpu-baseline"
+cd /tmp
+# 1. kernel trace + stats (graph replays, as bench.py runs by default)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- $BENCH > $OUT/ktrace.log 2>&1
+# 2./3. PMC passes, one counter each, kernel trace only
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $PMCB > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- $PMCB > $OUT/pmc_write.log 2>&1
+# 4. conv architecture (BASELINE configs[4]) kernel stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/conv -o conv -- python $ROOT/tools/bench_conv.py 256 20 > $OUT/conv.log 2>&1
+cd $ROOT
+# 5. the un-profiled bench lines of the same build
+timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 600 python bench.py --no-cpu-baseline --model 6h2,6s2,6e2 --fixed-curvature --reset-every 1000 > $OUT/bench_prod36.json 2>&1
+timeout 600 python bench.py --no-cpu-baseline --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
+# keep only the small summaries (the traces are large)
+find $OUT -name '*kernel_trace.csv' -size +20M -delete
+ls -la $OUT $OUT/*/ 2>/dev/null | head -60
