@@ -26,9 +26,21 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 1
+#define MVAE_ABI_VERSION 2
 
-enum { MVAE_EUCLIDEAN = 0, MVAE_HYPERBOLOID = 1, MVAE_SPHERE = 2, MVAE_POINCARE = 3 };
+/* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
+ * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
+ * MVAE_UNIVERSAL: Universal (ops/universal.py): its parameter is the CURVATURE K (component.py:225-242), passed
+ * wherever the other kinds take their raw radius parameter; K < -1e-6 -> Poincare ball, K > 1e-6 -> projected sphere,
+ * else Euclidean (universal.py:67-74), each at radius relu(1/sqrt|K|) (universal.py:30-32). */
+enum {
+  MVAE_EUCLIDEAN = 0,
+  MVAE_HYPERBOLOID = 1,
+  MVAE_SPHERE = 2,
+  MVAE_POINCARE = 3,
+  MVAE_PROJ_SPHERE = 4,
+  MVAE_UNIVERSAL = 5
+};
 
 enum {
   MVAE_OK = 0,
@@ -45,9 +57,11 @@ const char* mvae_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Manifold primitives (forward).  Manifold interface: mt/mvae/ops/manifold.py:22-75.
- * `radius_param` points at ONE float: the raw nn.Parameter (_nradius / _pradius, component.py:123,142,160); the
- * kernels apply radius = clamp(relu(p), 1e-8, 1e8) themselves (manifold.py:73-75).  Ignored for MVAE_EUCLIDEAN.
- * `d` is the TRUE dimension; ambient A = d+1 for h/s, d for e/p.
+ * `radius_param` points at ONE float: the raw nn.Parameter (_nradius / _pradius, component.py:123,142,160,179; for
+ * MVAE_UNIVERSAL the `_curvature` parameter, component.py:232); the kernels apply radius = clamp(relu(p), 1e-8, 1e8)
+ * themselves (manifold.py:73-75).  Ignored for MVAE_EUCLIDEAN.
+ * `d` is the TRUE dimension; ambient A = d+1 for h/s, d for e/p/d/u.
+ * Projected sphere: spherical_projected.py:31-88 (class), :140-196 (functions).
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* Manifold.exp_map_mu0: x[rows,d] -> out[rows,A].   hyperbolics.py:28-29,114-121 | spherical.py:28-29,94-101 |
@@ -81,8 +95,8 @@ int mvae_sample_projection_mu0(int kind, const float* v, const float* at, float*
 int mvae_inverse_sample_projection_mu0(int kind, const float* z, const float* at, float* u, float* v, int64_t rows,
                                        int64_t at_rows, int d, const float* radius_param, void* stream);
 
-/* Manifold.logdet(mu, std, z, data): h/s take u = data[0] ([rows,A]); p takes (mu, z) (poincare.py:55-89); e writes
- * zeros.  out[rows].   hyperbolics.py:49-51,58-65 | spherical.py:49-51,58-67 */
+/* Manifold.logdet(mu, std, z, data): h/s take u = data[0] ([rows,A]); p/d/u take (mu, z) (poincare.py:55-89,
+ * spherical_projected.py:56-88); e writes zeros.  out[rows].   hyperbolics.py:49-51,58-65 | spherical.py:49-51,58-67 */
 int mvae_logdet(int kind, const float* u, const float* mu, const float* z, float* out, int64_t rows, int64_t at_rows,
                 int d, const float* radius_param, void* stream);
 
@@ -168,8 +182,10 @@ int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, f
  * (same layout as mvae_model_desc.stats). */
 int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp, void* stream);
 /* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable
- * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180. */
-int mvae_optimizer_step_flat(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n_params,
+ * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180.
+ * radius_trainable[i]: 0 fixed, 1 trainable radius, 3 trainable universal curvature -- the entries marked 3 form the
+ * clip_grad_norm_(max_norm=1) group of vae.py:161-163 and are clipped IN PLACE in `grads` before the SGD step. */
+int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* adam_v, int64_t n_params,
                              int32_t* counters, int ncomp, const uint8_t* radius_trainable, double lr,
                              double curvature_lr, int do_curvature_step, void* stream);
 
@@ -233,6 +249,9 @@ typedef struct mvae_ctx mvae_ctx;
 int64_t mvae_workspace_floats(const mvae_model_desc* desc);
 int mvae_create(const mvae_model_desc* desc, mvae_ctx** out);
 void mvae_destroy(mvae_ctx* ctx);
+/* Change which radius / curvature parameters are trained (Parameter.requires_grad toggles of the --universal schedule,
+ * mt/examples/run.py:153-165).  trainable[ncomp], host pointer, copied; takes effect from the next step call. */
+int mvae_set_radius_trainable(mvae_ctx* ctx, const uint8_t* trainable);
 
 /* forward -> ELBO -> backward: fills `grads` (all P entries are written, nothing accumulates) and adds this step's
  * bce / kl / elbo sums to `stats`.  x[B, D] (binarised or soft targets), eps[B, eps_dim] ~ N(0,1).

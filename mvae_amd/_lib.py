@@ -11,8 +11,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
-EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE = 0, 1, 2, 3
-ABI_VERSION = 1
+EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 2
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),
     "mvae_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "mvae_destroy": (None, [C.c_void_p]),
+    "mvae_set_radius_trainable": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "mvae_step_forward_backward": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),

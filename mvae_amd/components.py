@@ -1,6 +1,7 @@
-"""Latent components (mt/mvae/components/component.py:30-203): same classes, constructor signatures, parameter names
-(`_nradius` for h/p, `_pradius` for s -- the optimizer routing and the radius warm-up key on these names,
-train.py:189-194,329-341) and `dim` convention (ambient: true_dim + 1 for h and s)."""
+"""Latent components (mt/mvae/components/component.py:30-242): same classes, constructor signatures, parameter names
+(`_nradius` for h/p, `_pradius` for s/d, `_curvature` for u -- the optimizer routing, the gradient clip and the radius
+warm-up key on these names, train.py:189-194,329-341, vae.py:161) and `dim` convention (ambient: true_dim + 1 for h
+and s)."""
 from typing import Dict, Optional, Tuple, Type
 
 import torch
@@ -8,7 +9,8 @@ from torch import Tensor
 
 from . import functional as Fn
 from .distributions import FusedPosterior, FusedPrior
-from .ops import Euclidean, Hyperboloid, Manifold, PoincareBall, Sphere
+from .ops import (Euclidean, Hyperboloid, Manifold, PoincareBall, Sphere, StereographicallyProjectedSphere,
+                  Universal)
 
 
 class Component(torch.nn.Module):
@@ -43,7 +45,7 @@ class Component(torch.nn.Module):
         return self._layout
 
     def _radius_param(self) -> Optional[Tensor]:
-        return getattr(self, "_nradius", getattr(self, "_pradius", None))
+        return getattr(self, "_nradius", getattr(self, "_pradius", getattr(self, "_curvature", None)))
 
     def _radii_tensor(self) -> Tensor:
         r = self._radius_param()
@@ -137,6 +139,41 @@ class SphericalComponent(Component):
     @property
     def true_dim(self) -> int:
         return self.dim - 1
+
+
+class StereographicallyProjectedSphereComponent(Component):  # component.py:170-189
+    LETTER = "d"
+
+    def __init__(self, dim: int, fixed_curvature: bool, sampling_procedure: Type, radius: float = 1.0) -> None:
+        super().__init__(dim, fixed_curvature, sampling_procedure)
+        self._pradius = torch.nn.Parameter(torch.tensor(radius), requires_grad=not fixed_curvature)
+
+    def create_manifold(self) -> Manifold:
+        return StereographicallyProjectedSphere(lambda: self._pradius)
+
+    @property
+    def true_dim(self) -> int:
+        return self.dim
+
+    def _shortcut(self) -> str:
+        return f"d{self.true_dim}"
+
+
+class UniversalComponent(Component):  # component.py:225-242
+    LETTER = "u"
+
+    def __init__(self, dim: int, fixed_curvature: bool, sampling_procedure: Type, curvature: float = 0.0,
+                 eps: float = 1e-6) -> None:
+        super().__init__(dim, fixed_curvature, sampling_procedure)
+        self._curvature = torch.nn.Parameter(torch.tensor(curvature), requires_grad=not fixed_curvature)
+        self._eps = eps
+
+    def create_manifold(self) -> Manifold:
+        return Universal(lambda: self._curvature, eps=self._eps)
+
+    @property
+    def true_dim(self) -> int:
+        return self.dim
 
 
 class EuclideanComponent(Component):

@@ -60,7 +60,7 @@ class ConvFlatLayout:
             take(name + ".bias", bias[name])
         self.n_params = o
         self.entries: List[Tuple[str, int, Tuple[int, ...]]] = []
-        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius"}
+        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius", "d": "_pradius", "u": "_curvature"}
         for i, (letter, d) in enumerate(layout.comps):
             desc = layout.descs[i]
             pre = f"components.{i}."
@@ -159,12 +159,19 @@ class ConvEngine:
         n = self.layout.n
         tr = [False] * n if radius_trainable is None else [bool(t) for t in radius_trainable]
         self.radius_trainable = [t and letter != "e" for t, (letter, _) in zip(tr, self.layout.comps)]
-        self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
+        self._trainable_arr = (C.c_uint8 * n)()
+        self.set_radius_trainable(self.radius_trainable)
         P = self.flat.n_params
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
         self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
         self.counters = z(32, torch.int32)
         self.stats = z(2 * (4 + n))
+
+    def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
+        """0 fixed / 1 trainable radius / 3 trainable universal curvature (clip group), see mvae_optimizer_step_flat."""
+        self.radius_trainable = [bool(t) and letter != "e" for t, (letter, _) in zip(radius_trainable, self.layout.comps)]
+        for i, (t, (letter, _)) in enumerate(zip(self.radius_trainable, self.layout.comps)):
+            self._trainable_arr[i] = (3 if letter == "u" else 1) if t else 0
 
     # ---- state (same surface as StepEngine)
     def param_views(self) -> Dict[str, Tensor]:
@@ -179,7 +186,7 @@ class ConvEngine:
 
     def set_radii(self, value: float) -> None:
         for i, (letter, _) in enumerate(self.layout.comps):
-            if letter != "e":
+            if letter in ("h", "p", "s", "d"):  # not the universal curvature, train.py:189-194
                 self.params[i] = value
 
     def set_lr(self, lr: float, curvature_lr: Optional[float] = None) -> None:

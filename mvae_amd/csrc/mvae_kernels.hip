@@ -72,7 +72,7 @@ struct CompTable {
   int total_dirs;
   mvae_component_desc c[kMaxComp];
   int dir_off[kMaxComp + 1];  // prefix sum of derivative directions per component (d + logvar_dim + trainable radius)
-  unsigned char trainable[kMaxComp];
+  unsigned char trainable[kMaxComp];  // bit 0: trainable radius/curvature, bit 1: in the gradient-clip group (`u`)
   // Placement of the components on the 4 waves of a latent workgroup: components of the same manifold kind share a
   // wave (one instruction stream, no divergence), different kinds run on different waves.
   unsigned char wave_of[kMaxComp];
@@ -96,13 +96,16 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
   int dmax = 0, off = 0;
   for (int i = 0; i < ncomp; ++i) {
     const mvae_component_desc& c = comps[i];
-    if (c.kind < 0 || c.kind > 3) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", c.kind);
+    if (c.kind < 0 || c.kind >= kNumKinds) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", c.kind);
     if (c.true_dim < 1 || c.true_dim > MVAE_MAX_TRUE_DIM)
       return fail(MVAE_E_UNSUPPORTED, "true_dim outside [1, MVAE_MAX_TRUE_DIM]%s (%lld)", "", c.true_dim);
     if (c.logvar_dim != 1 && c.logvar_dim != c.true_dim)
       return fail(MVAE_E_BADARG, "logvar_dim must be 1 or true_dim%s (%lld)", "", c.logvar_dim);
     t->c[i] = c;
-    t->trainable[i] = (trainable && c.kind != MVAE_EUCLIDEAN) ? trainable[i] : 0;
+    // bit 0: SGD-trainable radius / curvature; bit 1: member of the clip_grad_norm_ group (universal curvatures)
+    t->trainable[i] = (trainable && c.kind != MVAE_EUCLIDEAN && trainable[i])
+                          ? (unsigned char)(1 | (c.kind == MVAE_UNIVERSAL ? 2 : 0))
+                          : 0;
     t->dir_off[i] = off;
     off += c.true_dim + c.logvar_dim + (t->trainable[i] ? 1 : 0);
     if (c.true_dim > dmax) dmax = c.true_dim;
@@ -111,8 +114,8 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
   t->total_dirs = off;
   *dmax_out = dmax;
   // wave placement: the kinds present split the 4 waves between them; a kind's components go round-robin over its waves
-  int kinds[4], nk = 0;
-  for (int k = 0; k < 4; ++k) {
+  int kinds[kNumKinds], nk = 0;
+  for (int k = 0; k < kNumKinds; ++k) {
     bool present = false;
     for (int i = 0; i < ncomp; ++i) present |= (comps[i].kind == k);
     if (present) kinds[nk++] = k;
@@ -135,11 +138,13 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
 template <int DMAX, typename T>
 __device__ __forceinline__ void comp_eval(int kind, const T* m, const T* l, int lvd, const float* e, int d, T rp, T* z,
                                           T* kl, T* lq, T* lp, T* mu, T* sg) {
+  kind = resolve_universal(kind, rp);  // `u`: Poincare ball / projected sphere / Euclidean by the sign of K
 #define MV_KIND_SWITCH(DD, LL)                                                                              \
   switch (kind) {                                                                                           \
     case kEuclidean: component_forward<kEuclidean, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;     \
     case kHyperboloid: component_forward<kHyperboloid, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break; \
     case kSphere: component_forward<kSphere, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;           \
+    case kProjSphere: component_forward<kProjSphere, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;   \
     default: component_forward<kPoincare, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;              \
   }
   // the common case (every dimension equals the bucket bound) is instantiated with compile-time dimensions, which
@@ -346,8 +351,8 @@ __device__ __forceinline__ void prim_row(const float* a, const float* b, const f
     MV_FOR(i, 0, A) t1[i] = b[ar * A + i];
     if constexpr (KIND == kEuclidean) {
       MV_FOR(i, 0, d) t2[i] = a[r * d + i];
-    } else if constexpr (KIND == kPoincare) {
-      float lam = p_lambda<AMAX>(t1, A, 1.0f / (R * R));
+    } else if constexpr (KIND == kPoincare || KIND == kProjSphere) {
+      float lam = (KIND == kPoincare) ? p_lambda<AMAX>(t1, A, 1.0f / (R * R)) : d_lambda<AMAX>(t1, A, 1.0f / (R * R));
       MV_FOR(i, 0, d) t2[i] = a[r * d + i] / lam;
     } else {
       t0[0] = 0.f;
@@ -369,8 +374,8 @@ __device__ __forceinline__ void prim_row(const float* a, const float* b, const f
     MV_FOR(i, 0, A) o1[r * A + i] = t2[i];
     if constexpr (KIND == kEuclidean) {
       MV_FOR(i, 0, d) o2[r * d + i] = t2[i];
-    } else if constexpr (KIND == kPoincare) {
-      float lam = p_lambda<AMAX>(t1, A, 1.0f / (R * R));
+    } else if constexpr (KIND == kPoincare || KIND == kProjSphere) {
+      float lam = (KIND == kPoincare) ? p_lambda<AMAX>(t1, A, 1.0f / (R * R)) : d_lambda<AMAX>(t1, A, 1.0f / (R * R));
       MV_FOR(i, 0, d) o2[r * d + i] = t2[i] * lam;
     } else {
       inv_pt_mu0<KIND, AMAX>(t2, t1, A, R, t3);
@@ -379,13 +384,13 @@ __device__ __forceinline__ void prim_row(const float* a, const float* b, const f
   } else {  // OP_LOGDET: a = u (h,s) ; b = mu, c3 = z (p)
     if constexpr (KIND == kEuclidean) {
       o1[r] = 0.f;
-    } else if constexpr (KIND == kPoincare) {
+    } else if constexpr (KIND == kPoincare || KIND == kProjSphere) {
       const int64_t ar = r % at_rows;
       MV_FOR(i, 0, A) {
         t0[i] = b[ar * A + i];
         t1[i] = c3[r * A + i];
       }
-      o1[r] = p_logdet<AMAX>(t0, t1, A, R);
+      o1[r] = (KIND == kPoincare) ? p_logdet<AMAX>(t0, t1, A, R) : d_logdet<AMAX>(t0, t1, A, R);
     } else {
       MV_FOR(i, 0, A) t0[i] = a[r * A + i];
       o1[r] = logdet_u<KIND, AMAX>(t0, A, R);
@@ -397,12 +402,14 @@ template <int OP, int DMAX>
 __global__ __launch_bounds__(256) void k_prim(int kind, const float* a, const float* b, const float* c3, float* o1,
                                               float* o2, int64_t rows, int64_t at_rows, int d,
                                               const float* radius_param) {
-  const float rp = (kind == kEuclidean || !radius_param) ? 0.f : radius_param[0];
+  float rp = (kind == kEuclidean || !radius_param) ? 0.f : radius_param[0];
+  kind = resolve_universal(kind, rp);  // for `u`, radius_param holds the curvature K
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
     switch (kind) {
       case kEuclidean: prim_row<OP, kEuclidean, DMAX>(a, b, c3, o1, o2, d, rp, r, at_rows); break;
       case kHyperboloid: prim_row<OP, kHyperboloid, DMAX>(a, b, c3, o1, o2, d, rp, r, at_rows); break;
       case kSphere: prim_row<OP, kSphere, DMAX>(a, b, c3, o1, o2, d, rp, r, at_rows); break;
+      case kProjSphere: prim_row<OP, kProjSphere, DMAX>(a, b, c3, o1, o2, d, rp, r, at_rows); break;
       default: prim_row<OP, kPoincare, DMAX>(a, b, c3, o1, o2, d, rp, r, at_rows); break;
     }
   }
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256) void k_prim(int kind, const float* a, const fl
 template <int OP>
 static int launch_prim(int kind, const float* a, const float* b, const float* c3, float* o1, float* o2, int64_t rows,
                        int64_t at_rows, int d, const float* rp, void* stream) {
-  if (kind < 0 || kind > 3) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", kind);
+  if (kind < 0 || kind >= kNumKinds) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", kind);
   if (rows < 0 || d < 1) return fail(MVAE_E_BADARG, "bad rows/d%s (%lld)", "", d);
   if (d > MVAE_MAX_TRUE_DIM) return fail(MVAE_E_UNSUPPORTED, "true_dim > MVAE_MAX_TRUE_DIM%s (%lld)", "", d);
   if (kind != MVAE_EUCLIDEAN && !rp) return fail(MVAE_E_BADARG, "radius_param is NULL%s", "");
@@ -462,7 +469,8 @@ extern "C" int mvae_inverse_sample_projection_mu0(int kind, const float* z, cons
 extern "C" int mvae_logdet(int kind, const float* u, const float* mu, const float* z, float* out, int64_t rows,
                            int64_t at_rows, int d, const float* rp, void* st) {
   if (!out) return fail(MVAE_E_BADARG, "null pointer%s", "");
-  if (kind == MVAE_POINCARE && (!mu || !z)) return fail(MVAE_E_BADARG, "poincare logdet needs mu and z%s", "");
+  if ((kind == MVAE_POINCARE || kind == MVAE_PROJ_SPHERE || kind == MVAE_UNIVERSAL) && (!mu || !z))
+    return fail(MVAE_E_BADARG, "logdet of a projected model needs mu and z%s", "");
   if ((kind == MVAE_HYPERBOLOID || kind == MVAE_SPHERE) && !u) return fail(MVAE_E_BADARG, "logdet needs u%s", "");
   return launch_prim<OP_LOGDET>(kind, u, mu, z, out, nullptr, rows, at_rows, d, rp, st);
 }
@@ -749,6 +757,14 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
 
 extern "C" void mvae_destroy(mvae_ctx* ctx) { delete ctx; }
 
+extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) {
+  if (!c || !trainable) return fail(MVAE_E_BADARG, "null ctx / trainable%s", "");
+  mvae_component_desc comps[kMaxComp];
+  const int n = c->t.n;
+  for (int i = 0; i < n; ++i) comps[i] = c->t.c[i];
+  return fill_table(&c->t, comps, n, trainable, &c->dmax);
+}
+
 // ---------------------------------------------------------------------------------------------- Adam in the epilogue
 // torch.optim.Adam, single-tensor CPU formulas, defaults betas=(0.9, 0.999), eps=1e-8:
 //   m <- m + (1-b1)(g - m) ; v <- v*b2 + ((1-b2) g) g ; p <- p + (-lr/bc1 * m) / (sqrt(v)/sqrt(bc2) + eps)
@@ -789,6 +805,15 @@ __device__ __forceinline__ void adam1(float& P, float G, float& M, float& V, flo
   M = M + w1 * (G - M);
   V = V * b2 + (w2 * G) * G;
   P = P + (neg_step * M) / (sqrtf(V) / bc2s + 1e-8f);
+}
+
+// torch.nn.utils.clip_grad_norm_(curvature params, max_norm=1, norm_type=2) (vae.py:161-163): the coefficient
+// min(1, 1 / (||g|| + 1e-6)) over the universal components' curvature gradients g (index order).
+__device__ __forceinline__ float clip_coef(const CompTable& t, const float* g) {
+  float n2 = 0.f;
+  for (int j = 0; j < t.n; ++j)
+    if (t.trainable[j] & 2) n2 += g[j] * g[j];
+  return fminf(1.0f / (sqrtf(n2) + 1e-6f), 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------- step tile jobs
@@ -1527,26 +1552,36 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
   // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
   // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid < kRadiiRegion) G[tid] = 0.f;
+  float* gsh = &red[0][0][0];  // per-component batch sums
+  if (tid < kRadiiRegion) {
+    G[tid] = 0.f;
+    gsh[tid] = 0.f;
+  }
   __syncthreads();
   for (int ci = wave; ci < t.n; ci += 4) {
     if (!t.trainable[ci]) continue;
     float s = 0.f;
     for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
     s = wave_sum(s);
-    if (lane == 0) {
-      G[ci] = s;
-      if (ADAM && do_curv) P[ci] = P[ci] + (float)(-curv_lr) * s;
-    }
+    if (lane == 0) gsh[ci] = s;
+  }
+  __syncthreads();
+  if (tid < t.n && t.trainable[tid]) {
+    float s = gsh[tid];
+    if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
+    G[tid] = s;
+    if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
   }
 }
 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
-__global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const float* g, float* m, float* v, int n4,
+__global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, float* m, float* v, int n4,
                                                int* counters, double lr, double curv_lr, int do_curv) {
   __shared__ float sh[2];
+  __shared__ float gsh[kMaxComp];
   const int tid = threadIdx.x;
   adam_consts(sh, counters, lr, 1);
+  if (blockIdx.x == 0 && tid < t.n) gsh[tid] = g[tid];
   __syncthreads();
   const float neg_step = sh[0], bc2s = sh[1];
   const int i4 = blockIdx.x * 256 + tid + kRadiiRegion / 4;
@@ -1563,8 +1598,13 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, const floa
     reinterpret_cast<float4*>(m)[i4] = mm;
     reinterpret_cast<float4*>(v)[i4] = vv;
   }
-  if (blockIdx.x == 0 && do_curv && tid < t.n && t.trainable[tid]) {
-    p[tid] = p[tid] + (float)(-curv_lr) * g[tid];  // SGD: param.add_(grad, alpha=-lr)
+  if (blockIdx.x == 0 && tid < t.n && t.trainable[tid]) {
+    float gv = gsh[tid];
+    if (t.trainable[tid] & 2) {  // universal curvature: clipped (after the all-reduce), written back like .grad
+      gv *= clip_coef(t, gsh);
+      g[tid] = gv;
+    }
+    if (do_curv) p[tid] = p[tid] + (float)(-curv_lr) * gv;  // SGD: param.add_(grad, alpha=-lr)
   }
   // The last workgroup to arrive advances the step counter.  Every other workgroup consumed counters[0] before its
   // own arrival (the value fed the __syncthreads above), so no fence is needed: the plain stores below only have to
@@ -1743,7 +1783,7 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
 
 // Adam over a flat parameter buffer whose first 64 floats are the raw radii (SGD on the trainable ones): the optimizer
 // of any architecture laid out like StepEngine's buffers (used by the conv path).
-extern "C" int mvae_optimizer_step_flat(float* params, const float* grads, float* adam_m, float* adam_v,
+extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* adam_v,
                                         int64_t n_params, int32_t* counters, int ncomp,
                                         const uint8_t* radius_trainable, double lr, double curvature_lr,
                                         int do_curvature_step, void* stream) {

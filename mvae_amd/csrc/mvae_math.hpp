@@ -95,6 +95,18 @@ __device__ __forceinline__ Dual t_tanh(Dual x) {
   float t = tanhf(x.v);
   return {t, (1.0f - t * t) * x.d};
 }
+// torch.tan (derivative 1 + tan^2) from the shared sin/cos evaluation; torch.atan
+__device__ __forceinline__ float t_tan(float x) {
+  float sv, cv;
+  if (!mvf::sincos_fast(x, &sv, &cv)) return tanf(x);
+  return sv / cv;
+}
+__device__ __forceinline__ Dual t_tan(Dual x) {
+  const float t = t_tan(x.v);
+  return {t, (1.0f + t * t) * x.d};
+}
+__device__ __forceinline__ float t_atan(float x) { return atanf(x); }
+__device__ __forceinline__ Dual t_atan(Dual x) { return {atanf(x.v), x.d / (1.0f + x.v * x.v)}; }
 __device__ __forceinline__ float t_acos(float x) { return acosf(x); }
 __device__ __forceinline__ Dual t_acos(Dual x) { return {acosf(x.v), x.d * -rsqrtf(1.0f - x.v * x.v)}; }
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
@@ -239,7 +251,23 @@ template <typename T> __device__ __forceinline__ T normal_logprob_term(T v, T si
 }
 
 // =================================================================================================== manifolds
-enum Kind : int { kEuclidean = 0, kHyperboloid = 1, kSphere = 2, kPoincare = 3 };
+// kUniversal (universal.py) is not a geometry of its own: resolve_universal() turns it into kPoincare / kProjSphere /
+// kEuclidean by the sign of its curvature parameter before any of the templates below is entered.
+enum Kind : int { kEuclidean = 0, kHyperboloid = 1, kSphere = 2, kPoincare = 3, kProjSphere = 4, kUniversal = 5 };
+constexpr int kNumKinds = 6;
+
+// Universal._choice / .radius (universal.py:30-32,67-74): K < -eps -> Poincare ball, K > eps -> projected sphere, else
+// Euclidean; the sub-manifold sees relu(1/sqrt|K|) as its raw radius parameter (sqrt = the reference's guarded sqrt).
+template <typename T> __device__ __forceinline__ int resolve_universal(int kind, T& rp) {
+  if (kind != kUniversal) return kind;
+  const float k = val(rp);
+  if (k < -1e-6f || k > 1e-6f) {
+    rp = t_relu(1.0f / g_sqrt(t_abs(rp)));
+    return k < 0.0f ? kPoincare : kProjSphere;
+  }
+  rp = cst<T>(0.0f);
+  return kEuclidean;
+}
 
 __host__ __device__ inline int ambient_dim(int kind, int d) {
   return (kind == kHyperboloid || kind == kSphere) ? d + 1 : d;
@@ -259,6 +287,10 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ void exp_ma
     T n = hard_clamp(norm2<AMAX>(x, d), 1e-15f, INFINITY);
     T t = t_tanh(hard_clamp(sc * n, -15.0f, 15.0f));
     MV_FOR(i, 0, d) mu[i] = t * x[i] / (sc * n);
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:157-161
+    T r = hard_clamp(norm2<AMAX>(x, d), 1e-15f, INFINITY) / R;
+    T t = t_tan(r);
+    MV_FOR(i, 0, d) mu[i] = t * x[i] / r;
   } else {
     // hyperbolics.py:114-121 | spherical.py:94-101
     T n = norm2<AMAX>(x, d);
@@ -272,6 +304,11 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ void exp_ma
   }
 }
 
+// lambda_x_c of the projected sphere (spherical_projected.py:124-125): 2 / clamp(1 + c|x|^2, min=1e-15)
+template <int AMAX, typename T> __device__ __forceinline__ T d_lambda(const T* x, int A, T c) {
+  return 2.0f / hard_clamp(1.0f + c * dot<AMAX>(x, x, A), 1e-15f, INFINITY);
+}
+
 // ---- parallel_transport_mu0(x, dst) on ambient vectors
 template <int KIND, int AMAX, typename T>
 __device__ __forceinline__ void pt_mu0(const T* x, const T* dst, int A, T R, T* out) {
@@ -282,6 +319,9 @@ __device__ __forceinline__ void pt_mu0(const T* x, const T* dst, int A, T R, T* 
     T c = 1.0f / (R * R);  // geoopt parallel_transport0: v * clamp_min(1 - c|y|^2, MIN_NORM)
     T f = hard_clamp(1.0f - c * dot<AMAX>(dst, dst, A), 1e-15f, INFINITY);
     MV_FOR(i, 0, A) out[i] = x[i] * f;
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:140-141
+    T f = 2.0f / d_lambda<AMAX>(dst, A, 1.0f / (R * R));
+    MV_FOR(i, 0, A) out[i] = f * x[i];
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:87-93
     T coef = lorentz_product<AMAX>(dst, x, A) / (R * (R + dst[0]));
     out[0] = x[0] + coef * (dst[0] + R);
@@ -302,6 +342,9 @@ __device__ __forceinline__ void inv_pt_mu0(const T* x, const T* src, int A, T R,
     T c = 1.0f / (R * R);
     T f = hard_clamp(1.0f - c * dot<AMAX>(src, src, A), 1e-15f, INFINITY);
     MV_FOR(i, 0, A) out[i] = x[i] / f;
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:144-145
+    T f = d_lambda<AMAX>(src, A, 1.0f / (R * R)) / 2.0f;
+    MV_FOR(i, 0, A) out[i] = f * x[i];
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:96-103
     T coef = (-x[0]) / (R + src[0]);
     out[0] = x[0] + coef * (src[0] + R);
@@ -323,7 +366,7 @@ __device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c,
   T x2 = dot<AMAX>(x, x, A), y2 = dot<AMAX>(y, y, A), xy = dot<AMAX>(x, y, A);
   T fa = 1.0f + 2.0f * c * xy + c * y2;
   T fb = 1.0f - c * x2;
-  T den = (1.0f + 2.0f * c * xy + c * c * x2 * y2) + 1e-5f;
+  T den = hard_clamp(1.0f + 2.0f * c * xy + c * c * x2 * y2, 1e-15f, INFINITY);  // clamp_min(MIN_NORM)
   MV_FOR(i, 0, A) out[i] = (fa * x[i] + fb * y[i]) / den;
 }
 __device__ __forceinline__ float p_artanh(float x) {
@@ -349,6 +392,13 @@ __device__ __forceinline__ void exp_map(const T* u, const T* at, int A, T R, T* 
     T second[AMAX];
     MV_FOR(i, 0, A) second[i] = t * u[i] / (sc * n);
     p_mobius_add<AMAX>(at, second, A, c, z);
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:148-154; mob_add = geoopt mobius_add(c = -K)
+    T c = 1.0f / (R * R);
+    T r = hard_clamp(norm2<AMAX>(u, A), 1e-15f, INFINITY) / R;
+    T t = t_tan(r * d_lambda<AMAX>(at, A, c) / 2.0f);
+    T rhs[AMAX];
+    MV_FOR(i, 0, A) rhs[i] = t * u[i] / r;
+    p_mobius_add<AMAX>(at, rhs, A, -c, z);
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:106-111
     T n = g_sqrt(lorentz_product<AMAX>(u, u, A)) / R;
     T c, s;
@@ -376,6 +426,14 @@ __device__ __forceinline__ void log_map(const T* z, const T* at, int A, T R, T* 
     T sn = hard_clamp(norm2<AMAX>(sub, A), 1e-15f, INFINITY);
     T f = 2.0f / sc / p_lambda<AMAX>(at, A, c) * p_artanh(sc * sn);
     MV_FOR(i, 0, A) u[i] = f * sub[i] / sn;
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:164-169
+    T c = 1.0f / (R * R);
+    T neg[AMAX], sub[AMAX];
+    MV_FOR(i, 0, A) neg[i] = -at[i];
+    p_mobius_add<AMAX>(neg, z, A, -c, sub);
+    T nm = hard_clamp(norm2<AMAX>(sub, A), 1e-15f, INFINITY) / R;
+    T f = 2.0f / d_lambda<AMAX>(at, A, c) * t_atan(nm);
+    MV_FOR(i, 0, A) u[i] = f * (sub[i] / nm);
   } else if constexpr (KIND == kHyperboloid) {  // hyperbolics.py:124-128
     T alpha = -lorentz_product<AMAX>(at, z, A) / (R * R);
     T coef = g_acosh(alpha) / g_sqrt(alpha * alpha - 1.0f);
@@ -398,6 +456,10 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ void log_ma
     T n = hard_clamp(norm2<AMAX>(x, A), 1e-15f, INFINITY);
     T f = p_artanh(sc * n);
     MV_FOR(i, 0, A) out[i] = x[i] / n / sc * f;
+  } else if constexpr (KIND == kProjSphere) {  // spherical_projected.py:172-175
+    T nx = hard_clamp(norm2<AMAX>(x, A), 1e-15f, INFINITY) / R;
+    T f = t_atan(nx);
+    MV_FOR(i, 0, A) out[i] = f * (x[i] / nx);
   } else {
     T alpha = x[0] / R;
     T coef;
@@ -439,6 +501,26 @@ template <int AMAX, typename T> __device__ __forceinline__ T p_logdet(const T* m
   poincare_to_lorentz<AMAX + 1>(mu, A, R, ml);
   log_map<kHyperboloid, AMAX + 1>(zl, ml, A + 1, R, u);
   return logdet_u<kHyperboloid, AMAX + 1>(u, A + 1, R);
+}
+
+// projected_to_spherical (spherical_projected.py:191-196): y[A] -> out[A+1]   (AMAX bounds the OUTPUT)
+template <int AMAX, typename T> __device__ __forceinline__ void projected_to_spherical(const T* y, int A, T R, T* out) {
+  MV_BOUNDS(AMAX);
+  T n = norm2<AMAX>(y, A);
+  T n2 = n * n;
+  T r2 = R * R;
+  T den = n2 + r2;
+  out[0] = (R * (r2 - n2)) / den;
+  MV_FOR(i, 1, A + 1) out[i] = (2.0f * r2 * y[i - 1]) / den;
+}
+
+// StereographicallyProjectedSphere.logdet (spherical_projected.py:56-88): through the sphere.
+template <int AMAX, typename T> __device__ __forceinline__ T d_logdet(const T* mu, const T* z, int A, T R) {
+  T zs[AMAX + 1], ms[AMAX + 1], u[AMAX + 1];
+  projected_to_spherical<AMAX + 1>(z, A, R, zs);
+  projected_to_spherical<AMAX + 1>(mu, A, R, ms);
+  log_map<kSphere, AMAX + 1>(zs, ms, A + 1, R, u);
+  return logdet_u<kSphere, AMAX + 1>(u, A + 1, R);
 }
 
 // =================================================================================================== component
@@ -501,18 +583,24 @@ __device__ __forceinline__ void component_forward(const T* mraw, const T* lraw, 
 
     T logdet_q, logdet_p;
     T v0[AMAX];
-    if constexpr (KIND == kPoincare) {
+    if constexpr (KIND == kPoincare || KIND == kProjSphere) {  // the two projected models: tangent dim = ambient dim
       T c = 1.0f / (R * R);
-      T lam = p_lambda<AMAX>(mu, A, c);
-      MV_FOR(i, 0, A) u[i] = v[i] / lam;  // poincare.py:152-157
+      T lam;
+      if constexpr (KIND == kPoincare) lam = p_lambda<AMAX>(mu, A, c);
+      else lam = d_lambda<AMAX>(mu, A, c);
+      MV_FOR(i, 0, A) u[i] = v[i] / lam;  // poincare.py:152-157 | spherical_projected.py:178-181
       exp_map<KIND, AMAX>(u, mu, A, R, z);
-      logdet_q = p_logdet<AMAX>(mu, z, A, R);
+      if constexpr (KIND == kPoincare) logdet_q = p_logdet<AMAX>(mu, z, A, R);
+      else logdet_q = d_logdet<AMAX>(mu, z, A, R);
       T mu0[AMAX], u0[AMAX];
       MV_FOR(i, 0, A) mu0[i] = cst<T>(0.0f);
       log_map<KIND, AMAX>(z, mu0, A, R, u0);
-      T lam0 = p_lambda<AMAX>(mu0, A, c);
-      MV_FOR(i, 0, A) v0[i] = u0[i] * lam0;  // poincare.py:160-164
-      logdet_p = p_logdet<AMAX>(mu0, z, A, R);
+      T lam0;
+      if constexpr (KIND == kPoincare) lam0 = p_lambda<AMAX>(mu0, A, c);
+      else lam0 = d_lambda<AMAX>(mu0, A, c);
+      MV_FOR(i, 0, A) v0[i] = u0[i] * lam0;  // poincare.py:160-164 | spherical_projected.py:184-188
+      if constexpr (KIND == kPoincare) logdet_p = p_logdet<AMAX>(mu0, z, A, R);
+      else logdet_p = d_logdet<AMAX>(mu0, z, A, R);
     } else {
       x[0] = cst<T>(0.0f);  // expand_proj_dims (common.py:156-158)
       MV_FOR(i, 1, A) x[i] = v[i - 1];

@@ -3,7 +3,7 @@
 
 HBM layout (float32; every segment starts on a 64-float boundary so matrix rows are 16-byte aligned):
 
-    [0, 64)          raw radius parameters, entry i = component i   (components.{i}._nradius / _pradius)
+    [0, 64)          raw radius parameters, entry i = component i   (components.{i}._nradius / _pradius / _curvature)
     W_heads [NH, H]  fc_mean rows of every component, then fc_logvar rows     (component.py:52-57)
     b_heads [NH]
     W_e0 [H, D], b_e0 [H]            fc_e0        (ffnn_vae.py:36)
@@ -48,7 +48,7 @@ class FlatLayout:
         self.n_params = o
         # name -> (offset, shape), reference state-dict names and registration order
         self.entries: List[Tuple[str, int, Tuple[int, ...]]] = []
-        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius"}
+        radius_name = {"h": "_nradius", "p": "_nradius", "s": "_pradius", "d": "_pradius", "u": "_curvature"}
         for i, (letter, d) in enumerate(layout.comps):
             desc = layout.descs[i]
             pre = f"components.{i}."
@@ -106,6 +106,16 @@ class StepEngine:
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
         self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
 
+    def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
+        """Parameter.requires_grad toggles on radii / curvatures (the --universal schedule, run.py:153-165)."""
+        if len(radius_trainable) != self.layout.n:
+            raise ValueError("one flag per component")
+        self.radius_trainable = [bool(t) and letter != "e" for t, (letter, _) in zip(radius_trainable, self.layout.comps)]
+        for i, t in enumerate(self.radius_trainable):
+            self._trainable_arr[i] = 1 if t else 0
+        for ctx, _ in self._ctx.values():
+            check(load().mvae_set_radius_trainable(ctx, self._trainable_arr))
+
     # ---- state
     def param_views(self) -> Dict[str, Tensor]:
         return self.flat.views(self.params)
@@ -128,9 +138,9 @@ class StepEngine:
         return {k: v.detach().clone() for k, v in self.param_views().items()}
 
     def set_radii(self, value: float) -> None:
-        """Trainer._train_epoch warm-up override (train.py:189-194): every h/p/s radius <- value."""
+        """Trainer._train_epoch warm-up override (train.py:189-194): every h/p/s/d radius <- value."""
         for i, (letter, _) in enumerate(self.layout.comps):
-            if letter != "e":
+            if letter in ("h", "p", "s", "d"):  # not the universal curvature, train.py:189-194
                 self.params[i] = value
 
     def set_lr(self, lr: float, curvature_lr: Optional[float] = None) -> None:

@@ -12,7 +12,9 @@ from torch import Tensor
 from . import _lib
 from ._lib import ComponentDesc, check, load, ptr, stream_ptr
 
-KIND_OF_LETTER = {"e": _lib.EUCLIDEAN, "h": _lib.HYPERBOLOID, "s": _lib.SPHERE, "p": _lib.POINCARE}
+KIND_OF_LETTER = {"e": _lib.EUCLIDEAN, "h": _lib.HYPERBOLOID, "s": _lib.SPHERE, "p": _lib.POINCARE,
+                  "d": _lib.PROJ_SPHERE, "u": _lib.UNIVERSAL}
+_PROJECTED = (_lib.POINCARE, _lib.PROJ_SPHERE, _lib.UNIVERSAL)  # tangent dim = ambient dim; logdet takes (mu, z)
 
 
 def ambient_dim(kind: int, d: int) -> int:
@@ -141,10 +143,10 @@ def logdet(kind: int, u: Optional[Tensor], mu: Optional[Tensor], z: Optional[Ten
     out = ref.new_empty(ref.shape[:-1])
     r = _radius_arg(kind, radius, ref)
     mu_c, at_rows, z_c = None, rows, None
-    if kind == _lib.POINCARE:
+    if kind in _PROJECTED:
         z_c = ref
         mu_c, at_rows = _at_rows(ref, mu, A)
-    check(load().mvae_logdet(kind, ptr(ref) if kind != _lib.POINCARE else None, ptr(mu_c), ptr(z_c), ptr(out), rows,
+    check(load().mvae_logdet(kind, ptr(ref) if kind not in _PROJECTED else None, ptr(mu_c), ptr(z_c), ptr(out), rows,
                              at_rows, _true_dim(kind, A), ptr(r), stream_ptr(ref.device)))
     return out
 

@@ -215,8 +215,21 @@ class ModelVAE(nn.Module):
         x = x_mb.to(self.device, torch.float32)
         eps = self._eps(x.shape[0]) if eps is None else eps
         optimizer.bind(self)
+        self._sync_trainable()
         eng.train_step(x, eps, float(beta), optimizer.curv_condition())
         return BatchStatsFloat(eng, beta), (None, None, None)
+
+    def _sync_trainable(self) -> None:
+        """Parameter.requires_grad of the radii / curvatures is the source of truth (the --universal schedule flips it,
+        run.py:153-165); the engine learns about a change before the next step."""
+        eng = self.engine
+        flags = [bool(getattr(c._radius_param(), "requires_grad", False)) and c.LETTER != "e" for c in self.components]
+        if flags != list(eng.radius_trainable):
+            eng.set_radius_trainable(flags)
+            gviews = eng.grad_views()
+            for name, p in self.named_parameters():
+                if p.requires_grad and p.grad is None and name in gviews:
+                    p.grad = gviews[name]
 
 
 class FeedForwardVAE(ModelVAE):

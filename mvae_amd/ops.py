@@ -106,6 +106,17 @@ class PoincareBall(RadiusManifold):
         return Fn.logdet(self.KIND, None, mu, z, self._r())
 
 
+class StereographicallyProjectedSphere(RadiusManifold):
+    """spherical_projected.py:31-88."""
+    KIND = _lib.PROJ_SPHERE
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:  # spherical_projected.py:120-121
+        return torch.zeros(shape, **kwargs)
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
+        return Fn.logdet(self.KIND, None, mu, z, self._r())  # spherical_projected.py:56-88
+
+
 class Euclidean(Manifold):
     KIND = _lib.EUCLIDEAN
 
@@ -122,6 +133,55 @@ class Euclidean(Manifold):
 
     def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
         return torch.zeros_like(mu)  # euclidean.py:58-59
+
+
+class Universal(Manifold):
+    """universal.py:28-83.  Takes a callable returning the live CURVATURE parameter.  The kernels dispatch on its sign
+    on the device (kind MVAE_UNIVERSAL), so no method here synchronises; `manifold` / `_choice` (host-side views of the
+    same decision, as in the reference) do."""
+    KIND = _lib.UNIVERSAL
+
+    def __init__(self, curvature: Callable[[], Tensor], eps: float = 1e-6) -> None:
+        super().__init__()
+        self._curvature = curvature
+        self._manifolds = {
+            -1: PoincareBall(lambda: self._sub_radius_param()),
+            0: Euclidean(),
+            1: StereographicallyProjectedSphere(lambda: self._sub_radius_param()),
+        }
+        self.eps = eps
+
+    def _r(self):
+        return self._curvature()
+
+    def _sub_radius_param(self) -> Tensor:
+        return self.radius
+
+    @property
+    def radius(self) -> Tensor:  # universal.py:30-32 (sqrt = the reference's clamped sqrt, common.py:117-119)
+        k = self._curvature().detach()
+        return torch.relu(1 / torch.sqrt(torch.clamp(k.abs(), min=1e-9)))
+
+    @property
+    def curvature(self) -> Tensor:  # universal.py:34-36
+        return self._curvature()
+
+    @property
+    def _choice(self) -> int:  # universal.py:67-74
+        k = float(self._curvature())
+        return -1 if k < -self.eps else (1 if k > self.eps else 0)
+
+    @property
+    def manifold(self) -> Manifold:  # universal.py:63-65
+        return self._manifolds[self._choice]
+
+    def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:  # zeros in all three sub-manifolds
+        return torch.zeros(shape, **kwargs)
+
+    def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:  # universal.py:82-83
+        if self._choice == 0:
+            return torch.zeros_like(mu)
+        return Fn.logdet(self.KIND, None, mu, z, self._r())
 
 
 def lorentz_to_poincare(x: Tensor, radius: Tensor) -> Tensor:

@@ -57,8 +57,6 @@ def main(argv=None) -> None:
                          "(the reference falls back to cpu here, run.py:91-93).")
     if args.doubles:
         raise SystemExit("--doubles=True is not supported: the HIP path computes in float32.")
-    if args.universal:
-        raise SystemExit("--universal needs the 'u' component, which is not part of this build yet.")
     device = torch.device(args.device)
     print("Running on:", device, flush=True)
 
@@ -86,9 +84,31 @@ def main(argv=None) -> None:
     optimizer = trainer.build_optimizer(learning_rate=args.learning_rate, fixed_curvature=args.fixed_curvature)
     train_loader, test_loader = dataset.create_loaders(seed=args.seed)
     betas = utils.linear_betas(args.beta_start, args.beta_end, end_epoch=args.beta_end_epoch, epochs=args.epochs)
-    trainer.train_stopping(optimizer=optimizer, train_data=train_loader, eval_data=test_loader, warmup=args.warmup,
-                           lookahead=args.lookahead, betas=betas, likelihood_n=args.likelihood_n,
-                           max_epochs=args.epochs)
+    if args.universal:  # the universal training scheme, run.py:139-175
+        # pre-training at K = 0 (every `u` component is Euclidean)
+        trainer.train_epochs(optimizer=optimizer, train_data=train_loader, eval_data=test_loader,
+                             epochs=args.epochs // 2, betas=betas, likelihood_n=0)
+        # choose signs: a third hyperbolic, a third spherical, the rest stays Euclidean
+        eps = 1e-5
+        cn = len(model.components) // 3
+        signs = [-1] * cn + [1] * cn + [0] * (len(model.components) - 2 * cn)
+        print("Chosen signs:", signs)
+        for i, component in enumerate(model.components):
+            component._curvature.data += signs[i] * eps
+            component._curvature.requires_grad = False
+        # ... continue without learning curvature for 10 epochs
+        trainer.train_epochs(optimizer=optimizer, train_data=train_loader, eval_data=test_loader, epochs=10,
+                             betas=betas, likelihood_n=0)
+        # ... then unfix it
+        for component in model.components:
+            component._curvature.requires_grad = True
+        trainer.train_stopping(optimizer=optimizer, train_data=train_loader, eval_data=test_loader,
+                               warmup=args.lookahead + 1, lookahead=args.lookahead, betas=betas,
+                               likelihood_n=args.likelihood_n, max_epochs=args.epochs)
+    else:
+        trainer.train_stopping(optimizer=optimizer, train_data=train_loader, eval_data=test_loader,
+                               warmup=args.warmup, lookahead=args.lookahead, betas=betas,
+                               likelihood_n=args.likelihood_n, max_epochs=args.epochs)
     print(flush=True)
     print("Done.", flush=True)
 

@@ -106,7 +106,7 @@ class EpochRunner:
     """A training epoch with NO per-step host work: the data set lives in HBM as uint8, every step is the pair
     [mvae_prepare_batch (gather + dynamic binarisation + eps draw, Philox), fused train step], and the pairs are replayed
     as HIP graphs of `graph_steps` steps.  The batch cursor and the Adam step counter are device-resident, so one
-    captured graph serves every position of every epoch; only a change of (beta, curvature gate) re-captures.
+    captured graph serves every position of every epoch; only a change of (beta, curvature gate, trainable flags) re-captures.
     Replaces the reference's DataLoader worker processes + per-step H2D copy + torch RNG draw
     (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
 
@@ -140,7 +140,8 @@ class EpochRunner:
         self.eng.train_step(self.x, self.eps, beta, do_curv)
 
     def _graph(self, beta: float, do_curv: bool) -> torch.cuda.CUDAGraph:
-        key = (float(beta), bool(do_curv))
+        # the trainable flags travel in the kernel arguments, so a requires_grad toggle needs a fresh capture
+        key = (float(beta), bool(do_curv), tuple(self.eng.radius_trainable))
         g = self._graphs.get(key)
         if g is None:
             eng = self.eng

@@ -43,3 +43,22 @@ class WrappedNormalProcedure(SamplingProcedure):
 
 class EuclideanNormalProcedure(SamplingProcedure):
     pass
+
+
+class UniversalSamplingProcedure(SamplingProcedure):
+    """sampling_procedures.py:184-206: wrapped normal on the Poincare ball / projected sphere or the Euclidean normal
+    procedure, by the sign of the component's curvature.  The fused component operator takes that decision on the
+    device (kind MVAE_UNIVERSAL), so this class has nothing left to dispatch; `sampling_procedure` mirrors the
+    reference's property for callers that inspect it."""
+
+    def __init__(self, manifold, scalar_parametrization: bool) -> None:
+        super().__init__(manifold, scalar_parametrization)
+        self._sampling_procedures = {
+            -1: WrappedNormalProcedure(manifold._manifolds[-1], scalar_parametrization),
+            0: EuclideanNormalProcedure(manifold._manifolds[0], scalar_parametrization),
+            1: WrappedNormalProcedure(manifold._manifolds[1], scalar_parametrization),
+        }
+
+    @property
+    def sampling_procedure(self) -> SamplingProcedure:
+        return self._sampling_procedures[self._manifold._choice]

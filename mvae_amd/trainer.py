@@ -7,7 +7,8 @@ from typing import Any, Dict, Optional, Sequence
 import numpy as np
 import torch
 
-from .components import HyperbolicComponent, PoincareComponent, SphericalComponent
+from .components import (HyperbolicComponent, PoincareComponent, SphericalComponent,
+                         StereographicallyProjectedSphereComponent)
 from .models import ModelVAE
 from .stats import EpochStats
 
@@ -98,8 +99,8 @@ class Trainer:
         self.model.train()
         eng = self.model._need_engine()
         if self.epoch < 10:  # train.py:189-194 (applies to fixed-curvature models too)
-            if any(isinstance(c, (SphericalComponent, PoincareComponent, HyperbolicComponent))
-                   for c in self.model.components):
+            if any(isinstance(c, (SphericalComponent, PoincareComponent, HyperbolicComponent,
+                                  StereographicallyProjectedSphereComponent)) for c in self.model.components):
                 eng.set_radii(11 - self.epoch)
         eng.read_stats(reset=True)
         if not self._device_pipeline_epoch(optimizer, train_data, beta):
@@ -130,6 +131,7 @@ class Trainer:
                 int(train_data._gen.initial_seed())
             er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed)
         optimizer.bind(self.model)
+        self.model._sync_trainable()
         self.global_step += er.run_epoch(beta, optimizer.curv_condition())
         tail = er.N - er.nb * er.B
         if tail:

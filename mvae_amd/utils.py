@@ -5,24 +5,29 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
-from .components import (Component, EuclideanComponent, HyperbolicComponent, PoincareComponent, SphericalComponent)
-from .sampling import EuclideanNormalProcedure, WrappedNormalProcedure
+from .components import (Component, EuclideanComponent, HyperbolicComponent, PoincareComponent, SphericalComponent,
+                         StereographicallyProjectedSphereComponent, UniversalComponent)
+from .sampling import EuclideanNormalProcedure, UniversalSamplingProcedure, WrappedNormalProcedure
 
-# utils.py:30-48.  d (projected sphere), u (universal) and c (constant) are outside this build's scope (SURVEY.md
-# section 8f) and raise NotImplementedError like any unknown letter does in the reference.
+# utils.py:30-48.  c (the constant component, an ablation stub of the reference) is outside this build's scope
+#  and raises NotImplementedError like any unknown letter does in the reference.
 space_creator_map = {
     "h": HyperbolicComponent,
+    "u": UniversalComponent,
     "s": SphericalComponent,
+    "d": StereographicallyProjectedSphereComponent,
     "p": PoincareComponent,
     "e": EuclideanComponent,
 }
 sampling_procedure_map = {
     SphericalComponent: WrappedNormalProcedure,
+    StereographicallyProjectedSphereComponent: WrappedNormalProcedure,
     EuclideanComponent: EuclideanNormalProcedure,
     HyperbolicComponent: WrappedNormalProcedure,
     PoincareComponent: WrappedNormalProcedure,
+    UniversalComponent: UniversalSamplingProcedure,
 }
-_REFERENCE_ONLY = ("u", "d", "c")
+_REFERENCE_ONLY = ("c",)
 
 
 def set_seeds(seed: int) -> None:  # utils.py:56-59

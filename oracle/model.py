@@ -6,7 +6,7 @@ rsample) and the binarised `x` are explicit inputs, so results are reproducible 
 
 Follows (all under /root/reference):
   mt/mvae/utils.py:78-140           model-string grammar
-  mt/mvae/components/component.py   encode (63-75), per-type radius parameter names (114-203)
+  mt/mvae/components/component.py   encode (63-75), per-type radius / curvature parameter names (114-242)
   mt/mvae/sampling/sampling_procedures.py:91-116,145-155   q/p construction, MC-KL / analytic KL
   mt/mvae/distributions/wrapped_normal.py:33-107            wrapped normal sample + log-prob
   mt/mvae/models/{vae,ffnn_vae,conv_vae}.py                 forward, ELBO, train_step, log_likelihood
@@ -24,7 +24,7 @@ from torch import Tensor
 from . import ops
 
 LETTERS = ("h", "u", "s", "d", "p", "c", "e")  # utils.py:30-38
-SUPPORTED = ("h", "s", "e", "p")  # hot-path scope; d/u/c are "next"
+SUPPORTED = ("h", "s", "e", "p", "d", "u")  # SURVEY.md section 8 incl. row f-3; `c` (constant component) is not built
 
 
 # --------------------------------------------------------------------------------------------- grammar
@@ -58,7 +58,7 @@ class ComponentSpec:
 
     @property
     def radius_name(self) -> Optional[str]:  # component.py:123,142,160
-        return {"h": "_nradius", "p": "_nradius", "s": "_pradius"}.get(self.letter)
+        return {"h": "_nradius", "p": "_nradius", "s": "_pradius", "d": "_pradius", "u": "_curvature"}.get(self.letter)
 
 
 def parse_components(arg: str) -> List[ComponentSpec]:
@@ -178,7 +178,13 @@ def component_forward(c: ComponentSpec, mean_raw: Tensor, logvar_raw: Tensor, ep
     component.py:63-75 -> sampling_procedures.py:93-99|147-151 -> wrapped_normal.py:70-78 -> kl_loss :101-116|153-155
     """
     std = F.softplus(logvar_raw) + 1e-5  # component.py:72
-    if c.letter == "e":
+    letter = c.letter
+    if letter == "u":  # universal.py:63-74 + sampling_procedures.py:184-206: dispatch on the sign of the curvature
+        choice = ops.u_choice(radius_param)
+        letter = {-1: "p", 0: "e", 1: "d"}[choice]
+        if choice != 0:  # the sub-manifold sees relu(1/sqrt|K|) through RadiusManifold.radius (universal.py:30-32,57-61)
+            radius_param = ops.u_radius(radius_param)
+    if letter == "e":
         mu = ops.e_exp_map_mu0(mean_raw)
         z = mu + eps * std  # Normal.rsample (wrapped_distributions.py:25-27)
         out = ComponentOut(z=z, kl=None, mu=mu, std=std)
@@ -195,27 +201,34 @@ def component_forward(c: ComponentSpec, mean_raw: Tensor, logvar_raw: Tensor, ep
     if std.shape[-1] == 1 and c.true_dim > 1:  # wrapped_normal.py:46-49
         std = std.repeat(*([1] * (std.dim() - 1)), c.true_dim)
     v = eps * std  # Normal(0, std).rsample
-    if c.letter == "h":
+    if letter == "h":
         mu = ops.h_exp_map_mu0(mean_raw, R)
         z, (u, _) = ops.h_sample_projection_mu0(v, mu, R)
         logdet_q = ops.h_logdet(u, R)
         mu0 = ops.h_mu0(mu.shape, R, dtype=mu.dtype)
         u0, v0 = ops.h_inverse_sample_projection_mu0(z, mu0, R)
         logdet_p = ops.h_logdet(u0, R)
-    elif c.letter == "s":
+    elif letter == "s":
         mu = ops.s_exp_map_mu0(mean_raw, R)
         z, (u, _) = ops.s_sample_projection_mu0(v, mu, R)
         logdet_q = ops.s_logdet(u, R)
         mu0 = ops.h_mu0(mu.shape, R, dtype=mu.dtype)  # spherical.py:70-71: same R*e_0
         u0, v0 = ops.s_inverse_sample_projection_mu0(z, mu0, R)
         logdet_p = ops.s_logdet(u0, R)
-    elif c.letter == "p":
+    elif letter == "p":
         mu = ops.p_exp_map_mu0(mean_raw, R)
         z, (u, _) = ops.p_sample_projection_mu0(v, mu, R)
         logdet_q = ops.p_logdet(mu, z, R)
         mu0 = torch.zeros_like(mu)
         u0, v0 = ops.p_inverse_sample_projection_mu0(z, mu0, R)
         logdet_p = ops.p_logdet(mu0, z, R)
+    elif letter == "d":
+        mu = ops.d_exp_map_mu0(mean_raw, R)
+        z, (u, _) = ops.d_sample_projection_mu0(v, mu, R)
+        logdet_q = ops.d_logdet(mu, z, R)
+        mu0 = torch.zeros_like(mu)  # spherical_projected.py:120-121
+        u0, v0 = ops.d_inverse_sample_projection_mu0(z, mu0, R)
+        logdet_p = ops.d_logdet(mu0, z, R)
     else:
         raise NotImplementedError(c.letter)
     log_q = _normal_log_prob_sum(v, std.expand_as(v)) - logdet_q  # wrapped_normal.py:84-97
@@ -295,8 +308,8 @@ class StepOracle:
         for name, shape in spec.named_shapes():
             t = state[name].detach().clone().to(dtype)
             assert tuple(t.shape) == tuple(shape), (name, t.shape, shape)
-            is_radius = name.endswith("radius")
-            t.requires_grad_(not (is_radius and spec.fixed_curvature))  # component.py:123,160
+            is_radius = name.endswith("radius") or name.endswith("_curvature")
+            t.requires_grad_(not (is_radius and spec.fixed_curvature))  # component.py:123,160,232
             self.P[name] = t
         # train.py:327-360: routing by name substring
         net = [p for n, p in self.P.items() if "radius" not in n and "curvature" not in n]
@@ -319,6 +332,9 @@ class StepOracle:
             p.grad = None
         out = forward(self.spec, self.P, x, eps, beta)
         (-out.elbo).backward()
+        c_params = [p for n, p in self.P.items() if "curvature" in n]  # vae.py:161-163 (universal components only)
+        if c_params:
+            torch.nn.utils.clip_grad_norm_(c_params, max_norm=1.0, norm_type=2)
         self.adam.step()
         if (not self.spec.fixed_curvature) and epoch >= 10:
             if self.sgd_pos is not None:
@@ -335,5 +351,7 @@ def curvature_of(c: ComponentSpec, radius_param: Optional[Tensor]) -> float:
     """manifold.py:69-71, hyperbolics.py:53-55, spherical.py:53-55, poincare.py:30-32, euclidean.py:30-32."""
     if c.letter == "e":
         return 0.0
+    if c.letter == "u":  # universal.py:34-36
+        return float(radius_param)
     R = float(ops.radius_from_param(radius_param))
     return (-1.0 if c.letter in ("h", "p") else 1.0) / (R * R)

@@ -14,8 +14,8 @@ EPS = 1e-8  # common.py:21
 MAX_NORM = 85.0  # common.py:22
 LN_2 = math.log(2.0)
 
-EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE = 0, 1, 2, 3
-KIND_OF_LETTER = {"e": EUCLIDEAN, "h": HYPERBOLOID, "s": SPHERE, "p": POINCARE}
+EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
+KIND_OF_LETTER = {"e": EUCLIDEAN, "h": HYPERBOLOID, "s": SPHERE, "p": POINCARE, "d": PROJ_SPHERE, "u": UNIVERSAL}
 
 
 # --------------------------------------------------------------------------- guarded scalar functions
@@ -265,7 +265,11 @@ def e_inverse_sample_projection_mu0(z: Tensor, at: Tensor) -> Tuple[Tensor, Tens
 
 # --------------------------------------------------------------------------- Poincare ball  (PARITY UNPINNED)
 # poincare.py delegates to geoopt==0.1.0 (absent).  Formulas: Ganea et al. 2018, guards as in geoopt 0.1.0 as best
-# known: MIN_NORM=1e-15 on norms, tanh argument clamped to +-15, mobius_add denominator + 1e-5.
+# known: MIN_NORM=1e-15 on norms, tanh argument clamped to +-15, mobius_add denominator clamp_min(MIN_NORM).
+# The denominator guard is anchored on the reference's own tests: its exp/log round trips to atol 5e-6
+# (tests/mvae/ops/test_poincare.py:140-211, test_spherical_projected.py:202-270) hold with clamp_min(1e-15) and fail
+# by two orders of magnitude with the "+ 1e-5" variant some geoopt versions carried; the commented-out restatement in
+# spherical_projected.py:108-112 shows the same `denom.clamp(min=MIN_NORM)` form.
 P_MIN_NORM = 1e-15
 
 
@@ -302,7 +306,7 @@ def p_mobius_add(x: Tensor, y: Tensor, c: Tensor) -> Tensor:
     xy = (x * y).sum(dim=-1, keepdim=True)
     num = (1 + 2 * c * xy + c * y2) * x + (1 - c * x2) * y
     denom = 1 + 2 * c * xy + c**2 * x2 * y2
-    return num / (denom + 1e-5)
+    return num / denom.clamp_min(P_MIN_NORM)
 
 
 def p_exp_map_mu0(x: Tensor, R: Tensor) -> Tensor:  # poincare.py:132-137 -> geoopt expmap0
@@ -328,6 +332,20 @@ def p_log_map(y: Tensor, at: Tensor, R: Tensor) -> Tensor:  # poincare.py:140-14
     return 2 / sc / p_lambda_x(at, c) * _PArtanh.apply(sc * sn) * sub / sn
 
 
+def p_log_map_mu0(y: Tensor, R: Tensor) -> Tensor:  # poincare.py:148-149 -> geoopt logmap0
+    sc = _p_c(R)**0.5
+    n = y.norm(dim=-1, p=2, keepdim=True).clamp_min(P_MIN_NORM)
+    return y / n / sc * _PArtanh.apply(sc * n)
+
+
+def p_pt_mu0(x: Tensor, dst: Tensor, R: Tensor) -> Tensor:  # poincare.py:116-117 -> geoopt parallel_transport0
+    return x * (1 - _p_c(R) * dst.pow(2).sum(dim=-1, keepdim=True)).clamp_min(P_MIN_NORM)
+
+
+def p_inv_pt_mu0(x: Tensor, src: Tensor, R: Tensor) -> Tensor:  # poincare.py:120-121 -> geoopt parallel_transport0back
+    return x / (1 - _p_c(R) * src.pow(2).sum(dim=-1, keepdim=True)).clamp_min(P_MIN_NORM)
+
+
 def p_sample_projection_mu0(v: Tensor, at: Tensor, R: Tensor) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
     u = v / p_lambda_x(at, _p_c(R))  # poincare.py:152-157
     return p_exp_map(u, at, R), (u, v)
@@ -348,3 +366,106 @@ def p_logdet(mu: Tensor, z: Tensor, R: Tensor) -> Tensor:  # poincare.py:55-89 (
         mu = mu.unsqueeze(0).expand(z.shape)
     u, _ = h_inverse_sample_projection_mu0(poincare_to_lorentz(z, R), poincare_to_lorentz(mu, R), R)
     return h_logdet(u, R)
+
+
+# ------------------------------------------------------------- stereographically projected sphere `d`
+# spherical_projected.py.  Everything here is reference-owned EXCEPT mob_add, which calls geoopt's mobius_add with
+# c = -K (spherical_projected.py:113): that one formula is PARITY UNPINNED like the Poincare ball; the functions that
+# do not touch it (exp_map_mu0, inverse_exp_map_mu0, the two parallel transports, lambda_x, projected_to_spherical,
+# spherical_projected_distance) are pinned by tests/golden/g6_projected.npz.
+D_MIN_NORM = 1e-15  # spherical_projected.py:26
+
+
+def d_lambda_x_c(x: Tensor, c: Tensor) -> Tensor:  # spherical_projected.py:124-125
+    return 2 / (1 + c * x.pow(2).sum(dim=-1, keepdim=True)).clamp(min=D_MIN_NORM)
+
+
+def d_lambda_x(x: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:128-129
+    return d_lambda_x_c(x, 1 / R**2)
+
+
+def d_mob_add(x: Tensor, y: Tensor, K: Tensor) -> Tensor:  # spherical_projected.py:107-113 -> geoopt mobius_add(c=-K)
+    return p_mobius_add(x, y, -K)
+
+
+def d_pt_mu0(x: Tensor, dst: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:140-141
+    return (2 / d_lambda_x(dst, R)) * x
+
+
+def d_inv_pt_mu0(x: Tensor, src: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:144-145
+    return (d_lambda_x(src, R) / 2) * x
+
+
+def d_exp_map(x: Tensor, at: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:148-154
+    r = torch.norm(x, p=2, dim=-1, keepdim=True).clamp(min=D_MIN_NORM) / R
+    c = 1 / R**2
+    arg = r * d_lambda_x_c(at, c) / 2
+    rhs = torch.tan(arg) * x / r
+    return d_mob_add(at, rhs, c)
+
+
+def d_exp_map_mu0(x: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:157-161
+    r = torch.norm(x, p=2, dim=-1, keepdim=True).clamp(min=D_MIN_NORM) / R
+    return torch.tan(r) * x / r
+
+
+def d_log_map(x: Tensor, at: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:164-169
+    c = 1 / R**2
+    mxpy = d_mob_add(-at, x, c)
+    nmxpy = torch.norm(mxpy, p=2, dim=-1, keepdim=True).clamp(min=D_MIN_NORM) / R
+    normalized = mxpy / nmxpy
+    return 2 / d_lambda_x_c(at, c) * torch.atan(nmxpy) * normalized
+
+
+def d_log_map_mu0(x: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:172-175
+    nx = torch.norm(x, p=2, dim=-1, keepdim=True).clamp(min=D_MIN_NORM) / R
+    return torch.atan(nx) * (x / nx)
+
+
+def d_sample_projection_mu0(v: Tensor, at: Tensor, R: Tensor) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+    u = v / d_lambda_x(at, R)  # spherical_projected.py:178-181
+    return d_exp_map(u, at, R), (u, v)
+
+
+def d_inverse_sample_projection_mu0(z: Tensor, at: Tensor, R: Tensor) -> Tuple[Tensor, Tensor]:
+    u = d_log_map(z, at, R)  # spherical_projected.py:184-188
+    return u, u * d_lambda_x_c(at, 1 / R**2)
+
+
+def projected_to_spherical(y: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:191-196
+    yn2 = torch.norm(y, p=2, dim=-1, keepdim=True)**2
+    r2 = R * R
+    return torch.cat((R * (r2 - yn2), 2 * r2 * y), dim=-1) / (yn2 + r2)
+
+
+def d_logdet(mu: Tensor, z: Tensor, R: Tensor) -> Tensor:  # spherical_projected.py:56-88: through the sphere
+    if z.dim() > mu.dim():
+        mu = mu.unsqueeze(0).expand(z.shape)
+    u, _ = s_inverse_sample_projection_mu0(projected_to_spherical(z, R), projected_to_spherical(mu, R), R)
+    return s_logdet(u, R)
+
+
+def spherical_projected_distance(x: Tensor, y: Tensor, K: Tensor) -> Tensor:  # spherical_projected.py:91-98
+    diff = x - y
+    nd = torch.sum(diff * diff, dim=-1, keepdim=True)
+    nx = torch.sum(x * x, dim=-1, keepdim=True)
+    ny = torch.sum(y * y, dim=-1, keepdim=True)
+    return 1. / sqrt(K) * torch.acos(torch.clamp(1 - 2 * K * nd / ((1 + K * nx) * (1 + K * ny)), max=1.0))
+
+
+def spherical_projected_gyro_distance(x: Tensor, y: Tensor, K: Tensor) -> Tensor:  # spherical_projected.py:101-105
+    sk = sqrt(K)
+    return 2. / sk * torch.atan(sk * torch.norm(d_mob_add(-x, y, K), p=2, dim=-1, keepdim=True))
+
+
+# ------------------------------------------------------------- universal manifold `u`  (universal.py:28-83)
+U_EPS = 1e-6  # universal.py:53, component.py:231
+
+
+def u_radius(K: Tensor) -> Tensor:  # universal.py:30-32
+    return torch.relu(1 / sqrt(K.abs()))
+
+
+def u_choice(K: Tensor, eps: float = U_EPS) -> int:  # universal.py:67-74: -1 Poincare ball, +1 projected sphere, 0 Euclid
+    k = float(K.detach())
+    return -1 if k < -eps else (1 if k > eps else 0)

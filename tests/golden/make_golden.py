@@ -16,6 +16,8 @@ Files written (all small):
   g3_step_full.npz      same at the benchmark size (B=128, h=400, D=784): per-sample stats + summaries
   g4_loglik.npz         ModelVAE.log_likelihood(x, n=8)
   g5_parser.json        model-string grammar table
+  g6_projected.npz      the reference-owned part of the projected sphere `d` (everything that does not cross into
+                        geoopt's mobius_add) and Universal.radius / _choice, f32 and f64
 """
 import json
 import os
@@ -49,6 +51,43 @@ DTYPES = {"f32": torch.float32, "f64": torch.float64}
 
 def npy(t):
     return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------- G6
+def gen_projected():
+    from mt.mvae.ops import spherical_projected as SP
+    from mt.mvae.ops import StereographicallyProjectedSphere, Universal
+    out = {}
+    for dname, dtype in DTYPES.items():
+        torch.set_default_dtype(dtype)
+        for R in [0.5, 1.0, 2.0, 11.0]:
+            for d in [2, 5, 40]:
+                rows = 8
+                g = torch.Generator().manual_seed(7000 + int(R * 100) + d)
+                x = (torch.randn(rows, d, generator=g, dtype=torch.float64) * 0.6 * min(R, 3.0) / np.sqrt(d)).to(dtype)
+                y = (torch.randn(rows, d, generator=g, dtype=torch.float64) * 0.8 * R / np.sqrt(d)).to(dtype)
+                w = (torch.randn(rows, d, generator=g, dtype=torch.float64) * 0.8 * R / np.sqrt(d)).to(dtype)
+                radius = torch.tensor(R, dtype=dtype)
+                key = f"D/R{R:g}/d{d}/{dname}/"
+                out[key + "x"], out[key + "y"], out[key + "w"] = npy(x), npy(y), npy(w)
+                mu = SP.exp_map_mu0(x, radius=radius)
+                out[key + "mu"] = npy(mu)
+                out[key + "log_mu0"] = npy(SP.inverse_exp_map_mu0(mu, radius=radius))
+                out[key + "pt"] = npy(SP.parallel_transport_mu0(x, dst=y, radius=radius))
+                out[key + "ipt"] = npy(SP.inverse_parallel_transport_mu0(x, src=y, radius=radius))
+                out[key + "lambda"] = npy(SP.lambda_x(y, radius))
+                out[key + "to_sphere"] = npy(SP.projected_to_spherical(y, radius))
+                out[key + "dist"] = npy(SP.spherical_projected_distance(y, w, SP._c(radius)))
+                man = StereographicallyProjectedSphere(lambda: radius)
+                out[key + "logdet"] = npy(man.logdet(y, None, w, ()))  # (mu, std, z, data): uses mu and z only
+                out[key + "logdet0"] = npy(man.logdet(SP.mu_0(w.shape), None, w, ()))
+        ks = torch.tensor([-4.0, -0.25, -1e-5, -1e-7, 0.0, 1e-7, 1e-5, 0.25, 4.0], dtype=dtype)
+        out[f"U/{dname}/K"] = npy(ks)
+        out[f"U/{dname}/radius"] = npy(torch.stack([Universal(lambda k=k: k).radius for k in ks]))
+        out[f"U/{dname}/choice"] = np.array([Universal(lambda k=k: k)._choice for k in ks], dtype=np.int64)
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g6_projected.npz"), **out)
+    print("g6_projected:", len(out), "arrays")
 
 
 # ----------------------------------------------------------------------------------------------- G1
@@ -445,7 +484,7 @@ def gen_parser():
     torch.set_default_dtype(torch.float32)
     table = {}
     for s in ["e6", "h2,s2,e2", "6h2,6s2,6e2", "e2,h2,s2", "h40", "s40-wn", "2h3,p2,d2,u2,c3", "3e2,2s5", "  H2 , S2 ",
-              "p5", "e1"]:
+              "p5", "e1", "d2,u2,p2", "3u2", "u2,d3,h2,s2,e2", "2d40"]:
         comps = ref_utils.parse_components(s, fixed_curvature=False)
         table[s] = {
             "canonical": ref_utils.canonical_name(comps),
@@ -468,7 +507,7 @@ def gen_parser():
     # parameter names/shapes of the headline models (state-dict contract)
     shapes = {}
     for s, arch, in_dim, h in [("h2,s2,e2", "ff", 784, 400), ("6h2,6s2,6e2", "ff", 784, 400), ("e6", "ff", 784, 400),
-                               ("h2,s2,e2", "conv", 3072, 8192)]:
+                               ("h2,s2,e2", "conv", 3072, 8192), ("u2,d2,e2", "ff", 784, 400)]:
         m, _ = _build_reference_model(s, arch, in_dim, h, 4, False, False, 2.0, torch.float32)
         shapes[f"{s}|{arch}"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
     with open(os.path.join(HERE, "g5_parser.json"), "w") as fh:
@@ -478,7 +517,7 @@ def gen_parser():
 
 if __name__ == "__main__":
     os.makedirs("/tmp/golden_chkpt", exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5", "g6"]
     torch.set_num_threads(8)
     if "g1" in which:
         gen_primitives()
@@ -494,3 +533,5 @@ if __name__ == "__main__":
         gen_loglik()
     if "g5" in which:
         gen_parser()
+    if "g6" in which:
+        gen_projected()

@@ -273,8 +273,7 @@ def test_log_likelihood(name, model, dname):
 def test_parser_table():
     tab = load_json("g5_parser.json")
     for s, ref in tab["parse"].items():
-        if any(c["class"] in ("StereographicallyProjectedSphereComponent", "UniversalComponent", "ConstantComponent")
-               for c in ref["components"]):
+        if any(c["class"] == "ConstantComponent" for c in ref["components"]):  # `c` is not built
             with pytest.raises(NotImplementedError):
                 M.parse_components(s)
             continue
