@@ -109,16 +109,28 @@ def main():
                     help="latent space string; the driver's metric is the default (BASELINE configs[1]); "
                          "'e6' = configs[0], '6h2,6s2,6e2' = configs[3]")
     ap.add_argument("--fixed-curvature", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="diagnostic: take the data-parallel route (gradients -> RCCL all-reduce -> k_optim) even at "
+                         "world size 1")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Libraries below (RCCL's version banner, HIP runtime notices) write to
+    # the C-level stdout, buffered until exit: keep the real stdout aside for the JSON line and point fd 1 at stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or args.force_dp
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -140,11 +152,11 @@ def main():
     eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
     runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not args.fixed_curvature,
                         graph_steps=args.graph_steps,
-                        world_size=world, reset_every=args.reset_every)
+                        world_size=world, reset_every=args.reset_every, force_exchange=args.force_dp)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -154,7 +166,7 @@ def main():
     runner.run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -164,7 +176,7 @@ def main():
     assert finite or os.environ.get("MVAE_BENCH_ALLOW_NONFINITE"), "non-finite ELBO"
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -210,15 +222,17 @@ def main():
                                f"MNIST shapes (D=784), model {args.model}, "
                                f"{'fixed' if args.fixed_curvature else 'learnable'} curvature, "
                                "MLP h_dim=400, batch 128 per GPU, epoch>=10 state",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "graph_steps": args.graph_steps,
+                   "global_batch": B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
+                   "graph_steps": runner.gs,
                    "state_reset_every": args.reset_every,
                    "final_elbo_per_sample": stats["last"]["elbo"] / B},
         "roofline": roof,
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(model=args.model, fixed=args.fixed_curvature)
-    print(json.dumps(line), flush=True)
-    if world > 1:
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
+    if dist_on:
         dist.destroy_process_group()
 
 

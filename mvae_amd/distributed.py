@@ -27,9 +27,12 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 
 class DataParallelStep:
 
-    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None) -> None:
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False) -> None:
+        """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
+        exercises the collective, its graph capture and k_optim on a single GPU)."""
         self.engine = engine
         self.group = group
+        self.always_exchange = bool(always_exchange)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -41,7 +44,7 @@ class DataParallelStep:
 
     def train_step(self, x_local: Tensor, eps_local: Tensor, beta: float, do_curvature_step: bool) -> None:
         eng = self.engine
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             eng.train_step(x_local, eps_local, beta, do_curvature_step)
             return
         eng.forward_backward(x_local, eps_local, beta)

@@ -16,7 +16,7 @@ from .engine import StepEngine
 class StepRunner:
 
     def __init__(self, eng: StepEngine, xs: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
-                 graph_steps: int = 0, world_size: int = 1, reset_every: int = 0):
+                 graph_steps: int = 0, world_size: int = 1, reset_every: int = 0, force_exchange: bool = False):
         assert xs.shape[0] == eps.shape[0] and xs.shape[0] >= 1
         self.eng, self.xs, self.eps = eng, xs, eps
         self.beta, self.do_curv = float(beta), bool(do_curvature_step)
@@ -29,14 +29,14 @@ class StepRunner:
         self.capture_steps = 0  # steps executed while warming up / capturing (they only touch the statistics)
         self._snapshot = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
-        self.dp = DataParallelStep(eng) if self.world > 1 else None
+        self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
         if self.gs > 0:
             if self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
             try:
                 self._capture()
             except Exception as e:  # noqa: BLE001
-                if self.world == 1:
+                if self.dp is None:
                     raise
                 # a collective that cannot be captured on this stack must not take the run down: fall back to eager
                 # launches (same arithmetic, host launch cost back on the critical path)
