@@ -229,6 +229,21 @@ class ConvEngine:
         c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
 
+    def encode_heads(self, x: Tensor) -> Tensor:
+        """conv_vae.py:57-66 + the fused head matrix: x[B,3072] -> heads[B, NH]."""
+        PV = self.param_views()
+        B, NH = x.shape[0], self.layout.heads_dim
+        a0 = Fn.linear_forward(_im2col(x, None, B, 3, 32, _nchw(32, 3)), PV["e0.weight"].view(64, 48), PV["e0.bias"],
+                               relu=True)
+        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64)), PV["e1.weight"].view(128, 1024),
+                               PV["e1.bias"], relu=True)
+        a2 = Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128)), PV["e2.weight"].view(512, 2048),
+                               PV["e2.bias"], relu=True)
+        hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
+        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
+        b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
+        return Fn.linear_forward(hflat, w_heads, b_heads)
+
     def decode(self, z: Tensor) -> Tensor:
         """[..., B, Z] -> [..., B, 3072] (conv_vae.py:68-79)."""
         PV = self.param_views()

@@ -126,9 +126,63 @@ class MnistVaeDataset(VaeDataset):
         return Fn.bce_rows(x_mb_, x_mb)
 
 
+class CifarVaeDataset(VaeDataset):
+    """image_reconstruction.py:115-143: CIFAR-10 as [N, 3072] channel-major floats in [0,1] (ToTensor + flatten), BCE
+    with soft targets, no binarisation.  Reads either layout torchvision's CIFAR10 would have left on disk
+    (`cifar-10-batches-py` pickles) or the binary release (`cifar-10-batches-bin/*.bin`: 1 label byte + 3072 pixel
+    bytes per record); without files, a synthetic U[0,1) set of the same shape.  The set stays in HBM as uint8
+    (50000 x 3072 = 154 MB)."""
+
+    def __init__(self, batch_size: int, data_folder: str, device="cuda", synthetic_train: int = 50000,
+                 synthetic_test: int = 10000) -> None:
+        super().__init__(batch_size, img_dims=(-1, 3, 32, 32), in_dim=3072)
+        self.data_folder, self.device = data_folder, torch.device(device)
+        self._n = (synthetic_train, synthetic_test)
+
+    def _read(self, train: bool) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        import pickle
+        py = os.path.join(self.data_folder, "cifar-10-batches-py")
+        names = [f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]
+        if all(os.path.isfile(os.path.join(py, n)) for n in names):
+            xs, ys = [], []
+            for n in names:
+                with open(os.path.join(py, n), "rb") as fh:
+                    d = pickle.load(fh, encoding="latin1")
+                xs.append(np.asarray(d["data"], dtype=np.uint8).reshape(-1, 3072))
+                ys.append(np.asarray(d.get("labels", d.get("fine_labels")), dtype=np.int64))
+            return np.concatenate(xs), np.concatenate(ys)
+        bn = os.path.join(self.data_folder, "cifar-10-batches-bin")
+        names = [f"data_batch_{i}.bin" for i in range(1, 6)] if train else ["test_batch.bin"]
+        if all(os.path.isfile(os.path.join(bn, n)) for n in names):
+            rec = np.concatenate([np.fromfile(os.path.join(bn, n), dtype=np.uint8) for n in names]).reshape(-1, 3073)
+            return rec[:, 1:].copy(), rec[:, 0].astype(np.int64)
+        return None
+
+    def _load(self, train: bool) -> Tuple[Tensor, Tensor]:
+        got = self._read(train)
+        if got is not None:
+            return torch.from_numpy(got[0]).to(self.device), torch.from_numpy(got[1]).to(self.device)
+        n = self._n[0] if train else self._n[1]
+        print(f"CIFAR-10 files not found under '{self.data_folder}': using {n} synthetic U[0,1) images.")
+        g = torch.Generator().manual_seed(21 if train else 23)
+        x = torch.randint(0, 256, (n, 3072), generator=g, dtype=torch.uint8)
+        return x.to(self.device), torch.zeros(n, dtype=torch.int64, device=self.device)
+
+    def create_loaders(self, seed: Optional[int] = None):
+        tr_x, tr_y = self._load(True)
+        te_x, te_y = self._load(False)
+        return (DeviceLoader(tr_x, tr_y, self.batch_size, True, False, seed),
+                DeviceLoader(te_x, te_y, self.batch_size, False, False, seed))
+
+    def reconstruction_loss(self, x_mb_: Tensor, x_mb: Tensor) -> Tensor:
+        return Fn.bce_rows(x_mb_, x_mb)  # per-row sums, see MnistVaeDataset.reconstruction_loss
+
+
 def create_dataset(dataset_type: str, *args, **kwargs) -> VaeDataset:  # mt/data/__init__.py:32-42
     if dataset_type == "mnist":
         return MnistVaeDataset(*args, **kwargs)
-    if dataset_type in ("bdp", "omniglot", "cifar"):
+    if dataset_type == "cifar":
+        return CifarVaeDataset(*args, **kwargs)
+    if dataset_type in ("bdp", "omniglot"):
         raise NotImplementedError(f"dataset '{dataset_type}' is not part of the MI355X hot-path build yet")
     raise ValueError(f"Unknown dataset type: '{dataset_type}'.")

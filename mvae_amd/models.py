@@ -295,5 +295,22 @@ class ConvolutionalVAE(ModelVAE):
     def decode(self, concat_z: Tensor) -> Tensor:
         return self._need_engine().decode(concat_z)
 
-    def log_likelihood(self, x: Tensor, n: int = 500, eps: Optional[Tensor] = None):
-        raise NotImplementedError("log_likelihood on the conv architecture is not built yet")
+    def log_likelihood(self, x: Tensor, n: int = 500, eps: Optional[Tensor] = None, max_rows: int = 4096):
+        """vae.py:82-123 on the conv architecture.  The decoder's patch matrices are 4096 floats per 8x8 position, so
+        the n samples are decoded in chunks of at most `max_rows` (sample, image) rows; only the per-row BCE survives
+        a chunk (x.repeat((n,1,1)) is never materialised)."""
+        eng = self._need_engine()
+        x = x.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        eps = self._eps(n, B) if eps is None else eps
+        heads = eng.encode_heads(x)
+        co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=False, want_log_probs=True)
+        concat_z = co["z"]  # [n, B, Z]
+        step = max(1, max_rows // B)
+        bce = torch.cat([Fn.bce_rows(eng.decode(concat_z[i:i + step]), x) for i in range(0, n, step)], dim=0)  # [n, B]
+        log_p_x, mi = Fn.loglik_reduce(bce, co["log_p"].sum(dim=0), co["log_q"].sum(dim=0))
+        zc = (concat_z - concat_z.mean(dim=1, keepdim=True)).mean(dim=0)
+        xc = x - x.mean(dim=0, keepdim=True)
+        cov, _, _ = Fn.linear_backward(xc, torch.zeros(zc.shape[1], xc.shape[1], device=self.device), zc,
+                                       need_dx=False)
+        return log_p_x, mi, cov.norm()

@@ -475,6 +475,17 @@ def gen_loglik():
             out[key + "log_px"] = npy(log_px)
             out[key + "mi"] = npy(mi)
             out[key + "cov_norm"] = npy(cov_norm)
+        # conv architecture (CIFAR shapes, soft targets in [0,1])
+        B, n = 4, 4
+        model, state0 = _build_reference_model("h2,s2,e2", "conv", 3072, 8192, B, False, False, 2.0, dtype)
+        x = synthetic.uniform_batches(1, B, 3072, dtype=dtype)[0]
+        ref_shim.reseed_eps(2100)
+        with torch.no_grad():
+            log_px, mi, cov_norm = model.log_likelihood(x, n=n)
+        key = f"conv_h2s2e2/{dname}/"
+        out[key + "x"] = npy(x)
+        out[key + "eps"] = npy(torch.cat(list(ref_shim.eps_log), dim=-1))
+        out[key + "log_px"], out[key + "mi"], out[key + "cov_norm"] = npy(log_px), npy(mi), npy(cov_norm)
     np.savez_compressed(os.path.join(HERE, "g4_loglik.npz"), **out)
     print("g4_loglik:", len(out), "arrays")
 

@@ -106,3 +106,26 @@ def test_conv_step_full_batch_vs_oracle(dev):
     for n, t in eng.grad_views().items():
         if orc.P[n].grad is not None:
             assert_close(_cpu(t), orc.P[n].grad.numpy(), 2 * RTOL, "grad " + n, atol_frac=2e-4)
+
+
+def test_conv_log_likelihood_vs_golden(dev):
+    """ModelVAE.log_likelihood (vae.py:82-123) on the conv architecture against the reference's own output (g4), with
+    the decoder run in chunks of samples (max_rows smaller than n*B) and in one piece."""
+    from mvae_amd import synthetic, utils
+    from mvae_amd.data import VaeDataset
+    from mvae_amd.models import ConvolutionalVAE
+    from oracle import model as M
+    g = load_npz("g4_loglik.npz")
+    key = "conv_h2s2e2/f32/"
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    model = ConvolutionalVAE(8192, utils.parse_components("h2,s2,e2", False), VaeDataset(4, 3072, (3, 32, 32)),
+                             False).to(dev)
+    model.engine.load_state(state0)
+    x = torch.from_numpy(g[key + "x"]).to(dev)
+    eps = torch.from_numpy(g[key + "eps"]).to(dev)
+    for max_rows in (8, 4096):
+        lp, mi, cn = model.log_likelihood(x, n=eps.shape[0], eps=eps, max_rows=max_rows)
+        assert_close(_cpu(lp), g[key + "log_px"], 2 * RTOL, "log_px")
+        assert_close(_cpu(mi), g[key + "mi"], 2 * RTOL, "mi", atol_frac=1e-3)
+        assert_close(float(cn), float(g[key + "cov_norm"]), 2 * RTOL, "cov_norm")

@@ -112,3 +112,23 @@ def test_cli_flags_match_reference():
     assert run.str2bool("True") is True and run.str2bool("false") is False
     with pytest.raises(argparse.ArgumentTypeError):
         run.str2bool("maybe")
+
+
+def test_cifar_readers(tmp_path):
+    """Both on-disk layouts of CIFAR-10 decode to the same [N,3072] uint8 matrix and labels."""
+    import pickle
+    from mvae_amd.data import CifarVaeDataset
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 256, size=(7, 3072), dtype=np.uint8)
+    labels = rng.integers(0, 10, size=7)
+    py = tmp_path / "a" / "cifar-10-batches-py"
+    py.mkdir(parents=True)
+    with open(py / "test_batch", "wb") as fh:
+        pickle.dump({"data": data, "labels": labels.tolist()}, fh)
+    bn = tmp_path / "b" / "cifar-10-batches-bin"
+    bn.mkdir(parents=True)
+    np.concatenate([labels.astype(np.uint8)[:, None], data], axis=1).tofile(bn / "test_batch.bin")
+    for sub in ("a", "b"):
+        x, y = CifarVaeDataset(4, str(tmp_path / sub), device="cpu")._read(train=False)
+        assert np.array_equal(x, data) and np.array_equal(y, labels)
+    assert CifarVaeDataset(4, str(tmp_path / "none"), device="cpu")._read(train=True) is None

@@ -269,6 +269,21 @@ def test_log_likelihood(name, model, dname):
     assert_close(float(cn), float(g[key + "cov_norm"]), rt, "cov_norm")
 
 
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+def test_log_likelihood_conv(dname):
+    g = load_npz("g4_loglik.npz")
+    dt = DT[dname]
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    P = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, dtype=dt, transposed_conv=("d1", "d2", "d3"))
+    key = f"conv_h2s2e2/{dname}/"
+    with torch.no_grad():
+        lp, mi, cn = M.log_likelihood(spec, P, T(g[key + "x"], dt), T(g[key + "eps"], dt))
+    rt = 2e-4 if dname == "f32" else 1e-9
+    assert_close(lp.numpy(), g[key + "log_px"], rt, "log_px")
+    assert_close(mi.numpy(), g[key + "mi"], rt, "mi", atol_frac=1e-3 if dname == "f32" else None)
+    assert_close(float(cn), float(g[key + "cov_norm"]), rt, "cov_norm")
+
+
 # ------------------------------------------------------------------------------------------------ G5 parser
 def test_parser_table():
     tab = load_json("g5_parser.json")
