@@ -192,11 +192,12 @@ __device__ __forceinline__ void comp_fwd_row(const mvae_component_desc& c, const
   }
 }
 
-// d(loss)/d(input direction `dir`) for one (row, component): loss = <dz, z> + dkl * kl
+// Derivative of one (row, component) along input direction `dir` (0..d-1: mean head, d..d+lvd-1: logvar head,
+// d+lvd: radius / curvature): zd[i] = d z_i / d dir, returns d kl / d dir.  Needs no upstream gradient, so the latent
+// backward kernel runs it while dz is still being reduced.
 template <int DMAX>
-__device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, const float* heads_row,
-                                              const float* eps_row, const float* radii, const float* dz_row, float dkl,
-                                              int dir) {
+__device__ __forceinline__ float comp_dual_dir(const mvae_component_desc& c, const float* heads_row,
+                                               const float* eps_row, const float* radii, int dir, float* zd) {
   MV_BOUNDS(DMAX + 1);
   Dual m[kN], l[kN], z[kN];
   float e[kN];
@@ -210,8 +211,21 @@ __device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, cons
   Dual kl;
   comp_eval<DMAX, Dual>(c.kind, m, l, lvd, e, d, rp, z, &kl, nullptr, nullptr, nullptr, nullptr);
   const int A = ambient_dim(c.kind, d);
-  float g = dkl * kl.d;
-  MV_FOR(i, 0, A) g += dz_row[c.z_col + i] * z[i].d;
+  MV_FOR(i, 0, A) zd[i] = z[i].d;
+  return kl.d;
+}
+
+// d(loss)/d(input direction `dir`) for one (row, component): loss = <dz, z> + dkl * kl
+template <int DMAX>
+__device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, const float* heads_row,
+                                              const float* eps_row, const float* radii, const float* dz_row, float dkl,
+                                              int dir) {
+  MV_BOUNDS(DMAX + 1);
+  float zd[kN];
+  const float kld = comp_dual_dir<DMAX>(c, heads_row, eps_row, radii, dir, zd);
+  const int A = ambient_dim(c.kind, c.true_dim);
+  float g = dkl * kld;
+  MV_FOR(i, 0, A) g += dz_row[c.z_col + i] * zd[i];
   return g;
 }
 
@@ -1369,7 +1383,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   float* heads_s = part + 256;
   float* eps_s = heads_s + ((NH + 3) & ~3);
 
-  // ---- request everything
+  // ---- request everything; the row's own operands (written by the previous launch) first: loads retire in order,
+  // so what is needed first must be asked for first
   int ZP = 1, zsh = 0;  // ZP = next power of two >= Z: the (slice, j) split of the thread index is shifts and masks
   while (ZP < Z) {
     ZP <<= 1;
@@ -1377,80 +1392,137 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   }
   const int nsl = 256 >> zsh;
   const int zj = tid & (ZP - 1), sl = tid >> zsh;
-  float wz[16];   // FAST: this thread's W_d0 column slice (H/nsl <= 16 entries)
+  float dhd_r[2] = {0.f, 0.f};  // FAST: H <= 512
+  float wz[16];     // FAST: this thread's W_d0 column slice (H/nsl <= 16 entries)
   float wh[2][16];  // FAST: W_heads[:, c] for the two columns c of this thread
   float hm[2] = {0.f, 0.f};
+  // Branch-free requests (an index past the end is clamped to a valid address, the value zeroed afterwards): every
+  // `if (cond) load` costs an exec-mask branch and, worse, lets the compiler put a full `s_waitcnt vmcnt(0)` inside
+  // it -- the guarded version of this prologue spent ~3 us in serialized round trips.  32-bit unsigned offsets keep
+  // the addresses in the scalar-base + vector-offset form.
+  const unsigned rowH = (unsigned)row * (unsigned)H;
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      const float v = dhd[rowH + (unsigned)(c < H ? c : 0)];
+      dhd_r[u] = c < H ? v : 0.f;
+    }
+  }
+  float head_r = heads[(unsigned)row * (unsigned)ldh + (unsigned)(tid < NH ? tid : 0)];
+  float eps_r = eps[(unsigned)row * (unsigned)eps_ld + (unsigned)(tid < eps_ld ? tid : 0)];
+  // the component table (kernarg segment, indexed per lane) and the radii: tiny, but a wait on the LAST load issued
+  // is a wait on every load before it, so they go ahead of the bulk weight requests
+  const int tci = tid < t.n ? tid : 0;
+  const float rad_r = radii[tci];
+  const mvae_component_desc desc_r = t.c[tci];
+  const int ndir_r = t.dir_off[tci + 1] - t.dir_off[tci];
+  const int wave_r = t.wave_of[tci], lane_r = t.lane_of[tci];
+  __builtin_amdgcn_sched_barrier(0);  // keep the requests above ahead of the bulk below
   if (FAST) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int c = sl + q * nsl;
-      wz[q] = (zj < Z && c < H) ? Wd0[(size_t)c * Z + zj] : 0.f;
+      const bool ok = zj < Z && c < H;
+      const float v = Wd0[ok ? (unsigned)(c * Z + zj) : 0u];
+      wz[q] = ok ? v : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = tid + 256 * u;
-      if (c < H) {
-        hm[u] = h[row * H + c];
+      const unsigned cc = (unsigned)(c < H ? c : 0);
+      const float hv = h[rowH + cc];
+      hm[u] = c < H ? hv : 0.f;
+      // rows n >= NH re-read row 0 and are multiplied by dheads_s[n] = 0 below: selecting on the (uniform) n < NH
+      // here would turn every load into a scalar branch with its own wait
 #pragma unroll
-        for (int n = 0; n < 16; ++n) wh[u][n] = (n < NH) ? Wh[(size_t)n * H + c] : 0.f;
-      }
+      for (int n = 0; n < 16; ++n) wh[u][n] = Wh[(unsigned)(n < NH ? n : 0) * (unsigned)H + cc];
     }
   }
-  for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
   comp_at_s[tid >> 6][tid & 63] = -1;
   lds_barrier();
   if (tid < t.n) {
-    rad_s[tid] = radii[tid];
-    desc_s[tid] = t.c[tid];
-    ndir_s[tid] = t.dir_off[tid + 1] - t.dir_off[tid];
-    comp_at_s[t.wave_of[tid]][t.lane_of[tid]] = (signed char)tid;
+    rad_s[tid] = rad_r;
+    desc_s[tid] = desc_r;
+    ndir_s[tid] = ndir_r;
+    comp_at_s[wave_r][lane_r] = (signed char)tid;
   }
-  if (tid < NH) heads_s[tid] = heads[row * ldh + tid];
-  if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
+  if (tid < NH) heads_s[tid] = head_r;
+  if (tid < eps_ld) eps_s[tid] = eps_r;
+  if (FAST) {
+    if (tid < 16) dheads_s[tid] = 0.f;  // entries [NH, 16) stay zero (see the W_heads requests above)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) dhd_s[c] = dhd_r[u];
+    }
+  } else {
+    for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
+  }
   lds_barrier();
   MV_STAMP(9);
 
-  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c, slices meet in LDS
+  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c; the slices are added
+  // by wave 3 in slice order while the component lanes are already evaluating their duals (which need no dz)
   {
     float p = 0.f;
     if (FAST) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 16; ++q) {  // wz[q] = 0 past the end: no guard
         const int c = sl + q * nsl;
-        if (c < H) p = fmaf(dhd_s[c], wz[q], p);
+        p = fmaf(dhd_s[c < H ? c : 0], wz[q], p);
       }
     } else if (zj < Z) {
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
     part[tid] = p;
     lds_barrier();
-    // two short stages instead of one nsl-long dependent chain of LDS reads
-    const int nq = nsl >= 4 ? 4 : 1, per = nsl / nq;
-    float sum = 0.f;
-    if (tid < nq * ZP) {
-      const int qq = tid >> zsh, jj = tid & (ZP - 1);
-      for (int q = 0; q < per; ++q) sum += part[(qq * per + q) * ZP + jj];
+    if (wave == 3) {
+      for (int j = lane; j < Z; j += 64) {
+        float tot = 0.f;
+        for (int q = 0; q < nsl; ++q) tot += part[q * ZP + j];
+        dz_s[j] = tot;
+      }
     }
-    lds_barrier();
-    if (tid < nq * ZP) part[tid] = sum;
-    lds_barrier();
-    if (tid < Z) {
-      float tot = 0.f;
-      for (int q = 0; q < nq; ++q) tot += part[q * ZP + tid];
-      dz_s[tid] = tot;
-    }
-    lds_barrier();
   }
   MV_STAMP(10);
   // ---- component backward (forward-mode duals): the wave's components (all of one manifold kind) are flattened into
   // (component, input direction) items, one lane per item, 64 items per pass
-  {
-    int total = 0;
-    for (int sidx = 0; sidx < kMaxComp; ++sidx) {
-      const int ci = comp_at_s[wave][sidx];
-      if (ci < 0) break;
-      total += ndir_s[ci];
+  int total = 0;
+  for (int sidx = 0; sidx < kMaxComp; ++sidx) {
+    const int ci = comp_at_s[wave][sidx];
+    if (ci < 0) break;
+    total += ndir_s[ci];
+  }
+  if (FAST) {  // <= 64 items per wave: duals first, the contraction with dz after the barrier that publishes dz
+    constexpr int AM = DMAX + 1;
+    float zd[AM];
+    float kld = 0.f;
+    int my_ci = -1, my_dir = 0;
+    if (lane < total) {
+      int rem = lane, ci = comp_at_s[wave][0], sidx = 0;
+      while (rem >= ndir_s[ci]) {
+        rem -= ndir_s[ci];
+        ci = comp_at_s[wave][++sidx];
+      }
+      my_ci = ci;
+      my_dir = rem;
+      kld = comp_dual_dir<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, rem, zd);
     }
+    lds_barrier();
+    if (my_ci >= 0) {
+      const mvae_component_desc& c = desc_s[my_ci];
+      const int A = ambient_dim(c.kind, c.true_dim);
+      float gv = beta * kld;
+#pragma unroll
+      for (int i = 0; i < AM; ++i)
+        if (i < A) gv += dz_s[c.z_col + i] * zd[i];
+      if (my_dir < c.true_dim) dheads_s[c.mean_col + my_dir] = gv;
+      else if (my_dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (my_dir - c.true_dim)] = gv;
+      else drpart[(size_t)my_ci * B + row] = gv;
+    }
+  } else {
+    lds_barrier();
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
       if (item < total) {
@@ -1479,8 +1551,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       if (c < H) {
         float acc = 0.f;
 #pragma unroll
-        for (int n = 0; n < 16; ++n)
-          if (n < NH) acc = fmaf(dheads_s[n], wh[u][n], acc);
+        for (int n = 0; n < 16; ++n) acc = fmaf(dheads_s[n], wh[u][n], acc);
         dh[row * H + c] = (hm[u] > 0.f) ? acc : 0.f;
       }
     }
