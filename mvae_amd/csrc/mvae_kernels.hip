@@ -72,6 +72,7 @@ struct CompTable {
   int total_dirs;
   mvae_component_desc c[kMaxComp];
   int dir_off[kMaxComp + 1];  // prefix sum of derivative directions per component (d + logvar_dim + trainable radius)
+  short first_dir[kMaxComp];  // the same prefix with EVERY radius direction counted: record index in the dual workspace
   unsigned char trainable[kMaxComp];  // bit 0: trainable radius/curvature, bit 1: in the gradient-clip group (`u`)
   // Placement of the components on the 4 waves of a latent workgroup: components of the same manifold kind share a
   // wave (one instruction stream, no divergence), different kinds run on different waves.
@@ -93,7 +94,7 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
   if (!comps || ncomp < 1 || ncomp > kMaxComp) return fail(MVAE_E_BADARG, "ncomp out of range%s (%lld)", "", ncomp);
   memset(t, 0, sizeof(*t));
   t->n = ncomp;
-  int dmax = 0, off = 0;
+  int dmax = 0, off = 0, first = 0;
   for (int i = 0; i < ncomp; ++i) {
     const mvae_component_desc& c = comps[i];
     if (c.kind < 0 || c.kind >= kNumKinds) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", c.kind);
@@ -108,6 +109,8 @@ static int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
                           : 0;
     t->dir_off[i] = off;
     off += c.true_dim + c.logvar_dim + (t->trainable[i] ? 1 : 0);
+    t->first_dir[i] = (short)first;
+    first += c.true_dim + c.logvar_dim + 1;
     if (c.true_dim > dmax) dmax = c.true_dim;
   }
   t->dir_off[ncomp] = off;
@@ -681,14 +684,17 @@ struct mvae_ctx {
   int ldh;    // heads row stride (NH rounded up to 4)
   int ldz;    // z row stride
   // workspace carve (floats)
-  int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_total;
+  int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_total;
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
 };
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 static inline int64_t up64(int64_t x) { return (x + 63) & ~(int64_t)63; }
 
-static void carve(mvae_ctx* c) {
+// floats per (row, component, input direction) record of the dual workspace: {d kl, d z_0 .. d z_{A-1}}, A <= dmax + 1
+static inline int dual_stride(int dmax_bucket) { return dmax_bucket + 2; }
+
+static void carve(mvae_ctx* c, int dmax_bucket) {
   const mvae_model_desc& d = c->d;
   const int64_t B = d.batch, H = d.h_dim, D = d.in_dim;
   c->ldh = (int)up4(d.heads_dim);
@@ -710,6 +716,9 @@ static void carve(mvae_ctx* c) {
   c->o_dheads = take(B * c->ldh);
   c->o_dh = take(B * H);
   c->o_drpart = take(B * kMaxComp);  // [comp][B]
+  // [B][heads_dim + ncomp][dual_stride]: every input direction of every component (radius directions included
+  // whether or not they are trainable right now)
+  c->o_duals = take(B * ((int64_t)d.heads_dim + d.ncomp) * dual_stride(dmax_bucket));
   c->o_total = o;
 }
 
@@ -717,7 +726,12 @@ extern "C" int64_t mvae_workspace_floats(const mvae_model_desc* desc) {
   if (!desc) return -1;
   mvae_ctx tmp;
   tmp.d = *desc;
-  carve(&tmp);
+  int dmax = MVAE_MAX_TRUE_DIM;
+  if (desc->comps && desc->ncomp >= 1 && desc->ncomp <= kMaxComp) {
+    dmax = 1;
+    for (int i = 0; i < desc->ncomp; ++i) dmax = desc->comps[i].true_dim > dmax ? desc->comps[i].true_dim : dmax;
+  }
+  carve(&tmp, bucket_of(dmax));
   return tmp.o_total;
 }
 
@@ -764,7 +778,7 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   }
   c->d.comps = nullptr;
   c->d.radius_trainable = nullptr;
-  carve(c);
+  carve(c, bucket_of(c->dmax));
   *out = c;
   return 0;
 }
@@ -969,8 +983,8 @@ __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/,
 // the fabric 8 times.  Column tiles (= weight row-blocks) are therefore dealt to XCDs: XCD k owns nt = k, k+8, ... and
 // runs every row tile mt of those; the activation rows are the only operand every XCD fetches.  Placement only
 // changes speed, never results.  Launch with grid = 8 * ceil(NT/8) * MT; returns false for the padding workgroups.
-__device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt) {
-  const int L = blockIdx.x, k = L & 7, s = L >> 3;
+__device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L = blockIdx.x) {
+  const int k = L & 7, s = L >> 3;
   *nt = k + 8 * (s / MT);
   *mt = s % MT;
   return *nt < NT;
@@ -1035,23 +1049,67 @@ __device__ __forceinline__ float wave_sum(float v) {
 // instructions of the kernel (one memory round trip), and the small reductions are wavefront shuffles.
 // FAST: NH <= 16, Z <= 8, H <= 512 (operands of all phases are held in registers from the start).
 template <int DMAX, bool FAST>
-__global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h, const float* Wh, const float* bh,
+__global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h, const float* Wh, const float* bh,
                                                     const float* eps, int eps_ld, const float* radii, const float* Wd0,
                                                     const float* bd0, float* heads, int ldh, float* z, int ldz,
                                                     float* z_user, float* kl, float* kl_user, float* hd, int B, int H,
-                                                    int NH, int Z) {
+                                                    int NH, int Z, float* duals) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] the row of h, then [eps_dim] the row of eps
   __shared__ __attribute__((aligned(16))) float heads_s[kHeadsMax];
   __shared__ __attribute__((aligned(16))) float z_s[kHeadsMax];
   __shared__ mvae_component_desc desc_s[kMaxComp];  // per-lane indexed below: LDS, not the kernarg segment
   __shared__ float rad_s[kMaxComp];
   __shared__ signed char comp_at_s[4][kMaxComp];  // [wave][lane] -> component (or -1)
+  __shared__ int ndir_s[kMaxComp];   // active input directions of component i (radius included iff trainable)
+  __shared__ int first_s[kMaxComp];  // first record of component i inside a row of `duals`
+  __shared__ int done_s;             // main waves that have finished their primal components
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t row = blockIdx.x;
   float* h_s = dyn;
   float* eps_s = dyn + ((H + 3) & ~3);
   const bool vec = aligned16(Wh) && (H & 3) == 0;
   MV_STAMP(0);
+
+  // ---- dual waves (threads 256..511, launched iff duals != NULL).  Forward-mode derivatives need no upstream
+  // gradient: d z / d(direction) and d kl / d(direction) of every (component, input direction) of this row depend only
+  // on the head outputs, eps and the radii.  The ~500-instruction dependent dual chain (3.5 us for a lone lane)
+  // therefore runs HERE, on waves 4..7, next to the primal lanes of waves 0..3 (wave 4+w takes the components placed
+  // on wave w), instead of on the critical path of launch 5, which only contracts the stored records with dz.
+  // Record layout: duals[row][first_dir(ci) + dir][{d kl, d z_0 .. d z_{A-1}}].
+  if (tid >= 256) {
+    lds_barrier();  // the four barriers of the main path up to "heads_s final"
+    lds_barrier();
+    lds_barrier();
+    lds_barrier();
+    const int w = wave - 4;
+    int total = 0;
+    for (int sidx = 0; sidx < kMaxComp; ++sidx) {
+      const int ci = comp_at_s[w][sidx];
+      if (ci < 0) break;
+      total += ndir_s[ci];
+    }
+    constexpr int AM = DMAX + 1, DS = DMAX + 2;
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      if (item < total) {
+        int rem = item, ci = comp_at_s[w][0], sidx = 0;
+        while (rem >= ndir_s[ci]) {
+          rem -= ndir_s[ci];
+          ci = comp_at_s[w][++sidx];
+        }
+        const mvae_component_desc& c = desc_s[ci];
+        float zd[AM];
+        const float kld = comp_dual_dir<DMAX>(c, heads_s, eps_s, rad_s, rem, zd);
+        float* rec = duals + ((size_t)row * (NH + t.n) + first_s[ci] + rem) * DS;
+        const int A = ambient_dim(c.kind, c.true_dim);
+        rec[0] = kld;
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+          if (i < A) rec[1 + i] = zd[i];
+      }
+    }
+    return;  // terminated waves do not count at the remaining barriers
+  }
 
   // ---- request everything
   float hv[2] = {0.f, 0.f};
@@ -1102,10 +1160,13 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
   }
   if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
   comp_at_s[tid >> 6][tid & 63] = -1;
+  if (tid == 0) done_s = 0;
   lds_barrier();
   if (tid < t.n) {  // staged last so that its wait does not delay the issue of the loads above
     desc_s[tid] = t.c[tid];
     rad_s[tid] = radii[tid];
+    ndir_s[tid] = t.dir_off[tid + 1] - t.dir_off[tid];
+    first_s[tid] = t.first_dir[tid];
     comp_at_s[t.wave_of[tid]][t.lane_of[tid]] = (signed char)tid;
   }
   if (!FAST)
@@ -1188,7 +1249,12 @@ __global__ __launch_bounds__(256) void k_latent_fwd(CompTable t, const float* h,
       if (kl_user) kl_user[(size_t)ci * B + row] = klv;
     }
   }
-  lds_barrier();
+  // The four main waves meet on an LDS counter, not on s_barrier: a hardware barrier would also wait for the dual
+  // waves, which are still in the middle of their (longer) chains.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(&done_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&done_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   MV_STAMP(3);
   if (z_user && tid < Z) z_user[row * Z + tid] = z_s[tid];
 
@@ -1228,9 +1294,9 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   if (!xcd_tile((D + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
   const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
   const bool ok = threadIdx.x < 256 && m < B && n < D;
-  float t = 0.f, bias = 0.f;
+  float tv = 0.f, bias = 0.f;
   if (ok) {  // epilogue operands requested up front
-    t = x[(size_t)m * D + n];
+    tv = x[(size_t)m * D + n];
     bias = b[n];
   }
   const bool v1 = aligned16(hd) && (H & 3) == 0, v2 = aligned16(W) && (H & 3) == 0;
@@ -1244,9 +1310,9 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
     // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
     const float e = expf(-fabsf(y));
     const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
-    loss = (1.f - t) * y - log_sig;
+    loss = (1.f - tv) * y - log_sig;
     const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
-    g[(size_t)m * D + n] = sig - t;  // d(sum bce)/d(logit)
+    g[(size_t)m * D + n] = sig - tv;  // d(sum bce)/d(logit)
     if (logits_user) logits_user[(size_t)m * D + n] = y;
   }
   // sum over the tile's 16 columns: the 16 lanes of one row are contiguous
@@ -1356,16 +1422,15 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
                                                     const float* h, const float* Wh, float* dheads, float* dh,
                                                     float* drpart, const float* g, const float* hd, float* dWl,
                                                     float beta, int B, int H, int D, int NH, int Z, int n_rows,
-                                                    AdamArgs awl) {
+                                                    AdamArgs awl, const float* duals) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [256] partials | [NH] heads | [eps]
   __shared__ float red[4][16][17];
   __shared__ float sh2[2];
   __shared__ float dz_s[kHeadsMax];
   __shared__ float dheads_s[kHeadsMax];
-  __shared__ float rad_s[kMaxComp];
-  __shared__ signed char comp_at_s[4][kMaxComp];  // [wave][slot] -> component (or -1), slots in lane_of order
   __shared__ mvae_component_desc desc_s[kMaxComp];
-  __shared__ int ndir_s[kMaxComp];
+  __shared__ int doff_s[kMaxComp + 1];  // prefix of the ACTIVE input directions (radius included iff trainable)
+  __shared__ int first_s[kMaxComp + 1];  // first record of component i inside a row of `duals`
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (b >= n_rows) {  // dW_logits[D,H] tile
@@ -1380,8 +1445,6 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   const int H4 = (H + 3) & ~3;
   float* dhd_s = dyn;
   float* part = dyn + H4;
-  float* heads_s = part + 256;
-  float* eps_s = heads_s + ((NH + 3) & ~3);
 
   // ---- request everything; the row's own operands (written by the previous launch) first: loads retire in order,
   // so what is needed first must be asked for first
@@ -1409,15 +1472,12 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       dhd_r[u] = c < H ? v : 0.f;
     }
   }
-  float head_r = heads[(unsigned)row * (unsigned)ldh + (unsigned)(tid < NH ? tid : 0)];
-  float eps_r = eps[(unsigned)row * (unsigned)eps_ld + (unsigned)(tid < eps_ld ? tid : 0)];
-  // the component table (kernarg segment, indexed per lane) and the radii: tiny, but a wait on the LAST load issued
-  // is a wait on every load before it, so they go ahead of the bulk weight requests
-  const int tci = tid < t.n ? tid : 0;
-  const float rad_r = radii[tci];
-  const mvae_component_desc desc_r = t.c[tci];
-  const int ndir_r = t.dir_off[tci + 1] - t.dir_off[tci];
-  const int wave_r = t.wave_of[tci], lane_r = t.lane_of[tci];
+  // the component table (kernarg segment, indexed per lane): tiny, but a wait on the LAST load issued is a wait on
+  // every load before it, so it goes ahead of the bulk weight requests
+  const int tci = tid <= t.n ? tid : 0;
+  const mvae_component_desc desc_r = t.c[tci < t.n ? tci : 0];
+  const int doff_r = t.dir_off[tci];
+  const int first_r = t.first_dir[tci < t.n ? tci : 0];
   __builtin_amdgcn_sched_barrier(0);  // keep the requests above ahead of the bulk below
   if (FAST) {
 #pragma unroll
@@ -1439,16 +1499,11 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       for (int n = 0; n < 16; ++n) wh[u][n] = Wh[(unsigned)(n < NH ? n : 0) * (unsigned)H + cc];
     }
   }
-  comp_at_s[tid >> 6][tid & 63] = -1;
-  lds_barrier();
-  if (tid < t.n) {
-    rad_s[tid] = rad_r;
-    desc_s[tid] = desc_r;
-    ndir_s[tid] = ndir_r;
-    comp_at_s[wave_r][lane_r] = (signed char)tid;
+  if (tid <= t.n) {
+    if (tid < t.n) desc_s[tid] = desc_r;
+    doff_s[tid] = doff_r;
+    first_s[tid] = first_r;
   }
-  if (tid < NH) heads_s[tid] = head_r;
-  if (tid < eps_ld) eps_s[tid] = eps_r;
   if (FAST) {
     if (tid < 16) dheads_s[tid] = 0.f;  // entries [NH, 16) stay zero (see the W_heads requests above)
 #pragma unroll
@@ -1462,8 +1517,24 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   lds_barrier();
   MV_STAMP(9);
 
-  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c; the slices are added
-  // by wave 3 in slice order while the component lanes are already evaluating their duals (which need no dz)
+  // ---- this thread's dual record (written by launch 3): thread k owns the k-th active direction of the row; the
+  // request is in flight while dz is reduced
+  constexpr int DS = DMAX + 2;
+  const int total = doff_s[t.n];
+  const size_t rec0 = (size_t)row * (NH + t.n);
+  float du[DS];
+  int my_ci = 0, my_dir = 0;
+  if (FAST) {  // <= 24 active directions: at most one item per thread
+    const int gi = tid < total ? tid : 0;
+    while (gi >= doff_s[my_ci + 1]) ++my_ci;
+    my_dir = gi - doff_s[my_ci];
+    const float* rec = duals + (rec0 + first_s[my_ci] + my_dir) * DS;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) du[i] = rec[i];
+  }
+
+  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c; wave 3 adds the slices
+  // in slice order
   {
     float p = 0.f;
     if (FAST) {
@@ -1484,61 +1555,28 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
         dz_s[j] = tot;
       }
     }
+    lds_barrier();
   }
   MV_STAMP(10);
-  // ---- component backward (forward-mode duals): the wave's components (all of one manifold kind) are flattened into
-  // (component, input direction) items, one lane per item, 64 items per pass
-  int total = 0;
-  for (int sidx = 0; sidx < kMaxComp; ++sidx) {
-    const int ci = comp_at_s[wave][sidx];
-    if (ci < 0) break;
-    total += ndir_s[ci];
-  }
-  if (FAST) {  // <= 64 items per wave: duals first, the contraction with dz after the barrier that publishes dz
-    constexpr int AM = DMAX + 1;
-    float zd[AM];
-    float kld = 0.f;
-    int my_ci = -1, my_dir = 0;
-    if (lane < total) {
-      int rem = lane, ci = comp_at_s[wave][0], sidx = 0;
-      while (rem >= ndir_s[ci]) {
-        rem -= ndir_s[ci];
-        ci = comp_at_s[wave][++sidx];
-      }
-      my_ci = ci;
-      my_dir = rem;
-      kld = comp_dual_dir<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, rem, zd);
-    }
-    lds_barrier();
-    if (my_ci >= 0) {
-      const mvae_component_desc& c = desc_s[my_ci];
-      const int A = ambient_dim(c.kind, c.true_dim);
-      float gv = beta * kld;
+  // ---- d(loss)/d(direction) = beta * d kl + <dz, d z>: one record per (component, input direction)
+  for (int gi = tid; gi < total; gi += 256) {
+    if (!FAST) {
+      my_ci = 0;
+      while (gi >= doff_s[my_ci + 1]) ++my_ci;
+      my_dir = gi - doff_s[my_ci];
+      const float* rec = duals + (rec0 + first_s[my_ci] + my_dir) * DS;
 #pragma unroll
-      for (int i = 0; i < AM; ++i)
-        if (i < A) gv += dz_s[c.z_col + i] * zd[i];
-      if (my_dir < c.true_dim) dheads_s[c.mean_col + my_dir] = gv;
-      else if (my_dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (my_dir - c.true_dim)] = gv;
-      else drpart[(size_t)my_ci * B + row] = gv;
+      for (int i = 0; i < DS; ++i) du[i] = rec[i];
     }
-  } else {
-    lds_barrier();
-    for (int base = 0; base < total; base += 64) {
-      const int item = base + lane;
-      if (item < total) {
-        int rem = item, ci = comp_at_s[wave][0], sidx = 0;
-        while (rem >= ndir_s[ci]) {
-          rem -= ndir_s[ci];
-          ci = comp_at_s[wave][++sidx];
-        }
-        const mvae_component_desc& c = desc_s[ci];
-        const int dir = rem;
-        const float gv = comp_bwd_dir<DMAX>(c, heads_s, eps_s, rad_s, dz_s, beta, dir);
-        if (dir < c.true_dim) dheads_s[c.mean_col + dir] = gv;
-        else if (dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (dir - c.true_dim)] = gv;
-        else drpart[(size_t)ci * B + row] = gv;
-      }
-    }
+    const mvae_component_desc& c = desc_s[my_ci];
+    const int A = ambient_dim(c.kind, c.true_dim);
+    float gv = beta * du[0];
+#pragma unroll
+    for (int i = 0; i < DMAX + 1; ++i)
+      if (i < A) gv += dz_s[c.z_col + i] * du[1 + i];
+    if (my_dir < c.true_dim) dheads_s[c.mean_col + my_dir] = gv;
+    else if (my_dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (my_dir - c.true_dim)] = gv;
+    else drpart[(size_t)my_ci * B + row] = gv;
   }
   lds_barrier();
   MV_STAMP(11);
@@ -1714,7 +1752,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   float* ws = d.workspace;
   float *h = ws + c->o_h, *heads = ws + c->o_heads, *z = ws + c->o_z, *hd = ws + c->o_hd, *g = ws + c->o_g,
         *bce_part = ws + c->o_bce_part, *klw = ws + c->o_kl, *dhd = ws + c->o_dhd, *dheads = ws + c->o_dheads,
-        *dh = ws + c->o_dh, *drpart = ws + c->o_drpart;
+        *dh = ws + c->o_dh, *drpart = ws + c->o_drpart, *duals = ws + c->o_duals;
   float* P = d.params;
   float* G = d.grads;
   if (!want_outputs) logits = concat_z = bce = kl = nullptr;
@@ -1745,9 +1783,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   {
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
 #define LF(DM, FA)                                                                                                   \
-  STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(256), lds, c->t, h, P + d.off_w_heads,                 \
+  STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(512), lds, c->t, h, P + d.off_w_heads,                 \
                      P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
-                     c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z)
+                     c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z, duals)
     if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
 #undef LF
   }
@@ -1774,7 +1812,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LB(DM, FA, AD)                                                                                              \
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, c->t, dhd, P + d.off_w_d0,      \
                      heads, c->ldh, eps, d.eps_dim, P + d.off_radii, h, P + d.off_w_heads, dheads, dh, drpart, g,   \
-                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits))
+                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
     if (fast_b) {
       if (fused) { DMAX_SWITCH(c->dmax, LB(DM, true, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, true, false)); }
     } else {

@@ -21,7 +21,9 @@ for i in range(N):
     lib.mvae_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     lib.mvae_debug_read(buf, 16)
     v = [int(x) for x in buf]
-    d = [(v[1]-v[0]), (v[2]-v[1]), (v[3]-v[2]), (v[4]-v[3]), (v[9]-v[8]), (v[10]-v[9]), (v[11]-v[10]), (v[12]-v[11])]
+    d = [(v[1]-v[0]), (v[2]-v[1]), (v[3]-v[2]), (v[4]-v[3]), (v[9]-v[8]), (v[10]-v[9]), (v[11]-v[10]), (v[12]-v[11]),
+         (v[6]-v[5]), (v[7]-v[6])]
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
-names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:comps", "bwd:dh"]
+names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:dot", "bwd:dh",
+         "side:tables", "side:duals"]
 for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
