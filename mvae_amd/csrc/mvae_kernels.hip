@@ -1546,13 +1546,24 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
     } else if (zj < Z) {
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
-    part[tid] = p;
-    lds_barrier();
-    if (wave == 3) {
-      for (int j = lane; j < Z; j += 64) {
-        float tot = 0.f;
-        for (int q = 0; q < nsl; ++q) tot += part[q * ZP + j];
-        dz_s[j] = tot;
+    if (FAST) {
+      // ZP <= 8: the slices of one wave are the lanes with equal (lane & (ZP-1)): butterfly over the upper lane bits,
+      // then the four waves' sums meet in LDS (fixed order)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        if (off >= ZP) p += __shfl_xor(p, off);
+      if (lane < ZP) part[wave * ZP + lane] = p;
+      lds_barrier();
+      if (tid < Z) dz_s[tid] = (part[tid] + part[ZP + tid]) + (part[2 * ZP + tid] + part[3 * ZP + tid]);
+    } else {
+      part[tid] = p;
+      lds_barrier();
+      if (wave == 3) {
+        for (int j = lane; j < Z; j += 64) {
+          float tot = 0.f;
+          for (int q = 0; q < nsl; ++q) tot += part[q * ZP + j];
+          dz_s[j] = tot;
+        }
       }
     }
     lds_barrier();
