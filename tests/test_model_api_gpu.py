@@ -213,3 +213,51 @@ def test_training_improves_elbo(dev):
             first = eng.read_stats()["last"]["elbo"] / 128
     last = eng.read_stats()["last"]["elbo"] / 128
     assert np.isfinite(last) and last > first + 100, (first, last)
+
+
+# the wrapped-normal / Euclidean entries of the reference's model table (tests/mvae/models/test_vae.py:200-250)
+_REF_MODELS = ["e2", "s2-wn", "h2-wn", "p2-wn", "d2-wn", "h2,s2,e2", "d2-wn,e2,p2-wn", "h40-wn", "s40-wn", "d40-wn",
+               "p40-wn", "u2"]
+
+
+@pytest.mark.parametrize("fixed_curvature", [True, False])
+@pytest.mark.parametrize("model", _REF_MODELS)
+def test_run_training_like_the_reference(dev, tmp_path, model, fixed_curvature):
+    """tests/mvae/models/test_vae.py:255-335 restated: h_dim = 2, two epochs on a tiny fake data set, importance-sampled
+    log-likelihood inside (-1e4, eps), and the curvature expectations after the run -- +-1/(11-1)^2 for fixed curvature
+    (the warm-up override applies to fixed models too), not -1 / 0 / 1 for learnable ones."""
+    from mvae_amd import utils
+    from mvae_amd.components import (EuclideanComponent, HyperbolicComponent, PoincareComponent, SphericalComponent,
+                                     StereographicallyProjectedSphereComponent, UniversalComponent)
+    from mvae_amd.data import DeviceLoader
+    from mvae_amd.models import FeedForwardVAE
+    from mvae_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(6, 784, generator=g) * 255).to(torch.uint8).to(dev)
+    y = torch.zeros(6, dtype=torch.int64, device=dev)
+    train = DeviceLoader(x, y, 2, train=True, binarize=True, seed=1)
+    test = DeviceLoader(x[:2], y[:2], 2, train=False, binarize=True)
+    torch.manual_seed(0)
+    m = FeedForwardVAE(2, utils.parse_components(model, fixed_curvature), _DS(), False).to(dev)
+    m.seed_sampler(7)
+    tr = Trainer(m, chkpt_dir=str(tmp_path))
+    opt = tr.build_optimizer(1e-3, fixed_curvature=fixed_curvature)
+    res = tr.train_epochs(opt, train, test, betas=[1.0], epochs=2, likelihood_n=500)
+    assert len(res) == 1
+    for st in res.values():
+        for k, v in st.to_print().items():
+            assert np.isfinite(v), f"{k} is not finite."
+        assert -1e4 < float(st.log_likelihood) < 1e-8
+    for c in m.components:
+        K = float(c.manifold.curvature)
+        if isinstance(c, EuclideanComponent):
+            assert K == 0
+        elif isinstance(c, UniversalComponent):
+            assert np.isfinite(K)
+        elif fixed_curvature:
+            want = 0.01 if isinstance(c, (SphericalComponent, StereographicallyProjectedSphereComponent)) else -0.01
+            assert isinstance(c, (SphericalComponent, StereographicallyProjectedSphereComponent, HyperbolicComponent,
+                                  PoincareComponent))
+            assert abs(K - want) < 1e-6
+        else:
+            assert all(abs(K - v) > 1e-6 for v in (-1.0, 0.0, 1.0))
