@@ -1044,6 +1044,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// parts a head row is split into by the generic heads contraction of k_latent_fwd (256 threads = rows x parts)
+__host__ __device__ inline int heads_parts(int NH) {
+  const int p = NH >= 256 ? 1 : 256 / NH;
+  return p > 8 ? 8 : p;
+}
+
 // ---- 2: heads + latent components + first decoder layer; ONE batch row per workgroup.  The phases are short and
 // latency-bound, so rows are spread over as many CUs as possible, every global operand is requested in the first
 // instructions of the kernel (one memory round trip), and the small reductions are wavefront shuffles.
@@ -1077,10 +1083,14 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   // on wave w), instead of on the critical path of launch 5, which only contracts the stored records with dz.
   // Record layout: duals[row][first_dir(ci) + dir][{d kl, d z_0 .. d z_{A-1}}].
   if (tid >= 256) {
-    lds_barrier();  // the four barriers of the main path up to "heads_s final"
-    lds_barrier();
-    lds_barrier();
-    lds_barrier();
+    // as many barriers as the main path executes up to "heads_s final": 2 in the prologue, then 2 (register-resident
+    // path) or 2 per round of the generic heads contraction + 1
+    int nbar = 4;
+    if (!FAST) {
+      const int per = 256 / heads_parts(NH);
+      nbar = 2 + 2 * ((NH + per - 1) / per) + 1;
+    }
+    for (int i = 0; i < nbar; ++i) lds_barrier();
     const int w = wave - 4;
     int total = 0;
     for (int sidx = 0; sidx < kMaxComp; ++sidx) {
@@ -1209,25 +1219,43 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
       heads_s[tid] = v;  // same thread wrote nothing else here; published by the barrier below
     }
   } else {
-#pragma unroll 4
-    for (int n = wave; n < NH; n += 4) {
+    // generic: thread (n, part) streams its own stretch of row n of W_heads (all of its loads are independent);
+    // the `P` partial sums of a row meet in LDS (z_s is free until the components write it)
+    const int P = heads_parts(NH), per = 256 / P;
+    for (int n0 = 0; n0 < NH; n0 += per) {
+      const int nl = tid / P, part = tid - nl * P, n = n0 + nl;
       float p = 0.f;
-      if (vec) {
-        for (int k = lane * 4; k < H; k += 256) {
-          const float4 wv = *reinterpret_cast<const float4*>(Wh + (size_t)n * H + k);
-          const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
-          p = fmaf(xv.x, wv.x, p);
-          p = fmaf(xv.y, wv.y, p);
-          p = fmaf(xv.z, wv.z, p);
-          p = fmaf(xv.w, wv.w, p);
+      if (nl < per && n < NH) {
+        if (vec) {
+          const int H4 = H >> 2, chunk = (H4 + P - 1) / P;
+          const int k0 = part * chunk, k1 = (k0 + chunk < H4) ? k0 + chunk : H4;
+          const float4* wrow = reinterpret_cast<const float4*>(Wh + (size_t)n * H);
+          const float4* hrow = reinterpret_cast<const float4*>(h_s);
+#pragma unroll 8
+          for (int k = k0; k < k1; ++k) {
+            const float4 wv = wrow[k];
+            const float4 xv = hrow[k];
+            p = fmaf(xv.x, wv.x, p);
+            p = fmaf(xv.y, wv.y, p);
+            p = fmaf(xv.z, wv.z, p);
+            p = fmaf(xv.w, wv.w, p);
+          }
+        } else {
+          const int chunk = (H + P - 1) / P;
+          const int k0 = part * chunk, k1 = (k0 + chunk < H) ? k0 + chunk : H;
+#pragma unroll 8
+          for (int k = k0; k < k1; ++k) p = fmaf(h_s[k], Wh[(size_t)n * H + k], p);
         }
-      } else {
-        for (int k = lane; k < H; k += 64) p = fmaf(h_s[k], Wh[(size_t)n * H + k], p);
       }
-      p = wave_sum(p);
-      if (lane == 0) heads_s[n] = p + bh[n];
+      z_s[tid] = p;
+      lds_barrier();
+      if (tid < per && n0 + tid < NH) {
+        float sum = 0.f;
+        for (int q = 0; q < P; ++q) sum += z_s[tid * P + q];
+        heads_s[n0 + tid] = sum + bh[n0 + tid];
+      }
+      lds_barrier();
     }
-    lds_barrier();
     if (tid < NH) heads[row * ldh + tid] = heads_s[tid];
   }
   lds_barrier();
@@ -1273,10 +1301,25 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
       }
     }
   } else {
+    const bool vz = (Z & 3) == 0 && aligned16(Wd0);
     for (int c = tid; c < H; c += 256) {
       const float* w = Wd0 + (size_t)c * Z;
       float acc = 0.f;
-      for (int j = 0; j < Z; ++j) acc = fmaf(z_s[j], w[j], acc);
+      if (vz) {
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* z4 = reinterpret_cast<const float4*>(z_s);
+#pragma unroll 4
+        for (int j = 0; j < (Z >> 2); ++j) {
+          const float4 a = w4[j], zz = z4[j];
+          acc = fmaf(zz.x, a.x, acc);
+          acc = fmaf(zz.y, a.y, acc);
+          acc = fmaf(zz.z, a.z, acc);
+          acc = fmaf(zz.w, a.w, acc);
+        }
+      } else {
+#pragma unroll 4
+        for (int j = 0; j < Z; ++j) acc = fmaf(z_s[j], w[j], acc);
+      }
       acc += bd0[c];
       hd[row * H + c] = acc > 0.f ? acc : 0.f;
     }
@@ -1423,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
                                                     float* drpart, const float* g, const float* hd, float* dWl,
                                                     float beta, int B, int H, int D, int NH, int Z, int n_rows,
                                                     AdamArgs awl, const float* duals) {
-  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [256] partials | [NH] heads | [eps]
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [1024] dz partials
   __shared__ float red[4][16][17];
   __shared__ float sh2[2];
   __shared__ float dz_s[kHeadsMax];
@@ -1524,7 +1567,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   const size_t rec0 = (size_t)row * (NH + t.n);
   float du[DS];
   int my_ci = 0, my_dir = 0;
-  if (FAST) {  // <= 24 active directions: at most one item per thread
+  {  // the first (usually only) item of this thread
     const int gi = tid < total ? tid : 0;
     while (gi >= doff_s[my_ci + 1]) ++my_ci;
     my_dir = gi - doff_s[my_ci];
@@ -1543,7 +1586,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
         const int c = sl + q * nsl;
         p = fmaf(dhd_s[c < H ? c : 0], wz[q], p);
       }
-    } else if (zj < Z) {
+    } else if (zj < Z && !((Z & 3) == 0 && aligned16(Wd0))) {
+#pragma unroll 4
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
     if (FAST) {
@@ -1555,6 +1599,29 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
       if (lane < ZP) part[wave * ZP + lane] = p;
       lds_barrier();
       if (tid < Z) dz_s[tid] = (part[tid] + part[ZP + tid]) + (part[2 * ZP + tid] + part[3 * ZP + tid]);
+    } else if ((Z & 3) == 0 && aligned16(Wd0)) {
+      // generic, 16-byte path: thread (slice, j4) accumulates four neighbouring columns over a strided slice of c
+      const int nj4 = Z >> 2, nslv = 256 / nj4;
+      const int j4 = tid % nj4, s2 = tid / nj4;
+      if (s2 < nslv) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int c = s2; c < H; c += nslv) {
+          const float4 w = *reinterpret_cast<const float4*>(Wd0 + (size_t)c * Z + 4 * j4);
+          const float dv = dhd_s[c];
+          a.x = fmaf(dv, w.x, a.x);
+          a.y = fmaf(dv, w.y, a.y);
+          a.z = fmaf(dv, w.z, a.z);
+          a.w = fmaf(dv, w.w, a.w);
+        }
+        *reinterpret_cast<float4*>(part + s2 * Z + 4 * j4) = a;  // nslv * Z <= 1024 floats
+      }
+      lds_barrier();
+      for (int j = tid; j < Z; j += 256) {
+        float tot = 0.f;
+        for (int q = 0; q < nslv; ++q) tot += part[q * Z + j];
+        dz_s[j] = tot;
+      }
     } else {
       part[tid] = p;
       lds_barrier();
@@ -1571,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   MV_STAMP(10);
   // ---- d(loss)/d(direction) = beta * d kl + <dz, d z>: one record per (component, input direction)
   for (int gi = tid; gi < total; gi += 256) {
-    if (!FAST) {
+    if (gi >= 256) {  // more than 256 active directions: further items are fetched on demand
       my_ci = 0;
       while (gi >= doff_s[my_ci + 1]) ++my_ci;
       my_dir = gi - doff_s[my_ci];
@@ -1607,6 +1674,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   } else {
     for (int c = tid; c < H; c += 256) {
       float acc = 0.f;
+#pragma unroll 8
       for (int n = 0; n < NH; ++n) acc = fmaf(dheads_s[n], Wh[(size_t)n * H + c], acc);
       const size_t o = row * H + c;
       dh[o] = (h[o] > 0.f) ? acc : 0.f;
@@ -1818,8 +1886,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   }
   {
     const int n_dwl = c->nt_d * ((c->nt_h + 3) / 4);
-    const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 256 + (((size_t)NH + 3) & ~(size_t)3) + d.eps_dim + 4) *
-                       sizeof(float);
+    const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 1024 + 8) * sizeof(float);  // dhd row | dz partials
 #define LB(DM, FA, AD)                                                                                              \
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, c->t, dhd, P + d.off_w_d0,      \
                      heads, c->ldh, eps, d.eps_dim, P + d.off_radii, h, P + d.off_w_heads, dheads, dh, drpart, g,   \

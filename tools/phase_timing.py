@@ -7,15 +7,21 @@ from mvae_amd import _lib, synthetic
 from mvae_amd.engine import StepEngine
 lib = _lib.load()
 dev = torch.device("cuda:0")
-eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+MODEL = sys.argv[1] if len(sys.argv) > 1 else "h2,s2,e2"
+from mvae_amd.utils import parse_component_str
+comps = []
+for tok in MODEL.split(","):
+    mult, letter, dim = parse_component_str(tok)
+    comps += [(letter, dim)] * mult
+eng = StepEngine(comps, 784, 400, dev, radius_trainable=[l != "e" for l, _ in comps])
 eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
-xs = synthetic.binary_batches(8, 128, 784).to(dev); eps = synthetic.eps_batches(8, 128, 6).to(dev)
-for i in range(20): eng.train_step(xs[i % 8], eps[i % 8], 1.0, True)
+xs = synthetic.binary_batches(8, 128, 784).to(dev); eps = synthetic.eps_batches(8, 128, eng.layout.eps_dim).to(dev)
+for i in range(20): eng.train_step(xs[i % 8], eps[i % 8], 1.0, False)
 torch.cuda.synchronize()
 acc = None
 N = 50
 for i in range(N):
-    eng.train_step(xs[i % 8], eps[i % 8], 1.0, True)
+    eng.train_step(xs[i % 8], eps[i % 8], 1.0, False)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 16)()
     lib.mvae_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
