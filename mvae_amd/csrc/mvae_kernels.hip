@@ -588,11 +588,20 @@ extern "C" int mvae_component_backward(const mvae_component_desc* comps, int nco
 }
 
 // ------------------------------------------------------------------------------------------------ dense layers (API)
+// large, 16-byte aligned problems go to the LDS-tiled kernel (defined with the conv building blocks below)
+static bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
+                                 int relu, hipStream_t s);
+constexpr int64_t kTiledMinRows = 512;
+
 extern "C" int mvae_linear_forward(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
                                    int relu, void* stream) {
   if (!x || !W || !y || M < 0 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (M == 0) return 0;
   if (M > (1 << 20) * 16) return fail(MVAE_E_UNSUPPORTED, "M too large%s", "");
+  if (M >= kTiledMinRows && linear_forward_tiled(x, W, b, y, M, N, K, relu, (hipStream_t)stream)) {
+    LAUNCH_CHECK("tiled linear forward launch");
+    return 0;
+  }
   dim3 grid((N + 15) / 16, (unsigned)((M + 15) / 16));
   hipStream_t s = (hipStream_t)stream;
   if (relu) hipLaunchKernelGGL(k_linear_fwd<true>, grid, dim3(256), 0, s, x, W, b, y, (int)M, N, K);
@@ -1410,8 +1419,16 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     }
     for (; nt < ntD; ++nt) bce += bce_part[(size_t)nt * B + r];
     if (bce_user) bce_user[r] = bce;
-    float klr = 0.f;
-    for (int i = 0; i < ncomp; ++i) klr = (i == 0) ? kl[r] : klr + kl[(size_t)i * B + r];
+    float klr = kl[r];
+    int i = 1;
+    for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) klr += v[u];
+    }
+    for (; i < ncomp; ++i) klr += kl[(size_t)i * B + r];
     bce_acc += bce;
     elbo_acc += (-bce - beta * klr);
   }
@@ -2115,8 +2132,16 @@ __global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const flo
   };
   float b = 0.f, e = 0.f;
   for (int r = tid; r < B; r += 256) {
-    float klr = 0.f;
-    for (int i = 0; i < ncomp; ++i) klr = (i == 0) ? kl[r] : klr + kl[(size_t)i * B + r];
+    float klr = kl[r];
+    int i = 1;
+    for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) klr += v[u];
+    }
+    for (; i < ncomp; ++i) klr += kl[(size_t)i * B + r];
     b += bce[r];
     e += (-bce[r] - beta * klr);
   }
@@ -2172,6 +2197,173 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
   return 0;
 }
 
+// ---- LDS-tiled f32 MFMA contraction for the large shapes of the conv architecture (M = B*OH*OW up to 65536 rows).
+// C[M,N] = A . B with A(i,k) at A[i*sai + k*sak] and B(k,j) at B[k*sbk + j*sbj]; exactly one stride of each operand
+// is 1 (the template flag says which), so one kernel serves
+//   NT  y = x W^T        A = x [M,K] (k contiguous),  B = W [N,K] (k contiguous)     Conv2d forward / Linear
+//   NN  y = g W          A = g [M,K] (k contiguous),  B = W [K,N] (j contiguous)     ConvTranspose2d forward, dX
+//   TN  dW = P^T Q       A = P [Kc,M'] (i contiguous), B = Q [Kc,N] (j contiguous)   weight gradients (split-K slices)
+// Workgroup tile BM x BN, K step 16; 4 waves as 2 x 2, each wave (BM/2) x (BN/2) as 16 x 16 MFMA tiles.  Both operand
+// tiles sit in LDS as [row][k] with a row stride of 20 floats: a lane fetches ONE 16-byte vector per 16 x 16 x 16
+// sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and B), conflict-free for ds_read_b128.
+// Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
+constexpr int kGT_BK = 16, kGT_LD = 20;
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
+                                                    const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
+                                                    float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                                    const float* __restrict__ mask, int relu, int M, int N, int K,
+                                                    int k_per_slice, int64_t slice_stride) {
+  __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int LA = BM * 4 / 256, LB = BN * 4 / 256;  // 16-byte vectors per thread per K step
+  static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = blockIdx.z * k_per_slice;
+  const int ke = (kb + k_per_slice < K) ? kb + k_per_slice : K;
+  C += (size_t)blockIdx.z * slice_stride;
+
+  float4 ra[LA], rb[LB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + 256 * r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KC) {  // 4 consecutive k of row i
+        const int i = f >> 2, k = k0 + ((f & 3) << 2);
+        if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + i) * sai + k);
+      } else {  // 4 consecutive i of column k
+        const int k = k0 + (f & 15), i = (f >> 4) << 2;
+        if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)k * sak + (m0 + i));
+      }
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + 256 * r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_KC) {
+        const int j = f >> 2, k = k0 + ((f & 3) << 2);
+        if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + j) * sbj + k);
+      } else {
+        const int k = k0 + (f & 15), j = (f >> 4) << 2;
+        if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)k * sbk + (n0 + j));
+      }
+      rb[r] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + 256 * r;
+      if (A_KC) {
+        *reinterpret_cast<float4*>(As + (f >> 2) * kGT_LD + ((f & 3) << 2)) = ra[r];
+      } else {
+        const int k = f & 15, i = (f >> 4) << 2;
+        As[(i + 0) * kGT_LD + k] = ra[r].x;
+        As[(i + 1) * kGT_LD + k] = ra[r].y;
+        As[(i + 2) * kGT_LD + k] = ra[r].z;
+        As[(i + 3) * kGT_LD + k] = ra[r].w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + 256 * r;
+      if (B_KC) {
+        *reinterpret_cast<float4*>(Bs + (f >> 2) * kGT_LD + ((f & 3) << 2)) = rb[r];
+      } else {
+        const int k = f & 15, j = (f >> 4) << 2;
+        Bs[(j + 0) * kGT_LD + k] = rb[r].x;
+        Bs[(j + 1) * kGT_LD + k] = rb[r].y;
+        Bs[(j + 2) * kGT_LD + k] = rb[r].z;
+        Bs[(j + 3) * kGT_LD + k] = rb[r].w;
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int li = lane & 15, lk = (lane >> 4) << 2;
+
+  fetch(kb);
+  for (int k0 = kb; k0 < ke; k0 += kGT_BK) {
+    stage();
+    __syncthreads();
+    if (k0 + kGT_BK < ke) fetch(k0 + kGT_BK);
+    float4 af[TM], bf[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(As + (wm + a * 16 + li) * kGT_LD + lk);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(Bs + (wn + b * 16 + li) * kGT_LD + lk);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        acc[a][b] = mfma16(af[a].x, bf[b].x, acc[a][b]);
+        acc[a][b] = mfma16(af[a].y, bf[b].y, acc[a][b]);
+        acc[a][b] = mfma16(af[a].z, bf[b].z, acc[a][b]);
+        acc[a][b] = mfma16(af[a].w, bf[b].w, acc[a][b]);
+      }
+    __syncthreads();
+  }
+  // epilogue: lane holds rows 4*(lane>>4) + r, column lane&15 of every 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn + b * 16 + li;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + a * 16 + lk + r;
+        if (m >= M) continue;
+        float v = acc[a][b][r] + bv;
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (mask && !(mask[(size_t)m * ldc + n] > 0.f)) v = 0.f;
+        C[(size_t)m * ldc + n] = v;
+      }
+    }
+}
+
+// operand requirements of the 16-byte paths of k_gemm_tiled
+static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
+
+template <bool A_KC, bool B_KC>
+static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
+                              float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
+                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s) {
+  // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
+  // workgroups, half the LDS reuse) win on every conv layer shape of the reference
+  const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
+  if (N > 64 && wg128 < 512) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<64, 64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  } else if (N > 64) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  }
+}
+
+static bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
+                                 int relu, hipStream_t s) {
+  if (!tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff) return false;
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0, s);
+  return true;
+}
+
 // Long batch contractions (conv layers: M = B*OH*OW up to 65536 rows): the rows are cut into slices of kTnSlice, one
 // workgroup-row of tiles per slice writes its partial [NP, NQ] product, and a second launch adds the slices in index
 // order (deterministic; no float atomics).
@@ -2206,6 +2398,23 @@ extern "C" int64_t mvae_gemm_tn_workspace_floats(int64_t M, int NP, int NQ) {
 extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t M, int NP, int NQ, float* workspace,
                             void* stream) {
   if (!P || !Q || !out || M < 1 || NP < 1 || NQ < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (M >= kTiledMinRows && tiled_ok(P, NP) && tiled_ok(Q, NQ) && tiled_ok(out, NQ) && M <= 0x7fffffff) {
+    // split-K over the batch rows so that >= 256 workgroups exist; the slices are added in index order
+    const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
+    int slices = (256 + wg - 1) / wg;
+    const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);  // what mvae_gemm_tn_workspace_floats provides
+    if (slices > max_slices) slices = max_slices;
+    if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
+    const int kps = (int)((((M + slices - 1) / slices) + 15) & ~(int64_t)15);
+    slices = (int)((M + kps - 1) / kps);
+    const int64_t n = (int64_t)NP * NQ;
+    launch_gemm_tiled<false, false>(P, 1, NP, Q, NQ, 1, slices > 1 ? workspace : out, NQ, nullptr, nullptr, 0, NP, NQ,
+                                    (int)M, slices, kps, n, (hipStream_t)stream);
+    if (slices > 1)
+      hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+    LAUNCH_CHECK("tiled gemm_tn launch");
+    return 0;
+  }
   const int tiles = ((NP + 15) / 16) * (((NQ + 15) / 16 + 3) / 4);
   if (M <= kTnSlice) {
     hipLaunchKernelGGL(k_gemm_tn, dim3(tiles), dim3(256), 0, (hipStream_t)stream, P, Q, out, (int)M, NP, NQ);
@@ -2232,6 +2441,12 @@ extern "C" int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream
 extern "C" int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N,
                             void* stream) {
   if (!G || !W || !out || M < 1 || K < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (M >= kTiledMinRows && tiled_ok(G, K) && tiled_ok(W, N) && M <= 0x7fffffff) {
+    launch_gemm_tiled<true, false>(G, K, 1, W, N, 1, out, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
+                                   (hipStream_t)stream);
+    LAUNCH_CHECK("tiled gemm_nn launch");
+    return 0;
+  }
   const int64_t grid = ((M + 15) / 16) * ((N + 15) / 16);
   if (grid > 0x7fffffff) return fail(MVAE_E_UNSUPPORTED, "grid too large%s", "");
   hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, G, W, mask, out, (int)M, K, N);

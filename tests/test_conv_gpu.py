@@ -129,3 +129,22 @@ def test_conv_log_likelihood_vs_golden(dev):
         assert_close(_cpu(lp), g[key + "log_px"], 2 * RTOL, "log_px")
         assert_close(_cpu(mi), g[key + "mi"], 2 * RTOL, "mi", atol_frac=1e-3)
         assert_close(float(cn), float(g[key + "cov_norm"]), 2 * RTOL, "cov_norm")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (1024, 48, 64), (1536, 64, 48), (640, 132, 36), (2048, 128, 1024)])
+def test_tiled_contractions_vs_float64(dev, M, N, K):
+    """The LDS-tiled kernel behind mvae_linear_forward / mvae_gemm_nn / mvae_gemm_tn for M >= 512 (ragged tiles, N and K
+    that are not multiples of the tile, split-K slices) against float64 torch."""
+    from mvae_amd import functional as Fn
+    from mvae_amd.conv import _gemm_nn, _gemm_tn
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    y = Fn.linear_forward(x.to(dev), W.to(dev), b.to(dev), relu=True)  # NT
+    assert_close(_cpu(y), torch.relu(x.double() @ W.double().t() + b.double()).numpy(), 2e-5, "NT", atol_frac=2e-6)
+    Wn = torch.randn(K, N, generator=g) * 0.1
+    assert_close(_cpu(_gemm_nn(x.to(dev), Wn.to(dev))), (x.double() @ Wn.double()).numpy(), 2e-5, "NN", atol_frac=2e-6)
+    Q = torch.randn(M, N, generator=g)
+    assert_close(_cpu(_gemm_tn(x.to(dev), Q.to(dev))), (x.double().t() @ Q.double()).numpy(), 2e-5, "TN",
+                 atol_frac=5e-6)
