@@ -113,10 +113,13 @@ def _permute_rc(x: Tensor, B: int, R: int, Cc: int) -> Tensor:
     return out
 
 
-def _gemm_tn(P: Tensor, Q: Tensor) -> Tensor:
+def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[NP, NQ] = P^T Q; `out` may be a (contiguous) view into the flat gradient buffer."""
     M, NP = P.shape
     NQ = Q.shape[1]
-    out = P.new_empty(NP, NQ)
+    if out is None:
+        out = P.new_empty(NP, NQ)
+    assert out.is_contiguous() and out.numel() == NP * NQ
     nws = load().mvae_gemm_tn_workspace_floats(M, NP, NQ)
     ws = P.new_empty(int(nws)) if nws > 0 else None
     check(load().mvae_gemm_tn(ptr(P), ptr(Q), ptr(out), M, NP, NQ, ptr(ws), stream_ptr(P.device)))
@@ -131,8 +134,10 @@ def _gemm_nn(G: Tensor, W: Tensor) -> Tensor:
     return out
 
 
-def _colsum(G: Tensor) -> Tensor:
-    out = G.new_empty(G.shape[1])
+def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = G.new_empty(G.shape[1])
+    assert out.is_contiguous() and out.numel() == G.shape[1]
     nws = load().mvae_colsum_workspace_floats(G.shape[0], G.shape[1])
     ws = G.new_empty(int(nws)) if nws > 0 else None
     check(load().mvae_colsum(ptr(G), ptr(out), G.shape[0], G.shape[1], ptr(ws), stream_ptr(G.device)))
@@ -273,16 +278,16 @@ class ConvEngine:
         PV, GV = self.param_views(), self.grad_views()
         # ---- decoder backward
         dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
-        GV["d3.weight"].view(64, 48).copy_(_gemm_tn(c["b2"], dcol3))
-        GV["d3.bias"].copy_(_colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3)))
+        _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
+        _colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3), out=GV["d3.bias"])
         db2 = _relu_mask_(Fn.linear_forward(dcol3, PV["d3.weight"].view(64, 48), None), c["b2"])
         dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64))
-        GV["d2.weight"].view(256, 1024).copy_(_gemm_tn(c["b1"], dcol2))
-        GV["d2.bias"].copy_(_colsum(db2))
+        _gemm_tn(c["b1"], dcol2, out=GV["d2.weight"].view(256, 1024))
+        _colsum(db2, out=GV["d2.bias"])
         db1 = _relu_mask_(Fn.linear_forward(dcol2, PV["d2.weight"].view(256, 1024), None), c["b1"])
         dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256))
-        GV["d1.weight"].view(128, 4096).copy_(_gemm_tn(c["t0"], dcol1))
-        GV["d1.bias"].copy_(_colsum(db1))
+        _gemm_tn(c["t0"], dcol1, out=GV["d1.weight"].view(128, 4096))
+        _colsum(db1, out=GV["d1.bias"])
         dt0 = Fn.linear_forward(dcol1, PV["d1.weight"].view(128, 4096), None)  # [B*16, 128]
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         dW, db, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True)
@@ -301,16 +306,16 @@ class ConvEngine:
         self.grads[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH].copy_(dbh)
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
-        GV["e2.weight"].view(512, 2048).copy_(_gemm_tn(da2, c["col2"]))
-        GV["e2.bias"].copy_(_colsum(da2))
+        _gemm_tn(da2, c["col2"], out=GV["e2.weight"].view(512, 2048))
+        _colsum(da2, out=GV["e2.bias"])
         da1 = _col2im(_gemm_nn(da2, PV["e2.weight"].view(512, 2048)), None, c["a1"], B, 128, 8, _nhwc(8, 128), False,
                       (B * 64, 128))
-        GV["e1.weight"].view(128, 1024).copy_(_gemm_tn(da1, c["col1"]))
-        GV["e1.bias"].copy_(_colsum(da1))
+        _gemm_tn(da1, c["col1"], out=GV["e1.weight"].view(128, 1024))
+        _colsum(da1, out=GV["e1.bias"])
         da0 = _col2im(_gemm_nn(da1, PV["e1.weight"].view(128, 1024)), None, c["a0"], B, 64, 16, _nhwc(16, 64), False,
                       (B * 256, 64))
-        GV["e0.weight"].view(64, 48).copy_(_gemm_tn(da0, c["col0"]))
-        GV["e0.bias"].copy_(_colsum(da0))
+        _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
+        _colsum(da0, out=GV["e0.bias"])
         if want_outputs:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None

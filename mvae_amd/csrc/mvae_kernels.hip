@@ -2378,11 +2378,29 @@ __global__ __launch_bounds__(256) void k_gemm_tn_sliced(const float* P, const fl
   job_tn_wave<false>(P + (size_t)m0 * NP, NP, NP, tile / ntQ4, Q + (size_t)m0 * NQ, NQ, NQ,
                      (tile % ntQ4) * 4 + (threadIdx.x >> 6), rows, part + (size_t)slice * NP * NQ, NQ, none);
 }
+// out[i] = sum_k part[k][i], fixed order: a workgroup owns 64 outputs, its four waves take the slices k = w, w+4, ...
+// (8 loads in flight per lane), the four partial sums meet in LDS and are added in wave order.
 __global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* out, int64_t n, int slices) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + lane;
     float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    if (i < n) {
+      int k = w;
+      for (; k + 28 < slices; k += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < slices; k += 4) s += part[(size_t)k * n + i];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) out[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void k_relu_mask(float* dy, const float* y, int64_t n) {
@@ -2411,7 +2429,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     launch_gemm_tiled<false, false>(P, 1, NP, Q, NQ, 1, slices > 1 ? workspace : out, NQ, nullptr, nullptr, 0, NP, NQ,
                                     (int)M, slices, kps, n, (hipStream_t)stream);
     if (slices > 1)
-      hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+      hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
     LAUNCH_CHECK("tiled gemm_tn launch");
     return 0;
   }
@@ -2424,7 +2442,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     hipLaunchKernelGGL(k_gemm_tn_sliced, dim3((unsigned)(tiles * slices)), dim3(256), 0, (hipStream_t)stream, P, Q,
                        workspace, (int)M, NP, NQ, tiles);
     const int64_t n = (int64_t)NP * NQ;
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
   }
   LAUNCH_CHECK("gemm_tn launch");
   return 0;
@@ -2480,7 +2498,7 @@ extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* 
     const int slices = (int)((M + kColSlice - 1) / kColSlice);
     hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
                        workspace, (int)M, N, ncb);
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)stream, workspace, out, (int64_t)N,
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * (int64_t)N)), dim3(256), 0, (hipStream_t)stream, workspace, out, (int64_t)N,
                        slices);
   }
   LAUNCH_CHECK("colsum launch");
