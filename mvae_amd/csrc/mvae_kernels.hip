@@ -245,7 +245,7 @@ __device__ __forceinline__ void job_linear_fwd(float (*red)[16][17], const float
   const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
   if (m < M && n < N) {
     float v = s + (b ? b[n] : 0.f);
-    if (RELU) v = v > 0.f ? v : 0.f;
+    if (RELU) v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
     y[(size_t)m * ldy + n] = v;
   }
 }
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
     const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
     if (FULL || (m < B && n < H)) {
       const float v = s + b[n];
-      h[(size_t)m * H + n] = v > 0.f ? v : 0.f;
+      h[(size_t)m * H + n] = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
     }
   }
 }
@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
         for (int j = 0; j < 8; ++j)
           if (j < Z) acc = fmaf(z_s[j], wd[u][j], acc);
         acc += bd[u];
-        hd[row * H + c] = acc > 0.f ? acc : 0.f;
+        hd[row * H + c] = acc < 0.f ? 0.f : acc;
       }
     }
   } else {
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
         for (int j = 0; j < Z; ++j) acc = fmaf(z_s[j], w[j], acc);
       }
       acc += bd0[c];
-      hd[row * H + c] = acc > 0.f ? acc : 0.f;
+      hd[row * H + c] = acc < 0.f ? 0.f : acc;
     }
   }
   MV_STAMP(4);
@@ -2063,7 +2063,7 @@ __global__ __launch_bounds__(256) void k_col2im(const float* col, const float* b
       }
     }
     const int64_t o = b * sb + c * sc + y * sy + x * sx;
-    if (relu) acc = acc > 0.f ? acc : 0.f;
+    if (relu) acc = acc < 0.f ? 0.f : acc;
     if (mask && !(mask[o] > 0.f)) acc = 0.f;
     dst[o] = acc;
   }
@@ -2325,7 +2325,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
         const int m = m0 + wm + a * 16 + lk + r;
         if (m >= M) continue;
         float v = acc[a][b][r] + bv;
-        if (relu) v = v > 0.f ? v : 0.f;
+        if (relu) v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
         if (mask && !(mask[(size_t)m * ldc + n] > 0.f)) v = 0.f;
         C[(size_t)m * ldc + n] = v;
       }

@@ -114,25 +114,29 @@ __device__ __forceinline__ Dual t_abs(Dual x) {
   float s = (x.v > 0.0f) ? 1.0f : ((x.v < 0.0f) ? -1.0f : 0.0f);
   return {fabsf(x.v), x.d * s};
 }
-__device__ __forceinline__ float t_relu(float x) { return x > 0.0f ? x : 0.0f; }
-__device__ __forceinline__ Dual t_relu(Dual x) { return x.v > 0.0f ? x : Dual{0.0f, 0.0f}; }
+__device__ __forceinline__ float t_relu(float x) { return x < 0.0f ? 0.0f : x; }  // NaN propagates, as torch.relu
+__device__ __forceinline__ Dual t_relu(Dual x) { return x.v > 0.0f ? x : Dual{x.v < 0.0f ? 0.0f : x.v, 0.0f}; }
+
+// clamp that PROPAGATES NaN like torch.clamp (v_max_f32 / v_min_f32 return the other operand): what makes a diverged
+// run visible in the statistics, as the reference's isfinite asserts would
+__device__ __forceinline__ float nclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // torch.clamp (hard): derivative 1 inside [lo,hi] inclusive, 0 outside
-__device__ __forceinline__ float hard_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float hard_clamp(float x, float lo, float hi) { return nclamp(x, lo, hi); }
 __device__ __forceinline__ Dual hard_clamp(Dual x, float lo, float hi) {
   bool in = (x.v >= lo) && (x.v <= hi);
-  return {fminf(fmaxf(x.v, lo), hi), in ? x.d : 0.0f};
+  return {nclamp(x.v, lo, hi), in ? x.d : 0.0f};
 }
 // LeakyClamp (common.py:28-39)
-__device__ __forceinline__ float leaky_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float leaky_clamp(float x, float lo, float hi) { return nclamp(x, lo, hi); }
 __device__ __forceinline__ Dual leaky_clamp(Dual x, float lo, float hi) {
   bool in = (x.v >= lo) && (x.v <= hi);
-  return {fminf(fmaxf(x.v, lo), hi), in ? x.d : x.d * kEps};
+  return {nclamp(x.v, lo, hi), in ? x.d : x.d * kEps};
 }
 // F.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float t_softplus(float x) { return x > 20.0f ? x : mvf::log1p_pos(mvf::fexp(x)); }
 __device__ __forceinline__ Dual t_softplus(Dual x) {
-  const float e = mvf::fexp(fminf(x.v, 20.0f));
+  const float e = mvf::fexp(x.v > 20.0f ? 20.0f : x.v);  // NaN stays NaN
   const bool lin = x.v > 20.0f;
   return {lin ? x.v : mvf::log1p_pos(e), lin ? x.d : x.d * e / (e + 1.0f)};
 }
@@ -143,7 +147,7 @@ template <typename T> __device__ __forceinline__ T g_cosh(T x) { return t_cosh(l
 template <typename T> __device__ __forceinline__ T g_sinh(T x) { return t_sinh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
 // cosh and sinh of the same (leaky-clamped) argument, one exp (common.py:107-114)
 __device__ __forceinline__ void g_cosh_sinh(float x, float* c, float* s) {
-  mvf::sinhcosh(fminf(fmaxf(x, -kMaxNorm), kMaxNorm), s, c);
+  mvf::sinhcosh(nclamp(x, -kMaxNorm, kMaxNorm), s, c);
 }
 __device__ __forceinline__ void g_cosh_sinh(Dual x, Dual* c, Dual* s) {
   const Dual xc = leaky_clamp(x, -kMaxNorm, kMaxNorm);
@@ -167,8 +171,8 @@ __device__ __forceinline__ void t_cos_sin(Dual x, Dual* c, Dual* s) {
 }
 
 __device__ __forceinline__ float g_acosh_parts(float x, float* z_out) {
-  float xc = fmaxf(x, 1.0f + kEps);  // == 1.0f in f32, as in the reference's f32 path
-  float z = sqrtf(fmaxf(xc * xc - 1.0f, 1e-9f));
+  float xc = nclamp(x, 1.0f + kEps, INFINITY);  // == 1.0f in f32, as in the reference's f32 path
+  float z = sqrtf(nclamp(xc * xc - 1.0f, 1e-9f, INFINITY));
   *z_out = z;
   return mvf::flog(xc + z);
 }
@@ -182,11 +186,11 @@ __device__ __forceinline__ Dual g_acosh(Dual x) {
   return {y, x.d / z};
 }
 __device__ __forceinline__ float g_atanh(float x) {
-  float xc = fminf(fmaxf(x, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
+  float xc = nclamp(x, -1.0f + 4.0f * kEps, 1.0f - 4.0f * kEps);
   return (mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f;
 }
 __device__ __forceinline__ Dual g_atanh(Dual x) {
-  float xc = fminf(fmaxf(x.v, -1.0f + 4.0f * kEps), 1.0f - 4.0f * kEps);
+  float xc = nclamp(x.v, -1.0f + 4.0f * kEps, 1.0f - 4.0f * kEps);
   return {(mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
 }
 // logsinh (common.py:122-128 via logsumexp_signs :139-147); torch.max sends the derivative to the arg-max entry
@@ -370,11 +374,11 @@ __device__ __forceinline__ void p_mobius_add(const T* x, const T* y, int A, T c,
   MV_FOR(i, 0, A) out[i] = (fa * x[i] + fb * y[i]) / den;
 }
 __device__ __forceinline__ float p_artanh(float x) {
-  float xc = fminf(fmaxf(x, -1.0f + 1e-5f), 1.0f - 1e-5f);
+  float xc = nclamp(x, -1.0f + 1e-5f, 1.0f - 1e-5f);
   return (mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f;
 }
 __device__ __forceinline__ Dual p_artanh(Dual x) {
-  float xc = fminf(fmaxf(x.v, -1.0f + 1e-5f), 1.0f - 1e-5f);
+  float xc = nclamp(x.v, -1.0f + 1e-5f, 1.0f - 1e-5f);
   return {(mvf::flog(1.0f + xc) - mvf::flog(1.0f - xc)) * 0.5f, x.d / (1.0f - xc * xc)};
 }
 

@@ -5,8 +5,10 @@ state-dict keys and method names.  After `.to(device)` every nn.Parameter is a v
 buffer, so `state_dict()` / `load_state_dict()` / checkpoints keep working while the kernels see one contiguous
 parameter / gradient / optimizer-state layout.  float32 only (`--doubles=False`); there is no CPU execution path.
 """
+import os
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -17,6 +19,8 @@ from .components import Component
 from .distributions import FusedParts, FusedPosterior, FusedPrior
 from .engine import StepEngine  # noqa: F401  (ConvEngine has the same surface)
 from .stats import BatchStatsFloat
+
+_CHECK_FINITE_EVERY_STEP = os.environ.get("MVAE_CHECK_FINITE", "0") not in ("", "0")
 
 
 class Reparametrized:  # vae.py:29-35
@@ -217,7 +221,10 @@ class ModelVAE(nn.Module):
         optimizer.bind(self)
         self._sync_trainable()
         eng.train_step(x, eps, float(beta), optimizer.curv_condition())
-        return BatchStatsFloat(eng, beta), (None, None, None)
+        stats = BatchStatsFloat(eng, beta)
+        if _CHECK_FINITE_EVERY_STEP:  # debug mode: the reference's `assert torch.isfinite(loss).all()` (vae.py:158)
+            assert np.isfinite(stats.elbo), "non-finite ELBO"
+        return stats, (None, None, None)
 
     def _sync_trainable(self) -> None:
         """Parameter.requires_grad of the radii / curvatures is the source of truth (the --universal schedule flips it,

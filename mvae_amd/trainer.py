@@ -108,6 +108,11 @@ class Trainer:
                 self.model.train_step(optimizer, x_mb, beta=beta)
                 self.global_step += 1
         sums = eng.read_stats(reset=True)["sum"]  # the only device sync of the epoch
+        # The reference asserts isfinite after nearly every op (e.g. vae.py:158 on the loss), a host sync each.  Here a
+        # non-finite value in ANY step poisons the running sums, so one check per epoch reports the same condition
+        # with the same exception type (MVAE_CHECK_FINITE=1 moves the check to every step, see ModelVAE.train_step).
+        if not all(np.isfinite(v) for v in (sums["bce"], sums["kl"], sums["elbo"])):
+            raise AssertionError(f"non-finite training statistics in epoch {self.epoch}: {sums}")
         epoch_stats = EpochStats(sums, length=len(train_data.dataset), beta=beta)
         print(self._epoch_dict(epoch_stats), flush=True)
         return epoch_stats

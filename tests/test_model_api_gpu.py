@@ -261,3 +261,22 @@ def test_run_training_like_the_reference(dev, tmp_path, model, fixed_curvature):
             assert abs(K - want) < 1e-6
         else:
             assert all(abs(K - v) > 1e-6 for v in (-1.0, 0.0, 1.0))
+
+
+def test_non_finite_training_raises_like_the_reference(dev, tmp_path):
+    """The reference asserts isfinite on the loss every step (vae.py:158); this build reports the same condition, with
+    the same exception type, from the epoch's running sums (no per-step host sync)."""
+    from mvae_amd import utils
+    from mvae_amd.data import DeviceLoader
+    from mvae_amd.models import FeedForwardVAE
+    from mvae_amd.trainer import Trainer
+    x = (torch.rand(8, 784, generator=torch.Generator().manual_seed(0)) * 255).to(torch.uint8).to(dev)
+    y = torch.zeros(8, dtype=torch.int64, device=dev)
+    train = DeviceLoader(x, y, 4, train=True, binarize=True, seed=1)
+    m = FeedForwardVAE(8, utils.parse_components("h2,e2", False), _DS(), False).to(dev)
+    with torch.no_grad():
+        m.fc_e0.bias.fill_(float("nan"))
+    tr = Trainer(m, chkpt_dir=str(tmp_path))
+    opt = tr.build_optimizer(1e-3, fixed_curvature=False)
+    with pytest.raises(AssertionError):
+        tr.train_epochs(opt, train, train, betas=[1.0], epochs=1, likelihood_n=0)
