@@ -5,11 +5,12 @@
 //
 //   1 k_enc_fwd     h  = relu(x W_e0^T + b)                      MFMA NT, 16x16 tile / workgroup, 8 waves split K
 //   2 k_latent_fwd  one batch ROW per workgroup: heads = h W_heads^T + b -> per-component exp_map_mu0 / softplus /
-//                   wrapped-normal sample / KL -> concat_z -> hd = relu(z W_d0^T + b)
+//                   wrapped-normal sample / KL -> concat_z -> hd = relu(z W_d0^T + b); waves 4..7 evaluate the same
+//                   components over dual numbers (d z, d kl per input direction) for launch 5
 //   3 k_dec1_fwd    logits = hd W_logits^T + b ; BCE-with-logits row partials ; g = sigmoid(logits) - x
 //   4 k_dec1_bwd    dhd = (g W_logits) * [hd>0] ; db_logits (+Adam) ; step statistics (BatchStats)
-//   5 k_latent_bwd  rows: dz = dhd W_d0 -> component backward (forward-mode duals, one lane per input direction)
-//                   -> dheads ; dh = (dheads W_heads) * [h>0]      tiles: dW_logits = g^T hd (+Adam)
+//   5 k_latent_bwd  rows: dz = dhd W_d0 -> contraction with the dual records of launch 2 -> dheads ;
+//                   dh = (dheads W_heads) * [h>0]                  tiles: dW_logits = g^T hd (+Adam)
 //   6 k_enc_bwd     dW_e0 = dh^T x, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
 //
 // In the single-GPU step the optimizer runs in the gradient epilogues, each weight one launch after its last read;
@@ -1477,8 +1478,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
 // ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
 // workgroup) ; dW_logits = g^T hd (+Adam: W_logits was last read by launch 4)
 template <int DMAX, bool FAST, bool ADAM>  // FAST also implies tile-aligned B, H, D (checked on the host)
-__global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, const float* heads,
-                                                    int ldh, const float* eps, int eps_ld, const float* radii,
+__global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, int ldh,
                                                     const float* h, const float* Wh, float* dheads, float* dh,
                                                     float* drpart, const float* g, const float* hd, float* dWl,
                                                     float beta, int B, int H, int D, int NH, int Z, int n_rows,
@@ -1906,7 +1906,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 1024 + 8) * sizeof(float);  // dhd row | dz partials
 #define LB(DM, FA, AD)                                                                                              \
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, c->t, dhd, P + d.off_w_d0,      \
-                     heads, c->ldh, eps, d.eps_dim, P + d.off_radii, h, P + d.off_w_heads, dheads, dh, drpart, g,   \
+                     c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
     if (fast_b) {
       if (fused) { DMAX_SWITCH(c->dmax, LB(DM, true, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, true, false)); }
