@@ -280,3 +280,38 @@ def test_non_finite_training_raises_like_the_reference(dev, tmp_path):
     opt = tr.build_optimizer(1e-3, fixed_curvature=False)
     with pytest.raises(AssertionError):
         tr.train_epochs(opt, train, train, betas=[1.0], epochs=1, likelihood_n=0)
+
+
+def test_stdout_log_lines_parse_like_read_log(dev, tmp_path, capsys):
+    """The epoch lines the Trainer prints are what mt/visualization/read_log.py:53-75 parses (lower-cased line starts
+    with 'epoch ' / 'trainepoch ', ends with '}', the part after the first ':' is a dict literal whose keys include
+    bce / kl / elbo / ll / mi and one 'comp_XXX_<shortcut>/curvature' per component)."""
+    from mvae_amd import utils
+    from mvae_amd.data import DeviceLoader
+    from mvae_amd.models import FeedForwardVAE
+    from mvae_amd.trainer import Trainer
+    x = (torch.rand(8, 784, generator=torch.Generator().manual_seed(0)) * 255).to(torch.uint8).to(dev)
+    y = torch.zeros(8, dtype=torch.int64, device=dev)
+    train = DeviceLoader(x, y, 4, train=True, binarize=True, seed=1)
+    m = FeedForwardVAE(8, utils.parse_components("e2,h2,s2", True), _DS(), False).to(dev)
+    tr = Trainer(m, chkpt_dir=str(tmp_path))
+    opt = tr.build_optimizer(1e-3, fixed_curvature=True)
+    tr.train_epochs(opt, train, train, betas=[1.0], epochs=2, likelihood_n=2)
+    out = capsys.readouterr().out
+    parsed = {"epoch": [], "trainepoch": []}
+    for line in out.splitlines():
+        line = line.strip().lower()
+        if not line.endswith("}"):
+            continue
+        kind = "epoch" if line.startswith("epoch ") else ("trainepoch" if line.startswith("trainepoch ") else None)
+        if kind is None:
+            continue
+        idx = line.find(":")
+        d = eval(line[idx + 1:].strip())  # the reference parser does exactly this
+        d["epoch"] = int(line[:idx].strip().split(" ")[1])
+        parsed[kind].append(d)
+    assert [d["epoch"] for d in parsed["trainepoch"]] == [0, 1] and len(parsed["epoch"]) == 1
+    want = {"epoch", "bce", "kl", "elbo", "ll", "mi", "comp_000_e2/curvature", "comp_001_h2/curvature",
+            "comp_002_s2/curvature"}
+    for d in parsed["trainepoch"] + parsed["epoch"]:
+        assert want <= set(d.keys())
