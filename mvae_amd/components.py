@@ -159,6 +159,24 @@ class StereographicallyProjectedSphereComponent(Component):  # component.py:170-
         return f"d{self.true_dim}"
 
 
+class ConstantComponent(Component):  # component.py:206-222
+    """Parses and constructs like the reference's, and -- like the reference's -- cannot be wired into a model:
+    `init_layers` instantiates EuclideanConstantProcedure(manifold, scalar_parametrization) without the `dim` argument
+    its constructor requires (sampling_procedures.py:119-131), a TypeError in both code bases."""
+    LETTER = "c"
+
+    def __init__(self, dim: int, fixed_curvature: bool, sampling_procedure: Type, const: Optional[Tensor] = None,
+                 eps: Optional[Tensor] = None) -> None:
+        super().__init__(dim, fixed_curvature=False, sampling_procedure=sampling_procedure)
+
+    def create_manifold(self) -> Manifold:
+        return Euclidean()
+
+    @property
+    def true_dim(self) -> int:
+        return self.dim
+
+
 class UniversalComponent(Component):  # component.py:225-242
     LETTER = "u"
 

@@ -45,6 +45,16 @@ class EuclideanNormalProcedure(SamplingProcedure):
     pass
 
 
+class EuclideanConstantProcedure(SamplingProcedure):
+    """sampling_procedures.py:117-143.  Same constructor signature as the reference's -- including the required `dim`
+    that Component.init_layers does not pass, which is why the `c` component cannot be instantiated there either.  The
+    uniform-box distributions behind it are not built."""
+
+    def __init__(self, manifold, scalar_parametrization: bool, dim: int, const=None, eps=None) -> None:
+        super().__init__(manifold, scalar_parametrization)
+        raise NotImplementedError("EuclideanConstantProcedure (an ablation stub of the reference) is not built")
+
+
 class UniversalSamplingProcedure(SamplingProcedure):
     """sampling_procedures.py:184-206: wrapped normal on the Poincare ball / projected sphere or the Euclidean normal
     procedure, by the sign of the component's curvature.  The fused component operator takes that decision on the

@@ -5,18 +5,20 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
-from .components import (Component, EuclideanComponent, HyperbolicComponent, PoincareComponent, SphericalComponent,
-                         StereographicallyProjectedSphereComponent, UniversalComponent)
-from .sampling import EuclideanNormalProcedure, UniversalSamplingProcedure, WrappedNormalProcedure
+from .components import (Component, ConstantComponent, EuclideanComponent, HyperbolicComponent, PoincareComponent,
+                         SphericalComponent, StereographicallyProjectedSphereComponent, UniversalComponent)
+from .sampling import (EuclideanConstantProcedure, EuclideanNormalProcedure, UniversalSamplingProcedure,
+                       WrappedNormalProcedure)
 
-# utils.py:30-48.  c (the constant component, an ablation stub of the reference) is outside this build's scope
-#  and raises NotImplementedError like any unknown letter does in the reference.
+# utils.py:30-48.  `c` parses and constructs as in the reference and fails in init_layers as in the reference
+# (TypeError: EuclideanConstantProcedure needs a `dim` that Component.init_layers never passes).
 space_creator_map = {
     "h": HyperbolicComponent,
     "u": UniversalComponent,
     "s": SphericalComponent,
     "d": StereographicallyProjectedSphereComponent,
     "p": PoincareComponent,
+    "c": ConstantComponent,
     "e": EuclideanComponent,
 }
 sampling_procedure_map = {
@@ -25,9 +27,9 @@ sampling_procedure_map = {
     EuclideanComponent: EuclideanNormalProcedure,
     HyperbolicComponent: WrappedNormalProcedure,
     PoincareComponent: WrappedNormalProcedure,
+    ConstantComponent: EuclideanConstantProcedure,
     UniversalComponent: UniversalSamplingProcedure,
 }
-_REFERENCE_ONLY = ("c",)
 
 
 def set_seeds(seed: int) -> None:  # utils.py:56-59
@@ -71,8 +73,6 @@ def parse_components(arg: str, fixed_curvature: bool) -> List[Component]:  # uti
             raise ValueError(f"Space multiplier has to be at least 1, was: '{mult}'.")
         if dim < 1:
             raise ValueError(f"Dimension has to be at least 1, was: '{dim}'.")
-        if letter in _REFERENCE_ONLY:
-            raise NotImplementedError(f"Latent space type '{letter}' is not part of the MI355X hot-path build yet.")
         if letter not in space_creator_map:
             raise NotImplementedError(f"Unknown latent space type '{letter}'.")
         creator = space_creator_map[letter]

@@ -22,10 +22,6 @@ def test_parse_components_table():
     """Reference tests/mvae/test_utils.py + golden table recorded from the reference parser."""
     tab = load_json("g5_parser.json")
     for s, ref in tab["parse"].items():
-        if any(c["shortcut"][0] == "c" for c in ref["components"]):  # the constant component is not built
-            with pytest.raises(NotImplementedError):
-                utils.parse_components(s, False)
-            continue
         comps = utils.parse_components(s, fixed_curvature=False)
         assert utils.canonical_name(comps) == ref["canonical"]
         for c, r in zip(comps, ref["components"]):
@@ -40,6 +36,15 @@ def test_parse_components_table():
         a, b, c, d = k.split(",")
         got = utils.linear_betas(float(a), float(b), int(c), int(d))
         assert np.allclose(got[:len(v)], v)
+
+
+def test_constant_component_fails_where_the_reference_fails():
+    """`c` parses, but Component.init_layers cannot build its sampling procedure (missing `dim`): a TypeError in the
+    reference (component.py:48-50 + sampling_procedures.py:119-131) and here."""
+    comp = utils.parse_components("c3", False)[0]
+    assert type(comp).__name__ == "ConstantComponent" and comp._shortcut() == "c3"
+    with pytest.raises(TypeError):
+        comp.init_layers(8, scalar_parametrization=False)
 
 
 def test_fixed_curvature_freezes_radii():
