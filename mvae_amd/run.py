@@ -80,7 +80,9 @@ def main(argv=None) -> None:
                       scalar_parametrization=args.scalar_parametrization).to(device)
     if args.seed:
         model.seed_sampler(args.seed)
-    trainer = Trainer(model, img_dims=dataset.img_dims, chkpt_dir=chkpt_dir, test_every=args.test_every)
+    trainer = Trainer(model, img_dims=dataset.img_dims, chkpt_dir=chkpt_dir, train_statistics=args.train_statistics,
+                      show_embeddings=args.show_embeddings, export_embeddings=args.export_embeddings,
+                      test_every=args.test_every)
     optimizer = trainer.build_optimizer(learning_rate=args.learning_rate, fixed_curvature=args.fixed_curvature)
     train_loader, test_loader = dataset.create_loaders(seed=args.seed)
     betas = utils.linear_betas(args.beta_start, args.beta_end, end_epoch=args.beta_end_epoch, epochs=args.epochs)

@@ -46,6 +46,11 @@ class Trainer:
         self.epoch = 0
         self.global_step = 0
         self.test_every = test_every
+        # stats.py:35-52: tensorboard-side options.  The projector / figure output (`show_embeddings`) is outside the
+        # hot-path scope; the representation export (`export_embeddings`: every N-th test epoch) is built.
+        self.show_embeddings = show_embeddings
+        self.export_embeddings = export_embeddings
+        self.test_epochs = 0
         os.makedirs(chkpt_dir, exist_ok=True)
 
     # ---- checkpoints (train.py:57-77): model weights only, `{epoch}.chkpt`
@@ -173,8 +178,36 @@ class Trainer:
         epoch_stats = EpochStats(sums, length=len(test_data.dataset), beta=beta, log_likelihood=ll, mutual_info=mi,
                                  cov_norm=cn)
         print(self._epoch_dict(epoch_stats), flush=True)
+        if self.export_embeddings > 0 and self.test_epochs % self.export_embeddings == 0:  # train.py:288-291
+            self._export_representations(test_data)
         self.model.train()
+        self.test_epochs += 1
         return epoch_stats
+
+    def _export_representations(self, data, mode: str = "eval") -> None:
+        """train.py:297-325: posterior locations per component, the concatenated sample and the labels of every batch,
+        as `<chkpt_dir>/repr/<mode>_<component|total|labels>_<epoch>.pt` (what mt/data/representation_dataset.py reads)."""
+        print(f"\tExporting {mode} representations...")
+        self.model.eval()
+        repr_folder = os.path.join(self.chkpt_dir, "repr")
+        os.makedirs(repr_folder, exist_ok=True)
+
+        def _filename(component: str) -> str:
+            return os.path.join(repr_folder, f"{mode}_{component}_{self.epoch}.pt")
+
+        per_comp = [[] for _ in self.model.components]
+        totals, labels = [], []
+        with torch.no_grad():
+            for x_mb, y_mb in data:
+                reps, concat_z, _ = self.model(x_mb)
+                for i, r in enumerate(reps):
+                    per_comp[i].append(r.q_z.loc.to("cpu"))
+                totals.append(concat_z.to("cpu"))
+                labels.append(y_mb.to("cpu"))
+        torch.save(torch.cat(totals, dim=0), _filename("total"))
+        torch.save(torch.cat(labels, dim=0), _filename("labels"))
+        for i, component in enumerate(self.model.components):
+            torch.save(torch.cat(per_comp[i], dim=0), _filename(component.summary_name(i)))
 
     def _try_test_during_train(self, test_results, eval_data, likelihood_n, betas) -> None:
         if self.test_every > 0 and self.epoch % self.test_every == 0:

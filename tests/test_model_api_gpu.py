@@ -315,3 +315,26 @@ def test_stdout_log_lines_parse_like_read_log(dev, tmp_path, capsys):
             "comp_002_s2/curvature"}
     for d in parsed["trainepoch"] + parsed["epoch"]:
         assert want <= set(d.keys())
+
+
+def test_export_representations(dev, tmp_path):
+    """train.py:297-325: files, shapes and contents of the representation export."""
+    from mvae_amd import utils
+    from mvae_amd.data import DeviceLoader
+    from mvae_amd.models import FeedForwardVAE
+    from mvae_amd.trainer import Trainer
+    x = (torch.rand(10, 784, generator=torch.Generator().manual_seed(0)) * 255).to(torch.uint8).to(dev)
+    y = torch.arange(10, device=dev)
+    data = DeviceLoader(x, y, 4, train=False, binarize=True)
+    m = FeedForwardVAE(8, utils.parse_components("h2,e3", True), _DS(), False).to(dev)
+    m.seed_sampler(1)
+    tr = Trainer(m, chkpt_dir=str(tmp_path), export_embeddings=1)
+    tr._test_epoch(data, likelihood_n=0, beta=1.0)
+    rep = os.path.join(str(tmp_path), "repr")
+    assert sorted(os.listdir(rep)) == ["eval_comp_000_h2_0.pt", "eval_comp_001_e3_0.pt", "eval_labels_0.pt",
+                                       "eval_total_0.pt"]
+    assert torch.equal(torch.load(os.path.join(rep, "eval_labels_0.pt")), torch.arange(10))
+    h = torch.load(os.path.join(rep, "eval_comp_000_h2_0.pt"))
+    assert h.shape == (10, 3) and torch.load(os.path.join(rep, "eval_total_0.pt")).shape == (10, 6)
+    R = float(m.components[0].manifold.radius)
+    assert torch.allclose(-h[:, 0]**2 + (h[:, 1:]**2).sum(-1), torch.full((10,), -R * R), rtol=1e-4)  # on the hyperboloid
