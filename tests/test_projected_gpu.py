@@ -136,19 +136,21 @@ def _state_with_curvatures(spec, ks):
     return st
 
 
+@pytest.mark.parametrize("scalar", [False, True])
 @pytest.mark.parametrize("model,ks,B,D,H", [("d2,u2,p2", [-0.3], 16, 32, 16), ("3u2", [-0.5, 0.6, 0.0], 16, 32, 16),
                                             ("u2,d3,h2,s2,e2", [0.4], 128, 784, 400),
                                             ("2u3,2d2", [-1.0, 0.8], 32, 784, 400)])
-def test_fused_step_vs_oracle(dev, model, ks, B, D, H):
+def test_fused_step_vs_oracle(dev, model, ks, B, D, H, scalar):
     """Whole train steps (epoch >= 10: curvature SGD active, clip_grad_norm_ on the universal curvatures) against the
     oracle: ELBO, per-component KL sums, gradients after one step, parameters after three."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
     from oracle import model as M
-    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False)
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False, scalar_parametrization=scalar)
     st = _state_with_curvatures(spec, ks)
     comps = [(c.letter, c.true_dim) for c in spec.components]
-    eng = StepEngine(comps, D, H, dev, radius_trainable=[c.letter != "e" for c in spec.components])
+    eng = StepEngine(comps, D, H, dev, scalar_parametrization=scalar,
+                     radius_trainable=[c.letter != "e" for c in spec.components])
     eng.load_state(st)
     orc = M.StepOracle(spec, st)
     xs = synthetic.binary_batches(3, B, D)
