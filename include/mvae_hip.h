@@ -219,7 +219,8 @@ typedef struct mvae_model_desc {
   const mvae_component_desc* comps; /* HOST pointer, copied */
   /* offsets (in floats) into the flat buffers; every matrix row-major, torch.nn.Linear layout [out, in] */
   int64_t off_radii;    /* MUST be 0: the first 64 floats hold the raw radius parameters, entry i = component i
-                           (components.{i}._nradius/_pradius); comps[i].radius_idx == i                         */
+                           (components.{i}._nradius/_pradius, or _curvature for MVAE_UNIVERSAL);
+                           comps[i].radius_idx == i                                                             */
   int64_t off_w_heads;  /* [NH, H]            fc_mean rows of every component, then fc_logvar rows             */
   int64_t off_b_heads;  /* [NH]                                                                                */
   int64_t off_w_e0;     /* [H, D]             fc_e0                                                            */
@@ -235,7 +236,8 @@ typedef struct mvae_model_desc {
   int32_t* step_count;  /* [32] device-side so that a captured graph advances it; zeroed by the host at creation:
                            [0] Adam step counter, [1] arrival scratch, [2..3] this step's {-lr/bc1, sqrt(bc2)} as
                            float bits, [8] batch cursor of mvae_prepare_batch, [16..31] arrival scratch          */
-  float* workspace;     /* [mvae_workspace_floats(desc)] activations + partial sums                            */
+  float* workspace;     /* [mvae_workspace_floats(desc)] activations, partial sums and the per-direction dual records
+                           {d kl, d z} of the latent components (written by the forward, contracted by the backward) */
   float* stats;         /* [2 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
                            same record for the LAST step only (stats.py:120-127 without the per-step .item() syncs:
                            the host reads it when it wants to, e.g. once per epoch)                             */
@@ -260,8 +262,9 @@ int mvae_step_forward_backward(mvae_ctx* ctx, const float* x, const float* eps, 
                                float* logits, float* concat_z, float* bce, float* kl, void* stream);
 
 /* optimizer: fused Adam over the flat buffer (radii excluded) + SGD(lr=curvature_lr) on trainable radii iff
- * do_curvature_step (the reference's `not fixed_curvature and epoch >= 10`, train.py:357-358).  In data-parallel runs
- * the host all-reduces `grads` (SUM) between the two calls. */
+ * do_curvature_step (the reference's `not fixed_curvature and epoch >= 10`, train.py:357-358); the gradients of
+ * universal curvatures are first clipped to joint L2 norm 1, in place (vae.py:161-163).  In data-parallel runs the
+ * host all-reduces `grads` (SUM) between the two calls. */
 int mvae_step_optimizer(mvae_ctx* ctx, int do_curvature_step, void* stream);
 
 /* Both of the above back to back (single-GPU ModelVAE.train_step). */
