@@ -107,8 +107,13 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
         b[g] = Q[(size_t)mm * ldq + q0 + i];
         a[g] = m_ok ? av : 0.f;
       } else {
-        a[g] = (p_ok && m_ok) ? P[(size_t)m * ldp + p0 + i] : 0.f;
-        b[g] = (q_ok && m_ok) ? Q[(size_t)m * ldq + q0 + i] : 0.f;
+        // ragged tile: the same branch-free form with the column clamped too (a guarded load is an exec-mask branch
+        // with its own wait; 64 of them made the few ragged tiles of launch 6 its longest workgroups)
+        const int mm = m_ok ? m : 0;
+        const float av = P[(size_t)mm * ldp + (p_ok ? p0 + i : 0)];
+        const float bv = Q[(size_t)mm * ldq + (q_ok ? q0 + i : 0)];
+        a[g] = (p_ok && m_ok) ? av : 0.f;
+        b[g] = (q_ok && m_ok) ? bv : 0.f;
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -35,11 +35,22 @@ using namespace mv;
 #ifdef MV_DBG_TIMING
 __device__ unsigned long long g_dbg[64];
 #define MV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+#define MV_STAMP_B(i, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+// start / end time and kind of every workgroup of launch 6 (plain stores to per-workgroup slots: no contention)
+__device__ unsigned long long g_span[3][2048];
+#define MV_SPAN_BEGIN(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_span[0][blockIdx.x] = wall_clock64(); } while (0)
+#define MV_SPAN_END(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[1][blockIdx.x] = wall_clock64(); g_span[2][blockIdx.x] = (i); } } while (0)
 extern "C" int mvae_debug_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
 }
+extern "C" int mvae_debug_read_spans(unsigned long long* out /* [3][2048] */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 3 * 2048);
+}
 #else
 #define MV_STAMP(i) do {} while (0)
+#define MV_STAMP_B(i, blk) do {} while (0)
+#define MV_SPAN_BEGIN(i) do {} while (0)
+#define MV_SPAN_END(i) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -857,6 +868,13 @@ __device__ __forceinline__ float clip_coef(const CompTable& t, const float* g) {
 // ---------------------------------------------------------------------------------------------- step tile jobs
 // 8-wave (512-thread) variants for the long contractions (K = 784 / 400): every wave issues ALL of its operand loads
 // up front (<= 7 k-chunks per wave) and the eight partial tiles meet in LDS.
+// Waves per workgroup of the wave-level dW tiles.  A CU's load path saturates with two tile workgroups (measured in
+// launch 6: the ~50 CUs that received a second 4-wave workgroup finished at 4.6 us, the rest at 2.9 us), so launch 6
+// is sized to put ONE tile workgroup on every CU: 1225 tiles / 5 waves = 250 workgroups for 256 CUs (6.8 -> 5.6 us
+// together with the branch-free ragged tiles).  Launch 5 shares its CUs with the 128 row workgroups either way and
+// measured better with 4-wave tile workgroups (6.3 vs 7.2 us).
+constexpr int kTileWaves = 5;    // launch 6
+constexpr int kTileWaves5 = 4;   // launch 5
 constexpr int kW8 = 8;
 __device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) {
   const int tid = threadIdx.x;
@@ -886,6 +904,7 @@ template <bool ADAM, bool FULL = false>
 __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int pt, const float* Q, int ldq, int NQ,
                                             int qt, int Mrows, float* out, int ldo, const AdamArgs& aa) {
   if (qt * 16 >= NQ) return;
+  MV_STAMP_B(16, 200);
   const int lane = threadIdx.x & 63;
   const int pr = pt * 16 + (lane & 15), qc0 = qt * 16 + ((lane >> 4) << 2);
   const bool pok = pr < NP;
@@ -916,6 +935,7 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = tile_tn<32, FULL>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
+  MV_STAMP_B(17, 200);
   if (ADAM) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
@@ -939,6 +959,7 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
         }
       }
   }
+  MV_STAMP_B(18, 200);
 }
 
 // bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16
@@ -1478,7 +1499,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
 // ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
 // workgroup) ; dW_logits = g^T hd (+Adam: W_logits was last read by launch 4)
 template <int DMAX, bool FAST, bool ADAM>  // FAST also implies tile-aligned B, H, D (checked on the host)
-__global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, int ldh,
+__global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, int ldh,
                                                     const float* h, const float* Wh, float* dheads, float* dh,
                                                     float* drpart, const float* g, const float* hd, float* dWl,
                                                     float beta, int B, int H, int D, int NH, int Z, int n_rows,
@@ -1495,11 +1516,12 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
-    const int ntH4 = ((H + 15) / 16 + 3) / 4;
-    if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
-    else job_tn_wave<ADAM, false>(g, D, D, b / ntH4, hd, H, H, (b % ntH4) * 4 + wave, B, dWl, H, awl);
+    const int ntHg = ((H + 15) / 16 + kTileWaves5 - 1) / kTileWaves5;
+    if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
+    else job_tn_wave<ADAM, false>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
     return;
   }
+  if (tid >= 256) return;  // the row path is written for 4 waves
   const size_t row = b;
   MV_STAMP(8);
   const int H4 = (H + 3) & ~3;
@@ -1702,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd(CompTable t, const float* dh
 
 // ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
 template <bool ADAM, bool FULL>
-__global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
+__global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
                                                  int ldh, const float* h, const float* dhd, const float* z, int ldz,
                                                  const float* drpart, float* G, float* P, int B, int H, int D, int NH,
                                                  int Z, int n_we0, int n_wh, int n_wd0, int n_be0, int n_bh, int n_bd0,
@@ -1712,6 +1734,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
   __shared__ float red[4][16][17];
   __shared__ float sh2[2];
   int b = blockIdx.x;
+  MV_SPAN_BEGIN(23);
   auto at = [&](int64_t off) {
     AdamArgs a = base;
     a.p += off;
@@ -1720,38 +1743,44 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
     return a;
   };
   if (b < n_we0) {  // dW_e0[H,D] = dh^T x
-    const int ntD4 = ((D + 15) / 16 + 3) / 4;
-    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntD4, x, D, D, (b % ntD4) * 4 + (threadIdx.x >> 6), B, G + off_w_e0, D,
+    const int ntDg = ((D + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntDg, x, D, D, (b % ntDg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_e0, D,
                             at(off_w_e0));
+    MV_SPAN_END(24);
     return;
   }
   b -= n_we0;
   if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
-    const int ntH4 = ((H + 15) / 16 + 3) / 4;
-    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntH4, h, H, H, (b % ntH4) * 4 + (threadIdx.x >> 6), B, G + off_w_heads, H,
+    const int ntHg = ((H + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntHg, h, H, H, (b % ntHg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_heads, H,
                       at(off_w_heads));
+    MV_SPAN_END(25);
     return;
   }
   b -= n_wh;
   if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
-    const int ntZ4 = ((Z + 15) / 16 + 3) / 4;
-    job_tn_wave<ADAM>(dhd, H, H, b / ntZ4, z, ldz, Z, (b % ntZ4) * 4 + (threadIdx.x >> 6), B, G + off_w_d0, Z,
+    const int ntZg = ((Z + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dhd, H, H, b / ntZg, z, ldz, Z, (b % ntZg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_d0, Z,
                       at(off_w_d0));
+    MV_SPAN_END(26);
     return;
   }
   b -= n_wd0;
   if (b < n_be0) {
     job_colsum_opt<ADAM>(&red[0][0][0], dh, H, B, H, b * kColsPerBlock, G + off_b_e0, at(off_b_e0));
+    MV_SPAN_END(27);
     return;
   }
   b -= n_be0;
   if (b < n_bh) {
     job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, b * kColsPerBlock, G + off_b_heads, at(off_b_heads));
+    MV_SPAN_END(28);
     return;
   }
   b -= n_bh;
   if (b < n_bd0) {
     job_colsum_opt<ADAM>(&red[0][0][0], dhd, H, B, H, b * kColsPerBlock, G + off_b_d0, at(off_b_d0));
+    MV_SPAN_END(29);
     return;
   }
   // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
@@ -1763,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
     gsh[tid] = 0.f;
   }
   __syncthreads();
-  for (int ci = wave; ci < t.n; ci += 4) {
+  for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
     if (!t.trainable[ci]) continue;
     float s = 0.f;
     for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
@@ -1777,6 +1806,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(CompTable t, const float* dh, c
     G[tid] = s;
     if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
   }
+  MV_SPAN_END(30);
 }
 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
@@ -1902,10 +1932,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #undef DB
   }
   {
-    const int n_dwl = c->nt_d * ((c->nt_h + 3) / 4);
+    const int n_dwl = c->nt_d * ((c->nt_h + kTileWaves5 - 1) / kTileWaves5);
     const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 1024 + 8) * sizeof(float);  // dhd row | dz partials
 #define LB(DM, FA, AD)                                                                                              \
-  STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(256), lds, c->t, dhd, P + d.off_w_d0,      \
+  STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
     if (fast_b) {
@@ -1916,13 +1946,14 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #undef LB
   }
   {
-    const int n_we0 = c->nt_h * ((c->nt_d + 3) / 4), n_wh = ((NH + 15) / 16) * ((c->nt_h + 3) / 4),
-              n_wd0 = c->nt_h * (((Z + 15) / 16 + 3) / 4);
+    const int tw = kTileWaves;
+    const int n_we0 = c->nt_h * ((c->nt_d + tw - 1) / tw), n_wh = ((NH + 15) / 16) * ((c->nt_h + tw - 1) / tw),
+              n_wd0 = c->nt_h * (((Z + 15) / 16 + tw - 1) / tw);
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
 #define EB(AD, FU)                                                                                                   \
-  STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(256), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz,     \
+  STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(64 * kTileWaves), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz, \
                      drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
                      d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
     if (fused) { if (full) EB(true, true); else EB(true, false); }
