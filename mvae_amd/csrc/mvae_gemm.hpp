@@ -97,30 +97,28 @@ __device__ __forceinline__ f32x4 tile_tn(const float* __restrict__ P, int ldp, i
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
   for (int s = step0; s < nsteps; s += stride * G) {
     float a[G], b[G];
+    // requests: branch-free, indices past the end clamped to valid addresses.  NO select on a loaded value in this
+    // block -- it would need the value and so serialise the requests; the masks are applied after the barrier.
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int m = ((s + g * stride) << 2) + q;
-      const bool m_ok = m < Mrows;
-      if (FULL) {  // all columns exist; a row past the end is clamped and zeroed
-        const int mm = m_ok ? m : 0;
-        const float av = P[(size_t)mm * ldp + p0 + i];
+      const int mm = (m < Mrows) ? m : 0;
+      if (FULL) {  // all columns exist
+        a[g] = P[(size_t)mm * ldp + p0 + i];
         b[g] = Q[(size_t)mm * ldq + q0 + i];
-        a[g] = m_ok ? av : 0.f;
       } else {
-        // ragged tile: the same branch-free form with the column clamped too (a guarded load is an exec-mask branch
-        // with its own wait; 64 of them made the few ragged tiles of launch 6 its longest workgroups)
-        const int mm = m_ok ? m : 0;
-        const float av = P[(size_t)mm * ldp + (p_ok ? p0 + i : 0)];
-        const float bv = Q[(size_t)mm * ldq + (q_ok ? q0 + i : 0)];
-        a[g] = (p_ok && m_ok) ? av : 0.f;
-        b[g] = (q_ok && m_ok) ? bv : 0.f;
+        a[g] = P[(size_t)mm * ldp + (p_ok ? p0 + i : 0)];
+        b[g] = Q[(size_t)mm * ldq + (q_ok ? q0 + i : 0)];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < G; g += 2) {
-      acc = mfma16(a[g], b[g], acc);
-      if (g + 1 < G) acc2 = mfma16(a[g + 1], b[g + 1], acc2);
+    for (int g = 0; g < G; ++g) {  // mask, then multiply, in arrival order
+      const bool m_ok = (((s + g * stride) << 2) + q) < Mrows;
+      a[g] = (m_ok && (FULL || p_ok)) ? a[g] : 0.f;  // this lane's P column; a zero row factor covers m
+      if (!FULL) b[g] = q_ok ? b[g] : 0.f;           // this lane's Q column
+      if (g & 1) acc2 = mfma16(a[g], b[g], acc2);
+      else acc = mfma16(a[g], b[g], acc);
     }
   }
   return acc + acc2;

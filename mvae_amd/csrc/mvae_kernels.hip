@@ -36,21 +36,27 @@ using namespace mv;
 __device__ unsigned long long g_dbg[64];
 #define MV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
 #define MV_STAMP_B(i, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
-// start / end time and kind of every workgroup of launch 6 (plain stores to per-workgroup slots: no contention)
-__device__ unsigned long long g_span[3][2048];
-#define MV_SPAN_BEGIN(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_span[0][blockIdx.x] = wall_clock64(); } while (0)
-#define MV_SPAN_END(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[1][blockIdx.x] = wall_clock64(); g_span[2][blockIdx.x] = (i); } } while (0)
+#ifndef MV_STAMP_BLK
+#define MV_STAMP_BLK 200  // which workgroup of launches 5 / 6 stamps its wave-tile phases
+#endif
+// start / end time and kind of every workgroup of launch L (plain stores to per-workgroup slots: no contention)
+__device__ unsigned long long g_span[6][3][2048];
+#define MV_SPAN_BEGIN(L) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_span[L][0][blockIdx.x] = wall_clock64(); } while (0)
+#define MV_SPAN_END(L, kind) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[L][1][blockIdx.x] = wall_clock64(); g_span[L][2][blockIdx.x] = (kind); } } while (0)
+// the same for another thread of the workgroup, recorded `off` slots further (e.g. the dual waves of launch 2)
+#define MV_SPAN_END_T(L, kind, thr, off) do { if (threadIdx.x == (thr) && blockIdx.x + (off) < 2048) { g_span[L][0][blockIdx.x + (off)] = g_span[L][0][blockIdx.x]; g_span[L][1][blockIdx.x + (off)] = wall_clock64(); g_span[L][2][blockIdx.x + (off)] = (kind); } } while (0)
 extern "C" int mvae_debug_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
 }
-extern "C" int mvae_debug_read_spans(unsigned long long* out /* [3][2048] */) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 3 * 2048);
+extern "C" int mvae_debug_read_spans(unsigned long long* out /* [6][3][2048] */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 6 * 3 * 2048);
 }
 #else
 #define MV_STAMP(i) do {} while (0)
 #define MV_STAMP_B(i, blk) do {} while (0)
-#define MV_SPAN_BEGIN(i) do {} while (0)
-#define MV_SPAN_END(i) do {} while (0)
+#define MV_SPAN_BEGIN(L) do {} while (0)
+#define MV_SPAN_END(L, kind) do {} while (0)
+#define MV_SPAN_END_T(L, kind, thr, off) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -904,7 +910,7 @@ template <bool ADAM, bool FULL = false>
 __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int pt, const float* Q, int ldq, int NQ,
                                             int qt, int Mrows, float* out, int ldo, const AdamArgs& aa) {
   if (qt * 16 >= NQ) return;
-  MV_STAMP_B(16, 200);
+  MV_STAMP_B(16, MV_STAMP_BLK);
   const int lane = threadIdx.x & 63;
   const int pr = pt * 16 + (lane & 15), qc0 = qt * 16 + ((lane >> 4) << 2);
   const bool pok = pr < NP;
@@ -935,7 +941,7 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = tile_tn<32, FULL>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
-  MV_STAMP_B(17, 200);
+  MV_STAMP_B(17, MV_STAMP_BLK);
   if (ADAM) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
@@ -959,7 +965,7 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
         }
       }
   }
-  MV_STAMP_B(18, 200);
+  MV_STAMP_B(18, MV_STAMP_BLK);
 }
 
 // bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16
@@ -1031,6 +1037,7 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
   // Once per step: advance the counters and publish Adam's bias-correction scalars for the gradient epilogues of
   // launches 4-6 (double-precision pow / divide / sqrt: ~1 us for one lane -- done here by a padding workgroup of
   // the XCD-aware grid when there is one, so that it is off every critical path).
+  MV_SPAN_BEGIN(0);
   const bool real = xcd_tile((H + 15) / 16, (B + 15) / 16, &nt, &mt);
   const bool has_pad = (((H + 15) / 16) & 7) != 0;
   if (threadIdx.x == 0 && (has_pad ? blockIdx.x == gridDim.x - 1 : blockIdx.x == 0)) {
@@ -1056,6 +1063,7 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
       h[(size_t)m * H + n] = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
     }
   }
+  MV_SPAN_END(0, 1);
 }
 
 // wave-level sum (all 64 lanes end up with the total): DPP row operations + one readlane, ~50 cycles, instead of six
@@ -1106,6 +1114,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   float* eps_s = dyn + ((H + 3) & ~3);
   const bool vec = aligned16(Wh) && (H & 3) == 0;
   MV_STAMP(0);
+  MV_SPAN_BEGIN(1);
 
   // ---- dual waves (threads 256..511, launched iff duals != NULL).  Forward-mode derivatives need no upstream
   // gradient: d z / d(direction) and d kl / d(direction) of every (component, input direction) of this row depend only
@@ -1149,6 +1158,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
           if (i < A) rec[1 + i] = zd[i];
       }
     }
+    MV_SPAN_END_T(1, 2, 256, 1024);
     return;  // terminated waves do not count at the remaining barriers
   }
 
@@ -1356,6 +1366,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
     }
   }
   MV_STAMP(4);
+  MV_SPAN_END(1, 1);
 }
 
 // ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
@@ -1365,6 +1376,7 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
   int mt, nt;
+  MV_SPAN_BEGIN(2);
   if (!xcd_tile((D + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
   const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
   const bool ok = threadIdx.x < 256 && m < B && n < D;
@@ -1395,6 +1407,7 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
   if ((threadIdx.x & 15) == 0 && m < B) bce_part[(size_t)nt * B + m] = loss;
+  MV_SPAN_END(2, 1);
 }
 
 // ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
@@ -1406,6 +1419,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
   __shared__ float red[kW8][16][17];
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
+  MV_SPAN_BEGIN(3);
   if (b < n_dhd) {
     const int mt = b / ntH, nt = b % ntH;
     const int wave = threadIdx.x >> 6;
@@ -1418,11 +1432,13 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     acc = tile_nn<7, FULL>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
     const float s = reduce_tiles8(red, acc);
     if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
+    MV_SPAN_END(3, 1);
     return;
   }
   b -= n_dhd;
   if (b < n_db) {
     job_colsum_opt<ADAM>(&red[0][0][0], g, D, B, D, b * kColsPerBlock, db, ab);
+    MV_SPAN_END(3, 2);
     return;
   }
   // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo
@@ -1494,6 +1510,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     stats[last + 2] = elbo_sum;
     stats[last + 3] = 1.f;
   }
+  MV_SPAN_END(3, 3);
 }
 
 // ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
@@ -1514,11 +1531,13 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   __shared__ int first_s[kMaxComp + 1];  // first record of component i inside a row of `duals`
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MV_SPAN_BEGIN(4);
   if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
     const int ntHg = ((H + 15) / 16 + kTileWaves5 - 1) / kTileWaves5;
     if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
     else job_tn_wave<ADAM, false>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
+    MV_SPAN_END(4, 2);
     return;
   }
   if (tid >= 256) return;  // the row path is written for 4 waves
@@ -1720,6 +1739,7 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
     }
   }
   MV_STAMP(12);
+  MV_SPAN_END(4, 1);
 }
 
 // ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
@@ -1734,7 +1754,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
   __shared__ float red[4][16][17];
   __shared__ float sh2[2];
   int b = blockIdx.x;
-  MV_SPAN_BEGIN(23);
+  MV_SPAN_BEGIN(5);
   auto at = [&](int64_t off) {
     AdamArgs a = base;
     a.p += off;
@@ -1742,71 +1762,77 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
     a.v += off;
     return a;
   };
-  if (b < n_we0) {  // dW_e0[H,D] = dh^T x
-    const int ntDg = ((D + 15) / 16 + kTileWaves - 1) / kTileWaves;
-    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntDg, x, D, D, (b % ntDg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_e0, D,
-                            at(off_w_e0));
-    MV_SPAN_END(24);
+  // Workgroup order: the short jobs first, the 250 dW_e0 tile workgroups last.  The grid has ~80 more workgroups than
+  // the chip has CUs, so the last ones dispatched share a CU with the first ones: sharing with a short job costs a tile
+  // workgroup little, sharing with another tile workgroup (or a short job sharing with one) was the kernel's tail.
+  if (b == 0) {
+    // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
+    // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* gsh = &red[0][0][0];  // per-component batch sums
+    if (tid < kRadiiRegion) {
+      G[tid] = 0.f;
+      gsh[tid] = 0.f;
+    }
+    __syncthreads();
+    for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
+      if (!t.trainable[ci]) continue;
+      float s = 0.f;
+      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
+      s = wave_sum(s);
+      if (lane == 0) gsh[ci] = s;
+    }
+    __syncthreads();
+    if (tid < t.n && t.trainable[tid]) {
+      float s = gsh[tid];
+      if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
+      G[tid] = s;
+      if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
+    }
+    MV_SPAN_END(5, 7);
     return;
   }
-  b -= n_we0;
-  if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
-    const int ntHg = ((H + 15) / 16 + kTileWaves - 1) / kTileWaves;
-    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntHg, h, H, H, (b % ntHg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_heads, H,
-                      at(off_w_heads));
-    MV_SPAN_END(25);
+  b -= 1;
+  if (b < n_bd0) {
+    job_colsum_opt<ADAM>(&red[0][0][0], dhd, H, B, H, b * kColsPerBlock, G + off_b_d0, at(off_b_d0));
+    MV_SPAN_END(5, 6);
     return;
   }
-  b -= n_wh;
-  if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
-    const int ntZg = ((Z + 15) / 16 + kTileWaves - 1) / kTileWaves;
-    job_tn_wave<ADAM>(dhd, H, H, b / ntZg, z, ldz, Z, (b % ntZg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_d0, Z,
-                      at(off_w_d0));
-    MV_SPAN_END(26);
-    return;
-  }
-  b -= n_wd0;
+  b -= n_bd0;
   if (b < n_be0) {
     job_colsum_opt<ADAM>(&red[0][0][0], dh, H, B, H, b * kColsPerBlock, G + off_b_e0, at(off_b_e0));
-    MV_SPAN_END(27);
+    MV_SPAN_END(5, 4);
     return;
   }
   b -= n_be0;
   if (b < n_bh) {
     job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, b * kColsPerBlock, G + off_b_heads, at(off_b_heads));
-    MV_SPAN_END(28);
+    MV_SPAN_END(5, 5);
     return;
   }
   b -= n_bh;
-  if (b < n_bd0) {
-    job_colsum_opt<ADAM>(&red[0][0][0], dhd, H, B, H, b * kColsPerBlock, G + off_b_d0, at(off_b_d0));
-    MV_SPAN_END(29);
+  if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
+    const int ntZg = ((Z + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dhd, H, H, b / ntZg, z, ldz, Z, (b % ntZg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_d0, Z,
+                      at(off_w_d0));
+    MV_SPAN_END(5, 3);
     return;
   }
-  // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
-  // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float* gsh = &red[0][0][0];  // per-component batch sums
-  if (tid < kRadiiRegion) {
-    G[tid] = 0.f;
-    gsh[tid] = 0.f;
+  b -= n_wd0;
+  if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
+    const int ntHg = ((H + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntHg, h, H, H, (b % ntHg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_heads, H,
+                      at(off_w_heads));
+    MV_SPAN_END(5, 2);
+    return;
   }
-  __syncthreads();
-  for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
-    if (!t.trainable[ci]) continue;
-    float s = 0.f;
-    for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
-    s = wave_sum(s);
-    if (lane == 0) gsh[ci] = s;
+  b -= n_wh;
+  {  // dW_e0[H,D] = dh^T x
+    const int ntDg = ((D + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntDg, x, D, D, (b % ntDg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_e0, D,
+                            at(off_w_e0));
+    MV_SPAN_END(5, 1);
   }
-  __syncthreads();
-  if (tid < t.n && t.trainable[tid]) {
-    float s = gsh[tid];
-    if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
-    G[tid] = s;
-    if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
-  }
-  MV_SPAN_END(30);
 }
 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce

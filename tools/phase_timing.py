@@ -30,26 +30,27 @@ for i in range(N):
     v = [int(x) for x in buf]
     d = [(v[1]-v[0]), (v[2]-v[1]), (v[3]-v[2]), (v[4]-v[3]), (v[9]-v[8]), (v[10]-v[9]), (v[11]-v[10]), (v[12]-v[11]),
          (v[17]-v[16]), (v[18]-v[17])]
-    sp = (C.c_ulonglong * (3 * 2048))()
+    sp = (C.c_ulonglong * (6 * 3 * 2048))()
     lib.mvae_debug_read_spans(sp)
-    st, en, kd = sp[0:2048], sp[2048:4096], sp[4096:6144]
-    t0 = min(t for t, k in zip(st, kd) if k)
-    for kind in range(24, 31):
-        ends = [e - t0 for e, k in zip(en, kd) if k == kind]
-        starts = [t - t0 for t, k in zip(st, kd) if k == kind]
-        d.append(max(ends) if ends else 0)
-        d.append(max(starts) if starts else 0)
+    spans = {}
+    for L in range(6):
+        base = L * 3 * 2048
+        st, en, kd = sp[base:base + 2048], sp[base + 2048:base + 4096], sp[base + 4096:base + 6144]
+        used = [i for i in range(2048) if kd[i]]
+        t0 = min(st[i] for i in used)
+        for kind in sorted(set(kd[i] for i in used)):
+            ends = sorted((en[i] - t0) * 10 for i in used if kd[i] == kind)
+            spans.setdefault((L, kind), []).append((ends[len(ends) // 2], ends[-1], len(ends)))
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
 names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:dot", "bwd:dh",
-         "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores", "dW_e0 last end", "dW_e0 last start", "dW_heads last end", "dW_heads last start",
-         "dW_d0 last end", "dW_d0 last start", "b_e0 last end", "b_e0 last start", "b_heads last end",
-         "b_heads last start", "b_d0 last end", "b_d0 last start", "radii end", "radii start"]
+         "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores"]
 for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
-# distribution over the dW_e0 workgroups of the LAST step (10 ns ticks)
+KERNELS = ["enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd"]
+KINDS = {(0, 1): "tiles", (1, 1): "main waves", (1, 2): "dual waves", (2, 1): "tiles", (3, 1): "dhd tiles",
+         (3, 2): "db_logits", (3, 3): "statistics", (4, 1): "rows", (4, 2): "dW_logits tiles", (5, 1): "dW_e0 tiles",
+         (5, 2): "dW_heads", (5, 3): "dW_d0", (5, 4): "b_e0", (5, 5): "b_heads", (5, 6): "b_d0", (5, 7): "radii"}
 import numpy as np
-ends = np.array(sorted((e - t0) * 10 for e, k in zip(en, kd) if k == 24))
-print("dW_e0 workgroup end times (ns): min %d  p10 %d  p50 %d  p90 %d  p99 %d  max %d" %
-      (ends[0], *np.percentile(ends, [10, 50, 90, 99]), ends[-1]))
-idx = [i for i, k in enumerate(kd) if k == 24]
-late = sorted(idx, key=lambda i: en[i])[-12:]
-print("latest dW_e0 workgroups (block, end ns):", [(i, (en[i] - t0) * 10) for i in late])
+print("per launch: workgroup END time after the first workgroup's start, ns (median / latest over workgroups)")
+for (L, kind), v in sorted(spans.items()):
+    med = np.mean([x[0] for x in v]); mx = np.mean([x[1] for x in v])
+    print(f"  {KERNELS[L]:11s} {KINDS.get((L, kind), kind):16s} n={v[0][2]:4d}  median {med:7.0f}  latest {mx:7.0f}")
