@@ -109,6 +109,10 @@ def main():
                     help="latent space string; the driver's metric is the default (BASELINE configs[1]); "
                          "'e6' = configs[0], '6h2,6s2,6e2' = configs[3]")
     ap.add_argument("--fixed-curvature", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the GLOBAL batch stays 128 and is split by rows across the ranks (the "
+                         "configuration whose summed gradient equals the single-device step, SURVEY section 8d); the "
+                         "driver's contract is the default, weak scaling (128 rows per GPU)")
     ap.add_argument("--force-dp", action="store_true",
                     help="diagnostic: take the data-parallel route (gradients -> RCCL all-reduce -> k_optim) even at "
                          "world size 1")
@@ -148,8 +152,15 @@ def main():
     shapes = [(n, s) for n, _, s in eng.flat.entries]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0))
     n_data = max(args.graph_steps, 1) * 4  # distinct resident batches, cycled
-    xs = synthetic.digits_like_batches(n_data, B, seed=4321 + rank).to(dev)
-    eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
+    if args.strong and world > 1:
+        from mvae_amd.distributed import shard_rows
+        lo, hi = shard_rows(B, rank, world)  # every rank builds the same global batches and keeps its own rows
+        xs = synthetic.digits_like_batches(n_data, B, seed=4321)[:, lo:hi].contiguous().to(dev)
+        eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=0)[:, lo:hi].contiguous().to(dev)
+    else:
+        xs = synthetic.digits_like_batches(n_data, B, seed=4321 + rank).to(dev)
+        eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
+    strong = bool(args.strong and world > 1)
     runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not args.fixed_curvature,
                         graph_steps=args.graph_steps,
                         world_size=world, reset_every=args.reset_every, force_exchange=args.force_dp)
@@ -216,22 +227,23 @@ def main():
 
     line = {
         "metric": f"ELBO-steps/sec (batch 128) MNIST {args.model}",
-        "value": args.steps * world / dt,
+        "value": args.steps * (1 if strong else world) / dt,
         "unit": "ELBO-steps/sec",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: " if args.model == MODEL and not args.fixed_curvature else "") +
                                f"MNIST shapes (D=784), model {args.model}, "
                                f"{'fixed' if args.fixed_curvature else 'learnable'} curvature, "
-                               "MLP h_dim=400, batch 128 per GPU, epoch>=10 state",
-                   "global_batch": B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
+                               "MLP h_dim=400, " + ("global batch 128 split by rows" if strong else "batch 128 per GPU") +
+                               ", epoch>=10 state",
+                   "global_batch": B if strong else B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
                    "graph_steps": runner.gs,
                    "state_reset_every": args.reset_every,
                    "final_elbo_per_sample": stats["last"]["elbo"] / B},
