@@ -900,6 +900,14 @@ __device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) 
   return s;
 }
 
+// 16-byte store with the write-through cache policy, through a raw buffer descriptor built from the (wave-uniform)
+// base pointer; `idx` in floats (< 2^30).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(float* base, size_t idx, f32x4 v) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)(idx << 2), 0, /*aux: sc1*/ 16);
+}
+
 // dW tile per WAVE (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q].  The batch contraction (K = B = 128) is short
 // enough for one wave: 32 MFMA steps on two accumulators, all operand loads in flight at once, no LDS, no barrier.
 // The four waves of a workgroup take four neighbouring q-tiles (they share the P operand through L1).
@@ -947,11 +955,14 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
     for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
   }
   if (vec) {
-    *reinterpret_cast<float4*>(out + idx) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    // Write-through (sc1) 16-byte stores: nothing in this launch reads these lines again, and every line left dirty
+    // in the XCD's L2 has to be written back by the end-of-kernel release before the next launch may start -- with
+    // plain stores the 5 MB of g/p/m/v of one weight matrix cost ~2 us of idle chip after launches 5 and 6.
+    store16_wt(out, idx, acc);
     if (ADAM) {
-      *reinterpret_cast<float4*>(aa.p + idx) = make_float4(p0[0], p0[1], p0[2], p0[3]);
-      *reinterpret_cast<float4*>(aa.m + idx) = make_float4(m0[0], m0[1], m0[2], m0[3]);
-      *reinterpret_cast<float4*>(aa.v + idx) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+      store16_wt(aa.p, idx, f32x4{p0[0], p0[1], p0[2], p0[3]});
+      store16_wt(aa.m, idx, f32x4{m0[0], m0[1], m0[2], m0[3]});
+      store16_wt(aa.v, idx, f32x4{v0[0], v0[1], v0[2], v0[3]});
     }
   } else if (pok) {
 #pragma unroll
@@ -1855,9 +1866,10 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
     adam1(pp.y, gg.y, mm.y, vv.y, neg_step, bc2s);
     adam1(pp.z, gg.z, mm.z, vv.z, neg_step, bc2s);
     adam1(pp.w, gg.w, mm.w, vv.w, neg_step, bc2s);
-    reinterpret_cast<float4*>(p)[i4] = pp;
-    reinterpret_cast<float4*>(m)[i4] = mm;
-    reinterpret_cast<float4*>(v)[i4] = vv;
+    // write-through, as in the tile epilogues: 7.6 MB that nobody in this launch reads again
+    store16_wt(p, (size_t)i4 * 4, f32x4{pp.x, pp.y, pp.z, pp.w});
+    store16_wt(m, (size_t)i4 * 4, f32x4{mm.x, mm.y, mm.z, mm.w});
+    store16_wt(v, (size_t)i4 * 4, f32x4{vv.x, vv.y, vv.z, vv.w});
   }
   if (blockIdx.x == 0 && tid < t.n && t.trainable[tid]) {
     float gv = gsh[tid];

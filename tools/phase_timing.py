@@ -33,14 +33,18 @@ for i in range(N):
     sp = (C.c_ulonglong * (6 * 3 * 2048))()
     lib.mvae_debug_read_spans(sp)
     spans = {}
+    bounds = []
     for L in range(6):
         base = L * 3 * 2048
         st, en, kd = sp[base:base + 2048], sp[base + 2048:base + 4096], sp[base + 4096:base + 6144]
         used = [i for i in range(2048) if kd[i]]
         t0 = min(st[i] for i in used)
+        bounds.append((t0, max(en[i] for i in used)))
         for kind in sorted(set(kd[i] for i in used)):
             ends = sorted((en[i] - t0) * 10 for i in used if kd[i] == kind)
             spans.setdefault((L, kind), []).append((ends[len(ends) // 2], ends[-1], len(ends)))
+    gaps = [(bounds[L + 1][0] - bounds[L][1]) * 10 for L in range(5)] + [(bounds[5][1] - bounds[0][0]) * 10]
+    gap_acc = gaps if i == 0 else [a + b for a, b in zip(gap_acc, gaps)]
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
 names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:dot", "bwd:dh",
          "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores"]
@@ -54,3 +58,5 @@ print("per launch: workgroup END time after the first workgroup's start, ns (med
 for (L, kind), v in sorted(spans.items()):
     med = np.mean([x[0] for x in v]); mx = np.mean([x[1] for x in v])
     print(f"  {KERNELS[L]:11s} {KINDS.get((L, kind), kind):16s} n={v[0][2]:4d}  median {med:7.0f}  latest {mx:7.0f}")
+print("idle between the last workgroup (thread 0) of a launch and the first workgroup of the next, ns:",
+      [round(g / N) for g in gap_acc[:5]], " first start -> last end of the step:", round(gap_acc[5] / N))
