@@ -249,7 +249,7 @@ def main():
                    "final_elbo_per_sample": stats["last"]["elbo"] / B},
         "roofline": roof,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
         line["cpu_baseline"] = cpu_baseline(model=args.model, fixed=args.fixed_curvature)
     os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
