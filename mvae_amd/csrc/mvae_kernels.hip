@@ -1313,15 +1313,10 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   lds_barrier();
   MV_STAMP(2);
 
-  // ---- latent components: component ci runs on wave ci&3, lane ci>>2 (different manifolds land on different waves)
+  // ---- latent components: one lane per component, placed by fill_table (kinds on different waves)
   {
     const int ci = comp_at_s[wave][lane];
-#ifdef MV_DBG_SKIP_COMP
-    if (ci >= 0) { kl[(size_t)ci * B + row] = heads_s[0]; z_s[t.c[ci].z_col] = eps_s[0]; z_s[t.c[ci].z_col+1] = radii[0]; }
-    if (false) {
-#else
     if (ci >= 0) {
-#endif
       float klv;
       comp_fwd_row<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr,
                          nullptr);
