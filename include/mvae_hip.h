@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 2
+#define MVAE_ABI_VERSION 3
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -151,14 +151,18 @@ int mvae_linear_backward(const float* x, const float* W, const float* dy, int re
  * (b, c, y, x) element strides are explicit, so NCHW and channel-last activations share the kernels.
  * ------------------------------------------------------------------------------------------------------------------ */
 /* col[(b,oy,ox), (c,ky,kx)] = src[b, c, 2oy-1+ky, 2ox-1+kx] (0 outside; with mask != NULL also 0 where mask <= 0).
- * col is [B*IH/2*IW/2, C*16].  Forward of Conv2d (conv_vae.py:47-49,60-62) and backward of ConvTranspose2d. */
+ * col is [B*IH/2*IW/2, C*16].  Forward of Conv2d (conv_vae.py:47-49,60-62) and backward of ConvTranspose2d.
+ * taps_major != 0: the patch axis is ordered (ky,kx,c) instead of the weight layout's (c,ky,kx) -- 16-byte coalesced
+ * moves for channel-last tensors (needs sc == 1, C % 4 == 0, 16-byte alignment); the caller contracts with weights
+ * permuted to the same order (mvae_permute_rc on the [OC, C, 16] view). */
 int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, int C, int IH, int IW, int64_t sb,
-                       int64_t sc, int64_t sy, int64_t sx, void* stream);
+                       int64_t sc, int64_t sy, int64_t sx, int taps_major, void* stream);
 /* dst[b,c,y,x] = act(bias[c] + sum of the (<= 4) entries col[(b,py,px),(c,ky,kx)] with y = 2py-1+ky, x = 2px-1+kx);
  * col is [B*H/2*W/2, C*16].  Forward of ConvTranspose2d (conv_vae.py:52-55,72-74) and backward-data of Conv2d.
- * relu != 0: act = ReLU; mask != NULL: the result is zeroed where mask[b,c,y,x] <= 0 (backward through a ReLU). */
+ * relu != 0: act = ReLU; mask != NULL: the result is zeroed where mask[b,c,y,x] <= 0 (backward through a ReLU).
+ * taps_major: as above, col's second axis is (ky,kx,c). */
 int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C, int H, int W,
-                       int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, void* stream);
+                       int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, int taps_major, void* stream);
 /* out[b][c][r] = in[b][r][c]: the `.view(bs, -1)` / `.view(-1, 128, 4, 4)` re-flattenings of conv_vae.py:65,71. */
 int mvae_permute_rc(const float* in, float* out, int64_t B, int R, int Cc, void* stream);
 /* out[NP, NQ] = P[M, NP]^T Q[M, NQ]  (weight gradients).  For M > 256 the rows are processed in slices whose partial

@@ -85,17 +85,18 @@ class ConvFlatLayout:
         return out
 
 
-def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strides) -> Tensor:
+def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strides, taps_major: bool = False) -> Tensor:
     col = src.new_empty(B * (IH // 2) * (IH // 2), Cc * 16)
-    check(load().mvae_im2col_k4s2p1(ptr(src), ptr(mask), ptr(col), B, Cc, IH, IH, *strides, stream_ptr(src.device)))
+    check(load().mvae_im2col_k4s2p1(ptr(src), ptr(mask), ptr(col), B, Cc, IH, IH, *strides, 1 if taps_major else 0,
+                                    stream_ptr(src.device)))
     return col
 
 
 def _col2im(col: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, Hh: int, strides, relu: bool,
-            out_shape) -> Tensor:
+            out_shape, taps_major: bool = False) -> Tensor:
     dst = col.new_empty(out_shape)
     check(load().mvae_col2im_k4s2p1(ptr(col), ptr(bias), ptr(mask), ptr(dst), B, Cc, Hh, Hh, *strides,
-                                    1 if relu else 0, stream_ptr(col.device)))
+                                    1 if relu else 0, 1 if taps_major else 0, stream_ptr(col.device)))
     return dst
 
 
@@ -107,10 +108,24 @@ def _nchw(Hh: int, Cc: int):
     return (Cc * Hh * Hh, Hh * Hh, Hh, 1)
 
 
-def _permute_rc(x: Tensor, B: int, R: int, Cc: int) -> Tensor:
-    out = torch.empty_like(x)
+def _permute_rc(x: Tensor, B: int, R: int, Cc: int, out: Optional[Tensor] = None) -> Tensor:
+    """out[b][c][r] = x[b][r][c]."""
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.numel() == x.numel()
     check(load().mvae_permute_rc(ptr(x), ptr(out), B, R, Cc, stream_ptr(x.device)))
     return out
+
+
+def _taps_major(W: Tensor, rows: int, Cc: int) -> Tensor:
+    """[rows, Cc, 16] weight block (Conv2d: [OC, IC, 4, 4]; ConvTranspose2d: [IC, OC, 4, 4]) -> [rows, 16 * Cc] with
+    the patch axis ordered (ky, kx, c): what the taps-major gathers of the channel-last layers contract with."""
+    return _permute_rc(W.reshape(rows, Cc, 16), rows, Cc, 16).view(rows, 16 * Cc)
+
+
+def _from_taps_major(dWt: Tensor, rows: int, Cc: int, out: Tensor) -> Tensor:
+    """Inverse of _taps_major for a gradient, written straight into its slot of the flat gradient buffer."""
+    return _permute_rc(dWt.reshape(rows, 16, Cc), rows, 16, Cc, out=out)
 
 
 def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -209,12 +224,16 @@ class ConvEngine:
         B = x.shape[0]
         NH = lay.heads_dim
         c = {}
+        # e0 / d3 touch the 3-channel NCHW boundary and keep the weight layout's (c,ky,kx) patch order; the four
+        # channel-last layers in between run taps-major (coalesced gathers) against permuted weight matrices
+        c["We1"], c["We2"] = _taps_major(PV["e1.weight"], 128, 64), _taps_major(PV["e2.weight"], 512, 128)
+        c["Wd1"], c["Wd2"] = _taps_major(PV["d1.weight"], 128, 256), _taps_major(PV["d2.weight"], 256, 64)
         c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
         c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
-        c["col1"] = _im2col(c["a0"], None, B, 64, 16, _nhwc(16, 64))
-        c["a1"] = Fn.linear_forward(c["col1"], PV["e1.weight"].view(128, 1024), PV["e1.bias"], relu=True)
-        c["col2"] = _im2col(c["a1"], None, B, 128, 8, _nhwc(8, 128))
-        c["a2"] = Fn.linear_forward(c["col2"], PV["e2.weight"].view(512, 2048), PV["e2.bias"], relu=True)
+        c["col1"] = _im2col(c["a0"], None, B, 64, 16, _nhwc(16, 64), True)
+        c["a1"] = Fn.linear_forward(c["col1"], c["We1"], PV["e1.bias"], relu=True)
+        c["col2"] = _im2col(c["a1"], None, B, 128, 8, _nhwc(8, 128), True)
+        c["a2"] = Fn.linear_forward(c["col2"], c["We2"], PV["e2.bias"], relu=True)
         c["hflat"] = _permute_rc(c["a2"], B, 16, 512).view(B, H_DIM)  # NCHW flatten (conv_vae.py:65)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
@@ -226,10 +245,10 @@ class ConvEngine:
         R = zz.shape[0]
         c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
         c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
-        c["cT1"] = _gemm_nn(c["t0"], PV["d1.weight"].view(128, 256 * 16))
-        c["b1"] = _col2im(c["cT1"], PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True, (R * 64, 256))
-        c["cT2"] = _gemm_nn(c["b1"], PV["d2.weight"].view(256, 64 * 16))
-        c["b2"] = _col2im(c["cT2"], PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64))
+        c["cT1"] = _gemm_nn(c["t0"], c["Wd1"])
+        c["b1"] = _col2im(c["cT1"], PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True, (R * 64, 256), True)
+        c["cT2"] = _gemm_nn(c["b1"], c["Wd2"])
+        c["b2"] = _col2im(c["cT2"], PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64), True)
         c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
         c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
@@ -240,10 +259,10 @@ class ConvEngine:
         B, NH = x.shape[0], self.layout.heads_dim
         a0 = Fn.linear_forward(_im2col(x, None, B, 3, 32, _nchw(32, 3)), PV["e0.weight"].view(64, 48), PV["e0.bias"],
                                relu=True)
-        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64)), PV["e1.weight"].view(128, 1024),
+        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64), True), _taps_major(PV["e1.weight"], 128, 64),
                                PV["e1.bias"], relu=True)
-        a2 = Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128)), PV["e2.weight"].view(512, 2048),
-                               PV["e2.bias"], relu=True)
+        a2 = Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True),
+                               _taps_major(PV["e2.weight"], 512, 128), PV["e2.bias"], relu=True)
         hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
@@ -256,10 +275,10 @@ class ConvEngine:
         R = zz.shape[0]
         d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
         t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
-        b1 = _col2im(_gemm_nn(t0, PV["d1.weight"].view(128, 4096)), PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True,
-                     (R * 64, 256))
-        b2 = _col2im(_gemm_nn(b1, PV["d2.weight"].view(256, 1024)), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
-                     (R * 256, 64))
+        b1 = _col2im(_gemm_nn(t0, _taps_major(PV["d1.weight"], 128, 256)), PV["d1.bias"], None, R, 256, 8,
+                     _nhwc(8, 256), True, (R * 64, 256), True)
+        b2 = _col2im(_gemm_nn(b1, _taps_major(PV["d2.weight"], 256, 64)), PV["d2.bias"], None, R, 64, 16,
+                     _nhwc(16, 64), True, (R * 256, 64), True)
         lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
                      (R, 3072))
         return lo.view(z.shape[:-1] + (3072,))
@@ -281,14 +300,14 @@ class ConvEngine:
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
         _colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3), out=GV["d3.bias"])
         db2 = _relu_mask_(Fn.linear_forward(dcol3, PV["d3.weight"].view(64, 48), None), c["b2"])
-        dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64))
-        _gemm_tn(c["b1"], dcol2, out=GV["d2.weight"].view(256, 1024))
+        dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64), True)
+        _from_taps_major(_gemm_tn(c["b1"], dcol2), 256, 64, GV["d2.weight"])
         _colsum(db2, out=GV["d2.bias"])
-        db1 = _relu_mask_(Fn.linear_forward(dcol2, PV["d2.weight"].view(256, 1024), None), c["b1"])
-        dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256))
-        _gemm_tn(c["t0"], dcol1, out=GV["d1.weight"].view(128, 4096))
+        db1 = _relu_mask_(Fn.linear_forward(dcol2, c["Wd2"], None), c["b1"])
+        dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256), True)
+        _from_taps_major(_gemm_tn(c["t0"], dcol1), 128, 256, GV["d1.weight"])
         _colsum(db1, out=GV["d1.bias"])
-        dt0 = Fn.linear_forward(dcol1, PV["d1.weight"].view(128, 4096), None)  # [B*16, 128]
+        dt0 = Fn.linear_forward(dcol1, c["Wd1"], None)  # [B*16, 128]
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         dW, db, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True)
         GV["d0.weight"].copy_(dW)
@@ -306,14 +325,12 @@ class ConvEngine:
         self.grads[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH].copy_(dbh)
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
-        _gemm_tn(da2, c["col2"], out=GV["e2.weight"].view(512, 2048))
+        _from_taps_major(_gemm_tn(da2, c["col2"]), 512, 128, GV["e2.weight"])
         _colsum(da2, out=GV["e2.bias"])
-        da1 = _col2im(_gemm_nn(da2, PV["e2.weight"].view(512, 2048)), None, c["a1"], B, 128, 8, _nhwc(8, 128), False,
-                      (B * 64, 128))
-        _gemm_tn(da1, c["col1"], out=GV["e1.weight"].view(128, 1024))
+        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
+        _from_taps_major(_gemm_tn(da1, c["col1"]), 128, 64, GV["e1.weight"])
         _colsum(da1, out=GV["e1.bias"])
-        da0 = _col2im(_gemm_nn(da1, PV["e1.weight"].view(128, 1024)), None, c["a0"], B, 64, 16, _nhwc(16, 64), False,
-                      (B * 256, 64))
+        da0 = _col2im(_gemm_nn(da1, c["We1"]), None, c["a0"], B, 64, 16, _nhwc(16, 64), False, (B * 256, 64), True)
         _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
         _colsum(da0, out=GV["e0.bias"])
         if want_outputs:

@@ -2133,6 +2133,83 @@ __global__ __launch_bounds__(256) void k_col2im(const float* col, const float* b
   }
 }
 
+// ---- the same two gathers with the patch axis ordered (ky, kx, c) -- "taps-major" -- for channel-last tensors.
+// With c fastest, a patch row is 16 contiguous runs of C floats of the source, and the four terms of an output pixel are
+// contiguous runs of the patch matrix: both directions move 16-byte vectors, fully coalesced (the (c,ky,kx) order of the
+// reference's weight layout makes consecutive channels 64 bytes apart in the patch matrix).  The weight matrices are
+// permuted to the same order by the host layer (mvae_permute_rc on [OC, C, 16]).  Requires C % 4 == 0, sc == 1.
+__global__ __launch_bounds__(256) void k_im2col_tm(const float* src, const float* mask, float* col, int B, int C,
+                                                   int IH, int IW, int64_t sb, int64_t sy, int64_t sx) {
+  const int OH = IH / 2, OW = IW / 2, K4 = C * 4;  // K / 4
+  const int64_t total4 = (int64_t)B * OH * OW * K4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K4) * 4;
+    const int64_t m = i / K4;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((int64_t)OW * OH));
+    const int tap = k / C, c = k - tap * C, ky = tap >> 2, kx = tap & 3;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+      const int64_t o = b * sb + iy * sy + ix * sx + c;
+      v = *reinterpret_cast<const float4*>(src + o);
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+        if (!(mk.x > 0.f)) v.x = 0.f;
+        if (!(mk.y > 0.f)) v.y = 0.f;
+        if (!(mk.z > 0.f)) v.z = 0.f;
+        if (!(mk.w > 0.f)) v.w = 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(col + i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_col2im_tm(const float* col, const float* bias, const float* mask, float* dst,
+                                                   int B, int C, int H, int W, int64_t sb, int64_t sy, int64_t sx,
+                                                   int relu) {
+  const int PH = H / 2, PW = W / 2, K = C * 16, C4 = C / 4;
+  const int64_t total4 = (int64_t)B * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t r = i / C4;
+    const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((y + 1) & 1) + 2 * a;  // ky with the parity of y+1
+      const int py = (y + 1 - ky) / 2;
+      if (py < 0 || py >= PH) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kx = ((x + 1) & 1) + 2 * e;
+        const int px = (x + 1 - kx) / 2;
+        if (px < 0 || px >= PW) continue;
+        const float4 t =
+            *reinterpret_cast<const float4*>(col + (((int64_t)b * PH + py) * PW + px) * K + (ky * 4 + kx) * C + c);
+        acc.x += t.x;
+        acc.y += t.y;
+        acc.z += t.z;
+        acc.w += t.w;
+      }
+    }
+    const int64_t o = b * sb + y * sy + x * sx + c;
+    if (relu) {
+      acc.x = acc.x < 0.f ? 0.f : acc.x;
+      acc.y = acc.y < 0.f ? 0.f : acc.y;
+      acc.z = acc.z < 0.f ? 0.f : acc.z;
+      acc.w = acc.w < 0.f ? 0.f : acc.w;
+    }
+    if (mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+      if (!(mk.x > 0.f)) acc.x = 0.f;
+      if (!(mk.y > 0.f)) acc.y = 0.f;
+      if (!(mk.z > 0.f)) acc.z = 0.f;
+      if (!(mk.w > 0.f)) acc.w = 0.f;
+    }
+    *reinterpret_cast<float4*>(dst + o) = acc;
+  }
+}
+
 // out[b][c][r] = in[b][r][c]   (channel-last <-> channel-first flattening of a small activation)
 __global__ __launch_bounds__(256) void k_permute_rc(const float* in, float* out, int64_t B, int R, int Cc) {
   const int64_t total = B * R * Cc;
@@ -2233,10 +2310,23 @@ static int grid_for(int64_t total) {
   return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
+static bool taps_major_ok(const void* a, const void* b, const void* c, int C, int64_t sc, int64_t sb, int64_t sy,
+                          int64_t sx) {
+  return sc == 1 && (C & 3) == 0 && ((sb | sy | sx) & 3) == 0 && aligned16(a) && aligned16(b) && (!c || aligned16(c));
+}
+
 extern "C" int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, int C, int IH, int IW,
-                                  int64_t sb, int64_t sc, int64_t sy, int64_t sx, void* stream) {
+                                  int64_t sb, int64_t sc, int64_t sy, int64_t sx, int taps_major, void* stream) {
   if (!src || !col || B < 1 || C < 1 || IH < 2 || IW < 2 || (IH & 1) || (IW & 1))
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (taps_major) {
+    if (!taps_major_ok(src, col, mask, C, sc, sb, sy, sx))
+      return fail(MVAE_E_ALIGN, "taps-major im2col needs a channel-last source with C %% 4 == 0%s", "");
+    hipLaunchKernelGGL(k_im2col_tm, dim3(grid_for((int64_t)B * (IH / 2) * (IW / 2) * C * 4)), dim3(256), 0,
+                       (hipStream_t)stream, src, mask, col, B, C, IH, IW, sb, sy, sx);
+    LAUNCH_CHECK("im2col launch");
+    return 0;
+  }
   hipLaunchKernelGGL(k_im2col, dim3(grid_for((int64_t)B * (IH / 2) * (IW / 2) * C * 16)), dim3(256), 0,
                      (hipStream_t)stream, src, mask, col, B, C, IH, IW, sb, sc, sy, sx);
   LAUNCH_CHECK("im2col launch");
@@ -2245,9 +2335,17 @@ extern "C" int mvae_im2col_k4s2p1(const float* src, const float* mask, float* co
 
 extern "C" int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C,
                                   int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu,
-                                  void* stream) {
+                                  int taps_major, void* stream) {
   if (!col || !dst || B < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (taps_major) {
+    if (!taps_major_ok(col, dst, mask, C, sc, sb, sy, sx) || (bias && !aligned16(bias)))
+      return fail(MVAE_E_ALIGN, "taps-major col2im needs a channel-last destination with C %% 4 == 0%s", "");
+    hipLaunchKernelGGL(k_col2im_tm, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       col, bias, mask, dst, B, C, H, W, sb, sy, sx, relu);
+    LAUNCH_CHECK("col2im launch");
+    return 0;
+  }
   hipLaunchKernelGGL(k_col2im, dim3(grid_for((int64_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, col, bias,
                      mask, dst, B, C, H, W, sb, sc, sy, sx, relu);
   LAUNCH_CHECK("col2im launch");

@@ -148,3 +148,30 @@ def test_tiled_contractions_vs_float64(dev, M, N, K):
     Q = torch.randn(M, N, generator=g)
     assert_close(_cpu(_gemm_tn(x.to(dev), Q.to(dev))), (x.double().t() @ Q.double()).numpy(), 2e-5, "TN",
                  atol_frac=5e-6)
+
+
+def test_taps_major_layers_vs_torch(dev):
+    """The (ky,kx,c) patch order of the channel-last layers: Conv2d and ConvTranspose2d forward through the taps-major
+    gathers and permuted weight matrices against torch (float64), and the weight permutation round trip."""
+    import torch.nn.functional as F
+    from mvae_amd import functional as Fn
+    from mvae_amd.conv import _col2im, _from_taps_major, _gemm_nn, _im2col, _nhwc, _taps_major
+    g = torch.Generator().manual_seed(1)
+    B, C, OC, IH = 3, 8, 12, 8
+    x = torch.randn(B, C, IH, IH, generator=g)
+    W = torch.randn(OC, C, 4, 4, generator=g) * 0.2
+    b = torch.randn(OC, generator=g)
+    ref = F.conv2d(x.double(), W.double(), b.double(), stride=2, padding=1)  # [B, OC, 4, 4]
+    x_cl = x.permute(0, 2, 3, 1).contiguous().view(B * IH * IH, C).to(dev)  # channel-last rows
+    Wt = _taps_major(W.to(dev), OC, C)
+    assert torch.equal(_from_taps_major(Wt, OC, C, torch.empty(OC * C * 16, device=dev)).view(OC, C, 4, 4).cpu(), W)
+    col = _im2col(x_cl, None, B, C, IH, _nhwc(IH, C), True)
+    y = Fn.linear_forward(col, Wt, b.to(dev))  # [(b,oy,ox), oc]
+    assert_close(_cpu(y.view(B, 4, 4, OC).permute(0, 3, 1, 2)), ref.numpy(), 2e-5, "conv2d taps-major", atol_frac=1e-5)
+    Wtr = torch.randn(C, OC, 4, 4, generator=g) * 0.2  # ConvTranspose2d: [IC, OC, 4, 4]
+    bt = torch.randn(OC, generator=g)
+    reft = F.conv_transpose2d(x.double(), Wtr.double(), bt.double(), stride=2, padding=1)  # [B, OC, 16, 16]
+    colT = _gemm_nn(x_cl, _taps_major(Wtr.to(dev), C, OC))
+    yt = _col2im(colT, bt.to(dev), None, B, OC, 2 * IH, _nhwc(2 * IH, OC), False, (B * 4 * IH * IH, OC), True)
+    assert_close(_cpu(yt.view(B, 2 * IH, 2 * IH, OC).permute(0, 3, 1, 2)), reft.numpy(), 2e-5, "convT taps-major",
+                 atol_frac=1e-5)
