@@ -1,0 +1,45 @@
+"""bench.py prints exactly ONE JSON line on stdout with the fields the driver reads (single-GPU and forced exchange)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", *flags],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # library banners must not reach stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_schema():
+    d = _run("--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 300 and d["warmup"] == 50 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 300 / (d["ms_per_step"] * 1e-3 * 300)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert r["kernel"] in r["kernel_ms"] and set(r["per_kernel"]) == set(r["kernel_ms"])
+    assert d["value"] > 1000  # steps/s: a silent eager fallback would be two orders of magnitude below the HIP path
+
+
+def test_bench_forced_exchange_route():
+    """The data-parallel route (gradients -> RCCL all-reduce -> k_optim) inside HIP graphs, at world size 1."""
+    d = _run("--no-cpu-baseline", "--force-dp")
+    assert "forced exchange" in d["config"]["parallelism"] and d["config"]["graph_steps"] == 50
+    assert d["value"] > 1000
