@@ -163,6 +163,12 @@ int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, i
  * taps_major: as above, col's second axis is (ky,kx,c). */
 int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C, int H, int W,
                        int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, int taps_major, void* stream);
+/* mvae_linear_forward for few rows and a long contraction (the heads of the conv architecture, component.py:52-57 on
+ * the 8192-wide flatten): K is split into slices whose partial products are added in index order.  `workspace`:
+ * mvae_linear_forward_splitk_workspace_floats(M, N, K) floats (0 = not needed). */
+int64_t mvae_linear_forward_splitk_workspace_floats(int64_t M, int N, int K);
+int mvae_linear_forward_splitk(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
+                               int relu, float* workspace, void* stream);
 /* out[b][c][r] = in[b][r][c]: the `.view(bs, -1)` / `.view(-1, 128, 4, 4)` re-flattenings of conv_vae.py:65,71. */
 int mvae_permute_rc(const float* in, float* out, int64_t B, int R, int Cc, void* stream);
 /* out[NP, NQ] = P[M, NP]^T Q[M, NQ]  (weight gradients).  For M > 256 the rows are processed in slices whose partial

@@ -117,6 +117,17 @@ def _permute_rc(x: Tensor, B: int, R: int, Cc: int, out: Optional[Tensor] = None
     return out
 
 
+def _linear_splitk(x: Tensor, W: Tensor, b: Optional[Tensor]) -> Tensor:
+    """x W^T + b for few rows and a long contraction (the heads on the 8192-wide flatten)."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = x.new_empty(M, N)
+    nws = load().mvae_linear_forward_splitk_workspace_floats(M, N, K)
+    ws = x.new_empty(int(nws)) if nws > 0 else None
+    check(load().mvae_linear_forward_splitk(ptr(x), ptr(W), ptr(b), ptr(y), M, N, K, 0, ptr(ws), stream_ptr(x.device)))
+    return y
+
+
 def _taps_major(W: Tensor, rows: int, Cc: int) -> Tensor:
     """[rows, Cc, 16] weight block (Conv2d: [OC, IC, 4, 4]; ConvTranspose2d: [IC, OC, 4, 4]) -> [rows, 16 * Cc] with
     the patch axis ordered (ky, kx, c): what the taps-major gathers of the channel-last layers contract with."""
@@ -237,7 +248,7 @@ class ConvEngine:
         c["hflat"] = _permute_rc(c["a2"], B, 16, 512).view(B, H_DIM)  # NCHW flatten (conv_vae.py:65)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
-        c["heads"] = Fn.linear_forward(c["hflat"], w_heads, b_heads)
+        c["heads"] = _linear_splitk(c["hflat"], w_heads, b_heads)
         co = Fn.component_forward(lay, c["heads"], eps, self.params[:lay.n], want_kl=want_kl,
                                   want_log_probs=not want_kl, want_params=False)
         c["z"], c["kl"], c["co"] = co["z"], co["kl"], co
@@ -266,7 +277,7 @@ class ConvEngine:
         hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
-        return Fn.linear_forward(hflat, w_heads, b_heads)
+        return _linear_splitk(hflat, w_heads, b_heads)
 
     def decode(self, z: Tensor) -> Tensor:
         """[..., B, Z] -> [..., B, 3072] (conv_vae.py:68-79)."""

@@ -2542,7 +2542,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn_sliced(const float* P, const fl
 }
 // out[i] = sum_k part[k][i], fixed order: a workgroup owns 64 outputs, its four waves take the slices k = w, w+4, ...
 // (8 loads in flight per lane), the four partial sums meet in LDS and are added in wave order.
-__global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* out, int64_t n, int slices) {
+__global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* out, int64_t n, int slices,
+                                                    const float* bias = nullptr, int ncols = 1, int relu = 0) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
@@ -2561,7 +2562,12 @@ __global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* ou
     }
     sm[w][lane] = s;
     __syncthreads();
-    if (w == 0 && i < n) out[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    if (w == 0 && i < n) {
+      float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+      if (bias) v += bias[i % ncols];
+      if (relu) v = v < 0.f ? 0.f : v;
+      out[i] = v;
+    }
     __syncthreads();
   }
 }
@@ -2631,6 +2637,30 @@ extern "C" int mvae_gemm_nn(const float* G, const float* W, const float* mask, f
   if (grid > 0x7fffffff) return fail(MVAE_E_UNSUPPORTED, "grid too large%s", "");
   hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, G, W, mask, out, (int)M, K, N);
   LAUNCH_CHECK("gemm_nn launch");
+  return 0;
+}
+
+// y = act(x W^T + b) for FEW rows and a LONG contraction (the conv architecture's heads: M = B, N = 12, K = 8192: 16
+// output tiles).  K is cut into slices of kSplitK so that >= ~256 workgroups exist; the slices' partial products are
+// added in index order, with the bias and the activation, by k_sum_slices.
+constexpr int kSplitK = 128;
+extern "C" int64_t mvae_linear_forward_splitk_workspace_floats(int64_t M, int N, int K) {
+  const int64_t slices = (K + kSplitK - 1) / kSplitK;
+  return slices > 1 ? slices * M * N : 0;
+}
+extern "C" int mvae_linear_forward_splitk(const float* x, const float* W, const float* b, float* y, int64_t M, int N,
+                                          int K, int relu, float* workspace, void* stream) {
+  if (!x || !W || !y || M < 1 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int slices = (K + kSplitK - 1) / kSplitK;
+  if (slices == 1 || !tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff)
+    return mvae_linear_forward(x, W, b, y, M, N, K, relu, stream);
+  if (!workspace) return fail(MVAE_E_BADARG, "mvae_linear_forward_splitk needs its workspace%s", "");
+  const int64_t n = M * N;
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, workspace, N, nullptr, nullptr, 0, (int)M, N, K, slices, kSplitK, n,
+                                (hipStream_t)stream);
+  hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, y, n, slices, b,
+                     N, relu);
+  LAUNCH_CHECK("split-K linear forward launch");
   return 0;
 }
 

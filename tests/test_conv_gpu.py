@@ -175,3 +175,16 @@ def test_taps_major_layers_vs_torch(dev):
     yt = _col2im(colT, bt.to(dev), None, B, OC, 2 * IH, _nhwc(2 * IH, OC), False, (B * 4 * IH * IH, OC), True)
     assert_close(_cpu(yt.view(B, 2 * IH, 2 * IH, OC).permute(0, 3, 1, 2)), reft.numpy(), 2e-5, "convT taps-major",
                  atol_frac=1e-5)
+
+
+def test_linear_splitk_vs_float64(dev):
+    """Few rows, long contraction (the conv heads: [B, 8192] x [12, 8192]^T) through the split-K route."""
+    from mvae_amd.conv import _linear_splitk
+    g = torch.Generator().manual_seed(9)
+    for M, N, K in [(256, 12, 8192), (4, 12, 8192), (37, 5, 1000)]:
+        x = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * 0.05
+        b = torch.randn(N, generator=g)
+        y = _linear_splitk(x.to(dev), W.to(dev), b.to(dev))
+        assert_close(_cpu(y), (x.double() @ W.double().t() + b.double()).numpy(), 2e-5, f"splitk {M}x{N}x{K}",
+                     atol_frac=5e-6)
