@@ -2365,21 +2365,23 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 //   NT  y = x W^T        A = x [M,K] (k contiguous),  B = W [N,K] (k contiguous)     Conv2d forward / Linear
 //   NN  y = g W          A = g [M,K] (k contiguous),  B = W [K,N] (j contiguous)     ConvTranspose2d forward, dX
 //   TN  dW = P^T Q       A = P [Kc,M'] (i contiguous), B = Q [Kc,N] (j contiguous)   weight gradients (split-K slices)
-// Workgroup tile BM x BN, K step 16; 4 waves as 2 x 2, each wave (BM/2) x (BN/2) as 16 x 16 MFMA tiles.  Both operand
-// tiles sit in LDS as [row][k] with a row stride of 20 floats: a lane fetches ONE 16-byte vector per 16 x 16 x 16
-// sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and B), conflict-free for ds_read_b128.
-// Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
-constexpr int kGT_BK = 16, kGT_LD = 20;
-template <int BM, int BN, bool A_KC, bool B_KC>
+// Workgroup tile BM x BN, K step BK (32: with 16 a 64 x 64 tile has only 512 MFMA cycles per wave between two
+// barriers and the fixed barrier + LDS latency shows, MfmaUtil 56 %); 4 waves as 2 x 2, each wave (BM/2) x (BN/2) as
+// 16 x 16 MFMA tiles.  Both operand tiles sit in LDS as [row][k] with a row stride of BK + 8 floats: a lane fetches
+// ONE 16-byte vector per 16 x 16 x 16 sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and
+// B); strides 24 / 40 are conflict-free for ds_read_b128 under its 16-lane service groups ({0-3,12-15,20-27}, ...
+// over 64 banks).  Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
                                                     const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
                                                     float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
                                                     const float* __restrict__ mask, int relu, int M, int N, int K,
                                                     int k_per_slice, int64_t slice_stride) {
+  constexpr int kGT_BK = BK, kGT_LD = BK + 8, KQ = BK / 4;
   __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int LA = BM * 4 / 256, LB = BN * 4 / 256;  // 16-byte vectors per thread per K step
+  constexpr int LA = BM * KQ / 256, LB = BN * KQ / 256;  // 16-byte vectors per thread per K step
   static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -2394,10 +2396,10 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
       const int f = tid + 256 * r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_KC) {  // 4 consecutive k of row i
-        const int i = f >> 2, k = k0 + ((f & 3) << 2);
+        const int i = f / KQ, k = k0 + ((f % KQ) << 2);
         if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + i) * sai + k);
       } else {  // 4 consecutive i of column k
-        const int k = k0 + (f & 15), i = (f >> 4) << 2;
+        const int k = k0 + (f % BK), i = (f / BK) << 2;
         if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)k * sak + (m0 + i));
       }
       ra[r] = v;
@@ -2407,10 +2409,10 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
       const int f = tid + 256 * r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_KC) {
-        const int j = f >> 2, k = k0 + ((f & 3) << 2);
+        const int j = f / KQ, k = k0 + ((f % KQ) << 2);
         if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + j) * sbj + k);
       } else {
-        const int k = k0 + (f & 15), j = (f >> 4) << 2;
+        const int k = k0 + (f % BK), j = (f / BK) << 2;
         if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)k * sbk + (n0 + j));
       }
       rb[r] = v;
@@ -2421,26 +2423,28 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
     for (int r = 0; r < LA; ++r) {
       const int f = tid + 256 * r;
       if (A_KC) {
-        *reinterpret_cast<float4*>(As + (f >> 2) * kGT_LD + ((f & 3) << 2)) = ra[r];
-      } else {
-        const int k = f & 15, i = (f >> 4) << 2;
-        As[(i + 0) * kGT_LD + k] = ra[r].x;
-        As[(i + 1) * kGT_LD + k] = ra[r].y;
-        As[(i + 2) * kGT_LD + k] = ra[r].z;
-        As[(i + 3) * kGT_LD + k] = ra[r].w;
+        *reinterpret_cast<float4*>(As + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = ra[r];
+      } else {  // rows i and i+4 share banks at this stride: the odd 16-lane halves store their rows rotated by 2
+        const int k = f % BK, i = (f / BK) << 2;
+        const bool rot = BK == 16 && ((f >> 4) & 1);
+        As[(i + (rot ? 2 : 0)) * kGT_LD + k] = rot ? ra[r].z : ra[r].x;
+        As[(i + (rot ? 3 : 1)) * kGT_LD + k] = rot ? ra[r].w : ra[r].y;
+        As[(i + (rot ? 0 : 2)) * kGT_LD + k] = rot ? ra[r].x : ra[r].z;
+        As[(i + (rot ? 1 : 3)) * kGT_LD + k] = rot ? ra[r].y : ra[r].w;
       }
     }
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
       const int f = tid + 256 * r;
       if (B_KC) {
-        *reinterpret_cast<float4*>(Bs + (f >> 2) * kGT_LD + ((f & 3) << 2)) = rb[r];
+        *reinterpret_cast<float4*>(Bs + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = rb[r];
       } else {
-        const int k = f & 15, j = (f >> 4) << 2;
-        Bs[(j + 0) * kGT_LD + k] = rb[r].x;
-        Bs[(j + 1) * kGT_LD + k] = rb[r].y;
-        Bs[(j + 2) * kGT_LD + k] = rb[r].z;
-        Bs[(j + 3) * kGT_LD + k] = rb[r].w;
+        const int k = f % BK, j = (f / BK) << 2;
+        const bool rot = BK == 16 && ((f >> 4) & 1);
+        Bs[(j + (rot ? 2 : 0)) * kGT_LD + k] = rot ? rb[r].z : rb[r].x;
+        Bs[(j + (rot ? 3 : 1)) * kGT_LD + k] = rot ? rb[r].w : rb[r].y;
+        Bs[(j + (rot ? 0 : 2)) * kGT_LD + k] = rot ? rb[r].x : rb[r].z;
+        Bs[(j + (rot ? 1 : 3)) * kGT_LD + k] = rot ? rb[r].y : rb[r].w;
       }
     }
   };
@@ -2458,20 +2462,25 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
     stage();
     __syncthreads();
     if (k0 + kGT_BK < ke) fetch(k0 + kGT_BK);
-    float4 af[TM], bf[TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(As + (wm + a * 16 + li) * kGT_LD + lk);
+    for (int kk = 0; kk < BK; kk += 16) {
+      float4 af[TM], bf[TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(Bs + (wn + b * 16 + li) * kGT_LD + lk);
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const float4*>(As + (wm + a * 16 + li) * kGT_LD + kk + lk);
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+      for (int b = 0; b < TN; ++b)
+        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn + b * 16 + li) * kGT_LD + kk + lk);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        acc[a][b] = mfma16(af[a].x, bf[b].x, acc[a][b]);
-        acc[a][b] = mfma16(af[a].y, bf[b].y, acc[a][b]);
-        acc[a][b] = mfma16(af[a].z, bf[b].z, acc[a][b]);
-        acc[a][b] = mfma16(af[a].w, bf[b].w, acc[a][b]);
-      }
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = mfma16(af[a].x, bf[b].x, acc[a][b]);
+          acc[a][b] = mfma16(af[a].y, bf[b].y, acc[a][b]);
+          acc[a][b] = mfma16(af[a].z, bf[b].z, acc[a][b]);
+          acc[a][b] = mfma16(af[a].w, bf[b].w, acc[a][b]);
+        }
+    }
     __syncthreads();
   }
   // epilogue: lane holds rows 4*(lane>>4) + r, column lane&15 of every 16 x 16 tile
@@ -2497,6 +2506,13 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
 // operand requirements of the 16-byte paths of k_gemm_tiled
 static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
 
+#ifndef MV_BK64
+#define MV_BK64 32
+#endif
+#ifndef MV_BK128
+#define MV_BK128 32
+#endif
+constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128;
 template <bool A_KC, bool B_KC>
 static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
                               float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
@@ -2506,15 +2522,15 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
   if (N > 64 && wg128 < 512) {
     dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<64, 64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   } else if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   } else {
     dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   }
 }
