@@ -203,6 +203,8 @@ class ConvEngine:
         self.radius_trainable = [bool(t) and letter != "e" for t, (letter, _) in zip(radius_trainable, self.layout.comps)]
         for i, (t, (letter, _)) in enumerate(zip(self.radius_trainable, self.layout.comps)):
             self._trainable_arr[i] = (3 if letter == "u" else 1) if t else 0
+        self._trainable_mask = torch.tensor([1.0 if t else 0.0 for t in self.radius_trainable], dtype=torch.float32,
+                                            device=self.device)
 
     # ---- state (same surface as StepEngine)
     def param_views(self) -> Dict[str, Tensor]:
@@ -320,20 +322,17 @@ class ConvEngine:
         _colsum(db1, out=GV["d1.bias"])
         dt0 = Fn.linear_forward(dcol1, c["Wd1"], None)  # [B*16, 128]
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
-        dW, db, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True)
-        GV["d0.weight"].copy_(dW)
-        GV["d0.bias"].copy_(db)
+        _, _, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True,
+                                      out_dW=GV["d0.weight"], out_db=GV["d0.bias"])
         # ---- latent components
         dheads, dradii = Fn.component_backward(lay, c["heads"], eps, self.params[:lay.n], dz, None, float(beta))
-        self.grads[:_lib.RADII_REGION].zero_()
-        for i, t in enumerate(self.radius_trainable):
-            if t:
-                self.grads[i:i + 1].copy_(dradii[i:i + 1])
+        torch.mul(dradii, self._trainable_mask, out=self.grads[:lay.n])  # the rest of the radii region stays 0
         NH = lay.heads_dim
-        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
-        dWh, dbh, dhflat = Fn.linear_backward(c["hflat"], w_heads, dheads, relu_in=True, need_dx=True)
-        self.grads[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM).copy_(dWh)
-        self.grads[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH].copy_(dbh)
+        ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
+        w_heads = self.params[ow:ow + NH * H_DIM].view(NH, H_DIM)
+        _, _, dhflat = Fn.linear_backward(c["hflat"], w_heads, dheads, relu_in=True, need_dx=True,
+                                          out_dW=self.grads[ow:ow + NH * H_DIM].view(NH, H_DIM),
+                                          out_db=self.grads[ob:ob + NH])
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
         _from_taps_major(_gemm_tn(da2, c["col2"]), 512, 128, GV["e2.weight"])

@@ -2241,21 +2241,45 @@ __global__ __launch_bounds__(256) void k_colsum(const float* G, float* out, int 
   job_colsum_opt<false>(lds, G, N, M, N, blockIdx.x * kColsPerBlock, out, none);
 }
 
-// g[r][j] = sigmoid(logits[r][j]) - x[r][j];  bce[r] = sum_j BCE-with-logits   (one wavefront per row)
+// g[r][j] = sigmoid(logits[r][j]) - x[r][j];  bce[r] = sum_j BCE-with-logits   (one workgroup per row; 16-byte moves
+// when D % 4 == 0 and the buffers are aligned; the four wave sums are added in wave order)
 __global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* logits, const float* x, float* bce, float* g,
                                                      int64_t rows, int D) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  float s = 0.f;
-  for (int j = lane; j < D; j += 64) {
-    const float y = logits[r * D + j], t = x[r * D + j];
+  __shared__ float sm[4];
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x;
+  const float* yl = logits + r * D;
+  const float* tl = x + r * D;
+  float* gl = g + r * D;
+  auto term = [](float y, float t, float* gout) -> float {
     const float e = mvf::fexp(-fabsf(y));
-    s += (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
-    g[r * D + j] = ((y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t;
+    *gout = ((y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t;
+    return (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
+  };
+  float s = 0.f;
+  if ((D & 3) == 0 && ((((uintptr_t)logits | (uintptr_t)x | (uintptr_t)g) & 15) == 0)) {
+    for (int j = tid * 4; j < D; j += 1024) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(yl + j), t = *reinterpret_cast<const f32x4*>(tl + j);
+      f32x4 gv;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float go;
+        s += term(y[u], t[u], &go);
+        gv[u] = go;
+      }
+      *reinterpret_cast<f32x4*>(gl + j) = gv;
+    }
+  } else {
+    for (int j = tid; j < D; j += 256) {
+      float go;
+      s += term(yl[j], tl[j], &go);
+      gl[j] = go;
+    }
   }
   s = wave_sum(s);
-  if (lane == 0) bce[r] = s;
+  if ((tid & 63) == 0) sm[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) bce[r] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 // BatchStats (stats.py:144-212) for paths that do not run the fused MLP step: one workgroup
@@ -2464,43 +2488,68 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
     if (k0 + kGT_BK < ke) fetch(k0 + kGT_BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      float4 af[TM], bf[TN];
+      f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        af[a] = *reinterpret_cast<const float4*>(As + (wm + a * 16 + li) * kGT_LD + kk + lk);
+        af[a] = *reinterpret_cast<const f32x4*>(As + (wm + a * 16 + li) * kGT_LD + kk + lk);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn + b * 16 + li) * kGT_LD + kk + lk);
+        bf[b] = *reinterpret_cast<const f32x4*>(Bs + (wn + b * 16 + li) * kGT_LD + kk + lk);
+      // operands swapped (B fragment first): the lane's four accumulator values are four CONSECUTIVE columns of one
+      // output row, so the epilogue moves 16 bytes per lane.  Small wave tiles take the k-component outermost so
+      // that consecutive MFMAs write different accumulators.
+      if constexpr (TM * TN <= 4) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = mfma16(af[a].x, bf[b].x, acc[a][b]);
-          acc[a][b] = mfma16(af[a].y, bf[b].y, acc[a][b]);
-          acc[a][b] = mfma16(af[a].z, bf[b].z, acc[a][b]);
-          acc[a][b] = mfma16(af[a].w, bf[b].w, acc[a][b]);
-        }
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = mfma16(bf[b][j], af[a][j], acc[a][b]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][b] = mfma16(bf[b][j], af[a][j], acc[a][b]);
+      }
     }
     __syncthreads();
   }
-  // epilogue: lane holds rows 4*(lane>>4) + r, column lane&15 of every 16 x 16 tile
+  // epilogue: lane holds row lane&15, columns 4*(lane>>4) + r of every 16 x 16 tile
+  const bool vec = (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0 && (ldc & 3) == 0;
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + wm + a * 16 + li;
+    if (m >= M) continue;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int n = n0 + wn + b * 16 + li;
+      const int n = n0 + wn + b * 16 + lk;
       if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      f32x4 v = acc[a][b];
+      if (vec && n + 3 < N) {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (relu)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm + a * 16 + lk + r;
-        if (m >= M) continue;
-        float v = acc[a][b][r] + bv;
-        if (relu) v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
-        if (mask && !(mask[(size_t)m * ldc + n] > 0.f)) v = 0.f;
-        C[(size_t)m * ldc + n] = v;
+          for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];  // torch.relu: NaN propagates
+        if (mask) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (size_t)m * ldc + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float w = v[r] + (bias ? bias[n + r] : 0.f);
+          if (relu) w = w < 0.f ? 0.f : w;
+          if (mask && !(mask[(size_t)m * ldc + n + r] > 0.f)) w = 0.f;
+          C[(size_t)m * ldc + n + r] = w;
+        }
       }
     }
+  }
 }
 
 // operand requirements of the 16-byte paths of k_gemm_tiled
@@ -2716,7 +2765,7 @@ extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* 
 extern "C" int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, float* g, int64_t rows,
                                          int D, void* stream) {
   if (!logits || !x || !bce || !g || rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
-  hipLaunchKernelGGL(k_bce_fwd_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, x,
+  hipLaunchKernelGGL(k_bce_fwd_bwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, x,
                      bce, g, rows, D);
   LAUNCH_CHECK("bce launch");
   return 0;

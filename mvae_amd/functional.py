@@ -227,13 +227,16 @@ def linear_forward(x: Tensor, W: Tensor, b: Optional[Tensor], relu: bool = False
     return y
 
 
-def linear_backward(x: Tensor, W: Tensor, dy: Tensor, relu_in: bool = False, need_dx: bool = True):
+def linear_backward(x: Tensor, W: Tensor, dy: Tensor, relu_in: bool = False, need_dx: bool = True,
+                    out_dW: Optional[Tensor] = None, out_db: Optional[Tensor] = None):
+    """out_dW / out_db: contiguous destinations (e.g. views into a flat gradient buffer) written in place."""
     x, W, dy = _f32c(x), _f32c(W), _f32c(dy)
     K = x.shape[-1]
     N = W.shape[0]
     M = x.numel() // K
-    dW = torch.empty_like(W)
-    db = W.new_empty(N)
+    dW = torch.empty_like(W) if out_dW is None else out_dW
+    db = W.new_empty(N) if out_db is None else out_db
+    assert dW.is_contiguous() and dW.numel() == N * K and db.is_contiguous() and db.numel() == N
     dx = torch.empty_like(x) if need_dx else None
     check(load().mvae_linear_backward(ptr(x), ptr(W), ptr(dy), 1 if relu_in else 0, ptr(dW), ptr(db), ptr(dx), M, N, K,
                                       stream_ptr(x.device)))
