@@ -79,3 +79,42 @@ if fetch and write:
     with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     print(json.dumps(kernels, indent=1))
+
+
+def mfma_table(path):
+    """Per kernel: MFMA-pipe busy cycles (summed over the 1024 SIMDs), dispatch duration, utilisation."""
+    acc, n, dur = defaultdict(lambda: defaultdict(float)), defaultdict(int), defaultdict(float)
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Kernel_Name"].replace("void ", "")
+            name = name[:name.index("(")] if "(" in name else name
+            if not name.startswith("k_"):
+                continue
+            acc[name][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                n[name] += 1
+                dur[name] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    out = {}
+    for k in acc:
+        m = max(n[k], 1)
+        busy, d_ns = acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / m, dur[k] / m
+        out[k] = {"dispatches": n[k], "duration_us": round(d_ns / 1e3, 2), "mfma_busy_cycles": int(busy),
+                  "f32_mfma_instructions": int(busy / 32), "waves": int(acc[k]["SQ_WAVES"] / m),
+                  "mfma_util": round(busy / (d_ns * 2.4 * 1024), 4) if d_ns > 0 else None}
+    return out
+
+
+mf, mfc = first("pmc_mfma/**/*counter_collection.csv"), first("pmc_mfma_conv/**/*counter_collection.csv")
+if mf or mfc:
+    rec = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace "
+                     "(own pass) on `bench.py --steps 300 --warmup 50 --graph-steps 0 --no-cpu-baseline` (mlp_step) and "
+                     "`tools/bench_conv.py 256 5 0` (conv_step); per-dispatch averages",
+           "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (duration_ns * 2.4 GHz * 1024 SIMDs).  Calibration: the "
+                      "counter advances 32 cycles per v_mfma_f32_16x16x4_f32 (k_enc_fwd: 200 WG x 8 waves x 28 MFMAs x "
+                      "32 = 1 433 600, exactly the measured value), i.e. 100 % = the 157.3 TFLOP/s f32 peak; "
+                      "GRBM_GUI_ACTIVE / 8 XCDs over the dispatch duration gives 2.4-2.5 GHz on the long kernels.  "
+                      "Durations are those of the serialised PMC run (longer than in the graph replays).",
+           "mlp_step": mfma_table(mf) if mf else None, "conv_step": mfma_table(mfc) if mfc else None}
+    with open(os.path.join(dst, f"{tag}_pmc_mfma.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print("wrote", f"{tag}_pmc_mfma.json")
