@@ -20,7 +20,9 @@ def timeit(fn, n=20):
 
 shapes = [("e0", 65536, 64, 48), ("e1", 16384, 128, 1024), ("e2", 4096, 512, 2048), ("d1", 4096, 4096, 128),
           ("d2", 16384, 1024, 256), ("d3", 65536, 48, 64)]
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # batch multiplier (B = 256 * scale)
 for name, M, N, K in shapes:
+    M *= scale
     x = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev)
     Wn = torch.randn(K, N, device=dev)
