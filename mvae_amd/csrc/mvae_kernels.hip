@@ -2391,12 +2391,13 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 //   TN  dW = P^T Q       A = P [Kc,M'] (i contiguous), B = Q [Kc,N] (j contiguous)   weight gradients (split-K slices)
 // Workgroup tile BM x BN, K step BK (32: with 16 a 64 x 64 tile has only 512 MFMA cycles per wave between two
 // barriers and the fixed barrier + LDS latency shows, MfmaUtil 56 %); 4 waves as 2 x 2, each wave (BM/2) x (BN/2) as
-// 16 x 16 MFMA tiles.  Both operand tiles sit in LDS as [row][k] with a row stride of BK + 8 floats: a lane fetches
+// 16 x 16 MFMA tiles (the 64 x 64 and 128 x 128 launches run 8 waves as 2 x 4: four waves per SIMD at two workgroups
+// per CU, +3 % on the conv step).  Both operand tiles sit in LDS as [row][k] with a row stride of BK + 8 floats: a lane fetches
 // ONE 16-byte vector per 16 x 16 x 16 sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and
 // B); strides 24 / 40 are conflict-free for ds_read_b128 under its 16-lane service groups ({0-3,12-15,20-27}, ...
 // over 64 banks).  Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
-template <int BM, int BN, int BK, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
+template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
                                                     const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
                                                     float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
                                                     const float* __restrict__ mask, int relu, int M, int N, int K,
@@ -2404,9 +2405,10 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
   constexpr int kGT_BK = BK, kGT_LD = BK + 8, KQ = BK / 4;
   __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int LA = BM * KQ / 256, LB = BN * KQ / 256;  // 16-byte vectors per thread per K step
-  static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
+  constexpr int NT = 64 * NW, WCOLS = NW / 2;  // waves as 2 x WCOLS
+  constexpr int WM = BM / 2, WN = BN / WCOLS, TM = WM / 16, TN = WN / 16;
+  constexpr int LA = BM * KQ / NT, LB = BN * KQ / NT;  // 16-byte vectors per thread per K step
+  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kb = blockIdx.z * k_per_slice;
@@ -2417,7 +2419,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < LA; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NT * r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_KC) {  // 4 consecutive k of row i
         const int i = f / KQ, k = k0 + ((f % KQ) << 2);
@@ -2430,7 +2432,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
     }
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NT * r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_KC) {
         const int j = f / KQ, k = k0 + ((f % KQ) << 2);
@@ -2445,7 +2447,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
   auto stage = [&]() {
 #pragma unroll
     for (int r = 0; r < LA; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NT * r;
       if (A_KC) {
         *reinterpret_cast<float4*>(As + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = ra[r];
       } else {  // rows i and i+4 share banks at this stride: the odd 16-lane halves store their rows rotated by 2
@@ -2459,7 +2461,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
     }
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NT * r;
       if (B_KC) {
         *reinterpret_cast<float4*>(Bs + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = rb[r];
       } else {
@@ -2478,7 +2480,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const float* __restrict__ A,
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int wm = (wave / WCOLS) * WM, wn = (wave % WCOLS) * WN;
   const int li = lane & 15, lk = (lane >> 4) << 2;
 
   fetch(kb);
@@ -2561,7 +2563,13 @@ static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 
 #ifndef MV_BK128
 #define MV_BK128 32
 #endif
-constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128;
+#ifndef MV_NW64
+#define MV_NW64 8
+#endif
+#ifndef MV_NW128
+#define MV_NW128 8
+#endif
+constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128, kNW64 = MV_NW64, kNW128 = MV_NW128;
 template <bool A_KC, bool B_KC>
 static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
                               float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
@@ -2571,15 +2579,15 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
   if (N > 64 && wg128 < 512) {
     dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   } else if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, kNW128, A_KC, B_KC>), grid, dim3(64 * kNW128), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   } else {
     dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, 4, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
                        bias, mask, relu, M, N, K, k_per_slice, slice_stride);
   }
 }
