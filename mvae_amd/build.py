@@ -21,6 +21,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmvae_hip.so")
+    tmp = f"{LIB}.{os.getpid()}.tmp"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value",
            # a/b and sqrt lower to v_rcp_f32 / v_sqrt_f32 sequences (<= 2.5 ulp) instead of the ~10-instruction
            # correctly-rounded expansions: the manifold chain is latency-bound and the parity bar is 1e-4
@@ -28,11 +29,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
            # subnormal f32 inputs/outputs of VALU ops flush to zero (MFMA C/D never flush): removes the frexp/ldexp
            # range scaling around every v_rcp_f32 / v_exp_f32 / v_log_f32; and a/b may become a * (1/b)
            "-fgpu-flush-denormals-to-zero", "-freciprocal-math",
-           "-o", LIB + ".tmp", SRC]
+           "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)  # atomic: concurrent builders (one per rank) never expose a partial file
     return LIB
 
 
