@@ -1621,6 +1621,20 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   } else {
     for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
   }
+  // generic 16-byte path of dz: thread (slice s2, column quad j4) owns rows c = s2, s2 + nslv, ... of W_d0; the
+  // first 24 of them are requested here, ahead of the barrier (one round trip instead of one per 4 rows)
+  constexpr int kDzB = 24;
+  const bool dz_vec = !FAST && (Z & 3) == 0 && aligned16(Wd0);
+  const int nj4 = dz_vec ? (Z >> 2) : 1, nslv = 256 / (nj4 > 256 ? 256 : nj4);
+  const int j4 = tid % nj4, s2 = tid / nj4;
+  float4 wzv[kDzB];
+  if (dz_vec) {
+#pragma unroll
+    for (int u = 0; u < kDzB; ++u) {
+      const int c = s2 + u * nslv;
+      wzv[u] = *reinterpret_cast<const float4*>(Wd0 + ((s2 < nslv && c < H) ? (size_t)c * Z + 4 * j4 : 0));
+    }
+  }
   lds_barrier();
   MV_STAMP(9);
 
@@ -1650,7 +1664,7 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
         const int c = sl + q * nsl;
         p = fmaf(dhd_s[c < H ? c : 0], wz[q], p);
       }
-    } else if (zj < Z && !((Z & 3) == 0 && aligned16(Wd0))) {
+    } else if (zj < Z && !dz_vec) {
 #pragma unroll 4
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
@@ -1663,14 +1677,20 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
       if (lane < ZP) part[wave * ZP + lane] = p;
       lds_barrier();
       if (tid < Z) dz_s[tid] = (part[tid] + part[ZP + tid]) + (part[2 * ZP + tid] + part[3 * ZP + tid]);
-    } else if ((Z & 3) == 0 && aligned16(Wd0)) {
-      // generic, 16-byte path: thread (slice, j4) accumulates four neighbouring columns over a strided slice of c
-      const int nj4 = Z >> 2, nslv = 256 / nj4;
-      const int j4 = tid % nj4, s2 = tid / nj4;
-      if (s2 < nslv) {
+    } else if (dz_vec) {
+      if (s2 < nslv && j4 < nj4) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kDzB; ++u) {
+          const int c = s2 + u * nslv;
+          const float dv = c < H ? dhd_s[c < H ? c : 0] : 0.f;  // rows past the end were clamped to row 0
+          a.x = fmaf(dv, wzv[u].x, a.x);
+          a.y = fmaf(dv, wzv[u].y, a.y);
+          a.z = fmaf(dv, wzv[u].z, a.z);
+          a.w = fmaf(dv, wzv[u].w, a.w);
+        }
 #pragma unroll 4
-        for (int c = s2; c < H; c += nslv) {
+        for (int c = s2 + kDzB * nslv; c < H; c += nslv) {
           const float4 w = *reinterpret_cast<const float4*>(Wd0 + (size_t)c * Z + 4 * j4);
           const float dv = dhd_s[c];
           a.x = fmaf(dv, w.x, a.x);
@@ -1734,6 +1754,47 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
         for (int n = 0; n < 16; ++n) acc = fmaf(dheads_s[n], wh[u][n], acc);
         dh[row * H + c] = (hm[u] > 0.f) ? acc : 0.f;
       }
+    }
+  } else if ((H & 3) == 0 && H <= 1024 && aligned16(Wh) && aligned16(h) && aligned16(dh)) {
+    // thread (column quad c4, row group ng): rows n = ng, ng + G, ... of W_heads as 16-byte loads, 20 in flight;
+    // the G partial sums of a quad meet in LDS and are added in group order
+    const int nq = H >> 2, G = (256 / nq) < 1 ? 1 : ((256 / nq) > 8 ? 8 : 256 / nq);
+    const int c4 = tid % nq, ng = tid / nq;
+    const bool act = ng < G;
+    float4 hmv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < nq) hmv = *reinterpret_cast<const float4*>(h + row * H + 4 * tid);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nb = ng; nb < NH; nb += 20 * G) {
+      float4 w[20];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) {
+        const int n = nb + u * G;
+        w[u] = *reinterpret_cast<const float4*>(Wh + ((act && n < NH) ? (size_t)n * H + 4 * c4 : 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 20; ++u) {
+        const int n = nb + u * G;
+        const float dv = (act && n < NH) ? dheads_s[n < NH ? n : 0] : 0.f;
+        a.x = fmaf(dv, w[u].x, a.x);
+        a.y = fmaf(dv, w[u].y, a.y);
+        a.z = fmaf(dv, w[u].z, a.z);
+        a.w = fmaf(dv, w[u].w, a.w);
+      }
+    }
+    if (act) *reinterpret_cast<float4*>(part + ((size_t)ng * nq + c4) * 4) = a;  // G * H <= 1024 floats ... see below
+    lds_barrier();
+    if (tid < nq) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < G; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)q * nq + tid) * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+      }
+      tot.x = hmv.x > 0.f ? tot.x : 0.f;
+      tot.y = hmv.y > 0.f ? tot.y : 0.f;
+      tot.z = hmv.z > 0.f ? tot.z : 0.f;
+      tot.w = hmv.w > 0.f ? tot.w : 0.f;
+      *reinterpret_cast<float4*>(dh + row * H + 4 * tid) = tot;
     }
   } else {
     for (int c = tid; c < H; c += 256) {
