@@ -133,8 +133,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # MVAE_BENCH_BACKEND=gloo + MVAE_BENCH_ONE_DEVICE=1: a dry run of the N > 1 flow on a single-GPU box (all
+        # ranks on cuda:0, the exchange through the host; the step then runs un-captured).  Not a measurement.
+        backend = os.environ.get("MVAE_BENCH_BACKEND", "nccl")
+        if os.environ.get("MVAE_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -13,6 +13,19 @@ from .distributed import DataParallelStep
 from .engine import StepEngine
 
 
+def _clear_hip_error() -> None:
+    """An invalidated stream capture leaves its error code behind (hipGetLastError is read-and-clear); torch's next
+    launch check would otherwise report it against an unrelated, successful launch."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        for _ in range(8):
+            if hip.hipGetLastError() == 0:
+                break
+    except OSError:
+        pass
+
+
 class StepRunner:
 
     def __init__(self, eng: StepEngine, xs: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
@@ -30,6 +43,12 @@ class StepRunner:
         self._snapshot = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
+        if self.gs > 0 and self.dp is not None and self.dp.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(self.dp.group) != "nccl":
+                # only RCCL collectives can be captured; a host-side backend (gloo) invalidates the capture and leaves
+                # the process in an unusable capture state, so it is not even attempted
+                self.gs = 0
         if self.gs > 0:
             if self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
@@ -45,6 +64,7 @@ class StepRunner:
                       "running eagerly", file=sys.stderr, flush=True)
                 self.graphs = []
                 self.gs = 0
+                _clear_hip_error()
                 torch.cuda.synchronize()
 
     def _one(self, i: int) -> None:
