@@ -662,25 +662,52 @@ __global__ __launch_bounds__(256) void k_bce_rows(const float* logits, const flo
 
 // log p(x)[b] = logsumexp_n(-bce[n][b] + log_p[n][b] - log_q[n][b]) - log n ;
 // mi[b] = logsumexp_n(log_q[n][b] - log_p[n][b]) - log n        (vae.py:113-117)
+__device__ __forceinline__ float wave_sum(float v);  // defined with the fused step below
+// One workgroup per batch column b; thread t takes the samples t, t + 256, ...; block max, then block sum of exp(. - max)
+// (wave sums by DPP, the four wave totals added in wave order).
 __global__ __launch_bounds__(256) void k_loglik_reduce(const float* bce, const float* log_p, const float* log_q,
                                                        float* log_px, float* mi, int n, int B) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
+  __shared__ float sm[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
   float m1 = -INFINITY, m2 = -INFINITY;
-  for (int i = 0; i < n; ++i) {
+  for (int i = tid; i < n; i += 256) {
     const size_t o = (size_t)i * B + b;
-    m1 = fmaxf(m1, -bce[o] + log_p[o] - log_q[o]);
-    m2 = fmaxf(m2, log_q[o] - log_p[o]);
+    const float lp = log_p[o], lq = log_q[o];
+    m1 = fmaxf(m1, -bce[o] + lp - lq);
+    m2 = fmaxf(m2, lq - lp);
   }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    m1 = fmaxf(m1, __shfl_xor(m1, off));
+    m2 = fmaxf(m2, __shfl_xor(m2, off));
+  }
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = m1;
+    sm[1][tid >> 6] = m2;
+  }
+  __syncthreads();
+  m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+  m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+  __syncthreads();
   float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < n; ++i) {
+  for (int i = tid; i < n; i += 256) {
     const size_t o = (size_t)i * B + b;
-    s1 += expf((-bce[o] + log_p[o] - log_q[o]) - m1);
-    s2 += expf((log_q[o] - log_p[o]) - m2);
+    const float lp = log_p[o], lq = log_q[o];
+    s1 += expf((-bce[o] + lp - lq) - m1);
+    s2 += expf((lq - lp) - m2);
   }
-  const float ln = logf((float)n);
-  log_px[b] = m1 + logf(s1) - ln;
-  mi[b] = m2 + logf(s2) - ln;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = s1;
+    sm[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float ln = logf((float)n);
+    log_px[b] = m1 + logf((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) - ln;
+    mi[b] = m2 + logf((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) - ln;
+  }
 }
 
 extern "C" int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows, int64_t x_rows, int D,
@@ -697,7 +724,7 @@ extern "C" int mvae_loglik_reduce(const float* bce, const float* log_p, const fl
                                   int n, int B, void* stream) {
   if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1)
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
-  hipLaunchKernelGGL(k_loglik_reduce, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q,
+  hipLaunchKernelGGL(k_loglik_reduce, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q,
                      log_px, mi, n, B);
   LAUNCH_CHECK("loglik reduce launch");
   return 0;
