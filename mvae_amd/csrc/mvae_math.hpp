@@ -108,7 +108,17 @@ __device__ __forceinline__ Dual t_tan(Dual x) {
 __device__ __forceinline__ float t_atan(float x) { return atanf(x); }
 __device__ __forceinline__ Dual t_atan(Dual x) { return {atanf(x.v), x.d / (1.0f + x.v * x.v)}; }
 __device__ __forceinline__ float t_acos(float x) { return acosf(x); }
-__device__ __forceinline__ Dual t_acos(Dual x) { return {acosf(x.v), x.d * -rsqrtf(1.0f - x.v * x.v)}; }
+// d acos(x) = -dx / sqrt(1 - x^2).  At exactly x = +-1 (the hard clamp of the sphere's log map, spherical.py:104-116,
+// lets the boundary through) the reference's derivative is -inf and its backward pass produces NaN; in float64 the
+// boundary is never hit, in float32 alpha = <mu, z> / R^2 rounds to 1 as soon as |z - mu| / R < 3.4e-4, which the radius
+// warm-up (R = 11 ... 3) reaches within a few hundred steps.  Deliberate deviation AT that point only: the derivative
+// is capped the way the reference caps Acosh (g / z with z >= sqrt(1e-9), common.py:76-94).  The largest representable
+// |x| < 1 gives sqrt(1 - x^2) = 3.4e-4 > 3.16e-5, so no finite reference value is changed.
+__device__ __forceinline__ Dual t_acos(Dual x) {
+  const float s2 = 1.0f - x.v * x.v;
+  const float r = s2 == 0.0f ? 31622.7766f : rsqrtf(s2);  // NaN (and |x| > 1) propagate as before
+  return {acosf(x.v), x.d * -r};
+}
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ Dual t_abs(Dual x) {
   float s = (x.v > 0.0f) ? 1.0f : ((x.v < 0.0f) ? -1.0f : 0.0f);

@@ -203,6 +203,43 @@ def test_component_backward_poincare_vs_oracle(dev):
     assert_close(float(dr[0]), float(gr), 2 * RTOL, "d_radius")
 
 
+def test_sphere_backward_finite_at_the_acos_boundary(dev):
+    """alpha = <mu_0, z> / R^2 rounds to exactly 1 in float32 when z is (nearly) mu_0 and R is large -- the radius warm-up
+    regime.  The reference's backward is NaN there (acos'(1) = -inf, spherical.py:104-116; the oracle reproduces it);
+    the HIP path caps that derivative like the reference's Acosh and must stay finite, while rows away from the
+    boundary keep agreeing with the oracle."""
+    from mvae_amd import functional as Fn
+    from oracle import model as M
+    lay = Fn.ComponentLayout([("s", 2)])
+    g = torch.Generator().manual_seed(5)
+    B = 16
+    heads = torch.randn(B, 4, generator=g) * 0.3
+    eps = torch.randn(B, 2, generator=g)
+    # the prior term maps z back at mu_0 (log_map_mu0: alpha = z_0 / R): rows whose posterior sits at the pole with a
+    # small sigma have |z - mu_0| / R ~ 1e-5 and alpha rounds to 1
+    heads[:12, :2] *= 3e-4
+    heads[:12, 2:] = -40.0
+    R = 10.0
+    wz, wkl = torch.randn(B, 3, generator=g), torch.rand(B, generator=g) + 0.5
+    radii = torch.tensor([R], device=dev)
+    out = Fn.component_forward(lay, heads.to(dev), eps.to(dev), radii)
+    dheads, dr = Fn.component_backward(lay, heads.to(dev), eps.to(dev), radii, wz.to(dev), wkl.reshape(1, -1).to(dev))
+    assert torch.isfinite(out["z"]).all() and torch.isfinite(out["kl"]).all()
+    assert torch.isfinite(dheads).all() and torch.isfinite(dr).all()
+    # the oracle on the same rows: non-finite gradients at the boundary (that is the reference's behaviour) ...
+    rp = torch.tensor(R, requires_grad=True)
+    m = heads[:, :2].clone().requires_grad_(True)
+    l = heads[:, 2:].clone().requires_grad_(True)
+    o = M.component_forward(M.ComponentSpec("s", 2), m, l, eps, rp)
+    gm, gl = torch.autograd.grad((wz * o.z).sum() + (wkl * o.kl).sum(), [m, l])
+    assert not torch.isfinite(gm[:12]).all()
+    # ... and agreement on the well-conditioned rows (alpha computed in float32 at R = 10 loses ~3 digits)
+    ok = torch.isfinite(gm).all(dim=1) & torch.isfinite(gl).all(dim=1)
+    ok[:12] = False
+    assert int(ok.sum()) >= 2
+    assert_close(_cpu(out["z"])[ok.numpy()], o.z.detach().numpy()[ok.numpy()], RTOL, "z")
+
+
 # ------------------------------------------------------------------------------------------------ dense layers
 @pytest.mark.parametrize("M_,N,K", [(128, 400, 784), (128, 12, 400), (128, 784, 400), (128, 400, 8), (37, 50, 23),
                                     (1, 1, 1), (256, 400, 48)])
