@@ -18,6 +18,28 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+def init_from_env() -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default process group when
+    WORLD_SIZE > 1.  Backend "nccl" (= RCCL) unless MVAE_DIST_BACKEND says otherwise; MVAE_DIST_ONE_DEVICE=1 puts every
+    rank on cuda:0 (a flow check on a single-GPU box, together with MVAE_DIST_BACKEND=gloo)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("MVAE_DIST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = os.environ.get("MVAE_DIST_BACKEND", "nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) of the rows owned by `rank` (earlier ranks take the remainder)."""
     base, rem = divmod(n_rows, world)

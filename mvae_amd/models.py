@@ -113,6 +113,7 @@ class ModelVAE(nn.Module):
         self._scalar_parametrization = scalar_parametrization
         self.engine: Optional[StepEngine] = None
         self._generator: Optional[torch.Generator] = None
+        self._dp = None  # distributed.DataParallelStep once enable_data_parallel() was called
 
     # ---- device placement: build the StepEngine and alias every parameter into its flat buffer
     def to(self, device) -> "ModelVAE":
@@ -121,6 +122,15 @@ class ModelVAE(nn.Module):
         if self.device.type == "cuda":
             self._bind_engine()
         return self
+
+    def enable_data_parallel(self, group=None):
+        """Data-parallel training over torch.distributed (new functionality; the reference is single-device): every
+        rank feeds its own rows, the flat gradient buffer is all-reduced (SUM) before the replicated optimizer step.
+        Rank 0's parameters / optimizer state become everybody's starting point."""
+        from .distributed import DataParallelStep
+        self._dp = DataParallelStep(self._need_engine(), group=group)
+        self._dp.broadcast_state(0)
+        return self._dp
 
     def _comps_desc(self):
         return [(c.LETTER, c.true_dim) for c in self.components]
@@ -220,7 +230,10 @@ class ModelVAE(nn.Module):
         eps = self._eps(x.shape[0]) if eps is None else eps
         optimizer.bind(self)
         self._sync_trainable()
-        eng.train_step(x, eps, float(beta), optimizer.curv_condition())
+        if self._dp is None:
+            eng.train_step(x, eps, float(beta), optimizer.curv_condition())
+        else:  # x / eps are this rank's rows of the global batch: gradients -> all-reduce -> optimizer
+            self._dp.train_step(x, eps, float(beta), optimizer.curv_condition())
         stats = BatchStatsFloat(eng, beta)
         if _CHECK_FINITE_EVERY_STEP:  # debug mode: the reference's `assert torch.isfinite(loss).all()` (vae.py:158)
             assert np.isfinite(stats.elbo), "non-finite ELBO"

@@ -3,6 +3,7 @@ Same flags, same header / epoch log lines; `--doubles` defaults to False here (t
 import argparse
 import datetime
 import os
+import sys
 
 import torch
 
@@ -57,6 +58,20 @@ def main(argv=None) -> None:
                          "(the reference falls back to cpu here, run.py:91-93).")
     if args.doubles:
         raise SystemExit("--doubles=True is not supported: the HIP path computes in float32.")
+    # Data-parallel training (new functionality; the reference is single-device): under
+    #   python -m torch.distributed.run --nproc-per-node N -m mvae_amd.run ...
+    # --batch_size stays the GLOBAL batch: every rank trains on its own 1/N of the training set with batch_size / N
+    # rows per step, the flat gradient buffer is all-reduced over RCCL before the replicated optimizer step, the epoch
+    # statistics are global sums on every rank (identical early-stopping decisions), rank 0 prints.
+    from .distributed import init_from_env
+    rank, world, local_rank = init_from_env()
+    if world > 1:
+        if args.batch_size % world:
+            raise SystemExit(f"--batch_size={args.batch_size} is not divisible by the {world} ranks")
+        args.batch_size //= world
+        args.device = f"cuda:{local_rank}"
+        if rank != 0:
+            sys.stdout = open(os.devnull, "w")
     device = torch.device(args.device)
     print("Running on:", device, flush=True)
 
@@ -68,7 +83,7 @@ def main(argv=None) -> None:
     print(f"VAE Model: {model_name}; Epochs: {args.epochs}; Time: {cur_time}; Fixed curvature: {args.fixed_curvature}; "
           f"Dataset: {args.dataset}")
     print("#####", flush=True)
-    chkpt_dir = f"./chkpt/vae-{args.dataset}-{model_name}-{cur_time}"
+    chkpt_dir = f"./chkpt/vae-{args.dataset}-{model_name}-{cur_time}" + (f"-rank{rank}" if rank else "")
     os.makedirs(chkpt_dir)
     if args.architecture == "ff":
         model_cls = FeedForwardVAE
@@ -79,12 +94,19 @@ def main(argv=None) -> None:
     model = model_cls(h_dim=args.h_dim, components=components, dataset=dataset,
                       scalar_parametrization=args.scalar_parametrization).to(device)
     if args.seed:
-        model.seed_sampler(args.seed)
+        model.seed_sampler(args.seed + rank)
+    if world > 1:
+        model.enable_data_parallel()
     trainer = Trainer(model, img_dims=dataset.img_dims, chkpt_dir=chkpt_dir, train_statistics=args.train_statistics,
                       show_embeddings=args.show_embeddings, export_embeddings=args.export_embeddings,
                       test_every=args.test_every)
     optimizer = trainer.build_optimizer(learning_rate=args.learning_rate, fixed_curvature=args.fixed_curvature)
     train_loader, test_loader = dataset.create_loaders(seed=args.seed)
+    if world > 1:  # equal shards: every rank takes the same number of steps per epoch
+        n = (train_loader.images.shape[0] // world) * world
+        train_loader.images = train_loader.images[:n][rank::world].contiguous()
+        train_loader.labels = train_loader.labels[:n][rank::world].contiguous()
+        train_loader.dataset = range(train_loader.images.shape[0])
     betas = utils.linear_betas(args.beta_start, args.beta_end, end_epoch=args.beta_end_epoch, epochs=args.epochs)
     if args.universal:  # the universal training scheme, run.py:139-175
         # pre-training at K = 0 (every `u` component is Euclidean)
@@ -113,6 +135,9 @@ def main(argv=None) -> None:
                                likelihood_n=args.likelihood_n, max_epochs=args.epochs)
     print(flush=True)
     print("Done.", flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -131,7 +131,7 @@ class EpochRunner:
     (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
 
     def __init__(self, eng: StepEngine, images: Tensor, batch: int, seed: int = 0, graph_steps: int = 32,
-                 shuffle: bool = True):
+                 shuffle: bool = True, dp: Optional[DataParallelStep] = None):
         import ctypes as C
 
         from ._lib import check, load, ptr, stream_ptr
@@ -151,13 +151,23 @@ class EpochRunner:
         self._gen = torch.Generator(device=dev).manual_seed(self.seed)
         self._graphs = {}
         self._c = (C, check, load, ptr, stream_ptr)
+        # data parallel: `images` is this rank's shard, `batch` its rows of the global batch; the step becomes
+        # gradients -> all-reduce -> optimizer (captured only when the backend is RCCL)
+        self.dp = dp if (dp is not None and dp.world > 1) else None
+        self.capturable = True
+        if self.dp is not None:
+            import torch.distributed as dist
+            self.capturable = dist.get_backend(self.dp.group) == "nccl"
 
     def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
         C, check, load, ptr, stream_ptr = self._c
         check(load().mvae_prepare_batch(ptr(self.images), ptr(self.perm), self.N, self.D, self.B, self.E,
                                         C.c_uint64(self.seed), ptr(self.eng.counters), self.nb, 1 if train else 0,
                                         ptr(self.x), ptr(self.eps), stream_ptr(self.images.device)))
-        self.eng.train_step(self.x, self.eps, beta, do_curv)
+        if self.dp is None:
+            self.eng.train_step(self.x, self.eps, beta, do_curv)
+        else:
+            self.dp.train_step(self.x, self.eps, beta, do_curv)
 
     def _graph(self, beta: float, do_curv: bool) -> torch.cuda.CUDAGraph:
         # the trainable flags travel in the kernel arguments, so a requires_grad toggle needs a fresh capture
@@ -193,7 +203,7 @@ class EpochRunner:
         if cur % self.nb:
             self.eng.counters[8] = cur + (self.nb - cur % self.nb)
         left = self.nb
-        if use_graphs:
+        if use_graphs and self.capturable:
             g = self._graph(beta, do_curv)
             while left >= self.gs:
                 g.replay()

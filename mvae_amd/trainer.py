@@ -112,13 +112,18 @@ class Trainer:
             for x_mb, _ in train_data:
                 self.model.train_step(optimizer, x_mb, beta=beta)
                 self.global_step += 1
+        dp = getattr(self.model, "_dp", None)
+        world = dp.world if dp is not None else 1
+        if world > 1:  # global sums on every rank: the early-stopping decisions below stay identical across ranks
+            import torch.distributed as dist
+            dist.all_reduce(eng.stats, op=dist.ReduceOp.SUM, group=dp.group)
         sums = eng.read_stats(reset=True)["sum"]  # the only device sync of the epoch
         # The reference asserts isfinite after nearly every op (e.g. vae.py:158 on the loss), a host sync each.  Here a
         # non-finite value in ANY step poisons the running sums, so one check per epoch reports the same condition
         # with the same exception type (MVAE_CHECK_FINITE=1 moves the check to every step, see ModelVAE.train_step).
         if not all(np.isfinite(v) for v in (sums["bce"], sums["kl"], sums["elbo"])):
             raise AssertionError(f"non-finite training statistics in epoch {self.epoch}: {sums}")
-        epoch_stats = EpochStats(sums, length=len(train_data.dataset), beta=beta)
+        epoch_stats = EpochStats(sums, length=len(train_data.dataset) * world, beta=beta)  # equal shards per rank
         print(self._epoch_dict(epoch_stats), flush=True)
         return epoch_stats
 
@@ -139,7 +144,9 @@ class Trainer:
         if er is None or er.images is not train_data.images or er.B != train_data.batch_size:
             seed = int(torch.randint(0, 2**31 - 1, (1,)).item()) if train_data._gen is None else \
                 int(train_data._gen.initial_seed())
-            er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed)
+            dp = getattr(self.model, "_dp", None)
+            seed += 0 if dp is None else dp.rank  # every rank binarises / draws eps from its own Philox stream
+            er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed, dp=dp)
         optimizer.bind(self.model)
         self.model._sync_trainable()
         self.global_step += er.run_epoch(beta, optimizer.curv_condition())

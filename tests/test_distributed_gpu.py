@@ -75,3 +75,28 @@ def test_two_rank_data_parallel_equals_single_process():
     n = 4 + 3
     np.testing.assert_allclose(results[0][2][:3], tot[:3], rtol=2e-4)
     assert results[0][2][3] == 2 * steps and tot[3] == steps  # every rank counts its own steps
+
+
+@pytest.mark.timeout(900)
+def test_cli_data_parallel_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m mvae_amd.run ...`: the CLI's data-parallel mode (global
+    batch split over the ranks, sharded training set, all-reduced gradients and epoch statistics, rank 0 prints) runs
+    to completion, trains (ELBO improves) and stops through the reference's early-stopping logic on every rank."""
+    import re
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVAE_DIST_BACKEND="gloo", MVAE_DIST_ONE_DEVICE="1", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "mvae_amd.run", "--model", "h2,s2,e2",
+           "--fixed_curvature", "False", "--epochs", "4", "--warmup", "3", "--lookahead", "1", "--batch_size", "128",
+           "--likelihood_n", "0", "--seed", "7"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    elbos = [float(m) for m in re.findall(r"TrainEpoch \d+:\s*\{'bce': [-0-9.e]+, 'kl': [-0-9.e]+, 'elbo': ([-0-9.e]+)", out.stdout)]
+    assert len(elbos) >= 3 and all(np.isfinite(elbos)), out.stdout[-2000:]
+    assert elbos[-1] > elbos[0]  # per-sample ELBO of the GLOBAL training set improves
+    assert -400.0 < elbos[-1] < -250.0  # the same range as the single-process run on this synthetic set
+    assert out.stdout.count("Running on:") == 1 and "Done." in out.stdout  # only rank 0 prints
