@@ -3,7 +3,7 @@ where does either go non-finite, and how far apart are the ELBOs before that?"""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvae_amd import synthetic
 from mvae_amd.engine import StepEngine
 from oracle import model as M

@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvae_amd import synthetic  # noqa: E402
 from oracle import model as M  # noqa: E402
 

@@ -21,7 +21,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/conv -o
 # 4b. MFMA-pipe busy cycles (own PMC pass, kernel trace only): the MLP step and the conv step
 MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
 timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- $PMCB > $OUT/pmc_mfma.log 2>&1
-timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma_conv -o conv -- python $ROOT/tools/bench_conv.py 256 5 0 > $OUT/pmc_mfma_conv.log 2>&1
+timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma_conv -o conv -- python $ROOT/tools/bench_conv.py 256 5 > $OUT/pmc_mfma_conv.log 2>&1
 cd $ROOT
 # 5. the un-profiled bench lines of the same build
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err

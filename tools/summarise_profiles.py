@@ -108,7 +108,7 @@ mf, mfc = first("pmc_mfma/**/*counter_collection.csv"), first("pmc_mfma_conv/**/
 if mf or mfc:
     rec = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace "
                      "(own pass) on `bench.py --steps 300 --warmup 50 --graph-steps 0 --no-cpu-baseline` (mlp_step) and "
-                     "`tools/bench_conv.py 256 5 0` (conv_step); per-dispatch averages",
+                     "`tools/bench_conv.py 256 5` (conv_step); per-dispatch averages",
            "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (duration_ns * 2.4 GHz * 1024 SIMDs).  Calibration: the "
                       "counter advances 32 cycles per v_mfma_f32_16x16x4_f32 (k_enc_fwd: 200 WG x 8 waves x 28 MFMAs x "
                       "32 = 1 433 600, exactly the measured value), i.e. 100 % = the 157.3 TFLOP/s f32 peak; "
