@@ -14,8 +14,12 @@
  *   - tensors are row-major, coordinates in the last dim, leading dims flattened to `rows`;
  *   - return value: 0 on success, MVAE_E_* (<0) for argument errors, a positive hipError_t for runtime errors;
  *     mvae_last_error() returns a message for the calling thread's last failure;
- *   - manifold `kind`: the four latent component types of the reference's model-string grammar
- *     (mt/mvae/utils.py:30-38): e, h, s, p.
+ *   - manifold `kind`: the latent component types of the reference's model-string grammar
+ *     (mt/mvae/utils.py:30-38): e, h, s, p, d, u;
+ *   - arithmetic: float32, the reference's formulas, guards and custom backward rules (LeakyClamp, Acosh, ...).  One
+ *     deliberate difference: the derivative of the sphere's acos (spherical.py:104-116) at EXACTLY +-1 is capped at
+ *     1/sqrt(1e-9) instead of infinite, so the backward pass stays finite where the reference's is NaN; no finite
+ *     reference value is changed.
  */
 #ifndef MVAE_HIP_H
 #define MVAE_HIP_H
