@@ -173,6 +173,18 @@ def main():
                         graph_steps=args.graph_steps,
                         world_size=world, reset_every=args.reset_every, force_exchange=args.force_dp)
 
+    if (runner.capture_failed or os.environ.get("MVAE_BENCH_FAKE_CAPTURE_FAILURE")) and world > 1 and \
+            not os.environ.get("MVAE_BENCH_REEXEC"):
+        # An invalidated capture can leave HIP unusable for the rest of the process (every later call reports the
+        # capture error).  Rather than lose the measurement, every rank starts over as a fresh process image without
+        # graphs (all ranks fail alike, so they re-rendezvous; a new port, the old store's socket may still be open).
+        print("[bench] capture of the exchange failed: restarting without HIP graphs", file=sys.stderr, flush=True)
+        os.environ["MVAE_BENCH_REEXEC"] = "1"
+        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29531")) + 17)
+        os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"  # rank 0 hosts a fresh store (the agent's holds stale keys)
+        os.dup2(json_fd, 1)
+        os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--graph-steps", "0"])
+
     def sync_all():
         torch.cuda.synchronize()
         if dist_on:

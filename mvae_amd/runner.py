@@ -40,6 +40,7 @@ class StepRunner:
         self.reset_every = int(reset_every)
         self.since_reset = 0
         self.capture_steps = 0  # steps executed while warming up / capturing (they only touch the statistics)
+        self.capture_failed = False
         self._snapshot = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
@@ -64,6 +65,7 @@ class StepRunner:
                       "running eagerly", file=sys.stderr, flush=True)
                 self.graphs = []
                 self.gs = 0
+                self.capture_failed = True  # callers that can should start over without graphs (bench.py does)
                 _clear_hip_error()
                 torch.cuda.synchronize()
 
