@@ -207,7 +207,8 @@ def main():
     assert finite or os.environ.get("MVAE_BENCH_ALLOW_NONFINITE"), "non-finite ELBO"
 
     if rank != 0:
-        if dist_on:
+        if dist_on:  # leave together with rank 0 (which still profiles the launches): no rank tears the group down early
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -274,6 +275,7 @@ def main():
     os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
 
 

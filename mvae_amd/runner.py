@@ -69,6 +69,13 @@ class StepRunner:
                 _clear_hip_error()
                 torch.cuda.synchronize()
 
+    def _capture_mode(self) -> str:
+        """With a process group alive, ProcessGroupNCCL's watchdog thread polls the events of earlier collectives
+        (hipEventQuery); under the default "global" capture mode such a call from ANOTHER thread is an error while this
+        thread captures ("operation not permitted when stream is capturing": 2 of 12 runs died that way).
+        "thread_local" restricts the check to the capturing thread."""
+        return "thread_local" if self.dp is not None else "global"
+
     def _one(self, i: int) -> None:
         if self.dp is None:
             self.eng.train_step(self.xs[i], self.eps[i], self.beta, self.do_curv)
@@ -89,7 +96,7 @@ class StepRunner:
             torch.cuda.synchronize()
             for gi in range(self.n_data // self.gs):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
                     for i in range(gi * self.gs, (gi + 1) * self.gs):
                         self._one(i)
                 self.graphs.append(g)
@@ -186,7 +193,8 @@ class EpochRunner:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                mode = "thread_local" if self.dp is not None else "global"  # see StepRunner._capture_mode
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     for _ in range(self.gs):
                         self._pair(beta, do_curv)
                 torch.cuda.synchronize()
