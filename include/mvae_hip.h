@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 3
+#define MVAE_ABI_VERSION 4
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -104,6 +104,92 @@ int mvae_inverse_sample_projection_mu0(int kind, const float* z, const float* at
 int mvae_logdet(int kind, const float* u, const float* mu, const float* z, float* out, int64_t rows, int64_t at_rows,
                 int d, const float* radius_param, void* stream);
 
+/* Manifold exp / log maps at a GENERAL base point (the module-level functions the reference's op tests call directly,
+ * tests/mvae/ops/test_hyperbolics.py:168-217): x[rows,A] a tangent vector at at[at_rows,A] (row r uses at[r % at_rows])
+ * -> out[rows,A] on the manifold, and back.
+ * exp_map: hyperbolics.py:106-111 | spherical.py:86-91 | euclidean.py:74-75 | poincare.py:124-129 |
+ * spherical_projected.py:148-154.   inverse_exp_map: hyperbolics.py:124-128 | spherical.py:104-109 |
+ * euclidean.py:82-83 | poincare.py:140-145 | spherical_projected.py:164-169. */
+int mvae_exp_map(int kind, const float* x, const float* at, float* out, int64_t rows, int64_t at_rows, int d,
+                 const float* radius_param, void* stream);
+int mvae_inverse_exp_map(int kind, const float* x, const float* at, float* out, int64_t rows, int64_t at_rows, int d,
+                         const float* radius_param, void* stream);
+
+/* Geodesic distance between points x[rows,A] and y[y_rows,A] -> out[rows].
+ * h: R*acosh(-<x,y>_L/R^2) with the guarded Acosh (tests/mvae/ops/test_hyperbolics.py:46-47; ops/common.py:76-94)
+ * s: R*acos(clamp(<x,y>/R^2,-1,1))                 (tests/mvae/ops/test_spherical.py:45-48)
+ * e: 2*|x-y|                                        (tests/mvae/ops/test_euclidean.py:41-42)
+ * p: poincare_distance                              (ops/poincare.py:92-105)
+ * d: spherical_projected_distance                   (ops/spherical_projected.py:90-97); with MVAE_DIST_GYRO
+ *    spherical_projected_gyro_distance              (ops/spherical_projected.py:100-105)
+ * u: by the sign of the curvature, as everywhere. */
+enum { MVAE_DIST_GEODESIC = 0, MVAE_DIST_GYRO = 1 };
+int mvae_geodesic_distance(int kind, int variant, const float* x, const float* y, float* out, int64_t rows,
+                           int64_t y_rows, int d, const float* radius_param, void* stream);
+
+/* Backward of any primitive above (what torch.autograd does for the reference, ops/manifold.py:22-60 being plain
+ * differentiable torch code + the custom Functions of ops/common.py:28-94).  `op` = MVAE_OP_*; a, b, c3 are the
+ * primitive's inputs in the order of its forward call (unused ones NULL):
+ *   EXP0 a=x | LOG0 a=x | PT0/IPT0 a=x b=dst/src | SAMPLE a=v b=at | ISAMPLE a=z b=at | LOGDET a=u (h,s) or b=mu c3=z
+ *   (p,d,u) | EXP/LOG a=x b=at | DIST/DIST_GYRO a=x b=y
+ * g1 (and g2 for the two-output primitives SAMPLE: (z,u), ISAMPLE: (u,v); may be NULL) are the upstream gradients.
+ * Outputs (any may be NULL): ga[rows,.], gb[rows,.] (PER ROW even when b was broadcast over at_rows < rows: the caller
+ * sums the sample dim), gc[rows,.], gr[rows] = per-row terms of d/d(radius_param) (caller sums them in index order, so
+ * the result is deterministic; for MVAE_UNIVERSAL this is d/dK). */
+enum {
+  MVAE_OP_EXP0 = 0, MVAE_OP_LOG0 = 1, MVAE_OP_PT0 = 2, MVAE_OP_IPT0 = 3, MVAE_OP_SAMPLE = 4, MVAE_OP_ISAMPLE = 5,
+  MVAE_OP_LOGDET = 6, MVAE_OP_EXP = 7, MVAE_OP_LOG = 8, MVAE_OP_DIST = 9, MVAE_OP_DIST_GYRO = 10,
+  /* auxiliary functions of mvae_manifold_aux below (a = x, b = y) */
+  MVAE_OP_LPROD = 11, MVAE_OP_LNORM = 12, MVAE_OP_TO_BALL = 13, MVAE_OP_TO_AMBIENT = 14, MVAE_OP_LAMBDA = 15,
+  MVAE_OP_MOBADD = 16,
+  /* diagonal-normal pieces of mvae_normal_op below (a = value / eps / loc, b = loc, c3 = scale; for these BOTH b and c3
+   * are broadcast over at_rows and gb, gc are per-row gradients) */
+  MVAE_OP_NORMAL_LOGPROB = 17, MVAE_OP_NORMAL_RSAMPLE = 18, MVAE_OP_NORMAL_KL = 19
+};
+int mvae_primitive_backward(int op, int kind, const float* a, const float* b, const float* c3, const float* g1,
+                            const float* g2, float* ga, float* gb, float* gc, float* gr, int64_t rows,
+                            int64_t at_rows, int d, const float* radius_param, void* stream);
+
+/* Small public helpers of the reference's ops modules, x[rows,.] (and y[rows,.]) -> out[rows,.]:
+ *   MVAE_OP_LPROD      <x,y>_L (h: hyperbolics.py:72-78; other kinds: the plain dot product)         -> [rows,1]
+ *   MVAE_OP_LNORM      sqrt(<x,x>_L) with the guarded sqrt (h: hyperbolics.py:81-84; else |x|_2)     -> [rows,1]
+ *   MVAE_OP_TO_BALL    lorentz_to_poincare (h, hyperbolics.py:151-152) | spherical_to_projected (s,
+ *                      spherical.py:132-133): [rows,d+1] -> [rows,d]
+ *   MVAE_OP_TO_AMBIENT poincare_to_lorentz (p, poincare.py:167-170) | projected_to_spherical (d,
+ *                      spherical_projected.py:191-196): [rows,d] -> [rows,d+1]   (d + 1 <= MVAE_MAX_TRUE_DIM)
+ *   MVAE_OP_LAMBDA     conformal factor lambda_x (p: geoopt lambda_x; d: spherical_projected.py:124-129) -> [rows,1]
+ *   MVAE_OP_MOBADD     Moebius addition x (+) y with c = 1/R^2 (p) or K = 1/R^2 (d, spherical_projected.py:107-113)
+ * Differentiable through mvae_primitive_backward like the primitives above. */
+int mvae_manifold_aux(int op, int kind, const float* x, const float* y, float* out, int64_t rows, int d,
+                      const float* radius_param, void* stream);
+
+/* The diagonal normal underneath WrappedNormal / EuclideanNormal (distributions/wrapped_normal.py:60,
+ * wrapped_distributions.py:39-42; torch.distributions.Normal formulas), loc / scale [param_rows, d] broadcast over the
+ * leading sample dims of a[rows, d]:
+ *   MVAE_OP_NORMAL_LOGPROB  out[rows]    = sum_i log N(a_i; loc_i, scale_i)            (EuclideanNormal.log_prob)
+ *   MVAE_OP_NORMAL_RSAMPLE  out[rows, d] = loc + a * scale                             (Normal.rsample with eps = a)
+ *   MVAE_OP_NORMAL_KL       out[rows]    = KL(N(a, scale) || N(0, 1)) summed over d    (sampling_procedures.py:153-155;
+ *                                          loc unused, param_rows == rows)
+ * Differentiable through mvae_primitive_backward. */
+int mvae_normal_op(int op, const float* a, const float* loc, const float* scale, float* out, int64_t rows,
+                   int64_t param_rows, int d, void* stream);
+
+/* The reference's guarded scalar functions and their custom derivative rules (ops/common.py:28-147: LeakyClamp, Atanh,
+ * Acosh, cosh, sinh, sqrt, logsinh, logcosh) plus the short float32 elementary functions the kernels substitute for
+ * libm (csrc/mvae_fastmath.hpp), evaluated by the DEVICE code of the manifold kernels: y[i] = f(x[i]) through the float
+ * path, dy[i] = f'(x[i]) through the dual-number rule (dy may be NULL).  lo/hi: bounds of MVAE_FN_CLAMP.
+ * The *_PAIR ids return the two values the manifolds compute together: y = cosh|cos, dy = sinh|sin. */
+enum {
+  MVAE_FN_CLAMP = 0, MVAE_FN_ATANH, MVAE_FN_ACOSH, MVAE_FN_COSH, MVAE_FN_SINH, MVAE_FN_SQRT, MVAE_FN_LOGSINH,
+  MVAE_FN_LOGCOSH, MVAE_FN_COSH_SINH_PAIR, MVAE_FN_COS_SIN_PAIR, MVAE_FN_SOFTPLUS, MVAE_FN_ACOS, MVAE_FN_TAN,
+  MVAE_FN_LOG1P_POS, MVAE_FN_EXP, MVAE_FN_LOG, MVAE_FN_STD /* softplus(x) + 1e-5, component.py:72 */, MVAE_FN_COUNT
+};
+int mvae_scalar_fn(int fn, const float* x, float* y, float* dy, int64_t n, float lo, float hi, void* stream);
+/* out[i] = a[i] * b[i]: the chain-rule product g * f'(x) of the scalar functions' backward (out may alias a or b). */
+int mvae_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out[r][j] = g[r][j] * s[r]: the backward of a per-row loss (sum_j BCE) given its upstream gradient s[rows]. */
+int mvae_scale_rows(const float* g, const float* s, float* out, int64_t rows, int D, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * One latent component end to end:  Component.encode (component.py:63-75, given the two Linear-head outputs) ->
  * SamplingProcedure.reparametrize (sampling_procedures.py:93-99 | 147-151) -> q_z.rsample_with_parts
@@ -131,12 +217,15 @@ int mvae_component_forward(const mvae_component_desc* comps, int ncomp, const fl
                            void* stream);
 
 /* Backward of the above for the training path (rows == head_rows): given dz[rows, z_ld] and dkl[ncomp, rows]
- * (NULL = the scalar `dkl_scalar` for every entry), writes dheads[rows, heads_ld] and ACCUMULATES (atomicAdd) into
- * dradii[ncomp] (zero it first).  Gradient rules include the reference's non-standard ones (common.py:28-94). */
+ * (NULL = the scalar `dkl_scalar` for every entry), writes dheads[rows, heads_ld] and dradii[ncomp] (may be NULL).
+ * dradii is a fixed-order sum of per-row terms staged in `workspace`
+ * (mvae_component_backward_workspace_floats(ncomp, rows) floats): no atomics, bit-reproducible.
+ * Gradient rules include the reference's non-standard ones (common.py:28-94). */
+int64_t mvae_component_backward_workspace_floats(int ncomp, int64_t rows);
 int mvae_component_backward(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
                             const float* eps, int eps_ld, const float* radii, const float* dz, int z_ld,
-                            const float* dkl, float dkl_scalar, float* dheads, float* dradii, int64_t rows,
-                            void* stream);
+                            const float* dkl, float dkl_scalar, float* dheads, float* dradii, float* workspace,
+                            int64_t rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Dense layers (torch.nn.Linear semantics: y = x W^T + b, W is [N, K]).  FeedForwardVAE.encode / decode,

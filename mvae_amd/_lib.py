@@ -12,10 +12,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
+# MVAE_OP_* (mvae_primitive_backward) and MVAE_FN_* (mvae_scalar_fn) of include/mvae_hip.h
+(OP_EXP0, OP_LOG0, OP_PT0, OP_IPT0, OP_SAMPLE, OP_ISAMPLE, OP_LOGDET, OP_EXP, OP_LOG, OP_DIST, OP_DIST_GYRO, OP_LPROD,
+ OP_LNORM, OP_TO_BALL, OP_TO_AMBIENT, OP_LAMBDA, OP_MOBADD, OP_NORMAL_LOGPROB, OP_NORMAL_RSAMPLE,
+ OP_NORMAL_KL) = range(20)
+DIST_GEODESIC, DIST_GYRO = 0, 1
+SCALAR_FNS = {name: i for i, name in enumerate(
+    ["clamp", "atanh", "acosh", "cosh", "sinh", "sqrt", "logsinh", "logcosh", "cosh_sinh_pair", "cos_sin_pair",
+     "softplus", "acos", "tan", "log1p_pos", "exp", "log", "std"])}
 
 
 class ComponentDesc(C.Structure):
@@ -47,10 +55,20 @@ PROTOTYPES = {
     "mvae_sample_projection_mu0": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
     "mvae_inverse_sample_projection_mu0": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
     "mvae_logdet": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_exp_map": (C.c_int, [_I, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_inverse_exp_map": (C.c_int, [_I, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_geodesic_distance": (C.c_int, [_I, _I, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_manifold_aux": (C.c_int, [_I, _I, _P, _P, _P, _L, _I, _P, _P]),
+    "mvae_normal_op": (C.c_int, [_I, _P, _P, _P, _P, _L, _L, _I, _P]),
+    "mvae_primitive_backward": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "mvae_scalar_fn": (C.c_int, [_I, _P, _P, _P, _L, _F, _F, _P]),
+    "mvae_mul": (C.c_int, [_P, _P, _P, _L, _P]),
     "mvae_component_forward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
                                          _L, _L, _P]),
-    "mvae_component_backward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _F, _P, _P,
+    "mvae_component_backward_workspace_floats": (C.c_int64, [_I, _L]),
+    "mvae_component_backward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _F, _P, _P, _P,
                                           _L, _P]),
+    "mvae_scale_rows": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),

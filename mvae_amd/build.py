@@ -1,41 +1,77 @@
-"""Builds libmvae_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+"""Builds libmvae_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
+
+The library is three translation units (csrc/mvae_api.hip, mvae_step.hip, mvae_conv.hip) compiled in parallel into
+csrc/_obj/*.o and linked; a unit is recompiled only when it or a header is newer than its object.
+
+    python -m mvae_amd.build [--force] [--timing]      (--timing: the -DMV_DBG_TIMING build used by tools/phase_timing.py,
+                                                        written to libmvae_hip_timing.so)
+"""
 import os
 import shutil
 import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "mvae_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mvae_math.hpp"), os.path.join(HERE, "csrc", "mvae_gemm.hpp"),
-        os.path.join(HERE, "csrc", "mvae_fastmath.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "mvae_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+UNITS = ["mvae_api", "mvae_step", "mvae_conv"]
+HEADERS = [os.path.join(CSRC, h) for h in ("mvae_common.hpp", "mvae_math.hpp", "mvae_gemm.hpp", "mvae_fastmath.hpp")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "mvae_hip.h")]
+DEPS = [os.path.join(CSRC, u + ".hip") for u in UNITS] + HEADERS
 LIB = os.path.join(HERE, "libmvae_hip.so")
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value",
+         # a/b and sqrt lower to v_rcp_f32 / v_sqrt_f32 sequences (<= 2.5 ulp) instead of the ~10-instruction
+         # correctly-rounded expansions: the manifold chain is latency-bound and the parity bar is 1e-4
+         "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+         # subnormal f32 inputs/outputs of VALU ops flush to zero (MFMA C/D never flush): removes the frexp/ldexp
+         # range scaling around every v_rcp_f32 / v_exp_f32 / v_log_f32; and a/b may become a * (1/b)
+         "-fgpu-flush-denormals-to-zero", "-freciprocal-math"]
 
-def lib_is_fresh() -> bool:
-    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+
+def lib_is_fresh(lib: str = LIB) -> bool:
+    return os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and lib_is_fresh():
-        return LIB
+def _hipcc() -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmvae_hip.so")
-    tmp = f"{LIB}.{os.getpid()}.tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value",
-           # a/b and sqrt lower to v_rcp_f32 / v_sqrt_f32 sequences (<= 2.5 ulp) instead of the ~10-instruction
-           # correctly-rounded expansions: the manifold chain is latency-bound and the parity bar is 1e-4
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           # subnormal f32 inputs/outputs of VALU ops flush to zero (MFMA C/D never flush): removes the frexp/ldexp
-           # range scaling around every v_rcp_f32 / v_exp_f32 / v_log_f32; and a/b may become a * (1/b)
-           "-fgpu-flush-denormals-to-zero", "-freciprocal-math",
-           "-o", tmp, SRC]
+    return hipcc
+
+
+def build(force: bool = False, verbose: bool = False, timing: bool = False) -> str:
+    lib = LIB if not timing else os.path.join(HERE, "libmvae_hip_timing.so")
+    if not force and lib_is_fresh(lib):
+        return lib
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "_obj_timing" if timing else "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    extra = ["-DMV_DBG_TIMING"] if timing else []
+    newest_header = max(os.path.getmtime(h) for h in HEADERS)
+
+    def compile_unit(u: str) -> str:
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
+            return obj
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
+        objs = list(pool.map(compile_unit, UNITS))
+    tmp = f"{lib}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(tmp, LIB)  # atomic: concurrent builders (one per rank) never expose a partial file
-    return LIB
+    os.replace(tmp, lib)  # atomic: concurrent builders (one per rank) never expose a partial file
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))

@@ -48,15 +48,17 @@ class Component(torch.nn.Module):
         return getattr(self, "_nradius", getattr(self, "_pradius", getattr(self, "_curvature", None)))
 
     def _radii_tensor(self) -> Tensor:
+        """The raw radius / curvature parameter as a [1] tensor (keeps its autograd history)."""
         r = self._radius_param()
         if r is None:
             return torch.zeros(1, device=self.device)
-        return r.detach().reshape(1)
+        return r.reshape(1)
 
     def _heads(self, x: Tensor) -> Tensor:
-        W = torch.cat((self.fc_mean.weight.detach(), self.fc_logvar.weight.detach()), dim=0)
-        b = torch.cat((self.fc_mean.bias.detach(), self.fc_logvar.bias.detach()), dim=0)
-        return Fn.linear_forward(x, W, b)
+        """fc_mean(x) and fc_logvar(x) as ONE contraction over the stacked weights; differentiable (Fn.linear)."""
+        W = torch.cat((self.fc_mean.weight, self.fc_logvar.weight), dim=0)
+        b = torch.cat((self.fc_mean.bias, self.fc_logvar.bias), dim=0)
+        return Fn.linear(x, W, b)
 
     def forward(self, x: Tensor):  # component.py:32-35
         q_z = FusedPosterior(self, self._heads(x))
@@ -66,6 +68,11 @@ class Component(torch.nn.Module):
     def encode(self, x: Tensor) -> Tuple[Tensor, Tensor]:  # component.py:63-75
         q_z = FusedPosterior(self, self._heads(x))
         return q_z.loc, q_z.scale
+
+    def reparametrize(self, z_mean: Tensor, std: Tensor):  # component.py:77-78
+        """Free-standing (q_z, p_z) from already-encoded parameters, as the reference's method; Component.forward
+        returns the fused posterior instead (same protocol, one launch)."""
+        return self.sampling_procedure.reparametrize(z_mean, std)
 
     def kl_loss(self, q_z, p_z, z: Tensor, data: Tuple) -> Tensor:
         return self.sampling_procedure.kl_loss(q_z, p_z, z, data)

@@ -1,0 +1,771 @@
+// mvae_api.hip -- the operator-level part of the C ABI (include/mvae_hip.h): manifold primitives and their backward,
+// the reference's guarded scalar functions, the per-component operators, generic dense layers, log-likelihood helpers.
+#include "mvae_common.hpp"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a, long long b) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+
+extern "C" int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+extern "C" const char* mvae_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ generic kernels (API)
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_linear_fwd(const float* x, const float* W, const float* b, float* y, int M,
+                                                    int N, int K) {
+  __shared__ float red[4][16][17];
+  job_linear_fwd<RELU>(red, x, K, W, K, b, y, N, M, N, K, blockIdx.y, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_linear_bwd(const float* x, const float* W, const float* dy, float* dW,
+                                                    float* db, float* dx, int M, int N, int K, int relu_in, int n_dw,
+                                                    int n_dx) {
+  __shared__ float red[4][16][17];
+  int b = blockIdx.x;
+  const int ntN = (N + 15) / 16, ntK = (K + 15) / 16, ntM = (M + 15) / 16;
+  if (b < n_dx) {  // dx[M,K] = dy[M,N] W[N,K]
+    job_nn(red, dy, N, M, b / ntK, W, K, K, b % ntK, N, relu_in ? x : nullptr, K, dx, K);
+    return;
+  }
+  b -= n_dx;
+  if (b < n_dw) {  // dW[N,K] = dy^T x
+    job_tn(red, dy, N, N, b / ntK, x, K, K, b % ntK, M, dW, K);
+    return;
+  }
+  b -= n_dw;
+  (void)ntM;
+  (void)ntN;
+  job_colsum(&red[0][0][0], dy, N, M, N, b * kColsPerBlock, db);
+}
+
+// ------------------------------------------------------------------------------------------------ primitives (API)
+// Every primitive is ONE register-level template over the scalar type (prim_eval): T = float is the forward kernel,
+// T = Dual the backward kernel (one thread per (row, input entry) evaluates the primitive along that input direction
+// and contracts the output tangents with the upstream gradient -- the custom derivative rules of mvae_math.hpp apply,
+// so torch.autograd sees exactly the reference's gradients).
+enum PrimOp {
+  OP_EXP0 = 0, OP_LOG0, OP_PT0, OP_IPT0, OP_SAMPLE, OP_ISAMPLE, OP_LOGDET, OP_EXP, OP_LOG, OP_DIST, OP_DIST_GYRO,
+  OP_LPROD, OP_LNORM, OP_TO_BALL, OP_TO_AMBIENT, OP_LAMBDA, OP_MOBADD,
+  // kind-independent diagonal-normal pieces (a = value / eps / loc; b = loc, c3 = scale, BOTH broadcast over at_rows)
+  OP_NORMAL_LOGPROB, OP_NORMAL_RSAMPLE, OP_NORMAL_KL, OP_COUNT
+};
+
+// lengths of the row vectors of (op, RESOLVED kind, d): inputs a, b, c; outputs o1, o2.  b is the operand that may be
+// broadcast over leading sample dims (row r reads b[r % at_rows]).
+struct PrimShape {
+  int na, nb, nc, n1, n2;
+};
+__host__ __device__ inline PrimShape prim_shape(int op, int kind, int d) {
+  const int A = ambient_dim(kind, d);
+  const bool proj = kind == kPoincare || kind == kProjSphere;
+  switch (op) {
+    case OP_EXP0: return PrimShape{d, 0, 0, A, 0};
+    case OP_LOG0: return PrimShape{A, 0, 0, A, 0};
+    case OP_PT0:
+    case OP_IPT0: return PrimShape{A, A, 0, A, 0};
+    case OP_SAMPLE: return PrimShape{d, A, 0, A, A};
+    case OP_ISAMPLE: return PrimShape{A, A, 0, A, d};
+    case OP_LOGDET:
+      if (proj) return PrimShape{0, A, A, 1, 0};
+      if (kind == kEuclidean) return PrimShape{0, 0, 0, 1, 0};
+      return PrimShape{A, 0, 0, 1, 0};
+    case OP_EXP:
+    case OP_LOG:
+    case OP_MOBADD: return PrimShape{A, A, 0, A, 0};
+    case OP_LNORM:
+    case OP_LAMBDA: return PrimShape{A, 0, 0, 1, 0};
+    case OP_TO_BALL: return PrimShape{A, 0, 0, d, 0};       // h -> p, s -> d: ambient d+1 -> d
+    case OP_TO_AMBIENT: return PrimShape{d, 0, 0, d + 1, 0};  // p -> h, d -> s
+    case OP_NORMAL_LOGPROB: return PrimShape{d, d, d, 1, 0};
+    case OP_NORMAL_RSAMPLE: return PrimShape{d, d, d, d, 0};
+    case OP_NORMAL_KL: return PrimShape{d, 0, d, 1, 0};
+    default: return PrimShape{A, A, 0, 1, 0};  // geodesic distances, Lorentz product
+  }
+}
+
+template <int OP, int KIND, int DMAX, typename T>
+__device__ __forceinline__ void prim_eval(const T* a, const T* b, const T* c3, T rp, int d, T* o1, T* o2) {
+  constexpr int AMAX = DMAX + 1;
+  MV_BOUNDS(AMAX);
+  const int A = ambient_dim(KIND, d);
+  T R = cst<T>(0.f);
+  if constexpr (KIND != kEuclidean) R = radius_of(rp);
+  if constexpr (OP == OP_EXP0) {
+    exp_map_mu0<KIND, AMAX>(a, d, R, o1);
+  } else if constexpr (OP == OP_LOG0) {
+    log_map_mu0<KIND, AMAX>(a, A, R, o1);
+  } else if constexpr (OP == OP_PT0) {
+    pt_mu0<KIND, AMAX>(a, b, A, R, o1);
+  } else if constexpr (OP == OP_IPT0) {
+    inv_pt_mu0<KIND, AMAX>(a, b, A, R, o1);
+  } else if constexpr (OP == OP_SAMPLE) {  // a = v[d], b = at[A] -> o1 = z, o2 = u
+    if constexpr (KIND == kEuclidean) {
+      MV_FOR(i, 0, d) o2[i] = a[i];
+    } else if constexpr (KIND == kPoincare || KIND == kProjSphere) {
+      T lam;
+      if constexpr (KIND == kPoincare) lam = p_lambda<AMAX>(b, A, 1.0f / (R * R));
+      else lam = d_lambda<AMAX>(b, A, 1.0f / (R * R));
+      MV_FOR(i, 0, d) o2[i] = a[i] / lam;
+    } else {
+      T x[AMAX];
+      x[0] = cst<T>(0.f);
+      MV_FOR(i, 1, A) x[i] = a[i - 1];
+      pt_mu0<KIND, AMAX>(x, b, A, R, o2);
+    }
+    exp_map<KIND, AMAX>(o2, b, A, R, o1);
+  } else if constexpr (OP == OP_ISAMPLE) {  // a = z[A], b = at[A] -> o1 = u[A], o2 = v[d]
+    log_map<KIND, AMAX>(a, b, A, R, o1);
+    if constexpr (KIND == kEuclidean) {
+      MV_FOR(i, 0, d) o2[i] = o1[i];
+    } else if constexpr (KIND == kPoincare || KIND == kProjSphere) {
+      T lam;
+      if constexpr (KIND == kPoincare) lam = p_lambda<AMAX>(b, A, 1.0f / (R * R));
+      else lam = d_lambda<AMAX>(b, A, 1.0f / (R * R));
+      MV_FOR(i, 0, d) o2[i] = o1[i] * lam;
+    } else {
+      T w[AMAX];
+      inv_pt_mu0<KIND, AMAX>(o1, b, A, R, w);
+      MV_FOR(i, 1, A) o2[i - 1] = w[i];
+    }
+  } else if constexpr (OP == OP_LOGDET) {  // a = u (h, s) ; b = mu, c3 = z (p, d)
+    if constexpr (KIND == kEuclidean) o1[0] = cst<T>(0.f);
+    else if constexpr (KIND == kPoincare) o1[0] = p_logdet<AMAX>(b, c3, A, R);
+    else if constexpr (KIND == kProjSphere) o1[0] = d_logdet<AMAX>(b, c3, A, R);
+    else o1[0] = logdet_u<KIND, AMAX>(a, A, R);
+  } else if constexpr (OP == OP_EXP) {  // a = tangent vector at b
+    exp_map<KIND, AMAX>(a, b, A, R, o1);
+  } else if constexpr (OP == OP_LOG) {  // a = point, b = base point
+    log_map<KIND, AMAX>(a, b, A, R, o1);
+  } else if constexpr (OP == OP_DIST || OP == OP_DIST_GYRO) {  // geodesic distance between the points a and b
+    o1[0] = geodesic_distance<KIND, AMAX>(a, b, A, R, OP == OP_DIST_GYRO);
+  } else if constexpr (OP == OP_LPROD) {  // hyperbolics.py:72-78 (h); the plain dot product elsewhere
+    if constexpr (KIND == kHyperboloid) o1[0] = lorentz_product<AMAX>(a, b, A);
+    else o1[0] = dot<AMAX>(a, b, A);
+  } else if constexpr (OP == OP_LNORM) {  // hyperbolics.py:81-84 (h): guarded sqrt of <x,x>_L; torch.norm elsewhere
+    if constexpr (KIND == kHyperboloid) o1[0] = g_sqrt(lorentz_product<AMAX>(a, a, A));
+    else o1[0] = norm2<AMAX>(a, A);
+  } else if constexpr (OP == OP_TO_BALL) {  // lorentz_to_poincare hyperbolics.py:151-152 | spherical_to_projected spherical.py:132-133
+    if constexpr (KIND == kHyperboloid || KIND == kSphere) {
+      MV_FOR(i, 1, A) o1[i - 1] = R * a[i] / (R + a[0]);
+    } else {
+      MV_FOR(i, 0, d) o1[i] = a[i];
+    }
+  } else if constexpr (OP == OP_TO_AMBIENT) {  // poincare_to_lorentz poincare.py:167-170 | projected_to_spherical spherical_projected.py:191-196
+    if constexpr (KIND == kPoincare) poincare_to_lorentz<AMAX>(a, d, R, o1);
+    else if constexpr (KIND == kProjSphere) projected_to_spherical<AMAX>(a, d, R, o1);
+    else {
+      MV_FOR(i, 0, d + 1) o1[i] = cst<T>(0.f);
+    }
+  } else if constexpr (OP == OP_LAMBDA) {  // geoopt lambda_x (p) | lambda_x spherical_projected.py:124-129 (d)
+    if constexpr (KIND == kPoincare) o1[0] = p_lambda<AMAX>(a, A, 1.0f / (R * R));
+    else if constexpr (KIND == kProjSphere) o1[0] = d_lambda<AMAX>(a, A, 1.0f / (R * R));
+    else o1[0] = cst<T>(2.0f);
+  } else if constexpr (OP == OP_NORMAL_LOGPROB) {  // sum_i log N(a_i; loc_i, scale_i), torch Normal.log_prob(.).sum(-1)
+    T acc = cst<T>(0.f);
+    MV_FOR(i, 0, d) {
+      T term = normal_logprob_term(a[i] - b[i], c3[i]);
+      acc = (i == 0) ? term : acc + term;
+    }
+    o1[0] = acc;
+  } else if constexpr (OP == OP_NORMAL_RSAMPLE) {  // Normal.rsample: loc + eps * scale
+    MV_FOR(i, 0, d) o1[i] = b[i] + a[i] * c3[i];
+  } else if constexpr (OP == OP_NORMAL_KL) {  // kl_divergence(N(a, c3), N(0, 1)).sum(-1)  (torch _kl_normal_normal)
+    T acc = cst<T>(0.f);
+    MV_FOR(i, 0, d) {
+      T var_ratio = (c3[i] / 1.0f) * (c3[i] / 1.0f);
+      T t1 = ((a[i] - 0.0f) / 1.0f) * ((a[i] - 0.0f) / 1.0f);
+      T term = 0.5f * (var_ratio + t1 - 1.0f - t_log(var_ratio));
+      acc = (i == 0) ? term : acc + term;
+    }
+    o1[0] = acc;
+  } else {  // OP_MOBADD: geoopt mobius_add with c = 1/R^2 (p) | mob_add with K = 1/R^2 (d), spherical_projected.py:107-113
+    if constexpr (KIND == kPoincare) p_mobius_add<AMAX>(a, b, A, 1.0f / (R * R), o1);
+    else if constexpr (KIND == kProjSphere) p_mobius_add<AMAX>(a, b, A, -(1.0f / (R * R)), o1);
+    else {
+      MV_FOR(i, 0, A) o1[i] = a[i] + b[i];
+    }
+  }
+}
+
+template <int OP, int KIND, int DMAX>
+__device__ __forceinline__ void prim_row(const float* a, const float* b, const float* c3, float* o1, float* o2, int d,
+                                         float rp, int64_t r, int64_t at_rows) {
+  constexpr int AMAX = DMAX + 1;
+  MV_BOUNDS(AMAX);
+  const PrimShape sh = prim_shape(OP, KIND, d);
+  float ta[AMAX], tb[AMAX], tc[AMAX], t1[AMAX], t2[AMAX];
+  const int64_t ar = r % at_rows;
+  MV_FOR(i, 0, sh.na) ta[i] = a[r * sh.na + i];
+  MV_FOR(i, 0, sh.nb) tb[i] = b[ar * sh.nb + i];
+  const int64_t cr = (OP >= OP_NORMAL_LOGPROB) ? ar : r;  // the normal ops broadcast BOTH parameters
+  MV_FOR(i, 0, sh.nc) tc[i] = c3[cr * sh.nc + i];
+  prim_eval<OP, KIND, DMAX, float>(ta, tb, tc, rp, d, t1, t2);
+  MV_FOR(i, 0, sh.n1) o1[r * sh.n1 + i] = t1[i];
+  if (o2) {
+    MV_FOR(i, 0, sh.n2) o2[r * sh.n2 + i] = t2[i];
+  }
+}
+
+#define MV_PRIM_KIND_SWITCH(FN, ...)                                   \
+  if constexpr (OP >= OP_NORMAL_LOGPROB) {                             \
+    FN<OP, kEuclidean, DMAX>(__VA_ARGS__); /* kind-independent */      \
+  } else                                                               \
+  switch (kind) {                                                      \
+    case kEuclidean: FN<OP, kEuclidean, DMAX>(__VA_ARGS__); break;     \
+    case kHyperboloid: FN<OP, kHyperboloid, DMAX>(__VA_ARGS__); break; \
+    case kSphere: FN<OP, kSphere, DMAX>(__VA_ARGS__); break;           \
+    case kProjSphere: FN<OP, kProjSphere, DMAX>(__VA_ARGS__); break;   \
+    default: FN<OP, kPoincare, DMAX>(__VA_ARGS__); break;              \
+  }
+
+template <int OP, int DMAX>
+__global__ __launch_bounds__(256) void k_prim(int kind, const float* a, const float* b, const float* c3, float* o1,
+                                              float* o2, int64_t rows, int64_t at_rows, int d,
+                                              const float* radius_param) {
+  float rp = (kind == kEuclidean || !radius_param) ? 0.f : radius_param[0];
+  kind = resolve_universal(kind, rp);  // for `u`, radius_param holds the curvature K
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    MV_PRIM_KIND_SWITCH(prim_row, a, b, c3, o1, o2, d, rp, r, at_rows)
+  }
+}
+
+// Backward of one (row, input entry j): j enumerates a, then b, then c3, then the radius / curvature parameter.
+// ga/gb/gc are per-ROW gradients ([rows, na], [rows, nb], [rows, nc]; a broadcast `b` is reduced by the caller) and
+// gr[rows] the per-row terms of the radius gradient (the caller sums them in index order: no atomics).
+template <int OP, int KIND, int DMAX>
+__device__ __forceinline__ void prim_bwd_item(const float* a, const float* b, const float* c3, const float* g1,
+                                              const float* g2, float* ga, float* gb, float* gc, float* gr, int d,
+                                              Dual rp, int64_t r, int64_t at_rows, int j) {
+  constexpr int AMAX = DMAX + 1;
+  MV_BOUNDS(AMAX);
+  const PrimShape sh = prim_shape(OP, KIND, d);
+  Dual ta[AMAX], tb[AMAX], tc[AMAX], t1[AMAX], t2[AMAX];
+  const int64_t ar = r % at_rows;
+  MV_FOR(i, 0, sh.na) ta[i] = Dual{a[r * sh.na + i], j == i ? 1.f : 0.f};
+  MV_FOR(i, 0, sh.nb) tb[i] = Dual{b[ar * sh.nb + i], j == sh.na + i ? 1.f : 0.f};
+  const int64_t cr = (OP >= OP_NORMAL_LOGPROB) ? ar : r;
+  MV_FOR(i, 0, sh.nc) tc[i] = Dual{c3[cr * sh.nc + i], j == sh.na + sh.nb + i ? 1.f : 0.f};
+  rp.d = (j == sh.na + sh.nb + sh.nc) ? rp.d : 0.f;
+  MV_FOR(i, 0, AMAX) t2[i] = Dual{0.f, 0.f};
+  prim_eval<OP, KIND, DMAX, Dual>(ta, tb, tc, rp, d, t1, t2);
+  float g = 0.f;
+  MV_FOR(i, 0, sh.n1) g += g1[r * sh.n1 + i] * t1[i].d;
+  if (g2) {
+    MV_FOR(i, 0, sh.n2) g += g2[r * sh.n2 + i] * t2[i].d;
+  }
+  if (j < sh.na) {
+    if (ga) ga[r * sh.na + j] = g;
+  } else if (j < sh.na + sh.nb) {
+    if (gb) gb[r * sh.nb + (j - sh.na)] = g;
+  } else if (j < sh.na + sh.nb + sh.nc) {
+    if (gc) gc[r * sh.nc + (j - sh.na - sh.nb)] = g;
+  } else if (gr) {
+    gr[r] = g;
+  }
+}
+
+template <int OP, int DMAX>
+__global__ __launch_bounds__(256) void k_prim_bwd(int kind, const float* a, const float* b, const float* c3,
+                                                  const float* g1, const float* g2, float* ga, float* gb, float* gc,
+                                                  float* gr, int64_t rows, int64_t at_rows, int d,
+                                                  const float* radius_param) {
+  // the radius / curvature direction carries the chain through resolve_universal (d radius / d K for `u`)
+  Dual rp = Dual{(kind == kEuclidean || !radius_param) ? 0.f : radius_param[0], 1.f};
+  kind = resolve_universal(kind, rp);
+  const PrimShape sh = prim_shape(OP, kind, d);
+  const int nin = sh.na + sh.nb + sh.nc + 1;
+  const int64_t items = rows * nin;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t r = it / nin;
+    const int j = (int)(it - r * nin);
+    MV_PRIM_KIND_SWITCH(prim_bwd_item, a, b, c3, g1, g2, ga, gb, gc, gr, d, rp, r, at_rows, j)
+  }
+}
+#undef MV_PRIM_KIND_SWITCH
+
+static int prim_check(int kind, int64_t rows, int d, const float* rp) {
+  if (kind < 0 || kind >= kNumKinds) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", kind);
+  if (rows < 0 || d < 1) return fail(MVAE_E_BADARG, "bad rows/d%s (%lld)", "", d);
+  if (d > MVAE_MAX_TRUE_DIM) return fail(MVAE_E_UNSUPPORTED, "true_dim > MVAE_MAX_TRUE_DIM%s (%lld)", "", d);
+  if (kind != MVAE_EUCLIDEAN && !rp) return fail(MVAE_E_BADARG, "radius_param is NULL%s", "");
+  return 0;
+}
+
+template <int OP>
+static int launch_prim(int kind, const float* a, const float* b, const float* c3, float* o1, float* o2, int64_t rows,
+                       int64_t at_rows, int d, const float* rp, void* stream) {
+  int rc = prim_check(kind, rows, d, rp);
+  if (rc) return rc;
+  if (rows == 0) return 0;
+  if (at_rows < 1) at_rows = rows;
+  int grid = (int)((rows + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+#define PRIM_CASE(B) \
+  case B: hipLaunchKernelGGL((k_prim<OP, B>), dim3(grid), dim3(256), 0, s, kind, a, b, c3, o1, o2, rows, at_rows, d, rp); break;
+  switch (bucket_of(d)) {
+    PRIM_CASE(2) PRIM_CASE(4) PRIM_CASE(8) PRIM_CASE(16) PRIM_CASE(32) PRIM_CASE(64)
+  }
+#undef PRIM_CASE
+  LAUNCH_CHECK("primitive launch");
+  return 0;
+}
+
+template <int OP>
+static int launch_prim_bwd(int kind, const float* a, const float* b, const float* c3, const float* g1, const float* g2,
+                           float* ga, float* gb, float* gc, float* gr, int64_t rows, int64_t at_rows, int d,
+                           const float* rp, void* stream) {
+  int rc = prim_check(kind, rows, d, rp);
+  if (rc) return rc;
+  if (rows == 0) return 0;
+  if (at_rows < 1) at_rows = rows;
+  const int64_t items = rows * (3 * (int64_t)(d + 1) + 1);  // upper bound on rows * inputs
+  int grid = (int)((items + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipStream_t s = (hipStream_t)stream;
+#define PRIM_CASE(B)                                                                                                   \
+  case B: hipLaunchKernelGGL((k_prim_bwd<OP, B>), dim3(grid), dim3(256), 0, s, kind, a, b, c3, g1, g2, ga, gb, gc, gr, \
+                             rows, at_rows, d, rp); break;
+  switch (bucket_of(d)) {
+    PRIM_CASE(2) PRIM_CASE(4) PRIM_CASE(8) PRIM_CASE(16) PRIM_CASE(32) PRIM_CASE(64)
+  }
+#undef PRIM_CASE
+  LAUNCH_CHECK("primitive backward launch");
+  return 0;
+}
+
+extern "C" int mvae_exp_map_mu0(int kind, const float* x, float* out, int64_t rows, int d, const float* rp, void* st) {
+  if (!x || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_EXP0>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+}
+extern "C" int mvae_inverse_exp_map_mu0(int kind, const float* x, float* out, int64_t rows, int d, const float* rp,
+                                        void* st) {
+  if (!x || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_LOG0>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+}
+extern "C" int mvae_parallel_transport_mu0(int kind, const float* x, const float* dst, float* out, int64_t rows, int d,
+                                           const float* rp, void* st) {
+  if (!x || !dst || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_PT0>(kind, x, dst, nullptr, out, nullptr, rows, rows, d, rp, st);
+}
+extern "C" int mvae_inverse_parallel_transport_mu0(int kind, const float* x, const float* src, float* out,
+                                                   int64_t rows, int d, const float* rp, void* st) {
+  if (!x || !src || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_IPT0>(kind, x, src, nullptr, out, nullptr, rows, rows, d, rp, st);
+}
+extern "C" int mvae_sample_projection_mu0(int kind, const float* v, const float* at, float* z, float* u, int64_t rows,
+                                          int64_t at_rows, int d, const float* rp, void* st) {
+  if (!v || !at || !z) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_SAMPLE>(kind, v, at, nullptr, z, u, rows, at_rows, d, rp, st);
+}
+extern "C" int mvae_inverse_sample_projection_mu0(int kind, const float* z, const float* at, float* u, float* v,
+                                                  int64_t rows, int64_t at_rows, int d, const float* rp, void* st) {
+  if (!z || !at || !u || !v) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_ISAMPLE>(kind, z, at, nullptr, u, v, rows, at_rows, d, rp, st);
+}
+extern "C" int mvae_logdet(int kind, const float* u, const float* mu, const float* z, float* out, int64_t rows,
+                           int64_t at_rows, int d, const float* rp, void* st) {
+  if (!out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if ((kind == MVAE_POINCARE || kind == MVAE_PROJ_SPHERE || kind == MVAE_UNIVERSAL) && (!mu || !z))
+    return fail(MVAE_E_BADARG, "logdet of a projected model needs mu and z%s", "");
+  if ((kind == MVAE_HYPERBOLOID || kind == MVAE_SPHERE) && !u) return fail(MVAE_E_BADARG, "logdet needs u%s", "");
+  return launch_prim<OP_LOGDET>(kind, u, mu, z, out, nullptr, rows, at_rows, d, rp, st);
+}
+extern "C" int mvae_exp_map(int kind, const float* x, const float* at, float* out, int64_t rows, int64_t at_rows,
+                            int d, const float* rp, void* st) {
+  if (!x || !at || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_EXP>(kind, x, at, nullptr, out, nullptr, rows, at_rows, d, rp, st);
+}
+extern "C" int mvae_inverse_exp_map(int kind, const float* x, const float* at, float* out, int64_t rows,
+                                    int64_t at_rows, int d, const float* rp, void* st) {
+  if (!x || !at || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  return launch_prim<OP_LOG>(kind, x, at, nullptr, out, nullptr, rows, at_rows, d, rp, st);
+}
+extern "C" int mvae_geodesic_distance(int kind, int variant, const float* x, const float* y, float* out, int64_t rows,
+                                      int64_t y_rows, int d, const float* rp, void* st) {
+  if (!x || !y || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (variant == MVAE_DIST_GYRO) return launch_prim<OP_DIST_GYRO>(kind, x, y, nullptr, out, nullptr, rows, y_rows, d, rp, st);
+  if (variant != MVAE_DIST_GEODESIC) return fail(MVAE_E_BADARG, "unknown distance variant%s (%lld)", "", variant);
+  return launch_prim<OP_DIST>(kind, x, y, nullptr, out, nullptr, rows, y_rows, d, rp, st);
+}
+
+extern "C" int mvae_manifold_aux(int op, int kind, const float* x, const float* y, float* out, int64_t rows, int d,
+                                 const float* rp, void* st) {
+  if (!x || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  switch (op) {
+    case OP_LPROD:
+      if (!y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+      return launch_prim<OP_LPROD>(kind, x, y, nullptr, out, nullptr, rows, rows, d, rp, st);
+    case OP_LNORM: return launch_prim<OP_LNORM>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+    case OP_TO_BALL:
+      if (kind != MVAE_HYPERBOLOID && kind != MVAE_SPHERE) return fail(MVAE_E_BADARG, "TO_BALL is defined for h and s%s", "");
+      return launch_prim<OP_TO_BALL>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+    case OP_TO_AMBIENT:
+      if (kind != MVAE_POINCARE && kind != MVAE_PROJ_SPHERE) return fail(MVAE_E_BADARG, "TO_AMBIENT is defined for p and d%s", "");
+      if (d + 1 > MVAE_MAX_TRUE_DIM) return fail(MVAE_E_UNSUPPORTED, "true_dim + 1 > MVAE_MAX_TRUE_DIM%s (%lld)", "", d);
+      return launch_prim<OP_TO_AMBIENT>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+    case OP_LAMBDA:
+      if (kind != MVAE_POINCARE && kind != MVAE_PROJ_SPHERE) return fail(MVAE_E_BADARG, "LAMBDA is defined for p and d%s", "");
+      return launch_prim<OP_LAMBDA>(kind, x, nullptr, nullptr, out, nullptr, rows, rows, d, rp, st);
+    case OP_MOBADD:
+      if (!y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+      if (kind != MVAE_POINCARE && kind != MVAE_PROJ_SPHERE) return fail(MVAE_E_BADARG, "MOBADD is defined for p and d%s", "");
+      return launch_prim<OP_MOBADD>(kind, x, y, nullptr, out, nullptr, rows, rows, d, rp, st);
+  }
+  return fail(MVAE_E_BADARG, "unknown auxiliary op%s (%lld)", "", op);
+}
+
+extern "C" int mvae_normal_op(int op, const float* a, const float* loc, const float* scale, float* out, int64_t rows,
+                              int64_t param_rows, int d, void* st) {
+  if (!a || !scale || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  switch (op) {
+    case OP_NORMAL_LOGPROB:
+      if (!loc) return fail(MVAE_E_BADARG, "null pointer%s", "");
+      return launch_prim<OP_NORMAL_LOGPROB>(MVAE_EUCLIDEAN, a, loc, scale, out, nullptr, rows, param_rows, d, nullptr, st);
+    case OP_NORMAL_RSAMPLE:
+      if (!loc) return fail(MVAE_E_BADARG, "null pointer%s", "");
+      return launch_prim<OP_NORMAL_RSAMPLE>(MVAE_EUCLIDEAN, a, loc, scale, out, nullptr, rows, param_rows, d, nullptr, st);
+    case OP_NORMAL_KL:
+      return launch_prim<OP_NORMAL_KL>(MVAE_EUCLIDEAN, a, nullptr, scale, out, nullptr, rows, rows, d, nullptr, st);
+  }
+  return fail(MVAE_E_BADARG, "unknown normal op%s (%lld)", "", op);
+}
+
+extern "C" int mvae_primitive_backward(int op, int kind, const float* a, const float* b, const float* c3,
+                                       const float* g1, const float* g2, float* ga, float* gb, float* gc, float* gr,
+                                       int64_t rows, int64_t at_rows, int d, const float* rp, void* st) {
+  if (!g1) return fail(MVAE_E_BADARG, "null upstream gradient%s", "");
+#define BWD_CASE(O) \
+  case O: return launch_prim_bwd<O>(kind, a, b, c3, g1, g2, ga, gb, gc, gr, rows, at_rows, d, rp, st);
+  switch (op) {
+    BWD_CASE(OP_EXP0) BWD_CASE(OP_LOG0) BWD_CASE(OP_PT0) BWD_CASE(OP_IPT0) BWD_CASE(OP_SAMPLE) BWD_CASE(OP_ISAMPLE)
+    BWD_CASE(OP_LOGDET) BWD_CASE(OP_EXP) BWD_CASE(OP_LOG) BWD_CASE(OP_DIST) BWD_CASE(OP_DIST_GYRO)
+    BWD_CASE(OP_LPROD) BWD_CASE(OP_LNORM) BWD_CASE(OP_TO_BALL) BWD_CASE(OP_TO_AMBIENT) BWD_CASE(OP_LAMBDA)
+    BWD_CASE(OP_MOBADD) BWD_CASE(OP_NORMAL_LOGPROB) BWD_CASE(OP_NORMAL_RSAMPLE) BWD_CASE(OP_NORMAL_KL)
+  }
+#undef BWD_CASE
+  return fail(MVAE_E_BADARG, "unknown primitive op%s (%lld)", "", op);
+}
+
+// ------------------------------------------------------------------------------------------------ scalar functions (API)
+// The reference's guarded scalar functions (ops/common.py:28-147) and their custom derivative rules, evaluated by the
+// DEVICE code the manifold kernels use (value through the float overloads, derivative through the Dual rules), so the
+// rules can be pinned directly against vectors recorded from the reference.
+__global__ __launch_bounds__(256) void k_scalar_fn(int fn, const float* x, float* y, float* dy, int64_t n, float lo,
+                                                   float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i];
+    const Dual xd = Dual{xv, 1.f};
+    float v;
+    Dual r;
+    switch (fn) {
+      case MVAE_FN_CLAMP: v = leaky_clamp(xv, lo, hi); r = leaky_clamp(xd, lo, hi); break;
+      case MVAE_FN_ATANH: v = g_atanh(xv); r = g_atanh(xd); break;
+      case MVAE_FN_ACOSH: v = g_acosh(xv); r = g_acosh(xd); break;
+      case MVAE_FN_COSH: v = g_cosh(xv); r = g_cosh(xd); break;
+      case MVAE_FN_SINH: v = g_sinh(xv); r = g_sinh(xd); break;
+      case MVAE_FN_SQRT: v = g_sqrt(xv); r = g_sqrt(xd); break;
+      case MVAE_FN_LOGSINH: v = g_logsinh(xv); r = g_logsinh(xd); break;
+      case MVAE_FN_LOGCOSH: v = g_logcosh(xv); r = g_logcosh(xd); break;
+      case MVAE_FN_COSH_SINH_PAIR: {  // the shared-exp pair the manifolds use: y = cosh, dy = sinh (values)
+        float c, s_;
+        g_cosh_sinh(xv, &c, &s_);
+        v = c;
+        r = Dual{c, s_};
+      } break;
+      case MVAE_FN_COS_SIN_PAIR: {  // y = cos, dy = sin (values)
+        float c, s_;
+        t_cos_sin(xv, &c, &s_);
+        v = c;
+        r = Dual{c, s_};
+      } break;
+      case MVAE_FN_SOFTPLUS: v = t_softplus(xv); r = t_softplus(xd); break;
+      case MVAE_FN_ACOS: v = t_acos(xv); r = t_acos(xd); break;
+      case MVAE_FN_TAN: v = t_tan(xv); r = t_tan(xd); break;
+      case MVAE_FN_LOG1P_POS: v = mvf::log1p_pos(xv); r = Dual{v, 1.0f / (1.0f + xv)}; break;
+      case MVAE_FN_EXP: v = t_exp(xv); r = t_exp(xd); break;
+      case MVAE_FN_LOG: v = t_log(xv); r = t_log(xd); break;
+      case MVAE_FN_STD: v = t_softplus(xv) + 1e-5f; r = t_softplus(xd) + 1e-5f; break;  // component.py:72
+      default: v = NAN; r = Dual{NAN, NAN}; break;
+    }
+    y[i] = v;
+    if (dy) dy[i] = r.d;
+  }
+}
+
+extern "C" int mvae_scalar_fn(int fn, const float* x, float* y, float* dy, int64_t n, float lo, float hi, void* st) {
+  if (!x || !y || n < 0) return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
+  if (fn < 0 || fn >= MVAE_FN_COUNT) return fail(MVAE_E_BADARG, "unknown scalar function%s (%lld)", "", fn);
+  if (n == 0) return 0;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_scalar_fn, dim3(grid), dim3(256), 0, (hipStream_t)st, fn, x, y, dy, n, lo, hi);
+  LAUNCH_CHECK("scalar function launch");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_mul(const float* a, const float* b, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+// out[r][j] = g[r][j] * s[r]
+__global__ __launch_bounds__(256) void k_scale_rows(const float* g, const float* sc, float* out, int64_t rows, int D) {
+  const int64_t n = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = g[i] * sc[i / D];
+}
+extern "C" int mvae_scale_rows(const float* g, const float* sc, float* out, int64_t rows, int D, void* st) {
+  if (!g || !sc || !out || rows < 0 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
+  if (rows == 0) return 0;
+  int grid = (int)((rows * D + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_scale_rows, dim3(grid), dim3(256), 0, (hipStream_t)st, g, sc, out, rows, D);
+  LAUNCH_CHECK("scale rows launch");
+  return 0;
+}
+extern "C" int mvae_mul(const float* a, const float* b, float* out, int64_t n, void* st) {
+  if (!a || !b || !out || n < 0) return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
+  if (n == 0) return 0;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_mul, dim3(grid), dim3(256), 0, (hipStream_t)st, a, b, out, n);
+  LAUNCH_CHECK("mul launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ component kernels (API)
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_comp_fwd(CompTable t, const float* heads, int heads_ld, const float* eps,
+                                                  int eps_ld, const float* radii, float* z, int z_ld, float* kl,
+                                                  float* lq, float* lp, float* mu, float* sd, int64_t rows,
+                                                  int64_t head_rows) {
+  const int64_t items = rows * t.n;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t r = it % rows;
+    const int ci = (int)(it / rows);
+    const int64_t hr = r % head_rows;
+    const bool first = r < head_rows;
+    comp_fwd_row<DMAX>(t.c[ci], heads + hr * heads_ld, eps + r * eps_ld, radii, z + r * z_ld, nullptr,
+                       kl ? kl + (int64_t)ci * rows + r : nullptr, lq ? lq + (int64_t)ci * rows + r : nullptr,
+                       lp ? lp + (int64_t)ci * rows + r : nullptr, (mu && first) ? mu + hr * z_ld : nullptr,
+                       (sd && first) ? sd + hr * eps_ld : nullptr);
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_comp_bwd(CompTable t, const float* heads, int heads_ld, const float* eps,
+                                                  int eps_ld, const float* radii, const float* dz, int z_ld,
+                                                  const float* dkl, float dkl_scalar, float* dheads, float* drad_rows,
+                                                  int64_t rows) {
+  const int64_t items = rows * t.total_dirs;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t r = it / t.total_dirs;
+    const int gd = (int)(it % t.total_dirs);
+    int ci = 0;
+    while (gd >= t.dir_off[ci + 1]) ++ci;
+    const int dir = gd - t.dir_off[ci];
+    const mvae_component_desc& c = t.c[ci];
+    const float w = dkl ? dkl[(int64_t)ci * rows + r] : dkl_scalar;
+    float g = comp_bwd_dir<DMAX>(c, heads + r * heads_ld, eps + r * eps_ld, radii, dz + r * z_ld, w, dir);
+    if (dir < c.true_dim) dheads[r * heads_ld + c.mean_col + dir] = g;
+    else if (dir < c.true_dim + c.logvar_dim) dheads[r * heads_ld + c.logvar_col + (dir - c.true_dim)] = g;
+    else drad_rows[(int64_t)c.radius_idx * rows + r] = g;  // per-row term; summed in row order by k_rowsum_fixed
+  }
+}
+
+// out[i] = sum_r part[i][r], one workgroup per i, fixed order (thread t adds r = t, t+256, ...; wave sums by DPP; the four
+// wave totals in wave order): the radius gradient of the standalone component backward, bit-reproducible.
+__global__ __launch_bounds__(256) void k_rowsum_fixed(const float* part, float* out, int64_t rows) {
+  __shared__ float sm[4];
+  const float* p = part + (int64_t)blockIdx.x * rows;
+  float s = 0.f;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) s += p[r];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+extern "C" int mvae_component_forward(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                                      const float* eps, int eps_ld, const float* radii, float* z, int z_ld, float* kl,
+                                      float* log_q, float* log_p, float* mu, float* sd, int64_t rows,
+                                      int64_t head_rows, void* stream) {
+  if (!heads || !eps || !z || rows < 0 || head_rows < 1) return fail(MVAE_E_BADARG, "null pointer / bad rows%s", "");
+  if ((log_q == nullptr) != (log_p == nullptr)) return fail(MVAE_E_BADARG, "log_q and log_p go together%s", "");
+  CompTable t;
+  int dmax;
+  unsigned char all[kMaxComp];
+  memset(all, 1, sizeof(all));
+  int rc = fill_table(&t, comps, ncomp, all, &dmax);
+  if (rc) return rc;
+  for (int i = 0; i < ncomp; ++i)
+    if (comps[i].kind != MVAE_EUCLIDEAN && !radii) return fail(MVAE_E_BADARG, "radii is NULL%s", "");
+  if (rows == 0) return 0;
+  int grid = (int)((rows * ncomp + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_comp_fwd<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
+                                       radii, z, z_ld, kl, log_q, log_p, mu, sd, rows, head_rows));
+  LAUNCH_CHECK("component forward launch");
+  return 0;
+}
+
+extern "C" int64_t mvae_component_backward_workspace_floats(int ncomp, int64_t rows) {
+  return (ncomp < 0 || rows < 0) ? -1 : (int64_t)ncomp * rows;
+}
+
+extern "C" int mvae_component_backward(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                                       const float* eps, int eps_ld, const float* radii, const float* dz, int z_ld,
+                                       const float* dkl, float dkl_scalar, float* dheads, float* dradii,
+                                       float* workspace, int64_t rows, void* stream) {
+  if (!heads || !eps || !dz || !dheads || rows < 0) return fail(MVAE_E_BADARG, "null pointer / bad rows%s", "");
+  if (dradii && !workspace) return fail(MVAE_E_BADARG, "dradii needs the [ncomp, rows] workspace%s", "");
+  CompTable t;
+  int dmax;
+  unsigned char tr[kMaxComp];
+  memset(tr, dradii ? 1 : 0, sizeof(tr));
+  int rc = fill_table(&t, comps, ncomp, tr, &dmax);
+  if (rc) return rc;
+  for (int i = 0; i < ncomp; ++i)
+    if (comps[i].radius_idx < 0 || comps[i].radius_idx >= ncomp)
+      return fail(MVAE_E_BADARG, "radius_idx out of range%s (%lld)", "", comps[i].radius_idx);
+  if (rows == 0) return 0;
+  int grid = (int)((rows * t.total_dirs + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dradii) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)ncomp * (size_t)rows, s);  // Euclidean rows stay 0
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+  }
+  DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_comp_bwd<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
+                                       radii, dz, z_ld, dkl, dkl_scalar, dheads, workspace, rows));
+  if (dradii) hipLaunchKernelGGL(k_rowsum_fixed, dim3(ncomp), dim3(256), 0, s, workspace, dradii, rows);
+  LAUNCH_CHECK("component backward launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ dense layers (API)
+
+extern "C" int mvae_linear_forward(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
+                                   int relu, void* stream) {
+  if (!x || !W || !y || M < 0 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (M == 0) return 0;
+  if (M > (1 << 20) * 16) return fail(MVAE_E_UNSUPPORTED, "M too large%s", "");
+  if (M >= kTiledMinRows && linear_forward_tiled(x, W, b, y, M, N, K, relu, (hipStream_t)stream)) {
+    LAUNCH_CHECK("tiled linear forward launch");
+    return 0;
+  }
+  dim3 grid((N + 15) / 16, (unsigned)((M + 15) / 16));
+  hipStream_t s = (hipStream_t)stream;
+  if (relu) hipLaunchKernelGGL(k_linear_fwd<true>, grid, dim3(256), 0, s, x, W, b, y, (int)M, N, K);
+  else hipLaunchKernelGGL(k_linear_fwd<false>, grid, dim3(256), 0, s, x, W, b, y, (int)M, N, K);
+  LAUNCH_CHECK("linear forward launch");
+  return 0;
+}
+
+extern "C" int mvae_linear_backward(const float* x, const float* W, const float* dy, int relu_in, float* dW, float* db,
+                                    float* dx, int64_t M, int N, int K, void* stream) {
+  if (!x || !W || !dy || !dW || !db || M < 1 || N < 1 || K < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int ntN = (N + 15) / 16, ntK = (K + 15) / 16, ntM = (int)((M + 15) / 16);
+  const int n_dx = dx ? ntM * ntK : 0, n_dw = ntN * ntK, n_db = (N + kColsPerBlock - 1) / kColsPerBlock;
+  hipLaunchKernelGGL(k_linear_bwd, dim3(n_dx + n_dw + n_db), dim3(256), 0, (hipStream_t)stream, x, W, dy, dW, db, dx,
+                     (int)M, N, K, relu_in, n_dw, n_dx);
+  LAUNCH_CHECK("linear backward launch");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ log-likelihood helpers (API)
+// bce[r] = sum_j BCE-with-logits(logits[r][j], x[r % x_rows][j]); one wavefront per row.
+__global__ __launch_bounds__(256) void k_bce_rows(const float* logits, const float* x, float* out, int64_t rows,
+                                                  int64_t x_rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* lr = logits + r * D;
+  const float* xr = x + (r % x_rows) * D;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float y = lr[j], t = xr[j];
+    const float e = expf(-fabsf(y));
+    s += (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[r] = s;
+}
+
+// log p(x)[b] = logsumexp_n(-bce[n][b] + log_p[n][b] - log_q[n][b]) - log n ;
+// mi[b] = logsumexp_n(log_q[n][b] - log_p[n][b]) - log n        (vae.py:113-117)
+// One workgroup per batch column b; thread t takes the samples t, t + 256, ...; block max, then block sum of exp(. - max)
+// (wave sums by DPP, the four wave totals added in wave order).
+__global__ __launch_bounds__(256) void k_loglik_reduce(const float* bce, const float* log_p, const float* log_q,
+                                                       float* log_px, float* mi, int n, int B) {
+  __shared__ float sm[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float m1 = -INFINITY, m2 = -INFINITY;
+  for (int i = tid; i < n; i += 256) {
+    const size_t o = (size_t)i * B + b;
+    const float lp = log_p[o], lq = log_q[o];
+    m1 = fmaxf(m1, -bce[o] + lp - lq);
+    m2 = fmaxf(m2, lq - lp);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    m1 = fmaxf(m1, __shfl_xor(m1, off));
+    m2 = fmaxf(m2, __shfl_xor(m2, off));
+  }
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = m1;
+    sm[1][tid >> 6] = m2;
+  }
+  __syncthreads();
+  m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+  m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const size_t o = (size_t)i * B + b;
+    const float lp = log_p[o], lq = log_q[o];
+    s1 += expf((-bce[o] + lp - lq) - m1);
+    s2 += expf((lq - lp) - m2);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = s1;
+    sm[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float ln = logf((float)n);
+    log_px[b] = m1 + logf((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) - ln;
+    mi[b] = m2 + logf((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) - ln;
+  }
+}
+
+extern "C" int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows, int64_t x_rows, int D,
+                             void* stream) {
+  if (!logits || !x || !out || rows < 0 || x_rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_bce_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, x, out,
+                     rows, x_rows, D);
+  LAUNCH_CHECK("bce rows launch");
+  return 0;
+}
+
+extern "C" int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi,
+                                  int n, int B, void* stream) {
+  if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_loglik_reduce, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q,
+                     log_px, mi, n, B);
+  LAUNCH_CHECK("loglik reduce launch");
+  return 0;
+}

@@ -1,0 +1,550 @@
+// mvae_common.hpp -- what the translation units of libmvae_hip.so share: error reporting, the component table, the
+// per-(row, component) device code over float / dual numbers, the wave-level tile jobs and small reductions.
+// The library is built from three translation units compiled in parallel (mvae_amd/build.py):
+//   mvae_api.hip   manifold primitives (+ their backward), scalar functions, component operators, generic dense layers,
+//                  log-likelihood helpers
+//   mvae_step.hip  the fused ELBO step (six launches) and the flat optimizer
+//   mvae_conv.hip  building blocks of the conv architecture, the LDS-tiled contraction, the device-side input pipeline
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mvae_hip.h"
+#include "mvae_gemm.hpp"
+#include "mvae_math.hpp"
+
+using namespace mv;
+
+// ------------------------------------------------------------------------------------------------ dev timing hooks
+// -DMV_DBG_TIMING: workgroup 0 of the latent kernels stamps wall_clock64() (100 MHz) at phase boundaries.
+#ifdef MV_DBG_TIMING
+static __device__ unsigned long long g_dbg[64];
+#define MV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+#define MV_STAMP_B(i, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+#ifndef MV_STAMP_BLK
+#define MV_STAMP_BLK 200  // which workgroup of launches 5 / 6 stamps its wave-tile phases
+#endif
+// start / end time and kind of every workgroup of launch L (plain stores to per-workgroup slots: no contention)
+static __device__ unsigned long long g_span[6][3][2048];
+#define MV_SPAN_BEGIN(L) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_span[L][0][blockIdx.x] = wall_clock64(); } while (0)
+#define MV_SPAN_END(L, kind) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[L][1][blockIdx.x] = wall_clock64(); g_span[L][2][blockIdx.x] = (kind); } } while (0)
+// the same for another thread of the workgroup, recorded `off` slots further (e.g. the dual waves of launch 2)
+#define MV_SPAN_END_T(L, kind, thr, off) do { if (threadIdx.x == (thr) && blockIdx.x + (off) < 2048) { g_span[L][0][blockIdx.x + (off)] = g_span[L][0][blockIdx.x]; g_span[L][1][blockIdx.x + (off)] = wall_clock64(); g_span[L][2][blockIdx.x + (off)] = (kind); } } while (0)
+#else
+#define MV_STAMP(i) do {} while (0)
+#define MV_STAMP_B(i, blk) do {} while (0)
+#define MV_SPAN_BEGIN(L) do {} while (0)
+#define MV_SPAN_END(L, kind) do {} while (0)
+#define MV_SPAN_END_T(L, kind, thr, off) do {} while (0)
+#endif
+
+
+// ------------------------------------------------------------------------------------------------ errors
+// one message buffer per calling thread, defined in mvae_api.hip
+int fail(int code, const char* fmt, const char* a = "", long long b = 0);
+int hip_fail(hipError_t e, const char* where);
+#define LAUNCH_CHECK(where)                         \
+  do {                                              \
+    hipError_t e_ = hipGetLastError();              \
+    if (e_ != hipSuccess) return hip_fail(e_, where); \
+  } while (0)
+
+// large, 16-byte aligned problems of mvae_linear_forward go to the LDS-tiled kernel (mvae_conv.hip)
+constexpr int64_t kTiledMinRows = 512;
+bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K, int relu,
+                          hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ tables
+constexpr int kMaxComp = MVAE_MAX_COMPONENTS;
+constexpr int kRadiiRegion = 64;  // floats reserved at the start of the flat buffers for the raw radius parameters
+constexpr int kHeadsMax = 256;    // max heads_dim / z_dim held in LDS by the latent kernels
+constexpr int kRows = 16;         // batch rows per workgroup in the latent kernels (one MFMA tile)
+
+struct CompTable {
+  int n;
+  int total_dirs;
+  mvae_component_desc c[kMaxComp];
+  int dir_off[kMaxComp + 1];  // prefix sum of derivative directions per component (d + logvar_dim + trainable radius)
+  short first_dir[kMaxComp];  // the same prefix with EVERY radius direction counted: record index in the dual workspace
+  unsigned char trainable[kMaxComp];  // bit 0: trainable radius/curvature, bit 1: in the gradient-clip group (`u`)
+  // Placement of the components on the 4 waves of a latent workgroup: components of the same manifold kind share a
+  // wave (one instruction stream, no divergence), different kinds run on different waves.
+  unsigned char wave_of[kMaxComp];
+  unsigned char lane_of[kMaxComp];
+};
+
+inline int bucket_of(int dmax) {
+  if (dmax <= 2) return 2;
+  if (dmax <= 4) return 4;
+  if (dmax <= 8) return 8;
+  if (dmax <= 16) return 16;
+  if (dmax <= 32) return 32;
+  return 64;
+}
+
+inline int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp, const unsigned char* trainable,
+                      int* dmax_out) {
+  if (!comps || ncomp < 1 || ncomp > kMaxComp) return fail(MVAE_E_BADARG, "ncomp out of range%s (%lld)", "", ncomp);
+  memset(t, 0, sizeof(*t));
+  t->n = ncomp;
+  int dmax = 0, off = 0, first = 0;
+  for (int i = 0; i < ncomp; ++i) {
+    const mvae_component_desc& c = comps[i];
+    if (c.kind < 0 || c.kind >= kNumKinds) return fail(MVAE_E_BADARG, "unknown manifold kind%s (%lld)", "", c.kind);
+    if (c.true_dim < 1 || c.true_dim > MVAE_MAX_TRUE_DIM)
+      return fail(MVAE_E_UNSUPPORTED, "true_dim outside [1, MVAE_MAX_TRUE_DIM]%s (%lld)", "", c.true_dim);
+    if (c.logvar_dim != 1 && c.logvar_dim != c.true_dim)
+      return fail(MVAE_E_BADARG, "logvar_dim must be 1 or true_dim%s (%lld)", "", c.logvar_dim);
+    t->c[i] = c;
+    // bit 0: SGD-trainable radius / curvature; bit 1: member of the clip_grad_norm_ group (universal curvatures)
+    t->trainable[i] = (trainable && c.kind != MVAE_EUCLIDEAN && trainable[i])
+                          ? (unsigned char)(1 | (c.kind == MVAE_UNIVERSAL ? 2 : 0))
+                          : 0;
+    t->dir_off[i] = off;
+    off += c.true_dim + c.logvar_dim + (t->trainable[i] ? 1 : 0);
+    t->first_dir[i] = (short)first;
+    first += c.true_dim + c.logvar_dim + 1;
+    if (c.true_dim > dmax) dmax = c.true_dim;
+  }
+  t->dir_off[ncomp] = off;
+  t->total_dirs = off;
+  *dmax_out = dmax;
+  // wave placement: the kinds present split the 4 waves between them; a kind's components go round-robin over its waves
+  int kinds[kNumKinds], nk = 0;
+  for (int k = 0; k < kNumKinds; ++k) {
+    bool present = false;
+    for (int i = 0; i < ncomp; ++i) present |= (comps[i].kind == k);
+    if (present) kinds[nk++] = k;
+  }
+  const int wpk = nk ? (4 / nk > 0 ? 4 / nk : 1) : 1;
+  int fill[4] = {0, 0, 0, 0};
+  for (int ki = 0; ki < nk; ++ki) {
+    int rr = 0;
+    for (int i = 0; i < ncomp; ++i)
+      if (comps[i].kind == kinds[ki]) {
+        const int w = (ki * wpk + (rr++ % wpk)) & 3;
+        t->wave_of[i] = (unsigned char)w;
+        t->lane_of[i] = (unsigned char)fill[w]++;
+      }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ component device code
+template <int DMAX, typename T>
+__device__ __forceinline__ void comp_eval(int kind, const T* m, const T* l, int lvd, const float* e, int d, T rp, T* z,
+                                          T* kl, T* lq, T* lp, T* mu, T* sg) {
+  kind = resolve_universal(kind, rp);  // `u`: Poincare ball / projected sphere / Euclidean by the sign of K
+#define MV_KIND_SWITCH(DD, LL)                                                                              \
+  switch (kind) {                                                                                           \
+    case kEuclidean: component_forward<kEuclidean, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;     \
+    case kHyperboloid: component_forward<kHyperboloid, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break; \
+    case kSphere: component_forward<kSphere, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;           \
+    case kProjSphere: component_forward<kProjSphere, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;   \
+    default: component_forward<kPoincare, DMAX, T>(m, l, LL, e, DD, rp, z, kl, lq, lp, mu, sg); break;              \
+  }
+  // the common case (every dimension equals the bucket bound) is instantiated with compile-time dimensions, which
+  // folds away every loop guard of the small-vector code
+  if (d == DMAX && lvd == DMAX) {
+    MV_KIND_SWITCH(DMAX, DMAX)
+  } else {
+    MV_KIND_SWITCH(d, lvd)
+  }
+#undef MV_KIND_SWITCH
+}
+
+// forward for one (row, component); pointers are to the start of the row
+template <int DMAX>
+__device__ __forceinline__ void comp_fwd_row(const mvae_component_desc& c, const float* heads_row, const float* eps_row,
+                                             const float* radii, float* z_row, float* z_row2, float* kl, float* lq,
+                                             float* lp, float* mu_row, float* std_row) {
+  MV_BOUNDS(DMAX + 1);
+  float m[kN], l[kN], e[kN], z[kN], mu[kN], sg[kN];
+  const int d = c.true_dim, lvd = c.logvar_dim;
+  MV_FOR(i, 0, d) {
+    m[i] = heads_row[c.mean_col + i];
+    e[i] = eps_row[c.eps_col + i];
+  }
+  MV_FOR(i, 0, lvd) l[i] = heads_row[c.logvar_col + i];
+  float rp = (c.kind == kEuclidean) ? 0.f : radii[c.radius_idx];
+  float klv = 0.f, lqv = 0.f, lpv = 0.f;
+  comp_eval<DMAX, float>(c.kind, m, l, lvd, e, d, rp, z, kl ? &klv : nullptr, lq ? &lqv : nullptr,
+                         lq ? &lpv : nullptr, mu_row ? mu : nullptr, std_row ? sg : nullptr);
+  const int A = ambient_dim(c.kind, d);
+  MV_FOR(i, 0, A) z_row[c.z_col + i] = z[i];
+  if (z_row2) {
+    MV_FOR(i, 0, A) z_row2[c.z_col + i] = z[i];
+  }
+  if (kl) *kl = klv;
+  if (lq) {
+    *lq = lqv;
+    *lp = lpv;
+  }
+  if (mu_row) {
+    MV_FOR(i, 0, A) mu_row[c.z_col + i] = mu[i];
+  }
+  if (std_row) {
+    MV_FOR(i, 0, lvd) std_row[c.eps_col + i] = sg[i];
+  }
+}
+
+// Derivative of one (row, component) along input direction `dir` (0..d-1: mean head, d..d+lvd-1: logvar head,
+// d+lvd: radius / curvature): zd[i] = d z_i / d dir, returns d kl / d dir.  Needs no upstream gradient, so the latent
+// backward kernel runs it while dz is still being reduced.
+template <int DMAX>
+__device__ __forceinline__ float comp_dual_dir(const mvae_component_desc& c, const float* heads_row,
+                                               const float* eps_row, const float* radii, int dir, float* zd) {
+  MV_BOUNDS(DMAX + 1);
+  Dual m[kN], l[kN], z[kN];
+  float e[kN];
+  const int d = c.true_dim, lvd = c.logvar_dim;
+  MV_FOR(i, 0, d) {
+    m[i] = Dual{heads_row[c.mean_col + i], (dir == i) ? 1.f : 0.f};
+    e[i] = eps_row[c.eps_col + i];
+  }
+  MV_FOR(i, 0, lvd) l[i] = Dual{heads_row[c.logvar_col + i], (dir == d + i) ? 1.f : 0.f};
+  Dual rp = Dual{(c.kind == kEuclidean) ? 0.f : radii[c.radius_idx], (dir == d + lvd) ? 1.f : 0.f};
+  Dual kl;
+  comp_eval<DMAX, Dual>(c.kind, m, l, lvd, e, d, rp, z, &kl, nullptr, nullptr, nullptr, nullptr);
+  const int A = ambient_dim(c.kind, d);
+  MV_FOR(i, 0, A) zd[i] = z[i].d;
+  return kl.d;
+}
+
+// d(loss)/d(input direction `dir`) for one (row, component): loss = <dz, z> + dkl * kl
+template <int DMAX>
+__device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, const float* heads_row,
+                                              const float* eps_row, const float* radii, const float* dz_row, float dkl,
+                                              int dir) {
+  MV_BOUNDS(DMAX + 1);
+  float zd[kN];
+  const float kld = comp_dual_dir<DMAX>(c, heads_row, eps_row, radii, dir, zd);
+  const int A = ambient_dim(c.kind, c.true_dim);
+  float g = dkl * kld;
+  MV_FOR(i, 0, A) g += dz_row[c.z_col + i] * zd[i];
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------ tile jobs
+// y tile = act(x W^T + b); all 256 threads of the workgroup participate.
+template <bool RELU>
+__device__ __forceinline__ void job_linear_fwd(float (*red)[16][17], const float* x, int ldx, const float* W, int ldw,
+                                               const float* b, float* y, int ldy, int M, int N, int K, int mt, int nt) {
+  const int wave = threadIdx.x >> 6;
+  const bool vx = aligned16(x) && (ldx & 3) == 0, vw = aligned16(W) && (ldw & 3) == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_nt(x, ldx, M, mt * 16, W, ldw, N, nt * 16, K, wave, 4, vx, vw, acc);
+  float s = reduce_tiles(red, acc);
+  const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+  if (m < M && n < N) {
+    float v = s + (b ? b[n] : 0.f);
+    if (RELU) v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+    y[(size_t)m * ldy + n] = v;
+  }
+}
+
+// out[p][q] = sum_m P[m][p] Q[m][q]   (tile pt, qt)
+__device__ __forceinline__ void job_tn(float (*red)[16][17], const float* P, int ldp, int NP, int pt, const float* Q,
+                                       int ldq, int NQ, int qt, int Mrows, float* out, int ldo) {
+  const int wave = threadIdx.x >> 6;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_tn(P, ldp, NP, pt * 16, Q, ldq, NQ, qt * 16, Mrows, wave, 4, acc);
+  float s = reduce_tiles(red, acc);
+  const int p = pt * 16 + (threadIdx.x >> 4), q = qt * 16 + (threadIdx.x & 15);
+  if (p < NP && q < NQ) out[(size_t)p * ldo + q] = s;
+}
+
+// out[m][n] = (sum_k G[m][k] W[k][n]) * [mask[m][n] > 0]   (tile mt, nt)
+__device__ __forceinline__ void job_nn(float (*red)[16][17], const float* G, int ldg, int M, int mt, const float* W,
+                                       int ldw, int N, int nt, int K, const float* mask, int ldmask, float* out,
+                                       int ldo) {
+  const int wave = threadIdx.x >> 6;
+  const bool vg = aligned16(G) && (ldg & 3) == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_nn(G, ldg, M, mt * 16, W, ldw, N, nt * 16, K, wave, 4, vg, acc);
+  float s = reduce_tiles(red, acc);
+  const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+  if (m < M && n < N) {
+    if (mask && !(mask[(size_t)m * ldmask + n] > 0.f)) s = 0.f;
+    out[(size_t)m * ldo + n] = s;
+  }
+}
+
+// out[c] = sum_m Gm[m][c] for the 16 columns starting at c0: thread (g = tid>>4, c = tid&15) adds rows g, g+16, ...
+// (loads issued in batches of 8), the 16 row-groups meet in LDS and are added in index order.
+constexpr int kColsPerBlock = 16;
+__device__ __forceinline__ void job_colsum(float* lds /*>= 16*17 floats*/, const float* Gm, int ld, int Mrows,
+                                           int ncols, int c0, float* out) {
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  float s = 0.f;
+  if (c0 + c < ncols) {
+    const float* col = Gm + c0 + c;
+    int m = g;
+    for (; m + 16 * 7 < Mrows; m += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(m + 16 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; m < Mrows; m += 16) s += col[(size_t)m * ld];
+  }
+  lds[g * 17 + c] = s;
+  __syncthreads();
+  if (g == 0 && c0 + c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += lds[q * 17 + c];
+    out[c0 + c] = t;
+  }
+  __syncthreads();
+}
+
+// wave-level sum (all 64 lanes end up with the total): DPP row operations + one readlane, ~50 cycles, instead of six
+// dependent ds_bpermute round trips through the LDS crossbar (~130 cycles each) that __shfl_xor lowers to.
+__device__ __forceinline__ float wave_sum(float v) {
+  int x = __float_as_int(v);
+#define MV_DPP_ADD(CTRL, ROWMASK)                                                                       \
+  x = __float_as_int(__int_as_float(x) +                                                                \
+                     __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, true)));
+  MV_DPP_ADD(0xB1, 0xF)   // quad_perm [1,0,3,2]
+  MV_DPP_ADD(0x4E, 0xF)   // quad_perm [2,3,0,1]
+  MV_DPP_ADD(0x141, 0xF)  // row_half_mirror
+  MV_DPP_ADD(0x140, 0xF)  // row_mirror: every lane of a 16-lane row now holds the row sum
+  MV_DPP_ADD(0x142, 0xA)  // row_bcast15 into rows 1 and 3
+  MV_DPP_ADD(0x143, 0xC)  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef MV_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
+#define DMAX_SWITCH(dmax, ...) \
+  switch (bucket_of(dmax)) {    \
+    case 2: { constexpr int DM = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int DM = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int DM = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int DM = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int DM = 32; __VA_ARGS__; } break; \
+    default: { constexpr int DM = 64; __VA_ARGS__; } break; \
+  }
+
+// ---------------------------------------------------------------------------------------------- Adam in the epilogue
+// torch.optim.Adam, single-tensor CPU formulas, defaults betas=(0.9, 0.999), eps=1e-8:
+//   m <- m + (1-b1)(g - m) ; v <- v*b2 + ((1-b2) g) g ; p <- p + (-lr/bc1 * m) / (sqrt(v)/sqrt(bc2) + eps)
+// In the single-GPU step the update is applied by the workgroup that produced the gradient tile, in its epilogue,
+// one launch after the last read of that weight (see the launch list at the top); a data-parallel run applies it in
+// k_optim after the gradient all-reduce instead.
+struct AdamArgs {
+  float* p;
+  float* m;
+  float* v;
+  const int* counters;  // counters[0] = number of this step (already advanced by launch 1)
+  double lr;
+};
+
+__device__ __forceinline__ double pow_int(double base, int e) {  // base^e by squaring (e >= 0)
+  double r = 1.0, b = base;
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
+}
+
+// thread 0 writes {-lr/bc1, sqrt(bc2)} to sh[0..1]; the caller's next __syncthreads publishes it
+__device__ __forceinline__ void adam_consts(float* sh, const int* counters, double lr, int step_offset) {
+  if (threadIdx.x == 0) {
+    const int step = *(volatile const int*)&counters[0] + step_offset;
+    const double bc1 = 1.0 - pow_int(0.9, step);
+    const double bc2 = 1.0 - pow_int(0.999, step);
+    sh[0] = (float)(-(lr / bc1));
+    sh[1] = (float)sqrt(bc2);
+  }
+}
+
+__device__ __forceinline__ void adam1(float& P, float G, float& M, float& V, float neg_step, float bc2s) {
+  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999);
+  M = M + w1 * (G - M);
+  V = V * b2 + (w2 * G) * G;
+  P = P + (neg_step * M) / (sqrtf(V) / bc2s + 1e-8f);
+}
+
+// torch.nn.utils.clip_grad_norm_(curvature params, max_norm=1, norm_type=2) (vae.py:161-163): the coefficient
+// min(1, 1 / (||g|| + 1e-6)) over the universal components' curvature gradients g (index order).
+__device__ __forceinline__ float clip_coef(const CompTable& t, const float* g) {
+  float n2 = 0.f;
+  for (int j = 0; j < t.n; ++j)
+    if (t.trainable[j] & 2) n2 += g[j] * g[j];
+  return fminf(1.0f / (sqrtf(n2) + 1e-6f), 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------- step tile jobs
+// 8-wave (512-thread) variants for the long contractions (K = 784 / 400): every wave issues ALL of its operand loads
+// up front (<= 7 k-chunks per wave) and the eight partial tiles meet in LDS.
+// Waves per workgroup of the wave-level dW tiles.  A CU's load path saturates with two tile workgroups (measured in
+// launch 6: the ~50 CUs that received a second 4-wave workgroup finished at 4.6 us, the rest at 2.9 us), so launch 6
+// is sized to put ONE tile workgroup on every CU: 1225 tiles / 5 waves = 250 workgroups for 256 CUs (6.8 -> 5.6 us
+// together with the branch-free ragged tiles).  Launch 5 shares its CUs with the 128 row workgroups either way and
+// measured better with 4-wave tile workgroups (6.3 vs 7.2 us).
+constexpr int kTileWaves = 5;    // launch 6
+constexpr int kTileWaves5 = 4;   // launch 5
+constexpr int kW8 = 8;
+__device__ __forceinline__ float reduce_tiles8(float (*red)[16][17], f32x4 acc) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, rbase = (lane >> 4) << 2;
+  red[wave][rbase + 0][col] = acc[0];
+  red[wave][rbase + 1][col] = acc[1];
+  red[wave][rbase + 2][col] = acc[2];
+  red[wave][rbase + 3][col] = acc[3];
+  lds_barrier();
+  float s = 0.f;
+  if (tid < 256) {
+    const int r = tid >> 4, c = tid & 15;
+    s = ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) +
+        ((red[4][r][c] + red[5][r][c]) + (red[6][r][c] + red[7][r][c]));
+  }
+  return s;
+}
+
+// 16-byte store with the write-through cache policy, through a raw buffer descriptor built from the (wave-uniform)
+// base pointer; `idx` in floats (< 2^30).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(float* base, size_t idx, f32x4 v) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)(idx << 2), 0, /*aux: sc1*/ 16);
+}
+
+// dW tile per WAVE (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q].  The batch contraction (K = B = 128) is short
+// enough for one wave: 32 MFMA steps on two accumulators, all operand loads in flight at once, no LDS, no barrier.
+// The four waves of a workgroup take four neighbouring q-tiles (they share the P operand through L1).
+// The MFMA is issued with the operand roles swapped (A <- Q, B <- P), so that lane l ends up with the four
+// CONSECUTIVE outputs out[p0 + (l&15)][q0 + 4*(l>>4) + 0..3]: gradient, parameter and both Adam moments move as one
+// 16-byte access per lane each.
+template <bool ADAM, bool FULL = false>
+__device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int pt, const float* Q, int ldq, int NQ,
+                                            int qt, int Mrows, float* out, int ldo, const AdamArgs& aa) {
+  if (qt * 16 >= NQ) return;
+  MV_STAMP_B(16, MV_STAMP_BLK);
+  const int lane = threadIdx.x & 63;
+  const int pr = pt * 16 + (lane & 15), qc0 = qt * 16 + ((lane >> 4) << 2);
+  const bool pok = pr < NP;
+  const size_t idx = (size_t)pr * ldo + qc0;
+  const bool vec = pok && (qc0 + 3 < NQ) && (ldo & 3) == 0 && aligned16(out) && (!ADAM || aligned16(aa.p));
+  float p0[4] = {0.f, 0.f, 0.f, 0.f}, m0[4] = {0.f, 0.f, 0.f, 0.f}, v0[4] = {0.f, 0.f, 0.f, 0.f};
+  float neg_step = 0.f, bc2s = 1.f;
+  if (ADAM) {
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(aa.p + idx);
+      const float4 b = *reinterpret_cast<const float4*>(aa.m + idx);
+      const float4 c = *reinterpret_cast<const float4*>(aa.v + idx);
+      p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p0[3] = a.w;
+      m0[0] = b.x; m0[1] = b.y; m0[2] = b.z; m0[3] = b.w;
+      v0[0] = c.x; v0[1] = c.y; v0[2] = c.z; v0[3] = c.w;
+    } else if (pok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (qc0 + r < NQ) {
+          p0[r] = aa.p[idx + r];
+          m0[r] = aa.m[idx + r];
+          v0[r] = aa.v[idx + r];
+        }
+    }
+    // {-lr/bc1, sqrt(bc2)} of this step, published by launch 1 (k_enc_fwd)
+    neg_step = reinterpret_cast<const float*>(aa.counters)[2];
+    bc2s = reinterpret_cast<const float*>(aa.counters)[3];
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_tn<32, FULL>(Q, ldq, NQ, qt * 16, P, ldp, NP, pt * 16, Mrows, 0, 1, acc);
+  MV_STAMP_B(17, MV_STAMP_BLK);
+  if (ADAM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) adam1(p0[r], acc[r], m0[r], v0[r], neg_step, bc2s);
+  }
+  if (vec) {
+    // Write-through (sc1) 16-byte stores: nothing in this launch reads these lines again, and every line left dirty
+    // in the XCD's L2 has to be written back by the end-of-kernel release before the next launch may start -- with
+    // plain stores the 5 MB of g/p/m/v of one weight matrix cost ~2 us of idle chip after launches 5 and 6.
+    store16_wt(out, idx, acc);
+    if (ADAM) {
+      store16_wt(aa.p, idx, f32x4{p0[0], p0[1], p0[2], p0[3]});
+      store16_wt(aa.m, idx, f32x4{m0[0], m0[1], m0[2], m0[3]});
+      store16_wt(aa.v, idx, f32x4{v0[0], v0[1], v0[2], v0[3]});
+    }
+  } else if (pok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (qc0 + r < NQ) {
+        out[idx + r] = acc[r];
+        if (ADAM) {
+          aa.p[idx + r] = p0[r];
+          aa.m[idx + r] = m0[r];
+          aa.v[idx + r] = v0[r];
+        }
+      }
+  }
+  MV_STAMP_B(18, MV_STAMP_BLK);
+}
+
+// bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16
+template <bool ADAM>
+__device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/, const float* Gm, int ld, int Mrows,
+                                               int ncols, int c0, float* out, const AdamArgs& aa) {
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4, ng = blockDim.x >> 4;
+  float* sh = lds + 32 * 17;
+  float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+  const bool fin = (g == 0) && (c0 + c < ncols);
+  if (ADAM) {
+    if (fin) {
+      p0 = aa.p[c0 + c];
+      m0 = aa.m[c0 + c];
+      v0 = aa.v[c0 + c];
+    }
+    if (threadIdx.x == 0) {  // published by launch 1 (k_enc_fwd)
+      sh[0] = reinterpret_cast<const float*>(aa.counters)[2];
+      sh[1] = reinterpret_cast<const float*>(aa.counters)[3];
+    }
+  }
+  float s = 0.f;
+  if (c0 + c < ncols) {
+    const float* col = Gm + c0 + c;
+    int m = g;
+    for (; m + ng * 3 < Mrows; m += ng * 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = col[(size_t)(m + ng * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; m < Mrows; m += ng) s += col[(size_t)m * ld];
+  }
+  lds[g * 17 + c] = s;
+  __syncthreads();
+  if (fin) {
+    float t = 0.f;
+    for (int q = 0; q < ng; ++q) t += lds[q * 17 + c];
+    out[c0 + c] = t;
+    if (ADAM) {
+      adam1(p0, t, m0, v0, sh[0], sh[1]);
+      aa.p[c0 + c] = p0;
+      aa.m[c0 + c] = m0;
+      aa.v[c0 + c] = v0;
+    }
+  }
+}
+
+// XCD-aware tile assignment for the NT layers.  Workgroup L is observed to run on XCD L % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"); each XCD has a private L2, so a weight row-block fetched by workgroups on all 8 XCDs crosses
+// the fabric 8 times.  Column tiles (= weight row-blocks) are therefore dealt to XCDs: XCD k owns nt = k, k+8, ... and
+// runs every row tile mt of those; the activation rows are the only operand every XCD fetches.  Placement only
+// changes speed, never results.  Launch with grid = 8 * ceil(NT/8) * MT; returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L = blockIdx.x) {
+  const int k = L & 7, s = L >> 3;
+  *nt = k + 8 * (s / MT);
+  *mt = s % MT;
+  return *nt < NT;
+}
+

@@ -1,0 +1,799 @@
+// mvae_conv.hip -- building blocks of the conv architecture (conv_vae.py:28-79), the LDS-tiled f32 MFMA contraction
+// for large row counts, and the device-side input pipeline; the rest of the C ABI of include/mvae_hip.h.
+#include "mvae_common.hpp"
+
+// ------------------------------------------------------------------------------------------------ conv building blocks (API)
+// The reference's conv architecture (conv_vae.py:28-79) uses only Conv2d / ConvTranspose2d with kernel 4, stride 2,
+// padding 1.  Both are expressed on the dense MFMA contractions above through a patch matrix:
+//   Conv2d forward          y[(b,oy,ox), oc]       = im2col(x)[(b,oy,ox), (ic,ky,kx)] . W[oc, (ic,ky,kx)]^T      (NT)
+//   ConvTranspose2d forward col[(b,iy,ix),(oc,ky,kx)] = x[(b,iy,ix), ic] . W[ic, (oc,ky,kx)]  then y = col2im(col)   (NN)
+// and their backward passes are the same two gathers with the roles of input and output exchanged.
+// Activations are addressed through explicit (batch, channel, y, x) strides, so NCHW tensors at the model boundary
+// and channel-last tensors between layers use the same kernels.
+
+// col[(b,oy,ox), (c,ky,kx)] = src[b, c, 2oy-1+ky, 2ox-1+kx]  (0 outside), optionally masked by mask[...same index] > 0
+__global__ __launch_bounds__(256) void k_im2col(const float* src, const float* mask, float* col, int B, int C, int IH,
+                                                int IW, int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+  const int OH = IH / 2, OW = IW / 2, K = C * 16;
+  const int64_t total = (int64_t)B * OH * OW * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int64_t m = i / K;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((int64_t)OW * OH));
+    const int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    float v = 0.f;
+    if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+      const int64_t o = b * sb + c * sc + iy * sy + ix * sx;
+      v = src[o];
+      if (mask && !(mask[o] > 0.f)) v = 0.f;
+    }
+    col[i] = v;
+  }
+}
+
+// dst[b, c, y, x] = act(bias[c] + sum over the (ky,kx) with y = 2*py-1+ky, x = 2*px-1+kx of col[(b,py,px), (c,ky,kx)])
+// (PH = H/2 patch rows).  With mask != NULL the result is multiplied by [mask[b,c,y,x] > 0] (backward through a ReLU).
+__global__ __launch_bounds__(256) void k_col2im(const float* col, const float* bias, const float* mask, float* dst,
+                                                int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sy,
+                                                int64_t sx, int relu) {
+  const int PH = H / 2, PW = W / 2, K = C * 16;
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // enumerate with the channel fastest so that consecutive threads read consecutive (c,ky,kx) groups
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((y + 1) & 1) + 2 * a;  // ky with the parity of y+1
+      const int py = (y + 1 - ky) / 2;
+      if (py < 0 || py >= PH) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kx = ((x + 1) & 1) + 2 * e;
+        const int px = (x + 1 - kx) / 2;
+        if (px < 0 || px >= PW) continue;
+        acc += col[(((int64_t)b * PH + py) * PW + px) * K + c * 16 + ky * 4 + kx];
+      }
+    }
+    const int64_t o = b * sb + c * sc + y * sy + x * sx;
+    if (relu) acc = acc < 0.f ? 0.f : acc;
+    if (mask && !(mask[o] > 0.f)) acc = 0.f;
+    dst[o] = acc;
+  }
+}
+
+// ---- the same two gathers with the patch axis ordered (ky, kx, c) -- "taps-major" -- for channel-last tensors.
+// With c fastest, a patch row is 16 contiguous runs of C floats of the source, and the four terms of an output pixel are
+// contiguous runs of the patch matrix: both directions move 16-byte vectors, fully coalesced (the (c,ky,kx) order of the
+// reference's weight layout makes consecutive channels 64 bytes apart in the patch matrix).  The weight matrices are
+// permuted to the same order by the host layer (mvae_permute_rc on [OC, C, 16]).  Requires C % 4 == 0, sc == 1.
+__global__ __launch_bounds__(256) void k_im2col_tm(const float* src, const float* mask, float* col, int B, int C,
+                                                   int IH, int IW, int64_t sb, int64_t sy, int64_t sx) {
+  const int OH = IH / 2, OW = IW / 2, K4 = C * 4;  // K / 4
+  const int64_t total4 = (int64_t)B * OH * OW * K4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K4) * 4;
+    const int64_t m = i / K4;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((int64_t)OW * OH));
+    const int tap = k / C, c = k - tap * C, ky = tap >> 2, kx = tap & 3;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+      const int64_t o = b * sb + iy * sy + ix * sx + c;
+      v = *reinterpret_cast<const float4*>(src + o);
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+        if (!(mk.x > 0.f)) v.x = 0.f;
+        if (!(mk.y > 0.f)) v.y = 0.f;
+        if (!(mk.z > 0.f)) v.z = 0.f;
+        if (!(mk.w > 0.f)) v.w = 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(col + i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_col2im_tm(const float* col, const float* bias, const float* mask, float* dst,
+                                                   int B, int C, int H, int W, int64_t sb, int64_t sy, int64_t sx,
+                                                   int relu) {
+  const int PH = H / 2, PW = W / 2, K = C * 16, C4 = C / 4;
+  const int64_t total4 = (int64_t)B * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t r = i / C4;
+    const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((y + 1) & 1) + 2 * a;  // ky with the parity of y+1
+      const int py = (y + 1 - ky) / 2;
+      if (py < 0 || py >= PH) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kx = ((x + 1) & 1) + 2 * e;
+        const int px = (x + 1 - kx) / 2;
+        if (px < 0 || px >= PW) continue;
+        const float4 t =
+            *reinterpret_cast<const float4*>(col + (((int64_t)b * PH + py) * PW + px) * K + (ky * 4 + kx) * C + c);
+        acc.x += t.x;
+        acc.y += t.y;
+        acc.z += t.z;
+        acc.w += t.w;
+      }
+    }
+    const int64_t o = b * sb + y * sy + x * sx + c;
+    if (relu) {
+      acc.x = acc.x < 0.f ? 0.f : acc.x;
+      acc.y = acc.y < 0.f ? 0.f : acc.y;
+      acc.z = acc.z < 0.f ? 0.f : acc.z;
+      acc.w = acc.w < 0.f ? 0.f : acc.w;
+    }
+    if (mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+      if (!(mk.x > 0.f)) acc.x = 0.f;
+      if (!(mk.y > 0.f)) acc.y = 0.f;
+      if (!(mk.z > 0.f)) acc.z = 0.f;
+      if (!(mk.w > 0.f)) acc.w = 0.f;
+    }
+    *reinterpret_cast<float4*>(dst + o) = acc;
+  }
+}
+
+// out[b][c][r] = in[b][r][c]   (channel-last <-> channel-first flattening of a small activation)
+__global__ __launch_bounds__(256) void k_permute_rc(const float* in, float* out, int64_t B, int R, int Cc) {
+  const int64_t total = B * R * Cc;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i % R);
+    const int c = (int)((i / R) % Cc);
+    const int64_t b = i / ((int64_t)R * Cc);
+    out[i] = in[(b * R + r) * Cc + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* P, const float* Q, float* out, int M, int NP, int NQ) {
+  const int ntQ4 = ((NQ + 15) / 16 + 3) / 4;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_tn_wave<false>(P, NP, NP, blockIdx.x / ntQ4, Q, NQ, NQ, (blockIdx.x % ntQ4) * 4 + (threadIdx.x >> 6), M, out, NQ,
+                     none);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nn(const float* G, const float* W, const float* mask, float* out, int M,
+                                                 int K, int N) {
+  __shared__ float red[4][16][17];
+  const int ntN = (N + 15) / 16;
+  job_nn(red, G, K, M, blockIdx.x / ntN, W, N, N, blockIdx.x % ntN, K, mask, N, out, N);
+}
+
+__global__ __launch_bounds__(256) void k_colsum(const float* G, float* out, int M, int N) {
+  __shared__ float lds[32 * 17 + 2];
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_colsum_opt<false>(lds, G, N, M, N, blockIdx.x * kColsPerBlock, out, none);
+}
+
+// g[r][j] = sigmoid(logits[r][j]) - x[r][j];  bce[r] = sum_j BCE-with-logits   (one workgroup per row; 16-byte moves
+// when D % 4 == 0 and the buffers are aligned; the four wave sums are added in wave order)
+__global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* logits, const float* x, float* bce, float* g,
+                                                     int64_t rows, int D) {
+  __shared__ float sm[4];
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x;
+  const float* yl = logits + r * D;
+  const float* tl = x + r * D;
+  float* gl = g + r * D;
+  auto term = [](float y, float t, float* gout) -> float {
+    const float e = mvf::fexp(-fabsf(y));
+    *gout = ((y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t;
+    return (1.f - t) * y - (fminf(y, 0.f) - mvf::log1p_pos(e));
+  };
+  float s = 0.f;
+  if ((D & 3) == 0 && ((((uintptr_t)logits | (uintptr_t)x | (uintptr_t)g) & 15) == 0)) {
+    for (int j = tid * 4; j < D; j += 1024) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(yl + j), t = *reinterpret_cast<const f32x4*>(tl + j);
+      f32x4 gv;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float go;
+        s += term(y[u], t[u], &go);
+        gv[u] = go;
+      }
+      *reinterpret_cast<f32x4*>(gl + j) = gv;
+    }
+  } else {
+    for (int j = tid; j < D; j += 256) {
+      float go;
+      s += term(yl[j], tl[j], &go);
+      gl[j] = go;
+    }
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) sm[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) bce[r] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// BatchStats (stats.py:144-212) for paths that do not run the fused MLP step: one workgroup
+__global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B,
+                                                     int ncomp) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+  };
+  float b = 0.f, e = 0.f;
+  for (int r = tid; r < B; r += 256) {
+    float klr = kl[r];
+    int i = 1;
+    for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) klr += v[u];
+    }
+    for (; i < ncomp; ++i) klr += kl[(size_t)i * B + r];
+    b += bce[r];
+    e += (-bce[r] - beta * klr);
+  }
+  const float bs = block_sum(b), es = block_sum(e);
+  const int last = 4 + ncomp;
+  float kt = 0.f;
+  for (int i = 0; i < ncomp; ++i) {
+    float a = 0.f;
+    for (int r = tid; r < B; r += 256) a += kl[(size_t)i * B + r];
+    const float sres = block_sum(a);
+    kt += sres;
+    if (tid == 0) {
+      stats[4 + i] += sres;
+      stats[last + 4 + i] = sres;
+    }
+  }
+  if (tid == 0) {
+    stats[0] += bs; stats[1] += kt; stats[2] += es; stats[3] += 1.f;
+    stats[last] = bs; stats[last + 1] = kt; stats[last + 2] = es; stats[last + 3] = 1.f;
+  }
+}
+
+static int grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+static bool taps_major_ok(const void* a, const void* b, const void* c, int C, int64_t sc, int64_t sb, int64_t sy,
+                          int64_t sx) {
+  return sc == 1 && (C & 3) == 0 && ((sb | sy | sx) & 3) == 0 && aligned16(a) && aligned16(b) && (!c || aligned16(c));
+}
+
+extern "C" int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, int C, int IH, int IW,
+                                  int64_t sb, int64_t sc, int64_t sy, int64_t sx, int taps_major, void* stream) {
+  if (!src || !col || B < 1 || C < 1 || IH < 2 || IW < 2 || (IH & 1) || (IW & 1))
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (taps_major) {
+    if (!taps_major_ok(src, col, mask, C, sc, sb, sy, sx))
+      return fail(MVAE_E_ALIGN, "taps-major im2col needs a channel-last source with C %% 4 == 0%s", "");
+    hipLaunchKernelGGL(k_im2col_tm, dim3(grid_for((int64_t)B * (IH / 2) * (IW / 2) * C * 4)), dim3(256), 0,
+                       (hipStream_t)stream, src, mask, col, B, C, IH, IW, sb, sy, sx);
+    LAUNCH_CHECK("im2col launch");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_im2col, dim3(grid_for((int64_t)B * (IH / 2) * (IW / 2) * C * 16)), dim3(256), 0,
+                     (hipStream_t)stream, src, mask, col, B, C, IH, IW, sb, sc, sy, sx);
+  LAUNCH_CHECK("im2col launch");
+  return 0;
+}
+
+extern "C" int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C,
+                                  int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu,
+                                  int taps_major, void* stream) {
+  if (!col || !dst || B < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (taps_major) {
+    if (!taps_major_ok(col, dst, mask, C, sc, sb, sy, sx) || (bias && !aligned16(bias)))
+      return fail(MVAE_E_ALIGN, "taps-major col2im needs a channel-last destination with C %% 4 == 0%s", "");
+    hipLaunchKernelGGL(k_col2im_tm, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       col, bias, mask, dst, B, C, H, W, sb, sy, sx, relu);
+    LAUNCH_CHECK("col2im launch");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_col2im, dim3(grid_for((int64_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, col, bias,
+                     mask, dst, B, C, H, W, sb, sc, sy, sx, relu);
+  LAUNCH_CHECK("col2im launch");
+  return 0;
+}
+
+extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, int Cc, void* stream) {
+  if (!in || !out || B < 1 || R < 1 || Cc < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_permute_rc, dim3(grid_for(B * R * Cc)), dim3(256), 0, (hipStream_t)stream, in, out, B, R, Cc);
+  LAUNCH_CHECK("permute launch");
+  return 0;
+}
+
+// ---- LDS-tiled f32 MFMA contraction for the large shapes of the conv architecture (M = B*OH*OW up to 65536 rows).
+// C[M,N] = A . B with A(i,k) at A[i*sai + k*sak] and B(k,j) at B[k*sbk + j*sbj]; exactly one stride of each operand
+// is 1 (the template flag says which), so one kernel serves
+//   NT  y = x W^T        A = x [M,K] (k contiguous),  B = W [N,K] (k contiguous)     Conv2d forward / Linear
+//   NN  y = g W          A = g [M,K] (k contiguous),  B = W [K,N] (j contiguous)     ConvTranspose2d forward, dX
+//   TN  dW = P^T Q       A = P [Kc,M'] (i contiguous), B = Q [Kc,N] (j contiguous)   weight gradients (split-K slices)
+// Workgroup tile BM x BN, K step BK (32: with 16 a 64 x 64 tile has only 512 MFMA cycles per wave between two
+// barriers and the fixed barrier + LDS latency shows, MfmaUtil 56 %); 4 waves as 2 x 2, each wave (BM/2) x (BN/2) as
+// 16 x 16 MFMA tiles (the 64 x 64 and 128 x 128 launches run 8 waves as 2 x 4: four waves per SIMD at two workgroups
+// per CU, +3 % on the conv step).  Both operand tiles sit in LDS as [row][k] with a row stride of BK + 8 floats: a lane fetches
+// ONE 16-byte vector per 16 x 16 x 16 sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and
+// B); strides 24 / 40 are conflict-free for ds_read_b128 under its 16-lane service groups ({0-3,12-15,20-27}, ...
+// over 64 banks).  Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
+template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
+                                                    const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
+                                                    float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                                    const float* __restrict__ mask, int relu, int M, int N, int K,
+                                                    int k_per_slice, int64_t slice_stride) {
+  constexpr int kGT_BK = BK, kGT_LD = BK + 8, KQ = BK / 4;
+  __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
+  constexpr int NT = 64 * NW, WCOLS = NW / 2;  // waves as 2 x WCOLS
+  constexpr int WM = BM / 2, WN = BN / WCOLS, TM = WM / 16, TN = WN / 16;
+  constexpr int LA = BM * KQ / NT, LB = BN * KQ / NT;  // 16-byte vectors per thread per K step
+  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = blockIdx.z * k_per_slice;
+  const int ke = (kb + k_per_slice < K) ? kb + k_per_slice : K;
+  C += (size_t)blockIdx.z * slice_stride;
+
+  float4 ra[LA], rb[LB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + NT * r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KC) {  // 4 consecutive k of row i
+        const int i = f / KQ, k = k0 + ((f % KQ) << 2);
+        if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + i) * sai + k);
+      } else {  // 4 consecutive i of column k
+        const int k = k0 + (f % BK), i = (f / BK) << 2;
+        if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)k * sak + (m0 + i));
+      }
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + NT * r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_KC) {
+        const int j = f / KQ, k = k0 + ((f % KQ) << 2);
+        if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + j) * sbj + k);
+      } else {
+        const int k = k0 + (f % BK), j = (f / BK) << 2;
+        if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)k * sbk + (n0 + j));
+      }
+      rb[r] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + NT * r;
+      if (A_KC) {
+        *reinterpret_cast<float4*>(As + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = ra[r];
+      } else {  // rows i and i+4 share banks at this stride: the odd 16-lane halves store their rows rotated by 2
+        const int k = f % BK, i = (f / BK) << 2;
+        const bool rot = BK == 16 && ((f >> 4) & 1);
+        As[(i + (rot ? 2 : 0)) * kGT_LD + k] = rot ? ra[r].z : ra[r].x;
+        As[(i + (rot ? 3 : 1)) * kGT_LD + k] = rot ? ra[r].w : ra[r].y;
+        As[(i + (rot ? 0 : 2)) * kGT_LD + k] = rot ? ra[r].x : ra[r].z;
+        As[(i + (rot ? 1 : 3)) * kGT_LD + k] = rot ? ra[r].y : ra[r].w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + NT * r;
+      if (B_KC) {
+        *reinterpret_cast<float4*>(Bs + (f / KQ) * kGT_LD + ((f % KQ) << 2)) = rb[r];
+      } else {
+        const int k = f % BK, j = (f / BK) << 2;
+        const bool rot = BK == 16 && ((f >> 4) & 1);
+        Bs[(j + (rot ? 2 : 0)) * kGT_LD + k] = rot ? rb[r].z : rb[r].x;
+        Bs[(j + (rot ? 3 : 1)) * kGT_LD + k] = rot ? rb[r].w : rb[r].y;
+        Bs[(j + (rot ? 0 : 2)) * kGT_LD + k] = rot ? rb[r].x : rb[r].z;
+        Bs[(j + (rot ? 1 : 3)) * kGT_LD + k] = rot ? rb[r].y : rb[r].w;
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave / WCOLS) * WM, wn = (wave % WCOLS) * WN;
+  const int li = lane & 15, lk = (lane >> 4) << 2;
+
+  fetch(kb);
+  for (int k0 = kb; k0 < ke; k0 += kGT_BK) {
+    stage();
+    __syncthreads();
+    if (k0 + kGT_BK < ke) fetch(k0 + kGT_BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const f32x4*>(As + (wm + a * 16 + li) * kGT_LD + kk + lk);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bf[b] = *reinterpret_cast<const f32x4*>(Bs + (wn + b * 16 + li) * kGT_LD + kk + lk);
+      // operands swapped (B fragment first): the lane's four accumulator values are four CONSECUTIVE columns of one
+      // output row, so the epilogue moves 16 bytes per lane.  Small wave tiles take the k-component outermost so
+      // that consecutive MFMAs write different accumulators.
+      if constexpr (TM * TN <= 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = mfma16(bf[b][j], af[a][j], acc[a][b]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][b] = mfma16(bf[b][j], af[a][j], acc[a][b]);
+      }
+    }
+    __syncthreads();
+  }
+  // epilogue: lane holds row lane&15, columns 4*(lane>>4) + r of every 16 x 16 tile
+  const bool vec = (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0 && (ldc & 3) == 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + wm + a * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn + b * 16 + lk;
+      if (n >= N) continue;
+      f32x4 v = acc[a][b];
+      if (vec && n + 3 < N) {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (relu)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];  // torch.relu: NaN propagates
+        if (mask) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (size_t)m * ldc + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float w = v[r] + (bias ? bias[n + r] : 0.f);
+          if (relu) w = w < 0.f ? 0.f : w;
+          if (mask && !(mask[(size_t)m * ldc + n + r] > 0.f)) w = 0.f;
+          C[(size_t)m * ldc + n + r] = w;
+        }
+      }
+    }
+  }
+}
+
+// operand requirements of the 16-byte paths of k_gemm_tiled
+static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
+
+#ifndef MV_BK64
+#define MV_BK64 32
+#endif
+#ifndef MV_BK128
+#define MV_BK128 32
+#endif
+#ifndef MV_NW64
+#define MV_NW64 8
+#endif
+#ifndef MV_NW128
+#define MV_NW128 8
+#endif
+constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128, kNW64 = MV_NW64, kNW128 = MV_NW128;
+template <bool A_KC, bool B_KC>
+static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
+                              float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
+                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s) {
+  // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
+  // workgroups, half the LDS reuse) win on every conv layer shape of the reference
+  const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
+  if (N > 64 && wg128 < 512) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  } else if (N > 64) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, kNW128, A_KC, B_KC>), grid, dim3(64 * kNW128), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, 4, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+  }
+}
+
+bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
+                                 int relu, hipStream_t s) {
+  if (!tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff) return false;
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0, s);
+  return true;
+}
+
+// Long batch contractions (conv layers: M = B*OH*OW up to 65536 rows): the rows are cut into slices of kTnSlice, one
+// workgroup-row of tiles per slice writes its partial [NP, NQ] product, and a second launch adds the slices in index
+// order (deterministic; no float atomics).
+constexpr int kTnSlice = 256;
+__global__ __launch_bounds__(256) void k_gemm_tn_sliced(const float* P, const float* Q, float* part, int M, int NP,
+                                                        int NQ, int tiles) {
+  const int slice = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int ntQ4 = ((NQ + 15) / 16 + 3) / 4;
+  const int m0 = slice * kTnSlice;
+  const int rows = (M - m0) < kTnSlice ? (M - m0) : kTnSlice;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_tn_wave<false>(P + (size_t)m0 * NP, NP, NP, tile / ntQ4, Q + (size_t)m0 * NQ, NQ, NQ,
+                     (tile % ntQ4) * 4 + (threadIdx.x >> 6), rows, part + (size_t)slice * NP * NQ, NQ, none);
+}
+// out[i] = sum_k part[k][i], fixed order: a workgroup owns 64 outputs, its four waves take the slices k = w, w+4, ...
+// (8 loads in flight per lane), the four partial sums meet in LDS and are added in wave order.
+__global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* out, int64_t n, int slices,
+                                                    const float* bias = nullptr, int ncols = 1, int relu = 0) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + lane;
+    float s = 0.f;
+    if (i < n) {
+      int k = w;
+      for (; k + 28 < slices; k += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < slices; k += 4) s += part[(size_t)k * n + i];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) {
+      float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+      if (bias) v += bias[i % ncols];
+      if (relu) v = v < 0.f ? 0.f : v;
+      out[i] = v;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_relu_mask(float* dy, const float* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+extern "C" int64_t mvae_gemm_tn_workspace_floats(int64_t M, int NP, int NQ) {
+  if (M <= kTnSlice) return 0;
+  return ((M + kTnSlice - 1) / kTnSlice) * (int64_t)NP * NQ;
+}
+
+extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t M, int NP, int NQ, float* workspace,
+                            void* stream) {
+  if (!P || !Q || !out || M < 1 || NP < 1 || NQ < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (M >= kTiledMinRows && tiled_ok(P, NP) && tiled_ok(Q, NQ) && tiled_ok(out, NQ) && M <= 0x7fffffff) {
+    // split-K over the batch rows so that >= 256 workgroups exist; the slices are added in index order
+    const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
+    int slices = (256 + wg - 1) / wg;
+    const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);  // what mvae_gemm_tn_workspace_floats provides
+    if (slices > max_slices) slices = max_slices;
+    if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
+    const int kps = (int)((((M + slices - 1) / slices) + 15) & ~(int64_t)15);
+    slices = (int)((M + kps - 1) / kps);
+    const int64_t n = (int64_t)NP * NQ;
+    launch_gemm_tiled<false, false>(P, 1, NP, Q, NQ, 1, slices > 1 ? workspace : out, NQ, nullptr, nullptr, 0, NP, NQ,
+                                    (int)M, slices, kps, n, (hipStream_t)stream);
+    if (slices > 1)
+      hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+    LAUNCH_CHECK("tiled gemm_tn launch");
+    return 0;
+  }
+  const int tiles = ((NP + 15) / 16) * (((NQ + 15) / 16 + 3) / 4);
+  if (M <= kTnSlice) {
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles), dim3(256), 0, (hipStream_t)stream, P, Q, out, (int)M, NP, NQ);
+  } else {
+    if (!workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
+    const int slices = (int)((M + kTnSlice - 1) / kTnSlice);
+    hipLaunchKernelGGL(k_gemm_tn_sliced, dim3((unsigned)(tiles * slices)), dim3(256), 0, (hipStream_t)stream, P, Q,
+                       workspace, (int)M, NP, NQ, tiles);
+    const int64_t n = (int64_t)NP * NQ;
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+  }
+  LAUNCH_CHECK("gemm_tn launch");
+  return 0;
+}
+
+extern "C" int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream) {
+  if (!dy || !y || n < 0) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_relu_mask, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n);
+  LAUNCH_CHECK("relu mask launch");
+  return 0;
+}
+
+extern "C" int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N,
+                            void* stream) {
+  if (!G || !W || !out || M < 1 || K < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (M >= kTiledMinRows && tiled_ok(G, K) && tiled_ok(W, N) && M <= 0x7fffffff) {
+    launch_gemm_tiled<true, false>(G, K, 1, W, N, 1, out, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
+                                   (hipStream_t)stream);
+    LAUNCH_CHECK("tiled gemm_nn launch");
+    return 0;
+  }
+  const int64_t grid = ((M + 15) / 16) * ((N + 15) / 16);
+  if (grid > 0x7fffffff) return fail(MVAE_E_UNSUPPORTED, "grid too large%s", "");
+  hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, G, W, mask, out, (int)M, K, N);
+  LAUNCH_CHECK("gemm_nn launch");
+  return 0;
+}
+
+// y = act(x W^T + b) for FEW rows and a LONG contraction (the conv architecture's heads: M = B, N = 12, K = 8192: 16
+// output tiles).  K is cut into slices of kSplitK so that >= ~256 workgroups exist; the slices' partial products are
+// added in index order, with the bias and the activation, by k_sum_slices.
+constexpr int kSplitK = 128;
+extern "C" int64_t mvae_linear_forward_splitk_workspace_floats(int64_t M, int N, int K) {
+  const int64_t slices = (K + kSplitK - 1) / kSplitK;
+  return slices > 1 ? slices * M * N : 0;
+}
+extern "C" int mvae_linear_forward_splitk(const float* x, const float* W, const float* b, float* y, int64_t M, int N,
+                                          int K, int relu, float* workspace, void* stream) {
+  if (!x || !W || !y || M < 1 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int slices = (K + kSplitK - 1) / kSplitK;
+  if (slices == 1 || !tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff)
+    return mvae_linear_forward(x, W, b, y, M, N, K, relu, stream);
+  if (!workspace) return fail(MVAE_E_BADARG, "mvae_linear_forward_splitk needs its workspace%s", "");
+  const int64_t n = M * N;
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, workspace, N, nullptr, nullptr, 0, (int)M, N, K, slices, kSplitK, n,
+                                (hipStream_t)stream);
+  hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, y, n, slices, b,
+                     N, relu);
+  LAUNCH_CHECK("split-K linear forward launch");
+  return 0;
+}
+
+// tall matrices (conv activations: up to 65536 rows): row slices of kColSlice are summed by separate workgroups, the
+// slice totals are then added in index order
+constexpr int kColSlice = 512;
+__global__ __launch_bounds__(256) void k_colsum_sliced(const float* G, float* part, int M, int N, int ncb) {
+  __shared__ float lds[32 * 17 + 2];
+  const int slice = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+  const int m0 = slice * kColSlice;
+  const int rows = (M - m0) < kColSlice ? (M - m0) : kColSlice;
+  AdamArgs none = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  job_colsum_opt<false>(lds, G + (size_t)m0 * N, N, rows, N, cb * kColsPerBlock, part + (size_t)slice * N, none);
+}
+
+extern "C" int64_t mvae_colsum_workspace_floats(int64_t M, int N) {
+  return M <= kColSlice ? 0 : ((M + kColSlice - 1) / kColSlice) * (int64_t)N;
+}
+
+extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* workspace, void* stream) {
+  if (!G || !out || M < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int ncb = (N + kColsPerBlock - 1) / kColsPerBlock;
+  if (M <= kColSlice) {
+    hipLaunchKernelGGL(k_colsum, dim3(ncb), dim3(256), 0, (hipStream_t)stream, G, out, (int)M, N);
+  } else {
+    if (!workspace) return fail(MVAE_E_BADARG, "mvae_colsum needs a workspace for M > 512%s", "");
+    const int slices = (int)((M + kColSlice - 1) / kColSlice);
+    hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
+                       workspace, (int)M, N, ncb);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * (int64_t)N)), dim3(256), 0, (hipStream_t)stream, workspace, out, (int64_t)N,
+                       slices);
+  }
+  LAUNCH_CHECK("colsum launch");
+  return 0;
+}
+
+extern "C" int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, float* g, int64_t rows,
+                                         int D, void* stream) {
+  if (!logits || !x || !bce || !g || rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_bce_fwd_bwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, x,
+                     bce, g, rows, D);
+  LAUNCH_CHECK("bce launch");
+  return 0;
+}
+
+extern "C" int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp,
+                                void* stream) {
+  if (!bce || !kl || !stats || B < 1 || ncomp < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, bce, kl, stats, beta, B, ncomp);
+  LAUNCH_CHECK("batch stats launch");
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ device-side input pipeline
+// Row f-2 of the scope table: the reference feeds the step from 8 DataLoader worker processes that binarise every image
+// on the CPU (mt/data/image_reconstruction.py:44-53,70-74) plus a host->device copy, and draws eps with the torch RNG
+// inside the step.  Here the data set lives in HBM as uint8, and ONE small launch per step gathers the next batch by
+// a device-resident permutation, binarises it dynamically (x = pixel/255 > U(0,1)) and draws eps ~ N(0,1), both from
+// a counter-based Philox4x32-10 stream keyed by (seed, batch cursor) -- no host work, so a whole epoch can be
+// replayed as HIP graphs.  The cursor lives in counters[8] and is advanced by launch 1 of the step.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void k_prepare_batch(const unsigned char* images, const int* perm, int n_images,
+                                                       int D, int B, int E, unsigned long long seed,
+                                                       const int* counters, int batches_per_epoch, int train,
+                                                       float* x, float* eps) {
+  const unsigned cursor = (unsigned)counters[8];
+  const int bi = (int)(cursor % (unsigned)batches_per_epoch);
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  const int nx4 = (B * D + 3) / 4, ne4 = (B * E + 3) / 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nx4 + ne4; i += gridDim.x * 256) {
+    unsigned r[4];
+    if (i < nx4) {
+      philox4x32_10((unsigned)i, cursor, 0u, 0u, k0, k1, r);  // stream 0: binarisation
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int e = i * 4 + t;
+        if (e < B * D) {
+          const int b = e / D, j = e - b * D;
+          const int src = perm ? perm[(size_t)bi * B + b] : (bi * B + b);
+          const float pix = (float)images[(size_t)(src < n_images ? src : n_images - 1) * D + j] / 255.0f;
+          const float u = (float)(r[t] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+          x[e] = (train ? (pix > u) : (pix > 0.5f)) ? 1.0f : 0.0f;
+        }
+      }
+    } else {
+      const int q = i - nx4;
+      philox4x32_10((unsigned)q, cursor, 1u, 0u, k0, k1, r);  // stream 1: eps
+      // Box-Muller on two pairs
+      float n[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float u1 = ((float)(r[2 * t] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+        const float u2 = (float)(r[2 * t + 1] >> 8) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        n[2 * t] = rad * cs;
+        n[2 * t + 1] = rad * sn;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (q * 4 + t < B * E) eps[q * 4 + t] = n[t];
+    }
+  }
+}
+
+extern "C" int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E,
+                                  uint64_t seed, const int32_t* counters, int batches_per_epoch, int train, float* x,
+                                  float* eps, void* stream) {
+  if (!images || !counters || !x || !eps || n_images < 1 || D < 1 || B < 1 || E < 1 || batches_per_epoch < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const int work = (B * D + 3) / 4 + (B * E + 3) / 4;
+  hipLaunchKernelGGL(k_prepare_batch, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream, images, perm,
+                     n_images, D, B, E, (unsigned long long)seed, counters, batches_per_epoch, train, x, eps);
+  LAUNCH_CHECK("prepare batch launch");
+  return 0;
+}

@@ -484,6 +484,46 @@ template <int KIND, int AMAX, typename T> __device__ __forceinline__ void log_ma
   }
 }
 
+// ---- geodesic distance between two points of the manifold.  The reference holds these formulas next to its
+// operators: hyperboloid R*acosh(-<x,y>_L / R^2) (tests/mvae/ops/test_hyperbolics.py:46-47, guarded Acosh), sphere
+// R*acos(clamp(<x,y>/R^2, -1, 1)) (test_spherical.py:45-48), Euclidean 2*|x - y| (test_euclidean.py:41-42: the
+// convention that goes with exp_map_mu0(x) = x/2), Poincare ball poincare_distance_c (ops/poincare.py:92-105), projected
+// sphere spherical_projected_distance (ops/spherical_projected.py:90-97) or, with gyro != 0, its gyro form (:100-105).
+template <int KIND, int AMAX, typename T>
+__device__ __forceinline__ T geodesic_distance(const T* x, const T* y, int A, T R, bool gyro) {
+  MV_BOUNDS(AMAX);
+  if constexpr (KIND == kEuclidean) {
+    T df[AMAX];
+    MV_FOR(i, 0, A) df[i] = x[i] - y[i];
+    return 2.0f * norm2<AMAX>(df, A);
+  } else if constexpr (KIND == kHyperboloid) {
+    return R * g_acosh(-lorentz_product<AMAX>(x, y, A) / (R * R));
+  } else if constexpr (KIND == kSphere) {
+    return R * t_acos(hard_clamp(dot<AMAX>(x, y, A) / (R * R), -1.0f, 1.0f));
+  } else if constexpr (KIND == kPoincare) {
+    T c = 1.0f / (R * R);
+    T sc = g_sqrt(c);
+    T neg[AMAX], sub[AMAX];
+    MV_FOR(i, 0, A) neg[i] = -x[i];
+    p_mobius_add<AMAX>(neg, y, A, c, sub);
+    return g_atanh(sc * norm2<AMAX>(sub, A)) * 2.0f / sc;
+  } else {  // kProjSphere; K = 1 / R^2
+    T K = 1.0f / (R * R);
+    T sk = g_sqrt(K);
+    if (gyro) {
+      T neg[AMAX], sub[AMAX];
+      MV_FOR(i, 0, A) neg[i] = -x[i];
+      p_mobius_add<AMAX>(neg, y, A, -K, sub);
+      return 2.0f / sk * t_atan(sk * norm2<AMAX>(sub, A));
+    }
+    T df[AMAX];
+    MV_FOR(i, 0, A) df[i] = x[i] - y[i];
+    T nd = dot<AMAX>(df, df, A), nx = dot<AMAX>(x, x, A), ny = dot<AMAX>(y, y, A);
+    T arg = 1.0f - 2.0f * K * nd / ((1.0f + K * nx) * (1.0f + K * ny));
+    return 1.0f / sk * t_acos(hard_clamp(arg, -INFINITY, 1.0f));
+  }
+}
+
 // ---- logdet of the projection Jacobian from the tangent vector u (hyperbolics.py:58-65 | spherical.py:58-67)
 template <int KIND, int AMAX, typename T> __device__ __forceinline__ T logdet_u(const T* u, int A, T R) {
   float nm1 = (float)(A - 1 - 1);  // (n - 1) with n = A - 1

@@ -1,0 +1,1224 @@
+// mvae_step.hip -- the fused ELBO step of mvae on gfx950 (C ABI: include/mvae_hip.h, "The whole step").
+//
+// The ELBO step (reference: ModelVAE.train_step, mt/mvae/models/vae.py:149-166) is SIX launches; each cut is a
+// grid-wide data dependency (every output of launch k is needed by every workgroup of launch k+1):
+//
+//   1 k_enc_fwd     h  = relu(x W_e0^T + b)                      MFMA NT, 16x16 tile / workgroup, 8 waves split K
+//   2 k_latent_fwd  one batch ROW per workgroup: heads = h W_heads^T + b -> per-component exp_map_mu0 / softplus /
+//                   wrapped-normal sample / KL -> concat_z -> hd = relu(z W_d0^T + b); waves 4..7 evaluate the same
+//                   components over dual numbers (d z, d kl per input direction) for launch 5
+//   3 k_dec1_fwd    logits = hd W_logits^T + b ; BCE-with-logits row partials ; g = sigmoid(logits) - x
+//   4 k_dec1_bwd    dhd = (g W_logits) * [hd>0] ; db_logits (+Adam) ; step statistics (BatchStats)
+//   5 k_latent_bwd  rows: dz = dhd W_d0 -> contraction with the dual records of launch 2 -> dheads ;
+//                   dh = (dheads W_heads) * [h>0]                  tiles: dW_logits = g^T hd (+Adam)
+//   6 k_enc_bwd     dW_e0 = dh^T x, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
+//
+// In the single-GPU step the optimizer runs in the gradient epilogues, each weight one launch after its last read;
+// the two-call path (mvae_step_forward_backward -> all-reduce -> mvae_step_optimizer) uses k_optim instead.
+// Nothing here synchronises or allocates, so the host layer can capture any number of steps into one HIP graph.
+// Further down: manifold primitives, component operators, generic dense layers, log-likelihood helpers and the
+// patch-matrix gathers of the conv architecture -- the rest of the C ABI.
+#include "mvae_common.hpp"
+
+// ================================================================================================ the fused step
+struct mvae_ctx {
+  mvae_model_desc d;
+  CompTable t;
+  int dmax;
+  int ldh;    // heads row stride (NH rounded up to 4)
+  int ldz;    // z row stride
+  // workspace carve (floats)
+  int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_total;
+  int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
+};
+
+static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+static inline int64_t up64(int64_t x) { return (x + 63) & ~(int64_t)63; }
+
+// floats per (row, component, input direction) record of the dual workspace: {d kl, d z_0 .. d z_{A-1}}, A <= dmax + 1
+static inline int dual_stride(int dmax_bucket) { return dmax_bucket + 2; }
+
+static void carve(mvae_ctx* c, int dmax_bucket) {
+  const mvae_model_desc& d = c->d;
+  const int64_t B = d.batch, H = d.h_dim, D = d.in_dim;
+  c->ldh = (int)up4(d.heads_dim);
+  c->ldz = (int)up4(d.z_dim);
+  c->nt_d = (d.in_dim + 15) / 16;
+  c->nt_h = (d.h_dim + 15) / 16;
+  c->nt_b = (d.batch + 15) / 16;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += up64(n); return r; };
+  c->o_h = take(B * H);
+  c->o_heads = take(B * c->ldh);
+  c->o_z = take(B * c->ldz);
+  c->o_hd = take(B * H);
+  c->o_g = take(B * D);
+  c->o_bce_part = take((int64_t)c->nt_d * B);
+  c->o_kl = take((int64_t)d.ncomp * B);
+  c->o_dhd = take(B * H);
+  c->o_dz = take(B * c->ldz);
+  c->o_dheads = take(B * c->ldh);
+  c->o_dh = take(B * H);
+  c->o_drpart = take(B * kMaxComp);  // [comp][B]
+  // [B][heads_dim + ncomp][dual_stride]: every input direction of every component (radius directions included
+  // whether or not they are trainable right now)
+  c->o_duals = take(B * ((int64_t)d.heads_dim + d.ncomp) * dual_stride(dmax_bucket));
+  c->o_total = o;
+}
+
+extern "C" int64_t mvae_workspace_floats(const mvae_model_desc* desc) {
+  if (!desc) return -1;
+  mvae_ctx tmp;
+  tmp.d = *desc;
+  int dmax = MVAE_MAX_TRUE_DIM;
+  if (desc->comps && desc->ncomp >= 1 && desc->ncomp <= kMaxComp) {
+    dmax = 1;
+    for (int i = 0; i < desc->ncomp; ++i) dmax = desc->comps[i].true_dim > dmax ? desc->comps[i].true_dim : dmax;
+  }
+  carve(&tmp, bucket_of(dmax));
+  return tmp.o_total;
+}
+
+extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
+  if (!desc || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (desc->abi_version != MVAE_ABI_VERSION) return fail(MVAE_E_BADARG, "ABI version mismatch%s", "");
+  if (desc->arch != 0) return fail(MVAE_E_UNSUPPORTED, "only arch 0 (feed-forward) is built into the fused step%s", "");
+  if (desc->batch < 1 || desc->in_dim < 1 || desc->h_dim < 1) return fail(MVAE_E_BADARG, "bad dims%s", "");
+  if (desc->heads_dim > kHeadsMax || desc->z_dim > kHeadsMax)
+    return fail(MVAE_E_UNSUPPORTED, "heads_dim / z_dim above %s%lld", "", kHeadsMax);
+  if (!desc->params || !desc->grads || !desc->adam_m || !desc->adam_v || !desc->step_count || !desc->workspace ||
+      !desc->stats)
+    return fail(MVAE_E_BADARG, "null buffer in model desc%s", "");
+  if (desc->off_radii != 0) return fail(MVAE_E_BADARG, "radii must sit at offset 0 of the flat buffers%s", "");
+  const int64_t offs[] = {desc->off_w_heads, desc->off_b_heads, desc->off_w_e0, desc->off_b_e0, desc->off_w_d0,
+                          desc->off_b_d0, desc->off_w_logits, desc->off_b_logits};
+  for (int64_t o : offs)
+    if (o < kRadiiRegion || (o & 3) || o >= desc->n_params)
+      return fail(MVAE_E_ALIGN, "segment offsets must be multiples of 4 floats, >= 64 and < n_params%s (%lld)", "", o);
+  if ((desc->n_params & 3) || !aligned16(desc->params) || !aligned16(desc->grads) || !aligned16(desc->adam_m) ||
+      !aligned16(desc->adam_v) || !aligned16(desc->workspace))
+    return fail(MVAE_E_ALIGN, "flat buffers must be 16-byte aligned with n_params %% 4 == 0%s", "");
+  mvae_ctx* c = new mvae_ctx();
+  c->d = *desc;
+  int rc = fill_table(&c->t, desc->comps, desc->ncomp, desc->radius_trainable, &c->dmax);
+  if (rc) {
+    delete c;
+    return rc;
+  }
+  int eps_dim = 0, z_dim = 0, hd = 0;
+  for (int i = 0; i < desc->ncomp; ++i) {
+    const mvae_component_desc& k = desc->comps[i];
+    eps_dim += k.true_dim;
+    z_dim += ambient_dim(k.kind, k.true_dim);
+    hd += k.true_dim + k.logvar_dim;
+    if (k.radius_idx != i) {
+      delete c;
+      return fail(MVAE_E_BADARG, "comps[i].radius_idx must equal i in the fused step%s", "");
+    }
+  }
+  if (eps_dim != desc->eps_dim || z_dim != desc->z_dim || hd != desc->heads_dim) {
+    delete c;
+    return fail(MVAE_E_BADARG, "heads_dim / z_dim / eps_dim inconsistent with the component table%s", "");
+  }
+  c->d.comps = nullptr;
+  c->d.radius_trainable = nullptr;
+  carve(c, bucket_of(c->dmax));
+  *out = c;
+  return 0;
+}
+
+extern "C" void mvae_destroy(mvae_ctx* ctx) { delete ctx; }
+
+extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) {
+  if (!c || !trainable) return fail(MVAE_E_BADARG, "null ctx / trainable%s", "");
+  mvae_component_desc comps[kMaxComp];
+  const int n = c->t.n;
+  for (int i = 0; i < n; ++i) comps[i] = c->t.c[i];
+  return fill_table(&c->t, comps, n, trainable, &c->dmax);
+}
+
+#ifdef MV_DBG_TIMING
+extern "C" int mvae_debug_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
+}
+extern "C" int mvae_debug_read_spans(unsigned long long* out /* [6][3][2048] */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 6 * 3 * 2048);
+}
+#endif
+
+// ---- 1: encoder layer (512 threads).  In the fused single-GPU step, workgroup (0,0) also advances the step counter.
+template <bool FULL>
+__global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
+                                                 int D, int* counters, int bump_step, double lr) {
+  __shared__ float red[kW8][16][17];
+  const int wave = threadIdx.x >> 6;
+  int mt, nt;
+  // Once per step: advance the counters and publish Adam's bias-correction scalars for the gradient epilogues of
+  // launches 4-6 (double-precision pow / divide / sqrt: ~1 us for one lane -- done here by a padding workgroup of
+  // the XCD-aware grid when there is one, so that it is off every critical path).
+  MV_SPAN_BEGIN(0);
+  const bool real = xcd_tile((H + 15) / 16, (B + 15) / 16, &nt, &mt);
+  const bool has_pad = (((H + 15) / 16) & 7) != 0;
+  if (threadIdx.x == 0 && (has_pad ? blockIdx.x == gridDim.x - 1 : blockIdx.x == 0)) {
+    int step = counters[0];
+    if (bump_step) counters[0] = ++step;
+    counters[8] = counters[8] + 1;  // batch cursor of the device-side input pipeline (mvae_prepare_batch)
+    if (bump_step) {
+      const double bc1 = 1.0 - pow_int(0.9, step);
+      const double bc2 = 1.0 - pow_int(0.999, step);
+      reinterpret_cast<float*>(counters)[2] = (float)(-(lr / bc1));
+      reinterpret_cast<float*>(counters)[3] = (float)sqrt(bc2);
+    }
+  }
+  if (!real) return;
+  const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_nt<7, FULL>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
+  const float s = reduce_tiles8(red, acc);
+  if (threadIdx.x < 256) {
+    const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+    if (FULL || (m < B && n < H)) {
+      const float v = s + b[n];
+      h[(size_t)m * H + n] = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+    }
+  }
+  MV_SPAN_END(0, 1);
+}
+
+
+// parts a head row is split into by the generic heads contraction of k_latent_fwd (256 threads = rows x parts)
+__host__ __device__ inline int heads_parts(int NH) {
+  const int p = NH >= 256 ? 1 : 256 / NH;
+  return p > 8 ? 8 : p;
+}
+
+// ---- 2: heads + latent components + first decoder layer; ONE batch row per workgroup.  The phases are short and
+// latency-bound, so rows are spread over as many CUs as possible, every global operand is requested in the first
+// instructions of the kernel (one memory round trip), and the small reductions are wavefront shuffles.
+// FAST: NH <= 16, Z <= 8, H <= 512 (operands of all phases are held in registers from the start).
+template <int DMAX, bool FAST>
+__global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h, const float* Wh, const float* bh,
+                                                    const float* eps, int eps_ld, const float* radii, const float* Wd0,
+                                                    const float* bd0, float* heads, int ldh, float* z, int ldz,
+                                                    float* z_user, float* kl, float* kl_user, float* hd, int B, int H,
+                                                    int NH, int Z, float* duals) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] the row of h, then [eps_dim] the row of eps
+  __shared__ __attribute__((aligned(16))) float heads_s[kHeadsMax];
+  __shared__ __attribute__((aligned(16))) float z_s[kHeadsMax];
+  __shared__ mvae_component_desc desc_s[kMaxComp];  // per-lane indexed below: LDS, not the kernarg segment
+  __shared__ float rad_s[kMaxComp];
+  __shared__ signed char comp_at_s[4][kMaxComp];  // [wave][lane] -> component (or -1)
+  __shared__ int ndir_s[kMaxComp];   // active input directions of component i (radius included iff trainable)
+  __shared__ int first_s[kMaxComp];  // first record of component i inside a row of `duals`
+  __shared__ int done_s;             // main waves that have finished their primal components
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const size_t row = blockIdx.x;
+  float* h_s = dyn;
+  float* eps_s = dyn + ((H + 3) & ~3);
+  const bool vec = aligned16(Wh) && (H & 3) == 0;
+  MV_STAMP(0);
+  MV_SPAN_BEGIN(1);
+
+  // ---- dual waves (threads 256..511, launched iff duals != NULL).  Forward-mode derivatives need no upstream
+  // gradient: d z / d(direction) and d kl / d(direction) of every (component, input direction) of this row depend only
+  // on the head outputs, eps and the radii.  The ~500-instruction dependent dual chain (3.5 us for a lone lane)
+  // therefore runs HERE, on waves 4..7, next to the primal lanes of waves 0..3 (wave 4+w takes the components placed
+  // on wave w), instead of on the critical path of launch 5, which only contracts the stored records with dz.
+  // Record layout: duals[row][first_dir(ci) + dir][{d kl, d z_0 .. d z_{A-1}}].
+  if (tid >= 256) {
+    // as many barriers as the main path executes up to "heads_s final": 2 in the prologue, then 2 (register-resident
+    // path) or 2 per round of the generic heads contraction + 1
+    int nbar = 4;
+    if (!FAST) {
+      const int per = 256 / heads_parts(NH);
+      nbar = 2 + 2 * ((NH + per - 1) / per) + 1;
+    }
+    for (int i = 0; i < nbar; ++i) lds_barrier();
+    const int w = wave - 4;
+    int total = 0;
+    for (int sidx = 0; sidx < kMaxComp; ++sidx) {
+      const int ci = comp_at_s[w][sidx];
+      if (ci < 0) break;
+      total += ndir_s[ci];
+    }
+    constexpr int AM = DMAX + 1, DS = DMAX + 2;
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      if (item < total) {
+        int rem = item, ci = comp_at_s[w][0], sidx = 0;
+        while (rem >= ndir_s[ci]) {
+          rem -= ndir_s[ci];
+          ci = comp_at_s[w][++sidx];
+        }
+        const mvae_component_desc& c = desc_s[ci];
+        float zd[AM];
+        const float kld = comp_dual_dir<DMAX>(c, heads_s, eps_s, rad_s, rem, zd);
+        float* rec = duals + ((size_t)row * (NH + t.n) + first_s[ci] + rem) * DS;
+        const int A = ambient_dim(c.kind, c.true_dim);
+        rec[0] = kld;
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+          if (i < A) rec[1 + i] = zd[i];
+      }
+    }
+    MV_SPAN_END_T(1, 2, 256, 1024);
+    return;  // terminated waves do not count at the remaining barriers
+  }
+
+  // ---- request everything
+  float hv[2] = {0.f, 0.f};
+  float4 wf[4][2];
+  float wd[2][8], bd[2] = {0.f, 0.f};
+  float bhv = 0.f;
+  if (FAST) {
+    // Branch-free requests: an index past the end is clamped to a valid address and the value zeroed afterwards
+    // (every `if (cond) load` costs a lone wave a taken/not-taken branch; ~30 of them made this prologue 2.5 us).
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = tid + 256 * u;
+      const float v = h[row * H + (k < H ? k : 0)];
+      hv[u] = k < H ? v : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = wave + 4 * q;
+      const int nn = n < NH ? n : 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = lane * 4 + 256 * u;
+        const bool ok = n < NH && k < H;
+        float4 v = *reinterpret_cast<const float4*>(Wh + (size_t)nn * H + (k < H ? k : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        wf[q][u] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      const int cc = c < H ? c : 0;
+      bd[u] = bd0[cc];
+      if (Z == 8) {  // wave-uniform: the row of W_d0 is two 16-byte loads
+        const float4 a = *reinterpret_cast<const float4*>(Wd0 + (size_t)cc * 8);
+        const float4 b4 = *reinterpret_cast<const float4*>(Wd0 + (size_t)cc * 8 + 4);
+        wd[u][0] = a.x; wd[u][1] = a.y; wd[u][2] = a.z; wd[u][3] = a.w;
+        wd[u][4] = b4.x; wd[u][5] = b4.y; wd[u][6] = b4.z; wd[u][7] = b4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = Wd0[(size_t)cc * Z + (j < Z ? j : 0)];
+          wd[u][j] = j < Z ? v : 0.f;
+        }
+      }
+    }
+    bhv = bh[tid < NH ? tid : 0];
+  }
+  if (tid < eps_ld) eps_s[tid] = eps[row * eps_ld + tid];
+  comp_at_s[tid >> 6][tid & 63] = -1;
+  if (tid == 0) done_s = 0;
+  lds_barrier();
+  if (tid < t.n) {  // staged last so that its wait does not delay the issue of the loads above
+    desc_s[tid] = t.c[tid];
+    rad_s[tid] = radii[tid];
+    ndir_s[tid] = t.dir_off[tid + 1] - t.dir_off[tid];
+    first_s[tid] = t.first_dir[tid];
+    comp_at_s[t.wave_of[tid]][t.lane_of[tid]] = (signed char)tid;
+  }
+  if (!FAST)
+    for (int k = tid; k < H; k += 256) h_s[k] = h[row * H + k];
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + 256 * u < H) h_s[tid + 256 * u] = hv[u];
+  }
+  lds_barrier();
+  MV_STAMP(1);
+
+  // ---- heads = h W_heads^T + b
+  if (FAST) {
+    float part[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // rows past NH were loaded as zeros: no branch, the four reductions interleave
+      float p = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = lane * 4 + 256 * u;
+        if (k < H) {
+          const float4 xv = *reinterpret_cast<const float4*>(h_s + k);
+          p = fmaf(xv.x, wf[q][u].x, p);
+          p = fmaf(xv.y, wf[q][u].y, p);
+          p = fmaf(xv.z, wf[q][u].z, p);
+          p = fmaf(xv.w, wf[q][u].w, p);
+        }
+      }
+      part[q] = p;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[q] = wave_sum(part[q]);
+    const float mine = lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3];
+    if (lane < 4 && wave + 4 * lane < NH) heads_s[wave + 4 * lane] = mine;
+    lds_barrier();
+    if (tid < NH) {
+      const float v = heads_s[tid] + bhv;
+      heads[row * ldh + tid] = v;
+      heads_s[tid] = v;  // same thread wrote nothing else here; published by the barrier below
+    }
+  } else {
+    // generic: thread (n, part) streams its own stretch of row n of W_heads (all of its loads are independent);
+    // the `P` partial sums of a row meet in LDS (z_s is free until the components write it)
+    const int P = heads_parts(NH), per = 256 / P;
+    for (int n0 = 0; n0 < NH; n0 += per) {
+      const int nl = tid / P, part = tid - nl * P, n = n0 + nl;
+      float p = 0.f;
+      if (nl < per && n < NH) {
+        if (vec) {
+          const int H4 = H >> 2, chunk = (H4 + P - 1) / P;
+          const int k0 = part * chunk, k1 = (k0 + chunk < H4) ? k0 + chunk : H4;
+          const float4* wrow = reinterpret_cast<const float4*>(Wh + (size_t)n * H);
+          const float4* hrow = reinterpret_cast<const float4*>(h_s);
+#pragma unroll 8
+          for (int k = k0; k < k1; ++k) {
+            const float4 wv = wrow[k];
+            const float4 xv = hrow[k];
+            p = fmaf(xv.x, wv.x, p);
+            p = fmaf(xv.y, wv.y, p);
+            p = fmaf(xv.z, wv.z, p);
+            p = fmaf(xv.w, wv.w, p);
+          }
+        } else {
+          const int chunk = (H + P - 1) / P;
+          const int k0 = part * chunk, k1 = (k0 + chunk < H) ? k0 + chunk : H;
+#pragma unroll 8
+          for (int k = k0; k < k1; ++k) p = fmaf(h_s[k], Wh[(size_t)n * H + k], p);
+        }
+      }
+      z_s[tid] = p;
+      lds_barrier();
+      if (tid < per && n0 + tid < NH) {
+        float sum = 0.f;
+        for (int q = 0; q < P; ++q) sum += z_s[tid * P + q];
+        heads_s[n0 + tid] = sum + bh[n0 + tid];
+      }
+      lds_barrier();
+    }
+    if (tid < NH) heads[row * ldh + tid] = heads_s[tid];
+  }
+  lds_barrier();
+  MV_STAMP(2);
+
+  // ---- latent components: one lane per component, placed by fill_table (kinds on different waves)
+  {
+    const int ci = comp_at_s[wave][lane];
+    if (ci >= 0) {
+      float klv;
+      comp_fwd_row<DMAX>(desc_s[ci], heads_s, eps_s, rad_s, z_s, z + row * ldz, &klv, nullptr, nullptr, nullptr,
+                         nullptr);
+      kl[(size_t)ci * B + row] = klv;
+      if (kl_user) kl_user[(size_t)ci * B + row] = klv;
+    }
+  }
+  // The four main waves meet on an LDS counter, not on s_barrier: a hardware barrier would also wait for the dual
+  // waves, which are still in the middle of their (longer) chains.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(&done_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&done_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  MV_STAMP(3);
+  if (z_user && tid < Z) z_user[row * Z + tid] = z_s[tid];
+
+  // ---- first decoder layer: hd = relu(z W_d0^T + b)   (K = Z is tiny)
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < Z) acc = fmaf(z_s[j], wd[u][j], acc);
+        acc += bd[u];
+        hd[row * H + c] = acc < 0.f ? 0.f : acc;
+      }
+    }
+  } else {
+    const bool vz = (Z & 3) == 0 && aligned16(Wd0);
+    for (int c = tid; c < H; c += 256) {
+      const float* w = Wd0 + (size_t)c * Z;
+      float acc = 0.f;
+      if (vz) {
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* z4 = reinterpret_cast<const float4*>(z_s);
+#pragma unroll 4
+        for (int j = 0; j < (Z >> 2); ++j) {
+          const float4 a = w4[j], zz = z4[j];
+          acc = fmaf(zz.x, a.x, acc);
+          acc = fmaf(zz.y, a.y, acc);
+          acc = fmaf(zz.z, a.z, acc);
+          acc = fmaf(zz.w, a.w, acc);
+        }
+      } else {
+#pragma unroll 4
+        for (int j = 0; j < Z; ++j) acc = fmaf(z_s[j], w[j], acc);
+      }
+      acc += bd0[c];
+      hd[row * H + c] = acc < 0.f ? 0.f : acc;
+    }
+  }
+  MV_STAMP(4);
+  MV_SPAN_END(1, 1);
+}
+
+// ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
+template <bool FULL>
+__global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
+                                                  float* g, float* bce_part, float* logits_user, int B, int H, int D) {
+  __shared__ float red[kW8][16][17];
+  const int wave = threadIdx.x >> 6;
+  int mt, nt;
+  MV_SPAN_BEGIN(2);
+  if (!xcd_tile((D + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
+  const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
+  const bool ok = threadIdx.x < 256 && m < B && n < D;
+  float tv = 0.f, bias = 0.f;
+  if (ok) {  // epilogue operands requested up front
+    tv = x[(size_t)m * D + n];
+    bias = b[n];
+  }
+  const bool v1 = aligned16(hd) && (H & 3) == 0, v2 = aligned16(W) && (H & 3) == 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = tile_nt<4, FULL>(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, kW8, v1, v2, acc);
+  const float s = reduce_tiles8(red, acc);
+  if (threadIdx.x >= 256) return;
+  float loss = 0.f;
+  if (ok) {
+    const float y = s + bias;
+    // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
+    const float e = expf(-fabsf(y));
+    const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
+    loss = (1.f - tv) * y - log_sig;
+    const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+    g[(size_t)m * D + n] = sig - tv;  // d(sum bce)/d(logit)
+    if (logits_user) logits_user[(size_t)m * D + n] = y;
+  }
+  // sum over the tile's 16 columns: the 16 lanes of one row are contiguous
+  loss += __shfl_xor(loss, 8, 16);
+  loss += __shfl_xor(loss, 4, 16);
+  loss += __shfl_xor(loss, 2, 16);
+  loss += __shfl_xor(loss, 1, 16);
+  if ((threadIdx.x & 15) == 0 && m < B) bce_part[(size_t)nt * B + m] = loss;
+  MV_SPAN_END(2, 1);
+}
+
+// ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
+template <bool ADAM, bool FULL>
+__global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* hd, const float* W, float* db,
+                                                  float* dhd, const float* bce_part, const float* kl, float* bce_user,
+                                                  float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
+                                                  int n_db, AdamArgs ab) {
+  __shared__ float red[kW8][16][17];
+  int b = blockIdx.x;
+  const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
+  MV_SPAN_BEGIN(3);
+  if (b < n_dhd) {
+    const int mt = b / ntH, nt = b % ntH;
+    const int wave = threadIdx.x >> 6;
+    const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
+    const bool ok = threadIdx.x < 256 && m < B && n < H;
+    float mask = 0.f;
+    if (ok) mask = hd[(size_t)m * H + n];
+    const bool vg = aligned16(g) && (D & 3) == 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_nn<7, FULL>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
+    const float s = reduce_tiles8(red, acc);
+    if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
+    MV_SPAN_END(3, 1);
+    return;
+  }
+  b -= n_dhd;
+  if (b < n_db) {
+    job_colsum_opt<ADAM>(&red[0][0][0], g, D, B, D, b * kColsPerBlock, db, ab);
+    MV_SPAN_END(3, 2);
+    return;
+  }
+  // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo
+  float* sm = &red[0][0][0];  // >= 512 floats
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  float bce_acc = 0.f, elbo_acc = 0.f;
+  for (int r = tid; r < B; r += nthr) {
+    float bce = 0.f;
+    int nt = 0;
+    for (; nt + 7 < ntD; nt += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = bce_part[(size_t)(nt + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bce += v[u];
+    }
+    for (; nt < ntD; ++nt) bce += bce_part[(size_t)nt * B + r];
+    if (bce_user) bce_user[r] = bce;
+    float klr = kl[r];
+    int i = 1;
+    for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) klr += v[u];
+    }
+    for (; i < ncomp; ++i) klr += kl[(size_t)i * B + r];
+    bce_acc += bce;
+    elbo_acc += (-bce - beta * klr);
+  }
+  // block-wide sum: wavefront shuffles, then the (<= 8) wave totals meet in LDS -- two barriers per reduction
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (nthr >> 6); ++w) r += sm[w];
+    __syncthreads();
+    return r;
+  };
+  const float bce_sum = block_sum(bce_acc);
+  const float elbo_sum = block_sum(elbo_acc);
+  const int last = 4 + ncomp;
+  // per-component KL sums: one wave per component (waves take components round-robin), rows summed in lane order
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    for (int i = wave; i < ncomp; i += nw) {
+      float a = 0.f;
+      for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
+      a = wave_sum(a);
+      if (lane == 0) {
+        stats[4 + i] += a;
+        stats[last + 4 + i] = a;
+        sm[16 + i] = a;
+      }
+    }
+  }
+  __syncthreads();
+  float kl_total = 0.f;
+  if (tid == 0) {
+    for (int i = 0; i < ncomp; ++i) kl_total += sm[16 + i];
+    stats[0] += bce_sum;
+    stats[1] += kl_total;
+    stats[2] += elbo_sum;
+    stats[3] += 1.f;
+    stats[last + 0] = bce_sum;
+    stats[last + 1] = kl_total;
+    stats[last + 2] = elbo_sum;
+    stats[last + 3] = 1.f;
+  }
+  MV_SPAN_END(3, 3);
+}
+
+// ---- 5: backward through the first decoder layer, the latent components and the heads (one batch row per
+// workgroup) ; dW_logits = g^T hd (+Adam: W_logits was last read by launch 4)
+template <int DMAX, bool FAST, bool ADAM>  // FAST also implies tile-aligned B, H, D (checked on the host)
+__global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, const float* dhd, const float* Wd0, int ldh,
+                                                    const float* h, const float* Wh, float* dheads, float* dh,
+                                                    float* drpart, const float* g, const float* hd, float* dWl,
+                                                    float beta, int B, int H, int D, int NH, int Z, int n_rows,
+                                                    AdamArgs awl, const float* duals) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [1024] dz partials
+  __shared__ float red[4][16][17];
+  __shared__ float sh2[2];
+  __shared__ float dz_s[kHeadsMax];
+  __shared__ float dheads_s[kHeadsMax];
+  __shared__ mvae_component_desc desc_s[kMaxComp];
+  __shared__ int doff_s[kMaxComp + 1];  // prefix of the ACTIVE input directions (radius included iff trainable)
+  __shared__ int first_s[kMaxComp + 1];  // first record of component i inside a row of `duals`
+  int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MV_SPAN_BEGIN(4);
+  if (b >= n_rows) {  // dW_logits[D,H] tile
+    b -= n_rows;
+    const int ntHg = ((H + 15) / 16 + kTileWaves5 - 1) / kTileWaves5;
+    if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
+    else job_tn_wave<ADAM, false>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
+    MV_SPAN_END(4, 2);
+    return;
+  }
+  if (tid >= 256) return;  // the row path is written for 4 waves
+  const size_t row = b;
+  MV_STAMP(8);
+  const int H4 = (H + 3) & ~3;
+  float* dhd_s = dyn;
+  float* part = dyn + H4;
+
+  // ---- request everything; the row's own operands (written by the previous launch) first: loads retire in order,
+  // so what is needed first must be asked for first
+  int ZP = 1, zsh = 0;  // ZP = next power of two >= Z: the (slice, j) split of the thread index is shifts and masks
+  while (ZP < Z) {
+    ZP <<= 1;
+    ++zsh;
+  }
+  const int nsl = 256 >> zsh;
+  const int zj = tid & (ZP - 1), sl = tid >> zsh;
+  float dhd_r[2] = {0.f, 0.f};  // FAST: H <= 512
+  float wz[16];     // FAST: this thread's W_d0 column slice (H/nsl <= 16 entries)
+  float wh[2][16];  // FAST: W_heads[:, c] for the two columns c of this thread
+  float hm[2] = {0.f, 0.f};
+  // Branch-free requests (an index past the end is clamped to a valid address, the value zeroed afterwards): every
+  // `if (cond) load` costs an exec-mask branch and, worse, lets the compiler put a full `s_waitcnt vmcnt(0)` inside
+  // it -- the guarded version of this prologue spent ~3 us in serialized round trips.  32-bit unsigned offsets keep
+  // the addresses in the scalar-base + vector-offset form.
+  const unsigned rowH = (unsigned)row * (unsigned)H;
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      const float v = dhd[rowH + (unsigned)(c < H ? c : 0)];
+      dhd_r[u] = c < H ? v : 0.f;
+    }
+  }
+  // the component table (kernarg segment, indexed per lane): tiny, but a wait on the LAST load issued is a wait on
+  // every load before it, so it goes ahead of the bulk weight requests
+  const int tci = tid <= t.n ? tid : 0;
+  const mvae_component_desc desc_r = t.c[tci < t.n ? tci : 0];
+  const int doff_r = t.dir_off[tci];
+  const int first_r = t.first_dir[tci < t.n ? tci : 0];
+  __builtin_amdgcn_sched_barrier(0);  // keep the requests above ahead of the bulk below
+  if (FAST) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = sl + q * nsl;
+      const bool ok = zj < Z && c < H;
+      const float v = Wd0[ok ? (unsigned)(c * Z + zj) : 0u];
+      wz[q] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      const unsigned cc = (unsigned)(c < H ? c : 0);
+      const float hv = h[rowH + cc];
+      hm[u] = c < H ? hv : 0.f;
+      // rows n >= NH re-read row 0 and are multiplied by dheads_s[n] = 0 below: selecting on the (uniform) n < NH
+      // here would turn every load into a scalar branch with its own wait
+#pragma unroll
+      for (int n = 0; n < 16; ++n) wh[u][n] = Wh[(unsigned)(n < NH ? n : 0) * (unsigned)H + cc];
+    }
+  }
+  if (tid <= t.n) {
+    if (tid < t.n) desc_s[tid] = desc_r;
+    doff_s[tid] = doff_r;
+    first_s[tid] = first_r;
+  }
+  if (FAST) {
+    if (tid < 16) dheads_s[tid] = 0.f;  // entries [NH, 16) stay zero (see the W_heads requests above)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) dhd_s[c] = dhd_r[u];
+    }
+  } else {
+    for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
+  }
+  // generic 16-byte path of dz: thread (slice s2, column quad j4) owns rows c = s2, s2 + nslv, ... of W_d0; the
+  // first 24 of them are requested here, ahead of the barrier (one round trip instead of one per 4 rows)
+  constexpr int kDzB = 24;
+  const bool dz_vec = !FAST && (Z & 3) == 0 && aligned16(Wd0);
+  const int nj4 = dz_vec ? (Z >> 2) : 1, nslv = 256 / (nj4 > 256 ? 256 : nj4);
+  const int j4 = tid % nj4, s2 = tid / nj4;
+  float4 wzv[kDzB];
+  if (dz_vec) {
+#pragma unroll
+    for (int u = 0; u < kDzB; ++u) {
+      const int c = s2 + u * nslv;
+      wzv[u] = *reinterpret_cast<const float4*>(Wd0 + ((s2 < nslv && c < H) ? (size_t)c * Z + 4 * j4 : 0));
+    }
+  }
+  lds_barrier();
+  MV_STAMP(9);
+
+  // ---- this thread's dual record (written by launch 3): thread k owns the k-th active direction of the row; the
+  // request is in flight while dz is reduced
+  constexpr int DS = DMAX + 2;
+  const int total = doff_s[t.n];
+  const size_t rec0 = (size_t)row * (NH + t.n);
+  float du[DS];
+  int my_ci = 0, my_dir = 0;
+  {  // the first (usually only) item of this thread
+    const int gi = tid < total ? tid : 0;
+    while (gi >= doff_s[my_ci + 1]) ++my_ci;
+    my_dir = gi - doff_s[my_ci];
+    const float* rec = duals + (rec0 + first_s[my_ci] + my_dir) * DS;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) du[i] = rec[i];
+  }
+
+  // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c; wave 3 adds the slices
+  // in slice order
+  {
+    float p = 0.f;
+    if (FAST) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // wz[q] = 0 past the end: no guard
+        const int c = sl + q * nsl;
+        p = fmaf(dhd_s[c < H ? c : 0], wz[q], p);
+      }
+    } else if (zj < Z && !dz_vec) {
+#pragma unroll 4
+      for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
+    }
+    if (FAST) {
+      // ZP <= 8: the slices of one wave are the lanes with equal (lane & (ZP-1)): butterfly over the upper lane bits,
+      // then the four waves' sums meet in LDS (fixed order)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        if (off >= ZP) p += __shfl_xor(p, off);
+      if (lane < ZP) part[wave * ZP + lane] = p;
+      lds_barrier();
+      if (tid < Z) dz_s[tid] = (part[tid] + part[ZP + tid]) + (part[2 * ZP + tid] + part[3 * ZP + tid]);
+    } else if (dz_vec) {
+      if (s2 < nslv && j4 < nj4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kDzB; ++u) {
+          const int c = s2 + u * nslv;
+          const float dv = c < H ? dhd_s[c < H ? c : 0] : 0.f;  // rows past the end were clamped to row 0
+          a.x = fmaf(dv, wzv[u].x, a.x);
+          a.y = fmaf(dv, wzv[u].y, a.y);
+          a.z = fmaf(dv, wzv[u].z, a.z);
+          a.w = fmaf(dv, wzv[u].w, a.w);
+        }
+#pragma unroll 4
+        for (int c = s2 + kDzB * nslv; c < H; c += nslv) {
+          const float4 w = *reinterpret_cast<const float4*>(Wd0 + (size_t)c * Z + 4 * j4);
+          const float dv = dhd_s[c];
+          a.x = fmaf(dv, w.x, a.x);
+          a.y = fmaf(dv, w.y, a.y);
+          a.z = fmaf(dv, w.z, a.z);
+          a.w = fmaf(dv, w.w, a.w);
+        }
+        *reinterpret_cast<float4*>(part + s2 * Z + 4 * j4) = a;  // nslv * Z <= 1024 floats
+      }
+      lds_barrier();
+      for (int j = tid; j < Z; j += 256) {
+        float tot = 0.f;
+        for (int q = 0; q < nslv; ++q) tot += part[q * Z + j];
+        dz_s[j] = tot;
+      }
+    } else {
+      part[tid] = p;
+      lds_barrier();
+      if (wave == 3) {
+        for (int j = lane; j < Z; j += 64) {
+          float tot = 0.f;
+          for (int q = 0; q < nsl; ++q) tot += part[q * ZP + j];
+          dz_s[j] = tot;
+        }
+      }
+    }
+    lds_barrier();
+  }
+  MV_STAMP(10);
+  // ---- d(loss)/d(direction) = beta * d kl + <dz, d z>: one record per (component, input direction)
+  for (int gi = tid; gi < total; gi += 256) {
+    if (gi >= 256) {  // more than 256 active directions: further items are fetched on demand
+      my_ci = 0;
+      while (gi >= doff_s[my_ci + 1]) ++my_ci;
+      my_dir = gi - doff_s[my_ci];
+      const float* rec = duals + (rec0 + first_s[my_ci] + my_dir) * DS;
+#pragma unroll
+      for (int i = 0; i < DS; ++i) du[i] = rec[i];
+    }
+    const mvae_component_desc& c = desc_s[my_ci];
+    const int A = ambient_dim(c.kind, c.true_dim);
+    float gv = beta * du[0];
+#pragma unroll
+    for (int i = 0; i < DMAX + 1; ++i)
+      if (i < A) gv += dz_s[c.z_col + i] * du[1 + i];
+    if (my_dir < c.true_dim) dheads_s[c.mean_col + my_dir] = gv;
+    else if (my_dir < c.true_dim + c.logvar_dim) dheads_s[c.logvar_col + (my_dir - c.true_dim)] = gv;
+    else drpart[(size_t)my_ci * B + row] = gv;
+  }
+  lds_barrier();
+  MV_STAMP(11);
+  if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
+  // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
+  if (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < H) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc = fmaf(dheads_s[n], wh[u][n], acc);
+        dh[row * H + c] = (hm[u] > 0.f) ? acc : 0.f;
+      }
+    }
+  } else if ((H & 3) == 0 && H <= 1024 && aligned16(Wh) && aligned16(h) && aligned16(dh)) {
+    // thread (column quad c4, row group ng): rows n = ng, ng + G, ... of W_heads as 16-byte loads, 20 in flight;
+    // the G partial sums of a quad meet in LDS and are added in group order
+    const int nq = H >> 2, G = (256 / nq) < 1 ? 1 : ((256 / nq) > 8 ? 8 : 256 / nq);
+    const int c4 = tid % nq, ng = tid / nq;
+    const bool act = ng < G;
+    float4 hmv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < nq) hmv = *reinterpret_cast<const float4*>(h + row * H + 4 * tid);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nb = ng; nb < NH; nb += 20 * G) {
+      float4 w[20];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) {
+        const int n = nb + u * G;
+        w[u] = *reinterpret_cast<const float4*>(Wh + ((act && n < NH) ? (size_t)n * H + 4 * c4 : 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 20; ++u) {
+        const int n = nb + u * G;
+        const float dv = (act && n < NH) ? dheads_s[n < NH ? n : 0] : 0.f;
+        a.x = fmaf(dv, w[u].x, a.x);
+        a.y = fmaf(dv, w[u].y, a.y);
+        a.z = fmaf(dv, w[u].z, a.z);
+        a.w = fmaf(dv, w[u].w, a.w);
+      }
+    }
+    if (act) *reinterpret_cast<float4*>(part + ((size_t)ng * nq + c4) * 4) = a;  // G * H <= 1024 floats ... see below
+    lds_barrier();
+    if (tid < nq) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < G; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)q * nq + tid) * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+      }
+      tot.x = hmv.x > 0.f ? tot.x : 0.f;
+      tot.y = hmv.y > 0.f ? tot.y : 0.f;
+      tot.z = hmv.z > 0.f ? tot.z : 0.f;
+      tot.w = hmv.w > 0.f ? tot.w : 0.f;
+      *reinterpret_cast<float4*>(dh + row * H + 4 * tid) = tot;
+    }
+  } else {
+    for (int c = tid; c < H; c += 256) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < NH; ++n) acc = fmaf(dheads_s[n], Wh[(size_t)n * H + c], acc);
+      const size_t o = row * H + c;
+      dh[o] = (h[o] > 0.f) ? acc : 0.f;
+    }
+  }
+  MV_STAMP(12);
+  MV_SPAN_END(4, 1);
+}
+
+// ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
+template <bool ADAM, bool FULL>
+__global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
+                                                 int ldh, const float* h, const float* dhd, const float* z, int ldz,
+                                                 const float* drpart, float* G, float* P, int B, int H, int D, int NH,
+                                                 int Z, int n_we0, int n_wh, int n_wd0, int n_be0, int n_bh, int n_bd0,
+                                                 int64_t off_w_e0, int64_t off_b_e0, int64_t off_w_heads,
+                                                 int64_t off_b_heads, int64_t off_w_d0, int64_t off_b_d0, AdamArgs base,
+                                                 double curv_lr, int do_curv) {
+  __shared__ float red[4][16][17];
+  __shared__ float sh2[2];
+  int b = blockIdx.x;
+  MV_SPAN_BEGIN(5);
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
+  // Workgroup order: the short jobs first, the 250 dW_e0 tile workgroups last.  The grid has ~80 more workgroups than
+  // the chip has CUs, so the last ones dispatched share a CU with the first ones: sharing with a short job costs a tile
+  // workgroup little, sharing with another tile workgroup (or a short job sharing with one) was the kernel's tail.
+  if (b == 0) {
+    // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
+    // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* gsh = &red[0][0][0];  // per-component batch sums
+    if (tid < kRadiiRegion) {
+      G[tid] = 0.f;
+      gsh[tid] = 0.f;
+    }
+    __syncthreads();
+    for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
+      if (!t.trainable[ci]) continue;
+      float s = 0.f;
+      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
+      s = wave_sum(s);
+      if (lane == 0) gsh[ci] = s;
+    }
+    __syncthreads();
+    if (tid < t.n && t.trainable[tid]) {
+      float s = gsh[tid];
+      if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
+      G[tid] = s;
+      if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
+    }
+    MV_SPAN_END(5, 7);
+    return;
+  }
+  b -= 1;
+  if (b < n_bd0) {
+    job_colsum_opt<ADAM>(&red[0][0][0], dhd, H, B, H, b * kColsPerBlock, G + off_b_d0, at(off_b_d0));
+    MV_SPAN_END(5, 6);
+    return;
+  }
+  b -= n_bd0;
+  if (b < n_be0) {
+    job_colsum_opt<ADAM>(&red[0][0][0], dh, H, B, H, b * kColsPerBlock, G + off_b_e0, at(off_b_e0));
+    MV_SPAN_END(5, 4);
+    return;
+  }
+  b -= n_be0;
+  if (b < n_bh) {
+    job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, b * kColsPerBlock, G + off_b_heads, at(off_b_heads));
+    MV_SPAN_END(5, 5);
+    return;
+  }
+  b -= n_bh;
+  if (b < n_wd0) {  // dW_d0[H,Z] = dhd^T z
+    const int ntZg = ((Z + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dhd, H, H, b / ntZg, z, ldz, Z, (b % ntZg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_d0, Z,
+                      at(off_w_d0));
+    MV_SPAN_END(5, 3);
+    return;
+  }
+  b -= n_wd0;
+  if (b < n_wh) {  // dW_heads[NH,H] = dheads^T h
+    const int ntHg = ((H + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM>(dheads, ldh, NH, b / ntHg, h, H, H, (b % ntHg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_heads, H,
+                      at(off_w_heads));
+    MV_SPAN_END(5, 2);
+    return;
+  }
+  b -= n_wh;
+  {  // dW_e0[H,D] = dh^T x
+    const int ntDg = ((D + 15) / 16 + kTileWaves - 1) / kTileWaves;
+    job_tn_wave<ADAM, FULL>(dh, H, H, b / ntDg, x, D, D, (b % ntDg) * kTileWaves + (threadIdx.x >> 6), B, G + off_w_e0, D,
+                            at(off_w_e0));
+    MV_SPAN_END(5, 1);
+  }
+}
+
+// ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
+__global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, float* m, float* v, int n4,
+                                               int* counters, double lr, double curv_lr, int do_curv) {
+  __shared__ float sh[2];
+  __shared__ float gsh[kMaxComp];
+  const int tid = threadIdx.x;
+  adam_consts(sh, counters, lr, 1);
+  if (blockIdx.x == 0 && tid < t.n) gsh[tid] = g[tid];
+  __syncthreads();
+  const float neg_step = sh[0], bc2s = sh[1];
+  const int i4 = blockIdx.x * 256 + tid + kRadiiRegion / 4;
+  if (i4 < n4) {
+    float4 pp = reinterpret_cast<float4*>(p)[i4];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i4];
+    float4 mm = reinterpret_cast<float4*>(m)[i4];
+    float4 vv = reinterpret_cast<float4*>(v)[i4];
+    adam1(pp.x, gg.x, mm.x, vv.x, neg_step, bc2s);
+    adam1(pp.y, gg.y, mm.y, vv.y, neg_step, bc2s);
+    adam1(pp.z, gg.z, mm.z, vv.z, neg_step, bc2s);
+    adam1(pp.w, gg.w, mm.w, vv.w, neg_step, bc2s);
+    // write-through, as in the tile epilogues: 7.6 MB that nobody in this launch reads again
+    store16_wt(p, (size_t)i4 * 4, f32x4{pp.x, pp.y, pp.z, pp.w});
+    store16_wt(m, (size_t)i4 * 4, f32x4{mm.x, mm.y, mm.z, mm.w});
+    store16_wt(v, (size_t)i4 * 4, f32x4{vv.x, vv.y, vv.z, vv.w});
+  }
+  if (blockIdx.x == 0 && tid < t.n && t.trainable[tid]) {
+    float gv = gsh[tid];
+    if (t.trainable[tid] & 2) {  // universal curvature: clipped (after the all-reduce), written back like .grad
+      gv *= clip_coef(t, gsh);
+      g[tid] = gv;
+    }
+    if (do_curv) p[tid] = p[tid] + (float)(-curv_lr) * gv;  // SGD: param.add_(grad, alpha=-lr)
+  }
+  // The last workgroup to arrive advances the step counter.  Every other workgroup consumed counters[0] before its
+  // own arrival (the value fed the __syncthreads above), so no fence is needed: the plain stores below only have to
+  // be visible to the NEXT launch.  Arrivals are counted on 16 group words (counters[16..31]) first (one hot word
+  // would serialise ~600 device-scope atomics at ~12 ns each); the group-completing workgroups meet on counters[1].
+  if (tid == 0) {
+    constexpr int NG = 16;
+    const int grp = blockIdx.x % NG;
+    const int gsize = ((int)gridDim.x - grp + NG - 1) / NG;
+    if (atomicAdd(&counters[16 + grp], 1) == gsize - 1) {
+      counters[16 + grp] = 0;
+      const int ngroups = (int)gridDim.x < NG ? (int)gridDim.x : NG;
+      if (atomicAdd(&counters[1], 1) == ngroups - 1) {
+        counters[1] = 0;
+        counters[0] = counters[0] + 1;
+      }
+    }
+  }
+}
+
+// fused = single-GPU step (Adam/SGD in the gradient epilogues, no k_optim); otherwise gradients only.
+static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
+                     int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
+                     hipEvent_t* ev) {
+  int ki = 0;  // launch index; with `ev` != NULL launch k is bracketed by ev[2k] (start) / ev[2k+1] (stop)
+#define STEP_LAUNCH(KERN, GRID, BLOCK, LDS, ...)                                                              \
+  do {                                                                                                         \
+    if (ev) hipExtLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, ev[2 * ki], ev[2 * ki + 1], 0, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, __VA_ARGS__);                                          \
+    ++ki;                                                                                                      \
+  } while (0)
+  if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const mvae_model_desc& d = c->d;
+  const int B = d.batch, H = d.h_dim, D = d.in_dim, NH = d.heads_dim, Z = d.z_dim;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = d.workspace;
+  float *h = ws + c->o_h, *heads = ws + c->o_heads, *z = ws + c->o_z, *hd = ws + c->o_hd, *g = ws + c->o_g,
+        *bce_part = ws + c->o_bce_part, *klw = ws + c->o_kl, *dhd = ws + c->o_dhd, *dheads = ws + c->o_dheads,
+        *dh = ws + c->o_dh, *drpart = ws + c->o_drpart, *duals = ws + c->o_duals;
+  float* P = d.params;
+  float* G = d.grads;
+  if (!want_outputs) logits = concat_z = bce = kl = nullptr;
+  const AdamArgs base = {d.params, d.adam_m, d.adam_v, d.step_count, d.lr};
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
+  // register-resident fast paths of the latent kernels (the BASELINE MLP configs with few components qualify)
+  const bool fast = NH <= 16 && Z <= 8 && H <= 512 && (H & 3) == 0 && aligned16(P + d.off_w_heads);
+  int zp = 1;
+  while (zp < Z) zp <<= 1;
+  const bool fast_b = fast && (H + 256 / zp - 1) / (256 / zp) <= 16 && (B % 16 == 0) && (H % 16 == 0) &&
+                      (D % 16 == 0);
+
+  // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
+  const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
+                    aligned16(P + d.off_w_logits) && aligned16(ws);
+  if (full)
+    STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
+  else
+    STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
+  {
+    const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
+#define LF(DM, FA)                                                                                                   \
+  STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(512), lds, c->t, h, P + d.off_w_heads,                 \
+                     P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
+                     c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z, duals)
+    if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
+#undef LF
+  }
+  if (full)
+    STEP_LAUNCH(k_dec1_fwd<true>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+                P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
+  else
+    STEP_LAUNCH(k_dec1_fwd<false>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+                P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
+  {
+    const int n_dhd = c->nt_b * c->nt_h, n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
+#define DB(AD, FU)                                                                                             \
+  STEP_LAUNCH((k_dec1_bwd<AD, FU>), dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,               \
+              G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
+              at(d.off_b_logits))
+    if (fused) { if (full) DB(true, true); else DB(true, false); }
+    else { if (full) DB(false, true); else DB(false, false); }
+#undef DB
+  }
+  {
+    const int n_dwl = c->nt_d * ((c->nt_h + kTileWaves5 - 1) / kTileWaves5);
+    const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 1024 + 8) * sizeof(float);  // dhd row | dz partials
+#define LB(DM, FA, AD)                                                                                              \
+  STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
+                     c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
+                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
+    if (fast_b) {
+      if (fused) { DMAX_SWITCH(c->dmax, LB(DM, true, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, true, false)); }
+    } else {
+      if (fused) { DMAX_SWITCH(c->dmax, LB(DM, false, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, false, false)); }
+    }
+#undef LB
+  }
+  {
+    const int tw = kTileWaves;
+    const int n_we0 = c->nt_h * ((c->nt_d + tw - 1) / tw), n_wh = ((NH + 15) / 16) * ((c->nt_h + tw - 1) / tw),
+              n_wd0 = c->nt_h * (((Z + 15) / 16 + tw - 1) / tw);
+    const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
+              n_bd0 = n_be0;
+    const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
+#define EB(AD, FU)                                                                                                   \
+  STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(64 * kTileWaves), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz, \
+                     drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
+                     d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+    if (fused) { if (full) EB(true, true); else EB(true, false); }
+    else { if (full) EB(false, true); else EB(false, false); }
+#undef EB
+  }
+#undef STEP_LAUNCH
+  LAUNCH_CHECK("step launch");
+  return 0;
+}
+
+extern "C" int mvae_step_forward_backward(mvae_ctx* c, const float* x, const float* eps, float beta, int want_outputs,
+                                          float* logits, float* concat_z, float* bce, float* kl, void* stream) {
+  return step_impl(c, x, eps, beta, false, 0, want_outputs, logits, concat_z, bce, kl, stream, nullptr);
+}
+
+extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* stream) {
+  if (!c) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const mvae_model_desc& d = c->d;
+  const int n4 = d.n_params / 4;
+  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_optim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
+                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step);
+  LAUNCH_CHECK("optimizer launch");
+  return 0;
+}
+
+extern "C" int mvae_train_step(mvae_ctx* c, const float* x, const float* eps, float beta, int do_curvature_step,
+                               void* stream) {
+  return step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
+}
+
+extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, float beta, int do_curvature_step,
+                                 int iters, float* ms_out, void* stream) {
+  if (!c || !x || !eps || !ms_out || iters < 1) return fail(MVAE_E_BADARG, "null pointer / iters < 1%s", "");
+  constexpr int NK = MVAE_STEP_KERNELS;
+  hipEvent_t ev[2 * NK];
+  for (auto& e : ev) {
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return hip_fail(rc, "hipEventCreate");
+  }
+  double acc[NK] = {0};
+  int rc = 0;
+  for (int it = 0; it < iters && rc == 0; ++it) {
+    // every launch carries its own start/stop event (hipExtLaunchKernelGGL): the difference is the execution time
+    // of that dispatch alone, the quantity rocprofv3 --kernel-trace reports
+    rc = step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, ev);
+    if (rc) break;
+    hipError_t e = hipEventSynchronize(ev[2 * NK - 1]);
+    if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
+    for (int k = 0; k < NK; ++k) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
+      acc[k] += ms;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  for (int k = 0; k < NK; ++k) ms_out[k] = (float)(acc[k] / iters);
+  return 0;
+}
+
+// Adam over a flat parameter buffer whose first 64 floats are the raw radii (SGD on the trainable ones): the optimizer
+// of any architecture laid out like StepEngine's buffers (used by the conv path).
+extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* adam_v,
+                                        int64_t n_params, int32_t* counters, int ncomp,
+                                        const uint8_t* radius_trainable, double lr, double curvature_lr,
+                                        int do_curvature_step, void* stream) {
+  if (!params || !grads || !adam_m || !adam_v || !counters || n_params < kRadiiRegion || (n_params & 3) ||
+      ncomp < 0 || ncomp > kMaxComp)
+    return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
+  CompTable t;
+  memset(&t, 0, sizeof(t));
+  t.n = ncomp;
+  for (int i = 0; i < ncomp; ++i) t.trainable[i] = radius_trainable ? radius_trainable[i] : 0;
+  const int n4 = (int)(n_params / 4);
+  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_optim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v, n4,
+                     counters, lr, curvature_lr, do_curvature_step);
+  LAUNCH_CHECK("flat optimizer launch");
+  return 0;
+}

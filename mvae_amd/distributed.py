@@ -40,6 +40,34 @@ def init_from_env() -> Tuple[int, int, int]:
     return rank, world, local_rank
 
 
+_agree_seq = 0
+
+
+def agree_any(flag: bool, group: Optional[dist.ProcessGroup] = None, tag: str = "") -> bool:
+    """True on EVERY rank iff `flag` is true on ANY rank.  Goes through the rendezvous store (host side, no device
+    work), so it is usable right after a failed stream capture, when HIP may refuse further launches.  Every rank must
+    call it the same number of times in the same order.  Without a process group it returns `flag`."""
+    global _agree_seq
+    if not dist.is_initialized():
+        return bool(flag)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return bool(flag)
+    import time
+    store = dist.distributed_c10d._get_default_store()
+    ranks = ",".join(str(r) for r in dist.get_process_group_ranks(group)) if group is not None else "world"
+    _agree_seq += 1
+    key = f"mvae_amd/agree/{ranks}/{tag}/{_agree_seq}"
+    store.add(key + "/flag", 1 if flag else 0)
+    store.add(key + "/arrived", 1)
+    deadline = time.monotonic() + 600.0
+    while store.add(key + "/arrived", 0) < world:
+        if time.monotonic() > deadline:
+            raise RuntimeError(f"agree_any timed out waiting for the other ranks ({key}, rank {rank})")
+        time.sleep(0.002)
+    return store.add(key + "/flag", 0) > 0
+
+
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) of the rows owned by `rank` (earlier ranks take the remainder)."""
     base, rem = divmod(n_rows, world)

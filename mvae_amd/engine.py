@@ -91,6 +91,8 @@ class StepEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.MvaeHipError("StepEngine needs a HIP device: the product path has no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.layout = ComponentLayout(comps, scalar_parametrization)
         self.flat = FlatLayout(self.layout, in_dim, h_dim, scalar_parametrization)
         self.in_dim, self.h_dim = in_dim, h_dim
@@ -104,6 +106,10 @@ class StepEngine:
         self.counters = z(32, torch.int32)
         self.stats = z(2 * (4 + n))
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
+        self._last_batch: Optional[int] = None
+        # bumped whenever the contexts (workspace pointers, lr baked into kernel arguments) are rebuilt: anything that
+        # captured launches of this engine into a HIP graph must re-capture when it changes
+        self.generation = 0
         self._trainable_arr = (C.c_uint8 * n)(*[1 if t else 0 for t in self.radius_trainable])
 
     def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
@@ -158,6 +164,8 @@ class StepEngine:
         for h, _ in self._ctx.values():
             load().mvae_destroy(h)
         self._ctx.clear()
+        self._last_batch = None
+        self.generation += 1
 
     def __del__(self):
         try:
@@ -208,6 +216,7 @@ class StepEngine:
         """forward -> ELBO -> backward.  Fills self.grads with d(-ELBO)/d(theta); adds to self.stats."""
         B = self._check_inputs(x, eps)
         ctx = self._context(B)
+        self._last_batch = B
         out = None
         lo = cz = bce = kl = None
         if want_outputs:
@@ -221,11 +230,17 @@ class StepEngine:
         return out
 
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
-        ctx = self._context(batch if batch is not None else next(iter(self._ctx)))
+        """The optimizer kernel is independent of the batch size; `batch` only selects which context's component table
+        travels with the launch (default: the batch size of the last forward_backward, else any existing context, else
+        a context for batch 1 is created)."""
+        if batch is None:
+            batch = self._last_batch if self._last_batch is not None else (next(iter(self._ctx)) if self._ctx else 1)
+        ctx = self._context(batch)
         check(load().mvae_step_optimizer(ctx, 1 if do_curvature_step else 0, stream_ptr(self.device)))
 
     def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
         B = self._check_inputs(x, eps)
+        self._last_batch = B
         check(load().mvae_train_step(self._context(B), ptr(x), ptr(eps), float(beta),
                                      1 if do_curvature_step else 0, stream_ptr(self.device)))
 

@@ -29,126 +29,325 @@ def _f32c(t: Tensor) -> Tensor:
     return t.contiguous()
 
 
-def _radius_arg(kind: int, radius: Optional[Tensor], like: Tensor) -> Optional[Tensor]:
+def colsum(G: Tensor) -> Tensor:
+    """out[N] = column sums of G[M, N], fixed summation order (mvae_colsum)."""
+    G = _f32c(G)
+    M, N = G.shape
+    out = G.new_empty(N)
+    nws = int(load().mvae_colsum_workspace_floats(M, N))
+    ws = G.new_empty(max(nws, 1)) if nws > 0 else None
+    check(load().mvae_colsum(ptr(G), ptr(out), M, N, ptr(ws), stream_ptr(G.device)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------- primitives
+# Every manifold primitive is one forward kernel (mvae_<name>) and one backward kernel (mvae_primitive_backward, which
+# evaluates the same device template over dual numbers, so the reference's custom derivative rules -- LeakyClamp, Acosh,
+# hard clamps, norm'(0) = 0 -- are the ones torch.autograd sees).  `_Prim` is the torch.autograd.Function joining them;
+# it is only entered when an input requires grad.
+_FWD = {
+    _lib.OP_EXP0: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_exp_map_mu0(k, a, o1, rows, d, r, st),
+    _lib.OP_LOG0: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_inverse_exp_map_mu0(k, a, o1, rows, d, r, st),
+    _lib.OP_PT0: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_parallel_transport_mu0(k, a, b, o1, rows, d, r,
+                                                                                                  st),
+    _lib.OP_IPT0: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_inverse_parallel_transport_mu0(
+        k, a, b, o1, rows, d, r, st),
+    _lib.OP_SAMPLE: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_sample_projection_mu0(
+        k, a, b, o1, o2, rows, atr, d, r, st),
+    _lib.OP_ISAMPLE: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_inverse_sample_projection_mu0(
+        k, a, b, o1, o2, rows, atr, d, r, st),
+    _lib.OP_LOGDET: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_logdet(k, a, b, c, o1, rows, atr, d, r, st),
+    _lib.OP_EXP: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_exp_map(k, a, b, o1, rows, atr, d, r, st),
+    _lib.OP_LOG: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_inverse_exp_map(k, a, b, o1, rows, atr, d, r,
+                                                                                           st),
+    _lib.OP_DIST: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_geodesic_distance(
+        k, _lib.DIST_GEODESIC, a, b, o1, rows, atr, d, r, st),
+    _lib.OP_DIST_GYRO: lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_geodesic_distance(
+        k, _lib.DIST_GYRO, a, b, o1, rows, atr, d, r, st),
+}
+for _op in (_lib.OP_NORMAL_LOGPROB, _lib.OP_NORMAL_RSAMPLE, _lib.OP_NORMAL_KL):
+    _FWD[_op] = (lambda op_: (lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_normal_op(
+        op_, a, b, c, o1, rows, atr, d, st)))(_op)
+for _op in (_lib.OP_LPROD, _lib.OP_LNORM, _lib.OP_TO_BALL, _lib.OP_TO_AMBIENT, _lib.OP_LAMBDA, _lib.OP_MOBADD):
+    _FWD[_op] = (lambda op_: (lambda L, k, a, b, c, o1, o2, rows, atr, d, r, st: L.mvae_manifold_aux(
+        op_, k, a, b, o1, rows, d, r, st)))(_op)
+
+
+_NORMAL_OPS = (_lib.OP_NORMAL_LOGPROB, _lib.OP_NORMAL_RSAMPLE, _lib.OP_NORMAL_KL)
+
+
+def _prim_shape(op: int, kind: int, d: int) -> Tuple[int, int, int, int, int]:
+    """(na, nb, nc, n1, n2): host mirror of prim_shape() in csrc/mvae_api.hip."""
+    A = ambient_dim(kind, d)
+    proj = kind in _PROJECTED
+    if op == _lib.OP_EXP0:
+        return d, 0, 0, A, 0
+    if op == _lib.OP_LOG0:
+        return A, 0, 0, A, 0
+    if op in (_lib.OP_PT0, _lib.OP_IPT0, _lib.OP_EXP, _lib.OP_LOG, _lib.OP_MOBADD):
+        return A, A, 0, A, 0
+    if op in (_lib.OP_LNORM, _lib.OP_LAMBDA):
+        return A, 0, 0, 1, 0
+    if op == _lib.OP_TO_BALL:
+        return A, 0, 0, d, 0
+    if op == _lib.OP_TO_AMBIENT:
+        return d, 0, 0, d + 1, 0
+    if op == _lib.OP_NORMAL_LOGPROB:
+        return d, d, d, 1, 0
+    if op == _lib.OP_NORMAL_RSAMPLE:
+        return d, d, d, d, 0
+    if op == _lib.OP_NORMAL_KL:
+        return d, 0, d, 1, 0
+    if op == _lib.OP_SAMPLE:
+        return d, A, 0, A, A
+    if op == _lib.OP_ISAMPLE:
+        return A, A, 0, A, d
+    if op == _lib.OP_LOGDET:
+        return (0, A, A, 1, 0) if proj else ((0, 0, 0, 1, 0) if kind == _lib.EUCLIDEAN else (A, 0, 0, 1, 0))
+    return A, A, 0, 1, 0
+
+
+def _launch_fwd(op, kind, a, b, c3, rp, rows, at_rows, d, n1, n2, like):
+    o1 = like.new_empty(rows, n1)
+    o2 = like.new_empty(rows, n2) if n2 else None
+    check(_FWD[op](load(), kind, ptr(a), ptr(b), ptr(c3), ptr(o1), ptr(o2), rows, at_rows, d, ptr(rp),
+                   stream_ptr(like.device)))
+    return o1, o2
+
+
+class _Prim(torch.autograd.Function):
+    """inputs a[rows, na], b[at_rows, nb], c3[rows, nc] (2-D, contiguous, or None) and the radius / curvature
+    parameter rp[1] (or None) -> o1[rows, n1], o2[rows, n2] (or None)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c3, rp, op, kind, d, rows, at_rows):
+        na, nb, nc, n1, n2 = _prim_shape(op, kind, d)
+        like = a if a is not None else b
+        o1, o2 = _launch_fwd(op, kind, a, b, c3, rp, rows, at_rows, d, n1, n2, like)
+        ctx.save_for_backward(a, b, c3, rp)
+        ctx.meta = (op, kind, d, rows, at_rows)
+        if o2 is None:
+            o2 = like.new_empty(0)
+            ctx.mark_non_differentiable(o2)
+        return o1, o2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, b, c3, rp = ctx.saved_tensors
+        op, kind, d, rows, at_rows = ctx.meta
+        na, nb, nc, n1, n2 = _prim_shape(op, kind, d)
+        like = a if a is not None else b
+        g1 = like.new_zeros(rows, n1) if g1 is None else _f32c(g1)
+        g2 = None if (n2 == 0 or g2 is None) else _f32c(g2)
+        need = ctx.needs_input_grad
+        ga = like.new_zeros(rows, na) if (need[0] and na) else None
+        gb = like.new_zeros(rows, nb) if (need[1] and nb) else None
+        gc = like.new_zeros(rows, nc) if (need[2] and nc) else None
+        gr = like.new_zeros(rows, 1) if (need[3] and rp is not None) else None
+        check(load().mvae_primitive_backward(op, kind, ptr(a), ptr(b), ptr(c3), ptr(g1), ptr(g2), ptr(ga), ptr(gb),
+                                             ptr(gc), ptr(gr), rows, at_rows, d, ptr(rp), stream_ptr(like.device)))
+        if gb is not None and at_rows < rows:  # b was broadcast over leading sample dims: sum them (index order)
+            gb = colsum(gb.view(rows // at_rows, at_rows * nb)).view(at_rows, nb)
+        if gc is not None and at_rows < rows and op in _NORMAL_OPS:  # the normal ops broadcast c3 as well
+            gc = colsum(gc.view(rows // at_rows, at_rows * nc)).view(at_rows, nc)
+        if gr is not None:
+            gr = colsum(gr)
+        return ga, gb, gc, gr, None, None, None, None, None
+
+
+def _radius_param(kind: int, radius, like: Tensor) -> Optional[Tensor]:
+    """The radius (or, for `u`, curvature) as a 1-element float32 device tensor that keeps its autograd history."""
     if kind == _lib.EUCLIDEAN:
         return None
     if radius is None:
         raise _lib.MvaeHipError("this manifold needs a radius")
     if not torch.is_tensor(radius):
         radius = torch.tensor(float(radius), dtype=torch.float32, device=like.device)
-    return _f32c(radius.detach().reshape(1).to(like.device))
+    if radius.dtype != torch.float32:
+        raise _lib.MvaeHipError(f"the HIP path computes in float32, got a {radius.dtype} radius")
+    if radius.numel() != 1:
+        raise _lib.MvaeHipError("one radius per call: per-row radii are not supported")
+    return radius.to(like.device).reshape(1).contiguous()
 
 
-def _no_grad_inputs(*ts) -> None:
-    """The radius is exempt: it is the live nn.Parameter by construction (RadiusManifold takes a callable returning
-    it), while a tensor argument that requires grad means the caller expects autograd to flow through."""
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts):
-        raise NotImplementedError(
-            "the standalone manifold primitives are forward-only; differentiable paths go through the fused "
-            "component / step operators (Component.forward, ModelVAE.train_step)")
+def _rows2d(t: Optional[Tensor], n: int) -> Optional[Tensor]:
+    return None if t is None else _f32c(t).reshape(-1, n)
 
 
-# --------------------------------------------------------------------------------------------- primitives
-def exp_map_mu0(kind: int, x: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(x)
-    x = _f32c(x)
-    d = x.shape[-1]
-    out = x.new_empty(x.shape[:-1] + (ambient_dim(kind, d),))
-    r = _radius_arg(kind, radius, x)
-    check(load().mvae_exp_map_mu0(kind, ptr(x), ptr(out), x.numel() // d, d, ptr(r), stream_ptr(x.device)))
-    return out
+def _prim(op: int, kind: int, d: int, lead, a, b, c3, radius):
+    """Runs primitive `op`.  a / c3 have leading dims `lead`; b's leading dims are `lead` or a suffix of them
+    (broadcast over the missing sample dims).  Returns (o1, o2) shaped lead + (n,)."""
+    na, nb, nc, n1, n2 = _prim_shape(op, kind, d)
+    like = a if a is not None else c3
+    rows = 1
+    for s_ in lead:
+        rows *= int(s_)
+    a2 = _rows2d(a, na) if na else None
+    b2, at_rows = None, rows
+
+    def bcast(t, n):  # leading dims `lead`, or a suffix of them (broadcast over the missing sample dims)
+        t = _f32c(t)
+        tl = tuple(t.shape[:-1])
+        if tl != tuple(lead) and not (len(tl) <= len(lead) and tuple(lead[len(lead) - len(tl):]) == tl):
+            t = t.expand(tuple(lead) + (n,)).contiguous()
+        return t.reshape(-1, n)
+
+    if nb:
+        b2 = bcast(b, nb)
+        at_rows = max(1, b2.shape[0])
+    if nc and op in _NORMAL_OPS:
+        if nb:
+            c3 = torch.broadcast_to(c3, b.shape[:-1] + (nc,)) if tuple(c3.shape[:-1]) != tuple(b.shape[:-1]) else c3
+        c2 = bcast(c3, nc)
+        if nb and c2.shape[0] != at_rows:
+            raise ValueError("loc and scale must have the same leading dims")
+        if not nb:
+            at_rows = max(1, c2.shape[0])
+    else:
+        c2 = _rows2d(c3, nc) if nc else None
+    rp = _radius_param(kind, radius, like)
+    if rows == 0:
+        return like.new_empty(tuple(lead) + (n1,)), (like.new_empty(tuple(lead) + (n2,)) if n2 else None)
+    tensors = (a2, b2, c2, rp)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        o1, o2 = _Prim.apply(a2, b2, c2, rp, op, kind, d, rows, at_rows)
+    else:
+        det = [None if t is None else t.detach() for t in tensors]
+        o1, o2 = _launch_fwd(op, kind, det[0], det[1], det[2], det[3], rows, at_rows, d, n1, n2,
+                             det[0] if det[0] is not None else det[1])
+    o1 = o1.view(tuple(lead) + (n1,))
+    o2 = o2.view(tuple(lead) + (n2,)) if n2 else None
+    return o1, o2
 
 
 def _true_dim(kind: int, ambient: int) -> int:
     return ambient - 1 if kind in (_lib.HYPERBOLOID, _lib.SPHERE) else ambient
 
 
-def inverse_exp_map_mu0(kind: int, x: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(x)
-    x = _f32c(x)
-    A = x.shape[-1]
-    out = torch.empty_like(x)
-    r = _radius_arg(kind, radius, x)
-    check(load().mvae_inverse_exp_map_mu0(kind, ptr(x), ptr(out), x.numel() // A, _true_dim(kind, A), ptr(r),
-                                          stream_ptr(x.device)))
-    return out
+def exp_map_mu0(kind: int, x: Tensor, radius=None) -> Tensor:
+    return _prim(_lib.OP_EXP0, kind, x.shape[-1], x.shape[:-1], x, None, None, radius)[0]
 
 
-def _pt(fn_name: str, kind: int, x: Tensor, other: Tensor, radius: Optional[Tensor]) -> Tensor:
-    _no_grad_inputs(x, other)
+def inverse_exp_map_mu0(kind: int, x: Tensor, radius=None) -> Tensor:
+    return _prim(_lib.OP_LOG0, kind, _true_dim(kind, x.shape[-1]), x.shape[:-1], x, None, None, radius)[0]
+
+
+def _two(op: int, kind: int, x: Tensor, other: Tensor, radius) -> Tensor:
     x, other = torch.broadcast_tensors(x, other)
-    x, other = _f32c(x), _f32c(other)
-    A = x.shape[-1]
-    out = torch.empty_like(x)
-    r = _radius_arg(kind, radius, x)
-    check(getattr(load(), fn_name)(kind, ptr(x), ptr(other), ptr(out), x.numel() // A, _true_dim(kind, A), ptr(r),
-                                   stream_ptr(x.device)))
-    return out
+    return _prim(op, kind, _true_dim(kind, x.shape[-1]), x.shape[:-1], x, other, None, radius)[0]
 
 
-def parallel_transport_mu0(kind: int, x: Tensor, dst: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    return _pt("mvae_parallel_transport_mu0", kind, x, dst, radius)
+def parallel_transport_mu0(kind: int, x: Tensor, dst: Tensor, radius=None) -> Tensor:
+    return _two(_lib.OP_PT0, kind, x, dst, radius)
 
 
-def inverse_parallel_transport_mu0(kind: int, x: Tensor, src: Tensor, radius: Optional[Tensor] = None) -> Tensor:
-    return _pt("mvae_inverse_parallel_transport_mu0", kind, x, src, radius)
+def inverse_parallel_transport_mu0(kind: int, x: Tensor, src: Tensor, radius=None) -> Tensor:
+    return _two(_lib.OP_IPT0, kind, x, src, radius)
 
 
-def _at_rows(x: Tensor, at: Tensor, last: int) -> Tuple[Tensor, int]:
-    """`at_point` may lack leading sample dims ([B,A] against [n,B,d]); the kernels index it modulo at_rows."""
-    at = _f32c(at)
-    lead = x.shape[:-1]
-    if at.shape[:-1] == lead:
-        return at, max(1, at.numel() // last)
-    if at.dim() <= x.dim() and tuple(lead[len(lead) - (at.dim() - 1):]) == tuple(at.shape[:-1]):
-        return at, max(1, at.numel() // last)
-    at = at.expand(lead + (last,)).contiguous()
-    return at, max(1, at.numel() // last)
+def exp_map(kind: int, x: Tensor, at_point: Tensor, radius=None) -> Tensor:
+    """Manifold exp map of the tangent vector x at `at_point` (hyperbolics.py:106-111 and its siblings)."""
+    return _prim(_lib.OP_EXP, kind, _true_dim(kind, x.shape[-1]), x.shape[:-1], x, at_point, None, radius)[0]
 
 
-def sample_projection_mu0(kind: int, v: Tensor, at_point: Tensor, radius: Optional[Tensor] = None):
-    _no_grad_inputs(v, at_point)
-    v = _f32c(v)
-    d = v.shape[-1]
-    A = ambient_dim(kind, d)
-    at, at_rows = _at_rows(v, at_point, A)
-    z = v.new_empty(v.shape[:-1] + (A,))
-    u = torch.empty_like(z)
-    r = _radius_arg(kind, radius, v)
-    check(load().mvae_sample_projection_mu0(kind, ptr(v), ptr(at), ptr(z), ptr(u), v.numel() // d, at_rows, d, ptr(r),
-                                            stream_ptr(v.device)))
+def inverse_exp_map(kind: int, x: Tensor, at_point: Tensor, radius=None) -> Tensor:
+    return _prim(_lib.OP_LOG, kind, _true_dim(kind, x.shape[-1]), x.shape[:-1], x, at_point, None, radius)[0]
+
+
+def geodesic_distance(kind: int, x: Tensor, y: Tensor, radius=None, gyro: bool = False, keepdim: bool = True) -> Tensor:
+    """Geodesic distance of the manifold (include/mvae_hip.h: mvae_geodesic_distance), [..., 1] like the reference's
+    helpers (keepdim=True)."""
+    x, y = torch.broadcast_tensors(x, y)
+    out = _prim(_lib.OP_DIST_GYRO if gyro else _lib.OP_DIST, kind, _true_dim(kind, x.shape[-1]), x.shape[:-1], x, y,
+                None, radius)[0]
+    return out if keepdim else out.squeeze(-1)
+
+
+def sample_projection_mu0(kind: int, v: Tensor, at_point: Tensor, radius=None):
+    z, u = _prim(_lib.OP_SAMPLE, kind, v.shape[-1], v.shape[:-1], v, at_point, None, radius)
     return z, (u, v)
 
 
-def inverse_sample_projection_mu0(kind: int, z: Tensor, at_point: Tensor, radius: Optional[Tensor] = None):
-    _no_grad_inputs(z, at_point)
-    z = _f32c(z)
-    A = z.shape[-1]
-    d = _true_dim(kind, A)
-    at, at_rows = _at_rows(z, at_point, A)
-    u = torch.empty_like(z)
-    v = z.new_empty(z.shape[:-1] + (d,))
-    r = _radius_arg(kind, radius, z)
-    check(load().mvae_inverse_sample_projection_mu0(kind, ptr(z), ptr(at), ptr(u), ptr(v), z.numel() // A, at_rows, d,
-                                                    ptr(r), stream_ptr(z.device)))
+def inverse_sample_projection_mu0(kind: int, z: Tensor, at_point: Tensor, radius=None):
+    u, v = _prim(_lib.OP_ISAMPLE, kind, _true_dim(kind, z.shape[-1]), z.shape[:-1], z, at_point, None, radius)
     return u, v
 
 
-def logdet(kind: int, u: Optional[Tensor], mu: Optional[Tensor], z: Optional[Tensor],
-           radius: Optional[Tensor] = None) -> Tensor:
-    _no_grad_inputs(u, mu, z)
-    ref = _f32c(u if kind in (_lib.HYPERBOLOID, _lib.SPHERE) else z)
-    A = ref.shape[-1]
-    rows = ref.numel() // A
-    out = ref.new_empty(ref.shape[:-1])
-    r = _radius_arg(kind, radius, ref)
-    mu_c, at_rows, z_c = None, rows, None
+def logdet(kind: int, u: Optional[Tensor], mu: Optional[Tensor], z: Optional[Tensor], radius=None) -> Tensor:
     if kind in _PROJECTED:
-        z_c = ref
-        mu_c, at_rows = _at_rows(ref, mu, A)
-    check(load().mvae_logdet(kind, ptr(ref) if kind not in _PROJECTED else None, ptr(mu_c), ptr(z_c), ptr(out), rows,
-                             at_rows, _true_dim(kind, A), ptr(r), stream_ptr(ref.device)))
+        out = _prim(_lib.OP_LOGDET, kind, z.shape[-1], z.shape[:-1], None, mu, z, radius)[0]
+    else:
+        out = _prim(_lib.OP_LOGDET, kind, _true_dim(kind, u.shape[-1]), u.shape[:-1], u, None, None, radius)[0]
+    return out.squeeze(-1)
+
+
+def normal_log_prob(value: Tensor, loc: Tensor, scale: Tensor) -> Tensor:
+    """sum_i log N(value_i; loc_i, scale_i): EuclideanNormal.log_prob (wrapped_distributions.py:39-42); loc / scale may
+    lack leading sample dims of `value`."""
+    loc, scale = torch.broadcast_tensors(loc, scale)
+    return _prim(_lib.OP_NORMAL_LOGPROB, _lib.EUCLIDEAN, value.shape[-1], value.shape[:-1], value, loc, scale,
+                 None)[0].squeeze(-1)
+
+
+def normal_rsample(eps: Tensor, loc: Tensor, scale: Tensor) -> Tensor:
+    """loc + eps * scale (torch.distributions.Normal.rsample with the standard-normal draw given)."""
+    loc, scale = torch.broadcast_tensors(loc, scale)
+    return _prim(_lib.OP_NORMAL_RSAMPLE, _lib.EUCLIDEAN, eps.shape[-1], eps.shape[:-1], eps, loc, scale, None)[0]
+
+
+def normal_kl_standard(loc: Tensor, scale: Tensor) -> Tensor:
+    """KL(N(loc, scale) || N(0, 1)) summed over the last dim (sampling_procedures.py:153-155)."""
+    loc, scale = torch.broadcast_tensors(loc, scale)
+    return _prim(_lib.OP_NORMAL_KL, _lib.EUCLIDEAN, loc.shape[-1], loc.shape[:-1], loc, None, scale, None)[0].squeeze(-1)
+
+
+def manifold_aux(op: int, kind: int, x: Tensor, y: Optional[Tensor] = None, radius=None) -> Tensor:
+    """The small public helpers of the reference's ops modules (mvae_manifold_aux): Lorentz product / norm, the model
+    conversions, the conformal factor and Moebius addition.  Output [..., n]."""
+    if y is not None:
+        x, y = torch.broadcast_tensors(x, y)
+    n_in = x.shape[-1]
+    d = n_in if op == _lib.OP_TO_AMBIENT else _true_dim(kind, n_in)
+    return _prim(op, kind, d, x.shape[:-1], x, y, None, radius)[0]
+
+
+class _ScalarFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, name, lo, hi):
+        y, dy = scalar_fn(name, x.detach(), lo, hi)
+        ctx.save_for_backward(dy)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        return elementwise_mul(_f32c(g), dy), None, None, None
+
+
+def guarded(name: str, x: Tensor, lo: float = float("-inf"), hi: float = float("inf")) -> Tensor:
+    """Differentiable form of scalar_fn: f(x) with the reference's custom backward rule (ops/common.py:28-147)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ScalarFn.apply(x, name, lo, hi)
+    return scalar_fn(name, x.detach(), lo, hi)[0]
+
+
+def elementwise_mul(a: Tensor, b: Tensor) -> Tensor:
+    """a * b on the device (mvae_scalar_fn's companion: the chain-rule product of _ScalarFn.backward)."""
+    a, b = _f32c(a), _f32c(b)
+    out = torch.empty_like(a)
+    check(load().mvae_mul(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr(a.device)))
     return out
+
+
+def scalar_fn(name: str, x: Tensor, lo: float = float("-inf"), hi: float = float("inf")):
+    """(f(x), f'(x)) of one of the reference's guarded scalar functions (ops/common.py:28-147) through the device code
+    of the manifold kernels (mvae_scalar_fn)."""
+    x = _f32c(x)
+    y, dy = torch.empty_like(x), torch.empty_like(x)
+    check(load().mvae_scalar_fn(_lib.SCALAR_FNS[name], ptr(x), ptr(y), ptr(dy), x.numel(), float(lo), float(hi),
+                                stream_ptr(x.device)))
+    return y, dy
 
 
 # --------------------------------------------------------------------------------------------- components
@@ -202,17 +401,51 @@ def component_forward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii
 
 
 def component_backward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii: Optional[Tensor], dz: Tensor,
-                       dkl: Optional[Tensor], dkl_scalar: float = 0.0, want_dradii: bool = True):
+                       dkl: Optional[Tensor], dkl_scalar: float = 0.0, want_dradii: bool = True,
+                       out_dheads: Optional[Tensor] = None, workspace: Optional[Tensor] = None):
+    """dheads[rows, heads_dim] and dradii[ncomp] (a fixed-order sum over the rows: bit-reproducible)."""
     heads, eps, dz = _f32c(heads), _f32c(eps), _f32c(dz)
     rows = heads.shape[0]
-    dheads = torch.zeros_like(heads)
+    dheads = torch.zeros_like(heads) if out_dheads is None else out_dheads
     dradii = heads.new_zeros(layout.n) if want_dradii else None
+    if want_dradii and workspace is None:
+        workspace = heads.new_empty(max(1, layout.n * rows))
     dkl = None if dkl is None else _f32c(dkl)
     radii = None if radii is None else _f32c(radii)
     check(load().mvae_component_backward(layout.descs, layout.n, ptr(heads), heads.shape[-1], ptr(eps), layout.eps_dim,
                                          ptr(radii), ptr(dz), layout.z_dim, ptr(dkl), float(dkl_scalar), ptr(dheads),
-                                         ptr(dradii), rows, stream_ptr(heads.device)))
+                                         ptr(dradii), ptr(workspace if want_dradii else None), rows,
+                                         stream_ptr(heads.device)))
     return dheads, dradii
+
+
+class _ComponentFn(torch.autograd.Function):
+    """(heads[B, NH], radii[ncomp], eps[B, E]) -> (z[B, Z], kl[ncomp, B]) with the fused component operators
+    (training path: rows == head_rows)."""
+
+    @staticmethod
+    def forward(ctx, heads, radii, eps, layout):
+        out = component_forward(layout, heads.detach(), eps, radii.detach(), want_kl=True)
+        ctx.save_for_backward(heads.detach(), radii.detach(), eps)
+        ctx.layout = layout
+        return out["z"], out["kl"]
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        heads, radii, eps = ctx.saved_tensors
+        lay = ctx.layout
+        dz = torch.zeros(heads.shape[0], lay.z_dim, device=heads.device) if dz is None else dz
+        dkl = torch.zeros(lay.n, heads.shape[0], device=heads.device) if dkl is None else dkl
+        dheads, dradii = component_backward(lay, heads, eps, radii, dz, dkl, want_dradii=ctx.needs_input_grad[1])
+        return (dheads if ctx.needs_input_grad[0] else None), dradii, None, None
+
+
+def component_rsample_kl(layout: ComponentLayout, heads: Tensor, radii: Tensor, eps: Tensor):
+    """Differentiable (z, kl) of all components of `layout` (Component.forward -> rsample_with_parts -> kl_loss)."""
+    if torch.is_grad_enabled() and (heads.requires_grad or radii.requires_grad):
+        return _ComponentFn.apply(_f32c(heads), _f32c(radii), _f32c(eps), layout)
+    out = component_forward(layout, heads.detach(), eps, radii.detach(), want_kl=True)
+    return out["z"], out["kl"]
 
 
 # --------------------------------------------------------------------------------------------- dense layers
@@ -243,6 +476,40 @@ def linear_backward(x: Tensor, W: Tensor, dy: Tensor, relu_in: bool = False, nee
     return dW, db, dx
 
 
+def relu_mask_(dy: Tensor, y: Tensor) -> Tensor:
+    """dy[i] = 0 where y[i] <= 0, in place (backward through a ReLU whose output is y)."""
+    check(load().mvae_relu_mask(ptr(dy), ptr(y), dy.numel(), stream_ptr(dy.device)))
+    return dy
+
+
+class _LinearFn(torch.autograd.Function):
+    """torch.nn.Linear (+ optional ReLU) on the MFMA kernels: y = act(x W^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        y = linear_forward(x.detach(), W.detach(), None if b is None else b.detach(), relu)
+        ctx.save_for_backward(x.detach(), W.detach(), y if relu else None)
+        ctx.relu, ctx.has_bias = relu, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        if ctx.relu:
+            dy = relu_mask_(dy.clone(), y)
+        x2, dy2 = x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1])
+        dW, db, dx = linear_backward(x2, W, dy2, need_dx=ctx.needs_input_grad[0])
+        return (None if dx is None else dx.view(x.shape)), dW, (db if ctx.has_bias else None), None
+
+
+def linear(x: Tensor, W: Tensor, b: Optional[Tensor], relu: bool = False) -> Tensor:
+    """Differentiable torch.nn.functional.linear (+ ReLU) on the HIP kernels."""
+    if torch.is_grad_enabled() and (x.requires_grad or W.requires_grad or (b is not None and b.requires_grad)):
+        return _LinearFn.apply(x, W, b, relu)
+    return linear_forward(x.detach(), W.detach(), None if b is None else b.detach(), relu)
+
+
 # --------------------------------------------------------------------------------------------- log-likelihood pieces
 def bce_rows(logits: Tensor, x: Tensor) -> Tensor:
     """sum_j BCE-with-logits(logits[..., j], x[..., j]) with x broadcast over leading sample dims of logits."""
@@ -252,6 +519,42 @@ def bce_rows(logits: Tensor, x: Tensor) -> Tensor:
     out = logits.new_empty(logits.shape[:-1])
     check(load().mvae_bce_rows(ptr(logits), ptr(x), ptr(out), rows, x_rows, D, stream_ptr(logits.device)))
     return out
+
+
+def scale_rows(g: Tensor, sc: Tensor) -> Tensor:
+    g, sc = _f32c(g), _f32c(sc)
+    out = torch.empty_like(g)
+    D = g.shape[-1]
+    check(load().mvae_scale_rows(ptr(g), ptr(sc), ptr(out), g.numel() // D, D, stream_ptr(g.device)))
+    return out
+
+
+class _BceFn(torch.autograd.Function):
+    """sum_j BCE-with-logits per row and its gradient w.r.t. the logits (sigmoid(logits) - x) * upstream[row]."""
+
+    @staticmethod
+    def forward(ctx, logits, x):
+        logits, x = _f32c(logits.detach()), _f32c(x)
+        D = logits.shape[-1]
+        bce = logits.new_empty(logits.shape[:-1])
+        g = torch.empty_like(logits)
+        check(load().mvae_bce_forward_backward(ptr(logits), ptr(x), ptr(bce), ptr(g), logits.numel() // D, D,
+                                               stream_ptr(logits.device)))
+        ctx.save_for_backward(g)
+        return bce
+
+    @staticmethod
+    def backward(ctx, dbce):
+        (g,) = ctx.saved_tensors
+        return scale_rows(g, dbce), None
+
+
+def bce_with_logits_rows(logits: Tensor, x: Tensor) -> Tensor:
+    """Differentiable reconstruction loss summed over the pixels (image_reconstruction.py:81-82, vae.py:131); x has the
+    shape of logits (training path) or is broadcast over leading sample dims (evaluation, no grad)."""
+    if torch.is_grad_enabled() and logits.requires_grad and x.shape == logits.shape:
+        return _BceFn.apply(logits, x)
+    return bce_rows(logits.detach(), x)
 
 
 def loglik_reduce(bce: Tensor, log_p: Tensor, log_q: Tensor):

@@ -118,9 +118,14 @@ class ModelVAE(nn.Module):
     # ---- device placement: build the StepEngine and alias every parameter into its flat buffer
     def to(self, device) -> "ModelVAE":
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if self.engine is not None and self.engine.device == self.device:
+            return self  # already bound: a second .to(same device) must not orphan the optimizer / graph state
         super().to(self.device)
         if self.device.type == "cuda":
             self._bind_engine()
+            self._dp = None  # bound to the previous engine (if any): enable_data_parallel() again
         return self
 
     def enable_data_parallel(self, group=None):
@@ -179,16 +184,41 @@ class ModelVAE(nn.Module):
             reps.append(Reparametrized(q, FusedPrior(c, B, self.device), z, (FusedParts(kl=out["kl"][i]),)))
         return reps, out["concat_z"], out["logits"]
 
+    def _wants_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _stacked_heads_params(self):
+        """The fused head matrix / bias / radii as autograd-visible tensors: concatenations of the nn.Parameters in
+        the layout's order (all fc_mean rows, then all fc_logvar rows)."""
+        W = torch.cat([c.fc_mean.weight for c in self.components] + [c.fc_logvar.weight for c in self.components], dim=0)
+        b = torch.cat([c.fc_mean.bias for c in self.components] + [c.fc_logvar.bias for c in self.components], dim=0)
+        radii = torch.cat([c._radii_tensor() for c in self.components], dim=0)
+        return W, b, radii
+
     def forward(self, x: Tensor, eps: Optional[Tensor] = None) -> Outputs:  # vae.py:69-80
+        """With gradients enabled every dense layer / the component operator runs as a torch.autograd.Function over the
+        HIP kernels, so the reference's own sequence works: `stats = compute_batch_stats(...); (-stats.elbo).backward();
+        optimizer.step()` (vae.py:154-164).  ModelVAE.train_step does all of that as one fused launch sequence instead."""
         eng = self._need_engine()
         x = x.to(self.device, torch.float32)
         eps = self._eps(x.shape[0]) if eps is None else eps
         h = self.encode(x)
-        P = eng.param_views_raw()
-        heads = Fn.linear_forward(h, P["w_heads"], P["b_heads"])
-        co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=True, want_params=True)
-        x_ = self.decode(co["z"])
-        out = {"concat_z": co["z"], "kl": co["kl"], "mu": co["mu"], "std": co["std"], "logits": x_}
+        if self._wants_grad():
+            W, b, radii = self._stacked_heads_params()
+            heads = Fn.linear(h, W, b)
+            z, kl = Fn.component_rsample_kl(eng.layout, heads, radii, eps)
+            with torch.no_grad():  # q_z.loc / q_z.scale for summaries: values only
+                co = Fn.component_forward(eng.layout, heads.detach(), eps, radii.detach(), want_kl=False,
+                                          want_params=True)
+            x_ = self.decode(z)
+            out = {"concat_z": z, "kl": kl, "mu": co["mu"], "std": co["std"], "logits": x_}
+        else:
+            P = eng.param_views_raw()
+            heads = Fn.linear_forward(h, P["w_heads"], P["b_heads"])
+            co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=True,
+                                      want_params=True)
+            x_ = self.decode(co["z"])
+            out = {"concat_z": co["z"], "kl": co["kl"], "mu": co["mu"], "std": co["std"], "logits": x_}
         self._last_forward = (x, out)
         return self._wrap_outputs(out)
 
@@ -215,7 +245,7 @@ class ModelVAE(nn.Module):
 
     def compute_batch_stats(self, x_mb: Tensor, x_mb_: Tensor, reparametrized: List[Reparametrized], beta: float,
                             likelihood_n: int = 0) -> BatchStats:  # vae.py:125-147
-        bce = Fn.bce_rows(x_mb_, x_mb.to(self.device, torch.float32))
+        bce = Fn.bce_with_logits_rows(x_mb_, x_mb.to(self.device, torch.float32))
         kl = torch.stack([c.kl_loss(r.q_z, r.p_z, r.z, r.data) for c, r in zip(self.components, reparametrized)])
         ll = mi = cn = None
         if likelihood_n:
@@ -269,12 +299,12 @@ class FeedForwardVAE(ModelVAE):
 
     def encode(self, x: Tensor) -> Tensor:  # ffnn_vae.py:42-50
         assert x.dim() == 2 and x.shape[1] == self.in_dim
-        return Fn.linear_forward(x, self.fc_e0.weight.detach(), self.fc_e0.bias.detach(), relu=True)
+        return Fn.linear(x, self.fc_e0.weight, self.fc_e0.bias, relu=True)
 
     def decode(self, concat_z: Tensor) -> Tensor:  # ffnn_vae.py:52-60
         assert concat_z.dim() >= 2
-        h = Fn.linear_forward(concat_z, self.fc_d0.weight.detach(), self.fc_d0.bias.detach(), relu=True)
-        return Fn.linear_forward(h, self.fc_logits.weight.detach(), self.fc_logits.bias.detach())
+        h = Fn.linear(concat_z, self.fc_d0.weight, self.fc_d0.bias, relu=True)
+        return Fn.linear(h, self.fc_logits.weight, self.fc_logits.bias)
 
 
 class ConvolutionalVAE(ModelVAE):

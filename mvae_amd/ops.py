@@ -3,8 +3,9 @@
 Same class names, method names, argument meaning and conventions: tensors are [..., A] with coordinates last and
 arbitrary leading dims; RadiusManifold takes a callable returning the live radius parameter
 (component.py:125-126 `Hyperboloid(lambda: self._nradius)`); Hyperboloid / PoincareBall negate the curvature.
-The standalone primitives are forward-only (see functional._no_grad_inputs); training differentiates through the
-fused component / step operators.
+Every method is differentiable: a tensor argument (or the radius parameter) that requires grad routes the call through
+functional._Prim, whose backward kernel evaluates the same device template over dual numbers (the reference's custom
+derivative rules included).  The fused train step does not come through here.
 """
 from typing import Any, Callable, Tuple
 
@@ -39,6 +40,18 @@ class Manifold:
     def inverse_sample_projection_mu0(self, x_proj: Tensor, at_point: Tensor) -> Tuple[Tensor, Tensor]:
         return Fn.inverse_sample_projection_mu0(self.KIND, x_proj, at_point, self._r())
 
+    # general base point (the reference keeps these as module-level functions only, e.g. hyperbolics.py:106-128; the
+    # methods are a convenience over the same kernels)
+    def exp_map(self, x: Tensor, at_point: Tensor) -> Tensor:
+        return Fn.exp_map(self.KIND, x, at_point, self._r())
+
+    def inverse_exp_map(self, x: Tensor, at_point: Tensor) -> Tensor:
+        return Fn.inverse_exp_map(self.KIND, x, at_point, self._r())
+
+    def distance(self, x: Tensor, y: Tensor, keepdim: bool = True) -> Tensor:
+        """Geodesic distance (include/mvae_hip.h: mvae_geodesic_distance)."""
+        return Fn.geodesic_distance(self.KIND, x, y, self._r(), keepdim=keepdim)
+
     def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
         raise NotImplementedError
 
@@ -64,8 +77,8 @@ class RadiusManifold(Manifold):
         return self._radius()
 
     @property
-    def radius(self) -> Tensor:  # manifold.py:73-75
-        return torch.clamp(torch.relu(self._radius().detach()), min=1e-8, max=1e8)
+    def radius(self) -> Tensor:  # manifold.py:73-75 (differentiable, like the reference's property)
+        return torch.clamp(torch.relu(self._radius()), min=1e-8, max=1e8)
 
     @property
     def curvature(self) -> Tensor:  # manifold.py:69-71
@@ -74,7 +87,7 @@ class RadiusManifold(Manifold):
     def mu_0(self, shape: torch.Size, **kwargs: Any) -> Tensor:  # hyperbolics.py:68-69 | spherical.py:70-71
         e0 = torch.zeros(shape, **kwargs)
         e0[..., 0] = 1
-        return e0 * self.radius.to(e0.device)
+        return e0 * self.radius.detach().to(e0.device)
 
     def logdet(self, mu: Tensor, std: Tensor, z: Tensor, data: Tuple[Tensor, ...]) -> Tensor:
         return Fn.logdet(self.KIND, data[0], None, None, self._r())
@@ -185,5 +198,5 @@ class Universal(Manifold):
 
 
 def lorentz_to_poincare(x: Tensor, radius: Tensor) -> Tensor:
-    """hyperbolics.py:151-152 (used by the embedding export, train.py:271); a two-op torch expression on purpose."""
-    return radius * x[..., 1:] / (radius + x[..., 0:1])
+    """hyperbolics.py:151-152 (used by the embedding export, train.py:271)."""
+    return Fn.manifold_aux(_lib.OP_TO_BALL, _lib.HYPERBOLOID, x, None, radius)

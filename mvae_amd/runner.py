@@ -9,7 +9,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
-from .distributed import DataParallelStep
+from .distributed import DataParallelStep, agree_any
 from .engine import StepEngine
 
 
@@ -41,6 +41,7 @@ class StepRunner:
         self.since_reset = 0
         self.capture_steps = 0  # steps executed while warming up / capturing (they only touch the statistics)
         self.capture_failed = False
+        self.replays = 0  # graph replays issued by run()
         self._snapshot = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
@@ -53,6 +54,7 @@ class StepRunner:
         if self.gs > 0:
             if self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
+            failed = False
             try:
                 self._capture()
             except Exception as e:  # noqa: BLE001
@@ -61,12 +63,17 @@ class StepRunner:
                 # a collective that cannot be captured on this stack must not take the run down: fall back to eager
                 # launches (same arithmetic, host launch cost back on the critical path)
                 import sys
-                print(f"[StepRunner] graph capture with the gradient all-reduce failed ({type(e).__name__}: {e}); "
-                      "running eagerly", file=sys.stderr, flush=True)
+                print(f"[StepRunner] graph capture with the gradient all-reduce failed ({type(e).__name__}: {e})",
+                      file=sys.stderr, flush=True)
+                failed = True
+                _clear_hip_error()
+            # A capture failure is a per-process event (a watchdog thread's event query landing inside the capture): the
+            # ranks must take the SAME route afterwards, or one replays graphs / re-execs while its peers wait in an
+            # eager all-reduce.  The outcome is agreed through the rendezvous store: if any rank failed, all go eager.
+            if self.dp is not None and agree_any(failed, self.dp.group, "steprunner-capture"):
                 self.graphs = []
                 self.gs = 0
-                self.capture_failed = True  # callers that can should start over without graphs (bench.py does)
-                _clear_hip_error()
+                self.capture_failed = True  # identical on every rank; callers that can start over without graphs
                 torch.cuda.synchronize()
 
     def _capture_mode(self) -> str:
@@ -121,6 +128,7 @@ class StepRunner:
                 self.since_reset = 0
             if self.gs > 0 and self.cursor % self.gs == 0 and left >= self.gs:
                 self.graphs[self.cursor // self.gs].replay()
+                self.replays += 1
                 self.cursor = (self.cursor + self.gs) % self.n_data
                 left -= self.gs
                 self.since_reset += self.gs
@@ -180,9 +188,11 @@ class EpochRunner:
 
     def _graph(self, beta: float, do_curv: bool) -> torch.cuda.CUDAGraph:
         # the trainable flags travel in the kernel arguments, so a requires_grad toggle needs a fresh capture
-        key = (float(beta), bool(do_curv), tuple(self.eng.radius_trainable))
-        g = self._graphs.get(key)
-        if g is None:
+        key = (float(beta), bool(do_curv), tuple(self.eng.radius_trainable), self.eng.generation)
+        if key not in self._graphs:
+            # graphs of an older engine generation reference freed workspaces / a stale lr: drop them
+            self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self.eng.generation}
+            g, failed = None, False
             eng = self.eng
             keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
             try:
@@ -198,11 +208,22 @@ class EpochRunner:
                     for _ in range(self.gs):
                         self._pair(beta, do_curv)
                 torch.cuda.synchronize()
-            finally:
+            except Exception as e:  # noqa: BLE001
+                if self.dp is None:
+                    raise
+                import sys
+                print(f"[EpochRunner] graph capture with the gradient all-reduce failed ({type(e).__name__}: {e})",
+                      file=sys.stderr, flush=True)
+                failed = True
+                _clear_hip_error()
+            finally:  # capturing (or failing to) has no net effect on the model
                 for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
                     dst.copy_(src)
+            # every rank takes the same route (see StepRunner.__init__): any failure -> all run this key eagerly
+            if self.dp is not None and agree_any(failed, self.dp.group, "epochrunner-capture"):
+                g = None
             self._graphs[key] = g
-        return g
+        return self._graphs[key]
 
     def run_epoch(self, beta: float, do_curv: bool, use_graphs: bool = True) -> int:
         """Runs the `nb` full batches of one epoch; returns the number of steps taken."""
@@ -214,8 +235,8 @@ class EpochRunner:
             self.eng.counters[8] = cur + (self.nb - cur % self.nb)
         left = self.nb
         if use_graphs and self.capturable:
-            g = self._graph(beta, do_curv)
-            while left >= self.gs:
+            g = self._graph(beta, do_curv)  # None: this configuration could not be captured (agreed across ranks)
+            while g is not None and left >= self.gs:
                 g.replay()
                 left -= self.gs
         for _ in range(left):

@@ -22,19 +22,49 @@ class CurvatureOptimizer:
         self.learning_rate, self.curvature_lr = float(learning_rate), float(curvature_lr)
         self.curv_condition = should_do_curvature_step
         self._model: Optional[ModelVAE] = None
+        self._engine = None
 
     def bind(self, model: ModelVAE) -> None:
-        if self._model is not model:
-            eng = model._need_engine()
+        """Hands the hyper-parameters to the model's engine.  Re-binds when the model OR its engine changed (a second
+        `model.to(device)` builds a new engine) and refuses to share one engine between optimizers with different
+        learning rates silently: the later bind wins and the engine's contexts / captured graphs are rebuilt
+        (StepEngine.set_lr bumps its generation, which the graph caches are keyed on)."""
+        eng = model._need_engine()
+        if self._model is not model or self._engine is not eng or eng.lr != self.learning_rate or \
+                eng.curvature_lr != self.curvature_lr:
             if eng.lr != self.learning_rate or eng.curvature_lr != self.curvature_lr:
                 eng.set_lr(self.learning_rate, self.curvature_lr)
-            self._model = model
+            self._model, self._engine = model, eng
 
-    def zero_grad(self) -> None:  # gradients are overwritten, never accumulated
-        pass
+    def zero_grad(self) -> None:
+        """The fused train_step overwrites the gradients, so it never needs this.  In the reference's eager sequence
+        (`optimizer.zero_grad(); loss.backward(); optimizer.step()`, vae.py:150-164) autograd ACCUMULATES into p.grad:
+        zero the flat gradient buffer and point every p.grad at its slice of it, so the accumulation lands where the
+        optimizer kernel reads."""
+        if self._model is None or self._model.engine is None:
+            return
+        eng = self._model.engine
+        eng.grads.zero_()
+        gviews = eng.grad_views()
+        for name, p in self._model.named_parameters():
+            if p.requires_grad:
+                p.grad = gviews[name]
 
     def step(self, closure: Optional[Any] = None) -> None:
-        self._model._need_engine().optimizer_step(self.curv_condition())
+        """Adam on the network parameters + SGD on the radii iff `curv_condition()` (utils.py:174-180), one kernel over
+        the flat buffers.  Gradients that autograd left outside the flat buffer (p.grad re-assigned, or None after a
+        `zero_grad(set_to_none=True)`) are gathered first."""
+        model = self._model
+        eng = model._need_engine()
+        gviews = eng.grad_views()
+        for name, p in model.named_parameters():
+            v = gviews[name]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad.reshape(v.shape))
+                p.grad = v
+        eng.optimizer_step(self.curv_condition())
 
 
 class Trainer:
@@ -96,7 +126,10 @@ class Trainer:
         if not fixed_curvature and not has_radii:
             warnings.warn("Fixed curvature disabled, but found no curvature parameters. Did you mean to set "
                           "fixed=True, or not?")
-        return CurvatureOptimizer(learning_rate, 1e-4, condition)
+        opt = CurvatureOptimizer(learning_rate, 1e-4, condition)
+        if self.model.engine is not None:  # the eager sequence calls zero_grad() / step() without a train_step first
+            opt.bind(self.model)
+        return opt
 
     # ---- epochs
     def _train_epoch(self, optimizer: CurvatureOptimizer, train_data, beta: float) -> EpochStats:
@@ -141,13 +174,14 @@ class Trainer:
                 train_data.images.shape[0] >= train_data.batch_size):
             return False
         er = getattr(self, "_epoch_runner", None)
-        if er is None or er.images is not train_data.images or er.B != train_data.batch_size:
+        optimizer.bind(self.model)  # may change the engine's lr (-> new generation) before the runner is looked up
+        eng = self.model.engine
+        if er is None or er.images is not train_data.images or er.B != train_data.batch_size or er.eng is not eng:
             seed = int(torch.randint(0, 2**31 - 1, (1,)).item()) if train_data._gen is None else \
                 int(train_data._gen.initial_seed())
             dp = getattr(self.model, "_dp", None)
             seed += 0 if dp is None else dp.rank  # every rank binarises / draws eps from its own Philox stream
             er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed, dp=dp)
-        optimizer.bind(self.model)
         self.model._sync_trainable()
         self.global_step += er.run_epoch(beta, optimizer.curv_condition())
         tail = er.N - er.nb * er.B

@@ -458,6 +458,28 @@ def spherical_projected_gyro_distance(x: Tensor, y: Tensor, K: Tensor) -> Tensor
     return 2. / sk * torch.atan(sk * torch.norm(d_mob_add(-x, y, K), p=2, dim=-1, keepdim=True))
 
 
+# ------------------------------------------------------------- geodesic distances
+# The reference keeps these next to its operators: as helpers of its own op tests (h, s, e) and in the ops modules (p, d).
+def h_distance(x: Tensor, y: Tensor, R: Tensor) -> Tensor:  # tests/mvae/ops/test_hyperbolics.py:46-47
+    return R * acosh(-lorentz_product(x, y, keepdim=True) / (R**2))
+
+
+def s_distance(x: Tensor, y: Tensor, R: Tensor) -> Tensor:  # tests/mvae/ops/test_spherical.py:45-48
+    ndot = torch.sum(x * y, dim=-1, keepdim=True) / R**2
+    return R * torch.acos(torch.clamp(ndot, min=-1., max=1.))
+
+
+def e_distance(x: Tensor, y: Tensor) -> Tensor:  # tests/mvae/ops/test_euclidean.py:41-42
+    return 2 * torch.norm(x - y, dim=-1, p=2, keepdim=True)
+
+
+def p_distance(x: Tensor, y: Tensor, R: Tensor) -> Tensor:  # poincare.py:92-105 (mobius_add: PARITY UNPINNED)
+    c = _p_c(R)
+    sqrt_c = sqrt(c)
+    mob = p_mobius_add(-x, y, c).norm(dim=-1, p=2, keepdim=True)
+    return atanh(sqrt_c * mob) * 2 / sqrt_c
+
+
 # ------------------------------------------------------------- universal manifold `u`  (universal.py:28-83)
 U_EPS = 1e-6  # universal.py:53, component.py:231
 

@@ -16,6 +16,8 @@ Files written (all small):
   g3_step_full.npz      same at the benchmark size (B=128, h=400, D=784): per-sample stats + summaries
   g4_loglik.npz         ModelVAE.log_likelihood(x, n=8)
   g5_parser.json        model-string grammar table
+  g7_distances.npz      geodesic distances through the helpers of the reference's own op tests (lorentz_distance,
+                        spherical_distance, euclidean_distance) and the lorentz product / norm, H/S/E x R x d, f32 and f64
   g6_projected.npz      the reference-owned part of the projected sphere `d` (everything that does not cross into
                         geoopt's mobius_add) and Universal.radius / _choice, f32 and f64
 """
@@ -88,6 +90,55 @@ def gen_projected():
     torch.set_default_dtype(torch.float32)
     np.savez_compressed(os.path.join(HERE, "g6_projected.npz"), **out)
     print("g6_projected:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------- G7
+def _load_reference_test_module(name):
+    """Imports tests/mvae/ops/<name>.py of the REFERENCE by path (its helpers hold the distance formulas)."""
+    import importlib.util
+    path = os.path.join(ref_shim.REFERENCE_ROOT, "tests", "mvae", "ops", name + ".py")
+    spec = importlib.util.spec_from_file_location("ref_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_distances():
+    out = {}
+    for dname, dtype in DTYPES.items():
+        torch.set_default_dtype(dtype)
+        TH = _load_reference_test_module("test_hyperbolics")
+        TS = _load_reference_test_module("test_spherical")
+        TE = _load_reference_test_module("test_euclidean")
+        for mname, M in {"H": H, "S": S, "E": E}.items():
+            for R in [0.5, 1.0, 2.0, 11.0]:
+                for d in [2, 5, 40]:
+                    rows = 8
+                    g = torch.Generator().manual_seed(9000 + int(R * 100) + d)
+                    x = (torch.randn(rows, d, generator=g, dtype=torch.float64) * 0.6 * min(R, 3.0) / np.sqrt(d)).to(dtype)
+                    y = (torch.randn(rows, d, generator=g, dtype=torch.float64) * 0.6 * min(R, 3.0) / np.sqrt(d)).to(dtype)
+                    radius = torch.tensor(R, dtype=dtype)
+                    key = f"{mname}/R{R:g}/d{d}/{dname}/"
+                    out[key + "x"], out[key + "y"] = npy(x), npy(y)
+                    if mname == "E":
+                        p, q = M.exp_map_mu0(x), M.exp_map_mu0(y)
+                        out[key + "p"], out[key + "q"] = npy(p), npy(q)
+                        out[key + "dist"] = npy(TE.euclidean_distance(p, q))
+                        continue
+                    p = M.exp_map_mu0(C.expand_proj_dims(x), radius=radius)
+                    q = M.exp_map_mu0(C.expand_proj_dims(y), radius=radius)
+                    out[key + "p"], out[key + "q"] = npy(p), npy(q)
+                    if mname == "H":
+                        TH.radius = radius  # the helper reads the module-level radius of its test file
+                        out[key + "dist"] = npy(TH.lorentz_distance(p, q, keepdim=True))
+                        out[key + "lprod"] = npy(H.lorentz_product(p, q, keepdim=True))
+                        out[key + "lnorm_u"] = npy(H.lorentz_norm(H.inverse_exp_map(q, at_point=p, radius=radius),
+                                                                  keepdim=True))
+                    else:
+                        out[key + "dist"] = npy(TS.spherical_distance(p, q, radius))
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "g7_distances.npz"), **out)
+    print("g7_distances:", len(out), "arrays")
 
 
 # ----------------------------------------------------------------------------------------------- G1
@@ -528,7 +579,7 @@ def gen_parser():
 
 if __name__ == "__main__":
     os.makedirs("/tmp/golden_chkpt", exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5", "g6", "g7"]
     torch.set_num_threads(8)
     if "g1" in which:
         gen_primitives()
@@ -546,3 +597,5 @@ if __name__ == "__main__":
         gen_parser()
     if "g6" in which:
         gen_projected()
+    if "g7" in which:
+        gen_distances()

@@ -50,8 +50,10 @@ def test_manifold_classes_vs_golden(dev):
             assert_close(_cpu(man.logdet(mu, None, z, (u, v_))), g[k + "logdet_u"], RTOL, name + " logdet", atol_frac=1e-4)
             assert float(man.radius) == 2.0
     assert float(Hyperboloid(lambda: R).curvature) == -0.25 and float(Sphere(lambda: R).curvature) == 0.25
-    with pytest.raises(NotImplementedError):  # differentiable use goes through the fused operators
-        Hyperboloid(lambda: R).exp_map_mu0(torch.zeros(2, 2, device=dev, requires_grad=True))
+    # every Manifold method is differentiable (round 1 raised here): gradient flows to the argument and to the radius
+    xg = torch.full((2, 2), 0.3, device=dev, requires_grad=True)
+    Hyperboloid(lambda: R).exp_map_mu0(xg).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all() and R.grad is not None
 
 
 def test_component_api(dev):

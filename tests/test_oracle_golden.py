@@ -302,3 +302,31 @@ def test_parser_table():
         model, arch = key.split("|")
         spec = M.Spec(model, in_dim=3072 if arch == "conv" else 784, h_dim=8192 if arch == "conv" else 400, arch=arch)
         assert [[n, list(s)] for n, s in spec.named_shapes()] == shapes
+
+
+# ----------------------------------------------------------------------------------------------- G7 distances
+@pytest.mark.parametrize("dname,tol", [("f64", 1e-9), ("f32", 2e-5)])
+def test_distances_vs_reference_helpers(dname, tol):
+    """oracle h/s/e geodesic distances, Lorentz product and norm == the reference's own helpers
+    (tests/mvae/ops/test_{hyperbolics,spherical,euclidean}.py, recorded by make_golden.gen_distances)."""
+    from oracle import ops
+    g = load_npz("g7_distances.npz")
+    dt = torch.float64 if dname == "f64" else torch.float32
+    n = 0
+    for mname in "HSE":
+        for R in ["0.5", "1", "2", "11"]:
+            for d in [2, 5, 40]:
+                k = f"{mname}/R{R}/d{d}/{dname}/"
+                p, q, Rt = T(g[k + "p"], dt), T(g[k + "q"], dt), torch.tensor(float(R), dtype=dt)
+                if mname == "H":
+                    assert_close(ops.h_exp_map_mu0(T(g[k + "x"], dt), Rt).numpy(), g[k + "p"], tol, k + "p")
+                    assert_close(ops.h_distance(p, q, Rt).numpy(), g[k + "dist"], tol, k + "dist", atol_frac=tol)
+                    assert_close(ops.lorentz_product(p, q, keepdim=True).numpy(), g[k + "lprod"], tol, k + "lprod")
+                    u = ops.h_log_map(q, p, Rt)
+                    assert_close(ops.lorentz_norm(u, keepdim=True).numpy(), g[k + "lnorm_u"], 50 * tol, k + "lnorm_u")
+                elif mname == "S":
+                    assert_close(ops.s_distance(p, q, Rt).numpy(), g[k + "dist"], tol, k + "dist", atol_frac=tol)
+                else:
+                    assert_close(ops.e_distance(p, q).numpy(), g[k + "dist"], tol, k + "dist")
+                n += 1
+    assert n == 36
