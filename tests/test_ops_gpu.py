@@ -211,13 +211,19 @@ def test_device_fastmath_vs_float64(dev):
         want32 = want.astype(np.float32)
         return np.abs(got.astype(np.float64) - want) / np.maximum(np.spacing(np.abs(want32)).astype(np.float64), 1e-45)
 
+    # exp(x) = exp2(x * log2(e)) on the hardware pair: the rounding of the product costs |x| * 1.44 * 2^-24 * ln 2
+    # relative (mvae_fastmath.hpp header), on top of ~2 ulp of the evaluation itself
+    def rel_ok(got, want, x64):
+        return (np.abs(got.astype(np.float64) - want) <= (3e-7 + 6.5e-8 * np.abs(x64)) * np.abs(want) + 1e-37).all()
+
     x = torch.linspace(-20.0, 20.0, 20001, device=dev)
     c, s = Fn.scalar_fn("cosh_sinh_pair", x)
     x64 = _cpu(x).astype(np.float64)
-    assert ulps(_cpu(c), np.cosh(x64)).max() <= 8 and ulps(_cpu(s), np.sinh(x64)).max() <= 8
+    assert rel_ok(_cpu(c), np.cosh(x64), x64) and rel_ok(_cpu(s), np.sinh(x64), x64)
     small = torch.linspace(-0.4, 0.4, 4001, device=dev)  # around the polynomial / (e - 1/e) switch at 0.35
-    _, s2 = Fn.scalar_fn("cosh_sinh_pair", small)
-    assert ulps(_cpu(s2), np.sinh(_cpu(small).astype(np.float64))).max() <= 8
+    c2, s2 = Fn.scalar_fn("cosh_sinh_pair", small)
+    sm64 = _cpu(small).astype(np.float64)
+    assert ulps(_cpu(s2), np.sinh(sm64)).max() <= 8 and ulps(_cpu(c2), np.cosh(sm64)).max() <= 4
     a = torch.linspace(-50.0, 50.0, 40001, device=dev)
     c, s = Fn.scalar_fn("cos_sin_pair", a)
     a64 = _cpu(a).astype(np.float64)
@@ -234,7 +240,7 @@ def test_device_fastmath_vs_float64(dev):
     xs64 = _cpu(xs).astype(np.float64)
     want = np.where(xs64 > 20, xs64, np.log1p(np.exp(xs64)))
     ok = want > 1e-30  # below that float32 flushes
-    assert (np.abs(_cpu(y)[ok] - want[ok]) <= 2e-6 * np.abs(want[ok]) + 1e-37).all()
+    assert rel_ok(_cpu(y)[ok], want[ok], xs64[ok])  # softplus(x) ~ exp(x) for very negative x: the exp bound applies
     assert np.abs(_cpu(dy) - np.where(xs64 > 20, 1.0, 1 / (1 + np.exp(-xs64)))).max() < 1e-6
     xe = torch.linspace(-85.0, 85.0, 17001, device=dev)
     y, _ = Fn.scalar_fn("exp", xe)
