@@ -225,6 +225,14 @@ def main():
     prof = eng.profile_step(xs[0], eps[0], 1.0, not args.fixed_curvature, iters=200)
     alg = algorithmic_per_launch(eng.flat.n_logical_params(), eng.layout.heads_dim, eng.layout.z_dim,
                                  eng.layout.eps_dim)
+    if prof.get("latent_fwd", 1.0) == 0.0:  # the fused forward: launches 2 + 3 are ONE launch (k_fwd23); hd stays in LDS
+        f4, NHh, Zz = 4.0, eng.layout.heads_dim, eng.layout.z_dim
+        alg["latent_dec1_fwd"] = dict(
+            flops=alg["latent_fwd"]["flops"] + alg["dec1_fwd"]["flops"],
+            bytes=f4 * (B * H + NHh * H + NHh + B * eng.layout.eps_dim + H * Zz + H + D * H + D + 2 * B * D + B * H + B * Zz))
+        prof["latent_dec1_fwd"] = prof.pop("dec1_fwd")
+        del prof["latent_fwd"], alg["latent_fwd"], alg["dec1_fwd"]
+        prof = {k: prof[k] for k in ("enc_fwd", "latent_dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")}
     # The headline fraction is the WHOLE STEP against the roofline: SURVEY section 8(d)'s algorithmic bytes / flops of one
     # step (each tensor once: x, eps, and p, m, v, g read + written) over the measured ms_per_step.  `kernel` names the
     # longest launch -- whatever it is -- with its own numbers; every launch is listed in `per_kernel`.
@@ -243,8 +251,9 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 kern = json.load(fh)["kernels"]
-            traffic = kern["k_" + dom]["traffic_bytes"]
-            traffic_step = sum(kern["k_" + k]["traffic_bytes"] for k in prof)
+            names = {"latent_dec1_fwd": "k_fwd23"}
+            traffic = kern[names.get(dom, "k_" + dom)]["traffic_bytes"]
+            traffic_step = sum(kern[names.get(k, "k_" + k)]["traffic_bytes"] for k in prof)
             traffic_src = "profiles/" + name
             break
         except (OSError, KeyError, ValueError):

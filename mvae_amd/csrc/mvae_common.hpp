@@ -10,6 +10,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mvae_hip.h"
@@ -29,13 +30,23 @@ static __device__ unsigned long long g_dbg[64];
 #endif
 // start / end time and kind of every workgroup of launch L (plain stores to per-workgroup slots: no contention)
 static __device__ unsigned long long g_span[6][3][2048];
-#define MV_SPAN_BEGIN(L) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_span[L][0][blockIdx.x] = wall_clock64(); } while (0)
-#define MV_SPAN_END(L, kind) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[L][1][blockIdx.x] = wall_clock64(); g_span[L][2][blockIdx.x] = (kind); } } while (0)
+// the start time stays in a register until the workgroup's end (a store at kernel entry would sit in front of the first
+// s_waitcnt vmcnt(0) of the kernel and add its acknowledgement to the first phase)
+#define MV_SPAN_BEGIN(L) const unsigned long long mv_span0_ = wall_clock64()
+#define MV_SPAN_END(L, kind) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { g_span[L][0][blockIdx.x] = mv_span0_; g_span[L][1][blockIdx.x] = wall_clock64(); g_span[L][2][blockIdx.x] = (kind); } } while (0)
 // the same for another thread of the workgroup, recorded `off` slots further (e.g. the dual waves of launch 2)
-#define MV_SPAN_END_T(L, kind, thr, off) do { if (threadIdx.x == (thr) && blockIdx.x + (off) < 2048) { g_span[L][0][blockIdx.x + (off)] = g_span[L][0][blockIdx.x]; g_span[L][1][blockIdx.x + (off)] = wall_clock64(); g_span[L][2][blockIdx.x + (off)] = (kind); } } while (0)
+#define MV_SPAN_END_T(L, kind, thr, off) do { if (threadIdx.x == (thr) && blockIdx.x + (off) < 2048) { g_span[L][0][blockIdx.x + (off)] = mv_span0_; g_span[L][1][blockIdx.x + (off)] = wall_clock64(); g_span[L][2][blockIdx.x + (off)] = (kind); } } while (0)
+// register-resident stamps: MV_T(i) reads the clock into a local (no store between the phases, so a phase is not charged
+// the acknowledgement of a stamp's own store); MV_TFLUSH(base, n, blk) writes them out at the end of the kernel
+#define MV_TDECL unsigned long long mv_t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MV_T(i) do { mv_t_[i] = wall_clock64(); } while (0)
+#define MV_TFLUSH(base, n, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) { for (int q_ = 0; q_ < (n); ++q_) g_dbg[(base) + q_] = mv_t_[q_]; } } while (0)
 #else
 #define MV_STAMP(i) do {} while (0)
 #define MV_STAMP_B(i, blk) do {} while (0)
+#define MV_TDECL do {} while (0)
+#define MV_T(i) do {} while (0)
+#define MV_TFLUSH(base, n, blk) do {} while (0)
 #define MV_SPAN_BEGIN(L) do {} while (0)
 #define MV_SPAN_END(L, kind) do {} while (0)
 #define MV_SPAN_END_T(L, kind, thr, off) do {} while (0)
@@ -74,6 +85,10 @@ struct CompTable {
   // wave (one instruction stream, no divergence), different kinds run on different waves.
   unsigned char wave_of[kMaxComp];
   unsigned char lane_of[kMaxComp];
+  // the inverse for the first four slots of a wave: component at (wave, slot), or -1 (uniform -- scalar -- lookups in the
+  // 16-row latent kernels, where lane = slot * 16 + row)
+  signed char slot_ci[4][4];
+  mvae_component_desc slot_desc[4][4];  // the descriptor itself (kind = -1: empty slot): ONE uniform load per slot
 };
 
 inline int bucket_of(int dmax) {
@@ -130,6 +145,14 @@ inline int fill_table(CompTable* t, const mvae_component_desc* comps, int ncomp,
         t->lane_of[i] = (unsigned char)fill[w]++;
       }
   }
+  memset(t->slot_ci, -1, sizeof(t->slot_ci));
+  for (int w = 0; w < 4; ++w)
+    for (int sl = 0; sl < 4; ++sl) t->slot_desc[w][sl].kind = -1;
+  for (int i = 0; i < ncomp; ++i)
+    if (t->lane_of[i] < 4) {
+      t->slot_ci[t->wave_of[i]][t->lane_of[i]] = (signed char)i;
+      t->slot_desc[t->wave_of[i]][t->lane_of[i]] = comps[i];
+    }
   return 0;
 }
 
@@ -536,11 +559,26 @@ __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/,
   }
 }
 
-// XCD-aware tile assignment for the NT layers.  Workgroup L is observed to run on XCD L % 8 (MI355X_MICROARCH.md,
-// "Workgroup dispatch"); each XCD has a private L2, so a weight row-block fetched by workgroups on all 8 XCDs crosses
-// the fabric 8 times.  Column tiles (= weight row-blocks) are therefore dealt to XCDs: XCD k owns nt = k, k+8, ... and
-// runs every row tile mt of those; the activation rows are the only operand every XCD fetches.  Placement only
-// changes speed, never results.  Launch with grid = 8 * ceil(NT/8) * MT; returns false for the padding workgroups.
+// XCD-aware tile assignment.  Workgroup L is observed to run on XCD L % 8 (MI355X_MICROARCH.md, "Workgroup dispatch");
+// each XCD has a private L2 that does not survive a kernel boundary, so a weight block fetched by workgroups on all 8
+// XCDs crosses the fabric 8 times per launch.  Weight blocks (= tiles nt of the weight dimension) are therefore dealt
+// to XCDs in groups of G adjacent tiles: XCD k owns the groups k, k+8, ... and runs every row tile mt of those; the
+// activation rows are the only operand every XCD fetches.  G = 1 for K-contiguous weights (NT layers: a tile's weight
+// rows are whole cache lines); G = 2 when a 16-column tile covers only half of each 128-byte line of the weight (NN:
+// dx = dy W), so that both halves of a line are wanted by the same XCD.  Placement only changes speed, never results.
+// Launch with xcd_grid(NT, MT, G) workgroups; returns false for the padding workgroups.
+__host__ __device__ inline int xcd_grid(int NT, int MT, int G = 1) {
+  const int groups = (NT + G - 1) / G;
+  return 8 * ((groups + 7) / 8) * MT * G;
+}
+__device__ __forceinline__ bool xcd_tile_g(int NT, int MT, int G, int* nt, int* mt, int L = blockIdx.x) {
+  const int k = L & 7, s = L >> 3;
+  const int per = MT * G;
+  const int gi = s / per, rem = s - gi * per;
+  *mt = rem / G;
+  *nt = (k + 8 * gi) * G + (rem - (*mt) * G);
+  return *nt < NT;
+}
 __device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L = blockIdx.x) {
   const int k = L & 7, s = L >> 3;
   *nt = k + 8 * (s / MT);

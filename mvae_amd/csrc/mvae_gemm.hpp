@@ -59,12 +59,12 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
       const int k = (cc << 4) + (q << 2);
       const bool ok = cc < nchunks;
       if (FULL) {
+        // pure requests: NO select on a loaded value in this block (it needs the value, so hipcc puts an s_waitcnt
+        // between the requests and the batch becomes two serialized memory round trips); a chunk past the end reads a
+        // clamped address and is zeroed after the barrier
         const int kk = ok ? k : 0;
-        float4 av = *reinterpret_cast<const float4*>(arow + kk);
-        const float4 bv = *reinterpret_cast<const float4*>(wrow + kk);
-        if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
-        a[g] = av;
-        b[g] = bv;
+        a[g] = *reinterpret_cast<const float4*>(arow + kk);
+        b[g] = *reinterpret_cast<const float4*>(wrow + kk);
       } else {
         a[g] = load4_guarded(arow, k, K, a_ok && ok, vecA);
         b[g] = load4_guarded(wrow, k, K, w_ok && ok, vecW);
@@ -75,6 +75,7 @@ __device__ __forceinline__ f32x4 tile_nt(const float* __restrict__ A, int lda, i
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+      if (FULL && c + g * stride >= nchunks) a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = mfma16(a[g].x, b[g].x, acc);
       acc2 = mfma16(a[g].y, b[g].y, acc2);
       acc = mfma16(a[g].z, b[g].z, acc);
@@ -144,11 +145,9 @@ __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, 
       const int cc = c + g * stride;
       const int k = (cc << 4) + (q << 2);
       const bool ok = cc < nchunks;
-      if (FULL) {
+      if (FULL) {  // pure requests (see tile_nt); a chunk past the end is zeroed after the barrier
         const int kk = ok ? k : 0;
-        float4 av = *reinterpret_cast<const float4*>(grow + kk);
-        if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
-        a[g] = av;
+        a[g] = *reinterpret_cast<const float4*>(grow + kk);
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[g][t] = wcol[(size_t)(kk + t) * ldw];
         continue;
@@ -160,6 +159,7 @@ __device__ __forceinline__ f32x4 tile_nn(const float* __restrict__ Gm, int ldg, 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+      if (FULL && c + g * stride >= nchunks) a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = mfma16(a[g].x, b[g][0], acc);
       acc2 = mfma16(a[g].y, b[g][1], acc2);
       acc = mfma16(a[g].z, b[g][2], acc);

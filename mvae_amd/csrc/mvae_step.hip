@@ -30,6 +30,7 @@ struct mvae_ctx {
   // workspace carve (floats)
   int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_total;
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
+  bool no_fwd23;         // MVAE_NO_FWD23=1: keep launches 2 and 3 separate (A/B measurements)
 };
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
@@ -122,6 +123,8 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   }
   c->d.comps = nullptr;
   c->d.radius_trainable = nullptr;
+  const char* nf = getenv("MVAE_NO_FWD23");
+  c->no_fwd23 = nf && nf[0] && nf[0] != '0';
   carve(c, bucket_of(c->dmax));
   *out = c;
   return 0;
@@ -172,13 +175,17 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
   }
   if (!real) return;
   const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
+  // the epilogue's operand is requested with the tile operands (clamped address, no branch): asked for after the
+  // contraction it costs the epilogue a memory round trip of its own
+  const int n_ep = nt * 16 + (threadIdx.x & 15);
+  const float bias = b[n_ep < H ? n_ep : 0];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = tile_nt<7, FULL>(x, D, B, mt * 16, W, D, H, nt * 16, D, wave, kW8, vx, vw, acc);
   const float s = reduce_tiles8(red, acc);
   if (threadIdx.x < 256) {
-    const int m = mt * 16 + (threadIdx.x >> 4), n = nt * 16 + (threadIdx.x & 15);
+    const int m = mt * 16 + (threadIdx.x >> 4), n = n_ep;
     if (FULL || (m < B && n < H)) {
-      const float v = s + b[n];
+      const float v = s + bias;
       h[(size_t)m * H + n] = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
     }
   }
@@ -467,6 +474,317 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   MV_SPAN_END(1, 1);
 }
 
+// ---- 2+3 fused (the BASELINE MLP shapes): heads -> latent components -> first decoder layer -> output layer + BCE in ONE
+// launch, by RECOMPUTING the per-row latent chain in every output tile's workgroup instead of handing it over through
+// memory.  Workgroup (mt, nt) owns the 16 x 16 logits tile of row block mt; everything between `h` and that tile depends
+// only on the 16 rows of the block:
+//     heads[16, NH] = h[16, H] W_heads^T + b      one MFMA tile, K = H split over the 8 waves
+//     z[16, Z], kl                                one lane per (row, component), the same device code as launch 2
+//     hd[16, H]     = relu(z W_d0^T + b)          K = Z <= 8: one column per thread, 16 rows each, result kept in LDS
+//     logits tile   = hd[16, H] W_logits[nt]^T    MFMA with the A operand read from LDS, B prefetched at kernel entry
+// The 49 column tiles of a row block repeat the (tiny) chain 49 times -- the chip is idle otherwise -- and in exchange the
+// step loses a kernel boundary (1.2-1.7 us), a cold first-load phase (~1.7 us) and the round trip of hd through memory;
+// the W_logits / x / bias requests of the output tile are in flight while the chain runs.  The "lead" workgroup of a
+// row block (nt == mt mod ntD: spread over the XCDs) writes what later launches need: heads, z, kl, hd.
+// Forward-mode dual records for launch 5 are produced by extra workgroups of launch 4 (job_duals).
+// Preconditions (checked on the host): NH <= 16, Z <= 8, eps_dim <= 8, ncomp <= 8 with at most 4 components per wave,
+// H <= 512, B, H, D multiples of 16, 16-byte aligned operands.
+template <int DMAX>
+__global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, const float* Wh, const float* bh,
+                                               const float* eps, int eps_ld, const float* radii, const float* Wd0,
+                                               const float* bd0, const float* Wl, const float* bl, const float* x,
+                                               float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
+                                               float* kl_user, float* hd, float* g, float* bce_part,
+                                               float* logits_user, int B, int H, int D, int NH, int Z) {
+  // dynamic LDS: hd_s[16][ld] | wl_s[32][ld] | wd_s[H][8] | bd_s[H]     (ld = H + 4: conflict-free ds_read_b128 of the
+  // 16 rows an MFMA operand fetch touches)
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  __shared__ float red[kW8][16][17];
+  __shared__ float red2[kW8][16][17];  // second column tile of the pair
+  __shared__ __attribute__((aligned(16))) float heads_s[16][16];
+  __shared__ __attribute__((aligned(16))) float z_s[16][8];
+  __shared__ __attribute__((aligned(16))) float eps_s[16][8];
+  __shared__ float rad_s[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int mt, nt;
+  MV_SPAN_BEGIN(2);
+  // A workgroup owns TWO adjacent column tiles (16 x 32 logits): the per-row-block chain and its operands (h rows,
+  // W_heads: 51 KB) are shared by twice the output, and the grid (8 row blocks x 25 pairs = 200 workgroups) puts exactly
+  // one workgroup on a CU.
+  const int ntD = D >> 4, ntP = (ntD + 1) >> 1;
+  int pt;
+  if (!xcd_tile(ntP, B >> 4, &pt, &mt)) return;
+  nt = pt * 2;
+  const bool two = nt + 1 < ntD;  // the last pair of an odd tile count has one tile
+  const bool lead = pt == mt % ntP;
+  MV_TDECL;
+  MV_T(0);
+  const int ld = H + 4;
+  float* hd_s = dyn;
+  float* wl_s = dyn + 16 * ld;
+  float* wd_s = wl_s + 32 * ld;
+  float* bd_s = wd_s + H * 8;
+  const int i = lane & 15, q = lane >> 4;
+  const int nchunks = H >> 4;
+
+  // ---- requests of the FIRST phase only (branch-free, clamped addresses).  A CU's load path serves requests in issue
+  // order at ~30 cycles per wave-level request: everything a later phase needs is fetched later, by waves that would
+  // otherwise idle (see the component phase), so that nothing queues in front of these.
+  const float* hrow = h + (size_t)(mt * 16 + i) * H;
+  const float* whrow = Wh + (size_t)(i < NH ? i : 0) * H;
+  float4 ha[4], hb[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int c = wave + 8 * gq;
+    const int k = ((c < nchunks ? c : 0) << 4) + (q << 2);
+    ha[gq] = *reinterpret_cast<const float4*>(hrow + k);
+    hb[gq] = *reinterpret_cast<const float4*>(whrow + k);  // rows past NH re-read row 0: their columns are never used
+  }
+  const float bhv = bh[(tid & 15) < NH ? (tid & 15) : 0];
+  float epsv = 0.f;
+  {
+    const int r = (tid >> 3) & 15, j = tid & 7;
+    epsv = eps[(size_t)(mt * 16 + r) * eps_ld + (j < eps_ld ? j : 0)];
+  }
+  const float rad_r = radii[tid < t.n ? tid : 0];
+  // epilogue operands: threads 0..255 take the first tile of the pair, 256..511 the second
+  const int nt_ep = (tid < 256 || !two) ? nt : nt + 1;
+  const int m_ep = mt * 16 + ((tid & 255) >> 4), n_ep = nt_ep * 16 + (tid & 15);
+  const float tv = x[(size_t)m_ep * D + n_ep];
+  const float bias = bl[n_ep];
+  __builtin_amdgcn_sched_barrier(0);
+  // this lane's component: lane = slot * 16 + row; the four slot descriptors of this wave are fetched with UNIFORM
+  // (scalar) loads, all four in flight at once while the vector requests above travel, and selected per lane without a
+  // branch.  (A per-lane index into the kernarg table would be a vector load that hipcc sinks to its first use.)
+  mvae_component_desc my_desc;
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(wave) & 3;
+    const mvae_component_desc d0 = t.slot_desc[wv][0], d1 = t.slot_desc[wv][1], d2 = t.slot_desc[wv][2],
+                              d3 = t.slot_desc[wv][3];
+    const int sl = lane >> 4;
+#define MV_SEL(f) my_desc.f = (sl == 0 ? d0.f : (sl == 1 ? d1.f : (sl == 2 ? d2.f : d3.f)))
+    MV_SEL(kind); MV_SEL(true_dim); MV_SEL(mean_col); MV_SEL(logvar_col); MV_SEL(logvar_dim); MV_SEL(eps_col);
+    MV_SEL(z_col); MV_SEL(radius_idx);
+#undef MV_SEL
+  }
+  const int my_ci = (wave < 4 && my_desc.kind >= 0) ? my_desc.radius_idx : -1;  // radius_idx == component index here
+  if (tid < 8) rad_s[tid] = rad_r;
+  if (tid < 128) {
+    eps_s[tid >> 3][tid & 7] = (tid & 7) < eps_ld ? epsv : 0.f;
+    z_s[tid >> 3][tid & 7] = 0.f;  // columns past Z stay zero (K of the hd tiles is padded to 8)
+  }
+  // ---- heads = h W_heads^T + b
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (wave + 8 * gq >= nchunks) ha[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = mfma16(ha[gq].x, hb[gq].x, acc);
+      acc2 = mfma16(ha[gq].y, hb[gq].y, acc2);
+      acc = mfma16(ha[gq].z, hb[gq].z, acc);
+      acc2 = mfma16(ha[gq].w, hb[gq].w, acc2);
+    }
+    MV_T(1);
+    const float sv = reduce_tiles8(red, acc + acc2);
+    MV_T(2);
+    if (tid < 256) {
+      const int r = tid >> 4, n = tid & 15;
+      const float v = n < NH ? sv + bhv : 0.f;
+      heads_s[r][n] = v;
+      if (lead && n < NH) heads[(size_t)(mt * 16 + r) * ldh + n] = v;
+    }
+  }
+  lds_barrier();
+  MV_T(3);
+
+  // ---- waves 0..3: the latent components, one lane per (slot, row) -- a ~2 us dependent chain on a handful of lanes.
+  // ---- waves 4..7 meanwhile stage the operands of the two remaining phases in LDS: W_d0 / b_d0 (first decoder layer) and
+  // the two 16-row blocks of W_logits (B operands of the output tiles), 16-byte coalesced requests.
+  if (wave < 4) {
+    const int r = lane & 15;
+    if (my_ci >= 0) {
+      float klv;
+      const size_t row = (size_t)mt * 16 + r;
+      comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, &klv, nullptr,
+                         nullptr, nullptr, nullptr);
+      if (lead) {
+        kl[(size_t)my_ci * B + row] = klv;
+        if (kl_user) kl_user[(size_t)my_ci * B + row] = klv;
+      }
+    }
+  } else {
+    const int lt = tid - 256;  // 0..255
+    const int H4 = H >> 2;     // float4 per row of W_logits
+    // W_logits rows nt*16 .. nt*16+31 (the second tile repeats the first when the pair is incomplete)
+    constexpr int kWl = 13;  // ceil(32 * 128 / 256): rows of up to 512 floats
+    f32x4 wv[kWl];  // native vectors: whole-struct copies of HIP's float4 keep the array in scratch
+#pragma unroll
+    for (int u = 0; u < kWl; ++u) {
+      const int e4 = lt + 256 * u;
+      const int r = e4 / H4, c4 = e4 - r * H4;
+      const int rr = r < 32 ? r : 0;
+      const int grow = (rr < 16 || two) ? nt * 16 + rr : nt * 16 + rr - 16;
+      wv[u] = *reinterpret_cast<const f32x4*>(Wl + (size_t)grow * H + 4 * (r < 32 ? c4 : 0));
+    }
+    // W_d0 [H][Z] -> wd_s[H][8] (zero-padded columns), b_d0 -> bd_s
+    f32x4 dv[4];
+    const int nd4 = (H * Z) >> 2;  // Z == 8 or Z == 4: whole float4 (checked on the host: Z % 4 == 0), else scalar path
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = lt + 256 * u;
+      dv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nd4 ? e4 : 0));
+    }
+    float bdv2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = lt + 256 * u;
+      bdv2[u] = bd0[c < H ? c : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < kWl; ++u) {
+      const int e4 = lt + 256 * u;
+      const int r = e4 / H4, c4 = e4 - r * H4;
+      if (r < 32) *reinterpret_cast<f32x4*>(wl_s + r * ld + 4 * c4) = wv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = lt + 256 * u;
+      if (e4 < nd4) {
+        if (Z == 8) {
+          *reinterpret_cast<f32x4*>(wd_s + 4 * e4) = dv[u];
+        } else {  // Z == 4: row c = e4, columns 0..3; columns 4..7 are zero
+          *reinterpret_cast<f32x4*>(wd_s + 8 * e4) = dv[u];
+          *reinterpret_cast<f32x4*>(wd_s + 8 * e4 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = lt + 256 * u;
+      if (c < H) bd_s[c] = bdv2[u];
+    }
+  }
+  lds_barrier();
+  MV_T(4);
+  if (lead && z_user && tid < 16 * Z) z_user[((size_t)mt * 16 + tid / Z) * Z + tid % Z] = z_s[tid / Z][tid % Z];
+
+  // ---- hd = relu(z W_d0^T + b) as MFMA tiles (K = 8: two 16x16x4 steps per 16 columns), kept in LDS as the A operand
+  // of the output layer.  A[i][k] = z[i][k] (zero past Z): lane (i, q) supplies k = q and q + 4.
+  {
+    const float za0 = z_s[i][q];
+    const float za1 = z_s[i][q + 4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int c = wave + 8 * gq;
+      if (c < nchunks) {  // wave-uniform
+        const int col = (c << 4) + i;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = mfma16(za0, wd_s[col * 8 + q], a);
+        a = mfma16(za1, wd_s[col * 8 + q + 4], a);
+        const float bv = bd_s[col];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float v = a[r4] + bv;
+          v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+          hd_s[(q * 4 + r4) * ld + col] = v;
+        }
+      }
+    }
+  }
+  lds_barrier();
+  MV_T(5);
+  if (lead) {  // launches 4 and 5 read hd (ReLU mask, operand of dW_logits): coalesced 16-byte rows
+    for (int e4 = tid; e4 < 4 * H; e4 += 512) {
+      const int r = e4 / (H >> 2), c4 = e4 - r * (H >> 2);
+      *reinterpret_cast<float4*>(hd + ((size_t)mt * 16 + r) * H + 4 * c4) =
+          *reinterpret_cast<const float4*>(hd_s + r * ld + 4 * c4);
+    }
+  }
+
+  // ---- the two logits tiles = hd W_logits[nt, nt+1]^T (both operands from LDS), BCE-with-logits and its gradient
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, bcc = {0.f, 0.f, 0.f, 0.f}, bcc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int c = wave + 8 * gq;
+    if (c < nchunks) {  // wave-uniform
+      const int k = (c << 4) + (q << 2);
+      const float4 av = *reinterpret_cast<const float4*>(hd_s + i * ld + k);
+      const float4 b1 = *reinterpret_cast<const float4*>(wl_s + i * ld + k);
+      const float4 b2 = *reinterpret_cast<const float4*>(wl_s + (16 + i) * ld + k);
+      acc = mfma16(av.x, b1.x, acc);
+      bcc = mfma16(av.x, b2.x, bcc);
+      acc2 = mfma16(av.y, b1.y, acc2);
+      bcc2 = mfma16(av.y, b2.y, bcc2);
+      acc = mfma16(av.z, b1.z, acc);
+      bcc = mfma16(av.z, b2.z, bcc);
+      acc2 = mfma16(av.w, b1.w, acc2);
+      bcc2 = mfma16(av.w, b2.w, bcc2);
+    }
+  }
+  MV_T(6);
+  // both partial tiles go to LDS under one barrier; threads 0..255 add up the first tile, 256..511 the second
+  float sv;
+  {
+    const f32x4 pa = acc + acc2, pb = bcc + bcc2;
+    const int col = lane & 15, rbase = (lane >> 4) << 2;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      red[wave][rbase + r4][col] = pa[r4];
+      red2[wave][rbase + r4][col] = pb[r4];
+    }
+    lds_barrier();
+    const int r = (tid & 255) >> 4, c = tid & 15;
+    float (*rr)[16][17] = tid < 256 ? red : red2;
+    sv = ((rr[0][r][c] + rr[1][r][c]) + (rr[2][r][c] + rr[3][r][c])) +
+         ((rr[4][r][c] + rr[5][r][c]) + (rr[6][r][c] + rr[7][r][c]));
+  }
+  MV_T(7);
+  if (tid >= 256 && !two) return;
+  const float y = sv + bias;
+  // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
+  const float e = expf(-fabsf(y));
+  const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
+  float loss = (1.f - tv) * y - log_sig;
+  const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+  loss += __shfl_xor(loss, 8, 16);  // sum over the tile's 16 columns (the 16 lanes of one row are contiguous)
+  loss += __shfl_xor(loss, 4, 16);
+  loss += __shfl_xor(loss, 2, 16);
+  loss += __shfl_xor(loss, 1, 16);
+  g[(size_t)m_ep * D + n_ep] = sig - tv;  // d(sum bce)/d(logit)
+  if (logits_user) logits_user[(size_t)m_ep * D + n_ep] = y;
+  if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = loss;
+  MV_TFLUSH(24, 8, 96);
+  MV_SPAN_END(2, 1);
+}
+
+// Forward-mode dual records of the latent components (d kl / d dir and d z / d dir for every input direction of every
+// (row, component)), one thread per record: what waves 4..7 of k_latent_fwd produce in the six-launch step.  In the
+// fused step they are computed by extra workgroups of launch 4, off every critical path (they need heads / eps / radii
+// from the forward launch and are consumed by launch 5).
+template <int DMAX>
+__device__ __forceinline__ void job_duals(const CompTable& t, const float* heads, int ldh, const float* eps, int eps_ld,
+                                          const float* radii, float* duals, int B, int NH, int item) {
+  // item = direction-major: the 64 lanes of a wave hold 64 rows of ONE (component, direction), i.e. one manifold kind:
+  // one instruction stream per wave, no divergence
+  constexpr int AM = DMAX + 1, DS = DMAX + 2;
+  const int total = t.total_dirs;
+  if (item >= B * total) return;
+  const int gd = item / B, row = item - gd * B;
+  int ci = 0;
+  while (gd >= t.dir_off[ci + 1]) ++ci;
+  const int dir = gd - t.dir_off[ci];
+  const mvae_component_desc c = t.c[ci];
+  float zd[AM];
+  const float kld = comp_dual_dir<DMAX>(c, heads + (size_t)row * ldh, eps + (size_t)row * eps_ld, radii, dir, zd);
+  float* rec = duals + ((size_t)row * (NH + t.n) + t.first_dir[ci] + dir) * DS;
+  const int A = ambient_dim(c.kind, c.true_dim);
+  rec[0] = kld;
+#pragma unroll
+  for (int k = 0; k < AM; ++k)
+    if (k < A) rec[1 + k] = zd[k];
+}
+
 // ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
 template <bool FULL>
 __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
@@ -476,55 +794,87 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   int mt, nt;
   MV_SPAN_BEGIN(2);
   if (!xcd_tile((D + 15) / 16, (B + 15) / 16, &nt, &mt)) return;
+  MV_TDECL;
+  MV_T(0);
   const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
   const bool ok = threadIdx.x < 256 && m < B && n < D;
-  float tv = 0.f, bias = 0.f;
-  if (ok) {  // epilogue operands requested up front
-    tv = x[(size_t)m * D + n];
-    bias = b[n];
-  }
+  // epilogue operands requested up front, branch-free (clamped addresses; `ok` is applied in the epilogue)
+  const float tv = x[(size_t)(m < B ? m : 0) * D + (n < D ? n : 0)];
+  const float bias = b[n < D ? n : 0];
   const bool v1 = aligned16(hd) && (H & 3) == 0, v2 = aligned16(W) && (H & 3) == 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = tile_nt<4, FULL>(hd, H, B, mt * 16, W, H, D, nt * 16, H, wave, kW8, v1, v2, acc);
+  MV_T(1);
   const float s = reduce_tiles8(red, acc);
+  MV_T(2);
   if (threadIdx.x >= 256) return;
-  float loss = 0.f;
-  if (ok) {
-    const float y = s + bias;
-    // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
-    const float e = expf(-fabsf(y));
-    const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
-    loss = (1.f - tv) * y - log_sig;
-    const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
-    g[(size_t)m * D + n] = sig - tv;  // d(sum bce)/d(logit)
-    if (logits_user) logits_user[(size_t)m * D + n] = y;
-  }
-  // sum over the tile's 16 columns: the 16 lanes of one row are contiguous
+  const float y = s + bias;
+  // F.binary_cross_entropy_with_logits (image_reconstruction.py:81-82): (1-t)*y - log_sigmoid(y)
+  const float e = expf(-fabsf(y));
+  const float log_sig = fminf(y, 0.f) - mvf::log1p_pos(e);
+  float loss = ok ? (1.f - tv) * y - log_sig : 0.f;
+  const float sig = (y >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+  // sum over the tile's 16 columns (the 16 lanes of one row are contiguous) BEFORE the stores: hipcc drains vmcnt in
+  // front of the cross-lane operations, which would otherwise wait for the store acknowledgements
   loss += __shfl_xor(loss, 8, 16);
   loss += __shfl_xor(loss, 4, 16);
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
+  if (ok) {
+    g[(size_t)m * D + n] = sig - tv;  // d(sum bce)/d(logit)
+    if (logits_user) logits_user[(size_t)m * D + n] = y;
+  }
+  MV_T(3);
   if ((threadIdx.x & 15) == 0 && m < B) bce_part[(size_t)nt * B + m] = loss;
+  MV_TFLUSH(20, 4, 96);
   MV_SPAN_END(2, 1);
 }
 
 // ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
-template <bool ADAM, bool FULL>
-__global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* hd, const float* W, float* db,
+#ifndef MV_DHD_GROUP
+#define MV_DHD_GROUP 2
+#endif
+constexpr int kDhdGroup = MV_DHD_GROUP;  // adjacent 16-column tiles of W_logits owned by one XCD (see xcd_tile_g)
+// DUAL > 0 (fused step): the first n_dual workgroups compute the forward-mode dual records of the latent components
+// (job_duals<DUAL>), one thread per (row, input direction).
+struct DualArgs {
+  const float* heads;
+  const float* eps;
+  const float* radii;
+  float* duals;
+  int ldh, eps_ld, NH, n_dual;
+};
+template <bool ADAM, bool FULL, int DUAL>
+__global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
-                                                  int n_db, AdamArgs ab) {
+                                                  int n_db, AdamArgs ab, DualArgs da) {
   __shared__ float red[kW8][16][17];
+  // Workgroup order: the short jobs first (statistics, bias column sums, padded to a multiple of 8 so that the tile
+  // workgroups keep L % 8 == XCD), then the dhd tiles.  The grid is larger than the chip: workgroups dispatched last
+  // share a CU, which costs a tile workgroup little when the other one is short, but made the statistics workgroup the
+  // tail of the launch when it came last.
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
+  const int n_dual = DUAL > 0 ? da.n_dual : 0;
+  const int n_short = (n_dual + 1 + n_db + 7) & ~7;
   MV_SPAN_BEGIN(3);
-  if (b < n_dhd) {
-    const int mt = b / ntH, nt = b % ntH;
+  if (DUAL > 0 && b < n_dual) {  // the longest chains of the launch: dispatched first, ONE wave per workgroup (= per CU)
+    if (threadIdx.x < 64)
+      job_duals<(DUAL > 0 ? DUAL : 2)>(t, da.heads, da.ldh, da.eps, da.eps_ld, da.radii, da.duals, B, da.NH,
+                                       b * 64 + (int)threadIdx.x);
+    MV_SPAN_END(3, 4);
+    return;
+  }
+  b -= n_dual;
+  if (b >= n_short - n_dual) {  // n_dhd = xcd_grid(ntH, ntB, kDhdGroup): W_logits column blocks are dealt to XCDs
+    b -= n_short - n_dual;
+    int mt, nt;
+    if (!xcd_tile_g(ntH, (B + 15) / 16, kDhdGroup, &nt, &mt, b)) return;
     const int wave = threadIdx.x >> 6;
     const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
     const bool ok = threadIdx.x < 256 && m < B && n < H;
-    float mask = 0.f;
-    if (ok) mask = hd[(size_t)m * H + n];
+    const float mask = hd[(size_t)(m < B ? m : 0) * H + (n < H ? n : 0)];  // branch-free request, used in the epilogue
     const bool vg = aligned16(g) && (D & 3) == 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = tile_nn<7, FULL>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
@@ -533,40 +883,79 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
     MV_SPAN_END(3, 1);
     return;
   }
-  b -= n_dhd;
-  if (b < n_db) {
+  if (b > n_db) return;  // padding
+  if (b >= 1) {
+    b -= 1;
     job_colsum_opt<ADAM>(&red[0][0][0], g, D, B, D, b * kColsPerBlock, db, ab);
     MV_SPAN_END(3, 2);
     return;
   }
-  // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo
-  float* sm = &red[0][0][0];  // >= 512 floats
+  // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo.
+  // Thread (row r, part p) adds its quarter of the column tiles of the row's BCE partials with every load in flight at
+  // once (one memory round trip instead of one per 8 tiles: this workgroup used to be the tail of the launch); the P
+  // part sums of a row meet in LDS and are added in part order, so the result is deterministic.
+  float* sm = &red[0][0][0];  // kW8 * 16 * 17 = 2176 floats: [0, 64) block sums / component sums, [64, ...) part sums
+  __shared__ float kl_s[4096];   // kl[i][r] of this step when ncomp * B fits: the per-component sums then read LDS
+  __shared__ float old_s[8 + kMaxComp];  // the running sums this step is added to, requested with the first loads
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool kl_in_lds = (size_t)ncomp * B <= 4096;
+  if (tid < 4 + ncomp) old_s[tid] = stats[tid];
+  const int P = (4 * B <= nthr) ? 4 : ((2 * B <= nthr) ? 2 : 1);
+  const int rows_pass = nthr / P;  // rows handled per pass
+  const int chunk = (ntD + P - 1) / P;
   float bce_acc = 0.f, elbo_acc = 0.f;
-  for (int r = tid; r < B; r += nthr) {
-    float bce = 0.f;
-    int nt = 0;
-    for (; nt + 7 < ntD; nt += 8) {  // 8 loads in flight, added in index order
-      float v[8];
+  for (int r0 = 0; r0 < B; r0 += rows_pass) {
+    const int rl = tid % rows_pass, p = tid / rows_pass;
+    const int r = r0 + rl;
+    const bool act = p < P && r < B;
+    const int rr = act ? r : 0;
+    float part = 0.f;
+    for (int nt0 = p * chunk; nt0 < (p + 1) * chunk && nt0 < ntD; nt0 += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = bce_part[(size_t)(nt + u) * B + r];
+      for (int u = 0; u < 16; ++u) {
+        const int nt = nt0 + u;
+        const bool ok = nt < (p + 1) * chunk && nt < ntD;
+        const float x = bce_part[(size_t)(ok ? nt : 0) * B + rr];
+        v[u] = ok ? x : 0.f;
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) bce += v[u];
+      for (int u = 0; u < 16; ++u) part += v[u];
     }
-    for (; nt < ntD; ++nt) bce += bce_part[(size_t)nt * B + r];
-    if (bce_user) bce_user[r] = bce;
-    float klr = kl[r];
-    int i = 1;
-    for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
-      float v[8];
+    float klr = 0.f;
+    if (p == 0 && act) {  // requested before the barrier below
+      klr = kl[r];
+      if (kl_in_lds) kl_s[r] = klr;
+      int i = 1;
+      for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+        for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) klr += v[u];
+        for (int u = 0; u < 8; ++u) {
+          klr += v[u];
+          if (kl_in_lds) kl_s[(size_t)(i + u) * B + r] = v[u];
+        }
+      }
+      for (; i < ncomp; ++i) {
+        const float v = kl[(size_t)i * B + r];
+        klr += v;
+        if (kl_in_lds) kl_s[(size_t)i * B + r] = v;
+      }
     }
-    for (; i < ncomp; ++i) klr += kl[(size_t)i * B + r];
-    bce_acc += bce;
-    elbo_acc += (-bce - beta * klr);
+    if (P > 1) {
+      if (p < P) sm[64 + p * rows_pass + rl] = part;
+      __syncthreads();
+    }
+    if (p == 0 && act) {
+      float bce = part;
+      if (P == 2) bce = sm[64 + rl] + sm[64 + rows_pass + rl];
+      if (P == 4) bce = (sm[64 + rl] + sm[64 + rows_pass + rl]) + (sm[64 + 2 * rows_pass + rl] + sm[64 + 3 * rows_pass + rl]);
+      if (bce_user) bce_user[r] = bce;
+      bce_acc += bce;
+      elbo_acc += (-bce - beta * klr);
+    }
+    if (P > 1) __syncthreads();
   }
   // block-wide sum: wavefront shuffles, then the (<= 8) wave totals meet in LDS -- two barriers per reduction
   auto block_sum = [&](float v) -> float {
@@ -581,15 +970,20 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
   const float bce_sum = block_sum(bce_acc);
   const float elbo_sum = block_sum(elbo_acc);
   const int last = 4 + ncomp;
+  __syncthreads();
   // per-component KL sums: one wave per component (waves take components round-robin), rows summed in lane order
   {
     const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
     for (int i = wave; i < ncomp; i += nw) {
       float a = 0.f;
-      for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
+      if (kl_in_lds) {
+        for (int r = lane; r < B; r += 64) a += kl_s[(size_t)i * B + r];
+      } else {
+        for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
+      }
       a = wave_sum(a);
       if (lane == 0) {
-        stats[4 + i] += a;
+        stats[4 + i] = old_s[4 + i] + a;
         stats[last + 4 + i] = a;
         sm[16 + i] = a;
       }
@@ -599,10 +993,10 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(const float* g, const float* h
   float kl_total = 0.f;
   if (tid == 0) {
     for (int i = 0; i < ncomp; ++i) kl_total += sm[16 + i];
-    stats[0] += bce_sum;
-    stats[1] += kl_total;
-    stats[2] += elbo_sum;
-    stats[3] += 1.f;
+    stats[0] = old_s[0] + bce_sum;
+    stats[1] = old_s[1] + kl_total;
+    stats[2] = old_s[2] + elbo_sum;
+    stats[3] = old_s[3] + 1.f;
     stats[last + 0] = bce_sum;
     stats[last + 1] = kl_total;
     stats[last + 2] = elbo_sum;
@@ -632,6 +1026,11 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   MV_SPAN_BEGIN(4);
   if (b >= n_rows) {  // dW_logits[D,H] tile
     b -= n_rows;
+#ifdef MV_TILE_SLEEP
+    // let the row workgroups' requests (the critical path of this launch) enter the memory system first: the tile
+    // workgroups move ~16 MB and would otherwise queue ahead of them
+    __builtin_amdgcn_s_sleep(MV_TILE_SLEEP);
+#endif
     const int ntHg = ((H + 15) / 16 + kTileWaves5 - 1) / kTileWaves5;
     if (FAST) job_tn_wave<ADAM, true>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
     else job_tn_wave<ADAM, false>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
@@ -1050,12 +1449,13 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
 static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
                      int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
                      hipEvent_t* ev) {
-  int ki = 0;  // launch index; with `ev` != NULL launch k is bracketed by ev[2k] (start) / ev[2k+1] (stop)
+  // profile slot of the next launch (0 enc_fwd, 1 latent_fwd, 2 dec1_fwd | the fused 2+3, 3 dec1_bwd, 4 latent_bwd,
+  // 5 enc_bwd); with `ev` != NULL the launch is bracketed by ev[2 ki] (start) / ev[2 ki + 1] (stop)
+  int ki = 0;
 #define STEP_LAUNCH(KERN, GRID, BLOCK, LDS, ...)                                                              \
   do {                                                                                                         \
     if (ev) hipExtLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, ev[2 * ki], ev[2 * ki + 1], 0, __VA_ARGS__);      \
     else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, __VA_ARGS__);                                          \
-    ++ki;                                                                                                      \
   } while (0)
   if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const mvae_model_desc& d = c->d;
@@ -1086,13 +1486,42 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
   const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
                     aligned16(P + d.off_w_logits) && aligned16(ws);
+  ki = 0;
   if (full)
     STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
                 P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
   else
     STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
                 P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
+  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
+  int max_slot = 0;
+  for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
+  const bool fwd23 = fast && full && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 && bucket_of(c->dmax) <= 8 &&
+                     !c->no_fwd23;
+  if (fwd23) {
+    ki = 2;
+    const size_t lds = ((size_t)48 * (H + 4) + (size_t)H * 9) * sizeof(float);
+#define LF23(DM)                                                                                                     \
+  {                                                                                                                  \
+    static size_t lds_set = 0; /* more than 64 KB of dynamic LDS has to be allowed once per kernel */                \
+    if (lds > lds_set) {                                                                                             \
+      auto kfn_ = &k_fwd23<DM>;                                                                                      \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn_),                                       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e_ != hipSuccess) return hip_fail(e_, "hipFuncSetAttribute(k_fwd23)");                                     \
+      lds_set = lds;                                                                                                 \
+    }                                                                                                                \
+  }                                                                                                                  \
+  STEP_LAUNCH((k_fwd23<DM>), dim3(8 * (((c->nt_d + 1) / 2 + 7) / 8) * c->nt_b), dim3(512), lds, c->t, h, P + d.off_w_heads,   \
+              P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
+              P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
+              NH, Z)
+    const int bk = bucket_of(c->dmax);
+    if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
+#undef LF23
+  } else {
   {
+    ki = 1;
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
 #define LF(DM, FA)                                                                                                   \
   STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(512), lds, c->t, h, P + d.off_w_heads,                 \
@@ -1101,23 +1530,34 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
 #undef LF
   }
+  ki = 2;
   if (full)
     STEP_LAUNCH(k_dec1_fwd<true>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
                 P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
   else
     STEP_LAUNCH(k_dec1_fwd<false>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
                 P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
+  }
   {
-    const int n_dhd = c->nt_b * c->nt_h, n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
-#define DB(AD, FU)                                                                                             \
-  STEP_LAUNCH((k_dec1_bwd<AD, FU>), dim3(n_dhd + n_db + 1), dim3(512), 0, g, hd, P + d.off_w_logits,               \
+    const int n_dhd = xcd_grid(c->nt_h, c->nt_b, kDhdGroup), n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
+    ki = 3;
+    DualArgs da = {heads, eps, P + d.off_radii, duals, c->ldh, d.eps_dim, NH, 0};
+    if (fwd23) da.n_dual = (B * c->t.total_dirs + 63) / 64;
+    const int n_short = (da.n_dual + 1 + n_db + 7) & ~7;
+#define DB(AD, FU, DU)                                                                                         \
+  STEP_LAUNCH((k_dec1_bwd<AD, FU, DU>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits,     \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
-              at(d.off_b_logits))
-    if (fused) { if (full) DB(true, true); else DB(true, false); }
-    else { if (full) DB(false, true); else DB(false, false); }
+              at(d.off_b_logits), da)
+    if (fwd23) {  // full && dmax bucket in {2, 4, 8}
+      const int bk = bucket_of(c->dmax);
+      if (fused) { if (bk == 2) DB(true, true, 2); else if (bk == 4) DB(true, true, 4); else DB(true, true, 8); }
+      else { if (bk == 2) DB(false, true, 2); else if (bk == 4) DB(false, true, 4); else DB(false, true, 8); }
+    } else if (fused) { if (full) DB(true, true, 0); else DB(true, false, 0); }
+    else { if (full) DB(false, true, 0); else DB(false, false, 0); }
 #undef DB
   }
   {
+    ki = 4;
     const int n_dwl = c->nt_d * ((c->nt_h + kTileWaves5 - 1) / kTileWaves5);
     const size_t lds = ((((size_t)H + 3) & ~(size_t)3) + 1024 + 8) * sizeof(float);  // dhd row | dz partials
 #define LB(DM, FA, AD)                                                                                              \
@@ -1132,6 +1572,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #undef LB
   }
   {
+    ki = 5;
     const int tw = kTileWaves;
     const int n_we0 = c->nt_h * ((c->nt_d + tw - 1) / tw), n_wh = ((NH + 15) / 16) * ((c->nt_h + tw - 1) / tw),
               n_wd0 = c->nt_h * (((Z + 15) / 16 + tw - 1) / tw);
@@ -1188,11 +1629,14 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
     // of that dispatch alone, the quantity rocprofv3 --kernel-trace reports
     rc = step_impl(c, x, eps, beta, true, do_curvature_step, 0, nullptr, nullptr, nullptr, nullptr, stream, ev);
     if (rc) break;
-    hipError_t e = hipEventSynchronize(ev[2 * NK - 1]);
-    if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
-    for (int k = 0; k < NK; ++k) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize"); break; }
+    for (int k = 0; k < NK; ++k) {  // a slot the step did not use (launch 2 of the fused forward) stays 0
       float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
+      if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess) {
+        ms = 0.f;
+        (void)hipGetLastError();
+      }
       acc[k] += ms;
     }
   }

@@ -24,12 +24,13 @@ N = 50
 for i in range(N):
     eng.train_step(xs[i % 8], eps[i % 8], 1.0, False)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 48)()
     lib.mvae_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    lib.mvae_debug_read(buf, 32)
+    lib.mvae_debug_read(buf, 48)
     v = [int(x) for x in buf]
     d = [(v[1]-v[0]), (v[2]-v[1]), (v[3]-v[2]), (v[4]-v[3]), (v[9]-v[8]), (v[10]-v[9]), (v[11]-v[10]), (v[12]-v[11]),
-         (v[17]-v[16]), (v[18]-v[17])]
+         (v[17]-v[16]), (v[18]-v[17]), (v[21]-v[20]), (v[22]-v[21]), (v[23]-v[22])] + \
+        [(v[25 + j] - v[24 + j]) for j in range(7)]
     sp = (C.c_ulonglong * (6 * 3 * 2048))()
     lib.mvae_debug_read_spans(sp)
     spans = {}
@@ -38,25 +39,39 @@ for i in range(N):
         base = L * 3 * 2048
         st, en, kd = sp[base:base + 2048], sp[base + 2048:base + 4096], sp[base + 4096:base + 6144]
         used = [i for i in range(2048) if kd[i]]
+        if not used:  # launch not part of this step (launch 2 of the fused forward)
+            continue
         t0 = min(st[i] for i in used)
         bounds.append((t0, max(en[i] for i in used)))
         for kind in sorted(set(kd[i] for i in used)):
             ends = sorted((en[i] - t0) * 10 for i in used if kd[i] == kind)
-            spans.setdefault((L, kind), []).append((ends[len(ends) // 2], ends[-1], len(ends)))
-    gaps = [(bounds[L + 1][0] - bounds[L][1]) * 10 for L in range(5)] + [(bounds[5][1] - bounds[0][0]) * 10]
+            starts = sorted((st[i] - t0) * 10 for i in used if kd[i] == kind)
+            durs = sorted((en[i] - st[i]) * 10 for i in used if kd[i] == kind)
+            spans.setdefault((L, kind), []).append((ends[len(ends) // 2], ends[-1], len(ends), starts[len(starts) // 2],
+                                                    starts[-1], durs[len(durs) // 2], durs[-1]))
+    nb = len(bounds)
+    gaps = [(bounds[L + 1][0] - bounds[L][1]) * 10 for L in range(nb - 1)] + [(bounds[-1][1] - bounds[0][0]) * 10]
     gap_acc = gaps if i == 0 else [a + b for a, b in zip(gap_acc, gaps)]
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
+    wv = [v[32 + j] for j in range(8)]
+    wacc = wv if i == 0 else [a + b for a, b in zip(wacc, wv)]
 names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:dot", "bwd:dh",
-         "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores"]
+         "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores", "dec1_fwd tile:loads+mfma", "dec1_fwd tile:reduce",
+         "dec1_fwd tile:epilogue", "fwd23: loads+heads mfma", "fwd23: heads reduce", "fwd23: heads_s/tables",
+         "fwd23: components", "fwd23: hd", "fwd23: logits mfma", "fwd23: reduce"]
 for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
+print("fwd23 per-wave time to the end of the heads MFMA (ns):", [round(a / N * 10) for a in wacc])
 KERNELS = ["enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd"]
 KINDS = {(0, 1): "tiles", (1, 1): "main waves", (1, 2): "dual waves", (2, 1): "tiles", (3, 1): "dhd tiles",
-         (3, 2): "db_logits", (3, 3): "statistics", (4, 1): "rows", (4, 2): "dW_logits tiles", (5, 1): "dW_e0 tiles",
+         (3, 2): "db_logits", (3, 3): "statistics", (3, 4): "dual records", (4, 1): "rows", (4, 2): "dW_logits tiles", (5, 1): "dW_e0 tiles",
          (5, 2): "dW_heads", (5, 3): "dW_d0", (5, 4): "b_e0", (5, 5): "b_heads", (5, 6): "b_d0", (5, 7): "radii"}
 import numpy as np
 print("per launch: workgroup END time after the first workgroup's start, ns (median / latest over workgroups)")
 for (L, kind), v in sorted(spans.items()):
     med = np.mean([x[0] for x in v]); mx = np.mean([x[1] for x in v])
-    print(f"  {KERNELS[L]:11s} {KINDS.get((L, kind), kind):16s} n={v[0][2]:4d}  median {med:7.0f}  latest {mx:7.0f}")
+    sm_, sx = np.mean([x[3] for x in v]), np.mean([x[4] for x in v])
+    dm, dx = np.mean([x[5] for x in v]), np.mean([x[6] for x in v])
+    print(f"  {KERNELS[L]:11s} {KINDS.get((L, kind), kind):16s} n={v[0][2]:4d}  end median {med:6.0f} latest {mx:6.0f} | "
+          f"start median {sm_:5.0f} latest {sx:5.0f} | duration median {dm:5.0f} longest {dx:5.0f}")
 print("idle between the last workgroup (thread 0) of a launch and the first workgroup of the next, ns:",
-      [round(g / N) for g in gap_acc[:5]], " first start -> last end of the step:", round(gap_acc[5] / N))
+      [round(g / N) for g in gap_acc[:-1]], " first start -> last end of the step:", round(gap_acc[-1] / N))
