@@ -247,9 +247,13 @@ def main():
                       "hbm_frac": alg[k]["bytes"] / (prof[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "mfma_frac": alg[k]["flops"] / (prof[k] * 1e-3) / 1e12 / F32_MFMA_PEAK_TF} for k in prof}
     traffic, traffic_step, traffic_src = None, None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # fabric bytes per launch from the committed PMC passes
+    import glob
+    # fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, see profiles/README.md):
+    # the newest summary that knows every launch of this step
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        name = os.path.basename(path)
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
+            with open(path) as fh:
                 kern = json.load(fh)["kernels"]
             names = {"latent_dec1_fwd": "k_fwd23"}
             traffic = kern[names.get(dom, "k_" + dom)]["traffic_bytes"]

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mvae_destroy": (None, [C.c_void_p]),
     "mvae_set_radius_trainable": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "mvae_step_forward_backward": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
+    "mvae_step_forward_backward_parts": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),

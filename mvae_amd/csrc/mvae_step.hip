@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
 // fused = single-GPU step (Adam/SGD in the gradient epilogues, no k_optim); otherwise gradients only.
 static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
                      int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
-                     hipEvent_t* ev) {
+                     hipEvent_t* ev, int parts = MVAE_STEP_HEAD | MVAE_STEP_TAIL) {
   // profile slot of the next launch (0 enc_fwd, 1 latent_fwd, 2 dec1_fwd | the fused 2+3, 3 dec1_bwd, 4 latent_bwd,
   // 5 enc_bwd); with `ev` != NULL the launch is bracketed by ev[2 ki] (start) / ev[2 ki + 1] (stop)
   int ki = 0;
@@ -1486,6 +1486,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
   const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
                     aligned16(P + d.off_w_logits) && aligned16(ws);
+  if (parts & MVAE_STEP_HEAD) {  // launches 1-5
   ki = 0;
   if (full)
     STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
@@ -1571,7 +1572,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     }
 #undef LB
   }
-  {
+  }
+  if (parts & MVAE_STEP_TAIL) {
     ki = 5;
     const int tw = kTileWaves;
     const int n_we0 = c->nt_h * ((c->nt_d + tw - 1) / tw), n_wh = ((NH + 15) / 16) * ((c->nt_h + tw - 1) / tw),
@@ -1595,6 +1597,12 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 extern "C" int mvae_step_forward_backward(mvae_ctx* c, const float* x, const float* eps, float beta, int want_outputs,
                                           float* logits, float* concat_z, float* bce, float* kl, void* stream) {
   return step_impl(c, x, eps, beta, false, 0, want_outputs, logits, concat_z, bce, kl, stream, nullptr);
+}
+
+extern "C" int mvae_step_forward_backward_parts(mvae_ctx* c, const float* x, const float* eps, float beta, int parts,
+                                                void* stream) {
+  if (!(parts & (MVAE_STEP_HEAD | MVAE_STEP_TAIL))) return fail(MVAE_E_BADARG, "parts must name HEAD and / or TAIL%s", "");
+  return step_impl(c, x, eps, beta, false, 0, 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, parts);
 }
 
 extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* stream) {

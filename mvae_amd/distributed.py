@@ -4,8 +4,9 @@ New functionality (the reference is single-device).  Sampl
 parameters and the loss is a batch SUM (stats.py:200-202), so:
   * batch rows are split contiguously across ranks (`shard_rows`), every rank draws / receives its own eps rows;
   * parameters, optimizer state and radii are replicated;
-  * ONE exchange per step: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2), after which
-    every rank applies the identical optimizer step;
+  * ONE exchange per step, in two buckets: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2).
+    The fc_logits half of the buffer is final one launch before the rest, so its all-reduce is issued there and travels
+    while the last backward launch runs; then every rank applies the identical optimizer step;
   * the epoch >= 10 gate and the radius warm-up are functions of the epoch only: no communication;
   * statistics are summed across ranks only when somebody reads them (`reduce_stats`).
 `engine` is anything with `.grads` (flat tensor), `.stats`, `forward_backward(x, eps, beta)` and
@@ -77,12 +78,17 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 
 class DataParallelStep:
 
-    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False) -> None:
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False,
+                 overlap: Optional[bool] = None) -> None:
         """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
-        exercises the collective, its graph capture and k_optim on a single GPU)."""
+        exercises the collective, its graph capture and k_optim on a single GPU).
+        overlap: two-bucket exchange overlapped with the last backward launch (default: on; MVAE_DP_OVERLAP=0 turns it
+        off -- one all-reduce of the whole buffer after the backward pass)."""
+        import os
         self.engine = engine
         self.group = group
         self.always_exchange = bool(always_exchange)
+        self.overlap = (os.environ.get("MVAE_DP_OVERLAP", "1") not in ("0", "")) if overlap is None else bool(overlap)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -97,8 +103,21 @@ class DataParallelStep:
         if self.world == 1 and not self.always_exchange:
             eng.train_step(x_local, eps_local, beta, do_curvature_step)
             return
-        eng.forward_backward(x_local, eps_local, beta)
-        dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.group)
+        if self.overlap and hasattr(eng, "forward_backward_part"):
+            # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5.  An async
+            # collective is ordered after the work already on the current stream and runs on the backend's own stream,
+            # so it overlaps launch 6, which is issued next; both buckets are waited for (stream-level) before the
+            # optimizer kernel.
+            off = eng.flat.off_w_logits
+            eng.forward_backward_part(x_local, eps_local, beta, eng.HEAD)
+            w1 = dist.all_reduce(eng.grads[off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            eng.forward_backward_part(x_local, eps_local, beta, eng.TAIL)
+            w2 = dist.all_reduce(eng.grads[:off], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1.wait()
+            w2.wait()
+        else:
+            eng.forward_backward(x_local, eps_local, beta)
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.group)
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
 
     def reduce_stats(self) -> Tensor:

@@ -229,6 +229,16 @@ class StepEngine:
                                                 ptr(cz), ptr(bce), ptr(kl), stream_ptr(self.device)))
         return out
 
+    HEAD, TAIL = 1, 2  # MVAE_STEP_HEAD / MVAE_STEP_TAIL
+
+    def forward_backward_part(self, x: Tensor, eps: Tensor, beta: float, part: int) -> None:
+        """forward_backward in two calls (mvae_step_forward_backward_parts): HEAD = launches 1-5, after which
+        `grads[flat.off_w_logits:]` (fc_logits, half of the buffer) is final; TAIL = launch 6 (the rest)."""
+        B = self._check_inputs(x, eps)
+        self._last_batch = B
+        check(load().mvae_step_forward_backward_parts(self._context(B), ptr(x), ptr(eps), float(beta), int(part),
+                                                      stream_ptr(self.device)))
+
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
         """The optimizer kernel is independent of the batch size; `batch` only selects which context's component table
         travels with the launch (default: the batch size of the last forward_backward, else any existing context, else
