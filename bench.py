@@ -93,6 +93,95 @@ def cpu_baseline(seconds_budget=12.0, model=MODEL, fixed=False):
                       "cores); oracle = CPU restatement of ModelVAE.train_step, float32"}
 
 
+CONV_FLOPS_B256 = 79.5e9  # fwd 26.63 GFLOP, fwd + bwd ~79.5 GFLOP at B = 256
+
+
+def bench_conv(args, json_fd):
+    """BASELINE configs[4] on one GPU: CIFAR shapes (3x32x32, soft targets), conv architecture, h_dim 8192, batch 256,
+    model h2,s2,e2, learnable curvature.  One step = ConvEngine.train_step (forward, ELBO, backward, Adam + curvature
+    SGD), `graph_steps` steps per HIP graph.  MFMA-bound: the roofline is f32 MFMA flops."""
+    from mvae_amd import functional as Fn, synthetic
+    from mvae_amd.conv import ConvEngine
+    Bc = 256
+    dev = torch.device("cuda", 0)
+    eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
+    shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
+    eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
+    gs = max(1, min(args.graph_steps if args.graph_steps > 0 else 1, 10))
+    import math
+    if args.graph_steps > 0:
+        g_ = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
+        gs = max(d for d in range(1, min(g_, gs) + 1) if g_ % d == 0)
+    xs = synthetic.uniform_batches(gs, Bc, 3072).to(dev)
+    eps = synthetic.eps_batches(gs, Bc, 6).to(dev)
+    for i in range(3):
+        eng.train_step(xs[i % gs], eps[i % gs], 1.0, True)
+    torch.cuda.synchronize()
+    graph = None
+    if args.graph_steps > 0:
+        keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(gs):
+                eng.train_step(xs[i], eps[i], 1.0, True)
+        torch.cuda.synchronize()
+        for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
+            dst.copy_(src)
+
+    def run(n):
+        if graph is not None:
+            for _ in range(n // gs):
+                graph.replay()
+        else:
+            for i in range(n):
+                eng.train_step(xs[i % gs], eps[i % gs], 1.0, True)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.read_stats()["last"]
+    assert st["elbo"] == st["elbo"], "non-finite ELBO"
+    step_s = dt / args.steps
+    # the dominant kernel, timed live with events on the launch stream: the e2 forward contraction
+    # ([B*16, 2048] x [512, 2048]^T, 2.15 GFLOP at B = 256), the largest single launch of the step
+    a = torch.randn(Bc * 16, 2048, device=dev)
+    w = torch.randn(512, 2048, device=dev)
+    b = torch.zeros(512, device=dev)
+    for _ in range(5):
+        Fn.linear_forward(a, w, b, relu=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        Fn.linear_forward(a, w, b, relu=True)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 20
+    k_tf = 2.0 * Bc * 16 * 2048 * 512 / (k_ms * 1e-3) / 1e12
+    tf = CONV_FLOPS_B256 / step_s / 1e12
+    line = {
+        "metric": "ELBO-steps/sec (batch 256) CIFAR conv h2,s2,e2",
+        "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] on ONE GPU: CIFAR shapes (3x32x32, U[0,1] soft targets), model h2,s2,e2, "
+                               "learnable curvature, conv architecture h_dim=8192, batch 256, epoch>=10 state",
+                   "global_batch": Bc, "parallelism": "dp1", "graph_steps": gs if graph is not None else 0,
+                   "graph_replays": (args.steps // gs) if graph is not None else 0,
+                   "final_elbo_per_sample": st["elbo"] / Bc},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": tf / F32_MFMA_PEAK_TF,
+                     "scope": "whole step: SURVEY 8(d) 79.5 GFLOP (fwd + bwd contractions) over ms_per_step",
+                     "kernel": "k_gemm_tiled: e2 forward contraction [4096 x 2048] x [512 x 2048]^T + bias + ReLU",
+                     "kernel_ms": k_ms, "kernel_achieved_TFLOPs": k_tf, "kernel_mfma_frac": k_tf / F32_MFMA_PEAK_TF,
+                     "traffic": None},
+    }
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +198,9 @@ def main():
                     help="latent space string; the driver's metric is the default (BASELINE configs[1]); "
                          "'e6' = configs[0], '6h2,6s2,6e2' = configs[3]")
     ap.add_argument("--fixed-curvature", action="store_true")
+    ap.add_argument("--config", type=str, default="mlp", choices=["mlp", "conv"],
+                    help="mlp (default): the driver's metric, BASELINE configs[1]; conv: BASELINE configs[4] on one GPU "
+                         "(CIFAR shapes, conv architecture, batch 256), same JSON schema with an MFMA roofline")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the GLOBAL batch stays 128 and is split by rows across the ranks (the "
                          "configuration whose summed gradient equals the single-device step, SURVEY section 8d); the "
@@ -124,6 +216,11 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.config == "conv":
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        if args.steps == 2000 and args.warmup == 200:  # the MLP defaults: a conv step is ~40x longer
+            args.steps, args.warmup = 200, 20
+        return bench_conv(args, json_fd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -233,6 +233,10 @@ int mvae_component_backward(const mvae_component_desc* comps, int ncomp, const f
  * ------------------------------------------------------------------------------------------------------------------ */
 int mvae_linear_forward(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K, int relu,
                         void* stream);
+/* y = (x W^T) zeroed where mask[M, N] <= 0: the backward-data contraction of a layer whose input came out of a ReLU
+ * (mask = that ReLU's output), the mask applied in the contraction's epilogue.  16-byte aligned operands, K, N % 4 == 0. */
+int mvae_linear_forward_masked(const float* x, const float* W, const float* mask, float* y, int64_t M, int N, int K,
+                               void* stream);
 /* dW[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] = dy W  (dx may be NULL).  With relu_in != 0, x is the output of a
  * ReLU and dx is additionally masked by x > 0 (folds the previous activation's backward into this call). */
 int mvae_linear_backward(const float* x, const float* W, const float* dy, int relu_in, float* dW, float* db, float* dx,

@@ -70,6 +70,7 @@ PROTOTYPES = {
                                           _L, _P]),
     "mvae_scale_rows": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "mvae_linear_forward_masked": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),
     "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P]),

@@ -4,16 +4,19 @@ Layers (conv_vae.py:47-55): e0 Conv(3->64) e1 Conv(64->128) e2 Conv(128->512), a
 component heads -> latent components -> d0 Linear(Z->2048)+ReLU -> view [128,4,4] -> d1 ConvT(128->256) d2 ConvT(256->64)
 (+ReLU) d3 ConvT(64->3) -> flatten 3072 -> BCE-with-logits (soft targets).
 
-Every Conv2d / ConvTranspose2d is a patch-matrix gather (`mvae_im2col_k4s2p1` / `mvae_col2im_k4s2p1`) around one of the
-f32-MFMA contractions of the Linear layers; activations between layers are channel-last ([B*H*W, C]) so that they are
-directly the row-major operands of those contractions; weights stay in the reference's layouts ([OC, IC*16] for Conv2d,
-[IC, OC*16] for ConvTranspose2d are exactly the matrices the contractions need).  Backward of a ConvTranspose2d is the
-im2col of the incoming gradient; backward-data of a Conv2d is a col2im.  Parameters, gradients and optimizer state live
-in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming kernel and
-data-parallel training all-reduces one buffer.
+Every Conv2d / ConvTranspose2d is a patch-matrix gather (`mvae_im2col_k4s2p1` / `mvae_col2im_k4s2p1`) around an
+LDS-tiled f32-MFMA contraction (`k_gemm_tiled`, csrc/mvae_conv.hip); activations between layers are channel-last
+([B*H*W, C]) so that they are directly the row-major operands of those contractions.  Backward of a ConvTranspose2d is
+the im2col of the incoming gradient; backward-data of a Conv2d is a col2im.  Parameters, gradients and optimizer state
+live in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming kernel
+and data-parallel training all-reduces one buffer.
 
-First version: correctness and a complete path (BASELINE config [4]); the contractions use the small-batch tile
-kernels (no LDS-tiled large-M GEMM yet), so this path is far from the MFMA roofline.
+Weight layout in HBM: the four channel-last layers (e1, e2, d1, d2) keep their weights TAPS-MAJOR in the flat buffers --
+the matrix [rows, (ky, kx, c)] the coalesced gathers contract with -- and expose them to the host model as STRIDED views
+of the reference's logical shape ([OC, IC, 4, 4] / [IC, OC, 4, 4]); `state_dict()` / `load_state_dict()` / checkpoints
+see the reference's tensors, the kernels see the layout they want, and no weight or gradient is permuted per step
+(round 1 re-permuted 8 weight matrices and 4 gradients every step).  e0 / d3 sit on the 3-channel NCHW model boundary
+and keep the reference's (c, ky, kx) order.
 """
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -75,14 +78,28 @@ class ConvFlatLayout:
             self.entries.append((name + ".weight", self.off[name + ".weight"], shp))
             self.entries.append((name + ".bias", self.off[name + ".bias"], (bias[name],)))
 
+    TAPS_MAJOR = ("e1.weight", "e2.weight", "d1.weight", "d2.weight")
+
     def views(self, flat: Tensor) -> Dict[str, Tensor]:
+        """Name -> tensor of the reference's logical shape aliasing `flat`.  The taps-major weights are strided views:
+        element (r, c, ky, kx) of [R, Cc, 4, 4] lives at r * 16 Cc + (4 ky + kx) * Cc + c."""
         out = {}
         for name, off, shape in self.entries:
             n = 1
             for v in shape:
                 n *= v
-            out[name] = flat[off:off + n].view(shape)
+            if name in self.TAPS_MAJOR:
+                Cc = shape[1]
+                out[name] = flat[off:off + n].as_strided(shape, (16 * Cc, 1, 4 * Cc, Cc))
+            else:
+                out[name] = flat[off:off + n].view(shape)
         return out
+
+    def matrix(self, flat: Tensor, name: str) -> Tensor:
+        """The [rows, 16 * Cc] taps-major matrix of a channel-last layer's weight (or gradient), as stored."""
+        shape = self.shapes[name]
+        off = self.off[name + ".weight"]
+        return flat[off:off + shape[0] * shape[1] * 16].view(shape[0], shape[1] * 16)
 
 
 def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strides, taps_major: bool = False) -> Tensor:
@@ -170,6 +187,15 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def _linear_masked(x: Tensor, W: Tensor, mask: Tensor) -> Tensor:
+    """(x W^T) zeroed where mask <= 0: a Linear backward-data with the previous ReLU's mask applied in the epilogue."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = x.new_empty(M, N)
+    check(load().mvae_linear_forward_masked(ptr(x), ptr(W), ptr(mask), ptr(y), M, N, K, stream_ptr(x.device)))
+    return y
+
+
 def _relu_mask_(dy: Tensor, y: Tensor) -> Tensor:
     check(load().mvae_relu_mask(ptr(dy), ptr(y), dy.numel(), stream_ptr(dy.device)))
     return dy
@@ -203,8 +229,6 @@ class ConvEngine:
         self.radius_trainable = [bool(t) and letter != "e" for t, (letter, _) in zip(radius_trainable, self.layout.comps)]
         for i, (t, (letter, _)) in enumerate(zip(self.radius_trainable, self.layout.comps)):
             self._trainable_arr[i] = (3 if letter == "u" else 1) if t else 0
-        self._trainable_mask = torch.tensor([1.0 if t else 0.0 for t in self.radius_trainable], dtype=torch.float32,
-                                            device=self.device)
 
     # ---- state (same surface as StepEngine)
     def param_views(self) -> Dict[str, Tensor]:
@@ -239,8 +263,8 @@ class ConvEngine:
         c = {}
         # e0 / d3 touch the 3-channel NCHW boundary and keep the weight layout's (c,ky,kx) patch order; the four
         # channel-last layers in between run taps-major (coalesced gathers) against permuted weight matrices
-        c["We1"], c["We2"] = _taps_major(PV["e1.weight"], 128, 64), _taps_major(PV["e2.weight"], 512, 128)
-        c["Wd1"], c["Wd2"] = _taps_major(PV["d1.weight"], 128, 256), _taps_major(PV["d2.weight"], 256, 64)
+        c["We1"], c["We2"] = self.flat.matrix(self.params, "e1"), self.flat.matrix(self.params, "e2")
+        c["Wd1"], c["Wd2"] = self.flat.matrix(self.params, "d1"), self.flat.matrix(self.params, "d2")
         c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
         c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
         c["col1"] = _im2col(c["a0"], None, B, 64, 16, _nhwc(16, 64), True)
@@ -272,10 +296,10 @@ class ConvEngine:
         B, NH = x.shape[0], self.layout.heads_dim
         a0 = Fn.linear_forward(_im2col(x, None, B, 3, 32, _nchw(32, 3)), PV["e0.weight"].view(64, 48), PV["e0.bias"],
                                relu=True)
-        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64), True), _taps_major(PV["e1.weight"], 128, 64),
+        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64), True), self.flat.matrix(self.params, "e1"),
                                PV["e1.bias"], relu=True)
         a2 = Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True),
-                               _taps_major(PV["e2.weight"], 512, 128), PV["e2.bias"], relu=True)
+                               self.flat.matrix(self.params, "e2"), PV["e2.bias"], relu=True)
         hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
@@ -288,9 +312,9 @@ class ConvEngine:
         R = zz.shape[0]
         d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
         t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
-        b1 = _col2im(_gemm_nn(t0, _taps_major(PV["d1.weight"], 128, 256)), PV["d1.bias"], None, R, 256, 8,
+        b1 = _col2im(_gemm_nn(t0, self.flat.matrix(self.params, "d1")), PV["d1.bias"], None, R, 256, 8,
                      _nhwc(8, 256), True, (R * 64, 256), True)
-        b2 = _col2im(_gemm_nn(b1, _taps_major(PV["d2.weight"], 256, 64)), PV["d2.bias"], None, R, 64, 16,
+        b2 = _col2im(_gemm_nn(b1, self.flat.matrix(self.params, "d2")), PV["d2.bias"], None, R, 64, 16,
                      _nhwc(16, 64), True, (R * 256, 64), True)
         lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
                      (R, 3072))
@@ -312,21 +336,23 @@ class ConvEngine:
         dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
         _colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3), out=GV["d3.bias"])
-        db2 = _relu_mask_(Fn.linear_forward(dcol3, PV["d3.weight"].view(64, 48), None), c["b2"])
+        db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64), True)
-        _from_taps_major(_gemm_tn(c["b1"], dcol2), 256, 64, GV["d2.weight"])
+        _gemm_tn(c["b1"], dcol2, out=self.flat.matrix(self.grads, "d2"))
         _colsum(db2, out=GV["d2.bias"])
-        db1 = _relu_mask_(Fn.linear_forward(dcol2, c["Wd2"], None), c["b1"])
+        db1 = _linear_masked(dcol2, c["Wd2"], c["b1"])
         dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256), True)
-        _from_taps_major(_gemm_tn(c["t0"], dcol1), 128, 256, GV["d1.weight"])
+        _gemm_tn(c["t0"], dcol1, out=self.flat.matrix(self.grads, "d1"))
         _colsum(db1, out=GV["d1.bias"])
         dt0 = Fn.linear_forward(dcol1, c["Wd1"], None)  # [B*16, 128]
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         _, _, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True,
                                       out_dW=GV["d0.weight"], out_db=GV["d0.bias"])
         # ---- latent components
-        dheads, dradii = Fn.component_backward(lay, c["heads"], eps, self.params[:lay.n], dz, None, float(beta))
-        torch.mul(dradii, self._trainable_mask, out=self.grads[:lay.n])  # the rest of the radii region stays 0
+        # d/d(radius) lands in the radii region of the flat gradient buffer (fixed-order row sums); the optimizer kernel
+        # only applies it to trainable radii, the rest of the region stays 0
+        dheads, _ = Fn.component_backward(lay, c["heads"], eps, self.params[:lay.n], dz, None, float(beta),
+                                          out_dradii=self.grads[:lay.n])
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
         w_heads = self.params[ow:ow + NH * H_DIM].view(NH, H_DIM)
@@ -335,10 +361,10 @@ class ConvEngine:
                                           out_db=self.grads[ob:ob + NH])
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
-        _from_taps_major(_gemm_tn(da2, c["col2"]), 512, 128, GV["e2.weight"])
+        _gemm_tn(da2, c["col2"], out=self.flat.matrix(self.grads, "e2"))
         _colsum(da2, out=GV["e2.bias"])
         da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
-        _from_taps_major(_gemm_tn(da1, c["col1"]), 128, 64, GV["e1.weight"])
+        _gemm_tn(da1, c["col1"], out=self.flat.matrix(self.grads, "e1"))
         _colsum(da1, out=GV["e1.bias"])
         da0 = _col2im(_gemm_nn(da1, c["We1"]), None, c["a0"], B, 64, 16, _nhwc(16, 64), False, (B * 256, 64), True)
         _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))

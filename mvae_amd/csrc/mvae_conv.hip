@@ -524,6 +524,17 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   }
 }
 
+extern "C" int mvae_linear_forward_masked(const float* x, const float* W, const float* mask, float* y, int64_t M, int N,
+                                          int K, void* stream) {
+  if (!x || !W || !mask || !y || M < 1 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (!tiled_ok(x, K) || !tiled_ok(W, K) || !tiled_ok(y, N) || !tiled_ok(mask, N) || M > 0x7fffffff)
+    return fail(MVAE_E_ALIGN, "masked linear needs 16-byte aligned operands with K, N multiples of 4%s", "");
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
+                                (hipStream_t)stream);
+  LAUNCH_CHECK("masked linear launch");
+  return 0;
+}
+
 bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
                                  int relu, hipStream_t s) {
   if (!tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff) return false;

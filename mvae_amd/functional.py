@@ -402,12 +402,14 @@ def component_forward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii
 
 def component_backward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii: Optional[Tensor], dz: Tensor,
                        dkl: Optional[Tensor], dkl_scalar: float = 0.0, want_dradii: bool = True,
-                       out_dheads: Optional[Tensor] = None, workspace: Optional[Tensor] = None):
-    """dheads[rows, heads_dim] and dradii[ncomp] (a fixed-order sum over the rows: bit-reproducible)."""
+                       out_dheads: Optional[Tensor] = None, workspace: Optional[Tensor] = None,
+                       out_dradii: Optional[Tensor] = None):
+    """dheads[rows, heads_dim] and dradii[ncomp] (a fixed-order sum over the rows: bit-reproducible).  out_dradii: a
+    contiguous [ncomp] destination (e.g. the radii region of a flat gradient buffer), every entry is written."""
     heads, eps, dz = _f32c(heads), _f32c(eps), _f32c(dz)
     rows = heads.shape[0]
     dheads = torch.zeros_like(heads) if out_dheads is None else out_dheads
-    dradii = heads.new_zeros(layout.n) if want_dradii else None
+    dradii = (heads.new_zeros(layout.n) if out_dradii is None else out_dradii) if want_dradii else None
     if want_dradii and workspace is None:
         workspace = heads.new_empty(max(1, layout.n * rows))
     dkl = None if dkl is None else _f32c(dkl)

@@ -71,6 +71,16 @@ def test_two_rank_data_parallel_equals_single_process():
     ref = eng.params.cpu().numpy()
     assert np.array_equal(results[0][1], results[1][1]), "ranks diverged"
     assert_close_after_adam(results[0][1], ref, 1e-3, steps, "flat parameters, dp2 vs single process")
+    # ... and against the ORACLE (CPU restatement pinned to the reference), not only against our own single-GPU path
+    from oracle import model as M
+    spec = M.Spec("h2,s2,e2", in_dim=784, h_dim=400, fixed_curvature=False)
+    orc = M.StepOracle(spec, synthetic.synthetic_state(spec.named_shapes(), radius=2.0))
+    xs_c, eps_c = synthetic.digits_like_batches(steps, 128), synthetic.eps_batches(steps, 128, 6)
+    for s in range(steps):
+        orc.train_step(xs_c[s], eps_c[s], 1.0, epoch=12)
+    dp_params = torch.from_numpy(results[0][1])
+    for name, v in eng.flat.views(dp_params).items():
+        assert_close_after_adam(v.numpy(), orc.P[name].detach().numpy(), 1e-3, steps, "dp2 vs oracle: " + name)
     tot = eng.stats.cpu().numpy()
     n = 4 + 3
     np.testing.assert_allclose(results[0][2][:3], tot[:3], rtol=2e-4)
