@@ -260,6 +260,20 @@ int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, i
  * taps_major: as above, col's second axis is (ky,kx,c). */
 int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C, int H, int W,
                        int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, int taps_major, void* stream);
+/* The channel-last layers WITHOUT a patch matrix in memory (implicit contraction; the gather happens in the operand fetch
+ * of the LDS-tiled MFMA kernel).  src[B, IH, IW, C] channel-last, C % 32 == 0, IH and IW powers of two;
+ * Wt[OC, 16 C] with the patch axis taps-major (ky, kx, c); rows of y / dy are (b, oy, ox), OH = IH/2, OW = IW/2.
+ *   y[(b,oy,ox), oc] = act(bias[oc] + sum_{ky,kx,c} src[b, 2oy-1+ky, 2ox-1+kx, c] Wt[oc, (ky,kx,c)]), zeroed where
+ *   mask[(b,oy,ox), oc] <= 0 (mask may be NULL): Conv2d forward (conv_vae.py:60-62) and -- with src = the incoming
+ *   gradient, Wt = the ConvTranspose2d weight [IC, (ky,kx,oc)], mask = the previous ReLU's output -- the backward-data of
+ *   a ConvTranspose2d (conv_vae.py:72-74).
+ *   dWt[oc, (ky,kx,c)] = sum_{b,oy,ox} dy[(b,oy,ox), oc] src[b, 2oy-1+ky, 2ox-1+kx, c]: the weight gradient of either
+ *   (rows are cut into slices added in index order; workspace = mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats floats). */
+int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
+                          int IH, int IW, int OC, int relu, void* stream);
+int64_t mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(int B, int C, int IH, int IW, int OC);
+int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, float* dWt, int B, int C, int IH, int IW, int OC,
+                                float* workspace, void* stream);
 /* mvae_linear_forward for few rows and a long contraction (the heads of the conv architecture, component.py:52-57 on
  * the 8192-wide flatten): K is split into slices whose partial products are added in index order.  `workspace`:
  * mvae_linear_forward_splitk_workspace_floats(M, N, K) floats (0 = not needed). */

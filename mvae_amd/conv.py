@@ -4,10 +4,13 @@ Layers (conv_vae.py:47-55): e0 Conv(3->64) e1 Conv(64->128) e2 Conv(128->512), a
 component heads -> latent components -> d0 Linear(Z->2048)+ReLU -> view [128,4,4] -> d1 ConvT(128->256) d2 ConvT(256->64)
 (+ReLU) d3 ConvT(64->3) -> flatten 3072 -> BCE-with-logits (soft targets).
 
-Every Conv2d / ConvTranspose2d is a patch-matrix gather (`mvae_im2col_k4s2p1` / `mvae_col2im_k4s2p1`) around an
-LDS-tiled f32-MFMA contraction (`k_gemm_tiled`, csrc/mvae_conv.hip); activations between layers are channel-last
-([B*H*W, C]) so that they are directly the row-major operands of those contractions.  Backward of a ConvTranspose2d is
-the im2col of the incoming gradient; backward-data of a Conv2d is a col2im.  Parameters, gradients and optimizer state
+Every Conv2d / ConvTranspose2d runs on an LDS-tiled f32-MFMA contraction (`k_gemm_tiled`, csrc/mvae_conv.hip);
+activations between layers are channel-last ([B*H*W, C]).  Where a convolution GATHERS (Conv2d forward, its weight
+gradient, ConvTranspose2d backward-data and weight gradient) the contraction is implicit: the operand fetch of the tiled
+kernel reads the activation directly (`mvae_conv_k4s2p1_nhwc`, `..._wgrad`), no patch matrix exists in memory (round 1
+wrote and re-read 16x the activation for each of them: ~2 GB of HBM traffic per step at B = 256).  Where it SCATTERS
+(ConvTranspose2d forward, Conv2d backward-data) the contraction writes a patch matrix that `mvae_col2im_k4s2p1` folds
+(<= 4 terms per output, no atomics).  The 3-channel NCHW boundary layers (e0, d3) keep explicit patch matrices (48 wide).  Parameters, gradients and optimizer state
 live in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming kernel
 and data-parallel training all-reduces one buffer.
 
@@ -187,6 +190,28 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
+               relu: bool) -> Tensor:
+    """Implicit contraction (no patch matrix): src [B*IH*IH, Cc] channel-last -> [B*(IH/2)^2, OC]; Wt [OC, 16 Cc]
+    taps-major.  Conv2d forward, or ConvTranspose2d backward-data with `mask` = the previous ReLU's output."""
+    OC = Wt.shape[0]
+    y = src.new_empty(B * (IH // 2) * (IH // 2), OC)
+    check(load().mvae_conv_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
+                                       1 if relu else 0, stream_ptr(src.device)))
+    return y
+
+
+def _conv_nhwc_wgrad(dy: Tensor, src: Tensor, out: Tensor, B: int, Cc: int, IH: int) -> Tensor:
+    """out[OC, 16 Cc] (taps-major, e.g. a slot of the flat gradient buffer) = dy^T im2col(src), patch matrix implicit."""
+    OC = dy.shape[1]
+    assert out.is_contiguous() and out.numel() == OC * 16 * Cc
+    nws = int(load().mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(B, Cc, IH, IH, OC))
+    ws = dy.new_empty(nws) if nws > 0 else None
+    check(load().mvae_conv_k4s2p1_nhwc_wgrad(ptr(dy), ptr(src), ptr(out), B, Cc, IH, IH, OC, ptr(ws),
+                                             stream_ptr(dy.device)))
+    return out
+
+
 def _linear_masked(x: Tensor, W: Tensor, mask: Tensor) -> Tensor:
     """(x W^T) zeroed where mask <= 0: a Linear backward-data with the previous ReLU's mask applied in the epilogue."""
     M, K = x.shape
@@ -267,10 +292,8 @@ class ConvEngine:
         c["Wd1"], c["Wd2"] = self.flat.matrix(self.params, "d1"), self.flat.matrix(self.params, "d2")
         c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
         c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
-        c["col1"] = _im2col(c["a0"], None, B, 64, 16, _nhwc(16, 64), True)
-        c["a1"] = Fn.linear_forward(c["col1"], c["We1"], PV["e1.bias"], relu=True)
-        c["col2"] = _im2col(c["a1"], None, B, 128, 8, _nhwc(8, 128), True)
-        c["a2"] = Fn.linear_forward(c["col2"], c["We2"], PV["e2.bias"], relu=True)
+        c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True)   # [B*64, 128]
+        c["a2"] = _conv_nhwc(c["a1"], c["We2"], PV["e2.bias"], None, B, 128, 8, True)   # [B*16, 512]
         c["hflat"] = _permute_rc(c["a2"], B, 16, 512).view(B, H_DIM)  # NCHW flatten (conv_vae.py:65)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
@@ -296,10 +319,8 @@ class ConvEngine:
         B, NH = x.shape[0], self.layout.heads_dim
         a0 = Fn.linear_forward(_im2col(x, None, B, 3, 32, _nchw(32, 3)), PV["e0.weight"].view(64, 48), PV["e0.bias"],
                                relu=True)
-        a1 = Fn.linear_forward(_im2col(a0, None, B, 64, 16, _nhwc(16, 64), True), self.flat.matrix(self.params, "e1"),
-                               PV["e1.bias"], relu=True)
-        a2 = Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True),
-                               self.flat.matrix(self.params, "e2"), PV["e2.bias"], relu=True)
+        a1 = _conv_nhwc(a0, self.flat.matrix(self.params, "e1"), PV["e1.bias"], None, B, 64, 16, True)
+        a2 = _conv_nhwc(a1, self.flat.matrix(self.params, "e2"), PV["e2.bias"], None, B, 128, 8, True)
         hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
         w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
         b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
@@ -337,14 +358,13 @@ class ConvEngine:
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
         _colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3), out=GV["d3.bias"])
         db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
-        dcol2 = _im2col(db2, None, B, 64, 16, _nhwc(16, 64), True)
-        _gemm_tn(c["b1"], dcol2, out=self.flat.matrix(self.grads, "d2"))
+        # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
+        _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16)
         _colsum(db2, out=GV["d2.bias"])
-        db1 = _linear_masked(dcol2, c["Wd2"], c["b1"])
-        dcol1 = _im2col(db1, None, B, 256, 8, _nhwc(8, 256), True)
-        _gemm_tn(c["t0"], dcol1, out=self.flat.matrix(self.grads, "d1"))
+        db1 = _conv_nhwc(db2, c["Wd2"], None, c["b1"], B, 64, 16, False)  # [B*64, 256], ReLU mask in the epilogue
+        _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8)
         _colsum(db1, out=GV["d1.bias"])
-        dt0 = Fn.linear_forward(dcol1, c["Wd1"], None)  # [B*16, 128]
+        dt0 = _conv_nhwc(db1, c["Wd1"], None, None, B, 256, 8, False)  # [B*16, 128]
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         _, _, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True,
                                       out_dW=GV["d0.weight"], out_db=GV["d0.bias"])
@@ -361,10 +381,10 @@ class ConvEngine:
                                           out_db=self.grads[ob:ob + NH])
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
-        _gemm_tn(da2, c["col2"], out=self.flat.matrix(self.grads, "e2"))
+        _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
         da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
-        _gemm_tn(da1, c["col1"], out=self.flat.matrix(self.grads, "e1"))
+        _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
         _colsum(da1, out=GV["e1.bias"])
         da0 = _col2im(_gemm_nn(da1, c["We1"]), None, c["a0"], B, 64, 16, _nhwc(16, 64), False, (B * 256, 64), True)
         _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))

@@ -328,12 +328,21 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 // ONE 16-byte vector per 16 x 16 x 16 sub-product (k is consumed in the permuted order {kk*4 + j}, the same for A and
 // B); strides 24 / 40 are conflict-free for ds_read_b128 under its 16-lane service groups ({0-3,12-15,20-27}, ...
 // over 64 banks).  Global -> register prefetch of the next K step overlaps the MFMAs of the current one.
-template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC>
+// GATHER (implicit contraction for the k4 s2 p1 convolutions on channel-last tensors; the patch matrix is never written):
+//   1: the A operand is im2col(src) -- row m = (b, oy, ox), column k = (ky, kx, c) taps-major -- fetched straight from
+//      src[b, 2oy-1+ky, 2ox-1+kx, c] (zero outside the image).  Conv2d forward / ConvTranspose2d backward-data (A_KC, B_KC).
+//   2: the B operand is im2col(src) with the roles k = row m, j = (ky, kx, c): the weight gradient dy^T im2col(src).
+// A K step of 32 lies inside one tap (C % 32 == 0), so the tap of a step is uniform and a lane moves 16 contiguous bytes.
+struct ConvGeom {
+  int Cc, IH, IW;    // channels and extent of the SOURCE image
+  int lOW, lOHW;     // log2(OW), log2(OH * OW), OH = IH / 2, OW = IW / 2 (powers of two)
+};
+template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC, int GATHER = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
                                                     const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
                                                     float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
                                                     const float* __restrict__ mask, int relu, int M, int N, int K,
-                                                    int k_per_slice, int64_t slice_stride) {
+                                                    int k_per_slice, int64_t slice_stride, ConvGeom cg) {
   constexpr int kGT_BK = BK, kGT_LD = BK + 8, KQ = BK / 4;
   __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
@@ -353,7 +362,15 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
     for (int r = 0; r < LA; ++r) {
       const int f = tid + NT * r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (A_KC) {  // 4 consecutive k of row i
+      if (A_KC && GATHER == 1) {  // row = output pixel, k = (tap, c): the tap of this K step is uniform
+        const int i = f / KQ, k = k0 + ((f % KQ) << 2);
+        const int m = m0 + i;
+        const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
+        const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
+        const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+        if (m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW)
+          v = *reinterpret_cast<const float4*>(A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c);
+      } else if (A_KC) {  // 4 consecutive k of row i
         const int i = f / KQ, k = k0 + ((f % KQ) << 2);
         if (m0 + i < M && k < ke) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + i) * sai + k);
       } else {  // 4 consecutive i of column k
@@ -369,6 +386,13 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
       if (B_KC) {
         const int j = f / KQ, k = k0 + ((f % KQ) << 2);
         if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + j) * sbj + k);
+      } else if (GATHER == 2) {  // k = output pixel (the contraction index), j = (tap, c)
+        const int k = k0 + (f % BK), j = n0 + ((f / BK) << 2);
+        const int tap = j / cg.Cc, c = j - tap * cg.Cc;
+        const int ox = k & ((1 << cg.lOW) - 1), oy = (k & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = k >> cg.lOHW;
+        const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+        if (j < N && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW)
+          v = *reinterpret_cast<const float4*>(Bm + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c);
       } else {
         const int k = k0 + (f % BK), j = (f / BK) << 2;
         if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)k * sbk + (n0 + j));
@@ -502,25 +526,26 @@ static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 
 #define MV_NW128 8
 #endif
 constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128, kNW64 = MV_NW64, kNW128 = MV_NW128;
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int GATHER = 0>
 static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
                               float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
-                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s) {
+                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s,
+                              ConvGeom cg = ConvGeom{0, 0, 0, 0, 0}) {
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
   if (N > 64 && wg128 < 512) {
     dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+    hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC, GATHER>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
   } else if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, kNW128, A_KC, B_KC>), grid, dim3(64 * kNW128), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, kNW128, A_KC, B_KC, GATHER>), grid, dim3(64 * kNW128), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
   } else {
     dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
-    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, 4, A_KC, B_KC>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride);
+    hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, 4, A_KC, B_KC, GATHER>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
   }
 }
 
@@ -629,6 +654,73 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
   }
   LAUNCH_CHECK("gemm_tn launch");
+  return 0;
+}
+
+// ---- implicit contractions of the channel-last k4 s2 p1 convolutions (no patch matrix in memory)
+static int conv_geom(ConvGeom* g, int B, int Cc, int IH, int IW) {
+  if (B < 1 || Cc < 32 || (Cc & 31) || IH < 2 || IW < 2 || (IH & (IH - 1)) || (IW & (IW - 1)))
+    return fail(MVAE_E_UNSUPPORTED, "implicit conv needs C %% 32 == 0 and power-of-two extents%s (%lld)", "", Cc);
+  int lOW = 0, lOH = 0;
+  while ((1 << lOW) < IW / 2) ++lOW;
+  while ((1 << lOH) < IH / 2) ++lOH;
+  *g = ConvGeom{Cc, IH, IW, lOW, lOW + lOH};
+  return 0;
+}
+
+extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
+                                     int B, int Cc, int IH, int IW, int OC, int relu, void* stream) {
+  if (!src || !Wt || !y || OC < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  ConvGeom g;
+  int rc = conv_geom(&g, B, Cc, IH, IW);
+  if (rc) return rc;
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  const int K = 16 * Cc;
+  if (!tiled_ok(src, Cc) || !tiled_ok(Wt, K) || !tiled_ok(y, OC) || (mask && !tiled_ok(mask, OC)) ||
+      (bias && ((uintptr_t)bias & 15)) || M > 0x7fffffff)
+    return fail(MVAE_E_ALIGN, "implicit conv needs 16-byte aligned operands%s", "");
+  launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, y, OC, bias, mask, relu, (int)M, OC, K, 1, K, 0,
+                                   (hipStream_t)stream, g);
+  LAUNCH_CHECK("implicit conv launch");
+  return 0;
+}
+
+static int wgrad_slices(int64_t M, int NP, int NQ, int* kps) {
+  const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
+  int slices = (256 + wg - 1) / wg;
+  const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  *kps = (int)((((M + slices - 1) / slices) + 31) & ~(int64_t)31);
+  return (int)((M + *kps - 1) / *kps);
+}
+
+extern "C" int64_t mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(int B, int Cc, int IH, int IW, int OC) {
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  int kps;
+  const int slices = wgrad_slices(M, OC, 16 * Cc, &kps);
+  return slices > 1 ? (int64_t)slices * OC * 16 * Cc : 0;
+}
+
+extern "C" int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, float* dWt, int B, int Cc, int IH, int IW,
+                                           int OC, float* workspace, void* stream) {
+  if (!dy || !src || !dWt || OC < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  ConvGeom g;
+  int rc = conv_geom(&g, B, Cc, IH, IW);
+  if (rc) return rc;
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  const int NQ = 16 * Cc;
+  if (!tiled_ok(dy, OC) || !tiled_ok(src, Cc) || !tiled_ok(dWt, NQ) || M > 0x7fffffff)
+    return fail(MVAE_E_ALIGN, "implicit conv needs 16-byte aligned operands%s", "");
+  int kps;
+  const int slices = wgrad_slices(M, OC, NQ, &kps);
+  if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "the weight gradient needs its workspace%s", "");
+  const int64_t n = (int64_t)OC * NQ;
+  launch_gemm_tiled<false, false, 2>(dy, 1, OC, src, 0, 0, slices > 1 ? workspace : dWt, NQ, nullptr, nullptr, 0, OC, NQ,
+                                     (int)M, slices, kps, n, (hipStream_t)stream, g);
+  if (slices > 1)
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, dWt, n, slices);
+  LAUNCH_CHECK("implicit conv weight gradient launch");
   return 0;
 }
 
