@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
                                                const float* bd0, const float* Wl, const float* bl, const float* x,
                                                float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
                                                float* kl_user, float* hd, float* g, float* bce_part,
-                                               float* logits_user, int B, int H, int D, int NH, int Z) {
+                                               float* logits_user, int B, int H, int D, int NH, int Z, float* duals) {
   // dynamic LDS: hd_s[16][ld] | wl_s[32][ld] | wd_s[H][8] | bd_s[H]     (ld = H + 4: conflict-free ds_read_b128 of the
   // 16 rows an MFMA operand fetch touches)
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -512,11 +512,30 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   // W_heads: 51 KB) are shared by twice the output, and the grid (8 row blocks x 25 pairs = 200 workgroups) puts exactly
   // one workgroup on a CU.
   const int ntD = D >> 4, ntP = (ntD + 1) >> 1;
-  int pt;
-  if (!xcd_tile(ntP, B >> 4, &pt, &mt)) return;
+  int pt = 0;
+  // The first B/16 workgroups of the grid are DUAL workgroups, one per row block: they compute the heads of their 16
+  // rows like everybody else and then the forward-mode dual records of the latent components for launch 5 (d kl and
+  // d z along every input direction: a ~3.5 us dependent chain per lane, 16 rows x directions lanes).  They have a CU
+  // to themselves (208 workgroups on 256 CUs) and finish well inside the launch.
+  const int n_dual = B >> 4;  // dispatched FIRST (the longest job); a multiple of 8 keeps workgroup L on XCD L % 8
+  const bool is_dual = (int)blockIdx.x < n_dual;
+  if (is_dual) mt = (int)blockIdx.x;
+  else {
+    // XCD-aware without padding workgroups (a padding workgroup holds its CU's LDS allocation long enough to push a
+    // real one into a second round): the first 8 * floor(ntP / 8) pairs are dealt to the XCDs as in xcd_tile, the
+    // remaining pairs' workgroups follow in plain order (their W_logits rows are fetched by several XCDs: 50 KB each).
+    const int L = (int)blockIdx.x - n_dual, MT = B >> 4;
+    const int full = (ntP >> 3) << 3;
+    if (L < full * MT) (void)xcd_tile(full, MT, &pt, &mt, L);
+    else {
+      const int idx = L - full * MT;
+      pt = full + idx / MT;
+      mt = idx - (pt - full) * MT;
+    }
+  }
   nt = pt * 2;
   const bool two = nt + 1 < ntD;  // the last pair of an odd tile count has one tile
-  const bool lead = pt == mt % ntP;
+  const bool lead = !is_dual && pt == mt % ntP;
   MV_TDECL;
   MV_T(0);
   const int ld = H + 4;
@@ -596,6 +615,40 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   }
   lds_barrier();
   MV_T(3);
+
+  if (is_dual) {
+    // wave w and wave w + 4 share the components placed on wave w & 3 (one manifold kind: one instruction stream);
+    // item = (direction index within those components) * 16 + row
+    constexpr int AM = DMAX + 1, DS = DMAX + 2;
+    const int wk = __builtin_amdgcn_readfirstlane(wave) & 3;
+    int total = 0;
+    for (int ci = 0; ci < t.n; ++ci)
+      if (t.wave_of[ci] == wk) total += t.dir_off[ci + 1] - t.dir_off[ci];
+    for (int item = (wave >> 2) * 64 + lane; item < total * 16; item += 128) {
+      const int r = item & 15, dd = item >> 4;
+      int mine = 0, mydir = 0, base = 0;
+      for (int ci = 0; ci < t.n; ++ci) {  // uniform loop, per-lane select
+        if (t.wave_of[ci] != wk) continue;
+        const int nd = t.dir_off[ci + 1] - t.dir_off[ci];
+        if (dd >= base && dd < base + nd) {
+          mine = ci;
+          mydir = dd - base;
+        }
+        base += nd;
+      }
+      const mvae_component_desc c = t.c[mine];
+      float zd[AM];
+      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
+      float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + t.first_dir[mine] + mydir) * DS;
+      const int A = ambient_dim(c.kind, c.true_dim);
+      rec[0] = kld;
+#pragma unroll
+      for (int q2 = 0; q2 < AM; ++q2)
+        if (q2 < A) rec[1 + q2] = zd[q2];
+    }
+    MV_SPAN_END(2, 2);
+    return;
+  }
 
   // ---- waves 0..3: the latent components, one lane per (slot, row) -- a ~2 us dependent chain on a handful of lanes.
   // ---- waves 4..7 meanwhile stage the operands of the two remaining phases in LDS: W_d0 / b_d0 (first decoder layer) and
@@ -1497,11 +1550,12 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
   int max_slot = 0;
   for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
-  const bool fwd23 = fast && full && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 && bucket_of(c->dmax) <= 8 &&
+  const bool fwd23 = fast && full && (B % 128 == 0) && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 && bucket_of(c->dmax) <= 8 &&
                      !c->no_fwd23;
   if (fwd23) {
     ki = 2;
     const size_t lds = ((size_t)48 * (H + 4) + (size_t)H * 9) * sizeof(float);
+    const int n_main23 = ((c->nt_d + 1) / 2) * c->nt_b;  // no padding workgroups (see the kernel)
 #define LF23(DM)                                                                                                     \
   {                                                                                                                  \
     static size_t lds_set = 0; /* more than 64 KB of dynamic LDS has to be allowed once per kernel */                \
@@ -1513,10 +1567,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       lds_set = lds;                                                                                                 \
     }                                                                                                                \
   }                                                                                                                  \
-  STEP_LAUNCH((k_fwd23<DM>), dim3(8 * (((c->nt_d + 1) / 2 + 7) / 8) * c->nt_b), dim3(512), lds, c->t, h, P + d.off_w_heads,   \
+  STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b), dim3(512), lds, c->t, h, P + d.off_w_heads,                    \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
-              NH, Z)
+              NH, Z, duals)
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
@@ -1543,13 +1597,14 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_dhd = xcd_grid(c->nt_h, c->nt_b, kDhdGroup), n_db = (D + kColsPerBlock - 1) / kColsPerBlock;
     ki = 3;
     DualArgs da = {heads, eps, P + d.off_radii, duals, c->ldh, d.eps_dim, NH, 0};
-    if (fwd23) da.n_dual = (B * c->t.total_dirs + 63) / 64;
+    const bool duals_in_l4 = false;  // the fused forward's dual workgroups produce the records (job_duals stays available)
+    if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const int n_short = (da.n_dual + 1 + n_db + 7) & ~7;
 #define DB(AD, FU, DU)                                                                                         \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits,     \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
               at(d.off_b_logits), da)
-    if (fwd23) {  // full && dmax bucket in {2, 4, 8}
+    if (fwd23 && duals_in_l4) {  // full && dmax bucket in {2, 4, 8}
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) DB(true, true, 2); else if (bk == 4) DB(true, true, 4); else DB(true, true, 8); }
       else { if (bk == 2) DB(false, true, 2); else if (bk == 4) DB(false, true, 4); else DB(false, true, 8); }
