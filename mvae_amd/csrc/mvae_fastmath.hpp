@@ -8,7 +8,7 @@
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MVF __host__ __device__ __forceinline__
 #else
 #define MVF inline
