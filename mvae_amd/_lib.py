@@ -101,6 +101,7 @@ PROTOTYPES = {
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),
+    "mvae_step_kernel_path": (C.c_int, [_P]),
     "mvae_step_profile": (C.c_int, [_P, _P, _P, _F, _I, _I, C.POINTER(C.c_float), _P]),
 }
 

@@ -19,6 +19,7 @@
 // Further down: manifold primitives, component operators, generic dense layers, log-likelihood helpers and the
 // patch-matrix gathers of the conv architecture -- the rest of the C ABI.
 #include "mvae_common.hpp"
+#include "mvae_step_blk.hpp"
 
 // ================================================================================================ the fused step
 struct mvae_ctx {
@@ -28,9 +29,13 @@ struct mvae_ctx {
   int ldh;    // heads row stride (NH rounded up to 4)
   int ldz;    // z row stride
   // workspace carve (floats)
-  int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_total;
+  int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_dirtab, o_total;
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
   bool no_fwd23;         // MVAE_NO_FWD23=1: keep launches 2 and 3 separate (A/B measurements)
+  GroupTable gt;         // component groups of the 16-row block kernels (mvae_step_blk.hpp)
+  bool groups_ok;        // every component fits one 16-column head tile
+  bool no_blk;           // MVAE_NO_BLK=1: per-row latent kernels for many-component models too (A/B measurements)
+  bool blk_fwd;          // MVAE_BLK_FWD=1: block kernels in the forward launches as well (measured slower)
 };
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
@@ -64,7 +69,17 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   // [B][heads_dim + ncomp][dual_stride]: every input direction of every component (radius directions included
   // whether or not they are trainable right now)
   c->o_duals = take(B * ((int64_t)d.heads_dim + d.ncomp) * dual_stride(dmax_bucket));
+  c->o_dirtab = take(4 * (int64_t)kBlkDirs);  // int4 per active input direction (k_latent_bwd_blk)
   c->o_total = o;
+}
+
+// the active-direction table of the block kernels lives in the workspace; (re)written whenever the component table is
+static int upload_dirtab(mvae_ctx* c) {
+  int4 tab[kBlkDirs];
+  memset(tab, 0, sizeof(tab));
+  fill_dirtab(c->t, tab);
+  hipError_t e = hipMemcpy(c->d.workspace + c->o_dirtab, tab, sizeof(tab), hipMemcpyHostToDevice);
+  return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpy(direction table)");
 }
 
 extern "C" int64_t mvae_workspace_floats(const mvae_model_desc* desc) {
@@ -125,7 +140,16 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->d.radius_trainable = nullptr;
   const char* nf = getenv("MVAE_NO_FWD23");
   c->no_fwd23 = nf && nf[0] && nf[0] != '0';
+  const char* nb = getenv("MVAE_NO_BLK");
+  c->no_blk = nb && nb[0] && nb[0] != '0';
+  const char* bf = getenv("MVAE_BLK_FWD");
+  c->blk_fwd = bf && bf[0] && bf[0] != '0';
+  c->groups_ok = build_groups(c->t, &c->gt);
   carve(c, bucket_of(c->dmax));
+  if (c->groups_ok && (rc = upload_dirtab(c)) != 0) {
+    delete c;
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -137,7 +161,9 @@ extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) 
   mvae_component_desc comps[kMaxComp];
   const int n = c->t.n;
   for (int i = 0; i < n; ++i) comps[i] = c->t.c[i];
-  return fill_table(&c->t, comps, n, trainable, &c->dmax);
+  const int rc = fill_table(&c->t, comps, n, trainable, &c->dmax);
+  if (rc) return rc;
+  return c->groups_ok ? upload_dirtab(c) : 0;
 }
 
 #ifdef MV_DBG_TIMING
@@ -1498,6 +1524,29 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
   }
 }
 
+// Which latent kernels the step takes (see MVAE_PATH_* in the header)
+static int latent_path(const mvae_ctx* c, bool x_aligned) {
+  const mvae_model_desc& d = c->d;
+  const int B = d.batch, H = d.h_dim, D = d.in_dim, NH = d.heads_dim, Z = d.z_dim;
+  const float* P = d.params;
+  const bool fast = NH <= 16 && Z <= 8 && H <= 512 && (H & 3) == 0 && aligned16(P + d.off_w_heads);
+  const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && x_aligned && aligned16(P + d.off_w_e0) &&
+                    aligned16(P + d.off_w_logits) && aligned16(d.workspace);
+  int max_slot = 0;
+  for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
+  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
+  if (fast && full && (B % 128 == 0) && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 &&
+      bucket_of(c->dmax) <= 8 && !c->no_fwd23)
+    return MVAE_PATH_FUSED;
+  // many small components: 16-row block kernels (mvae_step_blk.hpp)
+  if (!fast && full && c->groups_ok && !c->no_blk && (Z & 3) == 0 && Z <= 64 && H <= 512 && NH <= kHeadsMax &&
+      bucket_of(c->dmax) <= 8 && aligned16(P + d.off_w_d0) && aligned16(P + d.off_w_heads))
+    return MVAE_PATH_BLOCK;
+  return MVAE_PATH_ROW;
+}
+
+extern "C" int mvae_step_kernel_path(const mvae_ctx* c) { return c ? latent_path(c, true) : MVAE_E_BADARG; }
+
 // fused = single-GPU step (Adam/SGD in the gradient epilogues, no k_optim); otherwise gradients only.
 static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
                      int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
@@ -1548,10 +1597,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
                 P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
   // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
-  int max_slot = 0;
-  for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
-  const bool fwd23 = fast && full && (B % 128 == 0) && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 && bucket_of(c->dmax) <= 8 &&
-                     !c->no_fwd23;
+  const int path = latent_path(c, aligned16(x));
+  const bool fwd23 = path == MVAE_PATH_FUSED, blk = path == MVAE_PATH_BLOCK;
   if (fwd23) {
     ki = 2;
     const size_t lds = ((size_t)48 * (H + 4) + (size_t)H * 9) * sizeof(float);
@@ -1574,6 +1621,19 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
+  } else if (blk && c->blk_fwd) {
+    ki = 1;
+#define LHC(DM)                                                                                                      \
+  STEP_LAUNCH((k_heads_comp<DM>), dim3(c->nt_b * c->gt.ng), dim3(512), 0, c->t, c->gt, h, P + d.off_w_heads,          \
+              P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, heads, c->ldh, z, c->ldz, concat_z, klw, kl, B, H,  \
+              NH, Z, duals)
+    const int bk = bucket_of(c->dmax);
+    if (bk == 2) { LHC(2); } else if (bk == 4) { LHC(4); } else { LHC(8); }
+#undef LHC
+    ki = 2;
+    const size_t lds = (size_t)16 * (H + 4) * sizeof(float);
+    STEP_LAUNCH(k_fwd3m, dim3(((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0,
+                P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z);
   } else {
   {
     ki = 1;
@@ -1620,7 +1680,20 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
-    if (fast_b) {
+    if (blk) {
+      const int n_blk = c->nt_b * ((H + 63) / 64);
+      const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
+#define LBB(DM, AD, TT)                                                                                               \
+  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_dwl), dim3(256), 0, c->t, dirtab, dhd, P + d.off_w_d0,    \
+              c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g, hd, G + d.off_w_logits, beta, B, H, D, NH, Z,       \
+              n_blk, at(d.off_w_logits), duals)
+#define LBB2(DM, AD) do { if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
+      const int bk = bucket_of(c->dmax);
+      if (fused) { if (bk == 2) LBB2(2, true); else if (bk == 4) LBB2(4, true); else LBB2(8, true); }
+      else { if (bk == 2) LBB2(2, false); else if (bk == 4) LBB2(4, false); else LBB2(8, false); }
+#undef LBB2
+#undef LBB
+    } else if (fast_b) {
       if (fused) { DMAX_SWITCH(c->dmax, LB(DM, true, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, true, false)); }
     } else {
       if (fused) { DMAX_SWITCH(c->dmax, LB(DM, false, true)); } else { DMAX_SWITCH(c->dmax, LB(DM, false, false)); }

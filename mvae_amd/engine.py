@@ -254,6 +254,14 @@ class StepEngine:
         check(load().mvae_train_step(self._context(B), ptr(x), ptr(eps), float(beta),
                                      1 if do_curvature_step else 0, stream_ptr(self.device)))
 
+    def kernel_path(self, batch: int = None) -> str:
+        """"row" | "fused" | "block": which latent kernels the step takes at this batch size (mvae_step_kernel_path)."""
+        B = int(batch) if batch is not None else (self._last_batch or 128)
+        rc = int(load().mvae_step_kernel_path(self._context(B)))
+        if rc < 0:
+            check(rc)
+        return ("row", "fused", "block")[rc]
+
     STEP_KERNELS = ("enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")
 
     def profile_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import T, assert_close, load_json, load_npz, summary_of
+from helpers import T, assert_close, assert_close_after_adam, load_json, load_npz, summary_of
 
 pytestmark = pytest.mark.gpu
 
@@ -373,6 +373,62 @@ def test_fused_step_matches_oracle_other_batch_sizes(dev):
         assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, f"elbo B={B}")
         for n, t in eng.param_views().items():
             assert_close(_cpu(t), orc.P[n].detach().numpy(), RTOL, f"param {n} B={B}")
+
+
+@pytest.mark.parametrize("model,H,D,B", [("3h2,s3,e2,p3,d2,u2,e2", 128, 96, 32), ("5e3,h4,2s2,e6", 64, 48, 16),
+                                         ("6h2,6s2,6e2", 400, 784, 128)])
+@pytest.mark.parametrize("blk_fwd", ["0", "1"])
+def test_block_latent_kernels_vs_oracle_and_row_kernels(dev, model, H, D, B, blk_fwd, monkeypatch):
+    """Many-small-component models take the 16-row block kernels (k_heads_comp, k_fwd3m, k_latent_bwd_blk): outputs,
+    gradients and the parameters after the optimizer against the oracle (1e-4), and against the one-row-per-workgroup
+    kernels (MVAE_NO_BLK=1) -- fused single-call step included."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, D)[0]
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+    comps = [(c.letter, c.true_dim) for c in spec.components]
+    monkeypatch.setenv("MVAE_BLK_FWD", blk_fwd)  # "1": k_heads_comp / k_fwd3m in the forward launches as well
+
+    def run(no_blk, fused):
+        if no_blk:
+            monkeypatch.setenv("MVAE_NO_BLK", "1")
+        else:
+            monkeypatch.delenv("MVAE_NO_BLK", raising=False)
+        eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * len(comps))
+        eng.load_state(state0)
+        out = None
+        if fused:
+            eng.train_step(x.to(dev), eps.to(dev), 0.7, True)
+        else:
+            out = eng.forward_backward(x.to(dev), eps.to(dev), 0.7, want_outputs=True)
+            out = {k: _cpu(v) for k, v in out.items()}
+            out["grads"] = {n: _cpu(t).copy() for n, t in eng.grad_views().items()}
+            eng.optimizer_step(True)
+        return eng, out
+
+    eng, out = run(False, False)
+    assert eng.kernel_path() == "block"
+    assert_close(out["concat_z"], ref.concat_z.detach().numpy(), RTOL, "concat_z")
+    assert_close(out["bce"], ref.bce.detach().numpy(), RTOL, "bce")
+    assert_close(out["kl"], ref.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, "elbo")
+    for n, t in eng.param_views().items():
+        assert_close_after_adam(_cpu(t), orc.P[n].detach().numpy(), 1e-3, 1, f"param {n}")
+    eng_r, out_r = run(True, False)
+    assert eng_r.kernel_path() == "row"
+    assert_close(out["logits"], out_r["logits"], 1e-5, "logits block vs row", atol_frac=1e-5)
+    for n in out["grads"]:
+        # radius / curvature gradients are sums over the batch of terms that cancel: float32 summation order shows
+        tol = 2e-4
+        assert_close(out["grads"][n], out_r["grads"][n], tol, f"grad {n} block vs row", atol_frac=tol)
+    eng_f, _ = run(False, True)
+    for (n, a), (_, b) in zip(eng_f.param_views().items(), eng.param_views().items()):
+        assert_close(_cpu(a), _cpu(b), 1e-5, f"fused vs two-call: {n}", atol_frac=1e-5)
 
 
 # ------------------------------------------------------------------------------------------------ robustness envelope
