@@ -50,7 +50,8 @@ enum {
   MVAE_OK = 0,
   MVAE_E_BADARG = -1,     /* null pointer, negative size, unknown kind */
   MVAE_E_UNSUPPORTED = -2,/* shape outside what the kernels were built for (e.g. true_dim > MVAE_MAX_TRUE_DIM) */
-  MVAE_E_ALIGN = -3       /* a matrix whose row stride is not a multiple of 4 floats / base not 16-byte aligned */
+  MVAE_E_ALIGN = -3,      /* a matrix whose row stride is not a multiple of 4 floats / base not 16-byte aligned */
+  MVAE_E_SYSTEM = -4      /* an operating-system call failed (shared-memory flag page of the peer exchange) */
 };
 
 #define MVAE_MAX_TRUE_DIM 64
@@ -417,6 +418,36 @@ int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images,
 #define MVAE_STEP_KERNELS 6
 int mvae_step_profile(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, int iters,
                       float* ms_out, void* stream);
+
+/* ---- Peer-read gradient exchange (data-parallel training on ONE node; new functionality -- the reference is
+ * single-device).  The intra-node alternative to "mvae_step_forward_backward -> RCCL all-reduce ->
+ * mvae_step_optimizer": every rank publishes its flat gradient buffer in its own HBM and the optimizer launch of every
+ * rank reads all ranks' buffers directly (hipIpc mappings: xGMI on a node) and adds them in RANK ORDER, so the sums --
+ * and therefore the parameters -- are bit-identical on every rank.  No host work per step; graph-capturable.
+ *
+ *   mvae_peer_create(n_floats = n_params, world, rank, shm_name, timeout_seconds, &peer)
+ *       allocates the rank's slot pair and opens the flag page `shm_name` (POSIX shared memory; the SAME fresh name on
+ *       every rank of the job, e.g. "/mvae-<random token broadcast by rank 0>").  world <= MVAE_PEER_MAX_WORLD.
+ *   mvae_peer_export(peer, handle)            the hipIpc handle of the rank's slots (MVAE_IPC_HANDLE_BYTES bytes) -- to be
+ *   mvae_peer_import(peer, r, handle_of_r)    all-gathered by the host layer and imported for every r != rank
+ *   per step, on `stream`:  mvae_step_forward_backward(...)  ->  mvae_peer_publish(peer, grads, stream)
+ *                           ->  mvae_step_optimizer_peer(ctx, peer, do_curvature_step, stream)
+ *       publish = copy into the slot of the next sequence number, then one signal kernel raises the rank's flag and waits
+ *       for every peer's flag (bounded: after timeout_seconds a rank stops waiting, COUNTS the event and goes on with
+ *       whatever is in the slot -- mvae_peer_timeouts() > 0 means the run is no longer synchronous);
+ *       mvae_step_optimizer_peer = mvae_step_optimizer with g := sum over ranks of their slots (also written to `grads`).
+ *   Every rank must call publish the same number of times.  mvae_peer_destroy synchronises the device. */
+typedef struct mvae_peer mvae_peer;
+#define MVAE_PEER_MAX_WORLD 16
+#define MVAE_IPC_HANDLE_BYTES 64
+int mvae_peer_create(int64_t n_floats, int world, int rank, const char* shm_name, double timeout_seconds,
+                     mvae_peer** out);
+void mvae_peer_destroy(mvae_peer* peer);
+int mvae_peer_export(mvae_peer* peer, uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
+int mvae_peer_import(mvae_peer* peer, int peer_rank, const uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
+int mvae_peer_publish(mvae_peer* peer, const float* grads, void* stream);
+int mvae_step_optimizer_peer(mvae_ctx* ctx, mvae_peer* peer, int do_curvature_step, void* stream);
+int mvae_peer_timeouts(mvae_peer* peer);
 
 /* Which kernels the latent part of the step takes for this context's shapes (a measurement / test aid; the result
  * of the step does not depend on it beyond float32 summation order):

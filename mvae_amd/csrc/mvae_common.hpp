@@ -68,6 +68,29 @@ constexpr int64_t kTiledMinRows = 512;
 bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K, int relu,
                           hipStream_t s);
 
+// ------------------------------------------------------------------------------------------------ peer exchange
+// State of the one-shot peer-read gradient exchange (mvae_peer.hip; read by the optimizer launch in mvae_step.hip).
+constexpr int kPeerMaxWorld = MVAE_PEER_MAX_WORLD;
+struct PeerSrc {  // kernel argument: where rank r's published gradients of the CURRENT sequence number live
+  const float* slot[kPeerMaxWorld];  // base of rank r's [2][n] slot pair, mapped into this process
+  const int* seq;                    // device word: sequence number of the last publish (parity selects the slot)
+  long long n;                       // floats per slot
+  int world;
+};
+struct mvae_peer {
+  int world = 0, rank = 0;
+  int64_t n = 0;
+  float* slots = nullptr;                    // own [2][n] floats (hipMalloc: exportable as ONE hipIpc handle)
+  float* peer_slots[kPeerMaxWorld] = {};     // rank r's slots in this process's address space (own pointer for r == rank)
+  bool imported[kPeerMaxWorld] = {};
+  int* seq = nullptr;                        // device: [0] sequence number, [1] spare
+  unsigned int* flags_host = nullptr;        // shared host page: [r] = last sequence number published by rank r,
+  unsigned int* flags_dev = nullptr;         //                   [32 + r] = wait time-outs seen by rank r
+  int shm_fd = -1;
+  char shm_name[128] = {};
+  unsigned long long timeout_ticks = 0;      // wall_clock64 ticks (100 MHz) a rank waits for a peer before giving up
+};
+
 // ------------------------------------------------------------------------------------------------ tables
 constexpr int kMaxComp = MVAE_MAX_COMPONENTS;
 constexpr int kRadiiRegion = 64;  // floats reserved at the start of the flat buffers for the raw radius parameters

@@ -38,6 +38,8 @@ struct mvae_ctx {
   bool blk_fwd;          // MVAE_BLK_FWD=1: block kernels in the forward launches as well (measured slower)
 };
 
+static int latent_path(const mvae_ctx* c, bool x_aligned);
+
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 static inline int64_t up64(int64_t x) { return (x + 63) & ~(int64_t)63; }
 
@@ -146,7 +148,8 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->blk_fwd = bf && bf[0] && bf[0] != '0';
   c->groups_ok = build_groups(c->t, &c->gt);
   carve(c, bucket_of(c->dmax));
-  if (c->groups_ok && (rc = upload_dirtab(c)) != 0) {
+  // the only device access of create, and only for models that take the block kernels
+  if (latent_path(c, true) == MVAE_PATH_BLOCK && (rc = upload_dirtab(c)) != 0) {
     delete c;
     return rc;
   }
@@ -163,7 +166,7 @@ extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) 
   for (int i = 0; i < n; ++i) comps[i] = c->t.c[i];
   const int rc = fill_table(&c->t, comps, n, trainable, &c->dmax);
   if (rc) return rc;
-  return c->groups_ok ? upload_dirtab(c) : 0;
+  return latent_path(c, true) == MVAE_PATH_BLOCK ? upload_dirtab(c) : 0;
 }
 
 #ifdef MV_DBG_TIMING
@@ -1473,19 +1476,47 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
 }
 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
+// PEER: the gradient is the sum of the ranks' published slots (mvae_peer.hip), added in rank order -- the same
+// floating-point sum on every rank -- and written to g like an all-reduced .grad.
+template <bool PEER>
 __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, float* m, float* v, int n4,
-                                               int* counters, double lr, double curv_lr, int do_curv) {
+                                               int* counters, double lr, double curv_lr, int do_curv, PeerSrc ps) {
   __shared__ float sh[2];
   __shared__ float gsh[kMaxComp];
   const int tid = threadIdx.x;
   adam_consts(sh, counters, lr, 1);
-  if (blockIdx.x == 0 && tid < t.n) gsh[tid] = g[tid];
+  size_t slot_off = 0;
+  if (PEER) slot_off = (size_t)(ps.seq[0] & 1) * (size_t)ps.n;
+  if (blockIdx.x == 0 && tid < t.n) {
+    float gv;
+    if (PEER) {
+      gv = ps.slot[0][slot_off + tid];
+      for (int r = 1; r < ps.world; ++r) gv += ps.slot[r][slot_off + tid];
+      g[tid] = gv;
+    } else {
+      gv = g[tid];
+    }
+    gsh[tid] = gv;
+  }
   __syncthreads();
   const float neg_step = sh[0], bc2s = sh[1];
   const int i4 = blockIdx.x * 256 + tid + kRadiiRegion / 4;
   if (i4 < n4) {
     float4 pp = reinterpret_cast<float4*>(p)[i4];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i4];
+    float4 gg;
+    if (PEER) {
+      gg = reinterpret_cast<const float4*>(ps.slot[0] + slot_off)[i4];
+      for (int r = 1; r < ps.world; ++r) {
+        const float4 o = reinterpret_cast<const float4*>(ps.slot[r] + slot_off)[i4];
+        gg.x += o.x;
+        gg.y += o.y;
+        gg.z += o.z;
+        gg.w += o.w;
+      }
+      store16_wt(g, (size_t)i4 * 4, f32x4{gg.x, gg.y, gg.z, gg.w});
+    } else {
+      gg = reinterpret_cast<const float4*>(g)[i4];
+    }
     float4 mm = reinterpret_cast<float4*>(m)[i4];
     float4 vv = reinterpret_cast<float4*>(v)[i4];
     adam1(pp.x, gg.x, mm.x, vv.x, neg_step, bc2s);
@@ -1738,9 +1769,29 @@ extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* str
   const mvae_model_desc& d = c->d;
   const int n4 = d.n_params / 4;
   const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
-  hipLaunchKernelGGL(k_optim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
-                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step);
+  hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
+                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, PeerSrc{});
   LAUNCH_CHECK("optimizer launch");
+  return 0;
+}
+
+extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_curvature_step, void* stream) {
+  if (!c || !peer) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const mvae_model_desc& d = c->d;
+  if (peer->n != d.n_params) return fail(MVAE_E_BADARG, "peer slots were sized for another parameter count%s", "");
+  PeerSrc ps{};
+  for (int r = 0; r < peer->world; ++r) {
+    if (!peer->imported[r]) return fail(MVAE_E_BADARG, "peer %s%lld has not been imported", "", r);
+    ps.slot[r] = peer->peer_slots[r];
+  }
+  ps.seq = peer->seq;
+  ps.n = peer->n;
+  ps.world = peer->world;
+  const int n4 = d.n_params / 4;
+  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
+                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, ps);
+  LAUNCH_CHECK("peer optimizer launch");
   return 0;
 }
 
@@ -1797,8 +1848,8 @@ extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam
   for (int i = 0; i < ncomp; ++i) t.trainable[i] = radius_trainable ? radius_trainable[i] : 0;
   const int n4 = (int)(n_params / 4);
   const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
-  hipLaunchKernelGGL(k_optim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v, n4,
-                     counters, lr, curvature_lr, do_curvature_step);
+  hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v,
+                     n4, counters, lr, curvature_lr, do_curvature_step, PeerSrc{});
   LAUNCH_CHECK("flat optimizer launch");
   return 0;
 }

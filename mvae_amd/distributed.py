@@ -79,11 +79,13 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 class DataParallelStep:
 
     def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False,
-                 overlap: Optional[bool] = None) -> None:
+                 overlap: Optional[bool] = None, exchange: Optional[str] = None) -> None:
         """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
         exercises the collective, its graph capture and k_optim on a single GPU).
         overlap: two-bucket exchange overlapped with the last backward launch (default: on; MVAE_DP_OVERLAP=0 turns it
-        off -- one all-reduce of the whole buffer after the backward pass)."""
+        off -- one all-reduce of the whole buffer after the backward pass).
+        exchange: "allreduce" (default: torch.distributed, RCCL on the GPU) or "peer" (MVAE_DP_EXCHANGE=peer): the
+        one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch -- ranks of ONE node only."""
         import os
         self.engine = engine
         self.group = group
@@ -91,6 +93,13 @@ class DataParallelStep:
         self.overlap = (os.environ.get("MVAE_DP_OVERLAP", "1") not in ("0", "")) if overlap is None else bool(overlap)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "allreduce")
+        if self.exchange not in ("allreduce", "peer"):
+            raise ValueError(f"unknown gradient exchange {self.exchange!r}")
+        self.peer = None
+        if self.exchange == "peer" and (self.world > 1 or self.always_exchange):
+            from .peer import PeerExchange
+            self.peer = PeerExchange(engine, group)
 
     def broadcast_state(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s parameters / optimizer state."""
@@ -102,6 +111,11 @@ class DataParallelStep:
         eng = self.engine
         if self.world == 1 and not self.always_exchange:
             eng.train_step(x_local, eps_local, beta, do_curvature_step)
+            return
+        if self.peer is not None:
+            eng.forward_backward(x_local, eps_local, beta)
+            self.peer.publish()
+            self.peer.optimizer_step(do_curvature_step, batch=x_local.shape[0])
             return
         if self.overlap and hasattr(eng, "forward_backward_part"):
             # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5.  An async

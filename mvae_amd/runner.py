@@ -47,7 +47,7 @@ class StepRunner:
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
         if self.gs > 0 and self.dp is not None and self.dp.world > 1:
             import torch.distributed as dist
-            if dist.get_backend(self.dp.group) != "nccl":
+            if dist.get_backend(self.dp.group) != "nccl" and self.dp.peer is None:
                 # only RCCL collectives can be captured; a host-side backend (gloo) invalidates the capture and leaves
                 # the process in an unusable capture state, so it is not even attempted
                 self.gs = 0
@@ -174,7 +174,8 @@ class EpochRunner:
         self.capturable = True
         if self.dp is not None:
             import torch.distributed as dist
-            self.capturable = dist.get_backend(self.dp.group) == "nccl"
+            # (the peer-read exchange has no collective in the step: capturable under any backend)
+            self.capturable = dist.get_backend(self.dp.group) == "nccl" or self.dp.peer is not None
 
     def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
         C, check, load, ptr, stream_ptr = self._c

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, q):
+def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None):
     import torch.distributed as dist
     from mvae_amd import synthetic
     from mvae_amd.distributed import DataParallelStep, shard_rows
@@ -35,12 +35,37 @@ def _worker(rank, world, port, steps, q):
     xs = synthetic.digits_like_batches(steps, 128)
     eps = synthetic.eps_batches(steps, 128, 6)
     lo, hi = shard_rows(128, rank, world)
-    dp = DataParallelStep(eng)
+    dp = DataParallelStep(eng, exchange=exchange)
     dp.broadcast_state()
-    for s in range(steps):
-        dp.train_step(xs[s, lo:hi].to(dev), eps[s, lo:hi].to(dev), 1.0, True)
+    xl, el = xs[:, lo:hi].contiguous().to(dev), eps[:, lo:hi].contiguous().to(dev)
+    if graph_steps:  # the whole [forward/backward, publish + wait, peer-read optimizer] sequence replayed as a HIP graph
+        for s in range(graph_steps):  # warm-up outside the capture (lazy initialisation), then rewind
+            dp.train_step(xl[s], el[s], 1.0, True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+        eng.reset_optimizer()
+        eng.stats.zero_()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for s in range(graph_steps):
+                    dp.train_step(xl[s], el[s], 1.0, True)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(steps // graph_steps):
+            g.replay()
+    else:
+        for s in range(steps):
+            dp.train_step(xl[s % (cycle or steps)], el[s % (cycle or steps)], 1.0, True)
+    torch.cuda.synchronize()
     total = dp.reduce_stats().cpu().numpy().copy()
-    q.put((rank, eng.params.cpu().numpy().copy(), total))
+    timeouts = dp.peer.timeouts() if dp.peer is not None else 0
+    q.put((rank, eng.params.cpu().numpy().copy(), total, timeouts))
+    dist.barrier()
+    if dp.peer is not None:
+        dp.peer.close()
     dist.destroy_process_group()
 
 
@@ -85,6 +110,38 @@ def test_two_rank_data_parallel_equals_single_process():
     n = 4 + 3
     np.testing.assert_allclose(results[0][2][:3], tot[:3], rtol=2e-4)
     assert results[0][2][3] == 2 * steps and tot[3] == steps  # every rank counts its own steps
+
+
+def _run_ranks(steps, world, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("graph_steps", [0, 3])
+def test_peer_read_exchange_two_processes_one_device(graph_steps):
+    """The one-shot peer-read reduction (mvae_peer_*: hipIpc-mapped gradient slots, host-coherent flags, the sum fused into
+    the optimizer launch) with two PROCESSES sharing cuda:0: no wait times out, the ranks end bit-identical, and the result
+    equals the all-reduce route -- bit for bit at world size 2, where both routes compute fl(g0 + g1).  graph_steps = 3:
+    the same through HIP graph replays (publish, flag wait and peer reads captured)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    steps, world = 6, 2
+    peer = _run_ranks(steps, world, exchange="peer", graph_steps=graph_steps)
+    assert peer[0][3] == 0 and peer[1][3] == 0, "a rank gave up waiting for its peer"
+    assert np.array_equal(peer[0][1], peer[1][1]), "ranks diverged"
+    ref = _run_ranks(steps, world, exchange="allreduce", cycle=graph_steps or None)  # a replay repeats its batches
+    assert np.array_equal(peer[0][1], ref[0][1]), "peer-read route differs from the all-reduce route"
+    np.testing.assert_allclose(peer[0][2][:3], ref[0][2][:3], rtol=1e-6)
 
 
 @pytest.mark.timeout(900)
