@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 4
+#define MVAE_ABI_VERSION 5
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -360,9 +360,10 @@ typedef struct mvae_model_desc {
                            float bits, [8] batch cursor of mvae_prepare_batch, [16..31] arrival scratch          */
   float* workspace;     /* [mvae_workspace_floats(desc)] activations, partial sums and the per-direction dual records
                            {d kl, d z} of the latent components (written by the forward, contracted by the backward) */
-  float* stats;         /* [2 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
+  float* stats;         /* [3 * (4 + ncomp)]: {bce, kl, elbo, n_steps, kl_0..} batch sums accumulated over steps, then the
                            same record for the LAST step only (stats.py:120-127 without the per-step .item() syncs:
-                           the host reads it when it wants to, e.g. once per epoch)                             */
+                           the host reads it when it wants to, e.g. once per epoch), then the Kahan compensation
+                           terms of the running sums (the reference accumulates Python doubles); zeroed by the host */
   uint8_t* radius_trainable; /* [ncomp] host pointer, copied: 0 = fixed curvature (requires_grad False)        */
   double lr;            /* Adam learning rate (run.py:33); betas (0.9, 0.999), eps 1e-8 = torch defaults        */
   double curvature_lr;  /* SGD lr on radii, 1e-4 (train.py:346,351)                                            */

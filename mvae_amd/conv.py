@@ -247,7 +247,7 @@ class ConvEngine:
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
         self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
         self.counters = z(32, torch.int32)
-        self.stats = z(2 * (4 + n))
+        self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
 
     def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
         """0 fixed / 1 trainable radius / 3 trainable universal curvature (clip group), see mvae_optimizer_step_flat."""

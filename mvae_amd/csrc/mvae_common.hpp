@@ -68,6 +68,16 @@ constexpr int64_t kTiledMinRows = 512;
 bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K, int relu,
                           hipStream_t s);
 
+// Running sums of the epoch statistics (stats.py:120-127 accumulates Python doubles): float32 with Kahan compensation,
+// sum block at stats[i], compensation at stats[comp_off + i].  A plain float32 sum drifts by ~1e-3 .. 4e-2 nats per
+// sample over a CIFAR-scale epoch (sum ~1e8, ulp 8); the compensated one stays within an ulp of the true total.
+__device__ __forceinline__ void kahan_add(float* stats, int i, int comp_off, float old_sum, float old_c, float x) {
+  const float y = x - old_c;
+  const float t = old_sum + y;
+  stats[comp_off + i] = (t - old_sum) - y;
+  stats[i] = t;
+}
+
 // ------------------------------------------------------------------------------------------------ peer exchange
 // State of the one-shot peer-read gradient exchange (mvae_peer.hip; read by the optimizer launch in mvae_step.hip).
 constexpr int kPeerMaxWorld = MVAE_PEER_MAX_WORLD;

@@ -251,12 +251,15 @@ __global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const flo
     const float sres = block_sum(a);
     kt += sres;
     if (tid == 0) {
-      stats[4 + i] += sres;
+      kahan_add(stats, 4 + i, 2 * last, stats[4 + i], stats[2 * last + 4 + i], sres);
       stats[last + 4 + i] = sres;
     }
   }
   if (tid == 0) {
-    stats[0] += bs; stats[1] += kt; stats[2] += es; stats[3] += 1.f;
+    kahan_add(stats, 0, 2 * last, stats[0], stats[2 * last], bs);
+    kahan_add(stats, 1, 2 * last, stats[1], stats[2 * last + 1], kt);
+    kahan_add(stats, 2, 2 * last, stats[2], stats[2 * last + 2], es);
+    stats[3] += 1.f;
     stats[last] = bs; stats[last + 1] = kt; stats[last + 2] = es; stats[last + 3] = 1.f;
   }
 }

@@ -981,7 +981,11 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   __shared__ float old_s[8 + kMaxComp];  // the running sums this step is added to, requested with the first loads
   const int tid = threadIdx.x, nthr = blockDim.x;
   const bool kl_in_lds = (size_t)ncomp * B <= 4096;
-  if (tid < 4 + ncomp) old_s[tid] = stats[tid];
+  __shared__ float old_c[8 + kMaxComp];  // their Kahan compensation terms (third block of `stats`)
+  if (tid < 4 + ncomp) {
+    old_s[tid] = stats[tid];
+    old_c[tid] = stats[2 * (4 + ncomp) + tid];
+  }
   const int P = (4 * B <= nthr) ? 4 : ((2 * B <= nthr) ? 2 : 1);
   const int rows_pass = nthr / P;  // rows handled per pass
   const int chunk = (ntD + P - 1) / P;
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       }
       a = wave_sum(a);
       if (lane == 0) {
-        stats[4 + i] = old_s[4 + i] + a;
+        kahan_add(stats, 4 + i, 2 * last, old_s[4 + i], old_c[4 + i], a);
         stats[last + 4 + i] = a;
         sm[16 + i] = a;
       }
@@ -1075,9 +1079,9 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   float kl_total = 0.f;
   if (tid == 0) {
     for (int i = 0; i < ncomp; ++i) kl_total += sm[16 + i];
-    stats[0] = old_s[0] + bce_sum;
-    stats[1] = old_s[1] + kl_total;
-    stats[2] = old_s[2] + elbo_sum;
+    kahan_add(stats, 0, 2 * last, old_s[0], old_c[0], bce_sum);
+    kahan_add(stats, 1, 2 * last, old_s[1], old_c[1], kl_total);
+    kahan_add(stats, 2, 2 * last, old_s[2], old_c[2], elbo_sum);
     stats[3] = old_s[3] + 1.f;
     stats[last + 0] = bce_sum;
     stats[last + 1] = kl_total;

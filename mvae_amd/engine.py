@@ -104,7 +104,7 @@ class StepEngine:
         z = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.device)  # noqa: E731
         self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
         self.counters = z(32, torch.int32)
-        self.stats = z(2 * (4 + n))
+        self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
         self._last_batch: Optional[int] = None
         # bumped whenever the contexts (workspace pointers, lr baked into kernel arguments) are rebuilt: anything that

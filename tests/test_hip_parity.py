@@ -431,6 +431,32 @@ def test_block_latent_kernels_vs_oracle_and_row_kernels(dev, model, H, D, B, blk
         assert_close(_cpu(a), _cpu(b), 1e-5, f"fused vs two-call: {n}", atol_frac=1e-5)
 
 
+def test_epoch_sums_are_compensated(dev):
+    """The running sums of the epoch statistics (the reference adds Python doubles, stats.py:120-127) are float32 with
+    Kahan compensation: at a CIFAR-scale running total (1e8, ulp 8) 300 further steps stay within one ulp of the
+    float64 total of the per-step values; a plain float32 sum is off by tens of ulps."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    xs = synthetic.binary_batches(4, 128, 784).to(dev)
+    eps = synthetic.eps_batches(4, 128, 6).to(dev)
+    base = np.array([1e8, 3e6, -1.03e8], dtype=np.float32)
+    eng.stats[:3] = torch.from_numpy(base).to(dev)
+    exact = base.astype(np.float64)
+    naive = base.copy()
+    n = 4 + 3
+    for s in range(300):
+        eng.train_step(xs[s % 4], eps[s % 4], 1.0, True)
+        last = eng.stats[n:n + 3].cpu().numpy()
+        exact += last.astype(np.float64)
+        naive = (naive + last).astype(np.float32)
+    got = eng.stats[:3].cpu().numpy().astype(np.float64)
+    ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(got - exact) <= 1.01 * ulp), (got - exact, ulp)
+    assert np.abs(naive.astype(np.float64) - exact).max() > 4 * ulp.max()  # what the compensation buys
+
+
 # ------------------------------------------------------------------------------------------------ robustness envelope
 @pytest.mark.parametrize("radius", [1e-5, 1.0, 1e5])
 @pytest.mark.parametrize("scale", [100.0, 1.01, 1.0])

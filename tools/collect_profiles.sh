@@ -25,7 +25,8 @@ timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc
 cd $ROOT
 # 5. the un-profiled bench lines of the same build
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
-timeout 600 python bench.py --no-cpu-baseline --model 6h2,6s2,6e2 --fixed-curvature > $OUT/bench_prod36.json 2>&1
+timeout 600 python bench.py --no-cpu-baseline --model 6h2,6s2,6e2 > $OUT/bench_prod36.json 2>&1   # learnable curvature, as golden mnist_prod36_learn
+timeout 600 python bench.py --no-cpu-baseline --config conv > $OUT/bench_conv.json 2>&1
 timeout 600 python bench.py --no-cpu-baseline --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
 # keep only the small summaries (the traces are large)
 find $OUT -name '*kernel_trace.csv' -size +20M -delete
