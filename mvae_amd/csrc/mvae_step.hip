@@ -35,10 +35,12 @@ struct mvae_ctx {
   GroupTable gt;         // component groups of the 16-row block kernels (mvae_step_blk.hpp)
   bool groups_ok;        // every component fits one 16-column head tile
   bool no_blk;           // MVAE_NO_BLK=1: per-row latent kernels for many-component models too (A/B measurements)
+  bool blk_small;        // MVAE_BLK_SMALL=1: the block backward kernel also for z_dim <= 16 (the fused-forward configs)
   bool blk_fwd;          // MVAE_BLK_FWD=1: block kernels in the forward launches as well (measured slower)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
+static bool uses_blk_bwd(const mvae_ctx* c, bool x_aligned);
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 static inline int64_t up64(int64_t x) { return (x + 63) & ~(int64_t)63; }
@@ -144,12 +146,14 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->no_fwd23 = nf && nf[0] && nf[0] != '0';
   const char* nb = getenv("MVAE_NO_BLK");
   c->no_blk = nb && nb[0] && nb[0] != '0';
+  const char* bs = getenv("MVAE_BLK_SMALL");
+  c->blk_small = bs && bs[0] && bs[0] != '0';
   const char* bf = getenv("MVAE_BLK_FWD");
   c->blk_fwd = bf && bf[0] && bf[0] != '0';
   c->groups_ok = build_groups(c->t, &c->gt);
   carve(c, bucket_of(c->dmax));
   // the only device access of create, and only for models that take the block kernels
-  if (latent_path(c, true) == MVAE_PATH_BLOCK && (rc = upload_dirtab(c)) != 0) {
+  if (uses_blk_bwd(c, true) && (rc = upload_dirtab(c)) != 0) {
     delete c;
     return rc;
   }
@@ -166,7 +170,7 @@ extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) 
   for (int i = 0; i < n; ++i) comps[i] = c->t.c[i];
   const int rc = fill_table(&c->t, comps, n, trainable, &c->dmax);
   if (rc) return rc;
-  return latent_path(c, true) == MVAE_PATH_BLOCK ? upload_dirtab(c) : 0;
+  return uses_blk_bwd(c, true) ? upload_dirtab(c) : 0;
 }
 
 #ifdef MV_DBG_TIMING
@@ -708,13 +712,25 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       const int grow = (rr < 16 || two) ? nt * 16 + rr : nt * 16 + rr - 16;
       wv[u] = *reinterpret_cast<const f32x4*>(Wl + (size_t)grow * H + 4 * (r < 32 ? c4 : 0));
     }
-    // W_d0 [H][Z] -> wd_s[H][8] (zero-padded columns), b_d0 -> bd_s
+    // W_d0 [H][Z] -> wd_s[H][8] (zero-padded columns), b_d0 -> bd_s.  Z == 8 / 4: whole 16-byte vectors; other even Z
+    // (Z == 6: BASELINE config [0], `e6`): 8-byte pairs, 4 x 256 x 2 floats cover H Z <= 2048 ... 512 * 6 needs 6
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x4 dv[4];
-    const int nd4 = (H * Z) >> 2;  // Z == 8 or Z == 4: whole float4 (checked on the host: Z % 4 == 0), else scalar path
+    f32x2 dp[6];
+    const int nd4 = (H * Z) >> 2, nd2 = (H * Z) >> 1;
+    const bool quads = Z == 8 || Z == 4;  // uniform
+    if (quads) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e4 = lt + 256 * u;
-      dv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nd4 ? e4 : 0));
+      for (int u = 0; u < 4; ++u) {
+        const int e4 = lt + 256 * u;
+        dv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nd4 ? e4 : 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int e2 = lt + 256 * u;
+        dp[u] = *reinterpret_cast<const f32x2*>(Wd0 + 2 * (size_t)(e2 < nd2 ? e2 : 0));
+      }
     }
     float bdv2[2];
 #pragma unroll
@@ -729,16 +745,32 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       const int r = e4 / H4, c4 = e4 - r * H4;
       if (r < 32) *reinterpret_cast<f32x4*>(wl_s + r * ld + 4 * c4) = wv[u];
     }
+    if (quads) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e4 = lt + 256 * u;
-      if (e4 < nd4) {
-        if (Z == 8) {
-          *reinterpret_cast<f32x4*>(wd_s + 4 * e4) = dv[u];
-        } else {  // Z == 4: row c = e4, columns 0..3; columns 4..7 are zero
-          *reinterpret_cast<f32x4*>(wd_s + 8 * e4) = dv[u];
-          *reinterpret_cast<f32x4*>(wd_s + 8 * e4 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 4; ++u) {
+        const int e4 = lt + 256 * u;
+        if (e4 < nd4) {
+          if (Z == 8) {
+            *reinterpret_cast<f32x4*>(wd_s + 4 * e4) = dv[u];
+          } else {  // Z == 4: row c = e4, columns 0..3; columns 4..7 are zero
+            *reinterpret_cast<f32x4*>(wd_s + 8 * e4) = dv[u];
+            *reinterpret_cast<f32x4*>(wd_s + 8 * e4 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
+      }
+    } else {
+      const int zh = Z >> 1;  // pairs per row
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int e2 = lt + 256 * u;
+        if (e2 < nd2) {
+          const int c = e2 / zh, j2 = e2 - c * zh;
+          *reinterpret_cast<f32x2*>(wd_s + 8 * c + 2 * j2) = dp[u];
+        }
+      }
+      for (int e = lt; e < H * (8 - Z); e += 256) {  // zero padding of the columns past Z
+        const int c = e / (8 - Z), j = Z + e - c * (8 - Z);
+        wd_s[8 * c + j] = 0.f;
       }
     }
 #pragma unroll
@@ -1570,7 +1602,8 @@ static int latent_path(const mvae_ctx* c, bool x_aligned) {
   int max_slot = 0;
   for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
   // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
-  if (fast && full && (B % 128 == 0) && (Z == 8 || Z == 4) && d.eps_dim <= 8 && d.ncomp <= 8 && max_slot < 4 &&
+  if (fast && full && (B % 128 == 0) && (Z == 8 || Z == 4 || Z == 6 || Z == 2) && d.eps_dim <= 8 && d.ncomp <= 8 &&
+      max_slot < 4 && aligned16(P + d.off_w_d0) &&
       bucket_of(c->dmax) <= 8 && !c->no_fwd23)
     return MVAE_PATH_FUSED;
   // many small components: 16-row block kernels (mvae_step_blk.hpp)
@@ -1578,6 +1611,15 @@ static int latent_path(const mvae_ctx* c, bool x_aligned) {
       bucket_of(c->dmax) <= 8 && aligned16(P + d.off_w_d0) && aligned16(P + d.off_w_heads))
     return MVAE_PATH_BLOCK;
   return MVAE_PATH_ROW;
+}
+
+// the block form of the latent BACKWARD launch: many-component models, and (MVAE_BLK_SMALL) the small-z ones
+static bool uses_blk_bwd(const mvae_ctx* c, bool x_aligned) {
+  const int path = latent_path(c, x_aligned);
+  if (path == MVAE_PATH_BLOCK) return true;
+  const mvae_model_desc& d = c->d;
+  return path == MVAE_PATH_FUSED && c->blk_small && c->groups_ok && !c->no_blk && (d.z_dim & 3) == 0 && d.z_dim <= 16 &&
+         d.heads_dim + d.ncomp <= 64 && aligned16(d.params + d.off_w_d0);
 }
 
 extern "C" int mvae_step_kernel_path(const mvae_ctx* c) { return c ? latent_path(c, true) : MVAE_E_BADARG; }
@@ -1715,14 +1757,15 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
-    if (blk) {
+    if (uses_blk_bwd(c, aligned16(x))) {
       const int n_blk = c->nt_b * ((H + 63) / 64);
+      const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
       const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
 #define LBB(DM, AD, TT)                                                                                               \
-  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_dwl), dim3(256), 0, c->t, dirtab, dhd, P + d.off_w_d0,    \
+  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_dwl), dim3(256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
               c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g, hd, G + d.off_w_logits, beta, B, H, D, NH, Z,       \
               n_blk, at(d.off_w_logits), duals)
-#define LBB2(DM, AD) do { if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
+#define LBB2(DM, AD) do { if (Z <= 16) LBB(DM, AD, 1); else if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) LBB2(2, true); else if (bk == 4) LBB2(4, true); else LBB2(8, true); }
       else { if (bk == 2) LBB2(2, false); else if (bk == 4) LBB2(4, false); else LBB2(8, false); }

@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
                                                         float* dheads, float* dh, float* drpart, const float* g,
                                                         const float* hd, float* dWl, float beta, int B, int H, int D,
                                                         int NH, int Z, int n_blk, AdamArgs awl, const float* duals) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // TT == 1: W_d0 [H][Z]
   __shared__ float red[4][4][16][17];  // [wave][interleaved tile][row][col]
   __shared__ __attribute__((aligned(16))) float dz_s[16][68];
   __shared__ __attribute__((aligned(16))) float dheads_s[16][kHeadsMax + 4];
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
   MV_T(0);
   const int i = lane & 15, q = lane >> 4;
   constexpr int DS = DMAX + 2;
-  constexpr int kPre = 2;  // 64-record rounds whose table entries and records are requested at the top
+  constexpr int kPre = TT == 1 ? 1 : 2;  // 64-record rounds whose table entries and records are requested at the top
   typedef float fTT __attribute__((ext_vector_type(TT), aligned(4)));
 
   // ---- requests, in the order of use.  Dual records: wave w takes rows 4w .. 4w+3, lane = record of the row (64 per
@@ -401,6 +402,54 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
       h + ((size_t)mt * 16 + (tid >> 4)) * H + ((s * 64 + 4 * (tid & 15) < H) ? s * 64 + 4 * (tid & 15) : 0));
   const int nchunks = H >> 4;
   const float* arow = dhd + (size_t)(mt * 16 + i) * H;
+  const int KC = (NH + 15) >> 4;  // 16-wide k chunks of the dh contraction
+  f32x4 acc[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (TT == 1) {
+    // z_dim <= 16 (the BASELINE configs with few components): W_d0 is a few KB -- staged once through LDS with coalesced
+    // 16-byte requests (H Z / 1024 per thread) instead of 4 strided 4-byte requests per chunk; the dhd block of this wave
+    // (<= 8 chunks) is requested up front.
+    float* wd_s = dyn;
+    const int nw4 = (H * Z) >> 2;
+    f32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // H Z <= 512 * 16: at most 8 per thread
+      const int e4 = tid + 256 * u;
+      wv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nw4 ? e4 : 0));
+    }
+    float4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = wave + 4 * u;
+      a[u] = *reinterpret_cast<const float4*>(arow + (c < nchunks ? c : 0) * 16 + 4 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int e = tid; e < 16 * (KC * 16 - NH); e += 256) {  // zero padding of the last chunk
+      const int w = KC * 16 - NH;
+      dheads_s[e / w][NH + e % w] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e4 = tid + 256 * u;
+      if (e4 < nw4) *reinterpret_cast<f32x4*>(wd_s + 4 * e4) = wv[u];
+    }
+    lds_barrier();
+    MV_T(1);
+    const int zi = i < Z ? i : 0;  // tile columns past Z repeat column 0; nobody reads their outputs
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = wave + 4 * u;
+      if (c < nchunks) {  // uniform
+        const float* wk = wd_s + (size_t)(c * 16 + 4 * q) * Z + zi;
+        acc[0] = mfma16(a[u].x, wk[0], acc[0]);
+        acc[1] = mfma16(a[u].y, wk[Z], acc[1]);
+        acc[0] = mfma16(a[u].z, wk[2 * Z], acc[0]);
+        acc[1] = mfma16(a[u].w, wk[3 * Z], acc[1]);
+      }
+    }
+    acc[0] += acc[1];
+  } else {
   // a lane whose first column exists reads its TT columns even if the last ones lie past the row (they belong to the
   // next row / the padding after the matrix: finite or not, they only reach output columns >= Z, which nobody reads);
   // lanes entirely past Z re-read column 0
@@ -421,15 +470,11 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
   constexpr int kAhead = 3;
 #pragma unroll
   for (int u = 0; u < kAhead; ++u) request(u);
-  const int KC = (NH + 15) >> 4;  // 16-wide k chunks of the dh contraction
   for (int e = tid; e < 16 * (KC * 16 - NH); e += 256) {  // zero padding of the last chunk
     const int w = KC * 16 - NH;
     dheads_s[e / w][NH + e % w] = 0.f;
   }
   MV_T(1);
-  f32x4 acc[4];
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     if (u + kAhead < 8) request(u + kAhead);
@@ -443,6 +488,7 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
   MV_T(2);
   // the W_heads requests of the last phase travel during the reduction and the record phase
   const int n0 = s * 64;
@@ -451,10 +497,12 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int c = wave + 4 * u;
+    if (c < KC) {  // uniform: chunks this wave does not have are not requested
 #pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-      const int krow = c * 16 + 4 * q + tp;
-      bw[u][tp] = *reinterpret_cast<const f32x4*>(Wh + (size_t)(krow < NH ? krow : 0) * H + col);
+      for (int tp = 0; tp < 4; ++tp) {
+        const int krow = c * 16 + 4 * q + tp;
+        bw[u][tp] = *reinterpret_cast<const f32x4*>(Wh + (size_t)(krow < NH ? krow : 0) * H + col);
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);

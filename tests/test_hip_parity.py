@@ -376,6 +376,7 @@ def test_fused_step_matches_oracle_other_batch_sizes(dev):
 
 
 @pytest.mark.parametrize("model,H,D,B", [("3h2,s3,e2,p3,d2,u2,e2", 128, 96, 32), ("5e3,h4,2s2,e6", 64, 48, 16),
+                                         ("4e2,h3", 64, 48, 16),
                                          ("6h2,6s2,6e2", 400, 784, 128)])
 @pytest.mark.parametrize("blk_fwd", ["0", "1"])
 def test_block_latent_kernels_vs_oracle_and_row_kernels(dev, model, H, D, B, blk_fwd, monkeypatch):
