@@ -420,6 +420,15 @@ int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images,
 int mvae_step_profile(mvae_ctx* ctx, const float* x, const float* eps, float beta, int do_curvature_step, int iters,
                       float* ms_out, void* stream);
 
+/* Deferred slice sums (conv step): mvae_gemm_tn, mvae_conv_k4s2p1_nhwc_wgrad and mvae_colsum split tall contractions
+ * into row slices and finish with "add the slices in index order".  Between mvae_slice_sums_defer(1) and
+ * mvae_slice_sums_flush(stream) they only write their slices and QUEUE that final sum; the flush performs all queued sums
+ * (same order of additions, hence the same bits) in ONE launch -- in the conv backward pass that replaces ~13 launches
+ * whose outputs nobody reads before the optimizer.  The caller keeps every workspace alive until the flush.  State is
+ * per calling thread and host-side only (graph-capturable); a full queue (24 entries) flushes itself. */
+int mvae_slice_sums_defer(int on);
+int mvae_slice_sums_flush(void* stream);
+
 /* ---- Peer-read gradient exchange (data-parallel training on ONE node; new functionality -- the reference is
  * single-device).  The intra-node alternative to "mvae_step_forward_backward -> RCCL all-reduce ->
  * mvae_step_optimizer": every rank publishes its flat gradient buffer in its own HBM and the optimizer launch of every

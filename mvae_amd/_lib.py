@@ -101,6 +101,8 @@ PROTOTYPES = {
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),
+    "mvae_slice_sums_defer": (C.c_int, [_I]),
+    "mvae_slice_sums_flush": (C.c_int, [_P]),
     "mvae_step_kernel_path": (C.c_int, [_P]),
     "mvae_peer_create": (C.c_int, [C.c_int64, _I, _I, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]),
     "mvae_peer_destroy": (None, [C.c_void_p]),

@@ -159,6 +159,16 @@ def _from_taps_major(dWt: Tensor, rows: int, Cc: int, out: Tensor) -> Tensor:
     return _permute_rc(dWt.reshape(rows, 16, Cc), rows, 16, Cc, out=out)
 
 
+# Workspaces whose final slice sum is queued (mvae_slice_sums_defer): alive until the flush.
+_DEFERRED_WS: list = []
+
+
+def _keep(ws: Optional[Tensor]) -> Optional[Tensor]:
+    if ws is not None:
+        _DEFERRED_WS.append(ws)
+    return ws
+
+
 def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[NP, NQ] = P^T Q; `out` may be a (contiguous) view into the flat gradient buffer."""
     M, NP = P.shape
@@ -167,7 +177,7 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
         out = P.new_empty(NP, NQ)
     assert out.is_contiguous() and out.numel() == NP * NQ
     nws = load().mvae_gemm_tn_workspace_floats(M, NP, NQ)
-    ws = P.new_empty(int(nws)) if nws > 0 else None
+    ws = _keep(P.new_empty(int(nws))) if nws > 0 else None
     check(load().mvae_gemm_tn(ptr(P), ptr(Q), ptr(out), M, NP, NQ, ptr(ws), stream_ptr(P.device)))
     return out
 
@@ -185,7 +195,7 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
         out = G.new_empty(G.shape[1])
     assert out.is_contiguous() and out.numel() == G.shape[1]
     nws = load().mvae_colsum_workspace_floats(G.shape[0], G.shape[1])
-    ws = G.new_empty(int(nws)) if nws > 0 else None
+    ws = _keep(G.new_empty(int(nws))) if nws > 0 else None
     check(load().mvae_colsum(ptr(G), ptr(out), G.shape[0], G.shape[1], ptr(ws), stream_ptr(G.device)))
     return out
 
@@ -206,7 +216,7 @@ def _conv_nhwc_wgrad(dy: Tensor, src: Tensor, out: Tensor, B: int, Cc: int, IH: 
     OC = dy.shape[1]
     assert out.is_contiguous() and out.numel() == OC * 16 * Cc
     nws = int(load().mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(B, Cc, IH, IH, OC))
-    ws = dy.new_empty(nws) if nws > 0 else None
+    ws = _keep(dy.new_empty(nws)) if nws > 0 else None
     check(load().mvae_conv_k4s2p1_nhwc_wgrad(ptr(dy), ptr(src), ptr(out), B, Cc, IH, IH, OC, ptr(ws),
                                              stream_ptr(dy.device)))
     return out
@@ -353,6 +363,16 @@ class ConvEngine:
         check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
                                       stream_ptr(self.device)))
         PV, GV = self.param_views(), self.grad_views()
+        # the final "add the slices" of every weight gradient / bias column sum below is queued and performed by ONE
+        # launch at the end of the backward pass (nobody reads those gradients before the optimizer)
+        _DEFERRED_WS.clear()
+        check(load().mvae_slice_sums_defer(1))
+        try:
+            return self._backward(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay)
+        finally:
+            check(load().mvae_slice_sums_defer(0))
+
+    def _backward(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
         # ---- decoder backward
         dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
@@ -389,6 +409,8 @@ class ConvEngine:
         da0 = _col2im(_gemm_nn(da1, c["We1"]), None, c["a0"], B, 64, 16, _nhwc(16, 64), False, (B * 256, 64), True)
         _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
         _colsum(da0, out=GV["e0.bias"])
+        check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
+        _DEFERRED_WS.clear()
         if want_outputs:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None

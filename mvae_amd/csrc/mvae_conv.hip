@@ -615,6 +615,87 @@ __global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* ou
     __syncthreads();
   }
 }
+// Deferred slice sums: between mvae_slice_sums_defer(1) and mvae_slice_sums_flush() the producers below (weight
+// gradients, tall column sums) only write their slices and QUEUE the final "add the slices in index order"; the flush
+// performs every queued sum in ONE launch.  In the conv step these sums are ~13 launches of ~5 us each whose outputs
+// nobody reads before the optimizer.  Host-side state, per calling thread; nothing here synchronises.
+constexpr int kMaxSumJobs = 24;
+struct SumJobs {
+  const float* part[kMaxSumJobs];
+  float* out[kMaxSumJobs];
+  long long n[kMaxSumJobs];
+  int slices[kMaxSumJobs];
+  int blk0[kMaxSumJobs + 1];
+  int njobs;
+};
+static thread_local SumJobs g_sums;
+static thread_local bool g_defer = false;
+
+__global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
+  __shared__ float sm[4][64];
+  int j = 0;
+  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
+  const float* part = jobs.part[j];
+  float* out = jobs.out[j];
+  const long long n = jobs.n[j];
+  const int slices = jobs.slices[j];
+  const int nblk = jobs.blk0[j + 1] - jobs.blk0[j];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (long long base = (long long)((int)blockIdx.x - jobs.blk0[j]) * 64; base < n; base += (long long)nblk * 64) {
+    const long long i = base + lane;
+    float s = 0.f;
+    if (i < n) {
+      int k = w;
+      for (; k + 28 < slices; k += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < slices; k += 4) s += part[(size_t)k * n + i];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) out[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);  // same order as k_sum_slices
+    __syncthreads();
+  }
+}
+
+static void flush_sums(hipStream_t s) {
+  if (g_sums.njobs == 0) return;
+  hipLaunchKernelGGL(k_sum_slices_batched, dim3((unsigned)g_sums.blk0[g_sums.njobs]), dim3(256), 0, s, g_sums);
+  g_sums.njobs = 0;
+}
+
+// the final sum of `slices` partial results: now, or queued while deferral is on
+static void sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
+  if (!g_defer) {
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, s, part, out, n, slices);
+    return;
+  }
+  if (g_sums.njobs == kMaxSumJobs) flush_sums(s);
+  const int j = g_sums.njobs++;
+  if (j == 0) g_sums.blk0[0] = 0;
+  g_sums.part[j] = part;
+  g_sums.out[j] = out;
+  g_sums.n[j] = n;
+  g_sums.slices[j] = slices;
+  const long long want = (n + 63) / 64;
+  g_sums.blk0[j + 1] = g_sums.blk0[j] + (int)(want < 256 ? want : 256);
+}
+
+extern "C" int mvae_slice_sums_defer(int on) {
+  g_defer = on != 0;
+  return 0;
+}
+
+extern "C" int mvae_slice_sums_flush(void* stream) {
+  flush_sums((hipStream_t)stream);
+  LAUNCH_CHECK("batched slice sums");
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void k_relu_mask(float* dy, const float* y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     if (!(y[i] > 0.f)) dy[i] = 0.f;
@@ -640,8 +721,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     const int64_t n = (int64_t)NP * NQ;
     launch_gemm_tiled<false, false>(P, 1, NP, Q, NQ, 1, slices > 1 ? workspace : out, NQ, nullptr, nullptr, 0, NP, NQ,
                                     (int)M, slices, kps, n, (hipStream_t)stream);
-    if (slices > 1)
-      hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+    if (slices > 1) sum_slices(workspace, out, n, slices, (hipStream_t)stream);
     LAUNCH_CHECK("tiled gemm_tn launch");
     return 0;
   }
@@ -654,7 +734,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     hipLaunchKernelGGL(k_gemm_tn_sliced, dim3((unsigned)(tiles * slices)), dim3(256), 0, (hipStream_t)stream, P, Q,
                        workspace, (int)M, NP, NQ, tiles);
     const int64_t n = (int64_t)NP * NQ;
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, out, n, slices);
+    sum_slices(workspace, out, n, slices, (hipStream_t)stream);
   }
   LAUNCH_CHECK("gemm_tn launch");
   return 0;
@@ -721,8 +801,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, fl
   const int64_t n = (int64_t)OC * NQ;
   launch_gemm_tiled<false, false, 2>(dy, 1, OC, src, 0, 0, slices > 1 ? workspace : dWt, NQ, nullptr, nullptr, 0, OC, NQ,
                                      (int)M, slices, kps, n, (hipStream_t)stream, g);
-  if (slices > 1)
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, dWt, n, slices);
+  if (slices > 1) sum_slices(workspace, dWt, n, slices, (hipStream_t)stream);
   LAUNCH_CHECK("implicit conv weight gradient launch");
   return 0;
 }
@@ -801,8 +880,7 @@ extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* 
     const int slices = (int)((M + kColSlice - 1) / kColSlice);
     hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
                        workspace, (int)M, N, ncb);
-    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * (int64_t)N)), dim3(256), 0, (hipStream_t)stream, workspace, out, (int64_t)N,
-                       slices);
+    sum_slices(workspace, out, (int64_t)N, slices, (hipStream_t)stream);
   }
   LAUNCH_CHECK("colsum launch");
   return 0;
