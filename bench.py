@@ -347,7 +347,12 @@ def main():
     import glob
     # fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, see profiles/README.md):
     # the newest summary that knows every launch of this step
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    def _order(path):  # r02 (the round's final set) after r02a, r02b (mid-round sets) after r01
+        tag = os.path.basename(path).split("_")[0]
+        digits = "".join(ch for ch in tag[1:] if ch.isdigit())
+        suffix = tag[1 + len(digits):]
+        return (int(digits or 0), 1 if suffix == "" else 0, suffix)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_order, reverse=True):
         name = os.path.basename(path)
         try:
             with open(path) as fh:
