@@ -270,8 +270,11 @@ int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, f
  *   a ConvTranspose2d (conv_vae.py:72-74).
  *   dWt[oc, (ky,kx,c)] = sum_{b,oy,ox} dy[(b,oy,ox), oc] src[b, 2oy-1+ky, 2ox-1+kx, c]: the weight gradient of either
  *   (rows are cut into slices added in index order; workspace = mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats floats). */
+/* workspace (may be NULL): mvae_conv_k4s2p1_nhwc_workspace_floats(...) floats; when given, a layer with fewer than 256
+ * output tiles and a patch axis >= 2048 splits the contraction into <= 4 slices added in index order (mask == NULL only). */
+int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
 int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
-                          int IH, int IW, int OC, int relu, void* stream);
+                          int IH, int IW, int OC, int relu, float* workspace, void* stream);
 int64_t mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(int B, int C, int IH, int IW, int OC);
 int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, float* dWt, int B, int C, int IH, int IW, int OC,
                                 float* workspace, void* stream);

@@ -206,8 +206,10 @@ def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[T
     taps-major.  Conv2d forward, or ConvTranspose2d backward-data with `mask` = the previous ReLU's output."""
     OC = Wt.shape[0]
     y = src.new_empty(B * (IH // 2) * (IH // 2), OC)
+    nws = int(load().mvae_conv_k4s2p1_nhwc_workspace_floats(B, Cc, IH, IH, OC, 0 if mask is None else 1))
+    ws = src.new_empty(nws) if nws > 0 else None  # split-K slices of a layer with few output tiles
     check(load().mvae_conv_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
-                                       1 if relu else 0, stream_ptr(src.device)))
+                                       1 if relu else 0, ptr(ws), stream_ptr(src.device)))
     return y
 
 

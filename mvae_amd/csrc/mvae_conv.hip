@@ -751,8 +751,29 @@ static int conv_geom(ConvGeom* g, int B, int Cc, int IH, int IW) {
   return 0;
 }
 
+// Split-K for the implicit forward contraction: a layer with few output tiles and a long patch axis (ConvTranspose d1
+// backward-data at B = 256: 4096 x 128 outputs = 128 tiles of 64 x 64, K = 4096) leaves half of the chip idle; its K range
+// is cut into up to 4 slices whose partial products are added in index order (+ bias, ReLU) by k_sum_slices.
+static int conv_fwd_slices(int64_t M, int OC, int K, bool has_mask, int* kps) {
+  *kps = K;
+  if (has_mask || OC <= 64) return 1;
+  const int64_t tiles = ((OC + 63) / 64) * ((M + 63) / 64);
+  if (tiles >= 256 || K < 2048) return 1;
+  int slices = (int)((256 + tiles - 1) / tiles);
+  if (slices > 4) slices = 4;
+  *kps = ((K + slices - 1) / slices + 31) & ~31;
+  return (K + *kps - 1) / *kps;
+}
+
+extern "C" int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int Cc, int IH, int IW, int OC, int has_mask) {
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  int kps;
+  const int slices = conv_fwd_slices(M, OC, 16 * Cc, has_mask != 0, &kps);
+  return slices > 1 ? (int64_t)slices * M * OC : 0;
+}
+
 extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
-                                     int B, int Cc, int IH, int IW, int OC, int relu, void* stream) {
+                                     int B, int Cc, int IH, int IW, int OC, int relu, float* workspace, void* stream) {
   if (!src || !Wt || !y || OC < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   ConvGeom g;
   int rc = conv_geom(&g, B, Cc, IH, IW);
@@ -762,8 +783,19 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
   if (!tiled_ok(src, Cc) || !tiled_ok(Wt, K) || !tiled_ok(y, OC) || (mask && !tiled_ok(mask, OC)) ||
       (bias && ((uintptr_t)bias & 15)) || M > 0x7fffffff)
     return fail(MVAE_E_ALIGN, "implicit conv needs 16-byte aligned operands%s", "");
-  launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, y, OC, bias, mask, relu, (int)M, OC, K, 1, K, 0,
-                                   (hipStream_t)stream, g);
+  int kps;
+  const int slices = workspace ? conv_fwd_slices(M, OC, K, mask != nullptr, &kps) : 1;
+  if (slices > 1) {
+    if (!tiled_ok(workspace, OC)) return fail(MVAE_E_ALIGN, "implicit conv workspace must be 16-byte aligned%s", "");
+    const int64_t n = M * OC;
+    launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, workspace, OC, nullptr, nullptr, 0, (int)M, OC, K, slices, kps,
+                                     n, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, y, n, slices,
+                       bias, OC, relu);
+  } else {
+    launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, y, OC, bias, mask, relu, (int)M, OC, K, 1, K, 0,
+                                     (hipStream_t)stream, g);
+  }
   LAUNCH_CHECK("implicit conv launch");
   return 0;
 }
