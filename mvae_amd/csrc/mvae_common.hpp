@@ -604,18 +604,25 @@ __host__ __device__ inline int xcd_grid(int NT, int MT, int G = 1) {
   const int groups = (NT + G - 1) / G;
   return 8 * ((groups + 7) / 8) * MT * G;
 }
+// a / b for 0 <= a < 2^20, b > 0 through the float reciprocal (5 instructions; hipcc's exact 32-bit division is ~35
+// dependent ones, and the tile index of a workgroup is computed BEFORE its first load can be issued).  Exact: (a + 0.5) / b
+// is at least 0.5 / b away from an integer, far more than the rounding of the product.
+__device__ __forceinline__ int fast_div(int a, int b) {
+  return (int)(((float)a + 0.5f) * __frcp_rn((float)b));
+}
 __device__ __forceinline__ bool xcd_tile_g(int NT, int MT, int G, int* nt, int* mt, int L = blockIdx.x) {
   const int k = L & 7, s = L >> 3;
   const int per = MT * G;
-  const int gi = s / per, rem = s - gi * per;
-  *mt = rem / G;
+  const int gi = fast_div(s, per), rem = s - gi * per;
+  *mt = fast_div(rem, G);
   *nt = (k + 8 * gi) * G + (rem - (*mt) * G);
   return *nt < NT;
 }
 __device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L = blockIdx.x) {
   const int k = L & 7, s = L >> 3;
-  *nt = k + 8 * (s / MT);
-  *mt = s % MT;
+  const int gi = fast_div(s, MT);
+  *nt = k + 8 * gi;
+  *mt = s - gi * MT;
   return *nt < NT;
 }
 

@@ -562,13 +562,13 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     if (L < full * MT) (void)xcd_tile(full, MT, &pt, &mt, L);
     else {
       const int idx = L - full * MT;
-      pt = full + idx / MT;
+      pt = full + fast_div(idx, MT);
       mt = idx - (pt - full) * MT;
     }
   }
   nt = pt * 2;
   const bool two = nt + 1 < ntD;  // the last pair of an odd tile count has one tile
-  const bool lead = !is_dual && pt == mt % ntP;
+  const bool lead = !is_dual && pt == mt - fast_div(mt, ntP) * ntP;
   MV_TDECL;
   MV_T(0);
   const int ld = H + 4;
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
     __builtin_amdgcn_s_sleep(MV_TILE_SLEEP);
 #endif
     const int ntHg = ((H + 15) / 16 + kTileWaves5 - 1) / kTileWaves5;
-    int pt = b / ntHg, qg = b - pt * ntHg;
+    const int pt = fast_div(b, ntHg), qg = b - pt * ntHg;
     // (tried: XCD parity classes of the g column blocks as in launch 6, and g-blocks-fastest order: 5.95 / 5.78 us against
     // 5.77 us in this plain order)
     if (FAST) job_tn_wave<ADAM, true>(g, D, D, pt, hd, H, H, qg * kTileWaves5 + wave, B, dWl, H, awl);
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
   {  // dW_e0[H,D] = dh^T x
     const int ntDg = ((D + 15) / 16 + kTileWaves - 1) / kTileWaves;
     // (tried: XCD parity classes of the x column groups, and dh-blocks-fastest order: no faster than this plain order)
-    const int pt = b / ntDg, qg = b - pt * ntDg;
+    const int pt = fast_div(b, ntDg), qg = b - pt * ntDg;
     job_tn_wave<ADAM, FULL>(dh, H, H, pt, x, D, D, qg * kTileWaves + (threadIdx.x >> 6), B, G + off_w_e0, D,
                             at(off_w_e0));
     MV_SPAN_END(5, 1);
