@@ -588,9 +588,13 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int c = wave + 8 * gq;
-    const int k = ((c < nchunks ? c : 0) << 4) + (q << 2);
-    ha[gq] = *reinterpret_cast<const float4*>(hrow + k);
-    hb[gq] = *reinterpret_cast<const float4*>(whrow + k);  // rows past NH re-read row 0: their columns are never used
+    ha[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    hb[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nchunks) {  // wave-uniform (scalar branch): a chunk this wave does not have is not requested
+      const int k = (c << 4) + (q << 2);
+      ha[gq] = *reinterpret_cast<const float4*>(hrow + k);
+      hb[gq] = *reinterpret_cast<const float4*>(whrow + k);  // rows past NH re-read row 0: their columns are never used
+    }
   }
   const float bhv = bh[(tid & 15) < NH ? (tid & 15) : 0];
   float epsv = 0.f;
@@ -602,8 +606,6 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   // epilogue operands: threads 0..255 take the first tile of the pair, 256..511 the second
   const int nt_ep = (tid < 256 || !two) ? nt : nt + 1;
   const int m_ep = mt * 16 + ((tid & 255) >> 4), n_ep = nt_ep * 16 + (tid & 15);
-  const float tv = x[(size_t)m_ep * D + n_ep];
-  const float bias = bl[n_ep];
   __builtin_amdgcn_sched_barrier(0);
   // this lane's component: lane = slot * 16 + row; the four slot descriptors of this wave are fetched with UNIFORM
   // (scalar) loads, all four in flight at once while the vector requests above travel, and selected per lane without a
@@ -683,6 +685,11 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     return;
   }
 
+  // the epilogue operands are requested only now: at the top of the kernel they were 16 of the ~100 wave-level requests
+  // the heads phase waits behind (the CU's load path serves ~1 request per 36 cycles whatever its size)
+  const float tv = x[(size_t)m_ep * D + n_ep];
+  const float bias = bl[n_ep];
+  __builtin_amdgcn_sched_barrier(0);
   // ---- waves 0..3: the latent components, one lane per (slot, row) -- a ~2 us dependent chain on a handful of lanes.
   // ---- waves 4..7 meanwhile stage the operands of the two remaining phases in LDS: W_d0 / b_d0 (first decoder layer) and
   // the two 16-row blocks of W_logits (B operands of the output tiles), 16-byte coalesced requests.
