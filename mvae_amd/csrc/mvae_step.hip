@@ -1208,6 +1208,30 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   const int doff_r = t.dir_off[tci];
   const int first_r = t.first_dir[tci < t.n ? tci : 0];
   __builtin_amdgcn_sched_barrier(0);  // keep the requests above ahead of the bulk below
+  // FAST with z_dim 8 or 4 (every BASELINE MLP config but e6): the two small weight matrices are requested as 16-byte
+  // vectors -- W_d0 [H][Z] flat (H Z / 1024 requests per thread), W_heads as four consecutive columns per thread (one
+  // request per head row, on the first H/4 threads) -- ~70 wave-level requests per workgroup instead of ~220 (4-byte
+  // ones): at ~36 cycles per request on the CU's load path that was ~3 us of this kernel's 5.
+  const bool zv = FAST && (Z == 8 || Z == 4);  // uniform
+  f32x4 wz4[4], wh4[16];
+  float4 hm4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (zv) {
+    const int nz4 = (H * Z) >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = tid + 256 * u;
+      wz4[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nz4 ? e4 : 0));
+    }
+    const unsigned c4 = 4u * (unsigned)(tid < (H >> 2) ? tid : 0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) wh4[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((wave << 6) < (H >> 2)) {  // wave-uniform: only the waves that own columns of dh request W_heads (and h)
+      hm4 = *reinterpret_cast<const float4*>(h + rowH + c4);
+#pragma unroll
+      for (int n = 0; n < 16; ++n)
+        if (n < NH) wh4[n] = *reinterpret_cast<const f32x4*>(Wh + (unsigned)n * (unsigned)H + c4);  // uniform
+    }
+  } else
   if (FAST) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1280,6 +1304,31 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   // in slice order
   {
     float p = 0.f;
+    if (zv) {
+      // thread's flat vectors e4 = tid + 256 u: row c = e4 / (Z/4), columns 4 (e4 % (Z/4)) .. +3; the column half is the
+      // parity of the lane (Z == 8) or none (Z == 4)
+      const int nz4 = (H * Z) >> 2, sh = Z == 8 ? 1 : 0;
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e4 = tid + 256 * u;
+        const float dv = e4 < nz4 ? dhd_s[(e4 < nz4 ? e4 : 0) >> sh] : 0.f;
+        a4 += dv * wz4[u];
+      }
+      // lanes of equal column half: butterfly over the remaining lane bits, then the four waves meet in LDS
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        if (off >= (1 << sh)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a4[k] += __shfl_xor(a4[k], off);
+        }
+      if (lane < (1 << sh)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[wave * ZP + lane * 4 + k] = a4[k];
+      }
+      lds_barrier();
+      if (tid < Z) dz_s[tid] = (part[tid] + part[ZP + tid]) + (part[2 * ZP + tid] + part[3 * ZP + tid]);
+    } else
     if (FAST) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {  // wz[q] = 0 past the end: no guard
@@ -1290,7 +1339,8 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
 #pragma unroll 4
       for (int c = sl; c < H; c += nsl) p = fmaf(dhd_s[c], Wd0[(size_t)c * Z + zj], p);
     }
-    if (FAST) {
+    if (zv) {
+    } else if (FAST) {
       // ZP <= 8: the slices of one wave are the lanes with equal (lane & (ZP-1)): butterfly over the upper lane bits,
       // then the four waves' sums meet in LDS (fixed order)
 #pragma unroll
@@ -1366,7 +1416,19 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   MV_STAMP(11);
   if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
   // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
-  if (FAST) {
+  if (zv) {
+    if (tid < (H >> 2)) {
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < 16; ++n) a4 += dheads_s[n] * wh4[n];  // entries [NH, 16) of dheads_s are zero
+      float4 o;
+      o.x = hm4.x > 0.f ? a4[0] : 0.f;
+      o.y = hm4.y > 0.f ? a4[1] : 0.f;
+      o.z = hm4.z > 0.f ? a4[2] : 0.f;
+      o.w = hm4.w > 0.f ? a4[3] : 0.f;
+      *reinterpret_cast<float4*>(dh + row * H + 4 * tid) = o;
+    }
+  } else if (FAST) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = tid + 256 * u;
