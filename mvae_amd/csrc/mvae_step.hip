@@ -1041,14 +1041,17 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     for (int nt0 = p * chunk; nt0 < (p + 1) * chunk && nt0 < ntD; nt0 += 16) {
       float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 16; ++u) {  // pure requests (clamped); the masks come after the batch
         const int nt = nt0 + u;
         const bool ok = nt < (p + 1) * chunk && nt < ntD;
-        const float x = bce_part[(size_t)(ok ? nt : 0) * B + rr];
-        v[u] = ok ? x : 0.f;
+        v[u] = bce_part[(size_t)(ok ? nt : 0) * B + rr];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) part += v[u];
+      for (int u = 0; u < 16; ++u) {
+        const int nt = nt0 + u;
+        part += (nt < (p + 1) * chunk && nt < ntD) ? v[u] : 0.f;
+      }
     }
     float klr = 0.f;
     if (p == 0 && act) {  // requested before the barrier below
