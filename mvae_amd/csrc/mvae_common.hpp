@@ -567,15 +567,19 @@ __device__ __forceinline__ void job_colsum_opt(float* lds /*>= 32*17+2 floats*/,
   float s = 0.f;
   if (c0 + c < ncols) {
     const float* col = Gm + c0 + c;
-    int m = g;
-    for (; m + ng * 3 < Mrows; m += ng * 4) {
-      float v[4];
+    // 8 rows per thread in flight, clamped requests and masks after the batch: with 20 row groups (320 threads) and 128
+    // rows the former 4-deep batch left 2-3 rows per thread to a serial tail loop -- one memory round trip each
+    for (int m = g; m < Mrows; m += ng * 8) {
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = col[(size_t)(m + ng * u) * ld];
+      for (int u = 0; u < 8; ++u) {
+        const int mm = m + ng * u;
+        v[u] = col[(size_t)(mm < Mrows ? mm : 0) * ld];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += (m + ng * u < Mrows) ? v[u] : 0.f;
     }
-    for (; m < Mrows; m += ng) s += col[(size_t)m * ld];
   }
   lds[g * 17 + c] = s;
   __syncthreads();
