@@ -459,6 +459,10 @@ void mvae_peer_destroy(mvae_peer* peer);
 int mvae_peer_export(mvae_peer* peer, uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
 int mvae_peer_import(mvae_peer* peer, int peer_rank, const uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
 int mvae_peer_publish(mvae_peer* peer, const float* grads, void* stream);
+/* on != 0: two-shot form (before the first publish; the same on every rank).  publish then also adds the rank's OWN 1/world
+ * slice of every slot (rank order) in place and raises a second flag; the optimizer launch reads slice j from rank j.
+ * Same sums, same bits as the one-shot form; per xGMI link and step 2 n / world floats instead of n. */
+int mvae_peer_set_two_shot(mvae_peer* peer, int on);
 int mvae_step_optimizer_peer(mvae_ctx* ctx, mvae_peer* peer, int do_curvature_step, void* stream);
 int mvae_peer_timeouts(mvae_peer* peer);
 

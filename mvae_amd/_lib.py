@@ -110,6 +110,7 @@ PROTOTYPES = {
     "mvae_peer_export": (C.c_int, [_P, C.POINTER(C.c_uint8)]),
     "mvae_peer_import": (C.c_int, [_P, _I, C.POINTER(C.c_uint8)]),
     "mvae_peer_publish": (C.c_int, [_P, _P, _P]),
+    "mvae_peer_set_two_shot": (C.c_int, [_P, _I]),
     "mvae_step_optimizer_peer": (C.c_int, [_P, _P, _I, _P]),
     "mvae_peer_timeouts": (C.c_int, [_P]),
     "mvae_step_profile": (C.c_int, [_P, _P, _P, _F, _I, _I, C.POINTER(C.c_float), _P]),

@@ -86,6 +86,7 @@ struct PeerSrc {  // kernel argument: where rank r's published gradients of the 
   const int* seq;                    // device word: sequence number of the last publish (parity selects the slot)
   long long n;                       // floats per slot
   int world;
+  long long slice4;                  // two-shot: float4 per owned slice (rank r owns [r slice4, (r+1) slice4)); 0 = one-shot
 };
 struct mvae_peer {
   int world = 0, rank = 0;
@@ -99,7 +100,15 @@ struct mvae_peer {
   int shm_fd = -1;
   char shm_name[128] = {};
   unsigned long long timeout_ticks = 0;      // wall_clock64 ticks (100 MHz) a rank waits for a peer before giving up
+  bool two_shot = false;                     // reduce-scatter + all-gather by direct reads instead of the one-shot sum
 };
+
+// float4 per owned slice of the two-shot exchange (the radii region, 16 float4, stays inside slice 0)
+inline long long peer_slice4(const mvae_peer* p) {
+  const long long n4 = p->n / 4;
+  long long s4 = (n4 + p->world - 1) / p->world;
+  return s4 < 16 ? 16 : s4;
+}
 
 // ------------------------------------------------------------------------------------------------ tables
 constexpr int kMaxComp = MVAE_MAX_COMPONENTS;

@@ -32,24 +32,47 @@ __global__ __launch_bounds__(256) void k_peer_copy(const float4* g, float4* slot
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = g[i];
 }
 
+// phase 0: after the copy (bumps the sequence number); phase 1 (two-shot only): after the rank's slice is reduced.
+// Flags of phase ph live at flags[64 ph + r]; time-outs are counted at flags[32 + r].
 __global__ __launch_bounds__(64) void k_peer_signal(int* seq, unsigned int* flags, int world, int rank,
-                                                    unsigned long long timeout_ticks) {
+                                                    unsigned long long timeout_ticks, int phase) {
   const int tid = threadIdx.x;
-  const unsigned int s = (unsigned int)seq[0] + 1u;
+  const unsigned int s = (unsigned int)seq[0] + (phase == 0 ? 1u : 0u);
+  unsigned int* fl = flags + 64 * phase;
   if (tid == 0) {
-    seq[0] = (int)s;  // read by the launches that follow (parity of the slot to sum)
-    __hip_atomic_store(&flags[rank], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (phase == 0) seq[0] = (int)s;  // read by the launches that follow (parity of the slot to sum)
+    __hip_atomic_store(&fl[rank], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (tid < world && tid != rank) {
     const unsigned long long t0 = wall_clock64();
     // sequence numbers only grow; the signed difference survives the wrap of the 32-bit counter
-    while ((int)(__hip_atomic_load(&flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
+    while ((int)(__hip_atomic_load(&fl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
       if (wall_clock64() - t0 > timeout_ticks) {
         atomicAdd_system(&flags[32 + rank], 1u);  // reported by mvae_peer_timeouts; the step goes on with stale data
         break;
       }
       __builtin_amdgcn_s_sleep(32);
     }
+  }
+}
+
+// Two-shot, first shot: rank r adds slice r of EVERY rank's slot (rank order) and leaves the sum in slice r of its own slot
+// -- the only reader of that region in this phase is rank r itself; the optimizer launch of every rank then reads slice j
+// from rank j.  Per link and step that is 2 n / W floats instead of the one-shot's n.
+__global__ __launch_bounds__(256) void k_peer_reduce_slice(PeerSrc ps, float* own, int rank) {
+  const size_t off4 = (size_t)(ps.seq[0] & 1) * (size_t)(ps.n / 4);
+  const long long n4 = ps.n / 4;
+  const long long lo = (long long)rank * ps.slice4, hi = lo + ps.slice4 < n4 ? lo + ps.slice4 : n4;
+  for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(ps.slot[0])[off4 + i];
+    for (int r = 1; r < ps.world; ++r) {
+      const float4 o = reinterpret_cast<const float4*>(ps.slot[r])[off4 + i];
+      a.x += o.x;
+      a.y += o.y;
+      a.z += o.z;
+      a.w += o.w;
+    }
+    reinterpret_cast<float4*>(own)[off4 + i] = a;
   }
 }
 
@@ -150,8 +173,26 @@ extern "C" int mvae_peer_publish(mvae_peer* p, const float* grads, void* stream)
   hipLaunchKernelGGL(k_peer_copy, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(grads),
                      reinterpret_cast<float4*>(p->slots), n4, p->seq);
   hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, s, p->seq, p->flags_dev, p->world, p->rank,
-                     p->timeout_ticks);
+                     p->timeout_ticks, 0);
+  if (p->two_shot) {
+    PeerSrc ps{};
+    for (int r = 0; r < p->world; ++r) ps.slot[r] = p->peer_slots[r];
+    ps.seq = p->seq;
+    ps.n = p->n;
+    ps.world = p->world;
+    ps.slice4 = peer_slice4(p);
+    const int rb = (int)((ps.slice4 + 255) / 256 < 256 ? (ps.slice4 + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_peer_reduce_slice, dim3(rb), dim3(256), 0, s, ps, p->slots, p->rank);
+    hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, s, p->seq, p->flags_dev, p->world, p->rank,
+                       p->timeout_ticks, 1);
+  }
   LAUNCH_CHECK("peer publish");
+  return 0;
+}
+
+extern "C" int mvae_peer_set_two_shot(mvae_peer* p, int on) {
+  if (!p) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  p->two_shot = on != 0;
   return 0;
 }
 

@@ -1608,8 +1608,9 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
   if (blockIdx.x == 0 && tid < t.n) {
     float gv;
     if (PEER) {
-      gv = ps.slot[0][slot_off + tid];
-      for (int r = 1; r < ps.world; ++r) gv += ps.slot[r][slot_off + tid];
+      gv = ps.slot[0][slot_off + tid];  // two-shot: slice 0 (which holds the radii region) was reduced by rank 0
+      if (ps.slice4 == 0)
+        for (int r = 1; r < ps.world; ++r) gv += ps.slot[r][slot_off + tid];
       g[tid] = gv;
     } else {
       gv = g[tid];
@@ -1622,7 +1623,12 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
   if (i4 < n4) {
     float4 pp = reinterpret_cast<float4*>(p)[i4];
     float4 gg;
-    if (PEER) {
+    if (PEER && ps.slice4 > 0) {  // two-shot: the reduced slice is read from its owner
+      int owner = (int)(i4 / ps.slice4);
+      owner = owner < ps.world ? owner : ps.world - 1;
+      gg = reinterpret_cast<const float4*>(ps.slot[owner] + slot_off)[i4];
+      store16_wt(g, (size_t)i4 * 4, f32x4{gg.x, gg.y, gg.z, gg.w});
+    } else if (PEER) {
       gg = reinterpret_cast<const float4*>(ps.slot[0] + slot_off)[i4];
       for (int r = 1; r < ps.world; ++r) {
         const float4 o = reinterpret_cast<const float4*>(ps.slot[r] + slot_off)[i4];
@@ -1917,6 +1923,7 @@ extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_cur
   ps.seq = peer->seq;
   ps.n = peer->n;
   ps.world = peer->world;
+  ps.slice4 = peer->two_shot ? peer_slice4(peer) : 0;
   const int n4 = d.n_params / 4;
   const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
   hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,

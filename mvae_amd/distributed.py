@@ -85,7 +85,9 @@ class DataParallelStep:
         overlap: two-bucket exchange overlapped with the last backward launch (default: on; MVAE_DP_OVERLAP=0 turns it
         off -- one all-reduce of the whole buffer after the backward pass).
         exchange: "allreduce" (default: torch.distributed, RCCL on the GPU) or "peer" (MVAE_DP_EXCHANGE=peer): the
-        one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch -- ranks of ONE node only."""
+        one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch -- ranks of ONE node only;
+        "peer2": its two-shot form (each rank reduces 1/world of the buffer, the optimizer reads every slice from its
+        owner)."""
         import os
         self.engine = engine
         self.group = group
@@ -94,12 +96,12 @@ class DataParallelStep:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "allreduce")
-        if self.exchange not in ("allreduce", "peer"):
+        if self.exchange not in ("allreduce", "peer", "peer2"):
             raise ValueError(f"unknown gradient exchange {self.exchange!r}")
         self.peer = None
-        if self.exchange == "peer" and (self.world > 1 or self.always_exchange):
+        if self.exchange in ("peer", "peer2") and (self.world > 1 or self.always_exchange):
             from .peer import PeerExchange
-            self.peer = PeerExchange(engine, group)
+            self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2")
 
     def broadcast_state(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s parameters / optimizer state."""

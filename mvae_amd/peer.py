@@ -23,7 +23,10 @@ IPC_HANDLE_BYTES = 64
 
 class PeerExchange:
 
-    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, timeout_seconds: float = 2.0) -> None:
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, timeout_seconds: float = 2.0,
+                 two_shot: bool = False) -> None:
+        """two_shot: every rank first reduces its own 1/world slice of all slots, the optimizer launch then reads each
+        slice from its owner (2 n / world floats per link and step instead of n; one more flag round per step)."""
         self.engine = engine
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -36,6 +39,7 @@ class PeerExchange:
         with torch.cuda.device(engine.device):
             check(load().mvae_peer_create(int(engine.grads.numel()), self.world, self.rank, name[0].encode(),
                                           float(timeout_seconds), C.byref(self._h)))
+            check(load().mvae_peer_set_two_shot(self._h, 1 if two_shot else 0))
             mine = (C.c_uint8 * IPC_HANDLE_BYTES)()
             check(load().mvae_peer_export(self._h, mine))
             handles = [None] * self.world

@@ -127,8 +127,8 @@ def _run_ranks(steps, world, **kw):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph_steps", [0, 3])
-def test_peer_read_exchange_two_processes_one_device(graph_steps):
+@pytest.mark.parametrize("graph_steps,exchange", [(0, "peer"), (3, "peer"), (0, "peer2"), (3, "peer2")])
+def test_peer_read_exchange_two_processes_one_device(graph_steps, exchange):
     """The one-shot peer-read reduction (mvae_peer_*: hipIpc-mapped gradient slots, host-coherent flags, the sum fused into
     the optimizer launch) with two PROCESSES sharing cuda:0: no wait times out, the ranks end bit-identical, and the result
     equals the all-reduce route -- bit for bit at world size 2, where both routes compute fl(g0 + g1).  graph_steps = 3:
@@ -136,7 +136,7 @@ def test_peer_read_exchange_two_processes_one_device(graph_steps):
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     steps, world = 6, 2
-    peer = _run_ranks(steps, world, exchange="peer", graph_steps=graph_steps)
+    peer = _run_ranks(steps, world, exchange=exchange, graph_steps=graph_steps)  # "peer2": the two-shot form
     assert peer[0][3] == 0 and peer[1][3] == 0, "a rank gave up waiting for its peer"
     assert np.array_equal(peer[0][1], peer[1][1]), "ranks diverged"
     ref = _run_ranks(steps, world, exchange="allreduce", cycle=graph_steps or None)  # a replay repeats its batches
