@@ -378,7 +378,10 @@ class ConvEngine:
         # ---- decoder backward
         dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
-        _colsum(_permute_rc(g, B, 3, 1024).view(B * 1024, 3), out=GV["d3.bias"])
+        # d3.bias gradient = sum over (b, y, x) of g[b, c, y, x]: column sums over the batch first ([B, 3072] -> [3072]),
+        # then the 1024 pixels of each channel -- instead of permuting the whole gradient to [B * 1024, 3]
+        gpix = _colsum(g.view(B, 3072))
+        _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
         db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
         _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16)
