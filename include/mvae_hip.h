@@ -470,7 +470,8 @@ int mvae_peer_timeouts(mvae_peer* peer);
  * of the step does not depend on it beyond float32 summation order):
  *   MVAE_PATH_ROW    one batch row per workgroup (k_latent_fwd / k_latent_bwd): the general case
  *   MVAE_PATH_FUSED  launches 2 + 3 fused (k_fwd23): heads_dim <= 16, z_dim in {2, 4, 6, 8} -- BASELINE configs [0], [1], [2]
- *   MVAE_PATH_BLOCK  16-row MFMA blocks (k_heads_comp, k_fwd3m, k_latent_bwd_blk): many small components --
+ *   MVAE_PATH_BLOCK  16-row MFMA blocks (k_heads_comp, k_fwd3m with the dual-record workgroups, k_latent_bwd_blk): many
+ *                    small components --
  *                    BASELINE config [3] (`6h2,6s2,6e2`)
  * Assumes 16-byte aligned x (true for every torch allocation). */
 #define MVAE_PATH_ROW 0

@@ -36,7 +36,7 @@ struct mvae_ctx {
   bool groups_ok;        // every component fits one 16-column head tile
   bool no_blk;           // MVAE_NO_BLK=1: per-row latent kernels for many-component models too (A/B measurements)
   bool blk_small;        // MVAE_BLK_SMALL=1: the block backward kernel also for z_dim <= 16 (the fused-forward configs)
-  bool blk_fwd;          // MVAE_BLK_FWD=1: block kernels in the forward launches as well (measured slower)
+  bool blk_fwd;          // block kernels in the forward launches as well (MVAE_BLK_FWD=0: per-row forward, A/B measurements)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
@@ -149,7 +149,7 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   const char* bs = getenv("MVAE_BLK_SMALL");
   c->blk_small = bs && bs[0] && bs[0] != '0';
   const char* bf = getenv("MVAE_BLK_FWD");
-  c->blk_fwd = bf && bf[0] && bf[0] != '0';
+  c->blk_fwd = !(bf && bf[0] == '0');
   c->groups_ok = build_groups(c->t, &c->gt);
   carve(c, bucket_of(c->dmax));
   // the only device access of create, and only for models that take the block kernels
@@ -1791,14 +1791,19 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LHC(DM)                                                                                                      \
   STEP_LAUNCH((k_heads_comp<DM>), dim3(c->nt_b * c->gt.ng), dim3(512), 0, c->t, c->gt, h, P + d.off_w_heads,          \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, heads, c->ldh, z, c->ldz, concat_z, klw, kl, B, H,  \
-              NH, Z, duals)
+              NH, Z)
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LHC(2); } else if (bk == 4) { LHC(4); } else { LHC(8); }
 #undef LHC
     ki = 2;
     const size_t lds = (size_t)16 * (H + 4) * sizeof(float);
-    STEP_LAUNCH(k_fwd3m, dim3(((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0,
-                P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z);
+    const int n_dual3 = c->nt_b * c->gt.ng;  // a multiple of 8 for B % 128 == 0: the tile workgroups keep L % 8 == XCD
+#define LF3(DM)                                                                                                      \
+  STEP_LAUNCH((k_fwd3m<DM>), dim3(n_dual3 + ((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, c->t, c->gt, heads,       \
+              c->ldh, eps, d.eps_dim, P + d.off_radii, NH, duals, n_dual3, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0, \
+              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z)
+    if (bk == 2) { LF3(2); } else if (bk == 4) { LF3(4); } else { LF3(8); }
+#undef LF3
   } else {
   {
     ki = 1;

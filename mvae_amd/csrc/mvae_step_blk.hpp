@@ -69,7 +69,7 @@ template <int DMAX>
 __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, const float* h, const float* Wh,
                                                     const float* bh, const float* eps, int eps_ld, const float* radii,
                                                     float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
-                                                    float* kl_user, int B, int H, int NH, int Z, float* duals) {
+                                                    float* kl_user, int B, int H, int NH, int Z) {
   __shared__ float red[kW8][16][17];
   __shared__ __attribute__((aligned(16))) float heads_s[16][16];
   __shared__ __attribute__((aligned(16))) float eps_s[16][16];
@@ -79,11 +79,10 @@ __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, 
   const int mt = (int)blockIdx.x % MT, grp = (int)blockIdx.x / MT;
   MV_SPAN_BEGIN(1);
   const int first = gt.first[grp], cnt = gt.count[grp];
-  int Md = 0, Ml = 0, gdirs = 0;
+  int Md = 0, Ml = 0;
   for (int k = 0; k < cnt; ++k) {  // uniform
     Md += t.c[first + k].true_dim;
     Ml += t.c[first + k].logvar_dim;
-    gdirs += t.dir_off[first + k + 1] - t.dir_off[first + k];
   }
   const int mean0 = t.c[first].mean_col, logvar0 = t.c[first].logvar_col, eps0 = t.c[first].eps_col,
             z0 = t.c[first].z_col;
@@ -147,36 +146,17 @@ __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, 
     MV_SPAN_END(1, 1);
     return;
   }
-  // waves 1..7: forward-mode dual records, item = (active direction of the group) * 16 + row
-  constexpr int AM = DMAX + 1, DS = DMAX + 2;
-  for (int item = (wave - 1) * 64 + lane; item < gdirs * 16; item += 7 * 64) {
-    const int r = item & 15, dd = item >> 4;
-    int mine = 0, mydir = 0, base = 0, firstd = 0;
-    for (int k = 0; k < cnt; ++k) {  // uniform loop, per-lane select
-      const int nd = t.dir_off[first + k + 1] - t.dir_off[first + k];
-      const int fd = t.first_dir[first + k];
-      if (dd >= base && dd < base + nd) {
-        mine = k;
-        mydir = dd - base;
-        firstd = fd;
-      }
-      base += nd;
-    }
-    const mvae_component_desc c = group_desc(t, first, cnt, mine, Md);
-    float zd[AM];
-    const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
-    float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + firstd + mydir) * DS;
-    const int A = ambient_dim(c.kind, c.true_dim);
-    rec[0] = kld;
-#pragma unroll
-    for (int q2 = 0; q2 < AM; ++q2)
-      if (q2 < A) rec[1 + q2] = zd[q2];
-  }
-  MV_SPAN_END_T(1, 2, 64, 512);
+  // waves 1..7 are done: the forward-mode dual records of these components are computed by dedicated workgroups of the
+  // NEXT launch (k_fwd3m), off every critical path -- inside this kernel their 3.5 us chains were its tail
 }
 
 // ---- 3': hd (recomputed per workgroup, K = Z <= 64) -> two logits tiles + BCE-with-logits
-__global__ __launch_bounds__(512) void k_fwd3m(const float* z, int ldz, const float* Wd0, const float* bd0,
+// The first n_dual = (B / 16) * (component groups) workgroups compute the forward-mode dual records of launch 2's
+// components (heads / eps / radii read back from memory): ~5.5 us each on CUs the 200 tile workgroups leave free.
+template <int DMAX>
+__global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const float* heads, int ldh,
+                                               const float* eps, int eps_ld, const float* radii, int NH, float* duals,
+                                               int n_dual, const float* z, int ldz, const float* Wd0, const float* bd0,
                                                const float* Wl, const float* bl, const float* x, float* hd, float* g,
                                                float* bce_part, float* logits_user, int B, int H, int D, int Z) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // hd_s[16][H + 4]
@@ -185,9 +165,60 @@ __global__ __launch_bounds__(512) void k_fwd3m(const float* z, int ldz, const fl
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   MV_SPAN_BEGIN(2);
   const int ntD = D >> 4, ntP = (ntD + 1) >> 1, MT = B >> 4;
+  if ((int)blockIdx.x < n_dual) {
+    // ---- dual records of (row block mt, component group grp): item = (active direction of the group) * 16 + row
+    float (*heads_s)[16] = reinterpret_cast<float (*)[16]>(&red[0][0][0]);   // [16][16]
+    float (*eps_s)[16] = reinterpret_cast<float (*)[16]>(&red2[0][0][0]);    // [16][16]
+    float* rad_s = &red2[1][0][0];
+    const int mt = (int)blockIdx.x % MT, grp = (int)blockIdx.x / MT;
+    const int first = gt.first[grp], cnt = gt.count[grp];
+    int Md = 0, Ml = 0, gdirs = 0;
+    for (int k = 0; k < cnt; ++k) {  // uniform
+      Md += t.c[first + k].true_dim;
+      Ml += t.c[first + k].logvar_dim;
+      gdirs += t.dir_off[first + k + 1] - t.dir_off[first + k];
+    }
+    const int mean0 = t.c[first].mean_col, logvar0 = t.c[first].logvar_col, eps0 = t.c[first].eps_col;
+    if (tid < 256) {
+      const int r = tid >> 4, j = tid & 15;
+      const int hcj = j < Md ? mean0 + j : (j < Md + Ml ? logvar0 + (j - Md) : -1);
+      const float hv = heads[(size_t)(mt * 16 + r) * ldh + (hcj < 0 ? 0 : hcj)];
+      const float ev = eps[(size_t)(mt * 16 + r) * eps_ld + eps0 + (j < Md ? j : 0)];
+      heads_s[r][j] = hcj < 0 ? 0.f : hv;
+      eps_s[r][j] = j < Md ? ev : 0.f;
+    }
+    if (tid < 4) rad_s[tid] = radii[first + (tid < cnt ? tid : 0)];
+    __syncthreads();
+    constexpr int AM = DMAX + 1, DS = DMAX + 2;
+    for (int item = tid; item < gdirs * 16; item += 512) {
+      const int r = item & 15, dd = item >> 4;
+      int mine = 0, mydir = 0, base = 0, firstd = 0;
+      for (int k = 0; k < cnt; ++k) {  // uniform loop, per-lane select
+        const int nd = t.dir_off[first + k + 1] - t.dir_off[first + k];
+        const int fd = t.first_dir[first + k];
+        if (dd >= base && dd < base + nd) {
+          mine = k;
+          mydir = dd - base;
+          firstd = fd;
+        }
+        base += nd;
+      }
+      const mvae_component_desc c = group_desc(t, first, cnt, mine, Md);
+      float zd[AM];
+      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
+      float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + firstd + mydir) * DS;
+      const int A = ambient_dim(c.kind, c.true_dim);
+      rec[0] = kld;
+#pragma unroll
+      for (int q2 = 0; q2 < AM; ++q2)
+        if (q2 < A) rec[1 + q2] = zd[q2];
+    }
+    MV_SPAN_END(2, 2);
+    return;
+  }
   int pt = 0, mt = 0;
   {  // XCD-aware for the first 8 * floor(ntP / 8) pairs, plain order for the rest (no padding workgroups), as k_fwd23
-    const int L = (int)blockIdx.x;
+    const int L = (int)blockIdx.x - n_dual;
     const int full = (ntP >> 3) << 3;
     if (L < full * MT) (void)xcd_tile(full, MT, &pt, &mt, L);
     else {
