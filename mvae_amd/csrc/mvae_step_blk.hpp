@@ -7,10 +7,11 @@
 // launch structure becomes
 //   2'  k_heads_comp   workgroup = (row block, GROUP of <= 4 consecutive components of one manifold kind whose head columns
 //                      fit one 16-column tile): heads tile (K = H over 8 waves) -> wave 0: the components, one lane per
-//                      (slot, row); waves 1..7: the forward-mode dual records of the same components
+//                      (slot, row)
 //   3'  k_fwd3m        workgroup = (row block, pair of logits column tiles): RECOMPUTES hd = relu(z W_d0^T + b) for its
 //                      16 rows (K = Z <= 64, 25 MFMA column tiles over 8 waves) into LDS and contracts it with its two
 //                      W_logits row blocks; BCE epilogue as in k_fwd23.  No launch boundary between hd and the logits.
+//                      Extra workgroups at the front of its grid: the forward-mode dual records of launch 2's components.
 //   5'  k_latent_bwd_blk   workgroup = (row block, 64-column group of dh): dz = dhd W_d0 (K = H), the records contracted
 //                      with dz -> dheads, dh group = (dheads W_heads) [h > 0]; plus the dW_logits tile workgroups of
 //                      launch 5.
