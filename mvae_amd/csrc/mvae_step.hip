@@ -1053,35 +1053,46 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
         part += (nt < (p + 1) * chunk && nt < ntD) ? v[u] : 0.f;
       }
     }
-    float klr = 0.f;
-    if (p == 0 && act) {  // requested before the barrier below
-      klr = kl[r];
-      if (kl_in_lds) kl_s[r] = klr;
-      int i = 1;
-      for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
+    // the row's KL terms: part p takes the components p, p + P, ... (one batch of requests instead of one round trip per
+    // 8 components on a quarter of the threads); the P partial sums meet in LDS next to the BCE partials
+    float klp = 0.f;
+    if (act) {
+      for (int i0 = p; i0 < ncomp; i0 += 8 * P) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = kl[(size_t)(i + u) * B + r];
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * P;
+          v[u] = kl[(size_t)(i < ncomp ? i : 0) * B + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          klr += v[u];
-          if (kl_in_lds) kl_s[(size_t)(i + u) * B + r] = v[u];
+          const int i = i0 + u * P;
+          if (i < ncomp) {
+            klp += v[u];
+            if (kl_in_lds) kl_s[(size_t)i * B + r] = v[u];
+          }
         }
-      }
-      for (; i < ncomp; ++i) {
-        const float v = kl[(size_t)i * B + r];
-        klr += v;
-        if (kl_in_lds) kl_s[(size_t)i * B + r] = v;
       }
     }
     if (P > 1) {
-      if (p < P) sm[64 + p * rows_pass + rl] = part;
+      if (p < P) {
+        sm[64 + p * rows_pass + rl] = part;
+        sm[64 + 1024 + p * rows_pass + rl] = klp;
+      }
       __syncthreads();
     }
     if (p == 0 && act) {
-      float bce = part;
-      if (P == 2) bce = sm[64 + rl] + sm[64 + rows_pass + rl];
-      if (P == 4) bce = (sm[64 + rl] + sm[64 + rows_pass + rl]) + (sm[64 + 2 * rows_pass + rl] + sm[64 + 3 * rows_pass + rl]);
+      float bce = part, klr = klp;
+      if (P == 2) {
+        bce = sm[64 + rl] + sm[64 + rows_pass + rl];
+        klr = sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl];
+      }
+      if (P == 4) {
+        bce = (sm[64 + rl] + sm[64 + rows_pass + rl]) + (sm[64 + 2 * rows_pass + rl] + sm[64 + 3 * rows_pass + rl]);
+        klr = (sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl]) +
+              (sm[64 + 1024 + 2 * rows_pass + rl] + sm[64 + 1024 + 3 * rows_pass + rl]);
+      }
       if (bce_user) bce_user[r] = bce;
       bce_acc += bce;
       elbo_acc += (-bce - beta * klr);
