@@ -306,10 +306,12 @@ class ConvEngine:
         c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
         c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True)   # [B*64, 128]
         c["a2"] = _conv_nhwc(c["a1"], c["We2"], PV["e2.bias"], None, B, 128, 8, True)   # [B*16, 512]
-        c["hflat"] = _permute_rc(c["a2"], B, 16, 512).view(B, H_DIM)  # NCHW flatten (conv_vae.py:65)
-        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
-        b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
-        c["heads"] = _linear_splitk(c["hflat"], w_heads, b_heads)
+        # The reference flattens NCHW (conv_vae.py:65: column c * 16 + p of the head matrices); the activation here is
+        # channel-last (column p * 512 + c).  Re-ordering the head matrix (NH x 8192: 0.4 MB) instead of the activation
+        # and its gradient (8 MB each) gives the same products.
+        c["hflat"] = c["a2"].view(B, H_DIM)
+        c["w_heads_cl"], b_heads = self._heads_channel_last()
+        c["heads"] = _linear_splitk(c["hflat"], c["w_heads_cl"], b_heads)
         co = Fn.component_forward(lay, c["heads"], eps, self.params[:lay.n], want_kl=want_kl,
                                   want_log_probs=not want_kl, want_params=False)
         c["z"], c["kl"], c["co"] = co["z"], co["kl"], co
@@ -325,6 +327,13 @@ class ConvEngine:
         c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
 
+    def _heads_channel_last(self):
+        """(W_heads with its 8192 columns re-ordered from the reference's (c, y, x) to channel-last (y, x, c), b_heads)."""
+        NH = self.layout.heads_dim
+        ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
+        w = self.params[ow:ow + NH * H_DIM]
+        return _permute_rc(w.view(NH, 512, 16), NH, 512, 16).view(NH, H_DIM), self.params[ob:ob + NH]
+
     def encode_heads(self, x: Tensor) -> Tensor:
         """conv_vae.py:57-66 + the fused head matrix: x[B,3072] -> heads[B, NH]."""
         PV = self.param_views()
@@ -333,10 +342,8 @@ class ConvEngine:
                                relu=True)
         a1 = _conv_nhwc(a0, self.flat.matrix(self.params, "e1"), PV["e1.bias"], None, B, 64, 16, True)
         a2 = _conv_nhwc(a1, self.flat.matrix(self.params, "e2"), PV["e2.bias"], None, B, 128, 8, True)
-        hflat = _permute_rc(a2, B, 16, 512).view(B, H_DIM)
-        w_heads = self.params[self.flat.off["w_heads"]:self.flat.off["w_heads"] + NH * H_DIM].view(NH, H_DIM)
-        b_heads = self.params[self.flat.off["b_heads"]:self.flat.off["b_heads"] + NH]
-        return _linear_splitk(hflat, w_heads, b_heads)
+        w_heads_cl, b_heads = self._heads_channel_last()
+        return _linear_splitk(a2.view(B, H_DIM), w_heads_cl, b_heads)
 
     def decode(self, z: Tensor) -> Tensor:
         """[..., B, Z] -> [..., B, 3072] (conv_vae.py:68-79)."""
@@ -400,12 +407,14 @@ class ConvEngine:
                                           out_dradii=self.grads[:lay.n])
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
-        w_heads = self.params[ow:ow + NH * H_DIM].view(NH, H_DIM)
-        _, _, dhflat = Fn.linear_backward(c["hflat"], w_heads, dheads, relu_in=True, need_dx=True,
-                                          out_dW=self.grads[ow:ow + NH * H_DIM].view(NH, H_DIM),
-                                          out_db=self.grads[ob:ob + NH])
+        # heads backward against the channel-last head matrix of the forward pass; its gradient is re-ordered into the
+        # reference's column order on the way into the flat gradient buffer, dhflat IS the channel-last da2
+        dW_cl = dheads.new_empty(NH, H_DIM)
+        _, _, dhflat = Fn.linear_backward(c["hflat"], c["w_heads_cl"], dheads, relu_in=True, need_dx=True,
+                                          out_dW=dW_cl, out_db=self.grads[ob:ob + NH])
+        _permute_rc(dW_cl.view(NH, 16, 512), NH, 16, 512, out=self.grads[ow:ow + NH * H_DIM])
         # ---- encoder backward (Conv2d backward-data = col2im)
-        da2 = _permute_rc(dhflat, B, 512, 16).view(B * 16, 512)
+        da2 = dhflat.view(B * 16, 512)
         _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
         da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
