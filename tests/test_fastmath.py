@@ -72,3 +72,15 @@ def test_log1p_pos(lib):
     out = np.empty_like(e)
     lib.t_log1p(e.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(e.size))
     assert _ulps(out, np.log1p(e.astype(np.float64))).max() <= 4
+
+
+def test_tile_index_division_by_float_reciprocal_is_exact():
+    """`fast_div` (csrc/mvae_common.hpp): a / b as int((a + 0.5) * rcp(b)) in float32, used for the tile index of a
+    workgroup.  Exact for every grid size in use, also with a reciprocal that is off by one or two ulps (v_rcp_f32)."""
+    a = np.arange(0, 1 << 16, dtype=np.int64)
+    for b in list(range(1, 600)) + [784, 1024, 4096]:
+        r = np.float32(1) / np.float32(b)
+        for rr in (r, np.nextafter(r, np.float32(0)), np.nextafter(r, np.float32(2)),
+                   np.nextafter(np.nextafter(r, np.float32(2)), np.float32(2))):
+            q = ((a.astype(np.float32) + np.float32(0.5)) * rr).astype(np.int64)
+            assert np.array_equal(q, a // b), b
