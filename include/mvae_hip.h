@@ -270,6 +270,16 @@ int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, f
  *   a ConvTranspose2d (conv_vae.py:72-74).
  *   dWt[oc, (ky,kx,c)] = sum_{b,oy,ox} dy[(b,oy,ox), oc] src[b, 2oy-1+ky, 2ox-1+kx, c]: the weight gradient of either
  *   (rows are cut into slices added in index order; workspace = mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats floats). */
+/* The TRANSPOSED convolution of the same family without its [B IH IW, 16 OC] product and without col2im: the output
+ * pixels of one parity class (oy % 2, ox % 2) receive exactly 4 taps each, so the layer is four implicit contractions over
+ * K = (4 taps, C).  src[B, IH, IW, C] channel-last -> y[B, 2 IH, 2 IW, OC] channel-last;
+ *   y[b, oy, ox, oc] = act(bias[oc] + sum_{ky,kx,c : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} src[b, iy, ix, c] Wt[c, (ky,kx,oc)]),
+ *   zeroed where mask[b, oy, ox, oc] <= 0.  Wt[C, 16 OC] = the ConvTranspose2d weight [C, OC, 4, 4] with its columns
+ *   taps-major: ConvTranspose2d forward (conv_vae.py:52-55,72-74); with src = the incoming gradient [.., OC'] of a
+ *   Conv2d, Wt = that layer's weight stored [OC', (ky,kx,c)], mask = the previous ReLU's output: its backward-data.
+ *   C % 32 == 0, OC % 4 == 0, IH and IW powers of two. */
+int mvae_convT_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
+                           int IH, int IW, int OC, int relu, void* stream);
 /* workspace (may be NULL): mvae_conv_k4s2p1_nhwc_workspace_floats(...) floats; when given, a layer with fewer than 256
  * output tiles and a patch axis >= 2048 splits the contraction into <= 4 slices added in index order (mask == NULL only). */
 int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);

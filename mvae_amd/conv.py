@@ -213,6 +213,17 @@ def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[T
     return y
 
 
+def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
+                OC: int, relu: bool) -> Tensor:
+    """Transposed convolution as four implicit contractions (one per output parity class; no [M, 16 OC] product, no
+    col2im): src [B*IH*IH, Cc] channel-last -> [B*(2 IH)^2, OC]; Wt [Cc, 16 OC] with columns (ky, kx, oc).
+    ConvTranspose2d forward, or Conv2d backward-data with `mask` = the previous ReLU's output."""
+    y = src.new_empty(B * (2 * IH) * (2 * IH), OC)
+    check(load().mvae_convT_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
+                                        1 if relu else 0, stream_ptr(src.device)))
+    return y
+
+
 def _conv_nhwc_wgrad(dy: Tensor, src: Tensor, out: Tensor, B: int, Cc: int, IH: int) -> Tensor:
     """out[OC, 16 Cc] (taps-major, e.g. a slot of the flat gradient buffer) = dy^T im2col(src), patch matrix implicit."""
     OC = dy.shape[1]
@@ -319,10 +330,8 @@ class ConvEngine:
         R = zz.shape[0]
         c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
         c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
-        c["cT1"] = _gemm_nn(c["t0"], c["Wd1"])
-        c["b1"] = _col2im(c["cT1"], PV["d1.bias"], None, R, 256, 8, _nhwc(8, 256), True, (R * 64, 256), True)
-        c["cT2"] = _gemm_nn(c["b1"], c["Wd2"])
-        c["b2"] = _col2im(c["cT2"], PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64), True)
+        c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True)   # [R*64, 256]
+        c["b2"] = _convT_nhwc(c["b1"], c["Wd2"], PV["d2.bias"], None, R, 256, 8, 64, True)    # [R*256, 64]
         c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
         c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
@@ -352,10 +361,8 @@ class ConvEngine:
         R = zz.shape[0]
         d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
         t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
-        b1 = _col2im(_gemm_nn(t0, self.flat.matrix(self.params, "d1")), PV["d1.bias"], None, R, 256, 8,
-                     _nhwc(8, 256), True, (R * 64, 256), True)
-        b2 = _col2im(_gemm_nn(b1, self.flat.matrix(self.params, "d2")), PV["d2.bias"], None, R, 64, 16,
-                     _nhwc(16, 64), True, (R * 256, 64), True)
+        b1 = _convT_nhwc(t0, self.flat.matrix(self.params, "d1"), PV["d1.bias"], None, R, 128, 4, 256, True)
+        b2 = _convT_nhwc(b1, self.flat.matrix(self.params, "d2"), PV["d2.bias"], None, R, 256, 8, 64, True)
         lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
                      (R, 3072))
         return lo.view(z.shape[:-1] + (3072,))
@@ -417,10 +424,10 @@ class ConvEngine:
         da2 = dhflat.view(B * 16, 512)
         _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
-        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
+        da1 = _convT_nhwc(da2, c["We2"], None, c["a1"], B, 512, 4, 128, False)   # [B*64, 128], ReLU mask of a1
         _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
         _colsum(da1, out=GV["e1.bias"])
-        da0 = _col2im(_gemm_nn(da1, c["We1"]), None, c["a0"], B, 64, 16, _nhwc(16, 64), False, (B * 256, 64), True)
+        da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False)    # [B*256, 64], ReLU mask of a0
         _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
         _colsum(da0, out=GV["e0.bias"])
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))

@@ -335,6 +335,11 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 //   1: the A operand is im2col(src) -- row m = (b, oy, ox), column k = (ky, kx, c) taps-major -- fetched straight from
 //      src[b, 2oy-1+ky, 2ox-1+kx, c] (zero outside the image).  Conv2d forward / ConvTranspose2d backward-data (A_KC, B_KC).
 //   2: the B operand is im2col(src) with the roles k = row m, j = (ky, kx, c): the weight gradient dy^T im2col(src).
+//   3: the TRANSPOSED convolution (ConvTranspose2d forward, Conv2d backward-data) without its [M, 16 C] product: the
+//      output pixels of one parity class (oy % 2, ox % 2) = blockIdx.z receive exactly 4 taps each, ky = 1 - py + 2 ty,
+//      iy = oy/2 + py - ty (ty = 0, 1; the same in x), so per class it is a contraction over K = (4 taps, C_in) whose A
+//      operand is gathered from src (zero outside the image), whose B operand is the tap's column block of the weight
+//      [C_in, (ky, kx, oc)], and whose rows are scattered to the class's pixels by the epilogue.
 // A K step of 32 lies inside one tap (C % 32 == 0), so the tap of a step is uniform and a lane moves 16 contiguous bytes.
 struct ConvGeom {
   int Cc, IH, IW;    // channels and extent of the SOURCE image
@@ -355,9 +360,10 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
   static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kb = blockIdx.z * k_per_slice;
-  const int ke = (kb + k_per_slice < K) ? kb + k_per_slice : K;
-  C += (size_t)blockIdx.z * slice_stride;
+  const int kb = GATHER == 3 ? 0 : blockIdx.z * k_per_slice;
+  const int ke = GATHER == 3 ? K : ((kb + k_per_slice < K) ? kb + k_per_slice : K);
+  if (GATHER != 3) C += (size_t)blockIdx.z * slice_stride;
+  const int par_y = GATHER == 3 ? (int)(blockIdx.z >> 1) : 0, par_x = GATHER == 3 ? (int)(blockIdx.z & 1) : 0;
 
   float4 ra[LA], rb[LB];
   auto fetch = [&](int k0) {
@@ -371,6 +377,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
         const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
         const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
         const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+        if (m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW)
+          v = *reinterpret_cast<const float4*>(A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c);
+      } else if (A_KC && GATHER == 3) {  // row = output pixel of this parity class, k = (tap, c)
+        const int i = f / KQ, k = k0 + ((f % KQ) << 2);
+        const int m = m0 + i;
+        const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;  // tap = 2 ty + tx, uniform for the K step
+        const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
+        const int iy = oy + par_y - (tap >> 1), ix = ox + par_x - (tap & 1);
         if (m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW)
           v = *reinterpret_cast<const float4*>(A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c);
       } else if (A_KC) {  // 4 consecutive k of row i
@@ -396,6 +410,12 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
         const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
         if (j < N && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW)
           v = *reinterpret_cast<const float4*>(Bm + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c);
+      } else if (GATHER == 3) {  // row k = (tap, c) of the weight [C_in][(ky, kx, oc)]: the tap picks the column block
+        const int k = k0 + (f % BK), j = (f / BK) << 2;
+        const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
+        const int ky = 1 - par_y + 2 * (tap >> 1), kx = 1 - par_x + 2 * (tap & 1);
+        if (n0 + j < N && k < ke)
+          v = *reinterpret_cast<const float4*>(Bm + (size_t)c * sbk + (size_t)(ky * 4 + kx) * N + (n0 + j));
       } else {
         const int k = k0 + (f % BK), j = (f / BK) << 2;
         if (n0 + j < N && k < ke) v = *reinterpret_cast<const float4*>(Bm + (size_t)k * sbk + (n0 + j));
@@ -481,8 +501,12 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
   const bool vec = (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0 && (ldc & 3) == 0;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
-    const int m = m0 + wm + a * 16 + li;
+    int m = m0 + wm + a * 16 + li;
     if (m >= M) continue;
+    if (GATHER == 3) {  // row of the parity class -> its pixel of the (2 IH) x (2 IW) output
+      const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, bb = m >> cg.lOHW;
+      m = (bb * 2 * cg.IH + 2 * oy + par_y) * 2 * cg.IW + 2 * ox + par_x;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int n = n0 + wn + b * 16 + lk;
@@ -797,6 +821,30 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
                                      (hipStream_t)stream, g);
   }
   LAUNCH_CHECK("implicit conv launch");
+  return 0;
+}
+
+// Transposed convolution (k4 s2 p1, channel-last) as four implicit contractions, one per output parity class (GATHER 3):
+// src[B, IH, IW, C] -> y[B, 2 IH, 2 IW, OC]; Wt[C, (ky, kx, oc)] = the ConvTranspose2d weight [C, OC, 4, 4] taps-major
+// (or, for the backward-data of a Conv2d with weight [C, OC', 4, 4] stored [C][(ky, kx, oc')], that same matrix).
+extern "C" int mvae_convT_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
+                                      int B, int Cc, int IH, int IW, int OC, int relu, void* stream) {
+  if (!src || !Wt || !y || OC < 4 || (OC & 3)) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (B < 1 || Cc < 32 || (Cc & 31) || IH < 1 || IW < 1 || (IH & (IH - 1)) || (IW & (IW - 1)))
+    return fail(MVAE_E_UNSUPPORTED, "implicit transposed conv needs C %% 32 == 0 and power-of-two extents%s (%lld)", "",
+                Cc);
+  int lOW = 0, lOH = 0;
+  while ((1 << lOW) < IW) ++lOW;
+  while ((1 << lOH) < IH) ++lOH;
+  const ConvGeom g{Cc, IH, IW, lOW, lOW + lOH};  // rows of a parity class = (b, oy / 2, ox / 2): the INPUT extent
+  const int64_t M = (int64_t)B * IH * IW;
+  const int K = 4 * Cc;
+  if (!tiled_ok(src, Cc) || !tiled_ok(Wt, 16 * OC) || !tiled_ok(y, OC) || (mask && !tiled_ok(mask, OC)) ||
+      (bias && ((uintptr_t)bias & 15)) || 4 * M > 0x7fffffff)
+    return fail(MVAE_E_ALIGN, "implicit transposed conv needs 16-byte aligned operands%s", "");
+  launch_gemm_tiled<true, false, 3>(src, 0, 0, Wt, (int64_t)16 * OC, 1, y, OC, bias, mask, relu, (int)M, OC, K, 4, K, 0,
+                                    (hipStream_t)stream, g);
+  LAUNCH_CHECK("implicit transposed conv launch");
   return 0;
 }
 
