@@ -331,7 +331,10 @@ class ConvEngine:
         c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
         c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
         c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True)   # [R*64, 256]
-        c["b2"] = _convT_nhwc(c["b1"], c["Wd2"], PV["d2.bias"], None, R, 256, 8, 64, True)    # [R*256, 64]
+        # (d2 and the backward-data of e2 keep the product + col2im form: measured 95 / 80 us against 98 / 96 us implicit,
+        #  tools/bench_conv_gather.py; d1 and the backward-data of e1 gain 11 / 10 us each)
+        c["b2"] = _col2im(_gemm_nn(c["b1"], c["Wd2"]), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
+                          (R * 256, 64), True)
         c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
         c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
@@ -362,7 +365,8 @@ class ConvEngine:
         d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
         t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
         b1 = _convT_nhwc(t0, self.flat.matrix(self.params, "d1"), PV["d1.bias"], None, R, 128, 4, 256, True)
-        b2 = _convT_nhwc(b1, self.flat.matrix(self.params, "d2"), PV["d2.bias"], None, R, 256, 8, 64, True)
+        b2 = _col2im(_gemm_nn(b1, self.flat.matrix(self.params, "d2")), PV["d2.bias"], None, R, 64, 16,
+                     _nhwc(16, 64), True, (R * 256, 64), True)
         lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
                      (R, 3072))
         return lo.view(z.shape[:-1] + (3072,))
@@ -424,7 +428,7 @@ class ConvEngine:
         da2 = dhflat.view(B * 16, 512)
         _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
-        da1 = _convT_nhwc(da2, c["We2"], None, c["a1"], B, 512, 4, 128, False)   # [B*64, 128], ReLU mask of a1
+        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
         _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
         _colsum(da1, out=GV["e1.bias"])
         da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False)    # [B*256, 64], ReLU mask of a0

@@ -31,3 +31,16 @@ for name, Cc, IH, OC in [("e1 fwd", 64, 16, 128), ("e2 fwd", 128, 8, 512), ("d2 
     a = timeit(lambda: _conv_nhwc(src, Wt, bias, None, B, Cc, IH, True))
     b = timeit(lambda: Fn.linear_forward(x, Wt, bias))
     print(f"{name}: M={M} N={N} K={K}  implicit {a*1e6:7.1f} us {fl/a/1e12:6.1f} TF | plain NT {b*1e6:7.1f} us {fl/b/1e12:6.1f} TF")
+
+from mvae_amd.conv import _convT_nhwc, _gemm_nn, _col2im, _nhwc
+print("transposed convolutions: implicit (4 parity classes) vs product + col2im")
+for name, Cc, IH, OC in [("d1 fwd", 128, 4, 256), ("d2 fwd", 256, 8, 64), ("e2 bwd-data", 512, 4, 128),
+                         ("e1 bwd-data", 128, 8, 64)]:
+    src = torch.randn(B * IH * IH, Cc, device=dev)
+    Wt = torch.randn(Cc, 16 * OC, device=dev)
+    bias = torch.randn(OC, device=dev)
+    fl = 2.0 * (B * IH * IH) * Cc * 16 * OC
+    a = timeit(lambda: _convT_nhwc(src, Wt, bias, None, B, Cc, IH, OC, True))
+    b = timeit(lambda: _col2im(_gemm_nn(src, Wt), bias, None, B, OC, 2 * IH, _nhwc(2 * IH, OC), True,
+                               (B * 4 * IH * IH, OC), True))
+    print(f"{name}: C={Cc} IH={IH} OC={OC}  implicit {a*1e6:7.1f} us {fl/a/1e12:6.1f} TF | product+col2im {b*1e6:7.1f} us")
