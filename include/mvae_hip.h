@@ -278,7 +278,7 @@ int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, f
  *   taps-major: ConvTranspose2d forward (conv_vae.py:52-55,72-74); with src = the incoming gradient [.., OC'] of a
  *   Conv2d, Wt = that layer's weight stored [OC', (ky,kx,c)], mask = the previous ReLU's output: its backward-data.
  *   C % 32 == 0, OC % 4 == 0, IH and IW powers of two. */
-int mvae_convT_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
+int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
                            int IH, int IW, int OC, int relu, void* stream);
 /* workspace (may be NULL): mvae_conv_k4s2p1_nhwc_workspace_floats(...) floats; when given, a layer with fewer than 256
  * output tiles and a patch axis >= 2048 splits the contraction into <= 4 slices added in index order (mask == NULL only). */

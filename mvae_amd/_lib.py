@@ -74,7 +74,7 @@ PROTOTYPES = {
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),
     "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P]),
-    "mvae_convT_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_k4s2p1_nhwc_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),

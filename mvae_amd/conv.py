@@ -219,7 +219,7 @@ def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[
     col2im): src [B*IH*IH, Cc] channel-last -> [B*(2 IH)^2, OC]; Wt [Cc, 16 OC] with columns (ky, kx, oc).
     ConvTranspose2d forward, or Conv2d backward-data with `mask` = the previous ReLU's output."""
     y = src.new_empty(B * (2 * IH) * (2 * IH), OC)
-    check(load().mvae_convT_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
+    check(load().mvae_conv_transpose_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
                                         1 if relu else 0, stream_ptr(src.device)))
     return y
 

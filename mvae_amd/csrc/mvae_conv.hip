@@ -827,7 +827,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
 // Transposed convolution (k4 s2 p1, channel-last) as four implicit contractions, one per output parity class (GATHER 3):
 // src[B, IH, IW, C] -> y[B, 2 IH, 2 IW, OC]; Wt[C, (ky, kx, oc)] = the ConvTranspose2d weight [C, OC, 4, 4] taps-major
 // (or, for the backward-data of a Conv2d with weight [C, OC', 4, 4] stored [C][(ky, kx, oc')], that same matrix).
-extern "C" int mvae_convT_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
+extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
                                       int B, int Cc, int IH, int IW, int OC, int relu, void* stream) {
   if (!src || !Wt || !y || OC < 4 || (OC & 3)) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (B < 1 || Cc < 32 || (Cc & 31) || IH < 1 || IW < 1 || (IH & (IH - 1)) || (IW & (IW - 1)))
