@@ -20,8 +20,13 @@ def _run(*flags):
     port = sock.getsockname()[1]
     sock.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # a free rendezvous port per run
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", *flags],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", *flags]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    if p.returncode != 0 and "--force-dp" in flags:
+        # one retry for the exchange route only: a capture of the RCCL collective invalidated by the process group's
+        # watchdog thread can take the process down before bench.py's own fallback gets to run (rare)
+        print("bench.py --force-dp failed once, retrying:\n" + p.stderr[-1500:])
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines  # library banners must not reach stdout
