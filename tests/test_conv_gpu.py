@@ -264,6 +264,50 @@ def test_taps_major_layers_vs_torch(dev):
                  atol_frac=1e-5)
 
 
+@pytest.mark.parametrize("B,C,OC,IH", [(2, 32, 32, 4), (3, 64, 96, 8), (2, 128, 64, 2)])
+def test_implicit_convolutions_vs_torch(dev, B, C, OC, IH):
+    """The implicit contractions (no patch matrix, no product + col2im) against torch.nn.functional in float64: Conv2d
+    forward with bias + ReLU (mvae_conv_k4s2p1_nhwc), the transposed convolution as four parity classes with bias and
+    with a mask (mvae_conv_transpose_k4s2p1_nhwc), and the weight gradient (mvae_conv_k4s2p1_nhwc_wgrad)."""
+    import torch.nn.functional as F
+    from mvae_amd.conv import _conv_nhwc, _conv_nhwc_wgrad, _convT_nhwc, _taps_major
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, C, IH, IH, generator=g)
+    x_cl = x.permute(0, 2, 3, 1).contiguous().view(B * IH * IH, C).to(dev)
+    # Conv2d forward
+    W = torch.randn(OC, C, 4, 4, generator=g) * 0.1
+    b = torch.randn(OC, generator=g)
+    ref = F.relu(F.conv2d(x.double(), W.double(), b.double(), stride=2, padding=1))
+    Wt = _taps_major(W.to(dev), OC, C)  # [OC, (ky, kx, c)]
+    y = _conv_nhwc(x_cl, Wt, b.to(dev), None, B, C, IH, True)
+    OH = IH // 2
+    assert_close(_cpu(y.view(B, OH, OH, OC).permute(0, 3, 1, 2)), ref.numpy(), 2e-5, "implicit conv2d", atol_frac=1e-5)
+    # weight gradient of that layer: dW[oc, c, ky, kx] = sum dy * patch
+    dy = torch.randn(B, OC, OH, OH, generator=g)
+    xd = x.double().requires_grad_(True)
+    Wd = W.double().requires_grad_(True)
+    (F.conv2d(xd, Wd, None, stride=2, padding=1) * dy.double()).sum().backward()
+    dy_cl = dy.permute(0, 2, 3, 1).contiguous().view(B * OH * OH, OC).to(dev)
+    dWt = _conv_nhwc_wgrad(dy_cl, x_cl, torch.empty(OC, 16 * C, device=dev), B, C, IH)
+    ref_dWt = Wd.grad.permute(0, 2, 3, 1).reshape(OC, 16 * C)  # taps-major (ky, kx, c)
+    assert_close(_cpu(dWt), ref_dWt.numpy(), 2e-5, "implicit weight gradient", atol_frac=1e-5)
+    # backward-data of that Conv2d = a transposed convolution with the conv's own taps-major matrix, masked
+    ref_dx = xd.grad
+    mask = torch.randn(B, C, IH, IH, generator=g)
+    dx = _convT_nhwc(dy_cl, Wt, None, mask.permute(0, 2, 3, 1).contiguous().view(B * IH * IH, C).to(dev), B, OC, OH, C,
+                     False)
+    want = torch.where(mask > 0, ref_dx, torch.zeros_like(ref_dx))
+    assert_close(_cpu(dx.view(B, IH, IH, C).permute(0, 3, 1, 2)), want.numpy(), 2e-5, "implicit conv backward-data",
+                 atol_frac=1e-5)
+    # ConvTranspose2d forward with bias + ReLU
+    Wtr = torch.randn(C, OC, 4, 4, generator=g) * 0.1  # [IC, OC, 4, 4]
+    bt = torch.randn(OC, generator=g)
+    reft = F.relu(F.conv_transpose2d(x.double(), Wtr.double(), bt.double(), stride=2, padding=1))  # [B, OC, 2IH, 2IH]
+    yt = _convT_nhwc(x_cl, _taps_major(Wtr.to(dev), C, OC), bt.to(dev), None, B, C, IH, OC, True)
+    assert_close(_cpu(yt.view(B, 2 * IH, 2 * IH, OC).permute(0, 3, 1, 2)), reft.numpy(), 2e-5, "implicit convT",
+                 atol_frac=1e-5)
+
+
 def test_linear_splitk_vs_float64(dev):
     """Few rows, long contraction (the conv heads: [B, 8192] x [12, 8192]^T) through the split-K route."""
     from mvae_amd.conv import _linear_splitk
