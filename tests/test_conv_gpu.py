@@ -308,6 +308,29 @@ def test_implicit_convolutions_vs_torch(dev, B, C, OC, IH):
                  atol_frac=1e-5)
 
 
+def test_deferred_slice_sums_are_the_same_sums(dev):
+    """mvae_slice_sums_defer / _flush: the queued final "add the slices" of several producers, performed by ONE launch,
+    gives bit-identical results to the immediate form (same order of additions); a queue longer than its capacity flushes
+    itself."""
+    from mvae_amd import conv as CV
+    from mvae_amd._lib import check, load, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    Ps = [torch.randn(2048, 24, generator=g).to(dev) for _ in range(30)]
+    Qs = [torch.randn(2048, 40, generator=g).to(dev) for _ in range(30)]
+    now = [CV._gemm_tn(P, Q) for P, Q in zip(Ps, Qs)] + [CV._colsum(P) for P in Ps]
+    CV._DEFERRED_WS.clear()
+    check(load().mvae_slice_sums_defer(1))
+    try:
+        later = [CV._gemm_tn(P, Q) for P, Q in zip(Ps, Qs)] + [CV._colsum(P) for P in Ps]  # 60 jobs > 24 slots
+        check(load().mvae_slice_sums_flush(stream_ptr(dev)))
+    finally:
+        check(load().mvae_slice_sums_defer(0))
+        torch.cuda.synchronize()
+        CV._DEFERRED_WS.clear()
+    for a, b in zip(now, later):
+        assert torch.equal(a, b)
+
+
 def test_linear_splitk_vs_float64(dev):
     """Few rows, long contraction (the conv heads: [B, 8192] x [12, 8192]^T) through the split-K route."""
     from mvae_amd.conv import _linear_splitk
