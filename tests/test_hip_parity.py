@@ -432,6 +432,19 @@ def test_block_latent_kernels_vs_oracle_and_row_kernels(dev, model, H, D, B, blk
         assert_close(_cpu(a), _cpu(b), 1e-5, f"fused vs two-call: {n}", atol_frac=1e-5)
 
 
+@pytest.mark.parametrize("model,batch,path", [("h2,s2,e2", 128, "fused"), ("e6", 128, "fused"), ("e2,h2,s2", 256, "fused"),
+                                              ("6h2,6s2,6e2", 128, "block"), ("h2,s2,e2,p2", 128, "row"),
+                                              ("h2,s2,e2", 100, "row"), ("h40", 128, "row")])
+def test_kernel_path_of_the_baseline_shapes(dev, model, batch, path):
+    """Which latent kernels a shape takes (mvae_step_kernel_path): the BASELINE MLP configs [0], [1], [2] the fused forward
+    launch, config [3] the 16-row block kernels, everything else (ragged batches, large components) the per-row kernels."""
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    comps = [(c.letter, c.true_dim) for c in M.parse_components(model)]
+    eng = StepEngine(comps, 784, 400, dev, radius_trainable=[True] * len(comps))
+    assert eng.kernel_path(batch) == path
+
+
 def test_epoch_sums_are_compensated(dev):
     """The running sums of the epoch statistics (the reference adds Python doubles, stats.py:120-127) are float32 with
     Kahan compensation: at a CIFAR-scale running total (1e8, ulp 8) 300 further steps stay within one ulp of the
