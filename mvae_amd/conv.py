@@ -224,6 +224,15 @@ def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[
     return y
 
 
+def _conv_e2(a1: Tensor, We2: Tensor, bias: Tensor, B: int) -> Tensor:
+    """The e2 layer forward (128 -> 512 channels on 8 x 8): with only B * 16 output pixels its patch matrix is small
+    (33 MB at B = 256), and patch matrix + plain contraction measured faster than the operand gather (12 + 83 us against
+    105 us, tools/bench_conv_gather.py); tiny batches keep the implicit form (the plain contraction wants >= 512 rows)."""
+    if B * 16 >= 512:
+        return Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True), We2, bias, relu=True)
+    return _conv_nhwc(a1, We2, bias, None, B, 128, 8, True)
+
+
 def _conv_nhwc_wgrad(dy: Tensor, src: Tensor, out: Tensor, B: int, Cc: int, IH: int) -> Tensor:
     """out[OC, 16 Cc] (taps-major, e.g. a slot of the flat gradient buffer) = dy^T im2col(src), patch matrix implicit."""
     OC = dy.shape[1]
@@ -316,7 +325,7 @@ class ConvEngine:
         c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
         c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
         c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True)   # [B*64, 128]
-        c["a2"] = _conv_nhwc(c["a1"], c["We2"], PV["e2.bias"], None, B, 128, 8, True)   # [B*16, 512]
+        c["a2"] = _conv_e2(c["a1"], c["We2"], PV["e2.bias"], B)   # [B*16, 512]
         # The reference flattens NCHW (conv_vae.py:65: column c * 16 + p of the head matrices); the activation here is
         # channel-last (column p * 512 + c).  Re-ordering the head matrix (NH x 8192: 0.4 MB) instead of the activation
         # and its gradient (8 MB each) gives the same products.
@@ -353,7 +362,7 @@ class ConvEngine:
         a0 = Fn.linear_forward(_im2col(x, None, B, 3, 32, _nchw(32, 3)), PV["e0.weight"].view(64, 48), PV["e0.bias"],
                                relu=True)
         a1 = _conv_nhwc(a0, self.flat.matrix(self.params, "e1"), PV["e1.bias"], None, B, 64, 16, True)
-        a2 = _conv_nhwc(a1, self.flat.matrix(self.params, "e2"), PV["e2.bias"], None, B, 128, 8, True)
+        a2 = _conv_e2(a1, self.flat.matrix(self.params, "e2"), PV["e2.bias"], B)
         w_heads_cl, b_heads = self._heads_channel_last()
         return _linear_splitk(a2.view(B, H_DIM), w_heads_cl, b_heads)
 
