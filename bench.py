@@ -9,10 +9,14 @@ GPU, float32, epoch >= 10 state (radii 2.0, curvature SGD active).  One "step" =
 backward, Adam + SGD on the radii (+ gradient all-reduce when N > 1).  Inputs (binarised x, eps) are synthetic
 (mvae_amd/synthetic.py: MNIST-shaped stroke images, dynamically binarised) and resident in HBM before the timed
 region; weights are the synthetic init.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The top-level fields are configs[1]; at N = 1 the default invocation also times short
+legs of the other single-GPU BASELINE configs and reports them under "configs": {"e6", "prod36", "conv"}
+(configs[0], [3], [4]); `--no-extra-configs` skips them.
 """
 import argparse
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -24,10 +28,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MODEL = "h2,s2,e2"
-COMPS = [("h", 2), ("s", 2), ("e", 2)]
 B, D, H = 128, 784, 400
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+ONE_GRAPH_MAX = 400  # a timed region of up to this many steps is captured as ONE graph (one replay)
 
 
 def algorithmic_per_launch(P, NH=12, Z=8, E=6):
@@ -48,11 +52,13 @@ def algorithmic_per_launch(P, NH=12, Z=8, E=6):
     }
 
 
-def cpu_baseline(seconds_budget=12.0, model=MODEL, fixed=False):
+def cpu_baseline(seconds_budget=8.0, model=MODEL, fixed=False):
     """The oracle (CPU restatement of the reference path, pinned to golden vectors recorded from the reference) timed
     on this box's host cores: same model, same synthetic inputs, same step (fwd, ELBO, bwd, Adam + curvature SGD).
-    torch's default (one thread per core) oversubscribes this op-dispatch-bound workload badly on a many-core host,
-    so a short probe picks the fastest intra-op thread count and that one is timed and reported."""
+    Rows (SURVEY 8d / BASELINE.md protocol): one intra-op thread; the fastest thread count of a short probe (torch's
+    default of one thread per core oversubscribes this dispatch-bound workload on a many-core host); and one float64
+    row at that thread count (float64 is the reference CLI's default, mt/examples/run.py:77).  The top-level
+    value / cores are the best float32 row."""
     from mvae_amd import synthetic
     from oracle import model as M
     spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=fixed)
@@ -61,14 +67,15 @@ def cpu_baseline(seconds_budget=12.0, model=MODEL, fixed=False):
     xs = synthetic.digits_like_batches(n_data, B)
     eps = synthetic.eps_batches(n_data, B, spec.total_true_dim)
 
-    def run(seconds, min_steps):
-        orc = M.StepOracle(spec, state0)
+    def run(seconds, min_steps, dtype=torch.float32):
+        orc = M.StepOracle(spec, state0, dtype=dtype)
+        xd, ed = xs.to(dtype), eps.to(dtype)
         for s in range(3):
-            orc.train_step(xs[s % n_data], eps[s % n_data], 1.0, epoch=12)
+            orc.train_step(xd[s % n_data], ed[s % n_data], 1.0, epoch=12)
         t0 = time.perf_counter()
         n = 0
         while True:
-            orc.train_step(xs[n % n_data], eps[n % n_data], 1.0, epoch=12)
+            orc.train_step(xd[n % n_data], ed[n % n_data], 1.0, epoch=12)
             n += 1
             if n >= min_steps and time.perf_counter() - t0 > seconds:
                 break
@@ -80,71 +87,77 @@ def cpu_baseline(seconds_budget=12.0, model=MODEL, fixed=False):
     for t in sorted({1, 4, 8, 16, min(32, ncpu)}):
         if t <= ncpu:
             torch.set_num_threads(t)
-            n, dt = run(1.5, 5)
+            n, dt = run(1.0, 5)
             probe[t] = n / dt
     best = max(probe, key=probe.get)
+    rows = []
+    torch.set_num_threads(1)
+    n1, dt1 = run(seconds_budget * 0.3, 20)
+    rows.append({"threads": 1, "dtype": "f32", "value": n1 / dt1, "steps": n1, "seconds": dt1})
     torch.set_num_threads(best)
-    n, dt = run(seconds_budget, 50)
+    n, dt = run(seconds_budget * 0.5, 30)
+    rows.append({"threads": best, "dtype": "f32", "value": n / dt, "steps": n, "seconds": dt})
+    n64, dt64 = run(seconds_budget * 0.2, 10, dtype=torch.float64)
+    rows.append({"threads": best, "dtype": "f64", "value": n64 / dt64, "steps": n64, "seconds": dt64,
+                 "note": "float64 is the reference CLI's default (--doubles True, run.py:77)"})
     torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "ELBO-steps/sec", "cores": best, "kind": "port",
-            "sample": f"{n} steps of the same h2,s2,e2 B=128 workload in {dt:.1f}s with {best} intra-op threads "
+    return {"value": n / dt, "unit": "ELBO-steps/sec", "cores": best, "kind": "port", "rows": rows,
+            "sample": f"{n} steps of the same {model} B=128 workload in {dt:.1f}s with {best} intra-op threads "
                       f"(best of a probe over {sorted(probe)} threads: "
                       f"{', '.join(f'{k}: {v:.0f}/s' for k, v in sorted(probe.items()))}; host has {ncpu} logical "
-                      "cores); oracle = CPU restatement of ModelVAE.train_step, float32"}
+                      "cores); oracle = CPU restatement of ModelVAE.train_step, float32, Python asserts on (not -O); "
+                      "rows: 1 thread f32, best-thread f32, best-thread f64"}
 
 
 CONV_FLOPS_B256 = 79.5e9  # fwd 26.63 GFLOP, fwd + bwd ~79.5 GFLOP at B = 256
 
 
-def bench_conv(args, json_fd):
+def conv_leg(steps, warmup, graph=True):
     """BASELINE configs[4] on one GPU: CIFAR shapes (3x32x32, soft targets), conv architecture, h_dim 8192, batch 256,
     model h2,s2,e2, learnable curvature.  One step = ConvEngine.train_step (forward, ELBO, backward, Adam + curvature
-    SGD), `graph_steps` steps per HIP graph.  MFMA-bound: the roofline is f32 MFMA flops."""
+    SGD); the warm-up and the timed region are ONE HIP graph each.  MFMA-bound: the roofline is f32 MFMA flops."""
     from mvae_amd import functional as Fn, synthetic
     from mvae_amd.conv import ConvEngine
     Bc = 256
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
     shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
-    gs = max(1, min(args.graph_steps if args.graph_steps > 0 else 1, 10))
-    import math
-    if args.graph_steps > 0:
-        g_ = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
-        gs = max(d for d in range(1, min(g_, gs) + 1) if g_ % d == 0)
-    xs = synthetic.uniform_batches(gs, Bc, 3072).to(dev)
-    eps = synthetic.eps_batches(gs, Bc, 6).to(dev)
+    n_data = 8
+    xs = synthetic.uniform_batches(n_data, Bc, 3072).to(dev)
+    eps = synthetic.eps_batches(n_data, Bc, 6).to(dev)
     for i in range(3):
-        eng.train_step(xs[i % gs], eps[i % gs], 1.0, True)
+        eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
     torch.cuda.synchronize()
-    graph = None
-    if args.graph_steps > 0:
+    graphs = {}
+    if graph:
         keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for i in range(gs):
-                eng.train_step(xs[i], eps[i], 1.0, True)
+        for n in sorted({warmup, steps} - {0}):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(n):
+                    eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
+            graphs[n] = g
         torch.cuda.synchronize()
         for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
             dst.copy_(src)
 
     def run(n):
-        if graph is not None:
-            for _ in range(n // gs):
-                graph.replay()
+        if n in graphs:
+            graphs[n].replay()
         else:
             for i in range(n):
-                eng.train_step(xs[i % gs], eps[i % gs], 1.0, True)
+                eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
 
-    run(args.warmup)
+    run(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = eng.read_stats()["last"]
     assert st["elbo"] == st["elbo"], "non-finite ELBO"
-    step_s = dt / args.steps
+    step_s = dt / steps
     # the dominant kernel, timed live with events on the launch stream: the e2 forward contraction
     # ([B*16, 2048] x [512, 2048]^T, 2.15 GFLOP at B = 256), the largest single launch of the step
     a = torch.randn(Bc * 16, 2048, device=dev)
@@ -161,15 +174,15 @@ def bench_conv(args, json_fd):
     k_ms = e0.elapsed_time(e1) / 20
     k_tf = 2.0 * Bc * 16 * 2048 * 512 / (k_ms * 1e-3) / 1e12
     tf = CONV_FLOPS_B256 / step_s / 1e12
-    line = {
+    return {
         "metric": "ELBO-steps/sec (batch 256) CIFAR conv h2,s2,e2",
-        "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": steps / dt, "unit": "ELBO-steps/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[4] on ONE GPU: CIFAR shapes (3x32x32, U[0,1] soft targets), model h2,s2,e2, "
                                "learnable curvature, conv architecture h_dim=8192, batch 256, epoch>=10 state",
-                   "global_batch": Bc, "parallelism": "dp1", "graph_steps": gs if graph is not None else 0,
-                   "graph_replays": (args.steps // gs) if graph is not None else 0,
+                   "global_batch": Bc, "parallelism": "dp1", "graph_steps": steps if graphs else 0,
+                   "graph_replays": 1 if graphs else 0,
                    "final_elbo_per_sample": st["elbo"] / Bc},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": tf / F32_MFMA_PEAK_TF,
@@ -178,8 +191,137 @@ def bench_conv(args, json_fd):
                      "kernel_ms": k_ms, "kernel_achieved_TFLOPs": k_tf, "kernel_mfma_frac": k_tf / F32_MFMA_PEAK_TF,
                      "traffic": None},
     }
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
-    os.close(json_fd)
+
+
+def parse_model(model):
+    from mvae_amd.utils import parse_component_str
+    comps = []
+    for tok in model.lower().split(","):
+        mult, letter, dim = parse_component_str(tok.strip())
+        comps += [(letter, dim)] * mult
+    return comps
+
+
+def make_plan(steps, warmup, graph_steps):
+    """How run(warmup); run(steps) is issued: (graph_steps, graph_plan).  Up to ONE_GRAPH_MAX steps the timed region is
+    ONE graph (and the warm-up another): a single replay, no per-replay launch cost inside the timed region.  Longer
+    runs replay `graph_steps`-step graphs (the cost of a replay, ~10-16 us, is then < 1 % of a graph's duration)."""
+    if graph_steps <= 0:
+        return 0, None
+    if steps <= ONE_GRAPH_MAX and warmup <= ONE_GRAPH_MAX:
+        return max(steps, warmup, 1), ([warmup, steps] if warmup > 0 else [steps])
+    if steps % graph_steps or warmup % graph_steps:
+        g = math.gcd(steps, warmup) if warmup > 0 else steps
+        graph_steps = max(d for d in range(1, min(g, graph_steps) + 1) if g % d == 0)
+    return graph_steps, None
+
+
+def mlp_roofline(eng, prof, step_s, fixed):
+    """Whole-step roofline + per-launch table."""
+    alg = algorithmic_per_launch(eng.flat.n_logical_params(), eng.layout.heads_dim, eng.layout.z_dim,
+                                 eng.layout.eps_dim)
+    prof = dict(prof)
+    if prof.get("latent_fwd", 1.0) == 0.0:  # the fused forward: launches 2 + 3 are ONE launch (k_fwd23); hd stays in LDS
+        f4, NHh, Zz = 4.0, eng.layout.heads_dim, eng.layout.z_dim
+        alg["latent_dec1_fwd"] = dict(
+            flops=alg["latent_fwd"]["flops"] + alg["dec1_fwd"]["flops"],
+            bytes=f4 * (B * H + NHh * H + NHh + B * eng.layout.eps_dim + H * Zz + H + D * H + D + 2 * B * D + B * H + B * Zz))
+        prof["latent_dec1_fwd"] = prof.pop("dec1_fwd")
+        del prof["latent_fwd"], alg["latent_fwd"], alg["dec1_fwd"]
+        prof = {k: prof[k] for k in ("enc_fwd", "latent_dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")}
+    # The headline fraction is the WHOLE STEP against the roofline: SURVEY section 8(d)'s algorithmic bytes / flops of one
+    # step (each tensor once: x, eps, and p, m, v, g read + written) over the measured ms_per_step.  `kernel` names the
+    # longest launch -- whatever it is -- with its own numbers; every launch is listed in `per_kernel`.
+    P_log = eng.flat.n_logical_params()
+    step_bytes_8d = 4.0 * (B * D + B * eng.layout.eps_dim + 8 * P_log)
+    step_flops = sum(v["flops"] for v in alg.values())
+    step_gbs, step_tf = step_bytes_8d / step_s / 1e9, step_flops / step_s / 1e12
+    dom = max(prof, key=prof.get)
+    dur_s = prof[dom] * 1e-3
+    per_kernel = {k: {"ms": prof[k], "bytes": alg[k]["bytes"], "flops": alg[k]["flops"],
+                      "hbm_frac": alg[k]["bytes"] / (prof[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "mfma_frac": alg[k]["flops"] / (prof[k] * 1e-3) / 1e12 / F32_MFMA_PEAK_TF} for k in prof}
+    traffic, traffic_step, traffic_src = None, None, None
+    # fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, see profiles/README.md): the
+    # newest summary recorded from THIS build of the step kernels (its `source_hash` equals the hash of the sources the
+    # loaded library was built from); a summary of an older build is stale the moment a kernel changes and is refused
+    from mvae_amd.build import source_hash
+    cur = source_hash()
+
+    def _order(path):  # r02 (the round's final set) after r02a, r02b (mid-round sets) after r01
+        tag = os.path.basename(path).split("_")[0]
+        digits = "".join(ch for ch in tag[1:] if ch.isdigit())
+        suffix = tag[1 + len(digits):]
+        return (int(digits or 0), 1 if suffix == "" else 0, suffix)
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_order, reverse=True):
+        name = os.path.basename(path)
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+            if doc.get("source_hash") != cur:
+                stale = stale or name
+                continue
+            kern = doc["kernels"]
+            names = {"latent_dec1_fwd": "k_fwd23"}
+            traffic = kern[names.get(dom, "k_" + dom)]["traffic_bytes"]
+            traffic_step = sum(kern[names.get(k, "k_" + k)]["traffic_bytes"] for k in prof)
+            traffic_src = "profiles/" + name
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if traffic is None and stale:
+        traffic_src = f"none: profiles/{stale} was recorded from another build of the kernels (source_hash mismatch)"
+    if step_gbs / HBM_PEAK_GBS >= step_tf / F32_MFMA_PEAK_TF:
+        roof = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": step_gbs / HBM_PEAK_GBS}
+    else:
+        roof = {"bound": "mfma", "achieved": step_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": step_tf / F32_MFMA_PEAK_TF}
+    roof.update({
+        "scope": "whole step: SURVEY 8(d) bytes 4(BD + B*eps_dim + 8P) and GEMM flops over ms_per_step",
+        "step_bytes": step_bytes_8d, "step_flops": step_flops,
+        "step_hbm_frac": step_gbs / HBM_PEAK_GBS, "step_mfma_frac": step_tf / F32_MFMA_PEAK_TF,
+        "kernel": dom, "kernel_rule": "the longest launch",
+        "kernel_achieved_GBps": alg[dom]["bytes"] / dur_s / 1e9, "kernel_hbm_frac": per_kernel[dom]["hbm_frac"],
+        "kernel_achieved_TFLOPs": alg[dom]["flops"] / dur_s / 1e12, "kernel_mfma_frac": per_kernel[dom]["mfma_frac"],
+        "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_src,
+        "launch_bytes_sum": sum(v["bytes"] for v in alg.values()),
+        "kernel_ms": prof, "per_kernel": per_kernel})
+    return roof
+
+
+def mlp_leg(model, fixed, steps, warmup, dev):
+    """A short single-GPU leg of another BASELINE MLP config (one graph for the warm-up, one for the timed region)."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import StepRunner
+    comps = parse_model(model)
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[not fixed] * len(comps), lr=1e-3)
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    n_data = 64
+    xs = synthetic.digits_like_batches(n_data, B, seed=4321).to(dev)
+    eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=0).to(dev)
+    gs, plan = make_plan(steps, warmup, 50)
+    runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not fixed, graph_steps=gs, graph_plan=plan)
+    runner.run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = eng.read_stats()
+    assert stats["sum"]["steps"] == warmup + steps, stats["sum"]["steps"]
+    assert stats["last"]["elbo"] == stats["last"]["elbo"], "non-finite ELBO"
+    prof = eng.profile_step(xs[0], eps[0], 1.0, not fixed, iters=100)
+    roof = mlp_roofline(eng, prof, dt / steps, fixed)
+    return {"metric": f"ELBO-steps/sec (batch 128) MNIST {model}", "value": steps / dt, "unit": "ELBO-steps/sec",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
+            "workload": f"MNIST shapes (D=784), model {model}, {'fixed' if fixed else 'learnable'} curvature, "
+                        "MLP h_dim=400, batch 128, epoch>=10 state",
+            "graph_replays": runner.replays,
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms",
+                                              "step_hbm_frac", "step_mfma_frac")}}
 
 
 def main():
@@ -187,13 +329,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--graph-steps", type=int, default=50,
-                    help="steps captured per HIP graph (0 = eager launches)")
+    ap.add_argument("--graph-steps", type=int, default=100,
+                    help="steps captured per HIP graph for timed regions longer than ONE_GRAPH_MAX steps (shorter "
+                         "regions are ONE graph); 0 = eager launches")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed repeats of --steps steps each (value = the median repeat, min / max reported); default: "
+                         "5 when --steps >= 1000 at N = 1 (SURVEY 8d protocol), else 1")
     ap.add_argument("--reset-every", type=int, default=0,
                     help="restore the initial parameters / optimizer state every N steps (0 = never, the default: "
                          "40 000 consecutive learnable-curvature steps on the cycled synthetic batches stay finite); a "
                          "diagnostic for configurations that diverge")
+    ap.add_argument("--no-prewarm", action="store_true",
+                    help="skip the clock / power pre-warm replays in front of a short (one-graph) timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short legs of BASELINE configs[0], [3], [4] reported under `configs`")
     ap.add_argument("--model", type=str, default=MODEL,
                     help="latent space string; the driver's metric is the default (BASELINE configs[1]); "
                          "'e6' = configs[0], '6h2,6s2,6e2' = configs[3]")
@@ -216,11 +366,15 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    def emit(line):
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.close(json_fd)
+
     if args.config == "conv":
         assert torch.cuda.is_available(), "bench.py needs a HIP device"
         if args.steps == 2000 and args.warmup == 200:  # the MLP defaults: a conv step is ~40x longer
             args.steps, args.warmup = 200, 20
-        return bench_conv(args, json_fd)
+        return emit(conv_leg(args.steps, args.warmup, graph=args.graph_steps > 0))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,22 +402,14 @@ def main():
     from mvae_amd.engine import StepEngine
     from mvae_amd.runner import StepRunner
 
-    from mvae_amd.utils import parse_component_str
-    comps = []
-    for tok in args.model.lower().split(","):
-        mult, letter, dim = parse_component_str(tok.strip())
-        comps += [(letter, dim)] * mult
+    comps = parse_model(args.model)
     eng = StepEngine(comps, D, H, dev, radius_trainable=[not args.fixed_curvature] * len(comps), lr=1e-3)
     shapes = [(n, s) for n, _, s in eng.flat.entries]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0))
-    # Every timed step should be a graph replay: when fewer steps are asked for than a default graph holds (the driver's
-    # `--steps 20 --warmup 5`), capture graphs of gcd(steps, warmup) steps instead, so both the warm-up and the timed
-    # region are whole numbers of replays.
-    import math
-    if args.graph_steps > 0 and (args.steps % args.graph_steps or args.warmup % args.graph_steps):
-        g = math.gcd(args.steps, args.warmup) if args.warmup > 0 else args.steps
-        args.graph_steps = max(d for d in range(1, min(g, args.graph_steps) + 1) if g % d == 0)
-    n_data = max(args.graph_steps, 1) * 4  # distinct resident batches, cycled
+    # Every timed step is part of a graph replay; a timed region of up to ONE_GRAPH_MAX steps (the driver's
+    # `--steps 20 --warmup 5`) is ONE graph, the warm-up another.
+    gs, plan = make_plan(args.steps, args.warmup, args.graph_steps)
+    n_data = min(256, args.steps + args.warmup) if plan is not None else max(gs, 1) * 2  # resident batches, cycled
     if args.strong and world > 1:
         from mvae_amd.distributed import shard_rows
         lo, hi = shard_rows(B, rank, world)  # every rank builds the same global batches and keeps its own rows
@@ -274,7 +420,7 @@ def main():
         eps = synthetic.eps_batches(n_data, B, eng.layout.eps_dim, rank=rank).to(dev)
     strong = bool(args.strong and world > 1)
     runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not args.fixed_curvature,
-                        graph_steps=args.graph_steps,
+                        graph_steps=gs, graph_plan=plan,
                         world_size=world, reset_every=args.reset_every, force_exchange=args.force_dp)
 
     if (runner.capture_failed or os.environ.get("MVAE_BENCH_FAKE_CAPTURE_FAILURE")) and world > 1 and \
@@ -295,20 +441,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    repeats = args.repeats if args.repeats > 0 else (5 if (args.steps >= 1000 and world == 1 and plan is None) else 1)
+    prewarm = 0
+    if plan is not None and runner.gs > 0 and not args.no_prewarm:
+        # A short timed region (the driver's 20 steps = 0.65 ms) starts on a device that has been idle since the capture:
+        # the first replays after an idle period run 5-35 % slower than the steady state the metric is about (clock /
+        # power ramp; tools/probe_short_run.py: 44, 33.9, 33.2, ... 32.5 us/step over the first nine 20-step replays).
+        # So the captured timed graph is replayed a few times on a snapshot of the model state, which is restored
+        # before the contractual warm-up; the timed region is untouched (exactly --steps steps, asserted below).
+        keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
+        timed_graph = runner.graphs[args.warmup if args.warmup > 0 else 0][0]
+        while prewarm < 12:
+            timed_graph.replay()
+            torch.cuda.synchronize()
+            prewarm += 1
+        for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
+            dst.copy_(src)
+        sync_all()
     runner.run(args.warmup)
     sync_all()
-    replays_before = runner.replays
-    t0 = time.perf_counter()
-    runner.run(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    graph_replays = runner.replays - replays_before
-    if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    times = []
+    replays_before, gsteps_before = runner.replays, runner.graph_steps_replayed
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        runner.run(args.steps)  # EXACTLY --steps steps per timed region
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    dt = sorted(times)[len(times) // 2]  # the median repeat
+    graph_replays = (runner.replays - replays_before) // repeats
+    graph_steps_replayed = (runner.graph_steps_replayed - gsteps_before) // repeats
     stats = eng.read_stats()
-    assert stats["sum"]["steps"] == args.warmup + args.steps + runner.capture_steps, stats["sum"]["steps"]
+    assert stats["sum"]["steps"] == args.warmup + repeats * args.steps + runner.capture_steps, stats["sum"]["steps"]
     finite = stats["last"]["elbo"] == stats["last"]["elbo"] and abs(stats["last"]["elbo"]) != float("inf")
     assert finite or os.environ.get("MVAE_BENCH_ALLOW_NONFINITE"), "non-finite ELBO"
 
@@ -320,66 +488,7 @@ def main():
 
     # per-launch durations measured live with HIP events on the launch stream (mvae_step_profile)
     prof = eng.profile_step(xs[0], eps[0], 1.0, not args.fixed_curvature, iters=200)
-    alg = algorithmic_per_launch(eng.flat.n_logical_params(), eng.layout.heads_dim, eng.layout.z_dim,
-                                 eng.layout.eps_dim)
-    if prof.get("latent_fwd", 1.0) == 0.0:  # the fused forward: launches 2 + 3 are ONE launch (k_fwd23); hd stays in LDS
-        f4, NHh, Zz = 4.0, eng.layout.heads_dim, eng.layout.z_dim
-        alg["latent_dec1_fwd"] = dict(
-            flops=alg["latent_fwd"]["flops"] + alg["dec1_fwd"]["flops"],
-            bytes=f4 * (B * H + NHh * H + NHh + B * eng.layout.eps_dim + H * Zz + H + D * H + D + 2 * B * D + B * H + B * Zz))
-        prof["latent_dec1_fwd"] = prof.pop("dec1_fwd")
-        del prof["latent_fwd"], alg["latent_fwd"], alg["dec1_fwd"]
-        prof = {k: prof[k] for k in ("enc_fwd", "latent_dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")}
-    # The headline fraction is the WHOLE STEP against the roofline: SURVEY section 8(d)'s algorithmic bytes / flops of one
-    # step (each tensor once: x, eps, and p, m, v, g read + written) over the measured ms_per_step.  `kernel` names the
-    # longest launch -- whatever it is -- with its own numbers; every launch is listed in `per_kernel`.
-    P_log = eng.flat.n_logical_params()
-    step_bytes_8d = 4.0 * (B * D + B * eng.layout.eps_dim + 8 * P_log)
-    step_flops = sum(v["flops"] for v in alg.values())
-    step_s = dt / args.steps
-    step_gbs, step_tf = step_bytes_8d / step_s / 1e9, step_flops / step_s / 1e12
-    dom = max(prof, key=prof.get)
-    dur_s = prof[dom] * 1e-3
-    per_kernel = {k: {"ms": prof[k], "bytes": alg[k]["bytes"], "flops": alg[k]["flops"],
-                      "hbm_frac": alg[k]["bytes"] / (prof[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "mfma_frac": alg[k]["flops"] / (prof[k] * 1e-3) / 1e12 / F32_MFMA_PEAK_TF} for k in prof}
-    traffic, traffic_step, traffic_src = None, None, None
-    import glob
-    # fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, see profiles/README.md):
-    # the newest summary that knows every launch of this step
-    def _order(path):  # r02 (the round's final set) after r02a, r02b (mid-round sets) after r01
-        tag = os.path.basename(path).split("_")[0]
-        digits = "".join(ch for ch in tag[1:] if ch.isdigit())
-        suffix = tag[1 + len(digits):]
-        return (int(digits or 0), 1 if suffix == "" else 0, suffix)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_order, reverse=True):
-        name = os.path.basename(path)
-        try:
-            with open(path) as fh:
-                kern = json.load(fh)["kernels"]
-            names = {"latent_dec1_fwd": "k_fwd23"}
-            traffic = kern[names.get(dom, "k_" + dom)]["traffic_bytes"]
-            traffic_step = sum(kern[names.get(k, "k_" + k)]["traffic_bytes"] for k in prof)
-            traffic_src = "profiles/" + name
-            break
-        except (OSError, KeyError, ValueError):
-            continue
-    if step_gbs / HBM_PEAK_GBS >= step_tf / F32_MFMA_PEAK_TF:
-        roof = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": step_gbs / HBM_PEAK_GBS}
-    else:
-        roof = {"bound": "mfma", "achieved": step_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": step_tf / F32_MFMA_PEAK_TF}
-    roof.update({
-        "scope": "whole step: SURVEY 8(d) bytes 4(BD + B*eps_dim + 8P) and GEMM flops over ms_per_step",
-        "step_bytes": step_bytes_8d, "step_flops": step_flops,
-        "step_hbm_frac": step_gbs / HBM_PEAK_GBS, "step_mfma_frac": step_tf / F32_MFMA_PEAK_TF,
-        "kernel": dom, "kernel_rule": "the longest launch",
-        "kernel_achieved_GBps": alg[dom]["bytes"] / dur_s / 1e9, "kernel_hbm_frac": per_kernel[dom]["hbm_frac"],
-        "kernel_achieved_TFLOPs": alg[dom]["flops"] / dur_s / 1e12, "kernel_mfma_frac": per_kernel[dom]["mfma_frac"],
-        "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_src,
-        "launch_bytes_sum": sum(v["bytes"] for v in alg.values()),
-        "kernel_ms": prof, "per_kernel": per_kernel})
+    roof = mlp_roofline(eng, prof, dt / args.steps, args.fixed_curvature)
 
     line = {
         "metric": f"ELBO-steps/sec (batch 128) MNIST {args.model}",
@@ -402,17 +511,38 @@ def main():
                    "global_batch": B if strong else B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
                    "graph_steps": runner.gs,
                    "graph_replays": graph_replays,
-                   "steps_in_graph_replays": graph_replays * runner.gs,
+                   "steps_in_graph_replays": graph_steps_replayed,
+                   "timed_repeats": repeats,
+                   "prewarm_replays": prewarm,  # of the timed graph, on a snapshot of the state that is restored
+                   "repeat_ms_per_step": {"median": dt / args.steps * 1e3, "min": min(times) / args.steps * 1e3,
+                                          "max": max(times) / args.steps * 1e3},
                    "inputs": "x and eps resident in HBM before the timed region (SURVEY 8d); the device-side gather + "
                              "binarisation + eps draw of mvae_prepare_batch is NOT in the timed step",
                    "state_reset_every": args.reset_every,
                    "final_elbo_per_sample": stats["last"]["elbo"] / xs.shape[1]},
         "roofline": roof,
     }
+    default_workload = args.model == MODEL and not args.fixed_curvature and not args.force_dp
+    if world == 1 and default_workload and not args.no_extra_configs:
+        # the other single-GPU BASELINE configs, short legs on the same box in the same run (configs[0..4])
+        del runner, eng
+        extra = {}
+        for key, fn in (("e6", lambda: mlp_leg("e6", True, 400, 40, dev)),
+                        ("prod36", lambda: mlp_leg("6h2,6s2,6e2", False, 400, 40, dev)),
+                        ("conv", lambda: {k: v for k, v in conv_leg(20, 5).items()
+                                          if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
+                                                   "dtype", "roofline")})):
+            try:
+                extra[key] = fn()
+            except Exception as e:  # noqa: BLE001  (a failing leg must not lose the headline line)
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        extra["e6"].setdefault("baseline_config", "configs[0]: MNIST e6, fixed curvature")
+        extra["prod36"].setdefault("baseline_config", "configs[3]: 6h2,6s2,6e2 (36-dim latent), learnable curvature")
+        extra["conv"].setdefault("baseline_config", "configs[4] on ONE GPU: CIFAR conv h_dim=8192, batch 256")
+        line["configs"] = extra
     if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
         line["cpu_baseline"] = cpu_baseline(model=args.model, fixed=args.fixed_curvature)
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
-    os.close(json_fd)
+    emit(line)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

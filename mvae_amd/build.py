@@ -29,6 +29,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-faile
          "-fgpu-flush-denormals-to-zero", "-freciprocal-math"]
 
 
+def source_hash() -> str:
+    """Fingerprint of the HIP sources the library is built from (sha1 over the .hip units and the headers, in a fixed
+    order).  profiles/*_pmc_traffic.json record it; bench.py only quotes counter summaries of the build it is running."""
+    import hashlib
+    h = hashlib.sha1()
+    for path in DEPS:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def lib_is_fresh(lib: str = LIB) -> bool:
     return os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in DEPS)
 

@@ -627,6 +627,51 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     eps_s[tid >> 3][tid & 7] = (tid & 7) < eps_ld ? epsv : 0.f;
     z_s[tid >> 3][tid & 7] = 0.f;  // columns past Z stay zero (K of the hd tiles is padded to 8)
   }
+  // ---- staging state of waves 4..7 (operands of the hd and logits phases, requested by MV_STAGE_REQUESTS, written to LDS
+  // after the heads barrier).  MV_EARLY_STAGE (default): the requests are issued right after the wave's heads MFMAs, i.e.
+  // once its own phase-1 operands have LANDED, instead of after the heads reduction + barrier: they travel during the
+  // reduction (~1 us earlier) and cannot queue in front of this wave's phase-1 requests.
+  const int lt = tid - 256;  // 0..255 on waves 4..7
+  const int H4 = H >> 2;     // float4 per row of W_logits
+  constexpr int kWl = 13;    // ceil(32 * 128 / 256): rows of up to 512 floats
+  f32x4 wv[kWl];             // native vectors: whole-struct copies of HIP's float4 keep the array in scratch
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x4 dv[4];
+  f32x2 dp[6];
+  const int nd4 = (H * Z) >> 2, nd2 = (H * Z) >> 1;
+  const bool quads = Z == 8 || Z == 4;  // uniform
+  float bdv2[2];
+#define MV_STAGE_REQUESTS()                                                                                           \
+  do {                                                                                                                \
+    /* W_logits rows nt*16 .. nt*16+31 (the second tile repeats the first when the pair is incomplete) */             \
+    _Pragma("unroll") for (int u = 0; u < kWl; ++u) {                                                                 \
+      const int e4 = lt + 256 * u;                                                                                    \
+      const int r = e4 / H4, c4 = e4 - r * H4;                                                                        \
+      const int rr = r < 32 ? r : 0;                                                                                  \
+      const int grow = (rr < 16 || two) ? nt * 16 + rr : nt * 16 + rr - 16;                                           \
+      wv[u] = *reinterpret_cast<const f32x4*>(Wl + (size_t)grow * H + 4 * (r < 32 ? c4 : 0));                         \
+    }                                                                                                                 \
+    /* W_d0 [H][Z] -> wd_s[H][8] (zero-padded columns), b_d0 -> bd_s.  Z == 8 / 4: whole 16-byte vectors; other even  \
+       Z (Z == 6: BASELINE config [0], `e6`): 8-byte pairs, 6 x 256 x 2 floats cover H Z <= 3072 */                   \
+    if (quads) {                                                                                                      \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                 \
+        const int e4 = lt + 256 * u;                                                                                  \
+        dv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nd4 ? e4 : 0));                               \
+      }                                                                                                               \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int u = 0; u < 6; ++u) {                                                                 \
+        const int e2 = lt + 256 * u;                                                                                  \
+        dp[u] = *reinterpret_cast<const f32x2*>(Wd0 + 2 * (size_t)(e2 < nd2 ? e2 : 0));                               \
+      }                                                                                                               \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                   \
+      const int c = lt + 256 * u;                                                                                     \
+      bdv2[u] = bd0[c < H ? c : 0];                                                                                   \
+    }                                                                                                                 \
+  } while (0)
+#ifndef MV_EARLY_STAGE
+#define MV_EARLY_STAGE 1
+#endif
   // ---- heads = h W_heads^T + b
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -638,6 +683,13 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       acc = mfma16(ha[gq].z, hb[gq].z, acc);
       acc2 = mfma16(ha[gq].w, hb[gq].w, acc2);
     }
+#if MV_EARLY_STAGE
+    if (wave >= 4 && !is_dual) {  // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);
+      MV_STAGE_REQUESTS();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     MV_T(1);
     const float sv = reduce_tiles8(red, acc + acc2);
     MV_T(2);
@@ -672,14 +724,22 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
         base += nd;
       }
       const mvae_component_desc c = t.c[mine];
-      float zd[AM];
-      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
+      float zd[AM], klv;
+      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd, &klv);
       float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + t.first_dir[mine] + mydir) * DS;
       const int A = ambient_dim(c.kind, c.true_dim);
       rec[0] = kld;
 #pragma unroll
       for (int q2 = 0; q2 < AM; ++q2)
         if (q2 < A) rec[1 + q2] = zd[q2];
+      // The KL term of (row, component) is the value part of the same evaluation: the lane of direction 0 writes it.
+      // The tile workgroups therefore stop their component chain at z -- the KL half of the chain (logdet, the inverse
+      // sample projection, the normal terms) was ~half of the dependent chain every one of them waited for.
+      if (mydir == 0) {
+        const size_t row = (size_t)mt * 16 + r;
+        kl[(size_t)mine * B + row] = klv;
+        if (kl_user) kl_user[(size_t)mine * B + row] = klv;
+      }
     }
     MV_SPAN_END(2, 2);
     return;
@@ -696,55 +756,15 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   if (wave < 4) {
     const int r = lane & 15;
     if (my_ci >= 0) {
-      float klv;
       const size_t row = (size_t)mt * 16 + r;
-      comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, &klv, nullptr,
+      // z only: the KL term is written by the dual workgroup of the row block (value part of its dual evaluation)
+      comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, nullptr, nullptr,
                          nullptr, nullptr, nullptr);
-      if (lead) {
-        kl[(size_t)my_ci * B + row] = klv;
-        if (kl_user) kl_user[(size_t)my_ci * B + row] = klv;
-      }
     }
   } else {
-    const int lt = tid - 256;  // 0..255
-    const int H4 = H >> 2;     // float4 per row of W_logits
-    // W_logits rows nt*16 .. nt*16+31 (the second tile repeats the first when the pair is incomplete)
-    constexpr int kWl = 13;  // ceil(32 * 128 / 256): rows of up to 512 floats
-    f32x4 wv[kWl];  // native vectors: whole-struct copies of HIP's float4 keep the array in scratch
-#pragma unroll
-    for (int u = 0; u < kWl; ++u) {
-      const int e4 = lt + 256 * u;
-      const int r = e4 / H4, c4 = e4 - r * H4;
-      const int rr = r < 32 ? r : 0;
-      const int grow = (rr < 16 || two) ? nt * 16 + rr : nt * 16 + rr - 16;
-      wv[u] = *reinterpret_cast<const f32x4*>(Wl + (size_t)grow * H + 4 * (r < 32 ? c4 : 0));
-    }
-    // W_d0 [H][Z] -> wd_s[H][8] (zero-padded columns), b_d0 -> bd_s.  Z == 8 / 4: whole 16-byte vectors; other even Z
-    // (Z == 6: BASELINE config [0], `e6`): 8-byte pairs, 4 x 256 x 2 floats cover H Z <= 2048 ... 512 * 6 needs 6
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x4 dv[4];
-    f32x2 dp[6];
-    const int nd4 = (H * Z) >> 2, nd2 = (H * Z) >> 1;
-    const bool quads = Z == 8 || Z == 4;  // uniform
-    if (quads) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e4 = lt + 256 * u;
-        dv[u] = *reinterpret_cast<const f32x4*>(Wd0 + 4 * (size_t)(e4 < nd4 ? e4 : 0));
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int e2 = lt + 256 * u;
-        dp[u] = *reinterpret_cast<const f32x2*>(Wd0 + 2 * (size_t)(e2 < nd2 ? e2 : 0));
-      }
-    }
-    float bdv2[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = lt + 256 * u;
-      bdv2[u] = bd0[c < H ? c : 0];
-    }
+#if !MV_EARLY_STAGE
+    MV_STAGE_REQUESTS();
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < kWl; ++u) {
@@ -878,6 +898,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   MV_TFLUSH(24, 8, 96);
   MV_SPAN_END(2, 1);
 }
+#undef MV_STAGE_REQUESTS
 
 // Forward-mode dual records of the latent components (d kl / d dir and d z / d dir for every input direction of every
 // (row, component)), one thread per record: what waves 4..7 of k_latent_fwd produce in the six-launch step.  In the
@@ -1812,7 +1833,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LF3(DM)                                                                                                      \
   STEP_LAUNCH((k_fwd3m<DM>), dim3(n_dual3 + ((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, c->t, c->gt, heads,       \
               c->ldh, eps, d.eps_dim, P + d.off_radii, NH, duals, n_dual3, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0, \
-              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z)
+              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z, klw, kl)
     if (bk == 2) { LF3(2); } else if (bk == 4) { LF3(4); } else { LF3(8); }
 #undef LF3
   } else {

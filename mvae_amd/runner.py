@@ -29,21 +29,34 @@ def _clear_hip_error() -> None:
 class StepRunner:
 
     def __init__(self, eng: StepEngine, xs: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False,
-                 graph_steps: int = 0, world_size: int = 1, reset_every: int = 0, force_exchange: bool = False):
+                 graph_steps: int = 0, world_size: int = 1, reset_every: int = 0, force_exchange: bool = False,
+                 graph_plan: Optional[List[int]] = None):
+        """graph_steps > 0: the resident batches are captured as graphs of `graph_steps` consecutive steps each.
+        graph_plan = [n0, n1, ...] instead captures ONE graph per span of n_i
+        consecutive steps (the batches cycled), so that run(n_i) issued at the start of span i is a single replay (bench.py: one graph for the
+        warm-up, one for the timed region).  A plan may be longer than the resident set: batches are cycled."""
         assert xs.shape[0] == eps.shape[0] and xs.shape[0] >= 1
         self.eng, self.xs, self.eps = eng, xs, eps
         self.beta, self.do_curv = float(beta), bool(do_curvature_step)
         self.world = int(world_size)
         self.n_data = xs.shape[0]
         self.gs = int(graph_steps)
+        self.plan = [int(n) for n in graph_plan] if graph_plan else None
+        if self.plan is not None:
+            if min(self.plan) < 1:
+                raise ValueError("graph_plan entries must be >= 1")
+            self.gs = max(self.plan)
+        # positions of one cycle of run(); position q steps on resident batch q % n_data
+        self.period = sum(self.plan) if self.plan is not None else self.n_data
         self.cursor = 0  # index of the next resident batch
         self.reset_every = int(reset_every)
         self.since_reset = 0
         self.capture_steps = 0  # steps executed while warming up / capturing (they only touch the statistics)
         self.capture_failed = False
         self.replays = 0  # graph replays issued by run()
+        self.graph_steps_replayed = 0  # steps those replays held
         self._snapshot = None
-        self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.graphs: dict = {}  # first resident batch of a span -> (graph, number of steps)
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
         if self.gs > 0 and self.dp is not None and self.dp.world > 1:
             import torch.distributed as dist
@@ -52,7 +65,7 @@ class StepRunner:
                 # the process in an unusable capture state, so it is not even attempted
                 self.gs = 0
         if self.gs > 0:
-            if self.n_data % self.gs != 0:
+            if self.plan is None and self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
             failed = False
             try:
@@ -71,7 +84,7 @@ class StepRunner:
             # ranks must take the SAME route afterwards, or one replays graphs / re-execs while its peers wait in an
             # eager all-reduce.  The outcome is agreed through the rendezvous store: if any rank failed, all go eager.
             if self.dp is not None and agree_any(failed, self.dp.group, "steprunner-capture"):
-                self.graphs = []
+                self.graphs = {}
                 self.gs = 0
                 self.capture_failed = True  # identical on every rank; callers that can start over without graphs
                 torch.cuda.synchronize()
@@ -101,12 +114,15 @@ class StepRunner:
                     self._one(i)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            for gi in range(self.n_data // self.gs):
+            spans = self.plan if self.plan is not None else [self.gs] * (self.n_data // self.gs)
+            start = 0
+            for n in spans:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
-                    for i in range(gi * self.gs, (gi + 1) * self.gs):
-                        self._one(i)
-                self.graphs.append(g)
+                    for i in range(start, start + n):
+                        self._one(i % self.n_data)
+                self.graphs[start] = (g, n)
+                start += n
             torch.cuda.synchronize()
         finally:  # capturing (or failing to) must have no net effect on the model
             for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
@@ -126,15 +142,17 @@ class StepRunner:
                 for dst, src in zip(self._state(), self._snapshot):
                     dst.copy_(src)
                 self.since_reset = 0
-            if self.gs > 0 and self.cursor % self.gs == 0 and left >= self.gs:
-                self.graphs[self.cursor // self.gs].replay()
+            span = self.graphs.get(self.cursor) if self.gs > 0 else None
+            if span is not None and left >= span[1]:
+                span[0].replay()
                 self.replays += 1
-                self.cursor = (self.cursor + self.gs) % self.n_data
-                left -= self.gs
-                self.since_reset += self.gs
+                self.graph_steps_replayed += span[1]
+                self.cursor = (self.cursor + span[1]) % self.period
+                left -= span[1]
+                self.since_reset += span[1]
             else:
-                self._one(self.cursor)
-                self.cursor = (self.cursor + 1) % self.n_data
+                self._one(self.cursor % self.n_data)
+                self.cursor = (self.cursor + 1) % self.period
                 left -= 1
                 self.since_reset += 1
 

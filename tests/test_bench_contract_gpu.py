@@ -47,13 +47,19 @@ def test_bench_line_schema():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     assert r["kernel"] in r["kernel_ms"] and set(r["per_kernel"]) == set(r["kernel_ms"])
     assert d["value"] > 1000  # steps/s: a silent eager fallback would be two orders of magnitude below the HIP path
+    assert d["config"]["graph_replays"] == 1 and d["config"]["steps_in_graph_replays"] == 300  # ONE replay is timed
+    # the other single-GPU BASELINE configs ride in the same line (configs[0..4])
+    for key in ("e6", "prod36", "conv"):
+        leg = d["configs"][key]
+        assert "error" not in leg, leg
+        assert leg["value"] > 100 and leg["ms_per_step"] > 0 and 0 < leg["roofline"]["frac"] < 1, leg
 
 
 def test_bench_forced_exchange_route():
     """The data-parallel route (gradients -> RCCL all-reduce -> k_optim) inside HIP graphs, at world size 1."""
     d = _run("--no-cpu-baseline", "--force-dp")
     assert "forced exchange" in d["config"]["parallelism"]
-    # 50 steps per graph; 0 = bench.py's documented fallback when the capture of the RCCL collective is invalidated by
-    # the process group's watchdog thread (rare, nondeterministic: DESIGN.md section 6) -- the line is still valid
-    assert d["config"]["graph_steps"] in (50, 0)
+    # the 300 timed steps are ONE graph; 0 = bench.py's documented fallback when the capture of the RCCL collective is
+    # invalidated by the process group's watchdog thread (rare, nondeterministic: DESIGN.md section 6) -- the line is still valid
+    assert d["config"]["graph_steps"] in (300, 0)
     assert d["value"] > 1000

@@ -4,6 +4,8 @@ import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mvae_amd.build import source_hash  # noqa: E402
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -75,6 +77,7 @@ if fetch and write:
                       "reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE taken as is "
                       "(uncalibrated per the guide). Both count L2<->fabric traffic, Infinity-Cache hits included, so "
                       "this is an upper bound on HBM bytes (the whole working set is ~12 MB and MALL-resident).",
+        "source_hash": source_hash(),  # bench.py refuses this summary once the kernels' sources change
         "kernels": kernels}
     with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
