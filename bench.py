@@ -384,9 +384,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        # MVAE_BENCH_BACKEND=gloo + MVAE_BENCH_ONE_DEVICE=1: a dry run of the N > 1 flow on a single-GPU box (all
-        # ranks on cuda:0, the exchange through the host; the step then runs un-captured).  Not a measurement.
-        backend = os.environ.get("MVAE_BENCH_BACKEND", "nccl")
+        # The process group is the HOST-side channel only (rendezvous, the RCCL communicator id, barriers): gloo.  The
+        # gradients are all-reduced by librccl directly on the step's streams (mvae_amd/rccl.py), captured into the
+        # graphs; no ProcessGroupNCCL / watchdog thread exists.  MVAE_BENCH_BACKEND=nccl + MVAE_DP_EXCHANGE=allreduce
+        # selects torch.distributed's own RCCL route instead.  MVAE_BENCH_ONE_DEVICE=1: a dry run of the N > 1 flow on
+        # a single-GPU box (all ranks on cuda:0, the exchange through gloo or the peer routes).  Not a measurement.
+        backend = os.environ.get("MVAE_BENCH_BACKEND", "gloo")
         if os.environ.get("MVAE_BENCH_ONE_DEVICE"):
             local_rank = 0
         torch.cuda.set_device(local_rank)
@@ -468,7 +471,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         if dist_on:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
@@ -480,6 +483,21 @@ def main():
     finite = stats["last"]["elbo"] == stats["last"]["elbo"] and abs(stats["last"]["elbo"]) != float("inf")
     assert finite or os.environ.get("MVAE_BENCH_ALLOW_NONFINITE"), "non-finite ELBO"
 
+    ranks_identical, peer_timeouts = None, None
+    if dist_on:
+        # the replicas must hold the same parameters after the run (the exchange is the only thing keeping them equal),
+        # and a peer route must not have given up a single wait: host-side checks, after the timed region
+        import hashlib
+        digest = hashlib.sha1(eng.params.cpu().numpy().tobytes()).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
+        ranks_identical = all(d_ == digests[0] for d_ in digests)
+        assert ranks_identical, f"the ranks' parameters differ after the run: {digests}"
+        if runner.dp is not None and runner.dp.peer is not None:
+            tmo = [None] * world
+            dist.all_gather_object(tmo, runner.dp.peer.timeouts())
+            peer_timeouts = int(sum(tmo))
+            assert peer_timeouts == 0, f"peer exchange: waits timed out per rank {tmo}"
     if rank != 0:
         if dist_on:  # leave together with rank 0 (which still profiles the launches): no rank tears the group down early
             dist.barrier()
@@ -509,6 +527,8 @@ def main():
                                "MLP h_dim=400, " + ("global batch 128 split by rows" if strong else "batch 128 per GPU") +
                                ", epoch>=10 state",
                    "global_batch": B if strong else B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
+                   "exchange": (runner.dp.exchange if runner.dp is not None else "none (fused optimizer epilogues)"),
+                   "ranks_identical": ranks_identical, "peer_timeouts": peer_timeouts,
                    "graph_steps": runner.gs,
                    "graph_replays": graph_replays,
                    "steps_in_graph_replays": graph_steps_replayed,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 5
+#define MVAE_ABI_VERSION 6
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -437,8 +437,13 @@ int mvae_step_profile(mvae_ctx* ctx, const float* x, const float* eps, float bet
  * into row slices and finish with "add the slices in index order".  Between mvae_slice_sums_defer(1) and
  * mvae_slice_sums_flush(stream) they only write their slices and QUEUE that final sum; the flush performs all queued sums
  * (same order of additions, hence the same bits) in ONE launch -- in the conv backward pass that replaces ~13 launches
- * whose outputs nobody reads before the optimizer.  The caller keeps every workspace alive until the flush.  State is
- * per calling thread and host-side only (graph-capturable); a full queue (24 entries) flushes itself. */
+ * whose outputs nobody reads before the optimizer; the tall column sums (mvae_colsum with M > 512 rows, 16-byte aligned,
+ * N % 4 == 0) are queued as a whole and performed by one more launch at the flush.  The caller keeps every workspace --
+ * and the INPUT of every queued mvae_colsum -- alive until the flush.  State is
+ * per calling thread and host-side only (graph-capturable); a full queue (24 entries) flushes itself.
+ * on = 1: defer (a queue left over from an aborted pass is dropped when deferral is switched on); on = 2: suspend --
+ * sums requested now run immediately, the queue is kept (for an intermediate result read before the flush; switch back
+ * with 1); on = 0: off, anything still queued is DROPPED. */
 int mvae_slice_sums_defer(int on);
 int mvae_slice_sums_flush(void* stream);
 
@@ -475,6 +480,27 @@ int mvae_peer_publish(mvae_peer* peer, const float* grads, void* stream);
 int mvae_peer_set_two_shot(mvae_peer* peer, int on);
 int mvae_step_optimizer_peer(mvae_ctx* ctx, mvae_peer* peer, int do_curvature_step, void* stream);
 int mvae_peer_timeouts(mvae_peer* peer);
+
+/* ---- Flat all-reduce on librccl directly (data-parallel training; new functionality -- the reference is single-device,
+ * SURVEY.md section 8b names this export).  One process per GPU; the SUM of the flat gradient buffer is the ONE exchange
+ * of a data-parallel step (the loss is a batch sum: mt/mvae/stats.py:200-202, vae.py:158).
+ *   rank 0: mvae_rccl_unique_id(id) -> the host layer hands the 128 bytes to every rank (any side channel: the c10d store)
+ *   all:    mvae_rccl_create(id, rank, world, &comm)            (collective: ncclCommInitRank)
+ *   per step, on `stream`: mvae_step_forward_backward(...) -> mvae_flat_allreduce(comm, grads, n_params, stream)
+ *                          -> mvae_step_optimizer(...)
+ * ncclAllReduce is enqueued on the caller's stream: ordered with the step's launches and captured into HIP graphs like
+ * them -- no torch ProcessGroupNCCL (and no watchdog thread polling events from another thread) exists on this route.
+ * librccl is dlopen'ed on first use (mvae_rccl_load(path): an explicit path, else the copy already mapped into the
+ * process, else the system's); single-GPU use never touches it. */
+#define MVAE_RCCL_ID_BYTES 128
+typedef struct mvae_rccl mvae_rccl;
+int mvae_rccl_load(const char* path);
+int mvae_rccl_unique_id(uint8_t id[MVAE_RCCL_ID_BYTES]);
+int mvae_rccl_create(const uint8_t id[MVAE_RCCL_ID_BYTES], int rank, int world, mvae_rccl** out);
+void mvae_rccl_destroy(mvae_rccl* comm);
+int mvae_flat_allreduce(mvae_rccl* comm, float* buf, int64_t n, void* stream);
+int mvae_flat_broadcast(mvae_rccl* comm, void* buf, int64_t n_words, int root, void* stream);
+int mvae_rccl_group(int begin);
 
 /* Which kernels the latent part of the step takes for this context's shapes (a measurement / test aid; the result
  * of the step does not depend on it beyond float32 summation order):

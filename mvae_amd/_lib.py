@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -115,6 +115,13 @@ PROTOTYPES = {
     "mvae_step_optimizer_peer": (C.c_int, [_P, _P, _I, _P]),
     "mvae_peer_timeouts": (C.c_int, [_P]),
     "mvae_step_profile": (C.c_int, [_P, _P, _P, _F, _I, _I, C.POINTER(C.c_float), _P]),
+    "mvae_rccl_load": (C.c_int, [C.c_char_p]),
+    "mvae_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "mvae_rccl_create": (C.c_int, [C.POINTER(C.c_uint8), _I, _I, C.POINTER(C.c_void_p)]),
+    "mvae_rccl_destroy": (None, [C.c_void_p]),
+    "mvae_flat_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mvae_flat_broadcast": (C.c_int, [_P, _P, C.c_int64, _I, _P]),
+    "mvae_rccl_group": (C.c_int, [_I]),
 }
 
 _lib: Optional[C.CDLL] = None

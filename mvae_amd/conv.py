@@ -196,6 +196,8 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
     assert out.is_contiguous() and out.numel() == G.shape[1]
     nws = load().mvae_colsum_workspace_floats(G.shape[0], G.shape[1])
     ws = _keep(G.new_empty(int(nws))) if nws > 0 else None
+    if nws > 0:
+        _keep(G)  # while deferral is on the column sum itself is queued: its input lives until the flush
     check(load().mvae_colsum(ptr(G), ptr(out), G.shape[0], G.shape[1], ptr(ws), stream_ptr(G.device)))
     return out
 
@@ -407,7 +409,11 @@ class ConvEngine:
         _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
         # d3.bias gradient = sum over (b, y, x) of g[b, c, y, x]: column sums over the batch first ([B, 3072] -> [3072]),
         # then the 1024 pixels of each channel -- instead of permuting the whole gradient to [B * 1024, 3]
+        # (an INTERMEDIATE: read two lines below, so its slice sum -- B > 512 rows are summed in slices -- must not wait
+        # for the flush: deferral is suspended around it)
+        check(load().mvae_slice_sums_defer(2))
         gpix = _colsum(g.view(B, 3072))
+        check(load().mvae_slice_sums_defer(1))
         _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
         db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices

@@ -46,6 +46,94 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float* x, const float*
   job_colsum(&red[0][0][0], dy, N, M, N, b * kColsPerBlock, db);
 }
 
+// Linear backward with FEW outputs and a WIDE input (the conv architecture's heads: dy [B, NH <= 16], x = the 8192-wide
+// flatten): one pass over x.  Workgroup = 32 columns of K (256 workgroups for K = 8192); thread (row group g = tid >> 3,
+// column quad c = tid & 7) walks rows g, g + 32, ... of every 256-row chunk: one 16-byte load of x feeds
+// dW[:, quad] += dy[m][:] x[m][quad] (registers) and dx[m][quad] = (dy[m][:] W[:, quad]) [x > 0] (stored at once); the 32
+// row groups' dW partials meet in LDS and are added in group order.  The last workgroup adds up the bias gradient.
+// (As 16 x 16 tiles this was 8192 + 512 workgroups.)
+constexpr int kSknN = 16;
+template <int NN>  // NN = N rounded up to a multiple of 4
+__global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const float* W, const float* dy, float* dW,
+                                                        float* db, float* dx, int M, int N, int K, int relu_in) {
+  __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
+  __shared__ f32x4 sm[32][9];
+  const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
+  if ((int)blockIdx.x == K / 32) {  // db[n] = sum_m dy[m][n]
+    const int cn = tid & 15, gn = tid >> 4;
+    float s = 0.f;
+    if (cn < N)
+      for (int m = gn; m < M; m += 16) s += dy[(size_t)m * N + cn];
+    float* sf = reinterpret_cast<float*>(&sm[0][0]);
+    sf[gn * 17 + cn] = s;
+    __syncthreads();
+    if (gn == 0 && cn < N) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += sf[q * 17 + cn];
+      db[cn] = t;
+    }
+    return;
+  }
+  const int col = (int)blockIdx.x * 32 + c * 4;
+  f32x4 wr[NN], acc[NN];
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    wr[n] = *reinterpret_cast<const f32x4*>(W + (size_t)(n < N ? n : 0) * K + col);
+    if (n >= N) wr[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int m0 = 0; m0 < M; m0 += 256) {
+    const int rows = (M - m0) < 256 ? (M - m0) : 256;
+    __syncthreads();
+    for (int e = tid; e < 256 * NN; e += 256) {
+      const int r = e / NN, n = e - r * NN;
+      dy_s[r][n] = (r < rows && n < N) ? dy[(size_t)(m0 + r) * N + n] : 0.f;
+    }
+    __syncthreads();
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = g + 32 * u;
+      xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + (r < rows ? r : 0)) * K + col);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = g + 32 * u;
+      if (r >= rows) continue;
+      f32x4 dxv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n4 = 0; n4 < NN; n4 += 4) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dy_s[r][n4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[n4 + j] += d[j] * xv[u];
+          dxv += d[j] * wr[n4 + j];
+        }
+      }
+      if (dx) {
+        if (relu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dxv[j] = (xv[u][j] > 0.f) ? dxv[j] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dx + (size_t)(m0 + r) * K + col) = dxv;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    if (n >= N) break;
+    __syncthreads();
+    sm[g][c] = acc[n];
+    __syncthreads();
+    if (g == 0) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 32; ++q) t += sm[q][c];
+      *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col) = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ primitives (API)
 // Every primitive is ONE register-level template over the scalar type (prim_eval): T = float is the forward kernel,
 // T = Dual the backward kernel (one thread per (row, input entry) evaluates the primitive along that input direction
@@ -673,6 +761,16 @@ extern "C" int mvae_linear_backward(const float* x, const float* W, const float*
                                     float* dx, int64_t M, int N, int K, void* stream) {
   if (!x || !W || !dy || !dW || !db || M < 1 || N < 1 || K < 1)
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (N <= kSknN && K >= 1024 && (K & 63) == 0 && M >= 64 && M <= 0x7fffffff &&
+      ((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)dW) | ((uintptr_t)dx)) & 15) == 0) {
+#define MV_SKN(NN_)                                                                                                  \
+  hipLaunchKernelGGL(k_linear_bwd_skn<NN_>, dim3(K / 32 + 1), dim3(256), 0, (hipStream_t)stream, x, W, dy, dW, db, dx, \
+                     (int)M, N, K, relu_in)
+    if (N <= 4) MV_SKN(4); else if (N <= 8) MV_SKN(8); else if (N <= 12) MV_SKN(12); else MV_SKN(16);
+#undef MV_SKN
+    LAUNCH_CHECK("skinny linear backward launch");
+    return 0;
+  }
   const int ntN = (N + 15) / 16, ntK = (K + 15) / 16, ntM = (int)((M + 15) / 16);
   const int n_dx = dx ? ntM * ntK : 0, n_dw = ntN * ntK, n_db = (N + kColsPerBlock - 1) / kColsPerBlock;
   hipLaunchKernelGGL(k_linear_bwd, dim3(n_dx + n_dw + n_db), dim3(256), 0, (hipStream_t)stream, x, W, dy, dW, db, dx,

@@ -261,8 +261,7 @@ __device__ __forceinline__ void comp_fwd_row(const mvae_component_desc& c, const
 // backward kernel runs it while dz is still being reduced.
 template <int DMAX>
 __device__ __forceinline__ float comp_dual_dir(const mvae_component_desc& c, const float* heads_row,
-                                               const float* eps_row, const float* radii, int dir, float* zd,
-                                               float* kl_primal = nullptr) {
+                                               const float* eps_row, const float* radii, int dir, float* zd) {
   MV_BOUNDS(DMAX + 1);
   Dual m[kN], l[kN], z[kN];
   float e[kN];
@@ -277,7 +276,6 @@ __device__ __forceinline__ float comp_dual_dir(const mvae_component_desc& c, con
   comp_eval<DMAX, Dual>(c.kind, m, l, lvd, e, d, rp, z, &kl, nullptr, nullptr, nullptr, nullptr);
   const int A = ambient_dim(c.kind, d);
   MV_FOR(i, 0, A) zd[i] = z[i].d;
-  if (kl_primal) *kl_primal = kl.v;  // the value part of the dual evaluation IS the component's KL term
   return kl.d;
 }
 

@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* ou
 // performs every queued sum in ONE launch.  In the conv step these sums are ~13 launches of ~5 us each whose outputs
 // nobody reads before the optimizer.  Host-side state, per calling thread; nothing here synchronises.
 constexpr int kMaxSumJobs = 24;
+constexpr int kColSlice = 512;  // rows per slice of the tall column sums (mvae_colsum)
 struct SumJobs {
   const float* part[kMaxSumJobs];
   float* out[kMaxSumJobs];
@@ -654,9 +655,13 @@ struct SumJobs {
 };
 static thread_local SumJobs g_sums;
 static thread_local bool g_defer = false;
+static thread_local bool g_suspended = false;  // deferral paused (mvae_slice_sums_defer(2)): immediate sums, queue kept
 
+// One workgroup owns 64 lanes x (4 | 1) consecutive outputs of one job; its four waves take the slices k = w, w + 4, ...
+// (8 requests in flight per lane: 16-byte ones when the job's n is a multiple of 4 and its pointers are 16-byte aligned),
+// the four partial sums meet in LDS and are added in wave order -- the same additions in the same order as k_sum_slices.
 __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
-  __shared__ float sm[4][64];
+  __shared__ f32x4 sm[4][64];
   int j = 0;
   while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
   const float* part = jobs.part[j];
@@ -665,6 +670,33 @@ __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
   const int slices = jobs.slices[j];
   const int nblk = jobs.blk0[j + 1] - jobs.blk0[j];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool vec = (n & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0;  // uniform
+  if (vec) {
+    const long long n4 = n >> 2;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+    for (long long base = (long long)((int)blockIdx.x - jobs.blk0[j]) * 64; base < n4; base += (long long)nblk * 64) {
+      const long long i = base + lane;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      if (i < n4) {
+        int k = w;
+        for (; k + 28 < slices; k += 32) {
+          f32x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = p4[(size_t)(k + 4 * u) * n4 + i];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < slices; k += 4) s += p4[(size_t)k * n4 + i];
+      }
+      sm[w][lane] = s;
+      __syncthreads();
+      if (w == 0 && i < n4)
+        reinterpret_cast<f32x4*>(out)[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+      __syncthreads();
+    }
+    return;
+  }
+  float* sms = reinterpret_cast<float*>(&sm[0][0]);  // [4][64] floats
   for (long long base = (long long)((int)blockIdx.x - jobs.blk0[j]) * 64; base < n; base += (long long)nblk * 64) {
     const long long i = base + lane;
     float s = 0.f;
@@ -679,14 +711,68 @@ __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
       }
       for (; k < slices; k += 4) s += part[(size_t)k * n + i];
     }
-    sm[w][lane] = s;
+    sms[w * 64 + lane] = s;
     __syncthreads();
-    if (w == 0 && i < n) out[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);  // same order as k_sum_slices
+    if (w == 0 && i < n) out[i] = (sms[lane] + sms[64 + lane]) + (sms[128 + lane] + sms[192 + lane]);  // same order as k_sum_slices
     __syncthreads();
   }
 }
 
+// Deferred column sums of tall matrices (bias gradients of the conv layers: 5 per backward pass, each its own ~5 us launch
+// of 256-512 workgroups before): queued like the slice sums and performed by ONE launch at the flush, ahead of the batched
+// slice sums that add their slice totals.  Thread (row group g = tid >> 4, column quad c = tid & 15) adds rows g, g + 16,
+// ... of its 512-row slice, 8 requests of 16 bytes in flight; the 16 row groups meet in LDS and are added in group order:
+// per column the same additions in the same order as k_colsum_sliced.
+constexpr int kMaxColJobs = 12;
+struct ColJobs {
+  const float* G[kMaxColJobs];
+  float* part[kMaxColJobs];
+  int M[kMaxColJobs], N[kMaxColJobs], ncb[kMaxColJobs];
+  int blk0[kMaxColJobs + 1];
+  int njobs;
+};
+static thread_local ColJobs g_cols;
+
+__global__ __launch_bounds__(256) void k_colsum_batched(ColJobs jobs) {
+  __shared__ f32x4 sm[16][17];
+  int j = 0;
+  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
+  const int b = (int)blockIdx.x - jobs.blk0[j];
+  const int ncb = jobs.ncb[j], N = jobs.N[j], M = jobs.M[j];
+  const int slice = b / ncb, cb = b - slice * ncb;
+  const int m0 = slice * kColSlice;
+  const int rows = (M - m0) < kColSlice ? (M - m0) : kColSlice;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int col = cb * 64 + c * 4;
+  const bool act = col < N;
+  const float* base = jobs.G[j] + (size_t)m0 * N + (act ? col : 0);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int m = g; m < rows; m += 16 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int mm = m + 16 * u;
+      v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(mm < rows ? mm : 0) * N);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (m + 16 * u < rows) s += v[u];
+  }
+  sm[g][c] = s;
+  __syncthreads();
+  if (g == 0 && act) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 16; ++q) t += sm[q][c];
+    *reinterpret_cast<f32x4*>(jobs.part[j] + (size_t)slice * N + col) = t;
+  }
+}
+
 static void flush_sums(hipStream_t s) {
+  if (g_cols.njobs > 0) {  // the slice totals the queued sums below add up
+    hipLaunchKernelGGL(k_colsum_batched, dim3((unsigned)g_cols.blk0[g_cols.njobs]), dim3(256), 0, s, g_cols);
+    g_cols.njobs = 0;
+  }
   if (g_sums.njobs == 0) return;
   hipLaunchKernelGGL(k_sum_slices_batched, dim3((unsigned)g_sums.blk0[g_sums.njobs]), dim3(256), 0, s, g_sums);
   g_sums.njobs = 0;
@@ -705,12 +791,28 @@ static void sum_slices(const float* part, float* out, int64_t n, int slices, hip
   g_sums.out[j] = out;
   g_sums.n[j] = n;
   g_sums.slices[j] = slices;
-  const long long want = (n + 63) / 64;
-  g_sums.blk0[j + 1] = g_sums.blk0[j] + (int)(want < 256 ? want : 256);
+  const bool vec = (n & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0;
+  const long long want = vec ? (n / 4 + 63) / 64 : (n + 63) / 64;
+  g_sums.blk0[j + 1] = g_sums.blk0[j] + (int)(want < 1024 ? want : 1024);
 }
 
+// on = 1: queue the final sums (a queue left behind by an aborted pass is dropped when deferral is switched on);
+// on = 2: SUSPEND -- sums requested now are performed immediately, the queue is kept (for an intermediate result that is
+//         read before the flush); on = 0: off, and anything still queued is DROPPED (the normal path has flushed; after an
+//         exception the queued outputs / workspaces may be gone, so the stale jobs must not run with the next pass).
 extern "C" int mvae_slice_sums_defer(int on) {
-  g_defer = on != 0;
+  if (on == 1) {
+    if (!g_defer && !g_suspended) g_sums.njobs = g_cols.njobs = 0;
+    g_defer = true;
+    g_suspended = false;
+  } else if (on == 2) {
+    g_suspended = g_defer || g_suspended;
+    g_defer = false;
+  } else {
+    g_defer = false;
+    g_suspended = false;
+    g_sums.njobs = g_cols.njobs = 0;
+  }
   return 0;
 }
 
@@ -766,7 +868,8 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
 
 // ---- implicit contractions of the channel-last k4 s2 p1 convolutions (no patch matrix in memory)
 static int conv_geom(ConvGeom* g, int B, int Cc, int IH, int IW) {
-  if (B < 1 || Cc < 32 || (Cc & 31) || IH < 2 || IW < 2 || (IH & (IH - 1)) || (IW & (IW - 1)))
+  constexpr int kStep = kBK64 > kBK128 ? kBK64 : kBK128;  // a K step must lie inside one tap
+  if (B < 1 || Cc < kStep || (Cc % kStep) || IH < 2 || IW < 2 || (IH & (IH - 1)) || (IW & (IW - 1)))
     return fail(MVAE_E_UNSUPPORTED, "implicit conv needs C %% 32 == 0 and power-of-two extents%s (%lld)", "", Cc);
   int lOW = 0, lOH = 0;
   while ((1 << lOW) < IW / 2) ++lOW;
@@ -936,7 +1039,6 @@ extern "C" int mvae_linear_forward_splitk(const float* x, const float* W, const 
 
 // tall matrices (conv activations: up to 65536 rows): row slices of kColSlice are summed by separate workgroups, the
 // slice totals are then added in index order
-constexpr int kColSlice = 512;
 __global__ __launch_bounds__(256) void k_colsum_sliced(const float* G, float* part, int M, int N, int ncb) {
   __shared__ float lds[32 * 17 + 2];
   const int slice = blockIdx.x / ncb, cb = blockIdx.x % ncb;
@@ -958,8 +1060,21 @@ extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* 
   } else {
     if (!workspace) return fail(MVAE_E_BADARG, "mvae_colsum needs a workspace for M > 512%s", "");
     const int slices = (int)((M + kColSlice - 1) / kColSlice);
-    hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
-                       workspace, (int)M, N, ncb);
+    if (g_defer && (N & 3) == 0 && ((((uintptr_t)G) | ((uintptr_t)workspace)) & 15) == 0 && M <= 0x7fffffff) {
+      // queued: the caller keeps G (and the workspace) alive until the flush
+      if (g_cols.njobs == kMaxColJobs) flush_sums((hipStream_t)stream);
+      const int j = g_cols.njobs++;
+      if (j == 0) g_cols.blk0[0] = 0;
+      g_cols.G[j] = G;
+      g_cols.part[j] = workspace;
+      g_cols.M[j] = (int)M;
+      g_cols.N[j] = N;
+      g_cols.ncb[j] = (N + 63) / 64;
+      g_cols.blk0[j + 1] = g_cols.blk0[j] + g_cols.ncb[j] * slices;
+    } else {
+      hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, (hipStream_t)stream, G,
+                         workspace, (int)M, N, ncb);
+    }
     sum_slices(workspace, out, (int64_t)N, slices, (hipStream_t)stream);
   }
   LAUNCH_CHECK("colsum launch");

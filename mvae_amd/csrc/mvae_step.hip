@@ -628,9 +628,10 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     z_s[tid >> 3][tid & 7] = 0.f;  // columns past Z stay zero (K of the hd tiles is padded to 8)
   }
   // ---- staging state of waves 4..7 (operands of the hd and logits phases, requested by MV_STAGE_REQUESTS, written to LDS
-  // after the heads barrier).  MV_EARLY_STAGE (default): the requests are issued right after the wave's heads MFMAs, i.e.
-  // once its own phase-1 operands have LANDED, instead of after the heads reduction + barrier: they travel during the
-  // reduction (~1 us earlier) and cannot queue in front of this wave's phase-1 requests.
+  // after the heads barrier).  MV_EARLY_STAGE=1 (an experiment, not the default): the requests are issued right after the
+  // wave's heads MFMAs, i.e. once its own phase-1 operands have landed, instead of after the heads reduction + barrier.
+  // Measured slower (heads reduce 0.8 -> 1.5 us, components 2.2 -> 1.7 us, kernel 8.9 -> 9.4 us): the other waves'
+  // phase-1 operands are still travelling and the CU's load path is the shared resource.
   const int lt = tid - 256;  // 0..255 on waves 4..7
   const int H4 = H >> 2;     // float4 per row of W_logits
   constexpr int kWl = 13;    // ceil(32 * 128 / 256): rows of up to 512 floats
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     }                                                                                                                 \
   } while (0)
 #ifndef MV_EARLY_STAGE
-#define MV_EARLY_STAGE 1
+#define MV_EARLY_STAGE 0  // measured (r03): 9.4 us against 8.9 us -- the early requests still delay the heads phase
 #endif
   // ---- heads = h W_heads^T + b
   {
@@ -724,22 +725,14 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
         base += nd;
       }
       const mvae_component_desc c = t.c[mine];
-      float zd[AM], klv;
-      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd, &klv);
+      float zd[AM];
+      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
       float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + t.first_dir[mine] + mydir) * DS;
       const int A = ambient_dim(c.kind, c.true_dim);
       rec[0] = kld;
 #pragma unroll
       for (int q2 = 0; q2 < AM; ++q2)
         if (q2 < A) rec[1 + q2] = zd[q2];
-      // The KL term of (row, component) is the value part of the same evaluation: the lane of direction 0 writes it.
-      // The tile workgroups therefore stop their component chain at z -- the KL half of the chain (logdet, the inverse
-      // sample projection, the normal terms) was ~half of the dependent chain every one of them waited for.
-      if (mydir == 0) {
-        const size_t row = (size_t)mt * 16 + r;
-        kl[(size_t)mine * B + row] = klv;
-        if (kl_user) kl_user[(size_t)mine * B + row] = klv;
-      }
     }
     MV_SPAN_END(2, 2);
     return;
@@ -756,10 +749,18 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   if (wave < 4) {
     const int r = lane & 15;
     if (my_ci >= 0) {
+      float klv;
       const size_t row = (size_t)mt * 16 + r;
-      // z only: the KL term is written by the dual workgroup of the row block (value part of its dual evaluation)
-      comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, nullptr, nullptr,
+      // (tried in round 3: the tile workgroups stop at z and the dual workgroup writes the KL terms from the value part
+      // of its dual evaluation -- no gain, the phase is bound by the staging loads of waves 4..7, not by this chain; and
+      // the value part of the dual evaluation differs from this one by rounding, which an ill-conditioned KL term of a
+      // projected-sphere component turned into 4e-4)
+      comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, &klv, nullptr,
                          nullptr, nullptr, nullptr);
+      if (lead) {
+        kl[(size_t)my_ci * B + row] = klv;
+        if (kl_user) kl_user[(size_t)my_ci * B + row] = klv;
+      }
     }
   } else {
 #if !MV_EARLY_STAGE
@@ -1628,6 +1629,8 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
 // PEER: the gradient is the sum of the ranks' published slots (mvae_peer.hip), added in rank order -- the same
 // floating-point sum on every rank -- and written to g like an all-reduced .grad.
+constexpr int kOptU = 2;  // 16-byte vectors per thread of k_optim
+static inline int optim_blocks(int n4) { return (n4 - kRadiiRegion / 4 + 256 * kOptU - 1) / (256 * kOptU); }
 template <bool PEER>
 __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, float* m, float* v, int n4,
                                                int* counters, double lr, double curv_lr, int do_curv, PeerSrc ps) {
@@ -1651,38 +1654,49 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
   }
   __syncthreads();
   const float neg_step = sh[0], bc2s = sh[1];
-  const int i4 = blockIdx.x * 256 + tid + kRadiiRegion / 4;
-  if (i4 < n4) {
-    float4 pp = reinterpret_cast<float4*>(p)[i4];
-    float4 gg;
+  // kOptU 16-byte vectors per thread, a grid-sized stride apart (coalesced), every request of the thread in flight
+  // before the first use: 8 (16 in the peer forms) 16-byte loads per lane instead of 4 -- the conv architecture's
+  // 8.4 MB buffers streamed at 4.1 TB/s with one vector per thread
+  float4 pp[kOptU], gg[kOptU], mm[kOptU], vv[kOptU];
+  int i4s[kOptU];
+#pragma unroll
+  for (int u = 0; u < kOptU; ++u) {
+    const int i4 = (u * (int)gridDim.x + (int)blockIdx.x) * 256 + tid + kRadiiRegion / 4;
+    i4s[u] = i4;
+    const int ic = i4 < n4 ? i4 : kRadiiRegion / 4;  // clamped request, masked at the store
+    pp[u] = reinterpret_cast<float4*>(p)[ic];
     if (PEER && ps.slice4 > 0) {  // two-shot: the reduced slice is read from its owner
-      int owner = (int)(i4 / ps.slice4);
+      int owner = (int)(ic / ps.slice4);
       owner = owner < ps.world ? owner : ps.world - 1;
-      gg = reinterpret_cast<const float4*>(ps.slot[owner] + slot_off)[i4];
-      store16_wt(g, (size_t)i4 * 4, f32x4{gg.x, gg.y, gg.z, gg.w});
+      gg[u] = reinterpret_cast<const float4*>(ps.slot[owner] + slot_off)[ic];
     } else if (PEER) {
-      gg = reinterpret_cast<const float4*>(ps.slot[0] + slot_off)[i4];
+      gg[u] = reinterpret_cast<const float4*>(ps.slot[0] + slot_off)[ic];
       for (int r = 1; r < ps.world; ++r) {
-        const float4 o = reinterpret_cast<const float4*>(ps.slot[r] + slot_off)[i4];
-        gg.x += o.x;
-        gg.y += o.y;
-        gg.z += o.z;
-        gg.w += o.w;
+        const float4 o = reinterpret_cast<const float4*>(ps.slot[r] + slot_off)[ic];
+        gg[u].x += o.x;
+        gg[u].y += o.y;
+        gg[u].z += o.z;
+        gg[u].w += o.w;
       }
-      store16_wt(g, (size_t)i4 * 4, f32x4{gg.x, gg.y, gg.z, gg.w});
     } else {
-      gg = reinterpret_cast<const float4*>(g)[i4];
+      gg[u] = reinterpret_cast<const float4*>(g)[ic];
     }
-    float4 mm = reinterpret_cast<float4*>(m)[i4];
-    float4 vv = reinterpret_cast<float4*>(v)[i4];
-    adam1(pp.x, gg.x, mm.x, vv.x, neg_step, bc2s);
-    adam1(pp.y, gg.y, mm.y, vv.y, neg_step, bc2s);
-    adam1(pp.z, gg.z, mm.z, vv.z, neg_step, bc2s);
-    adam1(pp.w, gg.w, mm.w, vv.w, neg_step, bc2s);
-    // write-through, as in the tile epilogues: 7.6 MB that nobody in this launch reads again
-    store16_wt(p, (size_t)i4 * 4, f32x4{pp.x, pp.y, pp.z, pp.w});
-    store16_wt(m, (size_t)i4 * 4, f32x4{mm.x, mm.y, mm.z, mm.w});
-    store16_wt(v, (size_t)i4 * 4, f32x4{vv.x, vv.y, vv.z, vv.w});
+    mm[u] = reinterpret_cast<float4*>(m)[ic];
+    vv[u] = reinterpret_cast<float4*>(v)[ic];
+  }
+#pragma unroll
+  for (int u = 0; u < kOptU; ++u) {
+    const int i4 = i4s[u];
+    if (i4 >= n4) continue;
+    if (PEER) store16_wt(g, (size_t)i4 * 4, f32x4{gg[u].x, gg[u].y, gg[u].z, gg[u].w});
+    adam1(pp[u].x, gg[u].x, mm[u].x, vv[u].x, neg_step, bc2s);
+    adam1(pp[u].y, gg[u].y, mm[u].y, vv[u].y, neg_step, bc2s);
+    adam1(pp[u].z, gg[u].z, mm[u].z, vv[u].z, neg_step, bc2s);
+    adam1(pp[u].w, gg[u].w, mm[u].w, vv[u].w, neg_step, bc2s);
+    // write-through, as in the tile epilogues: nobody in this launch reads these lines again
+    store16_wt(p, (size_t)i4 * 4, f32x4{pp[u].x, pp[u].y, pp[u].z, pp[u].w});
+    store16_wt(m, (size_t)i4 * 4, f32x4{mm[u].x, mm[u].y, mm[u].z, mm[u].w});
+    store16_wt(v, (size_t)i4 * 4, f32x4{vv[u].x, vv[u].y, vv[u].z, vv[u].w});
   }
   if (blockIdx.x == 0 && tid < t.n && t.trainable[tid]) {
     float gv = gsh[tid];
@@ -1833,7 +1847,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LF3(DM)                                                                                                      \
   STEP_LAUNCH((k_fwd3m<DM>), dim3(n_dual3 + ((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, c->t, c->gt, heads,       \
               c->ldh, eps, d.eps_dim, P + d.off_radii, NH, duals, n_dual3, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0, \
-              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z, klw, kl)
+              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z)
     if (bk == 2) { LF3(2); } else if (bk == 4) { LF3(4); } else { LF3(8); }
 #undef LF3
   } else {
@@ -1941,7 +1955,7 @@ extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* str
   if (!c) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const mvae_model_desc& d = c->d;
   const int n4 = d.n_params / 4;
-  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
                      d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, PeerSrc{});
   LAUNCH_CHECK("optimizer launch");
@@ -1962,7 +1976,7 @@ extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_cur
   ps.world = peer->world;
   ps.slice4 = peer->two_shot ? peer_slice4(peer) : 0;
   const int n4 = d.n_params / 4;
-  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
                      d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, ps);
   LAUNCH_CHECK("peer optimizer launch");
@@ -2021,7 +2035,7 @@ extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam
   t.n = ncomp;
   for (int i = 0; i < ncomp; ++i) t.trainable[i] = radius_trainable ? radius_trainable[i] : 0;
   const int n4 = (int)(n_params / 4);
-  const int blocks = (n4 - kRadiiRegion / 4 + 255) / 256;
+  const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v,
                      n4, counters, lr, curvature_lr, do_curvature_step, PeerSrc{});
   LAUNCH_CHECK("flat optimizer launch");

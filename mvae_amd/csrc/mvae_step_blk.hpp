@@ -138,10 +138,11 @@ __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, 
     const mvae_component_desc c = group_desc(t, first, cnt, sl, Md);
     if (sl < cnt) {
       const size_t row = (size_t)mt * 16 + r;
-      // z only: the KL terms are the value parts of the dual evaluations of k_fwd3m's dual workgroups, which write them
-      // (the KL half of the chain -- logdet, inverse sample projection, normal terms -- is off this kernel's tail)
+      float klv;
       comp_fwd_row<DMAX>(c, heads_s[r], eps_s[r], rad_s, z + row * ldz + z0, z_user ? z_user + row * Z + z0 : nullptr,
-                         nullptr, nullptr, nullptr, nullptr, nullptr);
+                         &klv, nullptr, nullptr, nullptr, nullptr);
+      kl[(size_t)(first + sl) * B + row] = klv;
+      if (kl_user) kl_user[(size_t)(first + sl) * B + row] = klv;
     }
     MV_SPAN_END(1, 1);
     return;
@@ -158,8 +159,7 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
                                                const float* eps, int eps_ld, const float* radii, int NH, float* duals,
                                                int n_dual, const float* z, int ldz, const float* Wd0, const float* bd0,
                                                const float* Wl, const float* bl, const float* x, float* hd, float* g,
-                                               float* bce_part, float* logits_user, int B, int H, int D, int Z,
-                                               float* kl, float* kl_user) {
+                                               float* bce_part, float* logits_user, int B, int H, int D, int Z) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // hd_s[16][H + 4]
   __shared__ float red[kW8][16][17];
   __shared__ float red2[kW8][16][17];
@@ -205,19 +205,14 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
         base += nd;
       }
       const mvae_component_desc c = group_desc(t, first, cnt, mine, Md);
-      float zd[AM], klv;
-      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd, &klv);
+      float zd[AM];
+      const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
       float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + firstd + mydir) * DS;
       const int A = ambient_dim(c.kind, c.true_dim);
       rec[0] = kld;
 #pragma unroll
       for (int q2 = 0; q2 < AM; ++q2)
         if (q2 < A) rec[1 + q2] = zd[q2];
-      if (mydir == 0) {  // the KL term of (row, component): value part of the same evaluation
-        const size_t row = (size_t)mt * 16 + r;
-        kl[(size_t)(first + mine) * B + row] = klv;
-        if (kl_user) kl_user[(size_t)(first + mine) * B + row] = klv;
-      }
     }
     MV_SPAN_END(2, 2);
     return;

@@ -21,8 +21,10 @@ from torch import Tensor
 
 def init_from_env() -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the default process group when
-    WORLD_SIZE > 1.  Backend "nccl" (= RCCL) unless MVAE_DIST_BACKEND says otherwise; MVAE_DIST_ONE_DEVICE=1 puts every
-    rank on cuda:0 (a flow check on a single-GPU box, together with MVAE_DIST_BACKEND=gloo)."""
+    WORLD_SIZE > 1.  Backend "gloo" unless MVAE_DIST_BACKEND says otherwise: the process group is the host-side channel
+    (rendezvous, the RCCL communicator id, barriers); the gradients travel on librccl directly (mvae_amd/rccl.py), so no
+    ProcessGroupNCCL -- and none of its watchdog threads -- lives next to the captured steps.  MVAE_DIST_ONE_DEVICE=1
+    puts every rank on cuda:0 (a flow check on a single-GPU box; the exchange then goes through gloo)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -31,7 +33,7 @@ def init_from_env() -> Tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("MVAE_DIST_BACKEND", "nccl")
+        backend = os.environ.get("MVAE_DIST_BACKEND", "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -84,8 +86,11 @@ class DataParallelStep:
         exercises the collective, its graph capture and k_optim on a single GPU).
         overlap: two-bucket exchange overlapped with the last backward launch (default: on; MVAE_DP_OVERLAP=0 turns it
         off -- one all-reduce of the whole buffer after the backward pass).
-        exchange: "allreduce" (default: torch.distributed, RCCL on the GPU) or "peer" (MVAE_DP_EXCHANGE=peer): the
-        one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch -- ranks of ONE node only;
+        exchange (MVAE_DP_EXCHANGE): "rccl" -- ncclAllReduce on librccl DIRECTLY, enqueued on the step's own streams
+        (mvae_amd/rccl.py: no ProcessGroupNCCL, no watchdog thread, captured natively; the process group is only the side
+        channel for the communicator id and may be gloo) -- the default for an engine on a HIP device; "allreduce" --
+        torch.distributed's all_reduce (what an engine without a HIP device gets: the gloo tests on CPU); "peer" -- the
+        one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch, ranks of ONE node only;
         "peer2": its two-shot form (each rank reduces 1/world of the buffer, the optimizer reads every slice from its
         owner)."""
         import os
@@ -95,19 +100,43 @@ class DataParallelStep:
         self.overlap = (os.environ.get("MVAE_DP_OVERLAP", "1") not in ("0", "")) if overlap is None else bool(overlap)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "allreduce")
-        if self.exchange not in ("allreduce", "peer", "peer2"):
+        on_hip = getattr(getattr(engine, "grads", None), "is_cuda", False)
+        # several ranks on ONE device (the flow checks on a single-GPU box): RCCL refuses duplicate devices
+        one_device = bool(os.environ.get("MVAE_DIST_ONE_DEVICE") or os.environ.get("MVAE_BENCH_ONE_DEVICE"))
+        self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "") or \
+            ("rccl" if (on_hip and not one_device) else "allreduce")
+        if self.exchange not in ("allreduce", "rccl", "peer", "peer2"):
             raise ValueError(f"unknown gradient exchange {self.exchange!r}")
         self.peer = None
-        if self.exchange in ("peer", "peer2") and (self.world > 1 or self.always_exchange):
+        self.rccl = None
+        active = self.world > 1 or self.always_exchange
+        if self.exchange in ("peer", "peer2") and active:
             from .peer import PeerExchange
             self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2")
+        if self.exchange == "rccl" and active:
+            from .rccl import FlatAllReduce
+            self.rccl = FlatAllReduce(engine.device, group)
+            self._side = torch.cuda.Stream(device=engine.device)  # the exchange travels here while launch 6 runs
+        self.steps_since_check = 0
+
+    @property
+    def capturable(self) -> bool:
+        """Whether a step of this route may be captured into a HIP graph: the direct RCCL route and the peer routes
+        always (their steps are kernels on the caller's streams), torch.distributed's all_reduce only on its RCCL backend."""
+        if self.world == 1 and not self.always_exchange:
+            return True
+        if self.rccl is not None or self.peer is not None:
+            return True
+        return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     def broadcast_state(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s parameters / optimizer state."""
         if self.world > 1:
             for t in (self.engine.params, self.engine.adam_m, self.engine.adam_v, self.engine.counters):
-                dist.broadcast(t, src=src, group=self.group)
+                if self.rccl is not None:
+                    self.rccl.broadcast(t, src)
+                else:
+                    dist.broadcast(t, src=src, group=self.group)
 
     def train_step(self, x_local: Tensor, eps_local: Tensor, beta: float, do_curvature_step: bool) -> None:
         eng = self.engine
@@ -118,6 +147,27 @@ class DataParallelStep:
             eng.forward_backward(x_local, eps_local, beta)
             self.peer.publish()
             self.peer.optimizer_step(do_curvature_step, batch=x_local.shape[0])
+            self.steps_since_check += 1
+            return
+        if self.rccl is not None:
+            main = torch.cuda.current_stream(eng.device)
+            if self.overlap and hasattr(eng, "forward_backward_part"):
+                # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5; its
+                # all-reduce is enqueued on the side stream behind an event and travels while launch 6 runs
+                off = eng.flat.off_w_logits
+                eng.forward_backward_part(x_local, eps_local, beta, eng.HEAD)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.rccl.all_reduce(eng.grads[off:])
+                eng.forward_backward_part(x_local, eps_local, beta, eng.TAIL)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.rccl.all_reduce(eng.grads[:off])
+                main.wait_stream(self._side)
+            else:
+                eng.forward_backward(x_local, eps_local, beta)
+                self.rccl.all_reduce(eng.grads)
+            eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
             return
         if self.overlap and hasattr(eng, "forward_backward_part"):
             # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5.  An async
@@ -140,5 +190,18 @@ class DataParallelStep:
         """Global sums of the running statistics (one small all-reduce, when the host wants to log)."""
         s = self.engine.stats.clone()
         if self.world > 1:
-            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+            if self.rccl is not None:
+                self.rccl.all_reduce(s)
+            else:
+                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s
+
+    def check_exchange(self) -> None:
+        """Host-side health check of the peer routes, to be called at log / epoch boundaries (it synchronises nothing):
+        a wait that timed out means a rank went on with stale or half-written gradient slots -- the ranks' parameters have
+        silently diverged -- so it is an error, not a statistic."""
+        if self.peer is not None and self.peer.timeouts() > 0:
+            raise RuntimeError(f"peer gradient exchange: {self.peer.timeouts()} wait(s) timed out on rank {self.rank}; "
+                               "the ranks are no longer synchronous (restart from the last checkpoint with "
+                               "MVAE_DP_EXCHANGE=rccl, or raise the time-out)")
+        self.steps_since_check = 0

@@ -58,12 +58,10 @@ class StepRunner:
         self._snapshot = None
         self.graphs: dict = {}  # first resident batch of a span -> (graph, number of steps)
         self.dp = DataParallelStep(eng, always_exchange=force_exchange) if (self.world > 1 or force_exchange) else None
-        if self.gs > 0 and self.dp is not None and self.dp.world > 1:
-            import torch.distributed as dist
-            if dist.get_backend(self.dp.group) != "nccl" and self.dp.peer is None:
-                # only RCCL collectives can be captured; a host-side backend (gloo) invalidates the capture and leaves
-                # the process in an unusable capture state, so it is not even attempted
-                self.gs = 0
+        if self.gs > 0 and self.dp is not None and not self.dp.capturable:
+            # only RCCL collectives can be captured; a host-side collective (gloo) invalidates the capture and leaves
+            # the process in an unusable capture state, so it is not even attempted
+            self.gs = 0
         if self.gs > 0:
             if self.plan is None and self.n_data % self.gs != 0:
                 raise ValueError("the number of resident batches must be a multiple of graph_steps")
@@ -90,7 +88,7 @@ class StepRunner:
                 torch.cuda.synchronize()
 
     def _capture_mode(self) -> str:
-        """With a process group alive, ProcessGroupNCCL's watchdog thread polls the events of earlier collectives
+        """(Only torch.distributed's own RCCL route needs this.)  With a ProcessGroupNCCL alive, ProcessGroupNCCL's watchdog thread polls the events of earlier collectives
         (hipEventQuery); under the default "global" capture mode such a call from ANOTHER thread is an error while this
         thread captures ("operation not permitted when stream is capturing": 2 of 12 runs died that way).
         "thread_local" restricts the check to the capturing thread."""
@@ -191,9 +189,8 @@ class EpochRunner:
         self.dp = dp if (dp is not None and dp.world > 1) else None
         self.capturable = True
         if self.dp is not None:
-            import torch.distributed as dist
-            # (the peer-read exchange has no collective in the step: capturable under any backend)
-            self.capturable = dist.get_backend(self.dp.group) == "nccl" or self.dp.peer is not None
+            # (the direct RCCL route and the peer routes are capturable under any process-group backend)
+            self.capturable = self.dp.capturable
 
     def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
         C, check, load, ptr, stream_ptr = self._c

@@ -148,8 +148,8 @@ class Trainer:
         dp = getattr(self.model, "_dp", None)
         world = dp.world if dp is not None else 1
         if world > 1:  # global sums on every rank: the early-stopping decisions below stay identical across ranks
-            import torch.distributed as dist
-            dist.all_reduce(eng.stats, op=dist.ReduceOp.SUM, group=dp.group)
+            dp.check_exchange()  # a timed-out peer wait means the ranks have diverged: an error, at the epoch boundary
+            eng.stats.copy_(dp.reduce_stats())
         sums = eng.read_stats(reset=True)["sum"]  # the only device sync of the epoch
         # The reference asserts isfinite after nearly every op (e.g. vae.py:158 on the loss), a host sync each.  Here a
         # non-finite value in ANY step poisons the running sums, so one check per epoch reports the same condition

@@ -22,12 +22,7 @@ def _run(*flags):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # a free rendezvous port per run
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", *flags]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    if p.returncode != 0 and "--force-dp" in flags:
-        # one retry for the exchange route only: a capture of the RCCL collective invalidated by the process group's
-        # watchdog thread can take the process down before bench.py's own fallback gets to run (rare)
-        print("bench.py --force-dp failed once, retrying:\n" + p.stderr[-1500:])
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == 0, p.stderr[-2000:]  # no retry: the exchange route has no watchdog thread to lose a capture to
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines  # library banners must not reach stdout
     return json.loads(lines[0])
@@ -56,10 +51,9 @@ def test_bench_line_schema():
 
 
 def test_bench_forced_exchange_route():
-    """The data-parallel route (gradients -> RCCL all-reduce -> k_optim) inside HIP graphs, at world size 1."""
+    """The data-parallel route (gradients -> ncclAllReduce on librccl directly, on the step's streams -> k_optim) captured
+    into ONE HIP graph, at world size 1: no ProcessGroupNCCL, so the capture cannot be lost to a watchdog thread."""
     d = _run("--no-cpu-baseline", "--force-dp")
-    assert "forced exchange" in d["config"]["parallelism"]
-    # the 300 timed steps are ONE graph; 0 = bench.py's documented fallback when the capture of the RCCL collective is
-    # invalidated by the process group's watchdog thread (rare, nondeterministic: DESIGN.md section 6) -- the line is still valid
-    assert d["config"]["graph_steps"] in (300, 0)
+    assert "forced exchange" in d["config"]["parallelism"] and d["config"]["exchange"] == "rccl"
+    assert d["config"]["graph_steps"] == 300 and d["config"]["graph_replays"] == 1
     assert d["value"] > 1000

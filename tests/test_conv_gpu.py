@@ -172,6 +172,44 @@ def test_conv_step_at_the_baseline_batch_256(dev):
         assert_close(halves[n], gnp, 2 * RTOL, "sum of the halves: " + n, atol_frac=2e-4)
 
 
+def test_conv_step_above_the_column_sum_slice(dev):
+    """B = 640 > 512 rows: the d3.bias gradient goes through an INTERMEDIATE column sum over the batch that is itself
+    summed in slices; that sum must be complete when the next kernel reads it although the backward pass defers its
+    other slice sums (mvae_slice_sums_defer(2) around it).  Property: the loss is a batch sum, so every gradient of the
+    640 rows equals the sum over its five 128-row chunks."""
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from oracle import model as M
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    B = 640
+    xd = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
+    ed = synthetic.eps_batches(1, B, 6)[0].to(dev)
+    eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True] * 3)
+    eng.load_state(state0)
+    eng.grads.fill_(float("nan"))  # whatever is not written shows
+    out = eng.forward_backward(xd, ed, 1.0, want_outputs=True)
+    grads = {n: _cpu(t).astype(np.float64) for n, t in eng.grad_views().items()}
+    bce = _cpu(out["bce"])
+    parts = {}
+    for lo in range(0, B, 128):
+        o = eng.forward_backward(xd[lo:lo + 128].contiguous(), ed[lo:lo + 128].contiguous(), 1.0, want_outputs=True)
+        assert_close(_cpu(o["bce"]), bce[lo:lo + 128], 2e-5, "bce of a chunk")
+        for n, t in eng.grad_views().items():
+            parts[n] = parts.get(n, 0) + _cpu(t).astype(np.float64)
+    # d3.bias (the gradient the intermediate feeds) is a plain sum of sigmoid(logits) - x: per entry.  The other tensors
+    # pass through ReLU masks, and the 640-row and 128-row forward passes take different contraction kernels (tile
+    # shapes chosen by the row count), so an activation within rounding of zero may fall on either side: norms, as in
+    # test_conv_step_at_the_baseline_batch_256.
+    assert_close(grads["d3.bias"], parts["d3.bias"], RTOL, "d3.bias: sum of the chunks", atol_frac=1e-5)
+    for n, gnp in grads.items():
+        assert np.isfinite(gnp).all(), n
+        b = parts[n]
+        err = np.abs(gnp - b)
+        assert np.sqrt((err**2).sum()) <= 1e-3 * np.sqrt((b**2).sum()) + 1e-12, f"grad {n}: relative L2 error"
+        assert err.max() <= 1e-2 * max(np.abs(b).max(), 1e-30), f"grad {n}: max error {err.max():.3e}"
+
+
 def test_conv_weights_are_taps_major_in_hbm_and_reference_shaped_outside(dev):
     """The channel-last layers keep their weights taps-major in the flat buffer; state_dict tensors have the reference's
     logical shape and values (strided views), and survive a save / load round trip."""
@@ -329,6 +367,25 @@ def test_deferred_slice_sums_are_the_same_sums(dev):
         CV._DEFERRED_WS.clear()
     for a, b in zip(now, later):
         assert torch.equal(a, b)
+    # suspended deferral: the sum is performed at once, the queue is kept; switching deferral off drops what is queued
+    check(load().mvae_slice_sums_defer(1))
+    try:
+        queued = CV._colsum(Ps[0], out=torch.full((24,), -7.0, device=dev))
+        check(load().mvae_slice_sums_defer(2))
+        direct = CV._colsum(Ps[1])
+        check(load().mvae_slice_sums_defer(1))
+        torch.cuda.synchronize()
+        assert torch.equal(direct, now[31]) and bool((queued == -7.0).all())  # not summed yet
+        check(load().mvae_slice_sums_flush(stream_ptr(dev)))
+        torch.cuda.synchronize()
+        assert torch.equal(queued, now[30])
+        dropped = CV._colsum(Ps[2], out=torch.full((24,), -7.0, device=dev))
+    finally:
+        check(load().mvae_slice_sums_defer(0))  # drops the queued job
+    check(load().mvae_slice_sums_flush(stream_ptr(dev)))
+    torch.cuda.synchronize()
+    CV._DEFERRED_WS.clear()
+    assert bool((dropped == -7.0).all())
 
 
 def test_linear_splitk_vs_float64(dev):

@@ -145,6 +145,58 @@ def test_peer_read_exchange_two_processes_one_device(graph_steps, exchange):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["peer", "peer2"])
+def test_peer_exchange_eight_processes_one_device(exchange):
+    """The node-sized case, rehearsed on one device: EIGHT processes (the `--gpus 8` layout: one process per rank, hipIpc
+    mappings and flags among 8 ranks, slots reused every second publish, 16 rows per rank) through HIP-graph replays: no
+    wait times out, all eight ranks end bit-identical, and the parameters equal the single-process step on the full
+    batch (the loss is a batch sum; the rank-order sum differs from the single-device row order only by rounding)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    steps, world = 6, 8
+    res = _run_ranks(steps, world, exchange=exchange, graph_steps=3)
+    assert all(r[3] == 0 for r in res), "a rank gave up waiting for a peer"
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1]), f"rank {r[0]} diverged from rank 0"
+    dev = torch.device("cuda:0")
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    xs = synthetic.digits_like_batches(steps, 128).to(dev)
+    eps = synthetic.eps_batches(steps, 128, 6).to(dev)
+    for s in range(steps):
+        eng.train_step(xs[s % 3], eps[s % 3], 1.0, True)  # a replay repeats its three batches
+    assert_close_after_adam(res[0][1], eng.params.cpu().numpy(), 1e-3, steps, "flat parameters, dp8 vs single process")
+    np.testing.assert_allclose(res[0][2][:3], eng.stats.cpu().numpy()[:3], rtol=2e-4)
+
+
+@pytest.mark.timeout(900)
+def test_bench_flow_eight_ranks_one_device():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, 8 ranks), dry-run on ONE device over the
+    two-shot peer route: the flow -- rendezvous, capture of the exchange, barrier-bracketed timed region, max over ranks,
+    ONE JSON line from rank 0 -- completes, no wait times out and the ranks hold identical parameters afterwards."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVAE_BENCH_BACKEND="gloo", MVAE_BENCH_ONE_DEVICE="1", MVAE_DP_EXCHANGE="peer2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20",
+           "--warmup", "5"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak" and d["config"]["exchange"] == "peer2"
+    assert d["config"]["graph_replays"] == 1 and d["config"]["ranks_identical"] is True
+    assert d["config"]["peer_timeouts"] == 0 and d["value"] > 0
+
+
+@pytest.mark.timeout(900)
 def test_cli_data_parallel_two_ranks(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 -m mvae_amd.run ...`: the CLI's data-parallel mode (global
     batch split over the ranks, sharded training set, all-reduced gradients and epoch statistics, rank 0 prints) runs

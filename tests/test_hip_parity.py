@@ -220,7 +220,10 @@ def test_sphere_backward_finite_at_the_acos_boundary(dev):
 
 # ------------------------------------------------------------------------------------------------ dense layers
 @pytest.mark.parametrize("M_,N,K", [(128, 400, 784), (128, 12, 400), (128, 784, 400), (128, 400, 8), (37, 50, 23),
-                                    (1, 1, 1), (256, 400, 48)])
+                                    (1, 1, 1), (256, 400, 48),
+                                    # few outputs over a wide input: the one-pass backward kernel (k_linear_bwd_skn; the
+                                    # conv heads are 256 x 12 x 8192), full / ragged row chunks
+                                    (256, 12, 8192), (300, 5, 1024), (64, 16, 2048)])
 def test_linear_forward_backward(dev, M_, N, K):
     from mvae_amd import functional as Fn
     g = torch.Generator().manual_seed(M_ * 7 + N)
