@@ -112,22 +112,46 @@ def cpu_baseline(seconds_budget=8.0, model=MODEL, fixed=False):
 CONV_FLOPS_B256 = 79.5e9  # fwd 26.63 GFLOP, fwd + bwd ~79.5 GFLOP at B = 256
 
 
-def conv_leg(steps, warmup, graph=True):
-    """BASELINE configs[4] on one GPU: CIFAR shapes (3x32x32, soft targets), conv architecture, h_dim 8192, batch 256,
-    model h2,s2,e2, learnable curvature.  One step = ConvEngine.train_step (forward, ELBO, backward, Adam + curvature
-    SGD); the warm-up and the timed region are ONE HIP graph each.  MFMA-bound: the roofline is f32 MFMA flops."""
+def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=None, strong=False, force_dp=False):
+    """BASELINE configs[4]: CIFAR shapes (3x32x32, soft targets), conv architecture, h_dim 8192, batch 256, model
+    h2,s2,e2, learnable curvature.  One step = ConvEngine.train_step (forward, ELBO, backward, Adam + curvature SGD); the
+    warm-up and the timed region are ONE HIP graph each.  MFMA-bound: the roofline is f32 MFMA flops.  N > 1 (or
+    --force-dp): ConvEngine behind DataParallelStep -- forward/backward on the rank's rows, ONE all-reduce (SUM) of the flat
+    gradient buffer (8.4 MB), the replicated optimizer; weak scaling = 256 rows per GPU, --strong = 256 rows in all."""
     from mvae_amd import functional as Fn, synthetic
     from mvae_amd.conv import ConvEngine
-    Bc = 256
+    Bg = 256  # BASELINE's batch
     dev = torch.device("cuda", torch.cuda.current_device())
     eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
     shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
     eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
     n_data = 8
-    xs = synthetic.uniform_batches(n_data, Bc, 3072).to(dev)
-    eps = synthetic.eps_batches(n_data, Bc, 6).to(dev)
+    if strong and world > 1:
+        from mvae_amd.distributed import shard_rows
+        lo, hi = shard_rows(Bg, rank, world)
+        xs = synthetic.uniform_batches(n_data, Bg, 3072)[:, lo:hi].contiguous().to(dev)
+        eps = synthetic.eps_batches(n_data, Bg, 6)[:, lo:hi].contiguous().to(dev)
+    else:
+        xs = synthetic.uniform_batches(n_data, Bg, 3072, seed=4321 + rank).to(dev)
+        eps = synthetic.eps_batches(n_data, Bg, 6, rank=rank).to(dev)
+    Bc = xs.shape[1]
+    dp = None
+    if dist_on:
+        import torch.distributed as dist
+        from mvae_amd.distributed import DataParallelStep
+        dp = DataParallelStep(eng, always_exchange=force_dp)
+        dp.broadcast_state()
+    one_step = eng.train_step if dp is None else dp.train_step
+    graph = graph and (dp is None or dp.capturable)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for i in range(3):
-        eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
+        one_step(xs[i % n_data], eps[i % n_data], 1.0, True)
     torch.cuda.synchronize()
     graphs = {}
     if graph:
@@ -136,7 +160,7 @@ def conv_leg(steps, warmup, graph=True):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for i in range(n):
-                    eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
+                    one_step(xs[i % n_data], eps[i % n_data], 1.0, True)
             graphs[n] = g
         torch.cuda.synchronize()
         for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
@@ -147,17 +171,25 @@ def conv_leg(steps, warmup, graph=True):
             graphs[n].replay()
         else:
             for i in range(n):
-                eng.train_step(xs[i % n_data], eps[i % n_data], 1.0, True)
+                one_step(xs[i % n_data], eps[i % n_data], 1.0, True)
 
     run(warmup)
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     run(steps)
-    torch.cuda.synchronize()
+    sync_all()
     dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     st = eng.read_stats()["last"]
     assert st["elbo"] == st["elbo"], "non-finite ELBO"
+    if rank != 0:
+        return None
     step_s = dt / steps
+    scale = 1 if (strong and world > 1) else world  # units (256-row steps) all ranks processed per step of the job
+    flops_step = CONV_FLOPS_B256 * (Bc * world / Bg)
     # the dominant kernel, timed live with events on the launch stream: the e2 forward contraction
     # ([B*16, 2048] x [512, 2048]^T, 2.15 GFLOP at B = 256), the largest single launch of the step
     a = torch.randn(Bc * 16, 2048, device=dev)
@@ -173,24 +205,58 @@ def conv_leg(steps, warmup, graph=True):
     torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / 20
     k_tf = 2.0 * Bc * 16 * 2048 * 512 / (k_ms * 1e-3) / 1e12
-    tf = CONV_FLOPS_B256 / step_s / 1e12
+    tf = flops_step / step_s / 1e12 / world  # per GPU
     return {
         "metric": "ELBO-steps/sec (batch 256) CIFAR conv h2,s2,e2",
-        "value": steps / dt, "unit": "ELBO-steps/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
-        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "BASELINE configs[4] on ONE GPU: CIFAR shapes (3x32x32, U[0,1] soft targets), model h2,s2,e2, "
-                               "learnable curvature, conv architecture h_dim=8192, batch 256, epoch>=10 state",
-                   "global_batch": Bc, "parallelism": "dp1", "graph_steps": steps if graphs else 0,
-                   "graph_replays": 1 if graphs else 0,
+        "value": steps * scale / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong" if (strong and world > 1) else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] on {world} GPU(s): CIFAR shapes (3x32x32, U[0,1] soft targets), model "
+                               "h2,s2,e2, learnable curvature, conv architecture h_dim=8192, " +
+                               ("global batch 256 split by rows" if (strong and world > 1) else "batch 256 per GPU") +
+                               ", epoch>=10 state",
+                   "global_batch": Bc * world, "parallelism": f"dp{world}" + ("(forced exchange)" if force_dp else ""),
+                   "exchange": dp.exchange if dp is not None else "none",
+                   "graph_steps": steps if graphs else 0, "graph_replays": 1 if graphs else 0,
                    "final_elbo_per_sample": st["elbo"] / Bc},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": tf / F32_MFMA_PEAK_TF,
-                     "scope": "whole step: SURVEY 8(d) 79.5 GFLOP (fwd + bwd contractions) over ms_per_step",
+                     "scope": "whole step, per GPU: SURVEY 8(d) 79.5 GFLOP (fwd + bwd contractions at 256 rows) over ms_per_step",
                      "kernel": "k_gemm_tiled: e2 forward contraction [4096 x 2048] x [512 x 2048]^T + bias + ReLU",
                      "kernel_ms": k_ms, "kernel_achieved_TFLOPs": k_tf, "kernel_mfma_frac": k_tf / F32_MFMA_PEAK_TF,
                      "traffic": None},
     }
+
+
+def init_dist(force_dp):
+    """(world, rank, local_rank, dist_on, backend): the torchrun environment; initialises the process group when the run
+    is data-parallel (or the exchange is forced at world size 1)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1 or force_dp
+    backend = None
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        # The process group is the HOST-side channel only (rendezvous, the RCCL communicator id, barriers): gloo.  The
+        # gradients are all-reduced by librccl directly on the step's streams (mvae_amd/rccl.py), captured into the
+        # graphs; no ProcessGroupNCCL / watchdog thread exists.  MVAE_BENCH_BACKEND=nccl + MVAE_DP_EXCHANGE=allreduce
+        # selects torch.distributed's own RCCL route instead.  MVAE_BENCH_ONE_DEVICE=1: a dry run of the N > 1 flow on
+        # a single-GPU box (all ranks on cuda:0, the exchange through gloo or the peer routes).  Not a measurement.
+        backend = os.environ.get("MVAE_BENCH_BACKEND", "gloo")
+        if os.environ.get("MVAE_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(torch.device("cuda", local_rank))
+    return world, rank, local_rank, dist_on, backend
 
 
 def parse_model(model):
@@ -371,35 +437,22 @@ def main():
         os.close(json_fd)
 
     if args.config == "conv":
-        assert torch.cuda.is_available(), "bench.py needs a HIP device"
         if args.steps == 2000 and args.warmup == 200:  # the MLP defaults: a conv step is ~40x longer
             args.steps, args.warmup = 200, 20
-        return emit(conv_leg(args.steps, args.warmup, graph=args.graph_steps > 0))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1 or args.force_dp
+        world, rank, local_rank, dist_on, backend = init_dist(args.force_dp)
+        line = conv_leg(args.steps, args.warmup, graph=args.graph_steps > 0, world=world, rank=rank, dist_on=dist_on,
+                        backend=backend, strong=args.strong, force_dp=args.force_dp)
+        if rank == 0:
+            emit(line)
+        if dist_on:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    world, rank, local_rank, dist_on, backend = init_dist(args.force_dp)
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        # The process group is the HOST-side channel only (rendezvous, the RCCL communicator id, barriers): gloo.  The
-        # gradients are all-reduced by librccl directly on the step's streams (mvae_amd/rccl.py), captured into the
-        # graphs; no ProcessGroupNCCL / watchdog thread exists.  MVAE_BENCH_BACKEND=nccl + MVAE_DP_EXCHANGE=allreduce
-        # selects torch.distributed's own RCCL route instead.  MVAE_BENCH_ONE_DEVICE=1: a dry run of the N > 1 flow on
-        # a single-GPU box (all ranks on cuda:0, the exchange through gloo or the peer routes).  Not a measurement.
-        backend = os.environ.get("MVAE_BENCH_BACKEND", "gloo")
-        if os.environ.get("MVAE_BENCH_ONE_DEVICE"):
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine

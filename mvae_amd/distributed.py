@@ -111,6 +111,9 @@ class DataParallelStep:
         self.rccl = None
         active = self.world > 1 or self.always_exchange
         if self.exchange in ("peer", "peer2") and active:
+            if not hasattr(engine, "_context"):
+                raise ValueError("the peer-read exchange is fused into the MLP step's optimizer launch (StepEngine); "
+                                 "other engines (ConvEngine) exchange through 'rccl' or 'allreduce'")
             from .peer import PeerExchange
             self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2")
         if self.exchange == "rccl" and active:

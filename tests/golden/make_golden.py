@@ -507,6 +507,55 @@ def gen_steps_full():
     print("g3_step_full:", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- G8
+def _summary_n(a, rng, n=64):
+    """(sum, L2, max|.|, n sampled indices, the n entries)"""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    idx = rng.choice(a.size, size=min(n, a.size), replace=False)
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum()), np.abs(a).max()], idx.astype(np.float64), a[idx]])
+
+
+G8_CASES = [
+    # name, model, arch, in_dim, h_dim, B, fixed, epoch, soft
+    # BASELINE configs[4] at its REAL batch size (the B = 4 case of g3_step_full pins the layers, this one the size)
+    ("cifar_conv_h2s2e2_learn_b256", "h2,s2,e2", "conv", 3072, 8192, 256, False, 12, True),
+    # the reference's own large-component models (tests/mvae/models/test_vae.py:212-249) at the benchmark size
+    ("mnist_h40_learn", "h40", "ff", 784, 400, 128, False, 12, False),
+    ("mnist_s40_learn", "s40", "ff", 784, 400, 128, False, 12, False),
+]
+
+
+def gen_full_size_extra():
+    """One reference step (forward, ELBO, backward, optimizer) per case and dtype: per-sample statistics in full, every
+    big tensor as (sum, L2, max|.|, 64 sampled entries).  float32 AND float64, so that a test can state the float32
+    reference's own distance from the float64 reference next to the HIP path's."""
+    out, meta = {}, {}
+    for name, model_str, arch, in_dim, h_dim, B, fixed, epoch, soft in G8_CASES:
+        for dname, dtype in DTYPES.items():
+            rng = np.random.RandomState(11)
+            r = run_reference(model_str, arch, in_dim, h_dim, B, 1, epoch, fixed, False, dtype, soft_targets=soft)
+            key = f"{name}/{dname}/"
+            s0 = r["steps"][0]
+            out[key + "concat_z"] = s0["concat_z"]
+            out[key + "bce_rows"] = s0["bce_rows"]
+            out[key + "kl_rows"] = s0["kl_rows"]
+            out[key + "logits_summary"] = _summary_n(s0["logits"], rng)
+            for k, v in s0["grads"].items():
+                if v is not None:
+                    out[key + "grad_summary/" + k] = _summary_n(v, rng)
+            for k, v in s0["state_after"].items():
+                out[key + "state1_summary/" + k] = _summary_n(v, rng)
+            out[key + "stats"] = np.array([[s["bce"], s["kl"], s["elbo"]] + s["component_kl"] for s in r["steps"]],
+                                          dtype=np.float64)
+        meta[name] = dict(model=model_str, arch=arch, in_dim=in_dim, h_dim=h_dim, batch=B, fixed_curvature=fixed,
+                          epoch=epoch, soft_targets=soft)
+        print("  g8 case done:", name, flush=True)
+    np.savez_compressed(os.path.join(HERE, "g8_full_size_extra.npz"), **out)
+    with open(os.path.join(HERE, "g8_full_size_extra.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print("g8_full_size_extra:", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------------------------- G4
 def gen_loglik():
     out = {}
@@ -579,7 +628,7 @@ def gen_parser():
 
 if __name__ == "__main__":
     os.makedirs("/tmp/golden_chkpt", exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g1s", "g2", "g3s", "g3f", "g4", "g5", "g6", "g7", "g8"]
     torch.set_num_threads(8)
     if "g1" in which:
         gen_primitives()
@@ -599,3 +648,5 @@ if __name__ == "__main__":
         gen_projected()
     if "g7" in which:
         gen_distances()
+    if "g8" in which:
+        gen_full_size_extra()

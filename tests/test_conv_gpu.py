@@ -172,6 +172,58 @@ def test_conv_step_at_the_baseline_batch_256(dev):
         assert_close(halves[n], gnp, 2 * RTOL, "sum of the halves: " + n, atol_frac=2e-4)
 
 
+def test_conv_step_b256_vs_the_reference(dev):
+    """BASELINE config [4] at its real batch size against the REFERENCE itself: tests/golden/g8_full_size_extra.npz holds
+    one reference step at B = 256 (per-sample bce / kl / z in full; logits, every gradient and the parameters after the
+    step as sum, L2, max and 64 sampled entries), recorded in float32 AND float64.  The HIP step is compared with the
+    float32 record at the 1e-4 bar per sampled entry, and its distance from the float64 record is reported next to the
+    float32 reference's own distance from it (printed; asserted to be of the same order)."""
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from oracle import model as M
+    g = load_npz("g8_full_size_extra.npz")
+    k32, k64 = "cifar_conv_h2s2e2_learn_b256/f32/", "cifar_conv_h2s2e2_learn_b256/f64/"
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    B = 256
+    x = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
+    eps = synthetic.eps_batches(1, B, 6)[0].to(dev)
+    eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True] * 3)
+    eng.load_state(state0)
+    out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
+    assert_close(_cpu(out["concat_z"]), g[k32 + "concat_z"], RTOL, "concat_z")
+    assert_close(_cpu(out["bce"]), g[k32 + "bce_rows"], RTOL, "bce rows")
+    assert_close(_cpu(out["kl"]), g[k32 + "kl_rows"], RTOL, "kl rows", atol_frac=1e-4)
+    ref = g[k32 + "logits_summary"]
+    assert_close(summary_of(_cpu(out["logits"]), ref), ref, RTOL, "logits summary")
+    worst_hip, worst_ref = 0.0, 0.0
+    for n, t in eng.grad_views().items():
+        if k32 + "grad_summary/" + n not in g:
+            continue
+        r32, r64 = g[k32 + "grad_summary/" + n], g[k64 + "grad_summary/" + n]
+        got = summary_of(_cpu(t), r32)
+        # sum / L2 / max and the 64 sampled entries: 1e-4 relative with a floor of 1e-4 of the tensor's max
+        assert_close(got, r32, RTOL, "grad " + n, atol_frac=1e-4 * r32[2] / max(np.abs(r32).max(), 1e-30))
+        k = (len(r32) - 3) // 2
+        scale = max(r64[2], 1e-30)
+        worst_hip = max(worst_hip, np.abs(got[3 + k:] - r64[3 + k:]).max() / scale)
+        worst_ref = max(worst_ref, np.abs(r32[3 + k:] - r64[3 + k:]).max() / scale)
+    print(f"sampled gradient entries, worst |err| / max|g| against the float64 reference: HIP {worst_hip:.2e}, "
+          f"float32 reference {worst_ref:.2e}")
+    assert worst_hip <= max(20 * worst_ref, 1e-4)
+    eng.optimizer_step(True)
+    for n, t in eng.param_views().items():
+        ref = g[k32 + "state1_summary/" + n]
+        got = summary_of(_cpu(t), ref)
+        k = (len(ref) - 3) // 2
+        # one Adam step moves an entry by lr = 1e-3 in the direction of its gradient's sign: sampled entries to 2e-4 of
+        # the tensor's scale unless the gradient there is rounding noise (then 2 lr apart at most)
+        d = np.abs(got[3 + k:] - ref[3 + k:])
+        assert d.max() <= 2e-3 * 1.01 + 2e-4 * ref[2], "param " + n
+        assert (d > 2e-4 * ref[2] + 1e-5).mean() <= 0.05, "param " + n
+        assert_close(got[:3], ref[:3], 2e-4, "param summary " + n)
+
+
 def test_conv_step_above_the_column_sum_slice(dev):
     """B = 640 > 512 rows: the d3.bias gradient goes through an INTERMEDIATE column sum over the batch that is itself
     summed in slices; that sum must be complete when the next kernel reads it although the backward pass defers its

@@ -112,6 +112,72 @@ def test_two_rank_data_parallel_equals_single_process():
     assert results[0][2][3] == 2 * steps and tot[3] == steps  # every rank counts its own steps
 
 
+def _conv_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from mvae_amd.distributed import DataParallelStep, shard_rows
+    from oracle import model as M
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
+    if rank == 0:
+        eng.load_state(state0)  # the other rank starts from zeros: broadcast_state has to bring it in line
+    B = 32
+    x = synthetic.uniform_batches(1, B, 3072)[0]
+    eps = synthetic.eps_batches(1, B, 6)[0]
+    lo, hi = shard_rows(B, rank, world)
+    dp = DataParallelStep(eng, exchange="allreduce")  # two ranks on ONE device: gloo (RCCL refuses duplicate devices)
+    dp.broadcast_state()
+    dp.train_step(x[lo:hi].contiguous().to(dev), eps[lo:hi].contiguous().to(dev), 1.0, True)
+    torch.cuda.synchronize()
+    q.put((rank, eng.grads.cpu().numpy().copy(), eng.params.cpu().numpy().copy(), dp.reduce_stats().cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_conv_step_equals_the_oracle():
+    """BASELINE config [4] is a data-parallel config: ConvEngine behind DataParallelStep, two ranks with 16 rows each of
+    a 32-row batch (strong-scaling parity).  The all-reduced gradients, the parameters after the replicated
+    optimizer step and the global statistics equal the ORACLE's single-device step on the 32 rows; the ranks end
+    bit-identical although only rank 0 was given the initial state."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from helpers import assert_close
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from oracle import model as M
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_conv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "ranks diverged"
+    spec = M.Spec("h2,s2,e2", in_dim=3072, h_dim=8192, arch="conv", fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, transposed_conv=("d1", "d2", "d3"))
+    x = synthetic.uniform_batches(1, 32, 3072)[0]
+    eps = synthetic.eps_batches(1, 32, 6)[0]
+    orc = M.StepOracle(spec, state0, lr=1e-3)
+    ref = orc.train_step(x, eps, beta=1.0, epoch=12)
+    lay = ConvEngine([("h", 2), ("s", 2), ("e", 2)], torch.device("cuda:0")).flat
+    grads, params = torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2])
+    for n, t in lay.views(grads).items():
+        if orc.P[n].grad is not None:
+            assert_close(t.numpy(), orc.P[n].grad.numpy(), 2e-4, "dp2 conv grad " + n, atol_frac=2e-4)
+    for n, t in lay.views(params).items():
+        assert_close_after_adam(t.numpy(), orc.P[n].detach().numpy(), 1e-3, 1, "dp2 conv param " + n)
+    np.testing.assert_allclose(res[0][3][2], float(ref.elbo), rtol=1e-4)
+
+
 def _run_ranks(steps, world, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

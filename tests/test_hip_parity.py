@@ -354,6 +354,41 @@ def test_fused_step_full_size_vs_golden(dev, name):
             assert_close(summary_of(_cpu(t), ref), ref, RTOL, "final " + n, atol_frac=1e-4)
 
 
+@pytest.mark.parametrize("name", ["mnist_h40_learn", "mnist_s40_learn"])
+def test_large_component_step_vs_the_reference(dev, name):
+    """The reference's own large-component models (`h40`, `s40`: tests/mvae/models/test_vae.py:212-249) at the benchmark
+    size, against one step recorded from the reference (g8_full_size_extra.npz): per-sample statistics in full, logits /
+    gradients / updated parameters as sum, L2, max and 64 sampled entries."""
+    from mvae_amd import synthetic
+    from oracle import model as M
+    g = load_npz("g8_full_size_extra.npz")
+    meta = load_json("g8_full_size_extra.json")[name]
+    spec = M.Spec(meta["model"], in_dim=meta["in_dim"], h_dim=meta["h_dim"], fixed_curvature=meta["fixed_curvature"])
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    key = f"{name}/f32/"
+    eng = _engine(dev, meta)
+    eng.load_state(state0)
+    x = synthetic.binary_batches(1, meta["batch"], meta["in_dim"])[0].to(dev)
+    eps = synthetic.eps_batches(1, meta["batch"], spec.total_true_dim)[0].to(dev)
+    out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
+    assert_close(_cpu(out["concat_z"]), g[key + "concat_z"], RTOL, "concat_z")
+    assert_close(_cpu(out["bce"]), g[key + "bce_rows"], RTOL, "bce rows")
+    assert_close(_cpu(out["kl"]), g[key + "kl_rows"], RTOL, "kl rows", atol_frac=1e-4)
+    ref = g[key + "logits_summary"]
+    assert_close(summary_of(_cpu(out["logits"]), ref), ref, RTOL, "logits summary")
+    for n, t in eng.grad_views().items():
+        if key + "grad_summary/" + n in g:
+            ref = g[key + "grad_summary/" + n]
+            assert_close(summary_of(_cpu(t), ref), ref, RTOL, "grad " + n, atol_frac=1e-4)
+    eng.optimizer_step(True)
+    st = eng.read_stats()["last"]
+    for got, want, nm in zip([st["bce"], st["kl"], st["elbo"]], g[key + "stats"][0][:3], ["bce", "kl", "elbo"]):
+        assert_close(got, want, RTOL, nm)
+    for n, t in eng.param_views().items():
+        ref = g[key + "state1_summary/" + n]
+        assert_close(summary_of(_cpu(t), ref), ref, 2e-4, "param " + n, atol_frac=2e-4)
+
+
 def test_fused_step_matches_oracle_other_batch_sizes(dev):
     """Ragged last batch (B not a multiple of 16) and B=256, against the oracle on the same seeded inputs."""
     from mvae_amd import synthetic

@@ -252,6 +252,47 @@ def test_train_step_full_size_f32(name):
             assert_close(summary_of(p.detach().numpy(), ref), ref, rt, "final " + n, atol_frac=1e-4)
 
 
+# ------------------------------------------------------------------------------------------------ G8 (full size, extra)
+EXTRA = load_json("g8_full_size_extra.json")
+
+
+@pytest.mark.parametrize("dname", ["f32", "f64"])
+@pytest.mark.parametrize("name", sorted(EXTRA))
+def test_train_step_full_size_extra(name, dname):
+    """The oracle against one reference step of BASELINE config [4] at its real batch (B = 256) and of the reference's
+    large-component models `h40` / `s40` at the benchmark size: float64 to 1e-9, float32 to 1e-4."""
+    g = load_npz("g8_full_size_extra.npz")
+    meta = EXTRA[name]
+    spec = M.Spec(meta["model"], in_dim=meta["in_dim"], h_dim=meta["h_dim"], arch=meta["arch"],
+                  fixed_curvature=meta["fixed_curvature"])
+    dt = torch.float32 if dname == "f32" else torch.float64
+    rt = 1e-4 if dname == "f32" else 1e-9
+    tconv = ("d1", "d2", "d3") if meta["arch"] == "conv" else ()
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0, dtype=dt, transposed_conv=tconv)
+    gen = synthetic.uniform_batches if meta["soft_targets"] else synthetic.binary_batches
+    key = f"{name}/{dname}/"
+    x = gen(1, meta["batch"], meta["in_dim"], dtype=dt)[0]
+    eps = synthetic.eps_batches(1, meta["batch"], spec.total_true_dim, dtype=dt)[0]
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    orc = M.StepOracle(spec, state0, dtype=dt)
+    orc.begin_epoch(meta["epoch"])
+    out = orc.train_step(x, eps, beta=1.0, epoch=meta["epoch"])
+    st = g[key + "stats"][0]
+    for got, want, nm in zip([out.bce.sum(), out.kl.sum(), out.elbo], st[:3], ["bce", "kl", "elbo"]):
+        assert_close(float(got), want, rt, nm)
+    assert_close(out.concat_z.detach().numpy(), g[key + "concat_z"], rt, "concat_z")
+    assert_close(out.bce.detach().numpy(), g[key + "bce_rows"], rt, "bce rows")
+    assert_close(out.kl.detach().numpy(), g[key + "kl_rows"], rt, "kl rows", atol_frac=rt)
+    ref = g[key + "logits_summary"]
+    assert_close(summary_of(out.logits.detach().numpy(), ref), ref, rt, "logits summary")
+    for n, p in orc.P.items():
+        if key + "grad_summary/" + n in g:
+            ref = g[key + "grad_summary/" + n]
+            assert_close(summary_of(p.grad.numpy(), ref), ref, rt, "grad " + n, atol_frac=rt)
+        ref = g[key + "state1_summary/" + n]
+        assert_close(summary_of(p.detach().numpy(), ref), ref, max(rt, 1e-7), "param " + n, atol_frac=max(rt, 1e-7))
+
+
 # ------------------------------------------------------------------------------------------------ G4 log-likelihood
 @pytest.mark.parametrize("dname", ["f32", "f64"])
 @pytest.mark.parametrize("name,model", [("h2s2e2", "h2,s2,e2"), ("e6", "e6"), ("h5s3e4", "h5,s3,e4")])
