@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 UNITS = ["mvae_api", "mvae_step", "mvae_conv", "mvae_peer", "mvae_rccl"]
-HEADERS = [os.path.join(CSRC, h) for h in ("mvae_common.hpp", "mvae_math.hpp", "mvae_gemm.hpp", "mvae_fastmath.hpp", "mvae_step_blk.hpp")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("mvae_common.hpp", "mvae_math.hpp", "mvae_gemm.hpp", "mvae_fastmath.hpp", "mvae_step_blk.hpp", "mvae_coop.hpp")] + \
           [os.path.join(os.path.dirname(HERE), "include", "mvae_hip.h")]
 DEPS = [os.path.join(CSRC, u + ".hip") for u in UNITS] + HEADERS
 LIB = os.path.join(HERE, "libmvae_hip.so")

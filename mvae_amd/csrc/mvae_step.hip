@@ -19,6 +19,7 @@
 // Further down: manifold primitives, component operators, generic dense layers, log-likelihood helpers and the
 // patch-matrix gathers of the conv architecture -- the rest of the C ABI.
 #include "mvae_common.hpp"
+#include "mvae_coop.hpp"
 #include "mvae_step_blk.hpp"
 
 // ================================================================================================ the fused step
@@ -37,6 +38,7 @@ struct mvae_ctx {
   bool no_blk;           // MVAE_NO_BLK=1: per-row latent kernels for many-component models too (A/B measurements)
   bool blk_small;        // MVAE_BLK_SMALL=1: the block backward kernel also for z_dim <= 16 (the fused-forward configs)
   bool blk_fwd;          // block kernels in the forward launches as well (MVAE_BLK_FWD=0: per-row forward, A/B measurements)
+  bool coop;             // large components (true dim >= 9, kinds h / s / e): wave-cooperative kernels (MVAE_NO_COOP=1: off)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
@@ -151,6 +153,8 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   const char* bf = getenv("MVAE_BLK_FWD");
   c->blk_fwd = !(bf && bf[0] == '0');
   c->groups_ok = build_groups(c->t, &c->gt);
+  const char* nc = getenv("MVAE_NO_COOP");
+  c->coop = bucket_of(c->dmax) > 8 && coop_eligible(c->t) && !(nc && nc[0] && nc[0] != '0');
   carve(c, bucket_of(c->dmax));
   // the only device access of create, and only for models that take the block kernels
   if (uses_blk_bwd(c, true) && (rc = upload_dirtab(c)) != 0) {
@@ -236,7 +240,9 @@ __host__ __device__ inline int heads_parts(int NH) {
 // latency-bound, so rows are spread over as many CUs as possible, every global operand is requested in the first
 // instructions of the kernel (one memory round trip), and the small reductions are wavefront shuffles.
 // FAST: NH <= 16, Z <= 8, H <= 512 (operands of all phases are held in registers from the start).
-template <int DMAX, bool FAST>
+// COOP: large components on the wave-cooperative form (mvae_coop.hpp); the per-lane component code (whose vectors live in
+// scratch memory beyond d = 8) is not instantiated then, so the kernel needs no scratch at all.
+template <int DMAX, bool FAST, bool COOP = false>
 __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h, const float* Wh, const float* bh,
                                                     const float* eps, int eps_ld, const float* radii, const float* Wd0,
                                                     const float* bd0, float* heads, int ldh, float* z, int ldz,
@@ -265,7 +271,8 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   // therefore runs HERE, on waves 4..7, next to the primal lanes of waves 0..3 (wave 4+w takes the components placed
   // on wave w), instead of on the critical path of launch 5, which only contracts the stored records with dz.
   // Record layout: duals[row][first_dir(ci) + dir][{d kl, d z_0 .. d z_{A-1}}].
-  if (tid >= 256) {
+  if (COOP && tid >= 256) return;  // large components: the records come from k_duals_coop (one WAVE per (row, direction))
+  if (!COOP && tid >= 256) {
     // as many barriers as the main path executes up to "heads_s final": 2 in the prologue, then 2 (register-resident
     // path) or 2 per round of the generic heads contraction + 1
     int nbar = 4;
@@ -292,7 +299,8 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
         }
         const mvae_component_desc& c = desc_s[ci];
         float zd[AM];
-        const float kld = comp_dual_dir<DMAX>(c, heads_s, eps_s, rad_s, rem, zd);
+        float kld = 0.f;
+        if constexpr (!COOP) kld = comp_dual_dir<DMAX>(c, heads_s, eps_s, rad_s, rem, zd);
         float* rec = duals + ((size_t)row * (NH + t.n) + first_s[ci] + rem) * DS;
         const int A = ambient_dim(c.kind, c.true_dim);
         rec[0] = kld;
@@ -445,8 +453,30 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   lds_barrier();
   MV_STAMP(2);
 
-  // ---- latent components: one lane per component, placed by fill_table (kinds on different waves)
-  {
+  // ---- latent components.  Large true dimensions (coop): one WAVE per component, lane i = entry i of the ambient vectors
+  // (mvae_coop.hpp); otherwise one lane per component, placed by fill_table (kinds on different waves)
+  if constexpr (COOP) {
+    for (int ci = wave; ci < t.n; ci += 4) {
+      const mvae_component_desc c = desc_s[ci];
+      const int d = c.true_dim, j = lane - 1;
+      const bool act = lane >= 1 && lane <= d;
+      const float m = act ? heads_s[c.mean_col + j] : 0.f;
+      const float l = act ? heads_s[c.logvar_col + (c.logvar_dim == 1 ? 0 : j)] : 0.f;
+      const float e = act ? eps_s[c.eps_col + j] : 0.f;
+      const float rp = c.kind == kEuclidean ? 0.f : rad_s[c.radius_idx];
+      float zl = 0.f, klv = 0.f;
+      (void)coop_eval<float>(c.kind, m, l, e, rp, d, lane, &zl, &klv);
+      const int idx = c.kind == kEuclidean ? j : lane;
+      if (idx >= 0 && idx < ambient_dim(c.kind, d)) {
+        z_s[c.z_col + idx] = zl;
+        z[row * ldz + c.z_col + idx] = zl;
+      }
+      if (lane == 0) {
+        kl[(size_t)ci * B + row] = klv;
+        if (kl_user) kl_user[(size_t)ci * B + row] = klv;
+      }
+    }
+  } else {
     const int ci = comp_at_s[wave][lane];
     if (ci >= 0) {
       float klv;
@@ -505,6 +535,37 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   }
   MV_STAMP(4);
   MV_SPAN_END(1, 1);
+}
+
+// ---- forward-mode dual records of LARGE components: one WAVE per (row, active input direction) evaluates the component
+// over dual numbers in the lane-distributed form of mvae_coop.hpp and writes {d kl, d z_0 .. d z_{A-1}} -- what the dual
+// waves of k_latent_fwd produce with one lane per record, whose 41-entry vectors (h40) live in scratch memory there.
+__global__ __launch_bounds__(512) void k_duals_coop(CompTable t, const float* heads, int ldh, const float* eps, int eps_ld,
+                                                    const float* radii, float* duals, int NH, int DS, int ngroups) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = (int)blockIdx.x / ngroups, grp = (int)blockIdx.x - row * ngroups;
+  const int gd = __builtin_amdgcn_readfirstlane(grp * 8 + wave);
+  if (gd >= t.total_dirs) return;
+  int ci = 0;
+  while (gd >= t.dir_off[ci + 1]) ++ci;
+  const int dir = gd - t.dir_off[ci];
+  const mvae_component_desc c = t.c[ci];
+  const int d = c.true_dim, lvd = c.logvar_dim, j = lane - 1;
+  const bool act = lane >= 1 && lane <= d;
+  const float* hrow = heads + (size_t)row * ldh;
+  const float mv_ = hrow[c.mean_col + (act ? j : 0)];
+  const float lv_ = hrow[c.logvar_col + ((act && lvd != 1) ? j : 0)];
+  const float ev_ = eps[(size_t)row * eps_ld + c.eps_col + (act ? j : 0)];
+  const float rv_ = c.kind == kEuclidean ? 0.f : radii[c.radius_idx];
+  const Dual m{act ? mv_ : 0.f, (act && dir == j) ? 1.f : 0.f};
+  const Dual l{act ? lv_ : 0.f, (act && (lvd == 1 ? dir == d : dir == d + j)) ? 1.f : 0.f};
+  const Dual rp{rv_, dir == d + lvd ? 1.f : 0.f};
+  Dual zl{0.f, 0.f}, klv{0.f, 0.f};
+  (void)coop_eval<Dual>(c.kind, m, l, act ? ev_ : 0.f, rp, d, lane, &zl, &klv);
+  float* rec = duals + ((size_t)row * (NH + t.n) + t.first_dir[ci] + dir) * DS;
+  const int idx = c.kind == kEuclidean ? j : lane;
+  if (idx >= 0 && idx < ambient_dim(c.kind, d)) rec[1 + idx] = zl.d;
+  if (lane == 0) rec[0] = klv.d;
 }
 
 // ---- 2+3 fused (the BASELINE MLP shapes): heads -> latent components -> first decoder layer -> output layer + BCE in ONE
@@ -1854,12 +1915,33 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   {
     ki = 1;
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
-#define LF(DM, FA)                                                                                                   \
-  STEP_LAUNCH((k_latent_fwd<DM, FA>), dim3(B), dim3(512), lds, c->t, h, P + d.off_w_heads,                 \
+    // large components (d >= 9; h, s, e only): the components of launch 2 one WAVE each, the dual records by one more
+    // launch of one wave per (row, direction) -- instead of one lane each over scratch-resident vectors
+    const bool coop = c->coop;
+    hipEvent_t ev_stop = nullptr;
+    if (coop && ev) {  // one profile slot for the two launches: start event on the first, stop event on the second
+      ev_stop = ev[2 * ki + 1];
+      ev[2 * ki + 1] = nullptr;
+    }
+#define LF(DM, FA, CO)                                                                                               \
+  STEP_LAUNCH((k_latent_fwd<DM, FA, CO>), dim3(B), dim3(CO ? 256 : 512), lds, c->t, h, P + d.off_w_heads,            \
                      P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
                      c->ldh, z, c->ldz, concat_z, klw, kl, hd, B, H, NH, Z, duals)
-    if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true)); } else { DMAX_SWITCH(c->dmax, LF(DM, false)); }
+    if (coop) { if (fast) LF(2, true, true); else LF(2, false, true); }
+    else if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true, false)); } else { DMAX_SWITCH(c->dmax, LF(DM, false, false)); }
 #undef LF
+    if (coop) {
+      const int ngroups = (c->t.total_dirs + 7) / 8;
+      const int DSr = dual_stride(bucket_of(c->dmax));
+      if (ev) {
+        ev[2 * ki + 1] = ev_stop;
+        hipExtLaunchKernelGGL(k_duals_coop, dim3(B * ngroups), dim3(512), 0, s, nullptr, ev_stop, 0, c->t, heads, c->ldh,
+                              eps, d.eps_dim, P + d.off_radii, duals, NH, DSr, ngroups);
+      } else {
+        hipLaunchKernelGGL(k_duals_coop, dim3(B * ngroups), dim3(512), 0, s, c->t, heads, c->ldh, eps, d.eps_dim,
+                           P + d.off_radii, duals, NH, DSr, ngroups);
+      }
+    }
   }
   ki = 2;
   if (full)

@@ -389,6 +389,51 @@ def test_large_component_step_vs_the_reference(dev, name):
         assert_close(summary_of(_cpu(t), ref), ref, 2e-4, "param " + n, atol_frac=2e-4)
 
 
+@pytest.mark.parametrize("model,scalar,B", [("h12,s20,e9", False, 48), ("h10,s10", True, 37), ("e33,h63", False, 16)])
+def test_wave_cooperative_components_vs_oracle(dev, model, scalar, B, monkeypatch):
+    """Large true dimensions (d >= 9) run on the wave-cooperative kernels (mvae_coop.hpp: one wave per (row, component
+    [, input direction]), lane = vector entry): outputs, every gradient (heads, radii) and the updated parameters against
+    the oracle, full and scalar parametrisation, ragged batches, d up to 63; and against the one-lane-per-record kernels
+    (MVAE_NO_COOP=1), which evaluate the same formulas with index-order sums."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    spec = M.Spec(model, in_dim=784, h_dim=400, fixed_curvature=False, scalar_parametrization=scalar)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, 784)[0]
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+    comps = [(c.letter, c.true_dim) for c in spec.components]
+
+    def run(no_coop):
+        if no_coop:
+            monkeypatch.setenv("MVAE_NO_COOP", "1")
+        else:
+            monkeypatch.delenv("MVAE_NO_COOP", raising=False)
+        eng = StepEngine(comps, 784, 400, dev, scalar_parametrization=scalar, radius_trainable=[True] * len(comps))
+        eng.load_state(state0)
+        out = eng.forward_backward(x.to(dev), eps.to(dev), 0.7, want_outputs=True)
+        out = {k: _cpu(v) for k, v in out.items()}
+        out["grads"] = {n: _cpu(t).copy() for n, t in eng.grad_views().items()}
+        eng.optimizer_step(True)
+        return eng, out
+
+    eng, out = run(False)
+    assert_close(out["concat_z"], ref.concat_z.detach().numpy(), RTOL, "concat_z")
+    assert_close(out["kl"], ref.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    assert_close(out["bce"], ref.bce.detach().numpy(), RTOL, "bce")
+    for n, gnp in out["grads"].items():
+        if orc.P[n].grad is not None:
+            assert_close(gnp, orc.P[n].grad.numpy(), 2 * RTOL, "grad " + n, atol_frac=2e-4)
+    for n, t in eng.param_views().items():
+        assert_close_after_adam(_cpu(t), orc.P[n].detach().numpy(), 1e-3, 1, f"param {n}")
+    _, out_l = run(True)
+    assert_close(out["concat_z"], out_l["concat_z"], 1e-5, "z coop vs lane", atol_frac=1e-5)
+    for n in out["grads"]:
+        assert_close(out["grads"][n], out_l["grads"][n], 2e-4, f"grad {n} coop vs lane", atol_frac=2e-4)
+
+
 def test_fused_step_matches_oracle_other_batch_sizes(dev):
     """Ragged last batch (B not a multiple of 16) and B=256, against the oracle on the same seeded inputs."""
     from mvae_amd import synthetic
