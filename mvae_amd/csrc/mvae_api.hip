@@ -75,21 +75,23 @@ __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const fl
     return;
   }
   const int col = (int)blockIdx.x * 32 + c * 4;
-  f32x4 wr[NN], acc[NN];
+  // Latency, not bandwidth, bounds this kernel (one wave per SIMD, 16 MB moved): EVERY request of a 256-row chunk -- the
+  // dy block, the W columns, the 8 rows of x -- is issued before the first use, so a chunk costs one memory round trip.
+  f32x4 acc[NN], wr[NN];
 #pragma unroll
   for (int n = 0; n < NN; ++n) {
-    wr[n] = *reinterpret_cast<const f32x4*>(W + (size_t)(n < N ? n : 0) * K + col);
-    if (n >= N) wr[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wr[n] = *reinterpret_cast<const f32x4*>(W + (size_t)(n < N ? n : 0) * K + col);
   }
+  constexpr int kDyPer = NN;  // 256 rows x NN entries / 256 threads
   for (int m0 = 0; m0 < M; m0 += 256) {
     const int rows = (M - m0) < 256 ? (M - m0) : 256;
-    __syncthreads();
-    for (int e = tid; e < 256 * NN; e += 256) {
-      const int r = e / NN, n = e - r * NN;
-      dy_s[r][n] = (r < rows && n < N) ? dy[(size_t)(m0 + r) * N + n] : 0.f;
+    float dyv[kDyPer];
+#pragma unroll
+    for (int q = 0; q < kDyPer; ++q) {
+      const int e = tid + 256 * q, r = e / NN, n = e - r * NN;
+      dyv[q] = dy[(size_t)(m0 + (r < rows ? r : 0)) * N + (n < N ? n : 0)];
     }
-    __syncthreads();
     f32x4 xv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -97,6 +99,13 @@ __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const fl
       xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + (r < rows ? r : 0)) * K + col);
     }
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // the previous chunk's readers of dy_s are done
+#pragma unroll
+    for (int q = 0; q < kDyPer; ++q) {
+      const int e = tid + 256 * q, r = e / NN, n = e - r * NN;
+      dy_s[r][n] = (r < rows && n < N) ? dyv[q] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int r = g + 32 * u;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const fl
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acc[n4 + j] += d[j] * xv[u];
-          dxv += d[j] * wr[n4 + j];
+          if (n4 + j < N) dxv += d[j] * wr[n4 + j];  // (uniform; rows of W past N were clamped to row 0)
         }
       }
       if (dx) {
@@ -121,12 +130,11 @@ __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const fl
     }
   }
 #pragma unroll
-  for (int n = 0; n < NN; ++n) {
-    if (n >= N) break;
+  for (int n = 0; n < NN; ++n) {  // (no early exit: a `break` keeps the loop rolled and acc[] in scratch memory)
     __syncthreads();
     sm[g][c] = acc[n];
     __syncthreads();
-    if (g == 0) {
+    if (g == 0 && n < N) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < 32; ++q) t += sm[q][c];
       *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col) = t;

@@ -107,6 +107,7 @@ class StepEngine:
         self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
         self._last_batch: Optional[int] = None
+        self.grads_from_engine = False  # the flat gradient buffer was filled by forward_backward(), not through p.grad
         # bumped whenever the contexts (workspace pointers, lr baked into kernel arguments) are rebuilt: anything that
         # captured launches of this engine into a HIP graph must re-capture when it changes
         self.generation = 0
@@ -227,6 +228,7 @@ class StepEngine:
             out = {"logits": lo, "concat_z": cz, "bce": bce, "kl": kl}
         check(load().mvae_step_forward_backward(ctx, ptr(x), ptr(eps), float(beta), 1 if want_outputs else 0, ptr(lo),
                                                 ptr(cz), ptr(bce), ptr(kl), stream_ptr(self.device)))
+        self.grads_from_engine = True  # CurvatureOptimizer.step uses the flat gradient buffer as it is
         return out
 
     HEAD, TAIL = 1, 2  # MVAE_STEP_HEAD / MVAE_STEP_TAIL
@@ -247,6 +249,7 @@ class StepEngine:
             batch = self._last_batch if self._last_batch is not None else (next(iter(self._ctx)) if self._ctx else 1)
         ctx = self._context(batch)
         check(load().mvae_step_optimizer(ctx, 1 if do_curvature_step else 0, stream_ptr(self.device)))
+        self.grads_from_engine = False
 
     def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
         B = self._check_inputs(x, eps)

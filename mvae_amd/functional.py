@@ -554,7 +554,9 @@ class _BceFn(torch.autograd.Function):
 def bce_with_logits_rows(logits: Tensor, x: Tensor) -> Tensor:
     """Differentiable reconstruction loss summed over the pixels (image_reconstruction.py:81-82, vae.py:131); x has the
     shape of logits (training path) or is broadcast over leading sample dims (evaluation, no grad)."""
-    if torch.is_grad_enabled() and logits.requires_grad and x.shape == logits.shape:
+    if torch.is_grad_enabled() and logits.requires_grad:
+        if x.shape != logits.shape:  # targets broadcast over leading sample dims: the gradient must still flow
+            x = x.expand(logits.shape).contiguous()
         return _BceFn.apply(logits, x)
     return bce_rows(logits.detach(), x)
 

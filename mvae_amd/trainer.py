@@ -45,6 +45,7 @@ class CurvatureOptimizer:
             return
         eng = self._model.engine
         eng.grads.zero_()
+        eng.grads_from_engine = False
         gviews = eng.grad_views()
         for name, p in self._model.named_parameters():
             if p.requires_grad:
@@ -56,15 +57,28 @@ class CurvatureOptimizer:
         `zero_grad(set_to_none=True)`) are gathered first."""
         model = self._model
         eng = model._need_engine()
-        gviews = eng.grad_views()
+        if getattr(eng, "grads_from_engine", False):
+            # the engine's own forward_backward() filled the flat gradient buffer (p.grad is not involved): use it as it is
+            eng.optimizer_step(self.curv_condition())
+            return
+        gviews, pviews = eng.grad_views(), eng.param_views()
+        mviews, vviews = eng.flat.views(eng.adam_m), eng.flat.views(eng.adam_v)
+        skipped = []
         for name, p in model.named_parameters():
             v = gviews[name]
             if p.grad is None:
+                # torch.optim.Adam / SGD SKIP a parameter without a gradient: neither the parameter nor its moments move.
+                # The optimizer here is one kernel over the flat buffers, so such a parameter is put back afterwards.
                 v.zero_()
+                skipped.append((name, pviews[name].clone(), mviews[name].clone(), vviews[name].clone()))
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad.reshape(v.shape))
                 p.grad = v
         eng.optimizer_step(self.curv_condition())
+        for name, p0, m0, v0 in skipped:
+            pviews[name].copy_(p0)
+            mviews[name].copy_(m0)
+            vviews[name].copy_(v0)
 
 
 class Trainer:

@@ -544,3 +544,58 @@ def test_eager_sequence_survives_zero_grad_set_to_none(dev):
     opt.step()
     for name, p in model.named_parameters():
         assert_close(_cpu(p), g[k + "state1/" + name], RTOL, "param after step " + name)
+
+
+def test_optimizer_skips_parameters_without_a_gradient(dev):
+    """torch.optim.Adam (the reference's optimizer, train.py:327-360) skips a parameter whose .grad is None: neither the
+    parameter nor its moments move.  Here only the decoder takes part in the loss; the encoder and the heads must stay
+    exactly where they were, moments included, while the decoder is updated."""
+    from mt.mvae import utils
+    from mt.mvae.models import FeedForwardVAE, Trainer
+    case = "h2s2e2_learn_ep12"
+    meta = load_json("g3_step_small.json")[case]
+    g = load_npz("g3_step_small.npz")
+    k = f"{case}/f32/steps1/"
+    state0 = {n[len(k + "state0/"):]: T(v) for n, v in g.items() if n.startswith(k + "state0/")}
+    model = FeedForwardVAE(meta["h_dim"], utils.parse_components(meta["model"], False), _DS(meta["in_dim"]), False)
+    model.load_state_dict(state0)
+    model.to(dev)
+    trainer = Trainer(model, chkpt_dir="/tmp/mvae_test_chkpt_skip")
+    trainer.epoch = meta["epoch"]
+    opt = trainer.build_optimizer(learning_rate=1e-3, fixed_curvature=False)
+    eng = model.engine
+    eng.adam_m.fill_(0.25)  # momentum that WOULD move a parameter if the optimizer touched it
+    eng.adam_v.fill_(0.5)
+    model.zero_grad(set_to_none=True)
+    z = torch.randn(8, eng.layout.z_dim, device=dev)
+    x = (torch.rand(8, meta["in_dim"], device=dev) > 0.5).float()
+    from mvae_amd import functional as Fn
+    loss = Fn.bce_with_logits_rows(model.decode(z), x).sum()
+    loss.backward()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    m_before = eng.adam_m.clone()
+    opt.step()
+    mv = eng.flat.views(eng.adam_m)
+    mb = eng.flat.views(m_before)
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert torch.equal(p.detach(), before[n]), f"{n} moved without a gradient"
+            assert torch.equal(mv[n], mb[n]), f"moments of {n} changed"
+        else:
+            assert not torch.equal(p.detach(), before[n]), f"{n} has a gradient but did not move"
+    assert any(p.grad is None for _, p in model.named_parameters()) and any(
+        p.grad is not None for _, p in model.named_parameters())
+
+
+def test_bce_gradient_flows_with_broadcast_targets(dev):
+    """x broadcast over a leading sample dimension (the log-likelihood path's shapes) while the logits require grad: the
+    loss must keep its grad_fn, and the gradient equals sigmoid(logits) - x."""
+    from mvae_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(3, 5, 32, generator=g).to(dev).requires_grad_(True)
+    x = torch.rand(5, 32, generator=g).to(dev)
+    loss = Fn.bce_with_logits_rows(logits, x)
+    assert loss.grad_fn is not None and loss.shape == (3, 5)
+    loss.sum().backward()
+    ref = torch.sigmoid(logits.detach().double()) - x.double()
+    assert_close(_cpu(logits.grad), ref.cpu().numpy(), 2e-5, "d bce / d logits", atol_frac=1e-5)

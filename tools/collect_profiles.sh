@@ -8,8 +8,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline"
-PMCB="python $ROOT/bench.py --steps 300 --warmup 50 --graph-steps 0 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-extra-configs"
+PMCB="python $ROOT/bench.py --steps 300 --warmup 50 --graph-steps 0 --no-cpu-baseline --no-extra-configs"
 cd /tmp
 # 1. kernel trace + stats (graph replays, as bench.py runs by default)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o bench -- $BENCH > $OUT/ktrace.log 2>&1
@@ -24,10 +24,13 @@ timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc
 timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma_conv -o conv -- python $ROOT/tools/bench_conv.py 256 5 > $OUT/pmc_mfma_conv.log 2>&1
 cd $ROOT
 # 5. the un-profiled bench lines of the same build
-timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
-timeout 600 python bench.py --no-cpu-baseline --model 6h2,6s2,6e2 > $OUT/bench_prod36.json 2>&1   # learnable curvature, as golden mnist_prod36_learn
+timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err   # the default invocation: configs [1] + the legs of [0], [3], [4] + CPU rows
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err   # as the driver calls it
+timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model 6h2,6s2,6e2 > $OUT/bench_prod36.json 2>&1   # learnable curvature, as golden mnist_prod36_learn
 timeout 600 python bench.py --no-cpu-baseline --config conv > $OUT/bench_conv.json 2>&1
-timeout 600 python bench.py --no-cpu-baseline --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --force-dp > $OUT/bench_forced_dp.json 2>&1   # world 1, exchange forced (librccl)
+timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model h40 --steps 500 --warmup 50 > $OUT/bench_h40.json 2>&1
 # keep only the small summaries (the traces are large)
 find $OUT -name '*kernel_trace.csv' -size +20M -delete
 ls -la $OUT $OUT/*/ 2>/dev/null | head -60

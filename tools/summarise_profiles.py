@@ -44,7 +44,8 @@ for sub, out in (("ktrace/**/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"
     if f:
         shutil.copy(f, os.path.join(dst, out))
         print("copied", out)
-for name in ("bench_line.json", "bench_prod36.json", "bench_e6.json", "bench_conv.json"):
+for name in ("bench_line.json", "bench_driver.json", "bench_prod36.json", "bench_e6.json", "bench_conv.json",
+             "bench_forced_dp.json", "bench_h40.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
