@@ -18,6 +18,9 @@
 // Nothing here synchronises or allocates, so the host layer can capture any number of steps into one HIP graph.
 // Further down: manifold primitives, component operators, generic dense layers, log-likelihood helpers and the
 // patch-matrix gathers of the conv architecture -- the rest of the C ABI.
+#ifndef MV_PREFETCH_WGS
+#define MV_PREFETCH_WGS 0  // L2 prefetch workgroups of k_fwd23 (an experiment, see the kernel)
+#endif
 #include "mvae_common.hpp"
 #include "mvae_coop.hpp"
 #include "mvae_step_blk.hpp"
@@ -613,12 +616,34 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   // to themselves (208 workgroups on 256 CUs) and finish well inside the launch.
   const int n_dual = B >> 4;  // dispatched FIRST (the longest job); a multiple of 8 keeps workgroup L on XCD L % 8
   const bool is_dual = (int)blockIdx.x < n_dual;
+#ifndef MV_PREFETCH_WGS
+#define MV_PREFETCH_WGS 0
+#endif
+  constexpr int n_pref = MV_PREFETCH_WGS;  // 0 or 48 (a multiple of 8): see below
+  if (n_pref > 0 && !is_dual && (int)blockIdx.x < n_dual + n_pref) {
+    // L2 PREFETCH workgroups (an experiment: MV_PREFETCH_WGS=48, the CUs the tile workgroups leave free).  The weights were
+    // written write-through by the previous step's optimizer epilogues, so the first reader of a line in this launch
+    // fetches it over the fabric.  Prefetcher j runs on XCD j % 8 and touches one 16-row block of W_logits that THIS
+    // XCD's tile workgroups stage ~2.5 us into the launch (pairs x, x + 8, x + 16 of XCD x), plus W_d0.
+    const int j = (int)blockIdx.x - n_dual, xk = j & 7, part = j >> 3;  // part 0..5
+    const int tile = (xk + 8 * (part >> 1)) * 2 + (part & 1);
+    const f32x4* src = reinterpret_cast<const f32x4*>(Wl + (size_t)tile * 16 * H);
+    const int n4 = 4 * H;  // 16 rows x H / 4 vectors
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < n4; e += 512) sink += src[e];
+    if (part == 0) {
+      const f32x4* wd = reinterpret_cast<const f32x4*>(Wd0);
+      for (int e = tid; e < (H * Z) >> 2; e += 512) sink += wd[e];
+    }
+    asm volatile("" ::"v"(sink));
+    return;
+  }
   if (is_dual) mt = (int)blockIdx.x;
   else {
     // XCD-aware without padding workgroups (a padding workgroup holds its CU's LDS allocation long enough to push a
     // real one into a second round): the first 8 * floor(ntP / 8) pairs are dealt to the XCDs as in xcd_tile, the
     // remaining pairs' workgroups follow in plain order (their W_logits rows are fetched by several XCDs: 50 KB each).
-    const int L = (int)blockIdx.x - n_dual, MT = B >> 4;
+    const int L = (int)blockIdx.x - n_dual - n_pref, MT = B >> 4;
     const int full = (ntP >> 3) << 3;
     if (L < full * MT) (void)xcd_tile(full, MT, &pt, &mt, L);
     else {
@@ -1886,7 +1911,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       lds_set = lds;                                                                                                 \
     }                                                                                                                \
   }                                                                                                                  \
-  STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b), dim3(512), lds, c->t, h, P + d.off_w_heads,                    \
+  STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b + MV_PREFETCH_WGS), dim3(512), lds, c->t, h, P + d.off_w_heads,  \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
               NH, Z, duals)
