@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 6
+#define MVAE_ABI_VERSION 7
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -316,6 +316,34 @@ int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, f
 /* BatchStats (stats.py:144-212): adds sum_b bce, sum_b kl_i, sum_b(-bce - beta*sum_i kl_i) to the statistics record
  * (same layout as mvae_model_desc.stats). */
 int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp, void* stream);
+/* The loss end of the conv step in one launch: mvae_bce_forward_backward + mvae_batch_stats (vae.py:125-147) + the bias
+ * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
+ * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first
+ * call and are left 0 by every call (arrival counters of the workgroups; the last one to finish performs the two
+ * batch-wide sums in a fixed order, so results do not depend on the arrival order). */
+int mvae_conv_bce_stats(const float* logits, const float* x, float* bce, float* g, const float* kl, float* stats,
+                        float beta, int64_t B, int D, int HW, int ncomp, float* chan_part, float* dbias,
+                        int32_t* counter, void* stream);
+/* The latent section of the conv architecture, conv_vae.py:65-71: the encoder's flatten -> fc_mean / fc_logvar of every
+ * component (component.py:52-57) -> rsample + KL (component.py:59-78) -> decoder fc + ReLU -> view(-1, 128, 4, 4), in two
+ * launches, and its backward in two.  a2 [B, 16, 512] and t0 [B, 16, 128] are the CHANNEL-LAST activations next to the
+ * convolutions; W_heads [heads_dim, 8192] (fc_mean rows of all components, then fc_logvar rows) and W_d0 [2048, z_dim]
+ * keep the reference's orders (column / row c * 16 + p).  Supported: heads_dim <= 16, z_dim <= 16, true dimensions <= 8
+ * (mvae_conv_latent_supported; other models use the generic operators above).  workspace:
+ * mvae_conv_latent_workspace_floats(B, ncomp) floats, 16-byte aligned, scratch of one call.  Forward writes heads [B, heads_dim], z [B, z_dim],
+ * kl [ncomp, B], t0.  Backward (loss = <dt0, t0> + beta * sum kl) writes dW_heads, db_heads, da2 (already masked by the
+ * encoder's last ReLU), dW_d0, db_d0, dradii [ncomp] (0 for Euclidean components; fixed-order sums) and dheads [B, heads_dim]. */
+int mvae_conv_latent_supported(const mvae_component_desc* comps, int ncomp);
+int64_t mvae_conv_latent_workspace_floats(int64_t B, int ncomp);
+int mvae_conv_latent_forward(const mvae_component_desc* comps, int ncomp, const float* a2, const float* W_heads,
+                             const float* b_heads, const float* eps, int eps_ld, const float* radii, const float* W_d0,
+                             const float* b_d0, float* heads, float* z, float* kl, float* t0, float* workspace,
+                             int64_t B, void* stream);
+int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const float* a2, const float* W_heads,
+                              const float* heads, const float* eps, int eps_ld, const float* radii, const float* z,
+                              const float* W_d0, const float* t0, const float* dt0, float beta, float* dW_heads,
+                              float* db_heads, float* da2, float* dW_d0, float* db_d0, float* dradii, float* dheads,
+                              float* workspace, int64_t B, void* stream);
 /* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable
  * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180.
  * radius_trainable[i]: 0 fixed, 1 trainable radius, 3 trainable universal curvature -- the entries marked 3 form the

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -90,6 +90,12 @@ PROTOTYPES = {
     "mvae_colsum": (C.c_int, [_P, _P, _L, _I, _P, _P]),
     "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
     "mvae_batch_stats": (C.c_int, [_P, _P, _P, _F, _I, _I, _P]),
+    "mvae_conv_bce_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "mvae_conv_latent_supported": (C.c_int, [_P, _I]),
+    "mvae_conv_latent_workspace_floats": (_L, [_L, _I]),
+    "mvae_conv_latent_forward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "mvae_conv_latent_backward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P,
+                                            _P, _P, _L, _P]),
     "mvae_optimizer_step_flat": (C.c_int, [_P, _P, _P, _P, _L, _P, _I, C.POINTER(C.c_uint8), C.c_double, C.c_double,
                                            _I, _P]),
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),

@@ -282,6 +282,20 @@ class ConvEngine:
         self.params, self.grads, self.adam_m, self.adam_v = z(P), z(P), z(P), z(P)
         self.counters = z(32, torch.int32)
         self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
+        self._arrive = z(32, torch.int32)  # arrival counters of mvae_conv_bce_stats (0 between launches)
+        # Backward pass on three HIP streams (MVAE_CONV_STREAMS=0: one): the backward-data chain is the critical path and
+        # stays on the caller's stream; every weight gradient depends on it only through ONE activation gradient and runs
+        # on side stream 0, the bias sums / re-orderings on side stream 1.  The streams fork and join through events, so a
+        # captured step becomes a HIP graph with parallel branches: the ramp-up and tail of a contraction (one round of
+        # workgroups: ~20 % of its duration) are filled by the workgroups of the other branch.
+        import os
+        # the latent section (flatten -> heads -> components -> decoder fc) and the loss end as fused launches
+        # (mvae_conv_latent_*, mvae_conv_bce_stats); MVAE_CONV_FUSED=0 or an unsupported model: the generic operators
+        self.fused = (os.environ.get("MVAE_CONV_FUSED", "1") != "0"
+                      and bool(load().mvae_conv_latent_supported(self.layout.descs, n)))
+        self.overlap = os.environ.get("MVAE_CONV_STREAMS", "0") == "1"
+        self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if self.overlap else []
+        self._forked: List[int] = []
 
     def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
         """0 fixed / 1 trainable radius / 3 trainable universal curvature (clip group), see mvae_optimizer_step_flat."""
@@ -313,6 +327,32 @@ class ConvEngine:
     def _w(self, name: str) -> Tensor:
         return self.param_views()[name]
 
+    # ---- side streams
+    def _branch(self, k: int, fn) -> None:
+        """Run `fn` (launches only) on side stream k, ordered after everything issued so far on the current stream.
+        Tensors the branch reads must stay referenced until `_join` (the caching allocator reuses a freed block on the
+        stream that allocated it without waiting for other streams)."""
+        if not self.overlap:
+            fn()
+            return
+        main = torch.cuda.current_stream(self.device)
+        side = self._side[k]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+        if k not in self._forked:
+            self._forked.append(k)
+
+    def _join(self) -> None:
+        main = torch.cuda.current_stream(self.device)
+        for k in self._forked:
+            ev = torch.cuda.Event()
+            ev.record(self._side[k])
+            main.wait_event(ev)
+        self._forked = []
+
     # ---- forward (keeps what backward needs)
     def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True):
         PV = self.param_views()
@@ -332,15 +372,30 @@ class ConvEngine:
         # channel-last (column p * 512 + c).  Re-ordering the head matrix (NH x 8192: 0.4 MB) instead of the activation
         # and its gradient (8 MB each) gives the same products.
         c["hflat"] = c["a2"].view(B, H_DIM)
-        c["w_heads_cl"], b_heads = self._heads_channel_last()
-        c["heads"] = _linear_splitk(c["hflat"], c["w_heads_cl"], b_heads)
-        co = Fn.component_forward(lay, c["heads"], eps, self.params[:lay.n], want_kl=want_kl,
-                                  want_log_probs=not want_kl, want_params=False)
-        c["z"], c["kl"], c["co"] = co["z"], co["kl"], co
-        zz = co["z"].reshape(-1, lay.z_dim)
-        R = zz.shape[0]
-        c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
-        c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
+        if self.fused and want_kl and eps.dim() == 2:
+            ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
+            c["heads"] = x.new_empty(B, NH)
+            c["z"], c["kl"] = x.new_empty(B, lay.z_dim), x.new_empty(lay.n, B)
+            c["t0"] = x.new_empty(B * 16, 128)
+            ws = x.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
+            eps = eps.contiguous()
+            check(load().mvae_conv_latent_forward(lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]),
+                                                  ptr(self.params[ob:ob + NH]), ptr(eps), eps.shape[1],
+                                                  ptr(self.params[:lay.n]), ptr(PV["d0.weight"]), ptr(PV["d0.bias"]),
+                                                  ptr(c["heads"]), ptr(c["z"]), ptr(c["kl"]), ptr(c["t0"]), ptr(ws), B,
+                                                  stream_ptr(self.device)))
+            c["co"], c["fused"] = None, True
+            R = B
+        else:
+            c["w_heads_cl"], b_heads = self._heads_channel_last()
+            c["heads"] = _linear_splitk(c["hflat"], c["w_heads_cl"], b_heads)
+            co = Fn.component_forward(lay, c["heads"], eps, self.params[:lay.n], want_kl=want_kl,
+                                      want_log_probs=not want_kl, want_params=False)
+            c["z"], c["kl"], c["co"] = co["z"], co["kl"], co
+            zz = co["z"].reshape(-1, lay.z_dim)
+            R = zz.shape[0]
+            c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
+            c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
         c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True)   # [R*64, 256]
         # (d2 and the backward-data of e2 keep the product + col2im form: measured 95 / 80 us against 98 / 96 us implicit,
         #  tools/bench_conv_gather.py; d1 and the backward-data of e1 gain 11 / 10 us each)
@@ -389,10 +444,19 @@ class ConvEngine:
         c = self._forward(x, eps)
         bce = x.new_empty(B)
         g = torch.empty_like(c["logits"])
-        check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
-                                               stream_ptr(self.device)))
-        check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
-                                      stream_ptr(self.device)))
+        if self.fused:
+            # BCE + its gradient, the batch statistics and the bias gradient of d3 (sum of g per channel) in one launch
+            chan = x.new_empty(B, 3)
+            check(load().mvae_conv_bce_stats(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats),
+                                             float(beta), B, 3072, 1024, lay.n, ptr(chan),
+                                             ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
+                                             stream_ptr(self.device)))
+            c["d3_bias_done"] = True
+        else:
+            check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
+                                                   stream_ptr(self.device)))
+            check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
+                                          stream_ptr(self.device)))
         PV, GV = self.param_views(), self.grad_views()
         # the final "add the slices" of every weight gradient / bias column sum below is queued and performed by ONE
         # launch at the end of the backward pass (nobody reads those gradients before the optimizer)
@@ -404,25 +468,71 @@ class ConvEngine:
             check(load().mvae_slice_sums_defer(0))
 
     def _backward(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
+        side = self._branch
+        try:
+            return self._backward_body(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side)
+        finally:
+            self._join()  # (also after an exception: a captured side stream must rejoin before the capture ends)
+
+    def _backward_body(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side):
+        # Every activation gradient below stays referenced by a local until the join at the end (see _branch).
         # ---- decoder backward
+        def d3_bias():
+            # d3.bias gradient = sum over (b, y, x) of g[b, c, y, x]: column sums over the batch first ([B, 3072] ->
+            # [3072]), then the 1024 pixels of each channel -- instead of permuting the whole gradient to [B * 1024, 3]
+            # (an INTERMEDIATE: read two lines below, so its slice sum -- B > 512 rows are summed in slices -- must not
+            # wait for the flush: deferral is suspended around it)
+            check(load().mvae_slice_sums_defer(2))
+            gpix = _colsum(g.view(B, 3072))
+            check(load().mvae_slice_sums_defer(1))
+            _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
+
+        if not c.get("d3_bias_done"):
+            side(1, d3_bias)
         dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
-        _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
-        # d3.bias gradient = sum over (b, y, x) of g[b, c, y, x]: column sums over the batch first ([B, 3072] -> [3072]),
-        # then the 1024 pixels of each channel -- instead of permuting the whole gradient to [B * 1024, 3]
-        # (an INTERMEDIATE: read two lines below, so its slice sum -- B > 512 rows are summed in slices -- must not wait
-        # for the flush: deferral is suspended around it)
-        check(load().mvae_slice_sums_defer(2))
-        gpix = _colsum(g.view(B, 3072))
-        check(load().mvae_slice_sums_defer(1))
-        _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
+        side(0, lambda: _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48)))
         db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
-        _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16)
-        _colsum(db2, out=GV["d2.bias"])
+        side(0, lambda: _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16))
+        side(1, lambda: _colsum(db2, out=GV["d2.bias"]))
         db1 = _conv_nhwc(db2, c["Wd2"], None, c["b1"], B, 64, 16, False)  # [B*64, 256], ReLU mask in the epilogue
-        _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8)
-        _colsum(db1, out=GV["d1.bias"])
+        side(0, lambda: _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8))
+        side(1, lambda: _colsum(db1, out=GV["d1.bias"]))
         dt0 = _conv_nhwc(db1, c["Wd1"], None, None, B, 256, 8, False)  # [B*16, 128]
+        NH = lay.heads_dim
+        ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
+        if c.get("fused"):
+            # decoder fc backward, the components, the heads' backward against the channel-last flatten: two launches
+            dhflat = torch.empty_like(c["hflat"])
+            dheads = dt0.new_empty(B, NH)
+            ws = dt0.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
+            epsc = eps.contiguous()
+            check(load().mvae_conv_latent_backward(
+                lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
+                epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
+                float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat),
+                ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
+                stream_ptr(self.device)))
+        else:
+            dhflat = self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay, side)
+        # ---- encoder backward (Conv2d backward-data = col2im)
+        da2 = dhflat.view(B * 16, 512)
+        side(0, lambda: _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8))
+        side(1, lambda: _colsum(da2, out=GV["e2.bias"]))
+        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
+        side(0, lambda: _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16))
+        side(1, lambda: _colsum(da1, out=GV["e1.bias"]))
+        da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False)    # [B*256, 64], ReLU mask of a0
+        side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
+        _colsum(da0, out=GV["e0.bias"])
+        self._join()
+        check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
+        _DEFERRED_WS.clear()
+        if want_outputs:
+            return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
+        return None
+
+    def _latent_backward_generic(self, c, dt0, eps, beta, PV, GV, B, lay, side):
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         _, _, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True,
                                       out_dW=GV["d0.weight"], out_db=GV["d0.bias"])
@@ -438,22 +548,9 @@ class ConvEngine:
         dW_cl = dheads.new_empty(NH, H_DIM)
         _, _, dhflat = Fn.linear_backward(c["hflat"], c["w_heads_cl"], dheads, relu_in=True, need_dx=True,
                                           out_dW=dW_cl, out_db=self.grads[ob:ob + NH])
-        _permute_rc(dW_cl.view(NH, 16, 512), NH, 16, 512, out=self.grads[ow:ow + NH * H_DIM])
-        # ---- encoder backward (Conv2d backward-data = col2im)
-        da2 = dhflat.view(B * 16, 512)
-        _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
-        _colsum(da2, out=GV["e2.bias"])
-        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
-        _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
-        _colsum(da1, out=GV["e1.bias"])
-        da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False)    # [B*256, 64], ReLU mask of a0
-        _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
-        _colsum(da0, out=GV["e0.bias"])
-        check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
-        _DEFERRED_WS.clear()
-        if want_outputs:
-            return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
-        return None
+        c["dW_cl"] = dW_cl  # (read on a side stream: alive until the join)
+        side(1, lambda: _permute_rc(dW_cl.view(NH, 16, 512), NH, 16, 512, out=self.grads[ow:ow + NH * H_DIM]))
+        return dhflat
 
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
         check(load().mvae_optimizer_step_flat(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),

@@ -46,100 +46,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float* x, const float*
   job_colsum(&red[0][0][0], dy, N, M, N, b * kColsPerBlock, db);
 }
 
-// Linear backward with FEW outputs and a WIDE input (the conv architecture's heads: dy [B, NH <= 16], x = the 8192-wide
-// flatten): one pass over x.  Workgroup = 32 columns of K (256 workgroups for K = 8192); thread (row group g = tid >> 3,
-// column quad c = tid & 7) walks rows g, g + 32, ... of every 256-row chunk: one 16-byte load of x feeds
-// dW[:, quad] += dy[m][:] x[m][quad] (registers) and dx[m][quad] = (dy[m][:] W[:, quad]) [x > 0] (stored at once); the 32
-// row groups' dW partials meet in LDS and are added in group order.  The last workgroup adds up the bias gradient.
-// (As 16 x 16 tiles this was 8192 + 512 workgroups.)
-constexpr int kSknN = 16;
+// Linear backward with FEW outputs and a WIDE input: job_linear_bwd_skn (mvae_common.hpp), one workgroup per 32 columns
+// of K plus one for the bias gradient.
 template <int NN>  // NN = N rounded up to a multiple of 4
 __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const float* W, const float* dy, float* dW,
                                                         float* db, float* dx, int M, int N, int K, int relu_in) {
-  __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
-  __shared__ f32x4 sm[32][9];
-  const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
-  if ((int)blockIdx.x == K / 32) {  // db[n] = sum_m dy[m][n]
-    const int cn = tid & 15, gn = tid >> 4;
-    float s = 0.f;
-    if (cn < N)
-      for (int m = gn; m < M; m += 16) s += dy[(size_t)m * N + cn];
-    float* sf = reinterpret_cast<float*>(&sm[0][0]);
-    sf[gn * 17 + cn] = s;
-    __syncthreads();
-    if (gn == 0 && cn < N) {
-      float t = 0.f;
-      for (int q = 0; q < 16; ++q) t += sf[q * 17 + cn];
-      db[cn] = t;
-    }
-    return;
-  }
-  const int col = (int)blockIdx.x * 32 + c * 4;
-  // Latency, not bandwidth, bounds this kernel (one wave per SIMD, 16 MB moved): EVERY request of a 256-row chunk -- the
-  // dy block, the W columns, the 8 rows of x -- is issued before the first use, so a chunk costs one memory round trip.
-  f32x4 acc[NN], wr[NN];
-#pragma unroll
-  for (int n = 0; n < NN; ++n) {
-    acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wr[n] = *reinterpret_cast<const f32x4*>(W + (size_t)(n < N ? n : 0) * K + col);
-  }
-  constexpr int kDyPer = NN;  // 256 rows x NN entries / 256 threads
-  for (int m0 = 0; m0 < M; m0 += 256) {
-    const int rows = (M - m0) < 256 ? (M - m0) : 256;
-    float dyv[kDyPer];
-#pragma unroll
-    for (int q = 0; q < kDyPer; ++q) {
-      const int e = tid + 256 * q, r = e / NN, n = e - r * NN;
-      dyv[q] = dy[(size_t)(m0 + (r < rows ? r : 0)) * N + (n < N ? n : 0)];
-    }
-    f32x4 xv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = g + 32 * u;
-      xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + (r < rows ? r : 0)) * K + col);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // the previous chunk's readers of dy_s are done
-#pragma unroll
-    for (int q = 0; q < kDyPer; ++q) {
-      const int e = tid + 256 * q, r = e / NN, n = e - r * NN;
-      dy_s[r][n] = (r < rows && n < N) ? dyv[q] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = g + 32 * u;
-      if (r >= rows) continue;
-      f32x4 dxv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int n4 = 0; n4 < NN; n4 += 4) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(&dy_s[r][n4]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[n4 + j] += d[j] * xv[u];
-          if (n4 + j < N) dxv += d[j] * wr[n4 + j];  // (uniform; rows of W past N were clamped to row 0)
-        }
-      }
-      if (dx) {
-        if (relu_in) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dxv[j] = (xv[u][j] > 0.f) ? dxv[j] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(dx + (size_t)(m0 + r) * K + col) = dxv;
-      }
-    }
-  }
-#pragma unroll
-  for (int n = 0; n < NN; ++n) {  // (no early exit: a `break` keeps the loop rolled and acc[] in scratch memory)
-    __syncthreads();
-    sm[g][c] = acc[n];
-    __syncthreads();
-    if (g == 0 && n < N) {
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < 32; ++q) t += sm[q][c];
-      *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col) = t;
-    }
-  }
+  job_linear_bwd_skn<NN, false>((int)blockIdx.x, x, W, dy, dW, db, dx, M, N, K, relu_in);
 }
 
 // ------------------------------------------------------------------------------------------------ primitives (API)

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* logits, const 
 }
 
 // BatchStats (stats.py:144-212) for paths that do not run the fused MLP step: one workgroup
-__global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B,
-                                                     int ncomp) {
+__device__ __forceinline__ void batch_stats_body(const float* bce, const float* kl, float* stats, float beta, int B,
+                                                 int ncomp) {
   __shared__ float sm[8];
   const int tid = threadIdx.x;
   auto block_sum = [&](float v) -> float {
@@ -262,6 +262,84 @@ __global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const flo
     stats[3] += 1.f;
     stats[last] = bs; stats[last + 1] = kt; stats[last + 2] = es; stats[last + 3] = 1.f;
   }
+}
+__global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B,
+                                                     int ncomp) {
+  batch_stats_body(bce, kl, stats, beta, B, ncomp);
+}
+
+// The loss end of the conv step in ONE launch (vae.py:125-147 + the bias gradient of the last ConvTranspose2d): workgroup r
+// = k_bce_fwd_bwd for row r (NCHW logits: D = C x HW with HW a multiple of 1024, so every 1024-entry pass of the
+// workgroup lies inside one channel) plus the row's per-channel sums of g; the LAST workgroup to finish (arrival counter)
+// adds those sums over the rows in row order -> dbias[c] = sum_{b, y, x} g[b, c, y, x] -- and computes the batch statistics.
+// Fixed orders everywhere: which workgroup arrives last does not change a bit.  (Separately: BCE, statistics, column sum
+// of g, re-order, column sum = 5 launches.)
+__global__ __launch_bounds__(256) void k_bce_stats(const float* logits, const float* x, float* bce, float* g,
+                                                   const float* kl, float* stats, float beta, int B, int D, int HW,
+                                                   int ncomp, float* chan_part, float* dbias, int* counter) {
+  __shared__ float sm[4];
+  __shared__ float chs[4][8];
+  __shared__ int last_s;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int r = blockIdx.x, C = D / HW;
+  const float* yl = logits + (size_t)r * D;
+  const float* tl = x + (size_t)r * D;
+  float* gl = g + (size_t)r * D;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float cs = 0.f;
+    for (int j = c * HW + tid * 4; j < (c + 1) * HW; j += 1024) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(yl + j), t = *reinterpret_cast<const f32x4*>(tl + j);
+      f32x4 gv;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float e = mvf::fexp(-fabsf(y[u]));
+        gv[u] = ((y[u] >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t[u];
+        s += (1.f - t[u]) * y[u] - (fminf(y[u], 0.f) - mvf::log1p_pos(e));
+        cs += gv[u];
+      }
+      *reinterpret_cast<f32x4*>(gl + j) = gv;
+    }
+    cs = wave_sum(cs);
+    if ((tid & 63) == 0) chs[wave][c] = cs;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) sm[wave] = s;
+  __syncthreads();
+  // The row's results leave as write-through stores and are waited for (vmcnt) before the arrival is counted; the last
+  // workgroup acquires before reading everyone's.  (A device-scope release fence here -- __threadfence() -- writes back the
+  // XCD's whole L2, dirty with 12 KB of g per row, once per workgroup: 28 us instead of 9.)
+  if (tid == 0) store4_wt(bce, (size_t)r, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+  if (tid < C) store4_wt(chan_part, (size_t)r * C + tid, (chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    // two-level count (one hot word would serialise B device-scope atomics at ~12 ns each): 16 group words, then counter[16];
+    // every word is re-armed (0) by the workgroup that completes it
+    constexpr int NG = 16;
+    const int grp = r % NG, gsize = (B - grp + NG - 1) / NG, ngroups = B < NG ? B : NG;
+    int last = 0;
+    if (atomicAdd(&counter[grp], 1) == gsize - 1) {
+      counter[grp] = 0;
+      if (atomicAdd(&counter[NG], 1) == ngroups - 1) {
+        counter[NG] = 0;
+        last = 1;
+      }
+    }
+    last_s = last;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid < 64) {  // wave 0: dbias, one channel at a time, rows in order (lane = row mod 64, then the DPP tree)
+    for (int c = 0; c < C; ++c) {
+      float a = 0.f;
+      for (int rr = tid; rr < B; rr += 64) a += chan_part[(size_t)rr * C + c];
+      a = wave_sum(a);
+      if (tid == 0) dbias[c] = a;
+    }
+  }
+  batch_stats_body(bce, kl, stats, beta, B, ncomp);
 }
 
 static int grid_for(int64_t total) {
@@ -1090,6 +1168,22 @@ extern "C" int mvae_bce_forward_backward(const float* logits, const float* x, fl
   return 0;
 }
 
+extern "C" int mvae_conv_bce_stats(const float* logits, const float* x, float* bce, float* g, const float* kl,
+                                   float* stats, float beta, int64_t B, int D, int HW, int ncomp, float* chan_part,
+                                   float* dbias, int32_t* counter, void* stream) {
+  if (!logits || !x || !bce || !g || !kl || !stats || !chan_part || !dbias || !counter || B < 1 || B > 0x7fffffff ||
+      D < 1 || HW < 1 || ncomp < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (D % HW != 0 || D / HW > 8 || (HW & 1023) != 0)
+    return fail(MVAE_E_UNSUPPORTED, "mvae_conv_bce_stats: D = C x HW with C <= 8 and HW a multiple of 1024%s", "");
+  if (((((uintptr_t)logits) | ((uintptr_t)x) | ((uintptr_t)g)) & 15) != 0)
+    return fail(MVAE_E_ALIGN, "mvae_conv_bce_stats needs 16-byte aligned logits / x / g%s", "");
+  hipLaunchKernelGGL(k_bce_stats, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, x, bce, g, kl, stats, beta,
+                     (int)B, D, HW, ncomp, chan_part, dbias, counter);
+  LAUNCH_CHECK("bce + statistics launch");
+  return 0;
+}
+
 extern "C" int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp,
                                 void* stream) {
   if (!bce || !kl || !stats || B < 1 || ncomp < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
@@ -1098,6 +1192,435 @@ extern "C" int mvae_batch_stats(const float* bce, const float* kl, float* stats,
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ conv architecture: the latent section in four launches
+// conv_vae.py:65-71 between the last encoder convolution and the first decoder convolution:
+//   h = a2.view(bs, -1)  (NCHW flatten: column c * 16 + p)  ->  fc_mean / fc_logvar of every component (component.py:52-57)
+//   ->  rsample + KL (component.py:59-78)  ->  fc(z) + ReLU  ->  .view(-1, 128, 4, 4)
+// and its backward.  Built from the generic operators this is 6 + 10 launches of ~5 us (re-order W_heads, split-K heads,
+// slice sum, components, fc, re-order | re-order, ReLU mask, fc backward, memset, components, row sum, heads backward,
+// re-order dW); here it is 2 + 2.  The activations on both sides are CHANNEL-LAST (a2: [B, 16, 512], t0: [B, 16, 128]) as
+// the convolutions want them; the weights keep the reference's orders (W_heads columns c * 16 + p, W_d0 rows c * 16 + p)
+// and the kernels index them accordingly.  Shapes: heads_dim <= 16, z_dim <= 16, true dimensions <= 8
+// (mvae_conv_latent_supported); other models take the generic operators.
+constexpr int kEncC = 512, kPix = 16, kDecC = 128;       // encoder output 512 x 4 x 4, decoder input 128 x 4 x 4
+constexpr int kFlat = kEncC * kPix, kD0 = kDecC * kPix;  // 8192, 2048
+constexpr int kClSlice = 128, kClSlices = kFlat / kClSlice;  // split-K slices of the heads: 128 channel-last columns each
+constexpr int kClNN = 16;                                // row stride of the slice partials (heads_dim <= 16)
+
+// sum over each 32-lane half of the wave: lanes 16..31 end up with the total of lanes 0..31, lanes 48..63 with that of
+// lanes 32..63 (DPP row operations + one row broadcast, fixed order)
+__device__ __forceinline__ float half_wave_sum(float v) {
+  int x = __float_as_int(v);
+#define MV_DPP_ADD(CTRL, ROWMASK)                                                                       \
+  x = __float_as_int(__int_as_float(x) +                                                                \
+                     __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xF, true)));
+  MV_DPP_ADD(0xB1, 0xF)   // quad_perm [1,0,3,2]
+  MV_DPP_ADD(0x4E, 0xF)   // quad_perm [2,3,0,1]
+  MV_DPP_ADD(0x141, 0xF)  // row_half_mirror
+  MV_DPP_ADD(0x140, 0xF)  // row_mirror: every lane of a 16-lane row holds the row sum
+  MV_DPP_ADD(0x142, 0xA)  // row_bcast15 into rows 1 and 3
+#undef MV_DPP_ADD
+  return __int_as_float(x);
+}
+
+// launch 1 of the forward: part[s][r][n] = sum_{k in slice s} a2[r][k] W_heads[n][ref(k)].  Workgroup = (slice s = (pixel
+// p, 128 channels), 64 rows); thread (row group g = tid >> 5, channel quad l = tid & 31) keeps its 4 x NN weights in
+// registers and walks 8 rows, one 16-byte load each (all requested first); the 32 quads of a row meet by DPP.
+template <int NN>
+__global__ __launch_bounds__(256) void k_cl_heads_part(const float* __restrict__ a2, const float* __restrict__ W,
+                                                       float* __restrict__ part, int B, int N) {
+  const int tid = threadIdx.x, l = tid & 31, g = tid >> 5;
+  const int s = blockIdx.x, p = s >> 2, c = ((s & 3) << 7) + (l << 2);
+  float w[NN][4];
+#pragma unroll
+  for (int n = 0; n < NN; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[n][i] = W[(size_t)(n < N ? n : 0) * kFlat + (c + i) * kPix + p];
+  const int r0 = blockIdx.y * 64;
+  f32x4 xv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int r = r0 + g + 8 * u;
+    xv[u] = *reinterpret_cast<const f32x4*>(a2 + (size_t)(r < B ? r : B - 1) * kFlat + p * kEncC + c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int r = r0 + g + 8 * u;
+    f32x4 o[NN / 4];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a = xv[u][0] * w[n][0];
+      a = fmaf(xv[u][1], w[n][1], a);
+      a = fmaf(xv[u][2], w[n][2], a);
+      a = fmaf(xv[u][3], w[n][3], a);
+      o[n >> 2][n & 3] = half_wave_sum(a);
+    }
+    if (l == 31 && r < B) {
+      float* dst = part + ((size_t)s * B + r) * kClNN;
+#pragma unroll
+      for (int q = 0; q < NN / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = o[q];
+    }
+  }
+}
+
+// launch 2 of the forward, one workgroup per batch row: heads = bias + the slices in index order (16 groups of 4, then the
+// groups in order); the components, each on the wave fill_table gave it (kinds do not share a wave); t0 = relu(z W_d0^T
+// + b) written channel-last through LDS.
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float* __restrict__ part,
+                                                       const float* __restrict__ b_heads, int NH,
+                                                       const float* __restrict__ eps, int eps_ld,
+                                                       const float* __restrict__ radii, const float* __restrict__ W_d0,
+                                                       const float* __restrict__ b_d0, int Z, float* __restrict__ heads,
+                                                       float* __restrict__ z, float* __restrict__ kl,
+                                                       float* __restrict__ t0, int B) {
+  __shared__ float hp[16][17];
+  __shared__ float heads_s[16], z_s[16];
+  __shared__ float t0_s[kPix * (kDecC + 1)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x;
+  // this thread's 8 rows of W_d0 are requested now and used after the component chain (Z = 8: the BASELINE model)
+  f32x4 wq[8][2];
+  float bq[8];
+  if (Z == 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = tid + 256 * i;
+      wq[i][0] = *reinterpret_cast<const f32x4*>(W_d0 + (size_t)n * 8);
+      wq[i][1] = *reinterpret_cast<const f32x4*>(W_d0 + (size_t)n * 8 + 4);
+      bq[i] = b_d0[n];
+    }
+  }
+  {
+    const int j = tid & 15, q = tid >> 4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = part[((size_t)(q * 4 + i) * B + r) * kClNN + j];
+    hp[q][j] = ((v[0] + v[1]) + v[2]) + v[3];
+    __syncthreads();
+    if (tid < 16) {
+      float h = hp[0][tid];
+#pragma unroll
+      for (int qq = 1; qq < 16; ++qq) h += hp[qq][tid];
+      if (tid < NH) {
+        h += b_heads[tid];
+        heads[(size_t)r * NH + tid] = h;
+      }
+      heads_s[tid] = tid < NH ? h : 0.f;
+    }
+    __syncthreads();
+  }
+  for (int ci = 0; ci < t.n; ++ci)
+    if (t.wave_of[ci] == wave && t.lane_of[ci] == lane)
+      comp_fwd_row<DMAX>(t.c[ci], heads_s, eps + (size_t)r * eps_ld, radii, z_s, z + (size_t)r * Z,
+                         kl + (size_t)ci * B + r, nullptr, nullptr, nullptr, nullptr);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = tid + 256 * i;
+    float a = 0.f;
+    if (Z == 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a = fmaf(z_s[k], wq[i][0][k], a);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a = fmaf(z_s[4 + k], wq[i][1][k], a);
+      a += bq[i];
+    } else {
+      for (int k = 0; k < Z; ++k) a = fmaf(z_s[k], W_d0[(size_t)n * Z + k], a);
+      a += b_d0[n];
+    }
+    t0_s[(n & 15) * (kDecC + 1) + (n >> 4)] = a < 0.f ? 0.f : a;  // torch.relu: NaN propagates
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid * 4 + 1024 * i, pp = idx >> 7, cc = idx & 127;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t0_s[pp * (kDecC + 1) + cc + e];
+    *reinterpret_cast<f32x4*>(t0 + (size_t)r * kD0 + idx) = v;
+  }
+}
+
+// launch 1 of the backward, one workgroup per batch row: dd0 = dt0 [t0 > 0] (kept channel-last for launch 2); dz = dd0
+// W_d0 (thread = row n of W_d0, fixed-order workgroup sum); the components' derivative directions (component ci on its
+// wave, lane = direction: dual numbers with the reference's derivative rules) -> dheads, per-row radius terms.
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const float* __restrict__ heads, int NH,
+                                                            const float* __restrict__ eps, int eps_ld,
+                                                            const float* __restrict__ radii,
+                                                            const float* __restrict__ W_d0, int Z,
+                                                            const float* __restrict__ t0, const float* __restrict__ dt0,
+                                                            float beta, float* __restrict__ dd0,
+                                                            float* __restrict__ dheads, float* __restrict__ drad_rows,
+                                                            int B) {
+  __shared__ float dd_s[kPix * (kDecC + 1)];
+  __shared__ float red_s[4][16];
+  __shared__ float dz_s[16], heads_s[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x;
+  if (tid < 16) heads_s[tid] = tid < NH ? heads[(size_t)r * NH + tid] : 0.f;
+  f32x4 wq[8][2];  // this thread's 8 rows of W_d0, requested with the first loads (Z = 8)
+  if (Z == 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = tid + 256 * i;
+      wq[i][0] = *reinterpret_cast<const f32x4*>(W_d0 + (size_t)n * 8);
+      wq[i][1] = *reinterpret_cast<const f32x4*>(W_d0 + (size_t)n * 8 + 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid * 4 + 1024 * i, pp = idx >> 7, cc = idx & 127;
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dt0 + (size_t)r * kD0 + idx);
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(t0 + (size_t)r * kD0 + idx);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (m4[e] > 0.f) ? d4[e] : 0.f;
+      dd_s[pp * (kDecC + 1) + cc + e] = v[e];
+    }
+    *reinterpret_cast<f32x4*>(dd0 + (size_t)r * kD0 + idx) = v;
+  }
+  __syncthreads();
+  float dzp[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dzp[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = tid + 256 * i;
+    const float dd = dd_s[(n & 15) * (kDecC + 1) + (n >> 4)];
+    if (Z == 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dzp[k] = fmaf(dd, wq[i][0][k], dzp[k]);
+        dzp[4 + k] = fmaf(dd, wq[i][1][k], dzp[4 + k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < Z) dzp[k] = fmaf(dd, W_d0[(size_t)n * Z + k], dzp[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < Z) {  // uniform
+      const float sres = wave_sum(dzp[k]);
+      if (lane == 0) red_s[wave][k] = sres;
+    }
+  }
+  __syncthreads();
+  if (tid < Z) dz_s[tid] = (red_s[0][tid] + red_s[1][tid]) + (red_s[2][tid] + red_s[3][tid]);
+  __syncthreads();
+  for (int ci = 0; ci < t.n; ++ci) {
+    if (t.wave_of[ci] != wave) continue;  // uniform per wave
+    const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
+    if (lane < ndir) {
+      const mvae_component_desc& c = t.c[ci];
+      const float gval = comp_bwd_dir<DMAX>(c, heads_s, eps + (size_t)r * eps_ld, radii, dz_s, beta, lane);
+      if (lane < c.true_dim) dheads[(size_t)r * NH + c.mean_col + lane] = gval;
+      else if (lane < c.true_dim + c.logvar_dim) dheads[(size_t)r * NH + c.logvar_col + (lane - c.true_dim)] = gval;
+      else drad_rows[(size_t)ci * B + r] = gval;
+    }
+  }
+}
+
+// launch 2 of the backward: everything that sums over the batch.  Workgroups [0, 256]: the heads -- job_linear_bwd_skn
+// against the channel-last flatten (dW_heads, da2 = (dheads W_heads) [a2 > 0], db_heads); the next 64: dW_d0 / db_d0 =
+// dd0^T [z | 1] for 32 channel-last entries each (thread = (row group, entry quad), rows g, g + 32, ... requested first,
+// the 32 groups added in order through LDS, stored at the reference's row c * 16 + p); the last: the radius gradients, each
+// a fixed-order sum over the rows.
+template <int NN>
+__global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const float* __restrict__ a2,
+                                                            const float* __restrict__ W_heads,
+                                                            const float* __restrict__ dheads, int NH,
+                                                            float* __restrict__ dW_heads, float* __restrict__ db_heads,
+                                                            float* __restrict__ da2, const float* __restrict__ dd0,
+                                                            const float* __restrict__ z, int Z,
+                                                            float* __restrict__ dW_d0, float* __restrict__ db_d0,
+                                                            const float* __restrict__ drad_rows,
+                                                            float* __restrict__ dradii, int B) {
+  const int nskn = kFlat / 32 + 1;
+  int blk = blockIdx.x;
+  if (blk < nskn) {
+    job_linear_bwd_skn<NN, true>(blk, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1);
+    return;
+  }
+  blk -= nskn;
+  const int tid = threadIdx.x;
+  if (blk < kD0 / 32) {
+    __shared__ f32x4 sm[32][9];
+    const int c8 = tid & 7, g = tid >> 3;
+    const int idx = blk * 32 + c8 * 4, pp = idx >> 7, cc = idx & 127;
+    f32x4 acc[17];  // [k < Z]: dW_d0 column k; [16]: the bias gradient
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m0 = 0; m0 < B; m0 += 256) {
+      f32x4 dv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + g + 32 * u;
+        dv[u] = *reinterpret_cast<const f32x4*>(dd0 + (size_t)(m < B ? m : B - 1) * kD0 + idx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + g + 32 * u;
+        if (m >= B) continue;
+        acc[16] += dv[u];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < Z) acc[k] += z[(size_t)m * Z + k] * dv[u];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+      if (k < 16 && k >= Z) continue;  // uniform
+      __syncthreads();
+      sm[g][c8] = acc[k];
+      __syncthreads();
+      if (g == 0) {
+        f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 32; ++q) tt += sm[q][c8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = (cc + e) * kPix + pp;
+          if (k < 16) dW_d0[(size_t)n * Z + k] = tt[e];
+          else db_d0[n] = tt[e];
+        }
+      }
+    }
+    return;
+  }
+  __shared__ float sw[4];
+  for (int ci = 0; ci < t.n; ++ci) {
+    if (tid == 0) dradii[ci] = 0.f;
+  }
+  __syncthreads();
+  for (int ci = 0; ci < t.n; ++ci) {
+    if (!(t.trainable[ci] & 1)) continue;  // uniform: no radius direction (Euclidean)
+    const float* prow = drad_rows + (size_t)ci * B;
+    float sacc = 0.f;
+    for (int rr = tid; rr < B; rr += 256) sacc += prow[rr];
+    sacc = wave_sum(sacc);
+    __syncthreads();
+    if ((tid & 63) == 0) sw[tid >> 6] = sacc;
+    __syncthreads();
+    if (tid == 0) dradii[t.c[ci].radius_idx] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+  }
+}
+
+static int conv_latent_dims(const mvae_component_desc* comps, int ncomp, int* NH, int* Z, int* eps_dim, int* dmax) {
+  if (!comps || ncomp < 1 || ncomp > kMaxComp) return 0;
+  int nh = 0, zz = 0, ed = 0, dm = 0;
+  for (int i = 0; i < ncomp; ++i) {
+    const mvae_component_desc& c = comps[i];
+    if (c.kind < 0 || c.kind >= kNumKinds || c.true_dim < 1) return 0;
+    const int a = c.mean_col + c.true_dim, b = c.logvar_col + c.logvar_dim, zc = c.z_col + ambient_dim(c.kind, c.true_dim);
+    nh = a > nh ? a : nh;
+    nh = b > nh ? b : nh;
+    zz = zc > zz ? zc : zz;
+    ed = (c.eps_col + c.true_dim) > ed ? (c.eps_col + c.true_dim) : ed;
+    dm = c.true_dim > dm ? c.true_dim : dm;
+  }
+  *NH = nh; *Z = zz; *eps_dim = ed; *dmax = dm;
+  return 1;
+}
+
+extern "C" int mvae_conv_latent_supported(const mvae_component_desc* comps, int ncomp) {
+  int NH, Z, ed, dm;
+  if (!conv_latent_dims(comps, ncomp, &NH, &Z, &ed, &dm)) return 0;
+  return (NH <= 16 && Z <= 16 && dm <= 8) ? 1 : 0;
+}
+
+extern "C" int64_t mvae_conv_latent_workspace_floats(int64_t B, int ncomp) {
+  if (B < 1 || ncomp < 1) return -1;
+  const int64_t fwd = (int64_t)kClSlices * B * kClNN, bwd = B * kD0 + (int64_t)ncomp * B;
+  return fwd > bwd ? fwd : bwd;
+}
+
+#define MV_CL_DMAX_SWITCH(dmax, ...)                              \
+  if (dmax <= 2) { constexpr int DM = 2; __VA_ARGS__; }           \
+  else if (dmax <= 4) { constexpr int DM = 4; __VA_ARGS__; }      \
+  else { constexpr int DM = 8; __VA_ARGS__; }
+#define MV_CL_NN_SWITCH(nh, ...)                                  \
+  if (nh <= 4) { constexpr int NN = 4; __VA_ARGS__; }             \
+  else if (nh <= 8) { constexpr int NN = 8; __VA_ARGS__; }        \
+  else if (nh <= 12) { constexpr int NN = 12; __VA_ARGS__; }      \
+  else { constexpr int NN = 16; __VA_ARGS__; }
+
+extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int ncomp, const float* a2,
+                                        const float* W_heads, const float* b_heads, const float* eps, int eps_ld,
+                                        const float* radii, const float* W_d0, const float* b_d0, float* heads, float* z,
+                                        float* kl, float* t0, float* workspace, int64_t B, void* stream) {
+  if (!a2 || !W_heads || !b_heads || !eps || !W_d0 || !b_d0 || !heads || !z || !kl || !t0 || !workspace || B < 1 ||
+      B > 0x3fffff)
+    return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+  int NH, Z, ed, dmax;
+  if (!mvae_conv_latent_supported(comps, ncomp) || !conv_latent_dims(comps, ncomp, &NH, &Z, &ed, &dmax))
+    return fail(MVAE_E_UNSUPPORTED, "fused conv latent section: heads_dim, z_dim <= 16 and true dimensions <= 8%s", "");
+  if (eps_ld < ed) return fail(MVAE_E_BADARG, "eps_ld smaller than the components' eps columns%s", "");
+  if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)workspace) | ((uintptr_t)W_d0)) & 15) != 0)
+    return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned a2 / t0 / W_d0 / workspace%s", "");
+  CompTable t;
+  unsigned char all[kMaxComp];
+  memset(all, 1, sizeof(all));
+  int dm2;
+  int rc = fill_table(&t, comps, ncomp, all, &dm2);
+  if (rc) return rc;
+  for (int i = 0; i < ncomp; ++i) {
+    if (comps[i].kind != MVAE_EUCLIDEAN && !radii) return fail(MVAE_E_BADARG, "radii is NULL%s", "");
+    if (t.lane_of[i] >= 64) return fail(MVAE_E_UNSUPPORTED, "too many components of one kind%s", "");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gridA(kClSlices, (unsigned)((B + 63) / 64));
+  MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_heads_part<NN>), gridA, dim3(256), 0, s, a2, W_heads, workspace, (int)B, NH));
+  MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_fwd<DM>), dim3((unsigned)B), dim3(256), 0, s, t, workspace,
+                                             b_heads, NH, eps, eps_ld, radii, W_d0, b_d0, Z, heads, z, kl, t0, (int)B));
+  LAUNCH_CHECK("fused conv latent forward launch");
+  return 0;
+}
+
+extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const float* a2,
+                                         const float* W_heads, const float* heads, const float* eps, int eps_ld,
+                                         const float* radii, const float* z, const float* W_d0, const float* t0,
+                                         const float* dt0, float beta, float* dW_heads, float* db_heads, float* da2,
+                                         float* dW_d0, float* db_d0, float* dradii, float* dheads, float* workspace,
+                                         int64_t B, void* stream) {
+  if (!a2 || !W_heads || !heads || !eps || !z || !W_d0 || !t0 || !dt0 || !dW_heads || !db_heads || !da2 || !dW_d0 ||
+      !db_d0 || !dradii || !dheads || !workspace || B < 1 || B > 0x3fffff)
+    return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+  int NH, Z, ed, dmax;
+  if (!mvae_conv_latent_supported(comps, ncomp) || !conv_latent_dims(comps, ncomp, &NH, &Z, &ed, &dmax))
+    return fail(MVAE_E_UNSUPPORTED, "fused conv latent section: heads_dim, z_dim <= 16 and true dimensions <= 8%s", "");
+  if (eps_ld < ed) return fail(MVAE_E_BADARG, "eps_ld smaller than the components' eps columns%s", "");
+  if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)dt0) | ((uintptr_t)da2) | ((uintptr_t)workspace) |
+        ((uintptr_t)W_d0)) & 15) != 0)
+    return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned activations / W_d0 / workspace%s", "");
+  CompTable t;
+  unsigned char tr[kMaxComp];
+  memset(tr, 1, sizeof(tr));
+  int dm2;
+  int rc = fill_table(&t, comps, ncomp, tr, &dm2);
+  if (rc) return rc;
+  for (int i = 0; i < ncomp; ++i) {
+    if (comps[i].kind != MVAE_EUCLIDEAN && !radii) return fail(MVAE_E_BADARG, "radii is NULL%s", "");
+    if (comps[i].radius_idx < 0 || comps[i].radius_idx >= ncomp)
+      return fail(MVAE_E_BADARG, "radius_idx out of range%s (%lld)", "", comps[i].radius_idx);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dd0 = workspace;
+  float* drad_rows = workspace + (size_t)B * kD0;
+  MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_bwd_rows<DM>), dim3((unsigned)B), dim3(256), 0, s, t, heads, NH,
+                                             eps, eps_ld, radii, W_d0, Z, t0, dt0, beta, dd0, dheads, drad_rows, (int)B));
+  const unsigned grid = kFlat / 32 + 1 + kD0 / 32 + 1;
+  MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_latent_bwd_cols<NN>), dim3(grid), dim3(256), 0, s, t, a2, W_heads, dheads,
+                                         NH, dW_heads, db_heads, da2, dd0, z, Z, dW_d0, db_d0, drad_rows, dradii, (int)B));
+  LAUNCH_CHECK("fused conv latent backward launch");
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------------ device-side input pipeline
 // Row f-2 of the scope table: the reference feeds the step from 8 DataLoader worker processes that binarise every image

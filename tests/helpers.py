@@ -62,12 +62,13 @@ def summary_of(a, summary):
     return np.concatenate([[a.sum(), np.sqrt((a * a).sum()), np.abs(a).max()], idx.astype(np.float64), a[idx]])
 
 
-def assert_close_after_adam(a, b, lr, steps, what="", rtol=2e-4):
+def assert_close_after_adam(a, b, lr, steps, what="", rtol=2e-4, max_steps_apart=1.0, bad_frac=1e-4):
     """Parameters after `steps` Adam steps.  Adam divides by sqrt(v): where a gradient entry is pure rounding noise
     (columns of x that are almost always 0) the update m/sqrt(v) is O(1) in BOTH implementations and its sign follows
     the noise, so a handful of entries may differ by up to ~lr per step although both runs are correct float32
     evaluations.  Bar: element-wise 1e-4-class agreement for all but 1e-4 of the entries, and NO entry further apart
-    than lr * steps."""
+    than lr * steps (max_steps_apart = 2: where the two runs' gradients themselves differ by a flipped ReLU output, an
+    entry whose gradient is ~0 can take the step in opposite directions)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape and np.isfinite(a).all(), what
@@ -75,5 +76,17 @@ def assert_close_after_adam(a, b, lr, steps, what="", rtol=2e-4):
         return
     scale = max(np.abs(b).max(), 1e-30)
     bad = np.abs(a - b) > rtol * np.abs(b) + rtol * scale
-    assert bad.sum() <= max(1, int(1e-4 * a.size)), f"{what}: {bad.sum()}/{a.size} entries off"
-    assert np.abs(a - b).max() <= lr * steps * 1.01 + rtol * scale, f"{what}: max diff {np.abs(a - b).max():.3e}"
+    assert bad.sum() <= max(1, int(bad_frac * a.size)), f"{what}: {bad.sum()}/{a.size} entries off"
+    assert np.abs(a - b).max() <= lr * steps * 1.01 * max_steps_apart + rtol * scale, f"{what}: max diff {np.abs(a - b).max():.3e}"
+
+
+def relu_flips(ca, cb):
+    """Entries of the six ReLU outputs of the conv step that are > 0 in one run and 0 in the other.  A rounding-level
+    difference in the forward pass (another summation order) can flip an activation whose exact value is ~0; its
+    derivative then switches between 0 and 1, and every gradient upstream of it changes by one term of a long sum."""
+    return sum(int(((ca[k] > 0) != (cb[k] > 0)).sum()) for k in ("a0", "a1", "a2", "t0", "b1", "b2"))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

@@ -170,11 +170,28 @@ def test_two_rank_conv_step_equals_the_oracle():
     ref = orc.train_step(x, eps, beta=1.0, epoch=12)
     lay = ConvEngine([("h", 2), ("s", 2), ("e", 2)], torch.device("cuda:0")).flat
     grads, params = torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2])
+    # per-entry bar unless the fused latent section's rounding flipped a ReLU output relative to the generic-operator step
+    # (helpers.relu_flips; tests/test_conv_gpu.py::test_conv_step_full_batch_vs_oracle): then a norm bar
+    from helpers import rel_l2, relu_flips
+    dev = torch.device("cuda:0")
+    acts = []
+    for fused in ("1", "0"):
+        os.environ["MVAE_CONV_FUSED"] = fused
+        e = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True] * 3)
+        e.load_state(state0)
+        acts.append(e._forward(x.to(dev), eps.to(dev)))
+    os.environ.pop("MVAE_CONV_FUSED")
+    flips = relu_flips(*acts)
     for n, t in lay.views(grads).items():
         if orc.P[n].grad is not None:
-            assert_close(t.numpy(), orc.P[n].grad.numpy(), 2e-4, "dp2 conv grad " + n, atol_frac=2e-4)
+            if flips == 0 or n in ("d3.weight", "d3.bias"):
+                assert_close(t.numpy(), orc.P[n].grad.numpy(), 2e-4, "dp2 conv grad " + n, atol_frac=2e-4)
+            else:
+                err = rel_l2(t.numpy(), orc.P[n].grad.numpy())
+                assert err < 2e-3, f"dp2 conv grad {n}: rel-L2 {err:.2e} with {flips} flipped ReLU outputs"
     for n, t in lay.views(params).items():
-        assert_close_after_adam(t.numpy(), orc.P[n].detach().numpy(), 1e-3, 1, "dp2 conv param " + n)
+        assert_close_after_adam(t.numpy(), orc.P[n].detach().numpy(), 1e-3, 1, "dp2 conv param " + n,
+                                max_steps_apart=2.0 if flips else 1.0, bad_frac=2e-3 if flips else 1e-4)
     np.testing.assert_allclose(res[0][3][2], float(ref.elbo), rtol=1e-4)
 
 
