@@ -293,6 +293,10 @@ class ConvEngine:
         # (mvae_conv_latent_*, mvae_conv_bce_stats); MVAE_CONV_FUSED=0 or an unsupported model: the generic operators
         self.fused = (os.environ.get("MVAE_CONV_FUSED", "1") != "0"
                       and bool(load().mvae_conv_latent_supported(self.layout.descs, n)))
+        # MVAE_CONV_SPLIT_BF16=1: the NT contractions through exact three-way bf16 splits on the bf16 MFMA (process-wide
+        # mode of the library, mvae_set_contraction_mode; off by default: the step's shapes are too small to gain)
+        if "MVAE_CONV_SPLIT_BF16" in os.environ:
+            load().mvae_set_contraction_mode(1 if os.environ["MVAE_CONV_SPLIT_BF16"] == "1" else 0)
         self.overlap = os.environ.get("MVAE_CONV_STREAMS", "0") == "1"
         self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if self.overlap else []
         self._forked: List[int] = []

@@ -615,6 +615,213 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
   }
 }
 
+// ---- f32 contraction through SPLIT bf16 products.  On gfx950 the f32-input MFMA runs at the f32 vector rate, 1/16 of the
+// bf16 MFMA (MI355X_MICROARCH.md: 157 vs 2500 TFLOP/s).  A float splits EXACTLY into three bf16 pieces by truncation,
+// a = a_h + a_m + a_l (8 + 8 + 8 = the 24 significant bits), so a * b = the nine piece products; the six largest are
+// kept -- lh, hl, mm, mh, hm, hh, each EXACT in the f32 accumulator's input (8 x 8-bit factors) and added in f32 from
+// the smallest up -- and ml + lm + ll <= 2^-23 |a b| is dropped: about one more f32 rounding per product, against 8/3 of
+// the MFMA rate (6 instructions of 16 cycles per 16 x 16 x 32 sub-product instead of 8 of 32).  Accumulation, bias,
+// activation and storage stay f32.  tests/test_conv_gpu.py::test_split_product_contractions_vs_float64 holds this
+// path to the same float64 bar as the f32-MFMA path.
+// Tile BM x BN, K step 32 = one MFMA; both operands K-contiguous (NT: Linear / Conv2d forward, the gathered implicit
+// forms of those).  Staging splits the 16-byte global vectors and stores each piece of an operand tile as [row][32 k]
+// bf16 with a 96-byte row stride (conflict-free for the ds_read_b128 lane groups: a lane's fragment is the 8 consecutive
+// k of its row, lane = (row, k octet)).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kB3LD = 24;  // dwords per LDS row: 16 of data + 8 of padding
+__device__ __forceinline__ void split3(const float4 v, u32x2* hi, u32x2* mi, u32x2* lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned int h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int xb = __float_as_uint(x[e]);
+    h[e] = xb;
+    const float r1 = x[e] - __uint_as_float(xb & 0xffff0000u);
+    const unsigned int r1b = __float_as_uint(r1);
+    m[e] = r1b;
+    l[e] = __float_as_uint(r1 - __uint_as_float(r1b & 0xffff0000u));
+  }
+  // two bf16 per dword: the upper halves of elements (0, 1) and (2, 3)
+  *hi = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  *mi = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  *lo = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+template <int BM, int BN, int NW, int GATHER>
+__global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A, int64_t sai,
+                                                 const float* __restrict__ Bm, int64_t sbj, float* __restrict__ C,
+                                                 int64_t ldc, const float* __restrict__ bias,
+                                                 const float* __restrict__ mask, int relu, int M, int N, int K,
+                                                 int k_per_slice, int64_t slice_stride, ConvGeom cg) {
+  constexpr int BK = 32, KQ = BK / 4;
+  __shared__ __attribute__((aligned(16))) unsigned int As[3][BM * kB3LD];
+  __shared__ __attribute__((aligned(16))) unsigned int Bs[3][BN * kB3LD];
+  constexpr int NT = 64 * NW, WCOLS = NW / 2;
+  constexpr int WM = BM / 2, WN = BN / WCOLS, TM = WM / 16, TN = WN / 16;
+  constexpr int LA = BM * KQ / NT, LB = BN * KQ / NT;
+  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = blockIdx.z * k_per_slice;
+  const int ke = (kb + k_per_slice < K) ? kb + k_per_slice : K;
+  C += (size_t)blockIdx.z * slice_stride;
+  // Requests run TWO K steps ahead of their stage, in two register sets.  They are branch-free -- a lane outside the
+  // tile / image / K range reads the operand's base address and is zeroed at the stage: with exec-masked requests inside
+  // branches hipcc's wait-count model loses the number in flight at the join and waits for ALL of them (vmcnt(0)), which
+  // silently turns two steps ahead into one.  One K step of this kernel (192 MFMA cycles per wave) is far shorter than a
+  // fabric round trip, so the distance is what sets its speed.
+  struct RegSet {
+    float4 ra[LA], rb[LB];
+    bool oka[LA], okb[LB];
+  };
+  RegSet rs0, rs1;
+  auto fetch = [&](int k0, RegSet& rs) {
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + NT * r;
+      const int i = f / KQ, k = k0 + ((f % KQ) << 2);
+      const int m = m0 + i;
+      bool ok;
+      const float* p;
+      if (GATHER == 1) {
+        const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
+        const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
+        const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+        ok = m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW;
+        p = A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c;
+      } else {
+        ok = m < M && k < ke;
+        p = A + (size_t)m * sai + k;
+      }
+      rs.ra[r] = *reinterpret_cast<const float4*>(ok ? p : A);
+      rs.oka[r] = ok;
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + NT * r;
+      const int j = f / KQ, k = k0 + ((f % KQ) << 2);
+      const bool ok = n0 + j < N && k < ke;
+      rs.rb[r] = *reinterpret_cast<const float4*>(ok ? Bm + (size_t)(n0 + j) * sbj + k : Bm);
+      rs.okb[r] = ok;
+    }
+  };
+  auto stage = [&](const RegSet& rs) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < LA; ++r) {
+      const int f = tid + NT * r;
+      const int o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      u32x2 h, m, l;
+      split3(rs.oka[r] ? rs.ra[r] : zero4, &h, &m, &l);
+      *reinterpret_cast<u32x2*>(&As[0][o]) = h;
+      *reinterpret_cast<u32x2*>(&As[1][o]) = m;
+      *reinterpret_cast<u32x2*>(&As[2][o]) = l;
+    }
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int f = tid + NT * r;
+      const int o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      u32x2 h, m, l;
+      split3(rs.okb[r] ? rs.rb[r] : zero4, &h, &m, &l);
+      *reinterpret_cast<u32x2*>(&Bs[0][o]) = h;
+      *reinterpret_cast<u32x2*>(&Bs[1][o]) = m;
+      *reinterpret_cast<u32x2*>(&Bs[2][o]) = l;
+    }
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave / WCOLS) * WM, wn = (wave % WCOLS) * WN;
+  const int li = lane & 15, lk = (lane >> 4) << 2;  // row of the fragment, dword offset of its k octet
+
+  auto compute = [&]() {
+    bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        af[a][q] = *reinterpret_cast<const bf16x8*>(&As[q][(wm + a * 16 + li) * kB3LD + lk]);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        bf[b][q] = *reinterpret_cast<const bf16x8*>(&Bs[q][(wn + b * 16 + li) * kB3LD + lk]);
+    // piece pairs from the smallest products up; operands swapped (B fragment first) so that a lane's four accumulator
+    // values are four consecutive columns of one output row, as in k_gemm_tiled
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b][PB[t]], af[a][PA[t]], acc[a][b], 0, 0, 0);
+  };
+  fetch(kb, rs0);
+  fetch(kb + BK, rs1);
+  for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+    // Both halves are unconditional (an odd number of K steps runs one all-zero step): the number of requests in flight is
+    // then the same on every path into the loop head and the waits stay counted.  sched_barrier: hipcc otherwise hoists the
+    // OTHER set's zeroing selects above this half's requests and MFMAs, and with them the wait for that set.
+    stage(rs0);
+    __syncthreads();
+    fetch(k0 + 2 * BK, rs0);
+    compute();
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    stage(rs1);
+    __syncthreads();
+    fetch(k0 + 3 * BK, rs1);
+    compute();
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const bool vec = (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0 && (ldc & 3) == 0;
+  const int lc = (lane >> 4) << 2;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + wm + a * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn + b * 16 + lc;
+      if (n >= N) continue;
+      f32x4 v = acc[a][b];
+      if (vec && n + 3 < N) {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (relu)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+        if (mask) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (size_t)m * ldc + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float w = v[r] + (bias ? bias[n + r] : 0.f);
+          if (relu) w = w < 0.f ? 0.f : w;
+          if (mask && !(mask[(size_t)m * ldc + n + r] > 0.f)) w = 0.f;
+          C[(size_t)m * ldc + n + r] = w;
+        }
+      }
+    }
+  }
+}
+
+// 0: f32-input MFMA everywhere (v_mfma_f32_16x16x4_f32); 1: split bf16 products where a kernel exists (NT forms)
+static int g_split_products = 0;
+extern "C" int mvae_set_contraction_mode(int split_bf16_products) {
+  const int old = g_split_products;
+  g_split_products = split_bf16_products ? 1 : 0;
+  return old;
+}
+
 // operand requirements of the 16-byte paths of k_gemm_tiled
 static inline bool tiled_ok(const void* p, int64_t ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
 
@@ -639,6 +846,20 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
+  if constexpr (A_KC && B_KC && (GATHER == 0 || GATHER == 1)) {
+    if (g_split_products && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
+      if (wg128 < 512) {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
+        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
+                           K, k_per_slice, slice_stride, cg);
+      } else {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
+        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M,
+                           N, K, k_per_slice, slice_stride, cg);
+      }
+      return;
+    }
+  }
   if (N > 64 && wg128 < 512) {
     dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
     hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC, GATHER>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,

@@ -621,3 +621,38 @@ def test_fused_conv_latent_section_is_only_taken_where_supported(dev):
     assert ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev).fused
     assert not ConvEngine([("h", 9)], dev).fused          # true dimension 9
     assert not ConvEngine([("e", 5), ("h", 4)], dev).fused  # heads_dim 18
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (16384, 1024, 256), (1000, 132, 96), (16384, 128, 1024)])
+def test_split_product_contractions_vs_float64(dev, M, N, K):
+    """mvae_set_contraction_mode(1): the NT contractions multiply through the exact three-way bf16 split of every float
+    (six piece products on the bf16 MFMA, f32 accumulation).  Same float64 bar as the f32-input MFMA path, and its error is
+    within 1.5x of that path's on the same operands -- the split drops <= 2^-23 |a b| per product.  Ragged tiles, bias,
+    ReLU and the gathered (implicit Conv2d) form included."""
+    from mvae_amd import functional as Fn
+    from mvae_amd._lib import load
+    from mvae_amd.conv import _conv_nhwc
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(N, K, generator=gen) * 0.1).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    ref = torch.relu(x.double() @ W.double().t() + b.double())
+    errs = []
+    try:
+        for mode in (0, 1):
+            load().mvae_set_contraction_mode(mode)
+            y = Fn.linear_forward(x, W, b, relu=True)
+            assert_close(_cpu(y), _cpu(ref), 2e-5, f"mode {mode}", atol_frac=1e-5)
+            errs.append(float((y.double() - ref).abs().max()))
+        assert errs[1] <= 1.5 * errs[0] + 1e-12, errs
+        # the gathered form: 64 -> 128 channels on 16 x 16 images
+        B, Cc, IH, OC = 8, 64, 16, 128
+        src = torch.randn(B * IH * IH, Cc, generator=gen).to(dev)
+        Wt = (torch.randn(OC, 16 * Cc, generator=gen) * 0.05).to(dev)
+        ys = []
+        for mode in (0, 1):
+            load().mvae_set_contraction_mode(mode)
+            ys.append(_conv_nhwc(src, Wt, None, None, B, Cc, IH, False))
+        assert_close(_cpu(ys[1]), _cpu(ys[0]), 2e-5, "gathered, split vs f32 MFMA", atol_frac=1e-5)
+    finally:
+        load().mvae_set_contraction_mode(0)
