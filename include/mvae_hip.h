@@ -316,7 +316,8 @@ int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, f
 /* BatchStats (stats.py:144-212): adds sum_b bce, sum_b kl_i, sum_b(-bce - beta*sum_i kl_i) to the statistics record
  * (same layout as mvae_model_desc.stats). */
 int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp, void* stream);
-/* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode).
+/* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode; a negative
+ * argument only queries).
  * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate.  1: every float split EXACTLY into three bf16 pieces,
  * the six largest piece products on the bf16 MFMA (16x the rate), f32 accumulation: |error| <= 2^-23 |a b| per product
  * on top of f32 accumulation, i.e. the float32 class of nn.Linear / nn.Conv2d on any BLAS (conv_vae.py:47-55). */

@@ -185,6 +185,9 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def _gemm_nn(G: Tensor, W: Tensor) -> Tensor:
     M, K = G.shape
     N = W.shape[1]
+    if M >= 512 and N > 64 and load().mvae_set_contraction_mode(-1) == 1:
+        # split-product mode has a kernel for the NT form only: transpose the (small) weight once and contract against it
+        return Fn.linear_forward(G, _permute_rc(W, 1, K, N).view(N, K), None)
     out = G.new_empty(M, N)
     check(load().mvae_gemm_nn(ptr(G), ptr(W), None, ptr(out), M, K, N, stream_ptr(G.device)))
     return out

@@ -814,11 +814,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   }
 }
 
+#ifndef MV_B3_MIN12864
+#define MV_B3_MIN12864 256  // plain NT shapes with < 512 128 x 128 tiles take 128 x 64 tiles when that still gives one per CU
+#endif
 // 0: f32-input MFMA everywhere (v_mfma_f32_16x16x4_f32); 1: split bf16 products where a kernel exists (NT forms)
 static int g_split_products = 0;
 extern "C" int mvae_set_contraction_mode(int split_bf16_products) {
   const int old = g_split_products;
-  g_split_products = split_bf16_products ? 1 : 0;
+  if (split_bf16_products >= 0) g_split_products = split_bf16_products ? 1 : 0;  // (< 0: query only)
   return old;
 }
 
@@ -848,7 +851,12 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
   if constexpr (A_KC && B_KC && (GATHER == 0 || GATHER == 1)) {
     if (g_split_products && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
-      if (wg128 < 512) {
+      const int64_t wg12864 = (int64_t)((N + 63) / 64) * ((M + 127) / 128) * slices;
+      if (GATHER == 0 && wg128 < 512 && wg12864 >= MV_B3_MIN12864) {
+        dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
+        hipLaunchKernelGGL((k_gemm_b3<128, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
+                           K, k_per_slice, slice_stride, cg);
+      } else if (wg128 < 512) {
         dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
         hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
                            K, k_per_slice, slice_stride, cg);
