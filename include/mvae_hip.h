@@ -316,6 +316,11 @@ int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, f
 /* BatchStats (stats.py:144-212): adds sum_b bce, sum_b kl_i, sum_b(-bce - beta*sum_i kl_i) to the statistics record
  * (same layout as mvae_model_desc.stats). */
 int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp, void* stream);
+/* nn.ConvTranspose2d(64, 3, 4, 2, 1) (conv_vae.py:54) direct, from the channel-last activation src [B*IH*IW, 64] to NCHW
+ * logits: y[b,c,Y,X] = bias[c] + sum src[(b,y,x)][f] W[f][c*16+ky*4+kx] over Y = 2y-1+ky, X = 2x-1+kx.  Geometry fixed to 64
+ * features -> 3 x 32 x 32 (MVAE_E_UNSUPPORTED otherwise; the generic form is mvae_gemm_nn + mvae_col2im_k4s2p1). */
+int mvae_convT_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F, int IH,
+                                  int IW, int C, void* stream);
 /* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode; a negative
  * argument only queries).
  * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate.  1: every float split EXACTLY into three bf16 pieces,

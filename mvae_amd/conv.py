@@ -229,6 +229,14 @@ def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[
     return y
 
 
+def _convT_to3(src: Tensor, W48: Tensor, bias: Tensor, R: int) -> Tensor:
+    """Direct ConvTranspose2d(64 -> 3, k4 s2 p1): channel-last [R * 256, 64] -> NCHW logits [R, 3072]."""
+    y = src.new_empty(R, 3072)
+    check(load().mvae_convT_to3_k4s2p1_forward(ptr(src), ptr(W48), ptr(bias), ptr(y), R, 64, 16, 16, 3,
+                                               stream_ptr(src.device)))
+    return y
+
+
 def _conv_e2(a1: Tensor, We2: Tensor, bias: Tensor, B: int) -> Tensor:
     """The e2 layer forward (128 -> 512 channels on 8 x 8): with only B * 16 output pixels its patch matrix is small
     (33 MB at B = 256), and patch matrix + plain contraction measured faster than the operand gather (12 + 83 us against
@@ -294,8 +302,8 @@ class ConvEngine:
         import os
         # the latent section (flatten -> heads -> components -> decoder fc) and the loss end as fused launches
         # (mvae_conv_latent_*, mvae_conv_bce_stats); MVAE_CONV_FUSED=0 or an unsupported model: the generic operators
-        self.fused = (os.environ.get("MVAE_CONV_FUSED", "1") != "0"
-                      and bool(load().mvae_conv_latent_supported(self.layout.descs, n)))
+        self.direct = os.environ.get("MVAE_CONV_FUSED", "1") != "0"  # direct boundary layers + the one-launch loss end
+        self.fused = self.direct and bool(load().mvae_conv_latent_supported(self.layout.descs, n))
         # MVAE_CONV_SPLIT_BF16=1: the NT contractions through exact three-way bf16 splits on the bf16 MFMA (process-wide
         # mode of the library, mvae_set_contraction_mode; off by default: the step's shapes are too small to gain)
         if "MVAE_CONV_SPLIT_BF16" in os.environ:
@@ -408,8 +416,11 @@ class ConvEngine:
         #  tools/bench_conv_gather.py; d1 and the backward-data of e1 gain 11 / 10 us each)
         c["b2"] = _col2im(_gemm_nn(c["b1"], c["Wd2"]), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
                           (R * 256, 64), True)
-        c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
-        c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
+        if self.direct:
+            c["logits"] = _convT_to3(c["b2"], PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
+        else:
+            c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
+            c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
 
     def _heads_channel_last(self):
@@ -440,8 +451,11 @@ class ConvEngine:
         b1 = _convT_nhwc(t0, self.flat.matrix(self.params, "d1"), PV["d1.bias"], None, R, 128, 4, 256, True)
         b2 = _col2im(_gemm_nn(b1, self.flat.matrix(self.params, "d2")), PV["d2.bias"], None, R, 64, 16,
                      _nhwc(16, 64), True, (R * 256, 64), True)
-        lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
-                     (R, 3072))
+        if self.direct:
+            lo = _convT_to3(b2, PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
+        else:
+            lo = _col2im(_gemm_nn(b2, PV["d3.weight"].view(64, 48)), PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False,
+                         (R, 3072))
         return lo.view(z.shape[:-1] + (3072,))
 
     def forward_backward(self, x: Tensor, eps: Tensor, beta: float = 1.0, want_outputs: bool = False):
@@ -451,7 +465,7 @@ class ConvEngine:
         c = self._forward(x, eps)
         bce = x.new_empty(B)
         g = torch.empty_like(c["logits"])
-        if self.fused:
+        if self.direct:
             # BCE + its gradient, the batch statistics and the bias gradient of d3 (sum of g per channel) in one launch
             chan = x.new_empty(B, 3)
             check(load().mvae_conv_bce_stats(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats),

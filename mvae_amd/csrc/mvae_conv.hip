@@ -1422,6 +1422,74 @@ extern "C" int mvae_batch_stats(const float* bce, const float* kl, float* stats,
 }
 
 
+// ------------------------------------------------------------------------------------------------ conv architecture: the last transposed convolution, direct
+// conv_vae.py:54, ConvTranspose2d(64, 3, 4, 2, 1) to the NCHW logits: 0.4 GFLOP; as product + col2im it costs 26 us, all of it
+// moving the 12.6 MB [B * 256, 48] product; the direct kernel reads the activation once (19.6 us).  Fixed geometry: 64 features
+// to 3 x 32 x 32.  (The same was built for the Conv2d(3 -> 64) side -- forward, ConvT backward-data, both weight gradients -- and
+// measured SLOWER than patch matrix + contraction (24 / 18 us against 27 / 12 with the patch matrix shared by two uses): removed.)
+constexpr int kBC = 3, kBF = 64, kBH = 32, kBO = 16, kBK = kBC * 16;  // channels, features, image / feature-map extent, patch
+
+// y[b, c, Y, X] = bias[c] + sum over the 4 (y, ky) x (x, kx) pairs with Y = 2 y - 1 + ky, X = 2 x - 1 + kx and the 64 input features
+// of src[(b, y, x)][ic] W[ic][c * 16 + ky * 4 + kx]: ConvTranspose2d(64 -> 3) to NCHW.  Workgroup = (image, 8 output rows); wave =
+// one parity class (Y % 2, X % 2), so that the taps -- the weight rows -- are uniform per wave (broadcast reads).
+__global__ __launch_bounds__(256) void k_convT_to3_fwd(const float* __restrict__ src, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ y) {
+  constexpr int LDP = kBF + 4;
+  __shared__ __attribute__((aligned(16))) float ss[6 * kBO * LDP];   // source rows Y0/2 - 1 .. Y0/2 + 4
+  __shared__ __attribute__((aligned(16))) float Wp[16][kBC][kBF];   // [ky * 4 + kx][c][ic]
+  const int tid = threadIdx.x, b = blockIdx.x >> 2, Y0 = (blockIdx.x & 3) << 3, ybase = (Y0 >> 1) - 1;
+  for (int e = tid; e < 6 * kBO * (kBF / 4); e += 256) {
+    const int q = e & 15, pixl = e >> 4, r = pixl >> 4, xx = pixl & 15, yy = ybase + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (yy >= 0 && yy < kBO) v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * kBO + yy) * kBO + xx) * kBF + 4 * q);
+    *reinterpret_cast<f32x4*>(&ss[(r * kBO + xx) * LDP + 4 * q]) = v;
+  }
+  for (int e = tid; e < kBF * kBK; e += 256) {
+    const int ic = e / kBK, k = e - ic * kBK;
+    Wp[k & 15][k >> 4][ic] = W[e];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, pyp = wave >> 1, pxp = wave & 1;
+  const int Y = Y0 + 2 * (lane >> 4) + pyp, X = 2 * (lane & 15) + pxp;
+  float acc[kBC];
+#pragma unroll
+  for (int c = 0; c < kBC; ++c) acc[c] = 0.f;
+#pragma unroll 1
+  for (int ty = 0; ty < 2; ++ty)
+#pragma unroll 1
+    for (int tx = 0; tx < 2; ++tx) {
+      const int ky = ((pyp + 1) & 1) + 2 * ty, kx = ((pxp + 1) & 1) + 2 * tx;  // uniform per wave
+      const int yy = (Y + 1 - ky) >> 1, xx = (X + 1 - kx) >> 1;
+      const bool ok = yy >= 0 && yy < kBO && xx >= 0 && xx < kBO;
+      const float* sp = &ss[((ok ? yy - ybase : 0) * kBO + (ok ? xx : 0)) * LDP];
+#pragma unroll 4
+      for (int q = 0; q < kBF / 4; ++q) {
+        f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 4 * q);
+        if (!ok) sv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < kBC; ++c) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wp[ky * 4 + kx][c][4 * q]);
+          acc[c] = fmaf(sv[0], wv[0], fmaf(sv[1], wv[1], fmaf(sv[2], wv[2], fmaf(sv[3], wv[3], acc[c]))));
+        }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < kBC; ++c)
+    y[(((size_t)b * kBC + c) * kBH + Y) * kBH + X] = acc[c] + (bias ? bias[c] : 0.f);
+}
+
+static bool boundary_geometry(int C, int H, int Wd, int F) { return C == kBC && H == kBH && Wd == kBH && F == kBF; }
+
+extern "C" int mvae_convT_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F,
+                                             int IH, int IW, int C, void* stream) {
+  if (!src || !W || !y || B < 1) return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+  if (!boundary_geometry(C, 2 * IH, 2 * IW, F)) return fail(MVAE_E_UNSUPPORTED, "direct boundary convolution: 64 features to 3 x 32 x 32%s", "");
+  if ((((uintptr_t)src) & 15) != 0) return fail(MVAE_E_ALIGN, "direct boundary transposed convolution needs a 16-byte aligned src%s", "");
+  hipLaunchKernelGGL(k_convT_to3_fwd, dim3((unsigned)B * 4), dim3(256), 0, (hipStream_t)stream, src, W, bias, y);
+  LAUNCH_CHECK("direct boundary transposed convolution launch");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ conv architecture: the latent section in four launches
 // conv_vae.py:65-71 between the last encoder convolution and the first decoder convolution:
 //   h = a2.view(bs, -1)  (NCHW flatten: column c * 16 + p)  ->  fc_mean / fc_logvar of every component (component.py:52-57)

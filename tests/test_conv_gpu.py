@@ -656,3 +656,19 @@ def test_split_product_contractions_vs_float64(dev, M, N, K):
         assert_close(_cpu(ys[1]), _cpu(ys[0]), 2e-5, "gathered, split vs f32 MFMA", atol_frac=1e-5)
     finally:
         load().mvae_set_contraction_mode(0)
+
+
+@pytest.mark.parametrize("B", [1, 5, 256])
+def test_direct_transposed_boundary_layer_vs_torch(dev, B):
+    """mvae_convT_to3_k4s2p1_forward (conv_vae.py:54 without the [B * 256, 48] product and col2im) against
+    torch.nn.functional.conv_transpose2d in float64."""
+    import torch.nn.functional as F
+    from mvae_amd import conv as Cv
+    gen = torch.Generator().manual_seed(B)
+    src = torch.relu(torch.randn(B, 64, 16, 16, generator=gen))
+    Wt = torch.randn(64, 3, 4, 4, generator=gen) * 0.2
+    bt = torch.randn(3, generator=gen) * 0.1
+    out = F.conv_transpose2d(src.double(), Wt.double(), bt.double(), stride=2, padding=1)  # [B, 3, 32, 32]
+    src_cl = src.permute(0, 2, 3, 1).contiguous().view(B * 256, 64).to(dev)
+    lo = Cv._convT_to3(src_cl, Wt.view(64, 48).to(dev), bt.to(dev), B)
+    assert_close(_cpu(lo.view(B, 3, 32, 32)), out.numpy(), 2e-5, "convT forward", atol_frac=1e-5)

@@ -46,12 +46,13 @@ def test_primitives_vs_golden(dev, man, R, d):
     assert_close(_cpu(u), g[k + "u"], RTOL, k + "u")
     z_ref = T(g[k + "z"]).to(dev)
     iu, iv = Fn.inverse_sample_projection_mu0(kind, z_ref, mu_ref, Rt)
-    # the inverse maps cancel catastrophically for points far from the origin (alpha^2 - 1); both sides evaluate
-    # the same expression, differences come from cosh/sinh/log ulps upstream
-    assert_close(_cpu(iu), g[k + "inv_u"], 5 * RTOL, k + "inv_u", atol_frac=5 * RTOL)
-    assert_close(_cpu(iv), g[k + "inv_v"], 5 * RTOL, k + "inv_v", atol_frac=5 * RTOL)
-    assert_close(_cpu(Fn.inverse_exp_map_mu0(kind, mu_ref, Rt)), g[k + "log_mu0"], 5 * RTOL, k + "log_mu0",
-                 atol_frac=5 * RTOL)
+    # The inverse maps cancel for points far from the origin (alpha^2 - 1); both sides evaluate the same expression.
+    # Measured over the whole grid (tests/dev/inverse_map_errors.py): worst |HIP - reference f32| = 5.0e-6 of the tensor's
+    # scale, where the reference's own float32 deviates 1.9e-6 from its float64 -- so the bar is the 1e-4 one with an
+    # absolute floor of 2e-5 of the scale (rounds 1-2 allowed 5e-4 on both).
+    assert_close(_cpu(iu), g[k + "inv_u"], RTOL, k + "inv_u", atol_frac=2e-5)
+    assert_close(_cpu(iv), g[k + "inv_v"], RTOL, k + "inv_v", atol_frac=2e-5)
+    assert_close(_cpu(Fn.inverse_exp_map_mu0(kind, mu_ref, Rt)), g[k + "log_mu0"], RTOL, k + "log_mu0", atol_frac=2e-5)
     if man == "E":
         return
     u_ref = T(g[k + "u"]).to(dev)
@@ -63,8 +64,8 @@ def test_primitives_vs_golden(dev, man, R, d):
     mu0 = torch.zeros_like(mu_ref)
     mu0[..., 0] = R
     iu0, iv0 = Fn.inverse_sample_projection_mu0(kind, z_ref, mu0, Rt)
-    assert_close(_cpu(iu0), g[k + "inv0_u"], 5 * RTOL, k + "inv0_u", atol_frac=5 * RTOL)
-    assert_close(_cpu(iv0), g[k + "inv0_v"], 5 * RTOL, k + "inv0_v", atol_frac=5 * RTOL)
+    assert_close(_cpu(iu0), g[k + "inv0_u"], RTOL, k + "inv0_u", atol_frac=2e-5)
+    assert_close(_cpu(iv0), g[k + "inv0_v"], RTOL, k + "inv0_v", atol_frac=2e-5)
 
 
 @pytest.mark.parametrize("kind,name", [(1, "h"), (2, "s"), (0, "e"), (3, "p")])
