@@ -41,7 +41,7 @@ struct mvae_ctx {
   bool no_blk;           // MVAE_NO_BLK=1: per-row latent kernels for many-component models too (A/B measurements)
   bool blk_small;        // MVAE_BLK_SMALL=1: the block backward kernel also for z_dim <= 16 (the fused-forward configs)
   bool blk_fwd;          // block kernels in the forward launches as well (MVAE_BLK_FWD=0: per-row forward, A/B measurements)
-  bool coop;             // large components (true dim >= 9, kinds h / s / e): wave-cooperative kernels (MVAE_NO_COOP=1: off)
+  bool coop;             // large components (true dim >= 9): wave-cooperative kernels (MVAE_NO_COOP=1: off)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
       const float rp = c.kind == kEuclidean ? 0.f : rad_s[c.radius_idx];
       float zl = 0.f, klv = 0.f;
       (void)coop_eval<float>(c.kind, m, l, e, rp, d, lane, &zl, &klv);
-      const int idx = c.kind == kEuclidean ? j : lane;
+      const int idx = coop_z_shifted(c.kind) ? j : lane;
       if (idx >= 0 && idx < ambient_dim(c.kind, d)) {
         z_s[c.z_col + idx] = zl;
         z[row * ldz + c.z_col + idx] = zl;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512) void k_duals_coop(CompTable t, const float* he
   Dual zl{0.f, 0.f}, klv{0.f, 0.f};
   (void)coop_eval<Dual>(c.kind, m, l, act ? ev_ : 0.f, rp, d, lane, &zl, &klv);
   float* rec = duals + ((size_t)row * (NH + t.n) + t.first_dir[ci] + dir) * DS;
-  const int idx = c.kind == kEuclidean ? j : lane;
+  const int idx = coop_z_shifted(c.kind) ? j : lane;
   if (idx >= 0 && idx < ambient_dim(c.kind, d)) rec[1 + idx] = zl.d;
   if (lane == 0) rec[0] = klv.d;
 }

@@ -390,17 +390,22 @@ def test_large_component_step_vs_the_reference(dev, name):
         assert_close(summary_of(_cpu(t), ref), ref, 2e-4, "param " + n, atol_frac=2e-4)
 
 
-@pytest.mark.parametrize("model,scalar,B", [("h12,s20,e9", False, 48), ("h10,s10", True, 37), ("e33,h63", False, 16)])
+@pytest.mark.parametrize("model,scalar,B", [("h12,s20,e9", False, 48), ("h10,s10", True, 37), ("e33,h63", False, 16),
+                                            ("p12,d10,e9", False, 24), ("d16,p9", True, 19), ("u10,p40,d40", False, 16)])
 def test_wave_cooperative_components_vs_oracle(dev, model, scalar, B, monkeypatch):
     """Large true dimensions (d >= 9) run on the wave-cooperative kernels (mvae_coop.hpp: one wave per (row, component
     [, input direction]), lane = vector entry): outputs, every gradient (heads, radii) and the updated parameters against
-    the oracle, full and scalar parametrisation, ragged batches, d up to 63; and against the one-lane-per-record kernels
-    (MVAE_NO_COOP=1), which evaluate the same formulas with index-order sums."""
+    the oracle, full and scalar parametrisation, ragged batches, d up to 63, the projected models (Poincare ball, projected
+    sphere, universal: the reference's `p40`, `d40`) included; and against the one-lane-per-record kernels (MVAE_NO_COOP=1),
+    which evaluate the same formulas with index-order sums."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
     from oracle import model as M
     spec = M.Spec(model, in_dim=784, h_dim=400, fixed_curvature=False, scalar_parametrization=scalar)
     state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    for n in state0:
+        if n.endswith("_curvature"):  # `u`: K = -0.5, a ball of radius 1.41 (K = +2 is a projected sphere of radius 0.71 whose
+            state0[n] = torch.full_like(state0[n], -0.5)  # 10-dimensional KL is conditioned past float32: tests/dev/coop_u_probe.py)
     x = synthetic.binary_batches(1, B, 784)[0]
     eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
     orc = M.StepOracle(spec, state0)
@@ -422,11 +427,26 @@ def test_wave_cooperative_components_vs_oracle(dev, model, scalar, B, monkeypatc
 
     eng, out = run(False)
     assert_close(out["concat_z"], ref.concat_z.detach().numpy(), RTOL, "concat_z")
-    assert_close(out["kl"], ref.kl.detach().numpy(), RTOL, "kl", atol_frac=1e-4)
+    # KL of the projected sphere at d >= 10 is ill-conditioned in float32 (tan near its pole): the float32 ORACLE is up to
+    # 1.7e-4 from its own float64 there (tests/dev/coop_u_probe.py: 24.1252 / 24.1293; per-lane kernels 24.1272, cooperative
+    # 24.1320).  The bar is the 1e-4 one around the float64 oracle, widened entry by entry by twice the float32 oracle's own
+    # deviation from it.
+    ref64 = M.StepOracle(spec, state0, dtype=torch.float64).train_step(x.double(), eps.double(), beta=0.7, epoch=12)
+    kl64, kl32 = ref64.kl.detach().numpy(), ref.kl.detach().numpy().astype(np.float64)
+    slack = RTOL * np.abs(kl64) + 1e-4 * np.abs(kl64).max() + 2.0 * np.abs(kl32 - kl64)
+    bad = np.abs(out["kl"].astype(np.float64) - kl64) > slack
+    assert not bad.any(), f"kl: {bad.sum()} entries off, worst {np.abs(out['kl'] - kl64)[bad].max():.3e}"
     assert_close(out["bce"], ref.bce.detach().numpy(), RTOL, "bce")
+    # (the universal curvatures' gradients are clipped to joint norm 1 inside the optimizer launch, vae.py:161-163; the
+    #  oracle's .grad is already clipped: apply clip_grad_norm_'s factor to the raw gradients read before the step)
+    cn = float(np.sqrt(sum(float((g_ ** 2).sum()) for n_, g_ in out["grads"].items() if n_.endswith("_curvature"))))
+    clip = min(1.0, 1.0 / (cn + 1e-6))
     for n, gnp in out["grads"].items():
         if orc.P[n].grad is not None:
-            assert_close(gnp, orc.P[n].grad.numpy(), 2 * RTOL, "grad " + n, atol_frac=2e-4)
+            got = gnp * clip if n.endswith("_curvature") else gnp
+            # (d/dK multiplies per-row terms that cancel: float32 oracle and kernels agree to ~1e-3 there)
+            assert_close(got, orc.P[n].grad.numpy(), 2 * RTOL if not n.endswith("_curvature") else 5e-3, "grad " + n,
+                         atol_frac=2e-4)
     for n, t in eng.param_views().items():
         assert_close_after_adam(_cpu(t), orc.P[n].detach().numpy(), 1e-3, 1, f"param {n}")
     _, out_l = run(True)
