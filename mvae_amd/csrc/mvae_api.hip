@@ -1,6 +1,7 @@
 // mvae_api.hip -- the operator-level part of the C ABI (include/mvae_hip.h): manifold primitives and their backward,
 // the reference's guarded scalar functions, the per-component operators, generic dense layers, log-likelihood helpers.
 #include "mvae_common.hpp"
+#include "mvae_coop.hpp"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -548,6 +549,10 @@ extern "C" int mvae_mul(const float* a, const float* b, float* out, int64_t n, v
 }
 
 // ------------------------------------------------------------------------------------------------ component kernels (API)
+static bool no_coop_env() {
+  const char* nc = getenv("MVAE_NO_COOP");
+  return nc && nc[0] && nc[0] != '0';
+}
 template <int DMAX>
 __global__ __launch_bounds__(256) void k_comp_fwd(CompTable t, const float* heads, int heads_ld, const float* eps,
                                                   int eps_ld, const float* radii, float* z, int z_ld, float* kl,
@@ -587,6 +592,81 @@ __global__ __launch_bounds__(256) void k_comp_bwd(CompTable t, const float* head
   }
 }
 
+// The same two operators for LARGE true dimensions (d >= 9: `h40`, `p40`, ...) in the wave-cooperative form of mvae_coop.hpp: one
+// WAVE per (row, component) forward, per (row, component, input direction) backward, lane = vector entry, no scratch memory.
+__global__ __launch_bounds__(256) void k_comp_fwd_coop(CompTable t, const float* heads, int heads_ld, const float* eps,
+                                                       int eps_ld, const float* radii, float* z, int z_ld, float* kl,
+                                                       float* lq, float* lp, float* mu, float* sd, int64_t rows,
+                                                       int64_t head_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= rows * t.n) return;
+  const int64_t r = it % rows;
+  const int ci = (int)(it / rows);
+  const int64_t hr = r % head_rows;
+  const bool first = r < head_rows;
+  const mvae_component_desc c = t.c[ci];
+  const int d = c.true_dim, lvd = c.logvar_dim, j = lane - 1;
+  const bool act = lane >= 1 && lane <= d;
+  const float* hrow = heads + hr * heads_ld;
+  const float m = act ? hrow[c.mean_col + j] : 0.f;
+  const float l = act ? hrow[c.logvar_col + (lvd == 1 ? 0 : j)] : 0.f;
+  const float e = act ? eps[r * eps_ld + c.eps_col + j] : 0.f;
+  const float rp = c.kind == kEuclidean ? 0.f : radii[c.radius_idx];
+  float zl = 0.f, klv = 0.f;
+  CoopExtra<float> ex{0.f, 0.f, 0.f, 0.f};
+  (void)coop_eval<float>(c.kind, m, l, e, rp, d, lane, &zl, &klv, &ex);
+  const int A = ambient_dim(c.kind, d), idx = coop_z_shifted(c.kind) ? j : lane;
+  if (idx >= 0 && idx < A) {
+    z[r * z_ld + c.z_col + idx] = zl;
+    if (mu && first) mu[hr * z_ld + c.z_col + idx] = ex.mu;
+  }
+  if (sd && first && act && j < lvd) sd[hr * eps_ld + c.eps_col + j] = ex.sg;
+  if (lane == 0) {
+    if (kl) kl[(int64_t)ci * rows + r] = klv;
+    if (lq) {
+      lq[(int64_t)ci * rows + r] = ex.lq;
+      lp[(int64_t)ci * rows + r] = ex.lp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_comp_bwd_coop(CompTable t, const float* heads, int heads_ld, const float* eps,
+                                                       int eps_ld, const float* radii, const float* dz, int z_ld,
+                                                       const float* dkl, float dkl_scalar, float* dheads,
+                                                       float* drad_rows, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= rows * t.total_dirs) return;
+  const int64_t r = it / t.total_dirs;
+  const int gd = (int)(it % t.total_dirs);
+  int ci = 0;
+  while (gd >= t.dir_off[ci + 1]) ++ci;
+  const int dir = gd - t.dir_off[ci];
+  const mvae_component_desc c = t.c[ci];
+  const int d = c.true_dim, lvd = c.logvar_dim, j = lane - 1;
+  const bool act = lane >= 1 && lane <= d;
+  const float* hrow = heads + r * heads_ld;
+  const float mv_ = hrow[c.mean_col + (act ? j : 0)];
+  const float lv_ = hrow[c.logvar_col + ((act && lvd != 1) ? j : 0)];
+  const float ev_ = eps[r * eps_ld + c.eps_col + (act ? j : 0)];
+  const float rv_ = c.kind == kEuclidean ? 0.f : radii[c.radius_idx];
+  const Dual m{act ? mv_ : 0.f, (act && dir == j) ? 1.f : 0.f};
+  const Dual l{act ? lv_ : 0.f, (act && (lvd == 1 ? dir == d : dir == d + j)) ? 1.f : 0.f};
+  const Dual rp{rv_, dir == d + lvd ? 1.f : 0.f};
+  Dual zl{0.f, 0.f}, klv{0.f, 0.f};
+  (void)coop_eval<Dual>(c.kind, m, l, act ? ev_ : 0.f, rp, d, lane, &zl, &klv);
+  const int A = ambient_dim(c.kind, d), idx = coop_z_shifted(c.kind) ? j : lane;
+  const float dzl = (idx >= 0 && idx < A) ? dz[r * z_ld + c.z_col + idx] : 0.f;
+  const float w = dkl ? dkl[(int64_t)ci * rows + r] : dkl_scalar;
+  const float g = w * klv.d + wave_sum(dzl * zl.d);
+  if (lane == 0) {
+    if (dir < d) dheads[r * heads_ld + c.mean_col + dir] = g;
+    else if (dir < d + lvd) dheads[r * heads_ld + c.logvar_col + (dir - d)] = g;
+    else drad_rows[(int64_t)c.radius_idx * rows + r] = g;
+  }
+}
+
 // out[i] = sum_r part[i][r], one workgroup per i, fixed order (thread t adds r = t, t+256, ...; wave sums by DPP; the four
 // wave totals in wave order): the radius gradient of the standalone component backward, bit-reproducible.
 __global__ __launch_bounds__(256) void k_rowsum_fixed(const float* part, float* out, int64_t rows) {
@@ -618,6 +698,13 @@ extern "C" int mvae_component_forward(const mvae_component_desc* comps, int ncom
   int grid = (int)((rows * ncomp + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipStream_t s = (hipStream_t)stream;
+  if (bucket_of(dmax) > 8 && coop_eligible(t) && !no_coop_env()) {
+    const int64_t waves = rows * ncomp;
+    hipLaunchKernelGGL(k_comp_fwd_coop, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
+                       radii, z, z_ld, kl, log_q, log_p, mu, sd, rows, head_rows);
+    LAUNCH_CHECK("cooperative component forward launch");
+    return 0;
+  }
   DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_comp_fwd<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
                                        radii, z, z_ld, kl, log_q, log_p, mu, sd, rows, head_rows));
   LAUNCH_CHECK("component forward launch");
@@ -651,8 +738,14 @@ extern "C" int mvae_component_backward(const mvae_component_desc* comps, int nco
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)ncomp * (size_t)rows, s);  // Euclidean rows stay 0
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
   }
-  DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_comp_bwd<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
-                                       radii, dz, z_ld, dkl, dkl_scalar, dheads, workspace, rows));
+  if (bucket_of(dmax) > 8 && coop_eligible(t) && !no_coop_env()) {
+    const int64_t waves = rows * t.total_dirs;
+    hipLaunchKernelGGL(k_comp_bwd_coop, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
+                       radii, dz, z_ld, dkl, dkl_scalar, dheads, workspace, rows);
+  } else {
+    DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_comp_bwd<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld,
+                                         radii, dz, z_ld, dkl, dkl_scalar, dheads, workspace, rows));
+  }
   if (dradii) hipLaunchKernelGGL(k_rowsum_fixed, dim3(ncomp), dim3(256), 0, s, workspace, dradii, rows);
   LAUNCH_CHECK("component backward launch");
   return 0;

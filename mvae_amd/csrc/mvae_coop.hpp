@@ -30,12 +30,18 @@ __device__ __forceinline__ Dual co_norm(Dual ss) {
   return {nv, nv == 0.0f ? 0.0f : 0.5f * ss.d / nv};
 }
 
+// Optional further outputs of a cooperative evaluation (the stand-alone operator's log_q / log_p / mu / sigma): log-probabilities
+// on every lane, mu in z's lane layout, sigma = entry lane - 1.
+template <typename T> struct CoopExtra {
+  T lq, lp, mu, sg;
+};
+
 // One (row, component[, direction]) per wave.  Lane i: m, l, e = entry i - 1 of the mean head, the logvar head (its ONE
 // entry on every lane under the scalar parametrisation) and eps, for 1 <= i <= d; anything on the other lanes is ignored.
 // Returns the component's KL term (every lane) and leaves in *z_lane: hyperboloid / sphere: entry `lane` of z (0 past A);
 // Euclidean: entry lane - 1 (lanes 1 .. d).
 template <int KIND, typename T>
-__device__ __forceinline__ T coop_component(T m, T l, float e, T rp, int d, int lane, T* z_lane) {
+__device__ __forceinline__ T coop_component(T m, T l, float e, T rp, int d, int lane, T* z_lane, CoopExtra<T>* ex = nullptr) {
   const bool act = lane >= 1 && lane <= d;
   const T zero = cst<T>(0.0f);
   m = co_sel(act, m, zero);
@@ -46,6 +52,12 @@ __device__ __forceinline__ T coop_component(T m, T l, float e, T rp, int d, int 
     const T var_ratio = (sigma / 1.0f) * (sigma / 1.0f);
     const T t1 = ((mu - 0.0f) / 1.0f) * ((mu - 0.0f) / 1.0f);
     const T term = 0.5f * (var_ratio + t1 - 1.0f - t_log(var_ratio));  // kl_divergence(N(mu, sigma), N(0, 1))
+    if (ex) {  // EuclideanNormal.log_prob (wrapped_distributions.py:39-42)
+      ex->lq = co_sum(co_sel(act, normal_logprob_term(*z_lane - mu, sigma), zero));
+      ex->lp = co_sum(co_sel(act, normal_logprob_term(*z_lane, cst<T>(1.0f)), zero));
+      ex->mu = co_sel(act, mu, zero);
+      ex->sg = sigma;
+    }
     return co_sum(co_sel(act, term, zero));
   } else {
     constexpr bool HYP = KIND == kHyperboloid;
@@ -114,6 +126,12 @@ __device__ __forceinline__ T coop_component(T m, T l, float e, T rp, int d, int 
     const T logdet_p = logdet(u0);
     const T nq = co_sum(co_sel(act, normal_logprob_term(v, sigma), zero));
     const T np = co_sum(co_sel(act, normal_logprob_term(v0, cst<T>(1.0f)), zero));
+    if (ex) {
+      ex->lq = nq - logdet_q;
+      ex->lp = np - logdet_p;
+      ex->mu = mu;
+      ex->sg = sigma;
+    }
     return (nq - logdet_q) - (np - logdet_p);       // wrapped_normal.py:84-97, sampling_procedures.py:101-104
   }
 }
@@ -127,7 +145,7 @@ __device__ __forceinline__ T coop_component(T m, T l, float e, T rp, int d, int 
 // ...), log_map at the origin, geoopt 0.1.0's guards (MIN_NORM 1e-15 on norms and the mobius_add denominator, tanh clamp 15,
 // artanh clamp 1 - 1e-5).  *z_lane = entry lane - 1 of z (lanes 1 .. d).
 template <int KIND, typename T>
-__device__ __forceinline__ T coop_projected(T m, T l, float e, T rp, int d, int lane, T* z_lane) {
+__device__ __forceinline__ T coop_projected(T m, T l, float e, T rp, int d, int lane, T* z_lane, CoopExtra<T>* ex = nullptr) {
   constexpr bool BALL = KIND == kPoincare;
   const bool act = lane >= 1 && lane <= d;
   const T zero = cst<T>(0.0f);
@@ -237,19 +255,26 @@ __device__ __forceinline__ T coop_projected(T m, T l, float e, T rp, int d, int 
   const T logdet_p = logdet(origin, z);
   const T nq = co_sum(co_sel(act, normal_logprob_term(v, sigma), zero));
   const T np = co_sum(co_sel(act, normal_logprob_term(v0, cst<T>(1.0f)), zero));
+  if (ex) {
+    ex->lq = nq - logdet_q;
+    ex->lp = np - logdet_p;
+    ex->mu = co_sel(act, mu, zero);
+    ex->sg = sigma;
+  }
   return (nq - logdet_q) - (np - logdet_p);
 }
 
 // dispatch on the (runtime, wave-uniform) kind; false if the kind has no cooperative form
 template <typename T>
-__device__ __forceinline__ bool coop_eval(int kind, T m, T l, float e, T rp, int d, int lane, T* z_lane, T* kl) {
+__device__ __forceinline__ bool coop_eval(int kind, T m, T l, float e, T rp, int d, int lane, T* z_lane, T* kl,
+                                          CoopExtra<T>* ex = nullptr) {
   kind = resolve_universal(kind, rp);  // `u`: Poincare ball / projected sphere / Euclidean by the sign of K (wave-uniform)
   switch (kind) {
-    case kEuclidean: *kl = coop_component<kEuclidean, T>(m, l, e, rp, d, lane, z_lane); return true;
-    case kHyperboloid: *kl = coop_component<kHyperboloid, T>(m, l, e, rp, d, lane, z_lane); return true;
-    case kSphere: *kl = coop_component<kSphere, T>(m, l, e, rp, d, lane, z_lane); return true;
-    case kPoincare: *kl = coop_projected<kPoincare, T>(m, l, e, rp, d, lane, z_lane); return true;
-    case kProjSphere: *kl = coop_projected<kProjSphere, T>(m, l, e, rp, d, lane, z_lane); return true;
+    case kEuclidean: *kl = coop_component<kEuclidean, T>(m, l, e, rp, d, lane, z_lane, ex); return true;
+    case kHyperboloid: *kl = coop_component<kHyperboloid, T>(m, l, e, rp, d, lane, z_lane, ex); return true;
+    case kSphere: *kl = coop_component<kSphere, T>(m, l, e, rp, d, lane, z_lane, ex); return true;
+    case kPoincare: *kl = coop_projected<kPoincare, T>(m, l, e, rp, d, lane, z_lane, ex); return true;
+    case kProjSphere: *kl = coop_projected<kProjSphere, T>(m, l, e, rp, d, lane, z_lane, ex); return true;
     default: return false;
   }
 }

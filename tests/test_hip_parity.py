@@ -610,3 +610,39 @@ def test_wrapped_normal_envelope(dev, d, scale, radius):
         assert_close(a[well], b[well], 2e-4, f"log_q d={d} scale={scale} R={radius}", atol_frac=2e-4)
     if (~well).any():
         assert np.abs(a[~well] - b[~well]).max() < 0.5 * (d - 1) + 1e-3
+
+
+@pytest.mark.parametrize("model,scalar", [("h40,s12", False), ("p40,d16,e9", False), ("u10,h9", True)])
+def test_cooperative_component_operators_vs_per_lane(dev, monkeypatch, model, scalar):
+    """mvae_component_forward / _backward (the operators behind Component.forward / rsample / kl_loss and the
+    log-likelihood) take the wave-cooperative kernels for true dimensions >= 9 too (k_comp_fwd_coop / k_comp_bwd_coop): z,
+    kl, log q, log p, mu, sigma, dheads and dradii against the one-lane-per-item kernels (MVAE_NO_COOP=1), with the heads
+    broadcast over a leading sample dimension and with both forms of the KL weight."""
+    from mvae_amd import functional as Fn
+    from mvae_amd.functional import ComponentLayout
+    comps = [(tok[0], int(tok[1:])) for tok in model.split(",")]
+    lay = ComponentLayout(comps, scalar)
+    gen = torch.Generator().manual_seed(11)
+    B, S = 21, 3
+    heads = (torch.randn(B, lay.heads_dim, generator=gen) * 0.3).to(dev)
+    eps = torch.randn(S, B, lay.eps_dim, generator=gen).to(dev)
+    radii = torch.tensor([-0.5 if k == "u" else 1.5 + 0.25 * i for i, (k, _) in enumerate(comps)]).to(dev)
+    dz = torch.randn(B, lay.z_dim, generator=gen).to(dev)
+    dkl = torch.randn(lay.n, B, generator=gen).to(dev)
+
+    def run(no_coop):
+        monkeypatch.setenv("MVAE_NO_COOP", no_coop)
+        a = Fn.component_forward(lay, heads, eps, radii, want_kl=True, want_log_probs=True, want_params=True)
+        b = Fn.component_forward(lay, heads, eps[0], radii, want_kl=True)
+        g1 = Fn.component_backward(lay, heads, eps[0], radii, dz, dkl)
+        g2 = Fn.component_backward(lay, heads, eps[0], radii, dz, None, 0.7)
+        torch.cuda.synchronize()
+        return a, b, g1, g2
+
+    (a, b, g1, g2), (al, bl, g1l, g2l) = run("0"), run("1")
+    for k in ("z", "kl", "log_q", "log_p", "mu", "std"):
+        assert_close(_cpu(a[k]), _cpu(al[k]), 1e-5, k, atol_frac=1e-5)
+    assert_close(_cpu(b["z"]), _cpu(bl["z"]), 1e-5, "z (training shape)", atol_frac=1e-5)
+    for (dh, dr), (dhl, drl), nm in ((g1, g1l, "per-row KL weights"), (g2, g2l, "scalar KL weight")):
+        assert_close(_cpu(dh), _cpu(dhl), 2e-4, "dheads, " + nm, atol_frac=2e-5)
+        assert_close(_cpu(dr), _cpu(drl), 2e-4, "dradii, " + nm, atol_frac=2e-5)
