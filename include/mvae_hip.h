@@ -319,7 +319,7 @@ int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta
 /* nn.ConvTranspose2d(64, 3, 4, 2, 1) (conv_vae.py:54) direct, from the channel-last activation src [B*IH*IW, 64] to NCHW
  * logits: y[b,c,Y,X] = bias[c] + sum src[(b,y,x)][f] W[f][c*16+ky*4+kx] over Y = 2y-1+ky, X = 2x-1+kx.  Geometry fixed to 64
  * features -> 3 x 32 x 32 (MVAE_E_UNSUPPORTED otherwise; the generic form is mvae_gemm_nn + mvae_col2im_k4s2p1). */
-int mvae_convT_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F, int IH,
+int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F, int IH,
                                   int IW, int C, void* stream);
 /* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode; a negative
  * argument only queries).

@@ -91,7 +91,7 @@ PROTOTYPES = {
     "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
     "mvae_batch_stats": (C.c_int, [_P, _P, _P, _F, _I, _I, _P]),
     "mvae_set_contraction_mode": (C.c_int, [_I]),
-    "mvae_convT_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mvae_convt_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_bce_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _P, _P, _P, _P]),
     "mvae_conv_latent_supported": (C.c_int, [_P, _I]),
     "mvae_conv_latent_workspace_floats": (_L, [_L, _I]),

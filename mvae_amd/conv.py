@@ -232,7 +232,7 @@ def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[
 def _convT_to3(src: Tensor, W48: Tensor, bias: Tensor, R: int) -> Tensor:
     """Direct ConvTranspose2d(64 -> 3, k4 s2 p1): channel-last [R * 256, 64] -> NCHW logits [R, 3072]."""
     y = src.new_empty(R, 3072)
-    check(load().mvae_convT_to3_k4s2p1_forward(ptr(src), ptr(W48), ptr(bias), ptr(y), R, 64, 16, 16, 3,
+    check(load().mvae_convt_to3_k4s2p1_forward(ptr(src), ptr(W48), ptr(bias), ptr(y), R, 64, 16, 16, 3,
                                                stream_ptr(src.device)))
     return y
 

@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void k_convT_to3_fwd(const float* __restrict__
 
 static bool boundary_geometry(int C, int H, int Wd, int F) { return C == kBC && H == kBH && Wd == kBH && F == kBF; }
 
-extern "C" int mvae_convT_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F,
+extern "C" int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F,
                                              int IH, int IW, int C, void* stream) {
   if (!src || !W || !y || B < 1) return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
   if (!boundary_geometry(C, 2 * IH, 2 * IW, F)) return fail(MVAE_E_UNSUPPORTED, "direct boundary convolution: 64 features to 3 x 32 x 32%s", "");

@@ -660,7 +660,7 @@ def test_split_product_contractions_vs_float64(dev, M, N, K):
 
 @pytest.mark.parametrize("B", [1, 5, 256])
 def test_direct_transposed_boundary_layer_vs_torch(dev, B):
-    """mvae_convT_to3_k4s2p1_forward (conv_vae.py:54 without the [B * 256, 48] product and col2im) against
+    """mvae_convt_to3_k4s2p1_forward (conv_vae.py:54 without the [B * 256, 48] product and col2im) against
     torch.nn.functional.conv_transpose2d in float64."""
     import torch.nn.functional as F
     from mvae_amd import conv as Cv
