@@ -567,11 +567,12 @@ def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
         assert_close(_cpu(got), _cpu(want), 2e-5, nm, atol_frac=2e-5)
 
 
-@pytest.mark.parametrize("B", [256, 77, 640])
-def test_fused_conv_step_vs_the_generic_step(dev, monkeypatch, B):
+@pytest.mark.parametrize("B,scalar", [(256, False), (77, False), (640, False), (48, True)])
+def test_fused_conv_step_vs_the_generic_step(dev, monkeypatch, B, scalar):
     """The whole ConvEngine step with the fused latent section and loss end (MVAE_CONV_FUSED=1, the default) against the
     generic operator sequence (=0): forward outputs and statistics to 2e-5; gradients per entry to 2e-5 when no ReLU
-    output changed sign between the two forward passes, else (see _relu_flips) by norm to 5e-3."""
+    output changed sign between the two forward passes, else (see _relu_flips) by norm to 5e-3.  scalar: one logvar per
+    component (component.py: scalar_parametrization)."""
     from mvae_amd import synthetic
     from mvae_amd.conv import ConvEngine
     comps = _comps_of("h2,s2,e2")
@@ -580,7 +581,7 @@ def test_fused_conv_step_vs_the_generic_step(dev, monkeypatch, B):
 
     def run(fused):
         monkeypatch.setenv("MVAE_CONV_FUSED", fused)
-        eng = ConvEngine(comps, dev, radius_trainable=[True] * len(comps))
+        eng = ConvEngine(comps, dev, scalar_parametrization=scalar, radius_trainable=[True] * len(comps))
         assert eng.fused == (fused == "1")
         shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
         eng.load_state(synthetic.synthetic_state(shapes, radius=1.7, transposed_conv=("d1", "d2", "d3")))
