@@ -10,9 +10,13 @@ gradient, ConvTranspose2d backward-data and weight gradient) the contraction is 
 kernel reads the activation directly (`mvae_conv_k4s2p1_nhwc`, `..._wgrad`), no patch matrix exists in memory (round 1
 wrote and re-read 16x the activation for each of them: ~2 GB of HBM traffic per step at B = 256).  Where it SCATTERS
 (ConvTranspose2d forward, Conv2d backward-data) the contraction writes a patch matrix that `mvae_col2im_k4s2p1` folds
-(<= 4 terms per output, no atomics).  The 3-channel NCHW boundary layers (e0, d3) keep explicit patch matrices (48 wide).  Parameters, gradients and optimizer state
-live in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming kernel
-and data-parallel training all-reduces one buffer.
+(<= 4 terms per output, no atomics) or runs as four implicit contractions, one per output parity class, whichever measured
+faster for the layer.  The 3-channel NCHW boundary layers keep explicit patch matrices (48 wide) except the forward of d3, a
+direct kernel (`mvae_convt_to3_k4s2p1_forward`).  Between the last encoder and the first decoder convolution the latent
+section (flatten -> heads -> components -> decoder fc) is two fused launches each way (`mvae_conv_latent_forward /
+_backward`), the loss end (BCE, statistics, d3.bias) one (`mvae_conv_bce_stats`).  Parameters, gradients and optimizer
+state live in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming
+kernel and data-parallel training all-reduces one buffer.
 
 Weight layout in HBM: the four channel-last layers (e1, e2, d1, d2) keep their weights TAPS-MAJOR in the flat buffers --
 the matrix [rows, (ky, kx, c)] the coalesced gathers contract with -- and expose them to the host model as STRIDED views
@@ -22,6 +26,7 @@ see the reference's tensors, the kernels see the layout they want, and no weight
 and keep the reference's (c, ky, kx) order.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -294,20 +299,19 @@ class ConvEngine:
         self.counters = z(32, torch.int32)
         self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
         self._arrive = z(32, torch.int32)  # arrival counters of mvae_conv_bce_stats (0 between launches)
-        # Backward pass on three HIP streams (MVAE_CONV_STREAMS=0: one): the backward-data chain is the critical path and
-        # stays on the caller's stream; every weight gradient depends on it only through ONE activation gradient and runs
-        # on side stream 0, the bias sums / re-orderings on side stream 1.  The streams fork and join through events, so a
-        # captured step becomes a HIP graph with parallel branches: the ramp-up and tail of a contraction (one round of
-        # workgroups: ~20 % of its duration) are filled by the workgroups of the other branch.
-        import os
-        # the latent section (flatten -> heads -> components -> decoder fc) and the loss end as fused launches
-        # (mvae_conv_latent_*, mvae_conv_bce_stats); MVAE_CONV_FUSED=0 or an unsupported model: the generic operators
-        self.direct = os.environ.get("MVAE_CONV_FUSED", "1") != "0"  # direct boundary layers + the one-launch loss end
+        # Switches (environment, read once per engine; DESIGN section 4, conv architecture):
+        # MVAE_CONV_FUSED (default 1): the loss end as one launch (mvae_conv_bce_stats), the last transposed convolution
+        #   direct (mvae_convt_to3_k4s2p1_forward) and -- where the model's shapes fit, mvae_conv_latent_supported -- the
+        #   latent section (flatten -> heads -> components -> decoder fc) as 2 + 2 fused launches; 0: the generic operators.
+        self.direct = os.environ.get("MVAE_CONV_FUSED", "1") != "0"
         self.fused = self.direct and bool(load().mvae_conv_latent_supported(self.layout.descs, n))
-        # MVAE_CONV_SPLIT_BF16=1: the NT contractions through exact three-way bf16 splits on the bf16 MFMA (process-wide
-        # mode of the library, mvae_set_contraction_mode; off by default: the step's shapes are too small to gain)
+        # MVAE_CONV_SPLIT_BF16 (default: leave the library's mode alone = off): the NT / NN contractions multiply through exact
+        #   three-way bf16 splits on the bf16 MFMA (process-wide, mvae_set_contraction_mode).
         if "MVAE_CONV_SPLIT_BF16" in os.environ:
             load().mvae_set_contraction_mode(1 if os.environ["MVAE_CONV_SPLIT_BF16"] == "1" else 0)
+        # MVAE_CONV_STREAMS (default 0): backward pass on three HIP streams -- the backward-data chain stays on the caller's
+        #   stream, the weight gradients go to side stream 0, the bias sums / re-orderings to side stream 1, forked and joined
+        #   through events (parallel branches in a captured graph).  Same bits, measured SLOWER (1.08 -> 1.21 ms): off.
         self.overlap = os.environ.get("MVAE_CONV_STREAMS", "0") == "1"
         self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if self.overlap else []
         self._forked: List[int] = []
