@@ -609,7 +609,7 @@ def main():
                 extra[key] = fn()
             except Exception as e:  # noqa: BLE001  (a failing leg must not lose the headline line)
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
-        # the conv step once more with the NT contractions multiplying through exact three-way bf16 splits on the bf16 MFMA
+        # the conv step once more with the large contractions multiplying through exact three-way bf16 splits on the bf16 MFMA
         # (mvae_set_contraction_mode(1): f32-class accuracy, tests/test_conv_gpu.py::test_split_product_contractions_vs_float64);
         # reported BESIDE configs.conv, which stays on the f32-input MFMA
         try:
@@ -619,7 +619,7 @@ def main():
             extra["conv_split_bf16_products"] = {
                 "value": leg["value"], "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
                 "dtype": "f32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 MFMA, f32 accumulation "
-                         "(NT contractions only; the rest on the f32-input MFMA)"}
+                         "(every LDS-tiled contraction with more than 64 output columns; the small ones on the f32-input MFMA)"}
         except Exception as e:  # noqa: BLE001
             extra["conv_split_bf16_products"] = {"error": f"{type(e).__name__}: {e}"}
         finally:

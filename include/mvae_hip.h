@@ -323,7 +323,8 @@ int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float*
                                   int IW, int C, void* stream);
 /* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode; a negative
  * argument only queries).
- * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate.  1: every float split EXACTLY into three bf16 pieces,
+ * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate.  1 (contractions with > 64 output columns): every float
+ * split EXACTLY into three bf16 pieces,
  * the six largest piece products on the bf16 MFMA (16x the rate), f32 accumulation: |error| <= 2^-23 |a b| per product
  * on top of f32 accumulation, i.e. the float32 class of nn.Linear / nn.Conv2d on any BLAS (conv_vae.py:47-55). */
 int mvae_set_contraction_mode(int split_bf16_products);

@@ -190,9 +190,6 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def _gemm_nn(G: Tensor, W: Tensor) -> Tensor:
     M, K = G.shape
     N = W.shape[1]
-    if M >= 512 and N > 64 and load().mvae_set_contraction_mode(-1) == 1:
-        # split-product mode has a kernel for the NT form only: transpose the (small) weight once and contract against it
-        return Fn.linear_forward(G, _permute_rc(W, 1, K, N).view(N, K), None)
     out = G.new_empty(M, N)
     check(load().mvae_gemm_nn(ptr(G), ptr(W), None, ptr(out), M, K, N, stream_ptr(G.device)))
     return out
@@ -305,7 +302,7 @@ class ConvEngine:
         #   latent section (flatten -> heads -> components -> decoder fc) as 2 + 2 fused launches; 0: the generic operators.
         self.direct = os.environ.get("MVAE_CONV_FUSED", "1") != "0"
         self.fused = self.direct and bool(load().mvae_conv_latent_supported(self.layout.descs, n))
-        # MVAE_CONV_SPLIT_BF16 (default: leave the library's mode alone = off): the NT / NN contractions multiply through exact
+        # MVAE_CONV_SPLIT_BF16 (default: leave the library's mode alone = off): the large contractions multiply through exact
         #   three-way bf16 splits on the bf16 MFMA (process-wide, mvae_set_contraction_mode).
         if "MVAE_CONV_SPLIT_BF16" in os.environ:
             load().mvae_set_contraction_mode(1 if os.environ["MVAE_CONV_SPLIT_BF16"] == "1" else 0)

@@ -647,12 +647,35 @@ __device__ __forceinline__ void split3(const float4 v, u32x2* hi, u32x2* mi, u32
   *mi = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
   *lo = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
 }
-template <int BM, int BN, int NW, int GATHER>
+// 4 x 4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): lane q of the quad holds row q (4 entries) before,
+// column q after.  The TN forms load 4 consecutive i (or j) of one contraction row k per lane, lanes of a quad = 4 consecutive
+// k: transposed, a lane holds 4 consecutive k of ONE output row -- what the [row][k] staging of k_gemm_b3 stores.
+__device__ __forceinline__ float dpp_quad(float x, int ctrl_xor1) {
+  const int v = __float_as_int(x);
+  return __int_as_float(ctrl_xor1 ? __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false)    // quad_perm [1,0,3,2]
+                                  : __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float4 quad_transpose(float4 v, int lane) {
+  const bool hi2 = lane & 2, hi1 = lane & 1;
+  // distance 2: exchange the off-diagonal 2 x 2 blocks
+  const float a = dpp_quad(hi2 ? v.x : v.z, 0), b = dpp_quad(hi2 ? v.y : v.w, 0);
+  if (hi2) { v.x = a; v.y = b; } else { v.z = a; v.w = b; }
+  // distance 1: transpose inside the 2 x 2 blocks
+  const float c = dpp_quad(hi1 ? v.x : v.y, 1), d = dpp_quad(hi1 ? v.z : v.w, 1);
+  if (hi1) { v.x = c; v.z = d; } else { v.y = c; v.w = d; }
+  return v;
+}
+template <int BM, int BN, int NW, int GATHER, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A, int64_t sai,
                                                  const float* __restrict__ Bm, int64_t sbj, float* __restrict__ C,
                                                  int64_t ldc, const float* __restrict__ bias,
                                                  const float* __restrict__ mask, int relu, int M, int N, int K,
                                                  int k_per_slice, int64_t slice_stride, ConvGeom cg) {
+  // TA / TB = the operand is stored with its OUTPUT index contiguous (A(i, k) = A[k * sai + i], B(k, j) = Bm[k * sbj + j]:
+  // sai / sbj are then the strides of the contraction index) and goes through the transposing stage; otherwise the
+  // contraction index is contiguous (A[i * sai + k], Bm[j * sbj + k]).  Forms: NT (Linear / Conv2d forward, GATHER 0 | 1),
+  // NN (TB: ConvTranspose2d forward / backward-data products; GATHER 3: the transposed convolution per parity class,
+  // blockIdx.z), TN (TA + TB: weight gradients; GATHER 2: against the implicit patch matrix).
   constexpr int BK = 32, KQ = BK / 4;
   __shared__ __attribute__((aligned(16))) unsigned int As[3][BM * kB3LD];
   __shared__ __attribute__((aligned(16))) unsigned int Bs[3][BN * kB3LD];
@@ -662,14 +685,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kb = blockIdx.z * k_per_slice;
-  const int ke = (kb + k_per_slice < K) ? kb + k_per_slice : K;
-  C += (size_t)blockIdx.z * slice_stride;
+  const int kb = GATHER == 3 ? 0 : blockIdx.z * k_per_slice;
+  const int ke = GATHER == 3 ? K : ((kb + k_per_slice < K) ? kb + k_per_slice : K);
+  if (GATHER != 3) C += (size_t)blockIdx.z * slice_stride;
+  const int par_y = GATHER == 3 ? (int)(blockIdx.z >> 1) : 0, par_x = GATHER == 3 ? (int)(blockIdx.z & 1) : 0;
   // Requests run TWO K steps ahead of their stage, in two register sets.  They are branch-free -- a lane outside the
   // tile / image / K range reads the operand's base address and is zeroed at the stage: with exec-masked requests inside
   // branches hipcc's wait-count model loses the number in flight at the join and waits for ALL of them (vmcnt(0)), which
-  // silently turns two steps ahead into one.  One K step of this kernel (192 MFMA cycles per wave) is far shorter than a
-  // fabric round trip, so the distance is what sets its speed.
+  // silently turns two steps ahead into one.
   struct RegSet {
     float4 ra[LA], rb[LB];
     bool oka[LA], okb[LB];
@@ -679,19 +702,26 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
 #pragma unroll
     for (int r = 0; r < LA; ++r) {
       const int f = tid + NT * r;
-      const int i = f / KQ, k = k0 + ((f % KQ) << 2);
-      const int m = m0 + i;
       bool ok;
       const float* p;
-      if (GATHER == 1) {
-        const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
-        const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
-        const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
-        ok = m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW;
-        p = A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c;
+      if constexpr (TA) {  // lane = one contraction row k (32 consecutive lanes = the K step), 4 consecutive i
+        const int k = k0 + (f % BK), i = (f / BK) << 2;
+        ok = m0 + i < M && k < ke;
+        p = A + (size_t)k * sai + (m0 + i);
       } else {
-        ok = m < M && k < ke;
-        p = A + (size_t)m * sai + k;
+        const int i = f / KQ, k = k0 + ((f % KQ) << 2);
+        const int m = m0 + i;
+        if (GATHER == 1 || GATHER == 3) {  // row = output pixel, k = (tap, c): the tap of a K step is uniform
+          const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
+          const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
+          const int iy = GATHER == 1 ? 2 * oy - 1 + (tap >> 2) : oy + par_y - (tap >> 1);
+          const int ix = GATHER == 1 ? 2 * ox - 1 + (tap & 3) : ox + par_x - (tap & 1);
+          ok = m < M && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW;
+          p = A + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c;
+        } else {
+          ok = m < M && k < ke;
+          p = A + (size_t)m * sai + k;
+        }
       }
       rs.ra[r] = *reinterpret_cast<const float4*>(ok ? p : A);
       rs.oka[r] = ok;
@@ -699,20 +729,52 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
       const int f = tid + NT * r;
-      const int j = f / KQ, k = k0 + ((f % KQ) << 2);
-      const bool ok = n0 + j < N && k < ke;
-      rs.rb[r] = *reinterpret_cast<const float4*>(ok ? Bm + (size_t)(n0 + j) * sbj + k : Bm);
+      bool ok;
+      const float* p;
+      if constexpr (TB) {
+        const int k = k0 + (f % BK), j = n0 + ((f / BK) << 2);
+        if (GATHER == 2) {  // B = the patch matrix of a channel-last image: k = output pixel, j = (tap, c)
+          const int tap = j / cg.Cc, c = j - tap * cg.Cc;
+          const int ox = k & ((1 << cg.lOW) - 1), oy = (k & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = k >> cg.lOHW;
+          const int iy = 2 * oy - 1 + (tap >> 2), ix = 2 * ox - 1 + (tap & 3);
+          ok = j < N && k < ke && iy >= 0 && iy < cg.IH && ix >= 0 && ix < cg.IW;
+          p = Bm + ((size_t)(b * cg.IH + iy) * cg.IW + ix) * cg.Cc + c;
+        } else if (GATHER == 3) {  // row k = (tap, c) of the weight [C_in][(ky, kx, oc)]: the tap picks the column block
+          const int tap = k0 / cg.Cc, c = k - tap * cg.Cc;
+          const int ky = 1 - par_y + 2 * (tap >> 1), kx = 1 - par_x + 2 * (tap & 1);
+          ok = j < N && k < ke;
+          p = Bm + (size_t)c * sbj + (size_t)(ky * 4 + kx) * N + j;
+        } else {
+          ok = j < N && k < ke;
+          p = Bm + (size_t)k * sbj + j;
+        }
+      } else {
+        const int j = f / KQ, k = k0 + ((f % KQ) << 2);
+        ok = n0 + j < N && k < ke;
+        p = Bm + (size_t)(n0 + j) * sbj + k;
+      }
+      rs.rb[r] = *reinterpret_cast<const float4*>(ok ? p : Bm);
       rs.okb[r] = ok;
     }
   };
+  // stage: split every float into its three bf16 pieces and store 4 consecutive k of one tile row (8 bytes per piece).  A
+  // transposed operand first turns its quad's 4 x 4 block (4 rows k x 4 entries i) in registers, after which this lane holds
+  // k = 4 (kl / 4) .. + 3 of tile row i + (lane & 3).
   auto stage = [&](const RegSet& rs) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < LA; ++r) {
       const int f = tid + NT * r;
-      const int o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      float4 v = rs.oka[r] ? rs.ra[r] : zero4;
+      int o;
+      if constexpr (TA) {
+        v = quad_transpose(v, lane);
+        o = (((f / BK) << 2) + (lane & 3)) * kB3LD + (((f % BK) >> 2) << 1);
+      } else {
+        o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      }
       u32x2 h, m, l;
-      split3(rs.oka[r] ? rs.ra[r] : zero4, &h, &m, &l);
+      split3(v, &h, &m, &l);
       *reinterpret_cast<u32x2*>(&As[0][o]) = h;
       *reinterpret_cast<u32x2*>(&As[1][o]) = m;
       *reinterpret_cast<u32x2*>(&As[2][o]) = l;
@@ -720,9 +782,16 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
       const int f = tid + NT * r;
-      const int o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      float4 v = rs.okb[r] ? rs.rb[r] : zero4;
+      int o;
+      if constexpr (TB) {
+        v = quad_transpose(v, lane);
+        o = (((f / BK) << 2) + (lane & 3)) * kB3LD + (((f % BK) >> 2) << 1);
+      } else {
+        o = (f / KQ) * kB3LD + ((f % KQ) << 1);
+      }
       u32x2 h, m, l;
-      split3(rs.okb[r] ? rs.rb[r] : zero4, &h, &m, &l);
+      split3(v, &h, &m, &l);
       *reinterpret_cast<u32x2*>(&Bs[0][o]) = h;
       *reinterpret_cast<u32x2*>(&Bs[1][o]) = m;
       *reinterpret_cast<u32x2*>(&Bs[2][o]) = l;
@@ -782,8 +851,12 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   const int lc = (lane >> 4) << 2;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
-    const int m = m0 + wm + a * 16 + li;
+    int m = m0 + wm + a * 16 + li;
     if (m >= M) continue;
+    if (GATHER == 3) {  // row of the parity class -> its pixel of the (2 IH) x (2 IW) output
+      const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, bb = m >> cg.lOHW;
+      m = (bb * 2 * cg.IH + 2 * oy + par_y) * 2 * cg.IW + 2 * ox + par_x;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int n = n0 + wn + b * 16 + lc;
@@ -849,6 +922,31 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
+  if constexpr (!A_KC && !B_KC && (GATHER == 0 || GATHER == 2)) {
+    // TN (weight gradients): the same kernel with a transposing stage; 64 x 64 tiles, slices as chosen by the caller
+    if (g_split_products && N > 64 && M > 64 && sai == 1 && (sak & 3) == 0 && (GATHER == 2 || (sbj == 1 && (sbk & 3) == 0))) {
+      dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
+      hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias, mask,
+                         relu, M, N, K, k_per_slice, slice_stride, cg);
+      return;
+    }
+  }
+  if constexpr (A_KC && !B_KC && (GATHER == 0 || GATHER == 3)) {
+    // NN (B = a weight stored [K][N]) and the transposed convolution per parity class: transposing stage for B only
+    if (g_split_products && N > 64 && (GATHER == 3 || sak == 1) && sbj == 1 && (sbk & 3) == 0) {
+      const int zdim = GATHER == 3 ? 4 : slices;
+      if (wg128 >= 512 && GATHER == 0) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, zdim);
+        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
+                           mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+      } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, zdim);
+        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
+                           mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+      }
+      return;
+    }
+  }
   if constexpr (A_KC && B_KC && (GATHER == 0 || GATHER == 1)) {
     if (g_split_products && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
       const int64_t wg12864 = (int64_t)((N + 63) / 64) * ((M + 127) / 128) * slices;

@@ -655,6 +655,30 @@ def test_split_product_contractions_vs_float64(dev, M, N, K):
             load().mvae_set_contraction_mode(mode)
             ys.append(_conv_nhwc(src, Wt, None, None, B, Cc, IH, False))
         assert_close(_cpu(ys[1]), _cpu(ys[0]), 2e-5, "gathered, split vs f32 MFMA", atol_frac=1e-5)
+        # the TN forms (weight gradients; the stage transposes 4 x 4 blocks in registers): plain and gathered
+        from mvae_amd.conv import _conv_nhwc_wgrad, _gemm_tn
+        Mr = min(M, 4096)
+        P, Q = torch.randn(Mr, 128, generator=gen).to(dev), torch.randn(Mr, 192, generator=gen).to(dev)
+        ref_tn = P.double().t() @ Q.double()
+        dy = torch.randn(B * 64, OC, generator=gen).to(dev)  # gradient of the 8 x 8 output of the conv above
+        outs = []
+        for mode in (0, 1):
+            load().mvae_set_contraction_mode(mode)
+            assert_close(_cpu(_gemm_tn(P, Q)), _cpu(ref_tn), 2e-5, f"TN mode {mode}", atol_frac=1e-5)
+            outs.append(_conv_nhwc_wgrad(dy, src, torch.empty(OC, 16 * Cc, device=dev), B, Cc, IH))
+        assert_close(_cpu(outs[1]), _cpu(outs[0]), 2e-5, "gathered weight gradient, split vs f32 MFMA", atol_frac=1e-5)
+        # the NN forms (transposing stage for B only): a plain product and the transposed convolution per parity class
+        from mvae_amd.conv import _convT_nhwc, _gemm_nn
+        Wn = (torch.randn(K, N, generator=gen) * 0.1).to(dev)
+        ref_nn = x.double() @ Wn.double()
+        Wtt = (torch.randn(Cc, 16 * 96, generator=gen) * 0.05).to(dev)  # ConvTranspose2d(64 -> 96) on the 16 x 16 images
+        bt, mk = torch.randn(96, generator=gen).to(dev), torch.randn(B * 4 * IH * IH, 96, generator=gen).to(dev)
+        outs = []
+        for mode in (0, 1):
+            load().mvae_set_contraction_mode(mode)
+            assert_close(_cpu(_gemm_nn(x, Wn)), _cpu(ref_nn), 2e-5, f"NN mode {mode}", atol_frac=1e-5)
+            outs.append(_convT_nhwc(src, Wtt, bt, mk, B, Cc, IH, 96, True))
+        assert_close(_cpu(outs[1]), _cpu(outs[0]), 2e-5, "transposed convolution, split vs f32 MFMA", atol_frac=1e-5)
     finally:
         load().mvae_set_contraction_mode(0)
 
@@ -673,3 +697,40 @@ def test_direct_transposed_boundary_layer_vs_torch(dev, B):
     src_cl = src.permute(0, 2, 3, 1).contiguous().view(B * 256, 64).to(dev)
     lo = Cv._convT_to3(src_cl, Wt.view(64, 48).to(dev), bt.to(dev), B)
     assert_close(_cpu(lo.view(B, 3, 32, 32)), out.numpy(), 2e-5, "convT forward", atol_frac=1e-5)
+
+
+def test_conv_step_in_split_product_mode(dev, monkeypatch):
+    """The whole conv step with mvae_set_contraction_mode(1) -- NT, NN, TN and parity-class contractions through split bf16
+    products -- against the default f32-input-MFMA step at B = 256: forward outputs and statistics to 2e-5; gradients per entry
+    to 1e-4 when no ReLU output changed sign between the two forward passes (helpers.relu_flips), else by norm to 5e-3."""
+    from mvae_amd import synthetic
+    from mvae_amd._lib import load
+    from mvae_amd.conv import ConvEngine
+    B = 256
+    comps = _comps_of("h2,s2,e2")
+    x = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
+    eps = synthetic.eps_batches(1, B, 6)[0].to(dev)
+
+    def run(mode):
+        load().mvae_set_contraction_mode(mode)
+        eng = ConvEngine(comps, dev, radius_trainable=[True] * 3)
+        shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
+        eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
+        acts = eng._forward(x, eps)
+        out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
+        torch.cuda.synchronize()
+        return eng, out, acts
+
+    try:
+        es, os_, cs = run(1)
+        ef, of, cf = run(0)
+    finally:
+        load().mvae_set_contraction_mode(0)
+    for k in ("logits", "concat_z", "bce", "kl"):
+        assert_close(_cpu(os_[k]), _cpu(of[k]), 2e-5, k, atol_frac=2e-5)
+    flips = _relu_flips(cs, cf)
+    for (n, a), (_, b) in zip(es.grad_views().items(), ef.grad_views().items()):
+        if flips == 0:
+            assert_close(_cpu(a), _cpu(b), 1e-4, "grad " + n, atol_frac=2e-5)
+        else:
+            assert _rel_l2(_cpu(a), _cpu(b)) < 5e-3, (n, flips, _rel_l2(_cpu(a), _cpu(b)))
