@@ -1822,11 +1822,11 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
   }
 }
 
-// launch 2 of the backward: everything that sums over the batch.  Workgroups [0, 256]: the heads -- job_linear_bwd_skn
-// against the channel-last flatten (dW_heads, da2 = (dheads W_heads) [a2 > 0], db_heads); the next 64: dW_d0 / db_d0 =
-// dd0^T [z | 1] for 32 channel-last entries each (thread = (row group, entry quad), rows g, g + 32, ... requested first,
-// the 32 groups added in order through LDS, stored at the reference's row c * 16 + p); the last: the radius gradients, each
-// a fixed-order sum over the rows.
+// launch 2 of the backward: everything that sums over the batch.  The first 64 workgroups: dW_d0 / db_d0 = dd0^T [z | 1] for
+// 32 channel-last entries each (thread = (row group, entry quad), rows g, g + 32, ... requested first, the 32 groups added in
+// order through LDS, stored at the reference's row c * 16 + p); the next: the radius gradients, each a fixed-order sum over
+// the rows; the last 257: the heads -- job_linear_bwd_skn against the channel-last flatten (dW_heads, da2 = (dheads W_heads)
+// [a2 > 0], db_heads).
 template <int NN>
 __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const float* __restrict__ a2,
                                                             const float* __restrict__ W_heads,
@@ -1837,13 +1837,14 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
                                                             float* __restrict__ dW_d0, float* __restrict__ db_d0,
                                                             const float* __restrict__ drad_rows,
                                                             float* __restrict__ dradii, int B) {
-  const int nskn = kFlat / 32 + 1;
+  // order: the 64 + 1 short jobs first, then the 257 workgroups of the heads -- the grid has 66 more workgroups than the chip
+  // has CUs, and a short job sharing a CU with a heads workgroup costs less at the front than as the kernel's tail
+  const int nshort = kD0 / 32 + 1;
   int blk = blockIdx.x;
-  if (blk < nskn) {
-    job_linear_bwd_skn<NN, true>(blk, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1);
+  if (blk >= nshort) {
+    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1);
     return;
   }
-  blk -= nskn;
   const int tid = threadIdx.x;
   if (blk < kD0 / 32) {
     __shared__ f32x4 sm[32][9];
