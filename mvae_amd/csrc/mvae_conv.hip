@@ -887,6 +887,15 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   }
 }
 
+#ifndef MV_WGRAD_TARGET_SPLIT
+#define MV_WGRAD_TARGET_SPLIT 256
+#endif
+#ifndef MV_B3_MIN128G
+#define MV_B3_MIN128G 256  // gathered forms: 128 x 128 tiles from this many workgroups (one per CU) on
+#endif
+#ifndef MV_B3_TN128
+#define MV_B3_TN128 256
+#endif
 #ifndef MV_B3_MIN12864
 #define MV_B3_MIN12864 256  // plain NT shapes with < 512 128 x 128 tiles take 128 x 64 tiles when that still gives one per CU
 #endif
@@ -925,6 +934,14 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   if constexpr (!A_KC && !B_KC && (GATHER == 0 || GATHER == 2)) {
     // TN (weight gradients): the same kernel with a transposing stage; 64 x 64 tiles, slices as chosen by the caller
     if (g_split_products && N > 64 && M > 64 && sai == 1 && (sak & 3) == 0 && (GATHER == 2 || (sbj == 1 && (sbk & 3) == 0))) {
+#if MV_B3_TN128
+      if (wg128 >= MV_B3_TN128) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
+        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias,
+                           mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        return;
+      }
+#endif
       dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
       hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias, mask,
                          relu, M, N, K, k_per_slice, slice_stride, cg);
@@ -935,7 +952,7 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
     // NN (B = a weight stored [K][N]) and the transposed convolution per parity class: transposing stage for B only
     if (g_split_products && N > 64 && (GATHER == 3 || sak == 1) && sbj == 1 && (sbk & 3) == 0) {
       const int zdim = GATHER == 3 ? 4 : slices;
-      if (wg128 >= 512 && GATHER == 0) {
+      if (wg128 >= (GATHER == 0 ? 512 : MV_B3_MIN128G)) {
         dim3 grid((N + 127) / 128, (M + 127) / 128, zdim);
         hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
                            mask, relu, M, N, K, k_per_slice, slice_stride, cg);
@@ -950,11 +967,12 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   if constexpr (A_KC && B_KC && (GATHER == 0 || GATHER == 1)) {
     if (g_split_products && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
       const int64_t wg12864 = (int64_t)((N + 63) / 64) * ((M + 127) / 128) * slices;
+      const int min128 = GATHER == 0 ? 512 : MV_B3_MIN128G;
       if (GATHER == 0 && wg128 < 512 && wg12864 >= MV_B3_MIN12864) {
         dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
         hipLaunchKernelGGL((k_gemm_b3<128, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
                            K, k_per_slice, slice_stride, cg);
-      } else if (wg128 < 512) {
+      } else if (wg128 < min128) {
         dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
         hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
                            K, k_per_slice, slice_stride, cg);
@@ -1243,7 +1261,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
   if (M >= kTiledMinRows && tiled_ok(P, NP) && tiled_ok(Q, NQ) && tiled_ok(out, NQ) && M <= 0x7fffffff) {
     // split-K over the batch rows so that >= 256 workgroups exist; the slices are added in index order
     const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
-    int slices = (256 + wg - 1) / wg;
+    int slices = ((g_split_products ? MV_WGRAD_TARGET_SPLIT : 256) + wg - 1) / wg;
     const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);  // what mvae_gemm_tn_workspace_floats provides
     if (slices > max_slices) slices = max_slices;
     if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
@@ -1358,7 +1376,7 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt
 
 static int wgrad_slices(int64_t M, int NP, int NQ, int* kps) {
   const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
-  int slices = (256 + wg - 1) / wg;
+  int slices = ((g_split_products ? MV_WGRAD_TARGET_SPLIT : 256) + wg - 1) / wg;
   const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;
