@@ -1715,7 +1715,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
 // PEER: the gradient is the sum of the ranks' published slots (mvae_peer.hip), added in rank order -- the same
 // floating-point sum on every rank -- and written to g like an all-reduced .grad.
-constexpr int kOptU = 2;  // 16-byte vectors per thread of k_optim
+constexpr int kOptU = 4;  // 16-byte vectors per thread of k_optim (1: 41.4 us, 2: 39.1, 4: 37.8, 8: 38.4 for the world-1 forced-exchange step)
 static inline int optim_blocks(int n4) { return (n4 - kRadiiRegion / 4 + 256 * kOptU - 1) / (256 * kOptU); }
 template <bool PEER>
 __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, float* m, float* v, int n4,
