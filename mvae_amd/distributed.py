@@ -84,8 +84,9 @@ class DataParallelStep:
                  overlap: Optional[bool] = None, exchange: Optional[str] = None) -> None:
         """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
         exercises the collective, its graph capture and k_optim on a single GPU).
-        overlap: two-bucket exchange overlapped with the last backward launch (default: on; MVAE_DP_OVERLAP=0 turns it
-        off -- one all-reduce of the whole buffer after the backward pass).
+        overlap: two-bucket exchange overlapped with the last backward launch (MVAE_DP_OVERLAP=1 / 0; default: off for the
+        direct RCCL route -- one all-reduce of the whole buffer after the backward pass, on the step's stream --, on for
+        torch.distributed's asynchronous all_reduce).
         exchange (MVAE_DP_EXCHANGE): "rccl" -- ncclAllReduce on librccl DIRECTLY, enqueued on the step's own streams
         (mvae_amd/rccl.py: no ProcessGroupNCCL, no watchdog thread, captured natively; the process group is only the side
         channel for the communicator id and may be gloo) -- the default for an engine on a HIP device; "allreduce" --
@@ -97,7 +98,8 @@ class DataParallelStep:
         self.engine = engine
         self.group = group
         self.always_exchange = bool(always_exchange)
-        self.overlap = (os.environ.get("MVAE_DP_OVERLAP", "1") not in ("0", "")) if overlap is None else bool(overlap)
+        env_overlap = os.environ.get("MVAE_DP_OVERLAP")
+        self.overlap = (env_overlap not in ("0", "")) if (overlap is None and env_overlap is not None) else overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         on_hip = getattr(getattr(engine, "grads", None), "is_cuda", False)
@@ -120,6 +122,12 @@ class DataParallelStep:
             from .rccl import FlatAllReduce
             self.rccl = FlatAllReduce(engine.device, group)
             self._side = torch.cuda.Stream(device=engine.device)  # the exchange travels here while launch 6 runs
+        if self.overlap is None:
+            # Default: on for torch.distributed's asynchronous all_reduce (the backend's own stream), OFF for the direct
+            # RCCL route, whose steps are captured: a kernel on a side stream between a fork and a join of a captured step
+            # costs ~20 us of cross-queue dependency on this runtime (measured at world 1 with half of k_optim on the side
+            # stream: 37.8 -> 58.6 us / step) against the <= 5.5 us of launch 6 the overlap can hide.
+            self.overlap = self.rccl is None
         self.steps_since_check = 0
 
     @property
