@@ -41,6 +41,17 @@ def test_argument_validation_without_gpu():
     assert b"kind" in lib.mvae_last_error()
     assert lib.mvae_exp_map_mu0(1, 16, 16, 4, 100, 16, None) == -2  # true_dim > MVAE_MAX_TRUE_DIM
     assert lib.mvae_linear_forward(None, None, None, None, 4, 4, 4, 0, None) == -1
+    # the conv architecture's fused entry points: NULL pointers, unsupported geometries and shapes
+    assert lib.mvae_conv_latent_forward(None, 1, None, None, None, None, 6, None, None, None, None, None, None, None, None, 4,
+                                        None) == -1
+    assert lib.mvae_conv_latent_backward(None, 1, None, None, None, None, 6, None, None, None, None, None, 1.0, None, None,
+                                         None, None, None, None, None, None, 4, None) == -1
+    assert lib.mvae_conv_bce_stats(None, None, None, None, None, None, 1.0, 4, 3072, 1024, 3, None, None, None, None) == -1
+    assert lib.mvae_conv_bce_stats(16, 16, 16, 16, 16, 16, 1.0, 4, 3072, 1000, 3, 16, 16, 16, None) == -2  # HW % 1024
+    assert lib.mvae_convt_to3_k4s2p1_forward(None, None, None, None, 4, 64, 16, 16, 3, None) == -1
+    assert lib.mvae_convt_to3_k4s2p1_forward(16, 16, 16, 16, 4, 32, 16, 16, 3, None) == -2  # 64 features only
+    assert lib.mvae_conv_latent_workspace_floats(256, 3) == max(64 * 256 * 16, 256 * 2048 + 3 * 256)
+    assert lib.mvae_set_contraction_mode(-1) in (0, 1)
     with pytest.raises(L.MvaeHipError):
         L.check(-1)
 
