@@ -22,6 +22,15 @@ def _cpu(t):
     return t.detach().cpu().numpy()
 
 
+def _default_mode_only():
+    """Step-level per-entry gradient bars are stated for the default contraction mode (f32-input MFMA).  Under
+    MVAE_CONV_SPLIT_BF16=1 the forward pass rounds differently and a flipped ReLU output moves gradients by one term of a long sum
+    (DESIGN section 4); that mode has its own step tests (test_conv_step_in_split_product_mode, ..._vs_the_reference_in_...)."""
+    from mvae_amd._lib import load
+    if load().mvae_set_contraction_mode(-1) == 1:
+        pytest.skip("per-entry step bars are for the default contraction mode; see the split-product mode's own step tests")
+
+
 def test_conv_layers_vs_torch(dev):
     """The two patch-matrix gathers + contractions against torch.nn.functional.conv2d / conv_transpose2d (float64)."""
     import torch.nn.functional as F
@@ -93,6 +102,7 @@ def test_conv_step_vs_golden(dev, monkeypatch, fused):
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_conv_step_full_batch_vs_oracle(dev, monkeypatch, fused):
     """B=32 of the BASELINE config [4] shapes: per-sample statistics and every gradient against the oracle."""
+    _default_mode_only()
     monkeypatch.setenv("MVAE_CONV_FUSED", fused)
     from mvae_amd import synthetic
     from mvae_amd.conv import ConvEngine
@@ -199,6 +209,7 @@ def test_conv_step_b256_vs_the_reference(dev):
     step as sum, L2, max and 64 sampled entries), recorded in float32 AND float64.  The HIP step is compared with the
     float32 record at the 1e-4 bar per sampled entry, and its distance from the float64 record is reported next to the
     float32 reference's own distance from it (printed; asserted to be of the same order)."""
+    _default_mode_only()
     from mvae_amd import synthetic
     from mvae_amd.conv import ConvEngine
     from oracle import model as M
