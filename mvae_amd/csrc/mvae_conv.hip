@@ -665,7 +665,7 @@ __device__ __forceinline__ float4 quad_transpose(float4 v, int lane) {
   if (hi1) { v.x = c; v.z = d; } else { v.y = c; v.w = d; }
   return v;
 }
-template <int BM, int BN, int NW, int GATHER, bool TA = false, bool TB = false>
+template <int BM, int BN, int NW, int GATHER, bool TA = false, bool TB = false, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A, int64_t sai,
                                                  const float* __restrict__ Bm, int64_t sbj, float* __restrict__ C,
                                                  int64_t ldc, const float* __restrict__ bias,
@@ -677,8 +677,11 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   // NN (TB: ConvTranspose2d forward / backward-data products; GATHER 3: the transposed convolution per parity class,
   // blockIdx.z), TN (TA + TB: weight gradients; GATHER 2: against the implicit patch matrix).
   constexpr int BK = 32, KQ = BK / 4;
-  __shared__ __attribute__((aligned(16))) unsigned int As[3][BM * kB3LD];
-  __shared__ __attribute__((aligned(16))) unsigned int Bs[3][BN * kB3LD];
+  constexpr int NBUF = PIPE ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned int As_[NBUF][3][BM * kB3LD];
+  __shared__ __attribute__((aligned(16))) unsigned int Bs_[NBUF][3][BN * kB3LD];
+  unsigned int (*As)[BM * kB3LD] = As_[0];
+  unsigned int (*Bs)[BN * kB3LD] = Bs_[0];
   constexpr int NT = 64 * NW, WCOLS = NW / 2;
   constexpr int WM = BM / 2, WN = BN / WCOLS, TM = WM / 16, TN = WN / 16;
   constexpr int LA = BM * KQ / NT, LB = BN * KQ / NT;
@@ -830,22 +833,47 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
   };
   fetch(kb, rs0);
   fetch(kb + BK, rs1);
-  for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
-    // Both halves are unconditional (an odd number of K steps runs one all-zero step): the number of requests in flight is
-    // then the same on every path into the loop head and the waits stay counted.  sched_barrier: hipcc otherwise hoists the
-    // OTHER set's zeroing selects above this half's requests and MFMAs, and with them the wait for that set.
+  if constexpr (PIPE) {
+    // Two LDS buffers, ONE barrier per K step: the stage of step k + 1 (split + stores) sits in the same block as the MFMAs of
+    // step k, so hipcc interleaves its VALU work with them instead of serialising stage -> barrier -> reads -> MFMAs -> barrier.
+    As = As_[0]; Bs = Bs_[0];
     stage(rs0);
     __syncthreads();
-    fetch(k0 + 2 * BK, rs0);
-    compute();
-    __syncthreads();
+    fetch(kb + 2 * BK, rs0);
     __builtin_amdgcn_sched_barrier(0);
-    stage(rs1);
-    __syncthreads();
-    fetch(k0 + 3 * BK, rs1);
-    compute();
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+      As = As_[0]; Bs = Bs_[0];
+      compute();
+      As = As_[1]; Bs = Bs_[1];
+      stage(rs1);
+      fetch(k0 + 3 * BK, rs1);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      compute();
+      As = As_[0]; Bs = Bs_[0];
+      stage(rs0);
+      fetch(k0 + 4 * BK, rs0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    for (int k0 = kb; k0 < ke; k0 += 2 * BK) {
+      // Both halves are unconditional (an odd number of K steps runs one all-zero step): the number of requests in flight is
+      // then the same on every path into the loop head and the waits stay counted.  sched_barrier: hipcc otherwise hoists the
+      // OTHER set's zeroing selects above this half's requests and MFMAs, and with them the wait for that set.
+      stage(rs0);
+      __syncthreads();
+      fetch(k0 + 2 * BK, rs0);
+      compute();
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      stage(rs1);
+      __syncthreads();
+      fetch(k0 + 3 * BK, rs1);
+      compute();
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   const bool vec = (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0 && (ldc & 3) == 0;
   const int lc = (lane >> 4) << 2;
@@ -937,13 +965,17 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
 #if MV_B3_TN128
       if (wg128 >= MV_B3_TN128) {
         dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
-        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias,
-                           mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        if (wg128 < 512)
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, true, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc,
+                             bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        else
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias,
+                             mask, relu, M, N, K, k_per_slice, slice_stride, cg);
         return;
       }
 #endif
       dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
-      hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias, mask,
+      hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, true, true, true>), grid, dim3(512), 0, s, A, sak, Bm, sbk, C, ldc, bias, mask,
                          relu, M, N, K, k_per_slice, slice_stride, cg);
       return;
     }
@@ -954,11 +986,16 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
       const int zdim = GATHER == 3 ? 4 : slices;
       if (wg128 >= (GATHER == 0 ? 512 : MV_B3_MIN128G)) {
         dim3 grid((N + 127) / 128, (M + 127) / 128, zdim);
-        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
-                           mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        // (two LDS buffers = 144 KB: only where there is one workgroup per CU anyway)
+        if (wg128 < 512)
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, true, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc,
+                             bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        else
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
+                             mask, relu, M, N, K, k_per_slice, slice_stride, cg);
       } else {
         dim3 grid((N + 63) / 64, (M + 63) / 64, zdim);
-        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
+        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, false, true, true>), grid, dim3(512), 0, s, A, sai, Bm, sbk, C, ldc, bias,
                            mask, relu, M, N, K, k_per_slice, slice_stride, cg);
       }
       return;
@@ -970,16 +1007,20 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
       const int min128 = GATHER == 0 ? 512 : MV_B3_MIN128G;
       if (GATHER == 0 && wg128 < 512 && wg12864 >= MV_B3_MIN12864) {
         dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
-        hipLaunchKernelGGL((k_gemm_b3<128, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
+        hipLaunchKernelGGL((k_gemm_b3<128, 64, 8, GATHER, false, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
                            K, k_per_slice, slice_stride, cg);
       } else if (wg128 < min128) {
         dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
-        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
+        hipLaunchKernelGGL((k_gemm_b3<64, 64, 8, GATHER, false, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M, N,
                            K, k_per_slice, slice_stride, cg);
       } else {
         dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
-        hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu, M,
-                           N, K, k_per_slice, slice_stride, cg);
+        if (wg128 < 512)
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER, false, false, true>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc,
+                             bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+        else
+          hipLaunchKernelGGL((k_gemm_b3<128, 128, 8, GATHER>), grid, dim3(512), 0, s, A, sai, Bm, sbj, C, ldc, bias, mask, relu,
+                             M, N, K, k_per_slice, slice_stride, cg);
       }
       return;
     }
