@@ -110,6 +110,26 @@ def cpu_baseline(seconds_budget=8.0, model=MODEL, fixed=False):
 
 
 CONV_FLOPS_B256 = 79.5e9  # fwd 26.63 GFLOP, fwd + bwd ~79.5 GFLOP at B = 256
+CONV_FWD_FLOPS_B256 = 26.63e9
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); a split product costs SIX bf16 MACs per f32 one
+CONV_MODES = {
+    0: ("f32", "f32-input MFMA (v_mfma_f32_16x16x4_f32) in every contraction"),
+    1: ("f32 via 3-way bf16 splits", "every LDS-tiled contraction with more than 64 output columns multiplies through exact "
+        "three-way bf16 splits (six piece products on the bf16 MFMA, f32 accumulation); the small ones on the f32-input MFMA"),
+    2: ("f32 (forward: f32-input MFMA; backward: exact 3-way bf16 splits on the bf16 MFMA, f32 accumulation)",
+        "forward contractions (they decide the ReLU masks and the logits) on the exact f32-input MFMA, bit-identical to mode 0; "
+        "backward-data and weight-gradient contractions through exact three-way bf16 splits, six piece products on the bf16 "
+        "MFMA, f32 accumulation (operator-level error vs float64 <= the f32 MFMA's)"),
+}
+
+
+def conv_effective_peak_tf(mode):
+    """The MFMA roofline of the conv step for a contraction mode: algorithmic f32 flops over the time the matrix pipes need at
+    their dense peaks -- f32-input MFMA 157.3 TFLOP/s for the exact part, bf16 MFMA 2500 TFLOP/s at SIX bf16 MACs per f32
+    multiply-add for the split part."""
+    split = {0: 0.0, 1: CONV_FLOPS_B256, 2: CONV_FLOPS_B256 - CONV_FWD_FLOPS_B256}[mode]
+    t = (CONV_FLOPS_B256 - split) / (F32_MFMA_PEAK_TF * 1e12) + 6.0 * split / (BF16_MFMA_PEAK_TF * 1e12)
+    return CONV_FLOPS_B256 / t / 1e12
 
 
 def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=None, strong=False, force_dp=False):
@@ -119,7 +139,9 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
     --force-dp): ConvEngine behind DataParallelStep -- forward/backward on the rank's rows, ONE all-reduce (SUM) of the flat
     gradient buffer (8.4 MB), the replicated optimizer; weak scaling = 256 rows per GPU, --strong = 256 rows in all."""
     from mvae_amd import functional as Fn, synthetic
+    from mvae_amd._lib import load as _load_lib
     from mvae_amd.conv import ConvEngine
+    mode = int(_load_lib().mvae_set_contraction_mode(-1))
     Bg = 256  # BASELINE's batch
     dev = torch.device("cuda", torch.cuda.current_device())
     eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
@@ -210,18 +232,23 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
         "metric": "ELBO-steps/sec (batch 256) CIFAR conv h2,s2,e2",
         "value": steps * scale / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong" if (strong and world > 1) else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4] on {world} GPU(s): CIFAR shapes (3x32x32, U[0,1] soft targets), model "
+        "vs_baseline": None, "dtype": CONV_MODES[mode][0], "data": "synthetic",
+        "config": {"contraction_mode": mode, "contraction_mode_meaning": CONV_MODES[mode][1],
+                   "workload": f"BASELINE configs[4] on {world} GPU(s): CIFAR shapes (3x32x32, U[0,1] soft targets), model "
                                "h2,s2,e2, learnable curvature, conv architecture h_dim=8192, " +
                                ("global batch 256 split by rows" if (strong and world > 1) else "batch 256 per GPU") +
                                ", epoch>=10 state",
                    "global_batch": Bc * world, "parallelism": f"dp{world}" + ("(forced exchange)" if force_dp else ""),
-                   "exchange": dp.exchange if dp is not None else "none",
+                   "exchange": (dp.exchange + (f" ({dp.exchange_note})" if dp.exchange_note else "")) if dp is not None else "none",
                    "graph_steps": steps if graphs else 0, "graph_replays": 1 if graphs else 0,
                    "final_elbo_per_sample": st["elbo"] / Bc},
-        "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": tf / F32_MFMA_PEAK_TF,
-                     "scope": "whole step, per GPU: SURVEY 8(d) 79.5 GFLOP (fwd + bwd contractions at 256 rows) over ms_per_step",
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": conv_effective_peak_tf(mode), "unit": "TFLOP/s",
+                     "frac": tf / conv_effective_peak_tf(mode),
+                     "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TF,
+                     "scope": "whole step, per GPU: SURVEY 8(d) 79.5 GFLOP (fwd + bwd contractions at 256 rows) over ms_per_step; "
+                              "peak = those flops over the time the matrix pipes need at their dense peaks in this contraction "
+                              "mode (f32-input MFMA 157.3 TF for the exact part; bf16 MFMA 2500 TF at six bf16 MACs per f32 "
+                              "multiply-add for the split part)",
                      "kernel": "k_gemm_tiled: e2 forward contraction [4096 x 2048] x [512 x 2048]^T + bias + ReLU",
                      "kernel_ms": k_ms, "kernel_achieved_TFLOPs": k_tf, "kernel_mfma_frac": k_tf / F32_MFMA_PEAK_TF,
                      "traffic": None},
@@ -390,6 +417,22 @@ def mlp_leg(model, fixed, steps, warmup, dev):
                                               "step_hbm_frac", "step_mfma_frac")}}
 
 
+def conv_short_leg(mode):
+    """A 20-step leg of the conv config in contraction mode `mode` (None: the library's current one), reduced to the fields
+    the `configs` block of the headline line carries."""
+    from mvae_amd._lib import load as _load
+    prev = _load().mvae_set_contraction_mode(-1)
+    try:
+        if mode is not None:
+            _load().mvae_set_contraction_mode(mode)
+        leg = conv_leg(20, 5)
+    finally:
+        _load().mvae_set_contraction_mode(prev)
+    out = {k: v for k, v in leg.items() if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")}
+    out["contraction_mode"] = leg["config"]["contraction_mode"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,8 +448,12 @@ def main():
                     help="restore the initial parameters / optimizer state every N steps (0 = never, the default: "
                          "40 000 consecutive learnable-curvature steps on the cycled synthetic batches stay finite); a "
                          "diagnostic for configurations that diverge")
-    ap.add_argument("--no-prewarm", action="store_true",
-                    help="skip the clock / power pre-warm replays in front of a short (one-graph) timed region")
+    ap.add_argument("--prewarm", type=int, default=0,
+                    help="OPT-IN diagnostic (default 0 = the contract's protocol: exactly --warmup untimed steps, then the "
+                         "timed region): replay the captured timed graph this many times, on a snapshot of the model state "
+                         "that is restored afterwards, in front of a short (one-graph) timed region.  A device that idled "
+                         "since the capture runs its first replays 5-35 %% slow; round 3 did 12 of these by default, which "
+                         "made its headline incomparable with the stated warm-up (ADVICE r3) -- now off unless asked for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short legs of BASELINE configs[0], [3], [4] reported under `configs`")
@@ -499,15 +546,15 @@ def main():
 
     repeats = args.repeats if args.repeats > 0 else (5 if (args.steps >= 1000 and world == 1 and plan is None) else 1)
     prewarm = 0
-    if plan is not None and runner.gs > 0 and not args.no_prewarm:
-        # A short timed region (the driver's 20 steps = 0.65 ms) starts on a device that has been idle since the capture:
-        # the first replays after an idle period run 5-35 % slower than the steady state the metric is about (clock /
-        # power ramp; tools/probe_short_run.py: 44, 33.9, 33.2, ... 32.5 us/step over the first nine 20-step replays).
-        # So the captured timed graph is replayed a few times on a snapshot of the model state, which is restored
-        # before the contractual warm-up; the timed region is untouched (exactly --steps steps, asserted below).
+    if plan is not None and runner.gs > 0 and args.prewarm > 0:
+        # Opt-in only (--prewarm N).  A short timed region (the driver's 20 steps = 0.65 ms) starts on a device that has
+        # been idle since the capture: the first replays after an idle period run 5-35 % slower than the steady state
+        # (clock / power ramp; tools/probe_short_run.py: 44, 33.9, 33.2, ... 32.5 us/step over the first nine 20-step
+        # replays).  With --prewarm the captured timed graph is replayed on a snapshot of the model state, which is
+        # restored before the contractual warm-up; the line then says so (config.prewarm_replays > 0).
         keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
         timed_graph = runner.graphs[args.warmup if args.warmup > 0 else 0][0]
-        while prewarm < 12:
+        while prewarm < args.prewarm:
             timed_graph.replay()
             torch.cuda.synchronize()
             prewarm += 1
@@ -580,7 +627,8 @@ def main():
                                "MLP h_dim=400, " + ("global batch 128 split by rows" if strong else "batch 128 per GPU") +
                                ", epoch>=10 state",
                    "global_batch": B if strong else B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
-                   "exchange": (runner.dp.exchange if runner.dp is not None else "none (fused optimizer epilogues)"),
+                   "exchange": ((runner.dp.exchange + (f" ({runner.dp.exchange_note})" if runner.dp.exchange_note else ""))
+                                if runner.dp is not None else "none (fused optimizer epilogues)"),
                    "ranks_identical": ranks_identical, "peer_timeouts": peer_timeouts,
                    "graph_steps": runner.gs,
                    "graph_replays": graph_replays,
@@ -602,28 +650,20 @@ def main():
         extra = {}
         for key, fn in (("e6", lambda: mlp_leg("e6", True, 400, 40, dev)),
                         ("prod36", lambda: mlp_leg("6h2,6s2,6e2", False, 400, 40, dev)),
-                        ("conv", lambda: {k: v for k, v in conv_leg(20, 5).items()
-                                          if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
-                                                   "dtype", "roofline")})):
+                        ("conv", lambda: conv_short_leg(None))):
             try:
                 extra[key] = fn()
             except Exception as e:  # noqa: BLE001  (a failing leg must not lose the headline line)
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
-        # the conv step once more with the large contractions multiplying through exact three-way bf16 splits on the bf16 MFMA
-        # (mvae_set_contraction_mode(1): f32-class accuracy, tests/test_conv_gpu.py::test_split_product_contractions_vs_float64);
-        # reported BESIDE configs.conv, which stays on the f32-input MFMA
-        try:
-            from mvae_amd._lib import load as _load
-            _load().mvae_set_contraction_mode(1)
-            leg = conv_leg(20, 5)
-            extra["conv_split_bf16_products"] = {
-                "value": leg["value"], "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
-                "dtype": "f32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 MFMA, f32 accumulation "
-                         "(every LDS-tiled contraction with more than 64 output columns; the small ones on the f32-input MFMA)"}
-        except Exception as e:  # noqa: BLE001
-            extra["conv_split_bf16_products"] = {"error": f"{type(e).__name__}: {e}"}
-        finally:
-            _load().mvae_set_contraction_mode(0)
+        # configs.conv is the library's DEFAULT contraction mode (2: exact-f32 forward, split-bf16 backward; per-entry 1e-4
+        # against the reference's own step, tests/test_conv_gpu.py::test_conv_step_b256_vs_the_reference).  Beside it, the
+        # same step with the f32-input MFMA everywhere (mode 0) and with split products everywhere (mode 1, whose
+        # step-level gradient bar is 1e-3: its forward rounding can flip a ReLU output).
+        for key, m in (("conv_f32_mfma", 0), ("conv_split_bf16_products", 1)):
+            try:
+                extra[key] = conv_short_leg(m)
+            except Exception as e:  # noqa: BLE001
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
         extra["e6"].setdefault("baseline_config", "configs[0]: MNIST e6, fixed curvature")
         extra["prod36"].setdefault("baseline_config", "configs[3]: 6h2,6s2,6e2 (36-dim latent), learnable curvature")
         extra["conv"].setdefault("baseline_config", "configs[4] on ONE GPU: CIFAR conv h_dim=8192, batch 256")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 7
+#define MVAE_ABI_VERSION 8
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -279,12 +279,12 @@ int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, f
  *   Conv2d, Wt = that layer's weight stored [OC', (ky,kx,c)], mask = the previous ReLU's output: its backward-data.
  *   C % 32 == 0, OC % 4 == 0, IH and IW powers of two. */
 int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
-                           int IH, int IW, int OC, int relu, void* stream);
+                           int IH, int IW, int OC, int relu, int pass, void* stream);
 /* workspace (may be NULL): mvae_conv_k4s2p1_nhwc_workspace_floats(...) floats; when given, a layer with fewer than 256
  * output tiles and a patch axis >= 2048 splits the contraction into <= 4 slices added in index order (mask == NULL only). */
 int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
 int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
-                          int IH, int IW, int OC, int relu, float* workspace, void* stream);
+                          int IH, int IW, int OC, int relu, float* workspace, int pass, void* stream);
 int64_t mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(int B, int C, int IH, int IW, int OC);
 int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, float* dWt, int B, int C, int IH, int IW, int OC,
                                 float* workspace, void* stream);
@@ -303,8 +303,10 @@ int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t M, int NP, 
                  void* stream);
 /* dy[i] = 0 where y[i] <= 0  (backward through a ReLU whose output is y). */
 int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream);
-/* out[M, N] = G[M, K] W[K, N], optionally zeroed where mask[M, N] <= 0. */
-int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N, void* stream);
+/* out[M, N] = G[M, K] W[K, N], optionally zeroed where mask[M, N] <= 0.  pass: MVAE_PASS_FORWARD (the product of a
+ * ConvTranspose2d forward) | MVAE_PASS_BACKWARD (a backward-data product), see mvae_set_contraction_mode. */
+int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N, int pass,
+                 void* stream);
 /* out[N] = column sums of G[M, N]  (bias gradients); for M > 512 `workspace` must hold
  * mvae_colsum_workspace_floats(M, N) floats (row slices are summed separately, then added in index order). */
 int64_t mvae_colsum_workspace_floats(int64_t M, int N);
@@ -321,13 +323,20 @@ int mvae_batch_stats(const float* bce, const float* kl, float* stats, float beta
  * features -> 3 x 32 x 32 (MVAE_E_UNSUPPORTED otherwise; the generic form is mvae_gemm_nn + mvae_col2im_k4s2p1). */
 int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float* bias, float* y, int B, int F, int IH,
                                   int IW, int C, void* stream);
-/* How the LDS-tiled contractions of the conv architecture multiply (process-wide; returns the previous mode; a negative
- * argument only queries).
- * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate.  1 (contractions with > 64 output columns): every float
- * split EXACTLY into three bf16 pieces,
- * the six largest piece products on the bf16 MFMA (16x the rate), f32 accumulation: |error| <= 2^-23 |a b| per product
- * on top of f32 accumulation, i.e. the float32 class of nn.Linear / nn.Conv2d on any BLAS (conv_vae.py:47-55). */
-int mvae_set_contraction_mode(int split_bf16_products);
+/* How the LDS-tiled contractions of the conv architecture multiply (process-wide, read once per call; returns the previous
+ * mode; a negative argument only queries).
+ * 0: f32-input MFMA (v_mfma_f32_16x16x4_f32), the f32 vector rate, everywhere.
+ * 1: (contractions with > 64 output columns) every float split EXACTLY into three bf16 pieces, the six largest piece
+ *    products on the bf16 MFMA (16x the rate), f32 accumulation: |error| <= 2^-23 |a b| per product on top of f32
+ *    accumulation, i.e. the float32 class of nn.Linear / nn.Conv2d on any BLAS (conv_vae.py:47-55).
+ * 2: (DEFAULT) as 1 for the contractions of the BACKWARD pass only (backward-data, weight gradients: autograd of
+ *    conv_vae.py:57-79); every forward contraction -- whose output decides a ReLU mask or is the logits -- is exactly
+ *    mode 0's, so forward values and masks are bit-identical to mode 0.
+ * The entry points that serve both passes take `pass`; mvae_conv_k4s2p1_nhwc_wgrad, mvae_gemm_tn and
+ * mvae_linear_forward_masked are backward by nature, mvae_linear_forward / _splitk forward. */
+#define MVAE_PASS_FORWARD 0
+#define MVAE_PASS_BACKWARD 1
+int mvae_set_contraction_mode(int mode);
 /* The loss end of the conv step in one launch: mvae_bce_forward_backward + mvae_batch_stats (vae.py:125-147) + the bias
  * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
  * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -74,9 +74,9 @@ PROTOTYPES = {
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),
     "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P]),
-    "mvae_conv_transpose_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_k4s2p1_nhwc_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
-    "mvae_conv_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mvae_conv_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_linear_forward_splitk_workspace_floats": (C.c_int64, [_L, _I, _I]),
@@ -85,7 +85,7 @@ PROTOTYPES = {
     "mvae_gemm_tn_workspace_floats": (C.c_int64, [_L, _I, _I]),
     "mvae_gemm_tn": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "mvae_relu_mask": (C.c_int, [_P, _P, _L, _P]),
-    "mvae_gemm_nn": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_gemm_nn": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mvae_colsum_workspace_floats": (C.c_int64, [_L, _I]),
     "mvae_colsum": (C.c_int, [_P, _P, _L, _I, _P, _P]),
     "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),

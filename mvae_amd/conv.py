@@ -187,11 +187,14 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
-def _gemm_nn(G: Tensor, W: Tensor) -> Tensor:
+FORWARD, BACKWARD = 0, 1  # MVAE_PASS_FORWARD / MVAE_PASS_BACKWARD: which pass a shared contraction belongs to
+
+
+def _gemm_nn(G: Tensor, W: Tensor, pass_: int = FORWARD) -> Tensor:
     M, K = G.shape
     N = W.shape[1]
     out = G.new_empty(M, N)
-    check(load().mvae_gemm_nn(ptr(G), ptr(W), None, ptr(out), M, K, N, stream_ptr(G.device)))
+    check(load().mvae_gemm_nn(ptr(G), ptr(W), None, ptr(out), M, K, N, pass_, stream_ptr(G.device)))
     return out
 
 
@@ -208,7 +211,7 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
-               relu: bool) -> Tensor:
+               relu: bool, pass_: int = FORWARD) -> Tensor:
     """Implicit contraction (no patch matrix): src [B*IH*IH, Cc] channel-last -> [B*(IH/2)^2, OC]; Wt [OC, 16 Cc]
     taps-major.  Conv2d forward, or ConvTranspose2d backward-data with `mask` = the previous ReLU's output."""
     OC = Wt.shape[0]
@@ -216,18 +219,18 @@ def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[T
     nws = int(load().mvae_conv_k4s2p1_nhwc_workspace_floats(B, Cc, IH, IH, OC, 0 if mask is None else 1))
     ws = src.new_empty(nws) if nws > 0 else None  # split-K slices of a layer with few output tiles
     check(load().mvae_conv_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
-                                       1 if relu else 0, ptr(ws), stream_ptr(src.device)))
+                                       1 if relu else 0, ptr(ws), pass_, stream_ptr(src.device)))
     return y
 
 
 def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
-                OC: int, relu: bool) -> Tensor:
+                OC: int, relu: bool, pass_: int = FORWARD) -> Tensor:
     """Transposed convolution as four implicit contractions (one per output parity class; no [M, 16 OC] product, no
     col2im): src [B*IH*IH, Cc] channel-last -> [B*(2 IH)^2, OC]; Wt [Cc, 16 OC] with columns (ky, kx, oc).
     ConvTranspose2d forward, or Conv2d backward-data with `mask` = the previous ReLU's output."""
     y = src.new_empty(B * (2 * IH) * (2 * IH), OC)
     check(load().mvae_conv_transpose_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
-                                        1 if relu else 0, stream_ptr(src.device)))
+                                        1 if relu else 0, pass_, stream_ptr(src.device)))
     return y
 
 
@@ -302,10 +305,12 @@ class ConvEngine:
         #   latent section (flatten -> heads -> components -> decoder fc) as 2 + 2 fused launches; 0: the generic operators.
         self.direct = os.environ.get("MVAE_CONV_FUSED", "1") != "0"
         self.fused = self.direct and bool(load().mvae_conv_latent_supported(self.layout.descs, n))
-        # MVAE_CONV_SPLIT_BF16 (default: leave the library's mode alone = off): the large contractions multiply through exact
-        #   three-way bf16 splits on the bf16 MFMA (process-wide, mvae_set_contraction_mode).
-        if "MVAE_CONV_SPLIT_BF16" in os.environ:
-            load().mvae_set_contraction_mode(1 if os.environ["MVAE_CONV_SPLIT_BF16"] == "1" else 0)
+        # MVAE_CONV_SPLIT_BF16 (default: leave the library's mode alone = 2): how the large contractions multiply
+        #   (process-wide, mvae_set_contraction_mode).  2: the backward pass through exact three-way bf16 splits on the bf16
+        #   MFMA, the forward pass -- whose outputs decide the ReLU masks -- on the exact f32-input MFMA; 1: split products
+        #   everywhere; 0: the f32-input MFMA everywhere.
+        if os.environ.get("MVAE_CONV_SPLIT_BF16", "") in ("0", "1", "2"):
+            load().mvae_set_contraction_mode(int(os.environ["MVAE_CONV_SPLIT_BF16"]))
         # MVAE_CONV_STREAMS (default 0): backward pass on three HIP streams -- the backward-data chain stays on the caller's
         #   stream, the weight gradients go to side stream 0, the bias sums / re-orderings to side stream 1, forked and joined
         #   through events (parallel branches in a captured graph).  Same bits, measured SLOWER (1.08 -> 1.21 ms): off.
@@ -486,6 +491,15 @@ class ConvEngine:
         check(load().mvae_slice_sums_defer(1))
         try:
             return self._backward(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay)
+        except BaseException:
+            # an aborted pass may have left arrival counters of mvae_conv_bce_stats non-zero (the kernel re-arms them
+            # itself only when it completes): without this no workgroup of the next step would ever see itself as the
+            # last one, and d3.bias / the batch statistics would silently stop updating
+            try:
+                self._arrive.zero_()
+            except Exception:  # noqa: BLE001  (a dead device: the original exception is the one to report)
+                pass
+            raise
         finally:
             check(load().mvae_slice_sums_defer(0))
 
@@ -517,10 +531,10 @@ class ConvEngine:
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
         side(0, lambda: _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16))
         side(1, lambda: _colsum(db2, out=GV["d2.bias"]))
-        db1 = _conv_nhwc(db2, c["Wd2"], None, c["b1"], B, 64, 16, False)  # [B*64, 256], ReLU mask in the epilogue
+        db1 = _conv_nhwc(db2, c["Wd2"], None, c["b1"], B, 64, 16, False, BACKWARD)  # [B*64, 256], ReLU mask in the epilogue
         side(0, lambda: _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8))
         side(1, lambda: _colsum(db1, out=GV["d1.bias"]))
-        dt0 = _conv_nhwc(db1, c["Wd1"], None, None, B, 256, 8, False)  # [B*16, 128]
+        dt0 = _conv_nhwc(db1, c["Wd1"], None, None, B, 256, 8, False, BACKWARD)  # [B*16, 128]
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
         if c.get("fused"):
@@ -541,10 +555,11 @@ class ConvEngine:
         da2 = dhflat.view(B * 16, 512)
         side(0, lambda: _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8))
         side(1, lambda: _colsum(da2, out=GV["e2.bias"]))
-        da1 = _col2im(_gemm_nn(da2, c["We2"]), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True)
+        da1 = _col2im(_gemm_nn(da2, c["We2"], BACKWARD), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128),
+                      True)
         side(0, lambda: _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16))
         side(1, lambda: _colsum(da1, out=GV["e1.bias"]))
-        da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False)    # [B*256, 64], ReLU mask of a0
+        da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False, BACKWARD)    # [B*256, 64], ReLU mask of a0
         side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
         _colsum(da0, out=GV["e0.bias"])
         self._join()

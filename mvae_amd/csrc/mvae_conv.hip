@@ -927,12 +927,26 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_b3(const float* __restrict__ A
 #ifndef MV_B3_MIN12864
 #define MV_B3_MIN12864 256  // plain NT shapes with < 512 128 x 128 tiles take 128 x 64 tiles when that still gives one per CU
 #endif
-// 0: f32-input MFMA everywhere (v_mfma_f32_16x16x4_f32); 1: split bf16 products where a kernel exists (NT forms)
-static int g_split_products = 0;
-extern "C" int mvae_set_contraction_mode(int split_bf16_products) {
-  const int old = g_split_products;
-  if (split_bf16_products >= 0) g_split_products = split_bf16_products ? 1 : 0;  // (< 0: query only)
+// Which multiply the LDS-tiled contractions take (mvae_set_contraction_mode):
+//   0  the f32-input MFMA everywhere (v_mfma_f32_16x16x4_f32: exact f32 products, k-ordered f32 accumulation);
+//   1  split bf16 products everywhere a kernel exists (k_gemm_b3);
+//   2  (DEFAULT) split products in the BACKWARD pass only: every forward contraction -- whose output decides a ReLU mask
+//      (conv_vae.py:57-79) or is the logits -- stays on the exact f32 MFMA, so the masks and every forward value are
+//      bit-identical to mode 0; backward-data and weight-gradient contractions (2/3 of the step's flops) take k_gemm_b3,
+//      whose error against float64 is no larger than the f32 MFMA's.
+// Every entry point states the pass it belongs to: the inherently backward ones (weight gradients, mvae_gemm_tn,
+// mvae_linear_forward_masked) implicitly, the shared ones through their `pass` argument (MVAE_PASS_FORWARD / _BACKWARD).
+// The mode is read ONCE per call (relaxed atomic); workspace sizes do not depend on it.
+#include <atomic>
+static std::atomic<int> g_contraction_mode{2};
+extern "C" int mvae_set_contraction_mode(int mode) {
+  const int old = g_contraction_mode.load(std::memory_order_relaxed);
+  if (mode >= 0) g_contraction_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);  // (< 0: query only)
   return old;
+}
+static inline bool split_for(int pass) {
+  const int m = g_contraction_mode.load(std::memory_order_relaxed);
+  return m == 1 || (m == 2 && pass == MVAE_PASS_BACKWARD);
 }
 
 // operand requirements of the 16-byte paths of k_gemm_tiled
@@ -954,14 +968,14 @@ constexpr int kBK64 = MV_BK64, kBK128 = MV_BK128, kNW64 = MV_NW64, kNW128 = MV_N
 template <bool A_KC, bool B_KC, int GATHER = 0>
 static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
                               float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
-                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s,
+                              int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s, bool split,
                               ConvGeom cg = ConvGeom{0, 0, 0, 0, 0}) {
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
   if constexpr (!A_KC && !B_KC && (GATHER == 0 || GATHER == 2)) {
     // TN (weight gradients): the same kernel with a transposing stage; 64 x 64 tiles, slices as chosen by the caller
-    if (g_split_products && N > 64 && M > 64 && sai == 1 && (sak & 3) == 0 && (GATHER == 2 || (sbj == 1 && (sbk & 3) == 0))) {
+    if (split && N > 64 && M > 64 && sai == 1 && (sak & 3) == 0 && (GATHER == 2 || (sbj == 1 && (sbk & 3) == 0))) {
 #if MV_B3_TN128
       if (wg128 >= MV_B3_TN128) {
         dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
@@ -982,7 +996,7 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   }
   if constexpr (A_KC && !B_KC && (GATHER == 0 || GATHER == 3)) {
     // NN (B = a weight stored [K][N]) and the transposed convolution per parity class: transposing stage for B only
-    if (g_split_products && N > 64 && (GATHER == 3 || sak == 1) && sbj == 1 && (sbk & 3) == 0) {
+    if (split && N > 64 && (GATHER == 3 || sak == 1) && sbj == 1 && (sbk & 3) == 0) {
       const int zdim = GATHER == 3 ? 4 : slices;
       if (wg128 >= (GATHER == 0 ? 512 : MV_B3_MIN128G)) {
         dim3 grid((N + 127) / 128, (M + 127) / 128, zdim);
@@ -1002,7 +1016,7 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
     }
   }
   if constexpr (A_KC && B_KC && (GATHER == 0 || GATHER == 1)) {
-    if (g_split_products && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
+    if (split && N > 64 && (GATHER == 1 || sak == 1) && sbk == 1) {
       const int64_t wg12864 = (int64_t)((N + 63) / 64) * ((M + 127) / 128) * slices;
       const int min128 = GATHER == 0 ? 512 : MV_B3_MIN128G;
       if (GATHER == 0 && wg128 < 512 && wg12864 >= MV_B3_MIN12864) {
@@ -1046,7 +1060,7 @@ extern "C" int mvae_linear_forward_masked(const float* x, const float* W, const 
   if (!tiled_ok(x, K) || !tiled_ok(W, K) || !tiled_ok(y, N) || !tiled_ok(mask, N) || M > 0x7fffffff)
     return fail(MVAE_E_ALIGN, "masked linear needs 16-byte aligned operands with K, N multiples of 4%s", "");
   launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, split_for(MVAE_PASS_BACKWARD));  // a Linear backward-data
   LAUNCH_CHECK("masked linear launch");
   return 0;
 }
@@ -1054,7 +1068,8 @@ extern "C" int mvae_linear_forward_masked(const float* x, const float* W, const 
 bool linear_forward_tiled(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,
                                  int relu, hipStream_t s) {
   if (!tiled_ok(x, K) || !tiled_ok(W, K) || M > 0x7fffffff) return false;
-  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0, s);
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0, s,
+                                split_for(MVAE_PASS_FORWARD));
   return true;
 }
 
@@ -1302,7 +1317,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
   if (M >= kTiledMinRows && tiled_ok(P, NP) && tiled_ok(Q, NQ) && tiled_ok(out, NQ) && M <= 0x7fffffff) {
     // split-K over the batch rows so that >= 256 workgroups exist; the slices are added in index order
     const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
-    int slices = ((g_split_products ? MV_WGRAD_TARGET_SPLIT : 256) + wg - 1) / wg;
+    int slices = (MV_WGRAD_TARGET_SPLIT + wg - 1) / wg;  // (the same in every contraction mode)
     const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);  // what mvae_gemm_tn_workspace_floats provides
     if (slices > max_slices) slices = max_slices;
     if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "mvae_gemm_tn needs a workspace for M > 256%s", "");
@@ -1310,7 +1325,7 @@ extern "C" int mvae_gemm_tn(const float* P, const float* Q, float* out, int64_t 
     slices = (int)((M + kps - 1) / kps);
     const int64_t n = (int64_t)NP * NQ;
     launch_gemm_tiled<false, false>(P, 1, NP, Q, NQ, 1, slices > 1 ? workspace : out, NQ, nullptr, nullptr, 0, NP, NQ,
-                                    (int)M, slices, kps, n, (hipStream_t)stream);
+                                    (int)M, slices, kps, n, (hipStream_t)stream, split_for(MVAE_PASS_BACKWARD));
     if (slices > 1) sum_slices(workspace, out, n, slices, (hipStream_t)stream);
     LAUNCH_CHECK("tiled gemm_tn launch");
     return 0;
@@ -1364,7 +1379,8 @@ extern "C" int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int Cc, int IH,
 }
 
 extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
-                                     int B, int Cc, int IH, int IW, int OC, int relu, float* workspace, void* stream) {
+                                     int B, int Cc, int IH, int IW, int OC, int relu, float* workspace, int pass,
+                                     void* stream) {
   if (!src || !Wt || !y || OC < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   ConvGeom g;
   int rc = conv_geom(&g, B, Cc, IH, IW);
@@ -1380,12 +1396,12 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
     if (!tiled_ok(workspace, OC)) return fail(MVAE_E_ALIGN, "implicit conv workspace must be 16-byte aligned%s", "");
     const int64_t n = M * OC;
     launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, workspace, OC, nullptr, nullptr, 0, (int)M, OC, K, slices, kps,
-                                     n, (hipStream_t)stream, g);
+                                     n, (hipStream_t)stream, split_for(pass), g);
     hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, y, n, slices,
                        bias, OC, relu);
   } else {
     launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, y, OC, bias, mask, relu, (int)M, OC, K, 1, K, 0,
-                                     (hipStream_t)stream, g);
+                                     (hipStream_t)stream, split_for(pass), g);
   }
   LAUNCH_CHECK("implicit conv launch");
   return 0;
@@ -1395,7 +1411,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
 // src[B, IH, IW, C] -> y[B, 2 IH, 2 IW, OC]; Wt[C, (ky, kx, oc)] = the ConvTranspose2d weight [C, OC, 4, 4] taps-major
 // (or, for the backward-data of a Conv2d with weight [C, OC', 4, 4] stored [C][(ky, kx, oc')], that same matrix).
 extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
-                                      int B, int Cc, int IH, int IW, int OC, int relu, void* stream) {
+                                      int B, int Cc, int IH, int IW, int OC, int relu, int pass, void* stream) {
   if (!src || !Wt || !y || OC < 4 || (OC & 3)) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (B < 1 || Cc < 32 || (Cc & 31) || IH < 1 || IW < 1 || (IH & (IH - 1)) || (IW & (IW - 1)))
     return fail(MVAE_E_UNSUPPORTED, "implicit transposed conv needs C %% 32 == 0 and power-of-two extents%s (%lld)", "",
@@ -1410,14 +1426,14 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt
       (bias && ((uintptr_t)bias & 15)) || 4 * M > 0x7fffffff)
     return fail(MVAE_E_ALIGN, "implicit transposed conv needs 16-byte aligned operands%s", "");
   launch_gemm_tiled<true, false, 3>(src, 0, 0, Wt, (int64_t)16 * OC, 1, y, OC, bias, mask, relu, (int)M, OC, K, 4, K, 0,
-                                    (hipStream_t)stream, g);
+                                    (hipStream_t)stream, split_for(pass), g);
   LAUNCH_CHECK("implicit transposed conv launch");
   return 0;
 }
 
 static int wgrad_slices(int64_t M, int NP, int NQ, int* kps) {
   const int wg = ((NP + 127) / 128) * ((NQ + (NQ > 64 ? 127 : 63)) / (NQ > 64 ? 128 : 64));
-  int slices = ((g_split_products ? MV_WGRAD_TARGET_SPLIT : 256) + wg - 1) / wg;
+  int slices = (MV_WGRAD_TARGET_SPLIT + wg - 1) / wg;  // (the same in every contraction mode)
   const int max_slices = (int)((M + kTnSlice - 1) / kTnSlice);
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;
@@ -1447,7 +1463,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, fl
   if (slices > 1 && !workspace) return fail(MVAE_E_BADARG, "the weight gradient needs its workspace%s", "");
   const int64_t n = (int64_t)OC * NQ;
   launch_gemm_tiled<false, false, 2>(dy, 1, OC, src, 0, 0, slices > 1 ? workspace : dWt, NQ, nullptr, nullptr, 0, OC, NQ,
-                                     (int)M, slices, kps, n, (hipStream_t)stream, g);
+                                     (int)M, slices, kps, n, (hipStream_t)stream, split_for(MVAE_PASS_BACKWARD), g);
   if (slices > 1) sum_slices(workspace, dWt, n, slices, (hipStream_t)stream);
   LAUNCH_CHECK("implicit conv weight gradient launch");
   return 0;
@@ -1462,11 +1478,11 @@ extern "C" int mvae_relu_mask(float* dy, const float* y, int64_t n, void* stream
 }
 
 extern "C" int mvae_gemm_nn(const float* G, const float* W, const float* mask, float* out, int64_t M, int K, int N,
-                            void* stream) {
+                            int pass, void* stream) {
   if (!G || !W || !out || M < 1 || K < 1 || N < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (M >= kTiledMinRows && tiled_ok(G, K) && tiled_ok(W, N) && M <= 0x7fffffff) {
     launch_gemm_tiled<true, false>(G, K, 1, W, N, 1, out, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, split_for(pass));
     LAUNCH_CHECK("tiled gemm_nn launch");
     return 0;
   }
@@ -1494,7 +1510,7 @@ extern "C" int mvae_linear_forward_splitk(const float* x, const float* W, const 
   if (!workspace) return fail(MVAE_E_BADARG, "mvae_linear_forward_splitk needs its workspace%s", "");
   const int64_t n = M * N;
   launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, workspace, N, nullptr, nullptr, 0, (int)M, N, K, slices, kSplitK, n,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, split_for(MVAE_PASS_FORWARD));
   hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, (hipStream_t)stream, workspace, y, n, slices, b,
                      N, relu);
   LAUNCH_CHECK("split-K linear forward launch");

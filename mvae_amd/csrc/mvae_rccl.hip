@@ -7,9 +7,18 @@
 // librccl is opened at run time (dlopen; the path may be given, default: the one already mapped into the process by
 // torch, else the system's): the library has no link-time dependency on it, and single-GPU use never touches it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "mvae_common.hpp"
+
+// The handful of librccl declarations this unit needs, stated locally (NCCL's stable public ABI: nccl.h / rccl.h) so that the
+// library builds on a ROCm install without the RCCL development headers -- librccl itself is only opened at run time.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;                     // (non-zero values are only printed, through rccl's text)
+typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;    // nccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ... ncclFloat32 7
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 namespace {
 struct RcclApi {

@@ -19,6 +19,12 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+def _env_on(name: str) -> bool:
+    """An environment switch is ON unless it is unset, empty or "0" (the same reading for every MVAE_* switch)."""
+    import os
+    return os.environ.get(name, "") not in ("", "0")
+
+
 def init_from_env() -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the default process group when
     WORLD_SIZE > 1.  Backend "gloo" unless MVAE_DIST_BACKEND says otherwise: the process group is the host-side channel
@@ -28,7 +34,7 @@ def init_from_env() -> Tuple[int, int, int]:
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if os.environ.get("MVAE_DIST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if _env_on("MVAE_DIST_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -104,7 +110,7 @@ class DataParallelStep:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         on_hip = getattr(getattr(engine, "grads", None), "is_cuda", False)
         # several ranks on ONE device (the flow checks on a single-GPU box): RCCL refuses duplicate devices
-        one_device = bool(os.environ.get("MVAE_DIST_ONE_DEVICE") or os.environ.get("MVAE_BENCH_ONE_DEVICE"))
+        one_device = _env_on("MVAE_DIST_ONE_DEVICE") or _env_on("MVAE_BENCH_ONE_DEVICE")
         self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "") or \
             ("rccl" if (on_hip and not one_device) else "allreduce")
         if self.exchange not in ("allreduce", "rccl", "peer", "peer2"):
@@ -118,10 +124,21 @@ class DataParallelStep:
                                  "other engines (ConvEngine) exchange through 'rccl' or 'allreduce'")
             from .peer import PeerExchange
             self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2")
+        self.exchange_note = ""   # why a route other than the requested one is in use (bench.py: config.exchange)
+        self._fallback_group = None
         if self.exchange == "rccl" and active:
-            from .rccl import FlatAllReduce
-            self.rccl = FlatAllReduce(engine.device, group)
-            self._side = torch.cuda.Stream(device=engine.device)  # the exchange travels here while launch 6 runs
+            from .rccl import FlatAllReduce, RcclUnavailable
+            try:
+                self.rccl = FlatAllReduce(engine.device, group)
+                self._side = torch.cuda.Stream(device=engine.device)  # the exchange travels here while launch 6 runs
+            except RcclUnavailable as e:
+                # EVERY rank is here (FlatAllReduce agrees on the outcome of each stage before going on, so a failure
+                # on one rank raises RcclUnavailable on all of them): the ranks fall back TOGETHER to torch.distributed's
+                # all_reduce, eager and uncaptured -- slower, but a first N > 1 run still ends with a number.
+                self.rccl = None
+                self.exchange = "allreduce"
+                self.exchange_note = f"fallback from rccl: {e}"
+                self._fallback_group = self._make_fallback_group(engine.device)
         if self.overlap is None:
             # Default: on for torch.distributed's asynchronous all_reduce (the backend's own stream), OFF for the direct
             # RCCL route, whose steps are captured: a kernel on a side stream between a fork and a join of a captured step
@@ -129,6 +146,32 @@ class DataParallelStep:
             # stream: 37.8 -> 58.6 us / step) against the <= 5.5 us of launch 6 the overlap can hide.
             self.overlap = self.rccl is None
         self.steps_since_check = 0
+
+    def _make_fallback_group(self, device):
+        """Process group for the all_reduce fall-back when the direct RCCL route could not be set up: torch's own RCCL
+        backend if it initialises and passes one collective on EVERY rank (agreed), else the existing group (gloo stages
+        device tensors through the host)."""
+        if self.world == 1:
+            return self.group
+        if dist.get_backend(self.group) == "nccl":
+            return self.group
+        ok, g = True, None
+        try:
+            if _env_on("MVAE_FAKE_RCCL_INIT_FAILURE") or _env_on("MVAE_DIST_ONE_DEVICE") or _env_on("MVAE_BENCH_ONE_DEVICE"):
+                raise RuntimeError("torch's RCCL backend not tried (fake failure / several ranks on one device)")
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+            g = dist.new_group(ranks=ranks, backend="nccl")
+            t = torch.ones(64, device=device)
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize(device)
+            ok = float(t[0].item()) == float(self.world)
+        except Exception:  # noqa: BLE001
+            ok = False
+        if agree_any(not ok, self.group, tag="fallback-nccl"):
+            self.exchange_note += "; torch RCCL backend unavailable too: all_reduce on the existing group"
+            return self.group
+        self.exchange_note += "; all_reduce on a torch RCCL process group"
+        return g
 
     @property
     def capturable(self) -> bool:
@@ -138,16 +181,23 @@ class DataParallelStep:
             return True
         if self.rccl is not None or self.peer is not None:
             return True
+        if self._fallback_group is not None or self.exchange_note:
+            return False  # the agreed fall-back runs eager
         return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
+    @property
+    def _xgroup(self):
+        """The group the all_reduce route reduces on (the agreed fall-back's group when there is one)."""
+        return self._fallback_group if self._fallback_group is not None else self.group
 
     def broadcast_state(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s parameters / optimizer state."""
         if self.world > 1:
             for t in (self.engine.params, self.engine.adam_m, self.engine.adam_v, self.engine.counters):
                 if self.rccl is not None:
-                    self.rccl.broadcast(t, src)
+                    self.rccl.broadcast(t, src)  # `src` is a GLOBAL rank on both routes (translated inside)
                 else:
-                    dist.broadcast(t, src=src, group=self.group)
+                    dist.broadcast(t, src=src, group=self._xgroup)
 
     def train_step(self, x_local: Tensor, eps_local: Tensor, beta: float, do_curvature_step: bool) -> None:
         eng = self.engine
@@ -187,14 +237,14 @@ class DataParallelStep:
             # optimizer kernel.
             off = eng.flat.off_w_logits
             eng.forward_backward_part(x_local, eps_local, beta, eng.HEAD)
-            w1 = dist.all_reduce(eng.grads[off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1 = dist.all_reduce(eng.grads[off:], op=dist.ReduceOp.SUM, group=self._xgroup, async_op=True)
             eng.forward_backward_part(x_local, eps_local, beta, eng.TAIL)
-            w2 = dist.all_reduce(eng.grads[:off], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w2 = dist.all_reduce(eng.grads[:off], op=dist.ReduceOp.SUM, group=self._xgroup, async_op=True)
             w1.wait()
             w2.wait()
         else:
             eng.forward_backward(x_local, eps_local, beta)
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
 
     def reduce_stats(self) -> Tensor:
@@ -204,7 +254,7 @@ class DataParallelStep:
             if self.rccl is not None:
                 self.rccl.all_reduce(s)
             else:
-                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self._xgroup)
         return s
 
     def check_exchange(self) -> None:

@@ -240,6 +240,9 @@ class StepEngine:
         self._last_batch = B
         check(load().mvae_step_forward_backward_parts(self._context(B), ptr(x), ptr(eps), float(beta), int(part),
                                                       stream_ptr(self.device)))
+        # HEAD leaves half of the buffer stale; after TAIL the whole flat gradient buffer is the engine's, like after
+        # forward_backward(): CurvatureOptimizer.step then applies it as it is
+        self.grads_from_engine = int(part) == self.TAIL
 
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
         """The optimizer kernel is independent of the batch size; `batch` only selects which context's component table

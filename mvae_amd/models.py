@@ -204,6 +204,9 @@ class ModelVAE(nn.Module):
         eps = self._eps(x.shape[0]) if eps is None else eps
         h = self.encode(x)
         if self._wants_grad():
+            # an autograd graph is being built: whatever the flat gradient buffer held from an engine-side
+            # forward_backward() is no longer what the next optimizer.step() should apply (it reads p.grad then)
+            eng.grads_from_engine = False
             W, b, radii = self._stacked_heads_params()
             heads = Fn.linear(h, W, b)
             z, kl = Fn.component_rsample_kl(eng.layout, heads, radii, eps)

@@ -32,14 +32,50 @@ def _rccl_path() -> Optional[bytes]:
     return cand.encode() if os.path.exists(cand) else None
 
 
+class RcclUnavailable(RuntimeError):
+    """The direct RCCL route could not be set up -- raised on EVERY rank of the group (the stages below are agreed
+    across ranks), so the callers can fall back together."""
+
+
+def _fake_failure(stage: str, rank: int) -> bool:
+    """MVAE_FAKE_RCCL_INIT_FAILURE=<stage>[:<rank>] (stage: load | create | warmup; "1" = load; without a rank: every rank)
+    makes that stage fail here -- the test hook of the agreed fall-back."""
+    v = os.environ.get("MVAE_FAKE_RCCL_INIT_FAILURE", "")
+    if v in ("", "0"):
+        return False
+    st, _, rk = v.partition(":")
+    st = "load" if st == "1" else st
+    return st == stage and (rk == "" or int(rk) == rank)
+
+
 class FlatAllReduce:
 
     def __init__(self, device, group: Optional[dist.ProcessGroup] = None) -> None:
+        from .distributed import agree_any
         self.device = torch.device(device)
+        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
-        check(load().mvae_rccl_load(_rccl_path()))
+        self._h = C.c_void_p()
+
+        def stage(name, fn):
+            """Run one set-up stage; the ranks AGREE on its outcome (host side, through the rendezvous store) before any
+            of them enters the next one, so that a rank whose librccl does not load never leaves its peers blocked in
+            the collective ncclCommInitRank, and every rank raises RcclUnavailable together."""
+            err = None
+            try:
+                if _fake_failure(name, self.rank):
+                    raise RuntimeError(f"MVAE_FAKE_RCCL_INIT_FAILURE at stage {name!r}")
+                fn()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            if agree_any(err is not None, group, tag="rccl-" + name):
+                self.close()
+                raise RcclUnavailable(f"stage {name!r} failed on " + (f"this rank ({type(err).__name__}: {err})"
+                                                                       if err is not None else "another rank"))
+
+        stage("load", lambda: check(load().mvae_rccl_load(_rccl_path())))
         ident = [None]
         if self.rank == 0:
             buf = (C.c_uint8 * ID_BYTES)()
@@ -47,14 +83,23 @@ class FlatAllReduce:
             ident[0] = bytes(buf)
         if self.world > 1:
             dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(ident[0])
-            check(load().mvae_rccl_create(buf, self.rank, self.world, C.byref(self._h)))  # collective
-            # first collective outside any capture: RCCL sets up its channels / proxy threads lazily
-            warm = torch.zeros(64, device=self.device)
-            self.all_reduce(warm)
-            torch.cuda.synchronize(self.device)
+
+        def create():
+            with torch.cuda.device(self.device):
+                buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(ident[0])
+                check(load().mvae_rccl_create(buf, self.rank, self.world, C.byref(self._h)))  # collective
+
+        def warmup():
+            with torch.cuda.device(self.device):
+                # first collective outside any capture: RCCL sets up its channels / proxy threads lazily
+                warm = torch.ones(64, device=self.device)
+                self.all_reduce(warm)
+                torch.cuda.synchronize(self.device)
+                if float(warm[0].item()) != float(self.world):
+                    raise RuntimeError(f"warm-up all-reduce returned {float(warm[0].item())}, expected {self.world}")
+
+        stage("create", create)
+        stage("warmup", warmup)
 
     def all_reduce(self, t: Tensor) -> None:
         """t <- sum over ranks of t, in place, on the current stream of the tensor's device."""
@@ -62,9 +107,11 @@ class FlatAllReduce:
         check(load().mvae_flat_allreduce(self._h, ptr(t), t.numel(), stream_ptr(t.device)))
 
     def broadcast(self, t: Tensor, src: int = 0) -> None:
-        """t of rank `src` -> every rank (float32 / int32 tensors, in place, current stream)."""
+        """t of GLOBAL rank `src` (torch.distributed's convention, dist.broadcast) -> every rank of the group (float32 /
+        int32 tensors, in place, current stream).  The communicator numbers its ranks inside the group."""
         assert t.element_size() == 4 and t.is_contiguous()
-        check(load().mvae_flat_broadcast(self._h, C.c_void_p(t.data_ptr()), t.numel(), int(src), stream_ptr(t.device)))
+        root = dist.get_group_rank(self.group, int(src)) if (self.group is not None and dist.is_initialized()) else int(src)
+        check(load().mvae_flat_broadcast(self._h, C.c_void_p(t.data_ptr()), t.numel(), root, stream_ptr(t.device)))
 
     def close(self) -> None:
         if self._h:

@@ -23,12 +23,13 @@ def _cpu(t):
 
 
 def _default_mode_only():
-    """Step-level per-entry gradient bars are stated for the default contraction mode (f32-input MFMA).  Under
-    MVAE_CONV_SPLIT_BF16=1 the forward pass rounds differently and a flipped ReLU output moves gradients by one term of a long sum
-    (DESIGN section 4); that mode has its own step tests (test_conv_step_in_split_product_mode, ..._vs_the_reference_in_...)."""
+    """Step-level per-entry gradient bars are stated for the contraction modes whose FORWARD pass runs on the exact f32-input
+    MFMA: 2 (the default: split bf16 products in the backward pass only) and 0.  Under MVAE_CONV_SPLIT_BF16=1 the forward pass
+    rounds differently and a flipped ReLU output moves gradients by one term of a long sum; that mode has its
+    own step tests (test_conv_step_in_split_product_mode, ..._vs_the_reference_in_...)."""
     from mvae_amd._lib import load
     if load().mvae_set_contraction_mode(-1) == 1:
-        pytest.skip("per-entry step bars are for the default contraction mode; see the split-product mode's own step tests")
+        pytest.skip("per-entry step bars are for the modes with an exact-f32 forward pass (2 = default, 0); see mode 1's own step tests")
 
 
 def test_conv_layers_vs_torch(dev):
@@ -650,6 +651,7 @@ def test_split_product_contractions_vs_float64(dev, M, N, K):
     b = torch.randn(N, generator=gen).to(dev)
     ref = torch.relu(x.double() @ W.double().t() + b.double())
     errs = []
+    prev = load().mvae_set_contraction_mode(-1)
     try:
         for mode in (0, 1):
             load().mvae_set_contraction_mode(mode)
@@ -691,7 +693,7 @@ def test_split_product_contractions_vs_float64(dev, M, N, K):
             outs.append(_convT_nhwc(src, Wtt, bt, mk, B, Cc, IH, 96, True))
         assert_close(_cpu(outs[1]), _cpu(outs[0]), 2e-5, "transposed convolution, split vs f32 MFMA", atol_frac=1e-5)
     finally:
-        load().mvae_set_contraction_mode(0)
+        load().mvae_set_contraction_mode(prev)
 
 
 @pytest.mark.parametrize("B", [1, 5, 256])
@@ -732,11 +734,12 @@ def test_conv_step_in_split_product_mode(dev, monkeypatch):
         torch.cuda.synchronize()
         return eng, out, acts
 
+    prev = load().mvae_set_contraction_mode(-1)
     try:
         es, os_, cs = run(1)
         ef, of, cf = run(0)
     finally:
-        load().mvae_set_contraction_mode(0)
+        load().mvae_set_contraction_mode(prev)
     for k in ("logits", "concat_z", "bce", "kl"):
         assert_close(_cpu(os_[k]), _cpu(of[k]), 2e-5, k, atol_frac=2e-5)
     flips = _relu_flips(cs, cf)
@@ -745,6 +748,47 @@ def test_conv_step_in_split_product_mode(dev, monkeypatch):
             assert_close(_cpu(a), _cpu(b), 1e-4, "grad " + n, atol_frac=2e-5)
         else:
             assert _rel_l2(_cpu(a), _cpu(b)) < 5e-3, (n, flips, _rel_l2(_cpu(a), _cpu(b)))
+
+
+def test_default_mode_keeps_the_forward_pass_bit_identical(dev):
+    """mvae_set_contraction_mode(2), the DEFAULT: backward-data and weight-gradient contractions on split bf16 products, every
+    forward contraction on the exact f32-input MFMA.  Against mode 0 at B = 256: every forward activation, the logits, z, kl
+    and bce are BIT-identical (so the six ReLU masks of conv_vae.py:57-79 are: zero flips by construction), and every
+    gradient holds the per-entry 1e-4 bar against mode 0's.  The mode is the library's default (no environment switch)."""
+    from mvae_amd import synthetic
+    from mvae_amd._lib import load
+    from mvae_amd.conv import ConvEngine
+    B = 256
+    comps = _comps_of("h2,s2,e2")
+    x = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
+    eps = synthetic.eps_batches(1, B, 6)[0].to(dev)
+
+    def run(mode):
+        load().mvae_set_contraction_mode(mode)
+        eng = ConvEngine(comps, dev, radius_trainable=[True] * 3)
+        shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
+        eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
+        acts = eng._forward(x, eps)
+        out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
+        torch.cuda.synchronize()
+        return eng, out, acts
+
+    prev = load().mvae_set_contraction_mode(-1)
+    try:
+        e2, o2, c2 = run(2)
+        e0, o0, c0 = run(0)
+    finally:
+        load().mvae_set_contraction_mode(prev)
+    for k in ("a0", "a1", "a2", "t0", "b1", "b2", "logits", "z", "kl", "heads"):
+        assert torch.equal(c2[k], c0[k]), "forward activation " + k + " differs between contraction modes 2 and 0"
+    for k in ("logits", "concat_z", "bce", "kl"):
+        assert torch.equal(o2[k], o0[k]), k
+    assert _relu_flips(c2, c0) == 0
+    worst = 0.0
+    for (n, a), (_, b) in zip(e2.grad_views().items(), e0.grad_views().items()):
+        assert_close(_cpu(a), _cpu(b), 1e-4, "grad " + n, atol_frac=2e-5)
+        worst = max(worst, _rel_l2(_cpu(a), _cpu(b)))
+    assert worst < 2e-5, worst  # by norm the two multiplies agree to f32 rounding
 
 
 def test_conv_step_b256_vs_the_reference_in_split_product_mode(dev):
@@ -764,6 +808,7 @@ def test_conv_step_b256_vs_the_reference_in_split_product_mode(dev):
     B = 256
     x = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
     eps = synthetic.eps_batches(1, B, 6)[0].to(dev)
+    prev = load().mvae_set_contraction_mode(-1)
     try:
         load().mvae_set_contraction_mode(1)
         eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True] * 3)
@@ -771,7 +816,7 @@ def test_conv_step_b256_vs_the_reference_in_split_product_mode(dev):
         out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
         torch.cuda.synchronize()
     finally:
-        load().mvae_set_contraction_mode(0)
+        load().mvae_set_contraction_mode(prev)
     assert_close(_cpu(out["concat_z"]), g[k32 + "concat_z"], RTOL, "concat_z")
     assert_close(_cpu(out["bce"]), g[k32 + "bce_rows"], RTOL, "bce rows")
     assert_close(_cpu(out["kl"]), g[k32 + "kl_rows"], RTOL, "kl rows", atol_frac=1e-4)

@@ -22,8 +22,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None):
+def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None, env=None):
     import torch.distributed as dist
+    os.environ.update(env or {})
     from mvae_amd import synthetic
     from mvae_amd.distributed import DataParallelStep, shard_rows
     from mvae_amd.engine import StepEngine
@@ -62,7 +63,7 @@ def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cy
     torch.cuda.synchronize()
     total = dp.reduce_stats().cpu().numpy().copy()
     timeouts = dp.peer.timeouts() if dp.peer is not None else 0
-    q.put((rank, eng.params.cpu().numpy().copy(), total, timeouts))
+    q.put((rank, eng.params.cpu().numpy().copy(), total, timeouts, (dp.exchange, dp.exchange_note, dp.capturable)))
     dist.barrier()
     if dp.peer is not None:
         dp.peer.close()
@@ -225,6 +226,30 @@ def test_peer_read_exchange_two_processes_one_device(graph_steps, exchange):
     ref = _run_ranks(steps, world, exchange="allreduce", cycle=graph_steps or None)  # a replay repeats its batches
     assert np.array_equal(peer[0][1], ref[0][1]), "peer-read route differs from the all-reduce route"
     np.testing.assert_allclose(peer[0][2][:3], ref[0][2][:3], rtol=1e-6)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fake", ["load:1", "create", "warmup"])
+def test_rccl_init_failure_falls_back_together(fake):
+    """The first N > 1 run must not end without a number: when the direct librccl route cannot be set up -- here faked with
+    MVAE_FAKE_RCCL_INIT_FAILURE at one stage of FlatAllReduce (`load:1`: librccl fails to load on rank 1 ONLY; `create` /
+    `warmup`: ncclCommInitRank / the first collective fail on every rank) -- the ranks agree on the failure through the
+    rendezvous store BEFORE any of them enters the next collective stage, and ALL of them fall back to torch.distributed's
+    all_reduce (eager: not capturable): same route on every rank, bit-identical parameters, equal to a run that asked for
+    the all_reduce route in the first place."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    steps, world = 3, 2
+    if fake == "warmup":
+        pytest.skip("RCCL refuses two ranks on one device: the stages before the warm-up cannot pass on a single-GPU box")
+    env = {"MVAE_FAKE_RCCL_INIT_FAILURE": fake}
+    got = _run_ranks(steps, world, exchange="rccl", env=env)
+    for r in got:
+        assert r[4][0] == "allreduce" and "fallback from rccl" in r[4][1] and r[4][2] is False, r[4]
+    assert ("this rank" in got[1][4][1]) and (("another rank" in got[0][4][1]) == (fake == "load:1")), (got[0][4], got[1][4])
+    assert np.array_equal(got[0][1], got[1][1]), "ranks diverged"
+    ref = _run_ranks(steps, world, exchange="allreduce")
+    assert np.array_equal(got[0][1], ref[0][1]), "the fall-back differs from the all_reduce route"
 
 
 @pytest.mark.timeout(900)
