@@ -237,7 +237,11 @@ int mvae_linear_forward(const float* x, const float* W, const float* b, float* y
 /* y = (x W^T) zeroed where mask[M, N] <= 0: the backward-data contraction of a layer whose input came out of a ReLU
  * (mask = that ReLU's output), the mask applied in the contraction's epilogue.  16-byte aligned operands, K, N % 4 == 0. */
 int mvae_linear_forward_masked(const float* x, const float* W, const float* mask, float* y, int64_t M, int N, int K,
-                               void* stream);
+                               uint16_t* y_planes, int64_t y_ps, void* stream);
+/* mvae_linear_forward (M >= 512 rows, 16-byte aligned operands, K and N multiples of 4) with the result's bf16 planes written
+ * by the epilogue next to y (the mvae_p3 section below says what planes are). */
+int mvae_linear_forward_planes(const float* x, const float* W, const float* b, float* y, uint16_t* y_planes, int64_t y_ps,
+                               int64_t M, int N, int K, int relu, void* stream);
 /* dW[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] = dy W  (dx may be NULL).  With relu_in != 0, x is the output of a
  * ReLU and dx is additionally masked by x > 0 (folds the previous activation's backward into this call). */
 int mvae_linear_backward(const float* x, const float* W, const float* dy, int relu_in, float* dW, float* db, float* dx,
@@ -260,7 +264,8 @@ int mvae_im2col_k4s2p1(const float* src, const float* mask, float* col, int B, i
  * relu != 0: act = ReLU; mask != NULL: the result is zeroed where mask[b,c,y,x] <= 0 (backward through a ReLU).
  * taps_major: as above, col's second axis is (ky,kx,c). */
 int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C, int H, int W,
-                       int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, int taps_major, void* stream);
+                       int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu, int taps_major, uint16_t* dst_planes,
+                       int64_t dst_ps, void* stream);  /* dst_planes (NULL: none): bf16 planes of dst, taps_major only */
 /* The channel-last layers WITHOUT a patch matrix in memory (implicit contraction; the gather happens in the operand fetch
  * of the LDS-tiled MFMA kernel).  src[B, IH, IW, C] channel-last, C % 32 == 0, IH and IW powers of two;
  * Wt[OC, 16 C] with the patch axis taps-major (ky, kx, c); rows of y / dy are (b, oy, ox), OH = IH/2, OW = IW/2.
@@ -279,12 +284,15 @@ int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, f
  *   Conv2d, Wt = that layer's weight stored [OC', (ky,kx,c)], mask = the previous ReLU's output: its backward-data.
  *   C % 32 == 0, OC % 4 == 0, IH and IW powers of two. */
 int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
-                           int IH, int IW, int OC, int relu, int pass, void* stream);
+                           int IH, int IW, int OC, int relu, int pass, uint16_t* y_planes, int64_t y_ps, void* stream);
 /* workspace (may be NULL): mvae_conv_k4s2p1_nhwc_workspace_floats(...) floats; when given, a layer with fewer than 256
  * output tiles and a patch axis >= 2048 splits the contraction into <= 4 slices added in index order (mask == NULL only). */
 int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
+/* y_planes (may be NULL; "planes": see the mvae_p3 section below): the bf16 planes of y, written by the epilogue next to it
+ * (plane stride y_ps elements; the split-K form is not taken then). */
 int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y, int B, int C,
-                          int IH, int IW, int OC, int relu, float* workspace, int pass, void* stream);
+                          int IH, int IW, int OC, int relu, float* workspace, int pass, uint16_t* y_planes, int64_t y_ps,
+                          void* stream);
 int64_t mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats(int B, int C, int IH, int IW, int OC);
 int mvae_conv_k4s2p1_nhwc_wgrad(const float* dy, const float* src, float* dWt, int B, int C, int IH, int IW, int OC,
                                 float* workspace, void* stream);
@@ -337,6 +345,37 @@ int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float*
 #define MVAE_PASS_FORWARD 0
 #define MVAE_PASS_BACKWARD 1
 int mvae_set_contraction_mode(int mode);
+/* ---- Contractions on PRE-SPLIT operands ("planes"), csrc/mvae_p3.hip: the backward pass of the conv architecture (autograd
+ * of conv_vae.py:57-79) in contraction mode 2.  A float splits EXACTLY into three bf16 pieces (hi, mid, lo: 8 + 8 + 8
+ * significant bits); a tensor's PLANES are three bf16 arrays of its shape, plane q at planes + q * plane_stride (elements).
+ * Whoever produces a tensor writes its planes once (the `*_planes` outputs below, mvae_split3_planes); the contractions
+ * stage them by LDS-DMA and multiply the six largest piece products on the bf16 MFMA with f32 accumulation -- the
+ * arithmetic of mvae_set_contraction_mode(1), error vs float64 no larger than the f32-input MFMA's.  Whole tiles only:
+ * mvae_p3_supported(form, M, N, K, C) says whether a shape qualifies (form 0: mvae_conv_k4s2p1_nhwc_p3, M = B OH OW, N = OC,
+ * K = 16 C; 1: mvae_gemm_nn_p3; 2: mvae_conv_transpose_k4s2p1_nhwc_p3, M = B IH IW, N = OC, K = 4 C; 3:
+ * mvae_conv_k4s2p1_nhwc_wgrad_p3, M = B OH OW, N = OC, K = 16 C); callers fall back to the f32-operand entry points. */
+int mvae_p3_supported(int form, int64_t M, int N, int K, int C);
+/* planes[j] (3 x n[j] bf16, plane stride n[j]) of src[j] (n[j] floats, a multiple of 4), up to 12 tensors in ONE launch:
+ * the conv weights after the optimizer step, activations whose producer does not write planes. */
+int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream);
+/* mvae_conv_k4s2p1_nhwc (backward-data of a ConvTranspose2d, conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of
+ * Wt [OC, 16 C]; y f32, its planes too when y_planes != NULL (not together with a split-K workspace). */
+int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
+int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
+                             const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int C, int IH, int IW, int OC,
+                             float* workspace, void* stream);
+/* mvae_gemm_nn on the planes of G [M, K] and W [K, N] (the product a Conv2d backward-data folds with mvae_col2im_k4s2p1). */
+int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uint16_t* W_planes, int64_t w_ps, float* out, int64_t M,
+                    int K, int N, void* stream);
+/* mvae_conv_transpose_k4s2p1_nhwc (a Conv2d's backward-data, conv_vae.py:47-50,57-63) on the planes of src [B IH IW, C] and of
+ * Wt [C, 16 OC]. */
+int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
+                                       const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int C, int IH,
+                                       int IW, int OC, void* stream);
+/* mvae_conv_k4s2p1_nhwc_wgrad on the planes of dy [B OH OW, OC] and of src [B IH IW, C]. */
+int64_t mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(int B, int C, int IH, int IW, int OC);
+int mvae_conv_k4s2p1_nhwc_wgrad_p3(const uint16_t* dy_planes, int64_t dy_ps, const uint16_t* src_planes, int64_t src_ps,
+                                   float* dWt, int B, int C, int IH, int IW, int OC, float* workspace, void* stream);
 /* The loss end of the conv step in one launch: mvae_bce_forward_backward + mvae_batch_stats (vae.py:125-147) + the bias
  * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
  * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first

@@ -70,13 +70,14 @@ PROTOTYPES = {
                                           _L, _P]),
     "mvae_scale_rows": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
-    "mvae_linear_forward_masked": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "mvae_linear_forward_masked": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "mvae_linear_forward_planes": (C.c_int, [_P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P]),
     "mvae_linear_backward": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P]),
     "mvae_im2col_k4s2p1": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P]),
-    "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P]),
-    "mvae_conv_transpose_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mvae_col2im_k4s2p1": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "mvae_conv_k4s2p1_nhwc_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
-    "mvae_conv_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "mvae_conv_k4s2p1_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P]),
     "mvae_conv_k4s2p1_nhwc_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_linear_forward_splitk_workspace_floats": (C.c_int64, [_L, _I, _I]),
@@ -91,6 +92,14 @@ PROTOTYPES = {
     "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
     "mvae_batch_stats": (C.c_int, [_P, _P, _P, _F, _I, _I, _P]),
     "mvae_set_contraction_mode": (C.c_int, [_I]),
+    "mvae_p3_supported": (C.c_int, [_I, _L, _I, _I, _I]),
+    "mvae_split3_planes": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
+    "mvae_conv_k4s2p1_nhwc_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
+    "mvae_conv_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "mvae_gemm_nn_p3": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "mvae_conv_k4s2p1_nhwc_wgrad_p3": (C.c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_convt_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_bce_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _P, _P, _P, _P]),
     "mvae_conv_latent_supported": (C.c_int, [_P, _I]),

@@ -110,6 +110,79 @@ class ConvFlatLayout:
         return flat[off:off + shape[0] * shape[1] * 16].view(shape[0], shape[1] * 16)
 
 
+# ---- pre-split operands ("planes", csrc/mvae_p3.hip): tensor [rows, cols] f32 -> bfloat16 [3, rows, cols] (hi, mid, lo pieces)
+def _new_planes(rows: int, cols: int, device) -> Tensor:
+    return torch.empty(3, rows, cols, dtype=torch.bfloat16, device=device)
+
+
+def _pptr(planes: Optional[Tensor]) -> Optional[int]:
+    if planes is None:
+        return None
+    assert planes.is_cuda and planes.dtype == torch.bfloat16 and planes.is_contiguous() and planes.shape[0] == 3
+    return planes.data_ptr()
+
+
+def _ps(planes: Optional[Tensor]) -> int:
+    return 0 if planes is None else planes[0].numel()
+
+
+def _split_planes(tensors: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> List[Tensor]:
+    """Planes of up to 12 f32 tensors ([rows, cols], element count a multiple of 4) in ONE launch (mvae_split3_planes)."""
+    n = len(tensors)
+    if outs is None:
+        outs = [_new_planes(t.shape[0], t.numel() // t.shape[0], t.device) for t in tensors]
+    src = (C.c_void_p * n)(*[ptr(t) for t in tensors])
+    dst = (C.c_void_p * n)(*[_pptr(o) for o in outs])
+    cnt = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    check(load().mvae_split3_planes(n, src, dst, cnt, stream_ptr(tensors[0].device)))
+    return list(outs)
+
+
+def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int,
+                  want_planes: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """_conv_nhwc (backward-data of a ConvTranspose2d) on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] ->
+    (y [B*(IH/2)^2, OC] f32, its planes or None)."""
+    OC = Wt_p.shape[1]
+    M = B * (IH // 2) * (IH // 2)
+    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
+    nws = int(load().mvae_conv_k4s2p1_nhwc_p3_workspace_floats(B, Cc, IH, IH, OC, 0 if mask is None else 1))
+    ws = y.new_empty(nws) if nws > 0 else None  # split-K slices, added in index order right away (y is an intermediate)
+    yp = _new_planes(M, OC, y.device) if (want_planes and nws == 0) else None
+    check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(y), _pptr(yp), _ps(yp),
+                                          B, Cc, IH, IH, OC, ptr(ws), stream_ptr(y.device)))
+    return y, yp
+
+
+def _gemm_nn_p3(G_p: Tensor, W_p: Tensor) -> Tensor:
+    M, K = G_p.shape[1], G_p.shape[2]
+    N = W_p.shape[2]
+    out = torch.empty(M, N, dtype=torch.float32, device=G_p.device)
+    check(load().mvae_gemm_nn_p3(_pptr(G_p), _ps(G_p), _pptr(W_p), _ps(W_p), ptr(out), M, K, N, stream_ptr(out.device)))
+    return out
+
+
+def _convT_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, OC: int,
+                   want_planes: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """_convT_nhwc (a Conv2d's backward-data, four parity classes) on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, Cc, 16 OC]."""
+    M = B * (2 * IH) * (2 * IH)
+    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
+    yp = _new_planes(M, OC, y.device) if want_planes else None
+    check(load().mvae_conv_transpose_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(y), _pptr(yp),
+                                                    _ps(yp), B, Cc, IH, IH, OC, stream_ptr(y.device)))
+    return y, yp
+
+
+def _conv_nhwc_wgrad_p3(dy_p: Tensor, src_p: Tensor, out: Tensor, B: int, Cc: int, IH: int) -> Tensor:
+    """_conv_nhwc_wgrad on planes: dy_p [3, B*(IH/2)^2, OC], src_p [3, B*IH*IH, Cc] -> out [OC, 16 Cc] (taps-major)."""
+    OC = dy_p.shape[2]
+    assert out.is_contiguous() and out.numel() == OC * 16 * Cc
+    nws = int(load().mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(B, Cc, IH, IH, OC))
+    ws = _keep(out.new_empty(nws)) if nws > 0 else None
+    check(load().mvae_conv_k4s2p1_nhwc_wgrad_p3(_pptr(dy_p), _ps(dy_p), _pptr(src_p), _ps(src_p), ptr(out), B, Cc, IH, IH, OC,
+                                                ptr(ws), stream_ptr(out.device)))
+    return out
+
+
 def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strides, taps_major: bool = False) -> Tensor:
     col = src.new_empty(B * (IH // 2) * (IH // 2), Cc * 16)
     check(load().mvae_im2col_k4s2p1(ptr(src), ptr(mask), ptr(col), B, Cc, IH, IH, *strides, 1 if taps_major else 0,
@@ -118,10 +191,12 @@ def _im2col(src: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, strid
 
 
 def _col2im(col: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, Hh: int, strides, relu: bool,
-            out_shape, taps_major: bool = False) -> Tensor:
+            out_shape, taps_major: bool = False, planes: Optional[Tensor] = None) -> Tensor:
+    """planes (taps-major only): bfloat16 [3, rows, Cc] receiving the bf16 planes of the result (csrc/mvae_p3.hpp)."""
     dst = col.new_empty(out_shape)
     check(load().mvae_col2im_k4s2p1(ptr(col), ptr(bias), ptr(mask), ptr(dst), B, Cc, Hh, Hh, *strides,
-                                    1 if relu else 0, 1 if taps_major else 0, stream_ptr(col.device)))
+                                    1 if relu else 0, 1 if taps_major else 0, _pptr(planes), _ps(planes),
+                                    stream_ptr(col.device)))
     return dst
 
 
@@ -211,7 +286,7 @@ def _colsum(G: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
-               relu: bool, pass_: int = FORWARD) -> Tensor:
+               relu: bool, pass_: int = FORWARD, planes: Optional[Tensor] = None) -> Tensor:
     """Implicit contraction (no patch matrix): src [B*IH*IH, Cc] channel-last -> [B*(IH/2)^2, OC]; Wt [OC, 16 Cc]
     taps-major.  Conv2d forward, or ConvTranspose2d backward-data with `mask` = the previous ReLU's output."""
     OC = Wt.shape[0]
@@ -219,18 +294,19 @@ def _conv_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[T
     nws = int(load().mvae_conv_k4s2p1_nhwc_workspace_floats(B, Cc, IH, IH, OC, 0 if mask is None else 1))
     ws = src.new_empty(nws) if nws > 0 else None  # split-K slices of a layer with few output tiles
     check(load().mvae_conv_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
-                                       1 if relu else 0, ptr(ws), pass_, stream_ptr(src.device)))
+                                       1 if relu else 0, ptr(ws), pass_, _pptr(planes), _ps(planes),
+                                       stream_ptr(src.device)))
     return y
 
 
 def _convT_nhwc(src: Tensor, Wt: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], B: int, Cc: int, IH: int,
-                OC: int, relu: bool, pass_: int = FORWARD) -> Tensor:
+                OC: int, relu: bool, pass_: int = FORWARD, planes: Optional[Tensor] = None) -> Tensor:
     """Transposed convolution as four implicit contractions (one per output parity class; no [M, 16 OC] product, no
     col2im): src [B*IH*IH, Cc] channel-last -> [B*(2 IH)^2, OC]; Wt [Cc, 16 OC] with columns (ky, kx, oc).
     ConvTranspose2d forward, or Conv2d backward-data with `mask` = the previous ReLU's output."""
     y = src.new_empty(B * (2 * IH) * (2 * IH), OC)
     check(load().mvae_conv_transpose_k4s2p1_nhwc(ptr(src), ptr(Wt), ptr(bias), ptr(mask), ptr(y), B, Cc, IH, IH, OC,
-                                        1 if relu else 0, pass_, stream_ptr(src.device)))
+                                        1 if relu else 0, pass_, _pptr(planes), _ps(planes), stream_ptr(src.device)))
     return y
 
 
@@ -262,12 +338,23 @@ def _conv_nhwc_wgrad(dy: Tensor, src: Tensor, out: Tensor, B: int, Cc: int, IH: 
     return out
 
 
-def _linear_masked(x: Tensor, W: Tensor, mask: Tensor) -> Tensor:
+def _linear_masked(x: Tensor, W: Tensor, mask: Tensor, planes: Optional[Tensor] = None) -> Tensor:
     """(x W^T) zeroed where mask <= 0: a Linear backward-data with the previous ReLU's mask applied in the epilogue."""
     M, K = x.shape
     N = W.shape[0]
     y = x.new_empty(M, N)
-    check(load().mvae_linear_forward_masked(ptr(x), ptr(W), ptr(mask), ptr(y), M, N, K, stream_ptr(x.device)))
+    check(load().mvae_linear_forward_masked(ptr(x), ptr(W), ptr(mask), ptr(y), M, N, K, _pptr(planes), _ps(planes),
+                                            stream_ptr(x.device)))
+    return y
+
+
+def _linear_forward_planes(x: Tensor, W: Tensor, b: Optional[Tensor], relu: bool, planes: Tensor) -> Tensor:
+    """Fn.linear_forward on the LDS-tiled kernel with the result's planes written by the epilogue."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = x.new_empty(M, N)
+    check(load().mvae_linear_forward_planes(ptr(x), ptr(W), ptr(b), ptr(y), _pptr(planes), _ps(planes), M, N, K,
+                                            1 if relu else 0, stream_ptr(x.device)))
     return y
 
 
@@ -311,6 +398,10 @@ class ConvEngine:
         #   everywhere; 0: the f32-input MFMA everywhere.
         if os.environ.get("MVAE_CONV_SPLIT_BF16", "") in ("0", "1", "2"):
             load().mvae_set_contraction_mode(int(os.environ["MVAE_CONV_SPLIT_BF16"]))
+        # MVAE_CONV_PLANES (default 1): in contraction mode 2 the backward pass runs on PRE-SPLIT operands (csrc/mvae_p3.hip):
+        #   the forward epilogues write the bf16 planes of the activations next to them, the backward contractions stage the
+        #   planes by LDS-DMA; 0: the split happens inside the backward kernels (k_gemm_b3).  Same arithmetic either way.
+        self.planes = os.environ.get("MVAE_CONV_PLANES", "1") != "0"
         # MVAE_CONV_STREAMS (default 0): backward pass on three HIP streams -- the backward-data chain stays on the caller's
         #   stream, the weight gradients go to side stream 0, the bias sums / re-orderings to side stream 1, forked and joined
         #   through events (parallel branches in a captured graph).  Same bits, measured SLOWER (1.08 -> 1.21 ms): off.
@@ -374,8 +465,18 @@ class ConvEngine:
             main.wait_event(ev)
         self._forked = []
 
+    def _use_p3(self, B: int) -> bool:
+        """Whether the backward pass of a B-row step runs on pre-split operands: contraction mode 2 (split products in the
+        backward pass), the switch on, no side streams, and every plane contraction's shape made of whole tiles."""
+        if not self.planes or self.overlap or load().mvae_set_contraction_mode(-1) != 2:
+            return False
+        sup = load().mvae_p3_supported
+        return bool(sup(0, B * 64, 256, 1024, 64) and sup(0, B * 16, 128, 4096, 256) and sup(1, B * 16, 2048, 512, 0) and
+                    sup(2, B * 64, 64, 512, 128) and sup(3, B * 64, 256, 1024, 64) and sup(3, B * 16, 128, 4096, 256) and
+                    sup(3, B * 16, 512, 2048, 128) and sup(3, B * 64, 128, 1024, 64) and B * 256 >= 512)
+
     # ---- forward (keeps what backward needs)
-    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True):
+    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True, planes: bool = False):
         PV = self.param_views()
         lay = self.layout
         B = x.shape[0]
@@ -386,8 +487,14 @@ class ConvEngine:
         c["We1"], c["We2"] = self.flat.matrix(self.params, "e1"), self.flat.matrix(self.params, "e2")
         c["Wd1"], c["Wd2"] = self.flat.matrix(self.params, "d1"), self.flat.matrix(self.params, "d2")
         c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
-        c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
-        c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True)   # [B*64, 128]
+        if planes:
+            # the backward pass will run on pre-split operands: the epilogues below write the bf16 planes of the activations
+            # its weight gradients gather (a0, a1) or contract with (t0, b1) next to the f32 tensors
+            c["a0_p"], c["a1_p"] = _new_planes(B * 256, 64, self.device), _new_planes(B * 64, 128, self.device)
+            c["a0"] = _linear_forward_planes(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], True, c["a0_p"])
+        else:
+            c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
+        c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True, FORWARD, c.get("a1_p"))   # [B*64, 128]
         c["a2"] = _conv_e2(c["a1"], c["We2"], PV["e2.bias"], B)   # [B*16, 512]
         # The reference flattens NCHW (conv_vae.py:65: column c * 16 + p of the head matrices); the activation here is
         # channel-last (column p * 512 + c).  Re-ordering the head matrix (NH x 8192: 0.4 MB) instead of the activation
@@ -417,7 +524,9 @@ class ConvEngine:
             R = zz.shape[0]
             c["d0o"] = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)  # [R, 2048] = [R,128,4,4]
             c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
-        c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True)   # [R*64, 256]
+        if planes:
+            c["b1_p"] = _new_planes(R * 64, 256, self.device)
+        c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True, FORWARD, c.get("b1_p"))   # [R*64, 256]
         # (d2 and the backward-data of e2 keep the product + col2im form: measured 95 / 80 us against 98 / 96 us implicit,
         #  tools/bench_conv_gather.py; d1 and the backward-data of e1 gain 11 / 10 us each)
         c["b2"] = _col2im(_gemm_nn(c["b1"], c["Wd2"]), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
@@ -468,7 +577,9 @@ class ConvEngine:
         x = x.contiguous()
         B = x.shape[0]
         lay = self.layout
-        c = self._forward(x, eps)
+        use_p3 = self._use_p3(B) and eps.dim() == 2
+        c = self._forward(x, eps, planes=use_p3)
+        c["p3"] = use_p3
         bce = x.new_empty(B)
         g = torch.empty_like(c["logits"])
         if self.direct:
@@ -506,7 +617,8 @@ class ConvEngine:
     def _backward(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
         side = self._branch
         try:
-            return self._backward_body(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side)
+            body = self._backward_body_p3 if c.get("p3") else self._backward_body
+            return body(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side)
         finally:
             self._join()  # (also after an exception: a captured side stream must rejoin before the capture ends)
 
@@ -563,6 +675,71 @@ class ConvEngine:
         side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
         _colsum(da0, out=GV["e0.bias"])
         self._join()
+        check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
+        _DEFERRED_WS.clear()
+        if want_outputs:
+            return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
+        return None
+
+    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side):
+        """Decoder fc backward, the components, the heads' backward: -> dhflat = the gradient of the channel-last a2."""
+        NH = lay.heads_dim
+        ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
+        if not c.get("fused"):
+            return self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay, side)
+        dhflat = torch.empty_like(c["hflat"])
+        dheads = dt0.new_empty(B, NH)
+        ws = dt0.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
+        epsc = eps.contiguous()
+        check(load().mvae_conv_latent_backward(
+            lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
+            epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
+            float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat),
+            ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
+            stream_ptr(self.device)))
+        return dhflat
+
+    def _backward_body_p3(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side):
+        """The backward pass on pre-split operands (contraction mode 2, csrc/mvae_p3.hip): the same sequence of contractions
+        as _backward_body -- autograd of conv_vae.py:57-79 -- with every large one reading bf16 planes: of the forward
+        activations (written by the forward epilogues), of the activation gradients (written by the epilogue that produces
+        each) and of the four channel-last weight matrices (split here, one launch, from the CURRENT parameters)."""
+        dev = self.device
+        # planes of the weights and of the one forward activation whose producer does not write them (t0: the fused latent
+        # section), in ONE launch
+        W = [c["We1"], c["We2"], c["Wd1"], c["Wd2"], c["t0"]]
+        We1_p, We2_p, Wd1_p, Wd2_p, t0_p = _split_planes(W)
+        # ---- decoder backward
+        if not c.get("d3_bias_done"):
+            check(load().mvae_slice_sums_defer(2))
+            gpix = _colsum(g.view(B, 3072))
+            check(load().mvae_slice_sums_defer(1))
+            _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
+        dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
+        _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
+        db2_p = _new_planes(B * 256, 64, dev)
+        db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"], planes=db2_p)  # ReLU mask in the epilogue
+        _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
+        _colsum(db2, out=GV["d2.bias"])
+        db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True)  # [B*64, 256], ReLU mask of b1
+        _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
+        _colsum(db1, out=GV["d1.bias"])
+        dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8)  # [B*16, 128]
+        # ---- latent section
+        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side)
+        # ---- encoder backward
+        da2 = dhflat.view(B * 16, 512)
+        da2_p = _split_planes([da2])[0]
+        _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
+        _colsum(da2, out=GV["e2.bias"])
+        da1_p = _new_planes(B * 64, 128, dev)
+        da1 = _col2im(_gemm_nn_p3(da2_p, We2_p), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True,
+                      planes=da1_p)
+        _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
+        _colsum(da1, out=GV["e1.bias"])
+        da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64)  # [B*256, 64], ReLU mask of a0
+        _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
+        _colsum(da0, out=GV["e0.bias"])
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
         _DEFERRED_WS.clear()
         if want_outputs:

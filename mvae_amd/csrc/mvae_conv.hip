@@ -1,6 +1,7 @@
 // mvae_conv.hip -- building blocks of the conv architecture (conv_vae.py:28-79), the LDS-tiled f32 MFMA contraction
 // for large row counts, and the device-side input pipeline; the rest of the C ABI of include/mvae_hip.h.
 #include "mvae_common.hpp"
+#include "mvae_p3.hpp"
 
 // ------------------------------------------------------------------------------------------------ conv building blocks (API)
 // The reference's conv architecture (conv_vae.py:28-79) uses only Conv2d / ConvTranspose2d with kernel 4, stride 2,
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_im2col_tm(const float* src, const float
 
 __global__ __launch_bounds__(256) void k_col2im_tm(const float* col, const float* bias, const float* mask, float* dst,
                                                    int B, int C, int H, int W, int64_t sb, int64_t sy, int64_t sx,
-                                                   int relu) {
+                                                   int relu, bf16r* dst_planes, int64_t dps) {
   const int PH = H / 2, PW = W / 2, K = C * 16, C4 = C / 4;
   const int64_t total4 = (int64_t)B * H * W * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_col2im_tm(const float* col, const float
       if (!(mk.w > 0.f)) acc.w = 0.f;
     }
     *reinterpret_cast<float4*>(dst + o) = acc;
+    if (dst_planes) store_planes4(dst_planes, dps, (size_t)o, acc.x, acc.y, acc.z, acc.w);
   }
 }
 
@@ -347,6 +349,8 @@ static int grid_for(int64_t total) {
   return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
+static bool planes_out_ok(const uint16_t* p, int64_t ps) { return !p || (((uintptr_t)p & 7) == 0 && (ps & 3) == 0); }
+
 static bool taps_major_ok(const void* a, const void* b, const void* c, int C, int64_t sc, int64_t sb, int64_t sy,
                           int64_t sx) {
   return sc == 1 && (C & 3) == 0 && ((sb | sy | sx) & 3) == 0 && aligned16(a) && aligned16(b) && (!c || aligned16(c));
@@ -372,17 +376,19 @@ extern "C" int mvae_im2col_k4s2p1(const float* src, const float* mask, float* co
 
 extern "C" int mvae_col2im_k4s2p1(const float* col, const float* bias, const float* mask, float* dst, int B, int C,
                                   int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int relu,
-                                  int taps_major, void* stream) {
+                                  int taps_major, uint16_t* dst_planes, int64_t dst_ps, void* stream) {
   if (!col || !dst || B < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (taps_major) {
     if (!taps_major_ok(col, dst, mask, C, sc, sb, sy, sx) || (bias && !aligned16(bias)))
       return fail(MVAE_E_ALIGN, "taps-major col2im needs a channel-last destination with C %% 4 == 0%s", "");
+    if (!planes_out_ok(dst_planes, dst_ps)) return fail(MVAE_E_ALIGN, "col2im planes must be 8-byte aligned%s", "");
     hipLaunchKernelGGL(k_col2im_tm, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       col, bias, mask, dst, B, C, H, W, sb, sy, sx, relu);
+                       col, bias, mask, dst, B, C, H, W, sb, sy, sx, relu, dst_planes, dst_ps);
     LAUNCH_CHECK("col2im launch");
     return 0;
   }
+  if (dst_planes) return fail(MVAE_E_UNSUPPORTED, "col2im writes planes for taps-major (channel-last) tensors only%s", "");
   hipLaunchKernelGGL(k_col2im, dim3(grid_for((int64_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, col, bias,
                      mask, dst, B, C, H, W, sb, sc, sy, sx, relu);
   LAUNCH_CHECK("col2im launch");
@@ -419,16 +425,16 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 //      operand is gathered from src (zero outside the image), whose B operand is the tap's column block of the weight
 //      [C_in, (ky, kx, oc)], and whose rows are scattered to the class's pixels by the epilogue.
 // A K step of 32 lies inside one tap (C % 32 == 0), so the tap of a step is uniform and a lane moves 16 contiguous bytes.
-struct ConvGeom {
-  int Cc, IH, IW;    // channels and extent of the SOURCE image
-  int lOW, lOHW;     // log2(OW), log2(OH * OW), OH = IH / 2, OW = IW / 2 (powers of two)
-};
+// (struct ConvGeom: mvae_p3.hpp)
 template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC, int GATHER = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
                                                     const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
                                                     float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
                                                     const float* __restrict__ mask, int relu, int M, int N, int K,
-                                                    int k_per_slice, int64_t slice_stride, ConvGeom cg) {
+                                                    int k_per_slice, int64_t slice_stride, ConvGeom cg,
+                                                    bf16r* __restrict__ Cp, int64_t psc) {
+  // Cp != NULL: the result's bf16 PLANES (mvae_p3.hpp) are written next to it, plane stride psc, same ldc -- for the plane
+  // contractions of the backward pass (mvae_p3.hip), so that nobody has to split the tensor again.
   constexpr int kGT_BK = BK, kGT_LD = BK + 8, KQ = BK / 4;
   __shared__ __attribute__((aligned(16))) float As[BM * kGT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kGT_LD];
@@ -601,6 +607,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict_
           for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
         }
         *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+        if (Cp) store_planes4(Cp, psc, (size_t)m * ldc + n, v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -969,7 +976,8 @@ template <bool A_KC, bool B_KC, int GATHER = 0>
 static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const float* Bm, int64_t sbk, int64_t sbj,
                               float* C, int64_t ldc, const float* bias, const float* mask, int relu, int M, int N,
                               int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s, bool split,
-                              ConvGeom cg = ConvGeom{0, 0, 0, 0, 0}) {
+                              ConvGeom cg = ConvGeom{0, 0, 0, 0, 0}, bf16r* Cp = nullptr, int64_t psc = 0) {
+  if (Cp) split = false;  // planes come out of the f32-MFMA kernels' epilogue only (forward results, the small layers)
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;
@@ -1042,25 +1050,26 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
   if (N > 64 && wg128 < 512) {
     dim3 grid((N + 63) / 64, (M + 63) / 64, slices);
     hipLaunchKernelGGL((k_gemm_tiled<64, 64, kBK64, kNW64, A_KC, B_KC, GATHER>), grid, dim3(64 * kNW64), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg, Cp, psc);
   } else if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128, slices);
     hipLaunchKernelGGL((k_gemm_tiled<128, 128, kBK128, kNW128, A_KC, B_KC, GATHER>), grid, dim3(64 * kNW128), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg, Cp, psc);
   } else {
     dim3 grid((N + 63) / 64, (M + 127) / 128, slices);
     hipLaunchKernelGGL((k_gemm_tiled<128, 64, kBK128, 4, A_KC, B_KC, GATHER>), grid, dim3(256), 0, s, A, sai, sak, Bm, sbk, sbj, C, ldc,
-                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg);
+                       bias, mask, relu, M, N, K, k_per_slice, slice_stride, cg, Cp, psc);
   }
 }
 
 extern "C" int mvae_linear_forward_masked(const float* x, const float* W, const float* mask, float* y, int64_t M, int N,
-                                          int K, void* stream) {
+                                          int K, uint16_t* y_planes, int64_t y_ps, void* stream) {
   if (!x || !W || !mask || !y || M < 1 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
-  if (!tiled_ok(x, K) || !tiled_ok(W, K) || !tiled_ok(y, N) || !tiled_ok(mask, N) || M > 0x7fffffff)
+  if (!tiled_ok(x, K) || !tiled_ok(W, K) || !tiled_ok(y, N) || !tiled_ok(mask, N) || M > 0x7fffffff || !planes_out_ok(y_planes, y_ps))
     return fail(MVAE_E_ALIGN, "masked linear needs 16-byte aligned operands with K, N multiples of 4%s", "");
   launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, nullptr, mask, 0, (int)M, N, K, 1, (K + 15) & ~15, 0,
-                                (hipStream_t)stream, split_for(MVAE_PASS_BACKWARD));  // a Linear backward-data
+                                (hipStream_t)stream, split_for(MVAE_PASS_BACKWARD), ConvGeom{0, 0, 0, 0, 0}, y_planes,
+                                y_ps);  // a Linear backward-data
   LAUNCH_CHECK("masked linear launch");
   return 0;
 }
@@ -1071,6 +1080,20 @@ bool linear_forward_tiled(const float* x, const float* W, const float* b, float*
   launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0, s,
                                 split_for(MVAE_PASS_FORWARD));
   return true;
+}
+
+// mvae_linear_forward on the LDS-tiled kernel with the result's planes written by the epilogue (the first conv layer of
+// conv_vae.py:47 as patch matrix x weight: its output is the gathered operand of the next layer's weight gradient)
+extern "C" int mvae_linear_forward_planes(const float* x, const float* W, const float* b, float* y, uint16_t* y_planes,
+                                          int64_t y_ps, int64_t M, int N, int K, int relu, void* stream) {
+  if (!x || !W || !y || !y_planes || M < 1 || N < 1 || K < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (!tiled_ok(x, K) || !tiled_ok(W, K) || !tiled_ok(y, N) || (b && !aligned16(b)) || M > 0x7fffffff ||
+      !planes_out_ok(y_planes, y_ps))
+    return fail(MVAE_E_ALIGN, "mvae_linear_forward_planes needs 16-byte aligned operands with K, N multiples of 4%s", "");
+  launch_gemm_tiled<true, true>(x, K, 1, W, 1, K, y, N, b, nullptr, relu, (int)M, N, K, 1, (K + 15) & ~15, 0,
+                                (hipStream_t)stream, false, ConvGeom{0, 0, 0, 0, 0}, y_planes, y_ps);
+  LAUNCH_CHECK("linear forward (planes) launch");
+  return 0;
 }
 
 // Long batch contractions (conv layers: M = B*OH*OW up to 65536 rows): the rows are cut into slices of kTnSlice, one
@@ -1275,6 +1298,13 @@ static void sum_slices(const float* part, float* out, int64_t n, int slices, hip
   g_sums.blk0[j + 1] = g_sums.blk0[j] + (int)(want < 1024 ? want : 1024);
 }
 
+// the same for the plane contractions of mvae_p3.hip: deferrable (weight gradients: nobody reads them before the flush) and
+// immediate (the split-K slices of a backward-data result, which the next launch reads)
+void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s) { sum_slices(part, out, n, slices, s); }
+void p3_sum_slices_now(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_slices, dim3(grid_for(4 * n)), dim3(256), 0, s, part, out, n, slices, nullptr, 1, 0);
+}
+
 // on = 1: queue the final sums (a queue left behind by an aborted pass is dropped when deferral is switched on);
 // on = 2: SUSPEND -- sums requested now are performed immediately, the queue is kept (for an intermediate result that is
 //         read before the flush); on = 0: off, and anything still queued is DROPPED (the normal path has flushed; after an
@@ -1380,7 +1410,7 @@ extern "C" int64_t mvae_conv_k4s2p1_nhwc_workspace_floats(int B, int Cc, int IH,
 
 extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
                                      int B, int Cc, int IH, int IW, int OC, int relu, float* workspace, int pass,
-                                     void* stream) {
+                                     uint16_t* y_planes, int64_t y_ps, void* stream) {
   if (!src || !Wt || !y || OC < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   ConvGeom g;
   int rc = conv_geom(&g, B, Cc, IH, IW);
@@ -1388,10 +1418,10 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
   const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
   const int K = 16 * Cc;
   if (!tiled_ok(src, Cc) || !tiled_ok(Wt, K) || !tiled_ok(y, OC) || (mask && !tiled_ok(mask, OC)) ||
-      (bias && ((uintptr_t)bias & 15)) || M > 0x7fffffff)
+      (bias && ((uintptr_t)bias & 15)) || M > 0x7fffffff || !planes_out_ok(y_planes, y_ps))
     return fail(MVAE_E_ALIGN, "implicit conv needs 16-byte aligned operands%s", "");
   int kps;
-  const int slices = workspace ? conv_fwd_slices(M, OC, K, mask != nullptr, &kps) : 1;
+  const int slices = (workspace && !y_planes) ? conv_fwd_slices(M, OC, K, mask != nullptr, &kps) : 1;
   if (slices > 1) {
     if (!tiled_ok(workspace, OC)) return fail(MVAE_E_ALIGN, "implicit conv workspace must be 16-byte aligned%s", "");
     const int64_t n = M * OC;
@@ -1401,7 +1431,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
                        bias, OC, relu);
   } else {
     launch_gemm_tiled<true, true, 1>(src, 0, 0, Wt, 1, K, y, OC, bias, mask, relu, (int)M, OC, K, 1, K, 0,
-                                     (hipStream_t)stream, split_for(pass), g);
+                                     (hipStream_t)stream, split_for(pass), g, y_planes, y_ps);
   }
   LAUNCH_CHECK("implicit conv launch");
   return 0;
@@ -1411,7 +1441,8 @@ extern "C" int mvae_conv_k4s2p1_nhwc(const float* src, const float* Wt, const fl
 // src[B, IH, IW, C] -> y[B, 2 IH, 2 IW, OC]; Wt[C, (ky, kx, oc)] = the ConvTranspose2d weight [C, OC, 4, 4] taps-major
 // (or, for the backward-data of a Conv2d with weight [C, OC', 4, 4] stored [C][(ky, kx, oc')], that same matrix).
 extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt, const float* bias, const float* mask, float* y,
-                                      int B, int Cc, int IH, int IW, int OC, int relu, int pass, void* stream) {
+                                      int B, int Cc, int IH, int IW, int OC, int relu, int pass, uint16_t* y_planes,
+                                      int64_t y_ps, void* stream) {
   if (!src || !Wt || !y || OC < 4 || (OC & 3)) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (B < 1 || Cc < 32 || (Cc & 31) || IH < 1 || IW < 1 || (IH & (IH - 1)) || (IW & (IW - 1)))
     return fail(MVAE_E_UNSUPPORTED, "implicit transposed conv needs C %% 32 == 0 and power-of-two extents%s (%lld)", "",
@@ -1423,10 +1454,10 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc(const float* src, const float* Wt
   const int64_t M = (int64_t)B * IH * IW;
   const int K = 4 * Cc;
   if (!tiled_ok(src, Cc) || !tiled_ok(Wt, 16 * OC) || !tiled_ok(y, OC) || (mask && !tiled_ok(mask, OC)) ||
-      (bias && ((uintptr_t)bias & 15)) || 4 * M > 0x7fffffff)
+      (bias && ((uintptr_t)bias & 15)) || 4 * M > 0x7fffffff || !planes_out_ok(y_planes, y_ps))
     return fail(MVAE_E_ALIGN, "implicit transposed conv needs 16-byte aligned operands%s", "");
   launch_gemm_tiled<true, false, 3>(src, 0, 0, Wt, (int64_t)16 * OC, 1, y, OC, bias, mask, relu, (int)M, OC, K, 4, K, 0,
-                                    (hipStream_t)stream, split_for(pass), g);
+                                    (hipStream_t)stream, split_for(pass), g, y_planes, y_ps);
   LAUNCH_CHECK("implicit transposed conv launch");
   return 0;
 }

@@ -1,0 +1,566 @@
+// mvae_p3.hip -- f32 contractions on PRE-SPLIT operands ("planes", mvae_p3.hpp) for the backward pass of the conv
+// architecture (autograd of conv_vae.py:57-79: backward-data and weight gradients of the k4 s2 p1 convolutions).
+//
+// Why: on gfx950 the f32-input MFMA runs at 1/16 of the bf16 MFMA.  k_gemm_b3 (mvae_conv.hip) already multiplies through the
+// exact three-way bf16 split, but splits WHILE STAGING -- 5.5 VALU instructions and three LDS stores per float per K step --
+// and its MFMA pipe is 22-34 % busy (profiles/r03b_conv_split_pmc_mfma.json).  Here the operands arrive as three bf16 planes
+// written once by whoever produced the tensor (a contraction's epilogue, mvae_split3_planes for the weights), so a K step is
+//   LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS, no VGPRs, no VALU, no ds_write)  ->  ds_read_b128 / ds_read_b64_tr_b16
+//   ->  6 x v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 sub-product (lh, hl, mm, mh, hm, hh; f32 accumulation).
+// Tile BM x BN (128 x 128 or 128 x 64), K step 32, 8 waves, two LDS buffers (one workgroup per CU), ONE barrier per K
+// step: [wait for this wave's pieces of step t | barrier | fragment reads of step t | LDS-DMA of step t + 1 into the other
+// buffer | MFMAs of step t].  The other buffer was last read in step t - 1, which every wave has left when it arrives at the
+// barrier of step t.
+//
+// Operand forms.  "KC": the contraction index is contiguous in memory, X(i, k) = X[i * ld + k] -- tile image in LDS
+// [rows][32 k] (64-byte rows), fragments by ds_read_b128; 16-byte chunk c of row r sits at slot c ^ h((r >> 2) & 3),
+// h = {0, 2, 3, 1}: conflict-free under the 16-lane service groups of ds_read_b128.  "KM": the contraction index is the ROW
+// index in memory, X(i, k) = X[k * ld + i] (the weight of an NN product, both operands of a weight gradient) -- image
+// [32 k][rows], fragments by ds_read_b64_tr_b16 (two per fragment: a 16-lane block reads a [4 k][16 rows] block and
+// receives it transposed -- probed in tools/probe_tr_dma.hip: lane j, element e <- (k row e, column j)); 32-byte chunk c of
+// k row kr sits at chunk c ^ x(kr), x = the row's index among the rows sharing a 256-byte bank row, so the 8 k rows a
+// 32-lane service group touches fall into 8 different bank octets.  LDS-DMA writes lane-linear (base + lane * 16), so both
+// swizzles are applied to the per-lane SOURCE address and again at the read (cdna_hip_programming.md, rule 21).
+// Gathered forms (implicit convolution, channel-last images; the patch matrix is never written): A_G1 / A_G3 / B_G2 / B_G3W
+// as GATHER 1 / 3 / 2 / 3 of k_gemm_tiled; a pixel outside the image reads 16 zero bytes from g_p3_zero.
+#include "mvae_common.hpp"
+#include "mvae_p3.hpp"
+
+typedef __bf16 p3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short p3_s16x4 __attribute__((ext_vector_type(4)));
+typedef short p3_s16x8 __attribute__((ext_vector_type(8)));
+
+enum { A_KC = 0, A_G1 = 1, A_G3 = 2, A_KM = 3 };
+enum { B_KC = 0, B_KM = 1, B_G2 = 2, B_G3W = 3 };
+
+struct P3Args {
+  const bf16r* A; long long lda, psa;  // plane q of A at A + q * psa
+  const bf16r* B; long long ldb, psb;
+  float* C; long long ldc;
+  bf16r* Cp; long long psc;            // planes of the result (NULL: none), same ldc
+  const float* mask;                   // result zeroed where mask <= 0 (same layout as C), or NULL
+  int M, N, K, k_per_slice;
+  long long slice_stride;              // floats between the partial results of consecutive K slices (blockIdx.z)
+  ConvGeom cg;
+  int lCc;                             // log2(cg.Cc)
+  int dbg;                             // (-DMV_P3_DBG builds only) bit 0: no DMA waits, 1: no A DMA, 2: no B DMA, 3: no MFMAs
+};
+
+__device__ __attribute__((aligned(16))) unsigned int g_p3_zero[4];
+
+__device__ __forceinline__ int p3_h(int x) { return (0x78 >> (2 * x)) & 3; }  // {0, 2, 3, 1}
+
+template <int BM, int BN, int WR, int AF, int BF, int NST = 3>
+__global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
+  constexpr int NW = 8, WC = NW / WR, WM = BM / WR, WN = BN / WC, TM = WM / 16, TN = WN / 16;
+  constexpr int PLA = BM * 64, PLB = BN * 64;  // bytes per plane tile (32 k x 2 bytes per row)
+  constexpr int SB = 3 * (PLA + PLB);          // bytes per LDS buffer
+  constexpr int NPA = 3 * BM / 16, NPB = 3 * BN / 16, NP = NPA + NPB;  // 1-KiB DMA pieces per K step
+  constexpr int U = (NP + NW - 1) / NW;        // pieces per wave
+  constexpr bool A_IS_KM = AF == A_KM, B_IS_KM = BF != B_KC;
+  constexpr bool PARITY = AF == A_G3;
+  static_assert(TM >= 1 && TN >= 1 && WM % 16 == 0 && WN % 16 == 0, "wave tile");
+  static_assert(NST == 2 || NST == 3, "LDS stages");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * SB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of the image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = PARITY ? 0 : (int)blockIdx.z * g.k_per_slice;
+  const int ke = PARITY ? g.K : ((kb + g.k_per_slice < g.K) ? kb + g.k_per_slice : g.K);
+  float* __restrict__ C = g.C + (PARITY ? 0 : (size_t)blockIdx.z * g.slice_stride);
+  const int par_y = PARITY ? (int)(blockIdx.z >> 1) : 0, par_x = PARITY ? (int)(blockIdx.z & 1) : 0;
+  const ConvGeom cg = g.cg;
+  const bf16r* zero = reinterpret_cast<const bf16r*>(g_p3_zero);
+
+  // ---- LDS-DMA geometry.  A plane tile is BM / 16 one-KiB pieces (KC: 16 rows of 64 bytes; KM: 1024 / (2 BM) k rows); wave w
+  // moves pieces w, w + 8, ... of EVERY plane of both operands, so one address computation per operand and K step serves
+  // three DMA instructions (the planes differ by a uniform stride).  Everything that does not depend on the K step is kept
+  // in registers: inv[0..3] per piece.
+  constexpr int PPA = BM / 16, PPB = BN / 16;         // pieces per plane
+  constexpr int UA = (PPA + NW - 1) / NW, UB = (PPB + NW - 1) / NW;
+  struct Inv { long long off; int i0, i1, i2, i3; };
+  // lane geometry inside a piece: KC -> (tile row r, source chunk offset c8 in elements); KM -> (k row kr, column offset col)
+  auto kc_lane = [&](int pc, int* r, int* c8) __attribute__((always_inline)) {
+    *r = pc * 16 + (lane >> 2);
+    *c8 = ((lane & 3) ^ p3_h((lane >> 4) & 3)) * 8;
+  };
+  auto km_lane = [&](int pc, int rows, int* kr, int* col) __attribute__((always_inline)) {
+    const int CPR = rows / 16, RPB = 8 / CPR;
+    const int off = pc * 1024 + lane * 16, inrow = off % (rows * 2);
+    *kr = off / (rows * 2);
+    *col = (((inrow >> 5) ^ ((*kr / RPB) & (CPR - 1))) << 4) + ((inrow >> 4) & 1) * 8;
+  };
+  auto a_inv = [&](int pc) __attribute__((always_inline)) -> Inv {
+    Inv v{0, 0, 0, 0, 0};
+    if constexpr (A_IS_KM) {
+      int kr, col;
+      km_lane(pc, BM, &kr, &col);
+      v.off = (long long)kr * g.lda + m0 + col;
+    } else {
+      int r, c8;
+      kc_lane(pc, &r, &c8);
+      const int m = m0 + r;
+      if constexpr (AF == A_KC) {
+        v.off = (long long)m * g.lda + c8;
+      } else {  // row = output pixel (A_G1) / pixel of this parity class (A_G3)
+        const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = m >> cg.lOHW;
+        v.i0 = AF == A_G1 ? 2 * oy - 1 : oy + par_y;
+        v.i1 = AF == A_G1 ? 2 * ox - 1 : ox + par_x;
+        v.i2 = b * cg.IH * cg.IW;
+        v.i3 = c8;
+      }
+    }
+    return v;
+  };
+  auto b_inv = [&](int pc) __attribute__((always_inline)) -> Inv {
+    Inv v{0, 0, 0, 0, 0};
+    if constexpr (!B_IS_KM) {
+      int r, c8;
+      kc_lane(pc, &r, &c8);
+      v.off = (long long)(n0 + r) * g.ldb + c8;
+    } else {
+      int kr, col;
+      km_lane(pc, BN, &kr, &col);
+      const int j = n0 + col;
+      if constexpr (BF == B_KM) {
+        v.off = (long long)kr * g.ldb + j;
+      } else if constexpr (BF == B_G2) {  // j = (tap, channel) of the patch: fixed per lane
+        const int tap = j >> g.lCc;
+        v.i0 = (tap >> 2) - 1;
+        v.i1 = (tap & 3) - 1;
+        v.i2 = j & ((1 << g.lCc) - 1);
+        v.i3 = kr;
+      } else {  // B_G3W
+        v.i2 = j;
+        v.i3 = kr;
+      }
+    }
+    return v;
+  };
+  // element offset of this lane's 16 bytes inside a plane at K step k0 (-1: outside the image -> zeros)
+  auto a_off = [&](const Inv& v, int k0, bool* ok) __attribute__((always_inline)) -> long long {
+    *ok = true;
+    if constexpr (AF == A_KC) return v.off + k0;
+    else if constexpr (AF == A_KM) return v.off + (long long)k0 * g.lda;
+    else {
+      const int tap = k0 >> g.lCc, ch = k0 - (tap << g.lCc);  // uniform
+      const int iy = v.i0 + (AF == A_G1 ? (tap >> 2) : -(tap >> 1)), ix = v.i1 + (AF == A_G1 ? (tap & 3) : -(tap & 1));
+      *ok = (unsigned)iy < (unsigned)cg.IH && (unsigned)ix < (unsigned)cg.IW;
+      return ((long long)(v.i2 + iy * cg.IW + ix) << g.lCc) + ch + v.i3;
+    }
+  };
+  auto b_off = [&](const Inv& v, int k0, bool* ok) __attribute__((always_inline)) -> long long {
+    *ok = true;
+    if constexpr (BF == B_KC) return v.off + k0;
+    else if constexpr (BF == B_KM) return v.off + (long long)k0 * g.ldb;
+    else if constexpr (BF == B_G2) {  // k = output pixel (the contraction index)
+      const int k = k0 + v.i3;
+      const int ox = k & ((1 << cg.lOW) - 1), oy = (k & ((1 << cg.lOHW) - 1)) >> cg.lOW, b = k >> cg.lOHW;
+      const int iy = 2 * oy + v.i0, ix = 2 * ox + v.i1;
+      *ok = (unsigned)iy < (unsigned)cg.IH && (unsigned)ix < (unsigned)cg.IW;
+      return ((long long)((b * cg.IH + iy) * cg.IW + ix) << g.lCc) + v.i2;
+    } else {  // B_G3W: row k = (tap, c) of the weight [C_in][(ky, kx, oc)]: the (uniform) tap picks the column block
+      const int tap = k0 >> g.lCc;
+      const int ky = 1 - par_y + 2 * (tap >> 1), kx = 1 - par_x + 2 * (tap & 1);
+      return (long long)(k0 - (tap << g.lCc) + v.i3) * g.ldb + (long long)(ky * 4 + kx) * g.N + v.i2;
+    }
+  };
+  Inv inva[UA], invb[UB];
+#pragma unroll
+  for (int i = 0; i < UA; ++i) inva[i] = a_inv((wave + NW * i) % PPA);
+#pragma unroll
+  for (int i = 0; i < UB; ++i) invb[i] = b_inv((wave + NW * i) % PPB);
+  auto dma3 = [&](const bf16r* base, long long ps, long long off, bool ok, int dst, int plane_bytes) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      // (outside the image: the 16 zero bytes of g_p3_zero, selected as an OFFSET so that the request stays one instruction)
+      const bf16r* plane = base + (size_t)q * ps;
+      const long long zoff = (long long)((uintptr_t)zero - (uintptr_t)plane) >> 1;
+      const bf16r* src = plane + (ok ? off : zoff);
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(lds + dst + q * plane_bytes), 16, 0, 0);
+    }
+  };
+#ifdef MV_P3_DBG
+  const int dbg = g.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+  auto issue = [&](int buf, int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      const int pc = wave + NW * i;  // wave-uniform
+      if ((PPA % NW == 0 || pc < PPA) && !(dbg & 2)) {
+        bool ok;
+        const long long off = a_off(inva[i], k0, &ok);
+        dma3(g.A, g.psa, off, ok, buf * SB + pc * 1024, PLA);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int pc = wave + NW * i;
+      if ((PPB % NW == 0 || pc < PPB) && !(dbg & 4)) {
+        bool ok;
+        const long long off = b_off(invb[i], k0, &ok);
+        dma3(g.B, g.psb, off, ok, buf * SB + 3 * PLA + pc * 1024, PLB);
+      }
+    }
+  };
+
+  // ---- fragments: lane l holds (tile row l & 15, k = 8 (l >> 4) .. + 7) of every 16-row block
+  const int wm = (wave / WC) * WM, wn = (wave % WC) * WN;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto frag = [&](int buf, bool is_b, int blk16, int q) __attribute__((always_inline)) -> p3_bf16x8 {
+    // blk16: index of the 16-row block inside the operand tile
+    const int plane = buf * SB + (is_b ? 3 * PLA + q * PLB : q * PLA);
+    const bool km = is_b ? B_IS_KM : A_IS_KM;
+    if (!km) {
+      const int row = blk16 * 16 + l15;
+      const int slot = l4 ^ p3_h(l15 >> 2);
+      return *reinterpret_cast<const p3_bf16x8*>(lds + plane + row * 64 + slot * 16);
+    } else {
+      const int ROWB = (is_b ? BN : BM) * 2, CPR = (is_b ? BN : BM) / 16, RPB = 8 / CPR;
+      p3_s16x8 v;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kr = 4 * (2 * l4 + t) + (l15 >> 2);
+        const int x = (kr / RPB) & (CPR - 1);
+        const int addr = plane + kr * ROWB + ((blk16 ^ x) << 5) + (l15 & 3) * 8;
+        // inline asm: behind the builtin hipcc waits for EVERY LDS-DMA in flight (s_waitcnt vmcnt(0)) before the read, which would
+        // drain the tile that is being prefetched; the wait for these reads is the explicit lgkmcnt(0) in step()
+        p3_s16x4 h;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h) : "v"(lds0 + (unsigned)addr));
+        v[4 * t + 0] = h[0]; v[4 * t + 1] = h[1]; v[4 * t + 2] = h[2]; v[4 * t + 3] = h[3];
+      }
+      return __builtin_bit_cast(p3_bf16x8, v);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA instructions this wave issues per tile (the count its s_waitcnt leaves in flight: the tile after the current one)
+  const int per_tile = 3 * ((PPA % NW == 0 ? UA : (wave < PPA ? 1 : 0)) + (PPB % NW == 0 ? UB : (wave < PPB ? 1 : 0)));
+  auto step = [&](int buf, int nbuf, int k_next) __attribute__((always_inline)) {
+    // [this wave's pieces of the current tile have landed | barrier: everybody's have, and every wave has left the previous
+    // step, whose buffer the DMA below overwrites | fragment reads | DMA of the tile NST - 1 steps ahead | MFMAs]
+    if (dbg & 1) asm volatile("s_barrier" ::: "memory");
+    else if (NST == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (per_tile == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if (per_tile == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    p3_bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) af[a][q] = frag(buf, false, (wm >> 4) + a, q);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bf[b][q] = frag(buf, true, (wn >> 4) + b, q);
+    if (A_IS_KM || B_IS_KM) {  // the transposing reads are inline asm: their wait is ours
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    issue(nbuf, k_next < ke ? k_next : kb);  // (past the end: a harmless re-read of the first tile, never consumed)
+    // piece pairs from the smallest products up; operands swapped (B fragment first) so that a lane's four accumulator
+    // values are four consecutive columns of one output row
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    if (dbg & 8) {  // (keep the fragments alive without the MFMAs)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(af[a][q]));
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(bf[b][q]));
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b][PB[t]], af[a][PA[t]], acc[a][b], 0, 0, 0);
+  };
+
+  issue(0, kb);
+  if constexpr (NST == 2) {
+    for (int k0 = kb; k0 < ke; k0 += 64) {
+      step(0, 1, k0 + 32);
+      if (k0 + 32 < ke) step(1, 0, k0 + 64);
+    }
+  } else {
+    issue(1, kb + 32 < ke ? kb + 32 : kb);
+    for (int k0 = kb; k0 < ke; k0 += 96) {
+      step(0, 2, k0 + 64);
+      if (k0 + 32 < ke) step(1, 0, k0 + 96);
+      if (k0 + 64 < ke) step(2, 1, k0 + 128);
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (unused) DMA of the last step
+  // ---- epilogue: lane holds row l15, columns 4 * l4 + r of every 16 x 16 tile
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    int m = m0 + wm + a * 16 + l15;
+    if (PARITY) {  // row of the parity class -> its pixel of the (2 IH) x (2 IW) output
+      const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, bb = m >> cg.lOHW;
+      m = (bb * 2 * cg.IH + 2 * oy + par_y) * 2 * cg.IW + 2 * ox + par_x;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn + b * 16 + l4 * 4;
+      f32x4 v = acc[a][b];
+      const size_t o = (size_t)m * g.ldc + n;
+      if (g.mask) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(C + o) = v;
+      if (g.Cp) store_planes4(g.Cp, g.psc, o, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// ---- planes of an existing f32 tensor (weights after the optimizer step; activations whose producer does not emit them)
+constexpr int kMaxSplitJobs = 12;
+struct SplitJobs {
+  const float* src[kMaxSplitJobs];
+  bf16r* dst[kMaxSplitJobs];
+  long long n[kMaxSplitJobs];  // floats, a multiple of 4; planes at dst, dst + n, dst + 2 n
+  int blk0[kMaxSplitJobs + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void k_split3(const SplitJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
+  const float* src = jobs.src[j];
+  bf16r* dst = jobs.dst[j];
+  const long long n = jobs.n[j], n4 = n >> 2;
+  const int nblk = jobs.blk0[j + 1] - jobs.blk0[j];
+  for (long long i = (long long)((int)blockIdx.x - jobs.blk0[j]) * 256 + threadIdx.x; i < n4; i += (long long)nblk * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    store_planes4(dst, n, (size_t)i * 4, v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream) {
+  if (njobs < 1 || njobs > kMaxSplitJobs || !src || !planes || !n) return fail(MVAE_E_BADARG, "1 .. 12 jobs%s", "");
+  SplitJobs jobs;
+  jobs.njobs = njobs;
+  jobs.blk0[0] = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!src[j] || !planes[j] || n[j] < 4 || (n[j] & 3)) return fail(MVAE_E_BADARG, "null pointer / n not a multiple of 4%s", "");
+    if (!aligned16(src[j]) || ((uintptr_t)planes[j] & 7)) return fail(MVAE_E_ALIGN, "mvae_split3_planes: 16-byte aligned source, 8-byte aligned planes%s", "");
+    jobs.src[j] = src[j];
+    jobs.dst[j] = planes[j];
+    jobs.n[j] = n[j];
+    const long long want = (n[j] / 4 + 256 * 4 - 1) / (256 * 4);  // ~4 vectors per thread
+    jobs.blk0[j + 1] = jobs.blk0[j] + (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  }
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)jobs.blk0[njobs]), dim3(256), 0, (hipStream_t)stream, jobs);
+  LAUNCH_CHECK("split3 planes launch");
+  return 0;
+}
+
+// ---- entry points -------------------------------------------------------------------------------------------------------
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+static bool planes_ok(const void* p, long long ld, long long ps) { return p && ((uintptr_t)p & 15) == 0 && (ld & 7) == 0 && (ps & 7) == 0; }
+
+#ifndef MV_P3_STAGES
+#define MV_P3_STAGES 3
+#endif
+template <int BM, int BN, int WR, int AF, int BF>
+static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
+  P3Args a = a0;
+#ifdef MV_P3_DBG
+  const char* e = getenv("MV_P3_DBG");
+  a.dbg = e ? atoi(e) : 0;
+#endif
+  dim3 grid(a.N / BN, a.M / BM, zdim);
+  hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES>), grid, dim3(512), 0, s, a);
+}
+
+// Which shapes the plane kernels take (the callers fall back to the f32-operand kernels otherwise): whole tiles only.
+//   form 0  conv backward-data   (M = B OH OW output pixels, N = OC, K = 16 C)        mvae_conv_k4s2p1_nhwc_p3
+//   form 1  NN product           (M rows, N columns, K)                               mvae_gemm_nn_p3
+//   form 2  transposed conv      (M = B IH IW pixels per parity class, N = OC, K = 4 C)  mvae_conv_transpose_k4s2p1_nhwc_p3
+//   form 3  conv weight gradient (M = B OH OW contracted rows, N = OC, K = 16 C columns) mvae_conv_k4s2p1_nhwc_wgrad_p3
+extern "C" int mvae_p3_supported(int form, int64_t M, int N, int K, int Cc) {
+  if (M < 256 || (M & 127) || M > 0x7fffffff || N < 64 || K < 32) return 0;
+  const bool cpow = Cc >= 16 && ilog2_exact(Cc) >= 0;
+  switch (form) {
+    case 0: return (N % 128 == 0) && (K % 32 == 0) && cpow && Cc >= 32;
+    case 1: return (N % 128 == 0) && (K % 32 == 0);
+    case 2: return (N % 64 == 0) && (K % 32 == 0) && cpow && Cc >= 32;
+    case 3: return (N % 128 == 0) && (K % 128 == 0) && (M % 256 == 0) && cpow;
+    default: return 0;
+  }
+}
+
+// Split-K slices of the gathered backward-data contraction: whole 128 x 128 tiles, >= ~256 workgroups, <= 8 slices of whole K steps
+static int p3_conv_slices(int64_t M, int OC, int K, bool has_mask, int* kps) {
+  *kps = K;
+  if (has_mask) return 1;
+  const int64_t tiles = (M / 128) * (OC / 128);
+  if (tiles >= 192 || K < 1024) return 1;
+  int slices = (int)((256 + tiles - 1) / tiles);
+  if (slices > 8) slices = 8;
+  *kps = ((K + slices - 1) / slices + 31) & ~31;
+  return (K + *kps - 1) / *kps;
+}
+extern "C" int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int Cc, int IH, int IW, int OC, int has_mask) {
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  int kps;
+  const int slices = p3_conv_slices(M, OC, 16 * Cc, has_mask != 0, &kps);
+  return slices > 1 ? (int64_t)slices * M * OC : 0;
+}
+
+void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);      // mvae_conv.hip (honours deferral)
+void p3_sum_slices_now(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (immediate)
+
+static int p3_geom(ConvGeom* g, int* lCc, int B, int Cc, int IH, int IW, bool out_is_half) {
+  const int l = ilog2_exact(Cc);
+  if (B < 1 || l < 0 || IH < 2 || IW < 2 || (IH & (IH - 1)) || (IW & (IW - 1)))
+    return fail(MVAE_E_UNSUPPORTED, "plane contractions need power-of-two channels and extents%s (%lld)", "", Cc);
+  int lOW = 0, lOH = 0;
+  const int OW = out_is_half ? IW / 2 : IW, OH = out_is_half ? IH / 2 : IH;
+  while ((1 << lOW) < OW) ++lOW;
+  while ((1 << lOH) < OH) ++lOH;
+  *g = ConvGeom{Cc, IH, IW, lOW, lOW + lOH};
+  *lCc = l;
+  return 0;
+}
+
+// y[(b,oy,ox), oc] = sum_{ky,kx,c} src[b, 2oy-1+ky, 2ox-1+kx, c] Wt[oc, (ky,kx,c)], zeroed where mask <= 0: the backward-data of a
+// ConvTranspose2d (conv_vae.py:52-55) as mvae_conv_k4s2p1_nhwc computes it, on the planes of src [B*IH*IW, C] and of Wt
+// [OC, 16 C]; y f32 (+ its planes when y_planes != NULL).
+extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
+                                        const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int Cc, int IH,
+                                        int IW, int OC, float* workspace, void* stream) {
+  if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  const int K = 16 * Cc;
+  if (!mvae_p3_supported(0, M, OC, K, Cc)) return fail(MVAE_E_UNSUPPORTED, "mvae_conv_k4s2p1_nhwc_p3: whole 128 x 128 tiles only%s", "");
+  P3Args a{};
+  int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, true);
+  if (rc) return rc;
+  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, K, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
+      (y_planes && !planes_ok(y_planes, OC, y_ps)))
+    return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
+  int kps;
+  const int slices = workspace ? p3_conv_slices(M, OC, K, mask != nullptr, &kps) : 1;
+  a.A = src_planes; a.lda = Cc; a.psa = src_ps;
+  a.B = Wt_planes; a.ldb = K; a.psb = w_ps;
+  a.ldc = OC; a.M = (int)M; a.N = OC; a.K = K;
+  if (slices > 1) {
+    if (!aligned16(workspace)) return fail(MVAE_E_ALIGN, "workspace must be 16-byte aligned%s", "");
+    a.C = workspace; a.Cp = nullptr; a.psc = 0; a.mask = nullptr; a.k_per_slice = kps; a.slice_stride = M * OC;
+    launch_p3<128, 128, 2, A_G1, B_KC>(a, slices, (hipStream_t)stream);
+    if (y_planes) return fail(MVAE_E_UNSUPPORTED, "planes of a split-K result are not produced%s", "");
+    p3_sum_slices_now(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
+  } else {
+    a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0;
+    launch_p3<128, 128, 2, A_G1, B_KC>(a, 1, (hipStream_t)stream);
+  }
+  LAUNCH_CHECK("plane conv backward-data launch");
+  return 0;
+}
+
+// out[M, N] = G[M, K] W[K, N] on the planes of G (K contiguous) and W (N contiguous): the product of a Conv2d backward-data
+// that mvae_col2im_k4s2p1 folds (mvae_gemm_nn).
+extern "C" int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uint16_t* W_planes, int64_t w_ps, float* out,
+                               int64_t M, int K, int N, void* stream) {
+  if (!G_planes || !W_planes || !out) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (!mvae_p3_supported(1, M, N, K, 0)) return fail(MVAE_E_UNSUPPORTED, "mvae_gemm_nn_p3: whole 128 x 128 tiles only%s", "");
+  if (!planes_ok(G_planes, K, g_ps) || !planes_ok(W_planes, N, w_ps) || !aligned16(out))
+    return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
+  P3Args a{};
+  a.A = G_planes; a.lda = K; a.psa = g_ps;
+  a.B = W_planes; a.ldb = N; a.psb = w_ps;
+  a.C = out; a.ldc = N; a.Cp = nullptr; a.mask = nullptr;
+  a.M = (int)M; a.N = N; a.K = K; a.k_per_slice = K; a.slice_stride = 0;
+  launch_p3<128, 128, 2, A_KC, B_KM>(a, 1, (hipStream_t)stream);
+  LAUNCH_CHECK("plane NN product launch");
+  return 0;
+}
+
+// The transposed convolution per output parity class (mvae_conv_transpose_k4s2p1_nhwc) on planes: src [B*IH*IW, C], Wt [C, 16 OC]
+// (columns (ky, kx, oc)); y [B * 2IH * 2IW, OC] f32 (+ planes), zeroed where mask <= 0.  A Conv2d's backward-data.
+extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes,
+                                                  int64_t w_ps, const float* mask, float* y, uint16_t* y_planes, int64_t y_ps,
+                                                  int B, int Cc, int IH, int IW, int OC, void* stream) {
+  if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const int64_t M = (int64_t)B * IH * IW;
+  const int K = 4 * Cc;
+  if (!mvae_p3_supported(2, M, OC, K, Cc)) return fail(MVAE_E_UNSUPPORTED, "mvae_conv_transpose_k4s2p1_nhwc_p3: whole tiles only%s", "");
+  P3Args a{};
+  int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, false);
+  if (rc) return rc;
+  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, 16 * OC, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
+      (y_planes && !planes_ok(y_planes, OC, y_ps)) || 4 * M > 0x7fffffff)
+    return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
+  a.A = src_planes; a.lda = Cc; a.psa = src_ps;
+  a.B = Wt_planes; a.ldb = (long long)16 * OC; a.psb = w_ps;
+  a.C = y; a.ldc = OC; a.Cp = y_planes; a.psc = y_ps; a.mask = mask;
+  a.M = (int)M; a.N = OC; a.K = K; a.k_per_slice = K; a.slice_stride = 0;
+  if (OC % 128 == 0) launch_p3<128, 128, 2, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
+  else launch_p3<128, 64, 4, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
+  LAUNCH_CHECK("plane transposed conv launch");
+  return 0;
+}
+
+// dWt[oc, (ky,kx,c)] = sum_{b,oy,ox} dy[(b,oy,ox), oc] src[b, 2oy-1+ky, 2ox-1+kx, c] on the planes of dy [B*OH*OW, OC] and src
+// [B*IH*IW, C] (mvae_conv_k4s2p1_nhwc_wgrad).  The rows are cut into slices (>= 256 workgroups) whose partial products
+// are added in index order; workspace = mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats floats.
+static int p3_wgrad_slices(int64_t M, int NP, int NQ, int* kps) {
+  const int wg = (NP / 128) * (NQ / 128);
+  int slices = (256 + wg - 1) / wg;
+  const int max_slices = (int)(M / 256);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  *kps = (int)((((M + slices - 1) / slices) + 31) & ~(int64_t)31);
+  return (int)((M + *kps - 1) / *kps);
+}
+extern "C" int64_t mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(int B, int Cc, int IH, int IW, int OC) {
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  int kps;
+  const int slices = p3_wgrad_slices(M, OC, 16 * Cc, &kps);
+  return slices > 1 ? (int64_t)slices * OC * 16 * Cc : 0;
+}
+extern "C" int mvae_conv_k4s2p1_nhwc_wgrad_p3(const uint16_t* dy_planes, int64_t dy_ps, const uint16_t* src_planes, int64_t src_ps,
+                                              float* dWt, int B, int Cc, int IH, int IW, int OC, float* workspace, void* stream) {
+  if (!dy_planes || !src_planes || !dWt) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
+  const int NQ = 16 * Cc;
+  if (!mvae_p3_supported(3, M, OC, NQ, Cc))
+    return fail(MVAE_E_UNSUPPORTED, "mvae_conv_k4s2p1_nhwc_wgrad_p3: whole 128 x 128 tiles, rows a multiple of 256%s", "");
+  P3Args a{};
+  int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, true);
+  if (rc) return rc;
+  if (!planes_ok(dy_planes, OC, dy_ps) || !planes_ok(src_planes, Cc, src_ps) || !aligned16(dWt))
+    return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
+  int kps;
+  const int slices = p3_wgrad_slices(M, OC, NQ, &kps);
+  if (slices > 1 && (!workspace || !aligned16(workspace))) return fail(MVAE_E_BADARG, "the weight gradient needs its workspace%s", "");
+  const int64_t n = (int64_t)OC * NQ;
+  a.A = dy_planes; a.lda = OC; a.psa = dy_ps;
+  a.B = src_planes; a.ldb = Cc; a.psb = src_ps;
+  a.C = slices > 1 ? workspace : dWt; a.ldc = NQ; a.Cp = nullptr; a.mask = nullptr;
+  a.M = OC; a.N = NQ; a.K = (int)M; a.k_per_slice = kps; a.slice_stride = n;
+  launch_p3<128, 128, 2, A_KM, B_G2>(a, slices, (hipStream_t)stream);
+  if (slices > 1) p3_sum_slices(workspace, dWt, n, slices, (hipStream_t)stream);
+  LAUNCH_CHECK("plane weight gradient launch");
+  return 0;
+}

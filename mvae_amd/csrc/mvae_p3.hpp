@@ -1,0 +1,47 @@
+// mvae_p3.hpp -- shared by mvae_conv.hip and mvae_p3.hip: the geometry record of the k4 s2 p1 convolutions and the exact
+// three-way bf16 split of a float ("planes").
+//
+// A float has 24 significant bits; truncating to bf16 keeps 8.  x = h + m + l EXACTLY with h = bf16_trunc(x),
+// m = bf16_trunc(x - h), l = bf16_trunc(x - h - m) (each subtraction is exact: the operands share the leading bits).
+// Stored as three bf16 PLANES of the tensor's shape, a contraction multiplies through the six largest piece products on the
+// bf16 MFMA (mvae_p3.hip); a producing epilogue writes the planes next to its f32 result, so no consumer splits again.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct ConvGeom {
+  int Cc, IH, IW;    // channels and extent of the SOURCE image
+  int lOW, lOHW;     // log2(OW), log2(OH * OW), OH = IH / 2, OW = IW / 2 (powers of two)
+};
+
+typedef unsigned short bf16r;  // storage type of a plane entry (raw bf16 bits)
+typedef unsigned int p3_u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 consecutive floats -> their (hi, mid, lo) bf16 pieces, two per dword (element 0 in the low half)
+__device__ __forceinline__ void split3_planes(const float x0, const float x1, const float x2, const float x3, p3_u32x2* hi,
+                                              p3_u32x2* mi, p3_u32x2* lo) {
+  const float x[4] = {x0, x1, x2, x3};
+  unsigned int h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int xb = __float_as_uint(x[e]);
+    h[e] = xb;
+    const float r1 = x[e] - __uint_as_float(xb & 0xffff0000u);
+    const unsigned int r1b = __float_as_uint(r1);
+    m[e] = r1b;
+    l[e] = __float_as_uint(r1 - __uint_as_float(r1b & 0xffff0000u));
+  }
+  *hi = p3_u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  *mi = p3_u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  *lo = p3_u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+
+// store the planes of 4 consecutive entries starting at element index `idx` (a multiple of 4): three 8-byte stores
+__device__ __forceinline__ void store_planes4(bf16r* planes, long long plane_stride, size_t idx, float x0, float x1, float x2,
+                                              float x3) {
+  p3_u32x2 h, m, l;
+  split3_planes(x0, x1, x2, x3, &h, &m, &l);
+  *reinterpret_cast<p3_u32x2*>(planes + idx) = h;
+  *reinterpret_cast<p3_u32x2*>(planes + plane_stride + idx) = m;
+  *reinterpret_cast<p3_u32x2*>(planes + 2 * plane_stride + idx) = l;
+}

@@ -1,0 +1,41 @@
+"""Dev tool: ONE backward contraction of the conv step at B = 256 on pre-split planes, repeated (for rocprofv3 --pmc runs):
+   python tools/p3_one.py db1|dt0|da1|da0|dWd2|dWd1|dWe2|dWe1 [b3]     (b3: the in-kernel-split kernel instead)"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvae_amd._lib import load
+from mvae_amd import conv as Cv
+dev = torch.device("cuda:0")
+B = 256
+op = sys.argv[1] if len(sys.argv) > 1 else "db1"
+b3 = len(sys.argv) > 2 and sys.argv[2] == "b3"
+load().mvae_set_contraction_mode(1 if b3 else 2)
+g = torch.Generator().manual_seed(0)
+rnd = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+P = lambda t: Cv._split_planes([t])[0]  # noqa: E731
+if op in ("db1", "dt0"):
+    Cc, IH, OC, masked = (64, 16, 256, True) if op == "db1" else (256, 8, 128, False)
+    src, Wt = rnd(B * IH * IH, Cc), rnd(OC, 16 * Cc) * 0.05
+    mask = rnd(B * (IH // 2) ** 2, OC) if masked else None
+    sp, wp = P(src), P(Wt)
+    fn = (lambda: Cv._conv_nhwc(src, Wt, None, mask, B, Cc, IH, False, Cv.BACKWARD)) if b3 else \
+         (lambda: Cv._conv_nhwc_p3(sp, wp, mask, B, Cc, IH, want_planes=masked))
+elif op == "da1":
+    x, Wn = rnd(B * 16, 512), rnd(512, 2048) * 0.05
+    xp, wp = P(x), P(Wn)
+    fn = (lambda: Cv._gemm_nn(x, Wn, Cv.BACKWARD)) if b3 else (lambda: Cv._gemm_nn_p3(xp, wp))
+elif op == "da0":
+    src, Wt, mask = rnd(B * 64, 128), rnd(128, 16 * 64) * 0.05, rnd(B * 256, 64)
+    sp, wp = P(src), P(Wt)
+    fn = (lambda: Cv._convT_nhwc(src, Wt, None, mask, B, 128, 8, 64, False, Cv.BACKWARD)) if b3 else \
+         (lambda: Cv._convT_nhwc_p3(sp, wp, mask, B, 128, 8, 64))
+else:
+    Cc, IH, OC = {"dWd2": (64, 16, 256), "dWd1": (256, 8, 128), "dWe2": (128, 8, 512), "dWe1": (64, 16, 128)}[op]
+    dy, src = rnd(B * (IH // 2) ** 2, OC), rnd(B * IH * IH, Cc)
+    out = torch.empty(OC, 16 * Cc, device=dev)
+    dp, sp = P(dy), P(src)
+    fn = (lambda: Cv._conv_nhwc_wgrad(dy, src, out, B, Cc, IH)) if b3 else (lambda: Cv._conv_nhwc_wgrad_p3(dp, sp, out, B, Cc, IH))
+for _ in range(20):
+    fn()
+    Cv._DEFERRED_WS.clear()
+torch.cuda.synchronize()
