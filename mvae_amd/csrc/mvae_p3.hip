@@ -23,6 +23,8 @@
 // swizzles are applied to the per-lane SOURCE address and again at the read (cdna_hip_programming.md, rule 21).
 // Gathered forms (implicit convolution, channel-last images; the patch matrix is never written): A_G1 / A_G3 / B_G2 / B_G3W
 // as GATHER 1 / 3 / 2 / 3 of k_gemm_tiled; a pixel outside the image reads 16 zero bytes from g_p3_zero.
+#include <type_traits>
+
 #include "mvae_common.hpp"
 #include "mvae_p3.hpp"
 
@@ -43,7 +45,7 @@ struct P3Args {
   long long slice_stride;              // floats between the partial results of consecutive K slices (blockIdx.z)
   ConvGeom cg;
   int lCc;                             // log2(cg.Cc)
-  int dbg;                             // (-DMV_P3_DBG builds only) bit 0: no DMA waits, 1: no A DMA, 2: no B DMA, 3: no MFMAs
+  int dbg;                             // (-DMV_P3_DBG builds only) bit 0: no DMA waits, 1: no A DMA, 2: no B DMA, 3: no MFMAs, 4: every step loads tile 0, 5: no barriers, 6: no fragment reads
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_p3_zero[4];
@@ -73,12 +75,13 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   const ConvGeom cg = g.cg;
   const bf16r* zero = reinterpret_cast<const bf16r*>(g_p3_zero);
 
-  // ---- LDS-DMA geometry.  A plane tile is BM / 16 one-KiB pieces (KC: 16 rows of 64 bytes; KM: 1024 / (2 BM) k rows); wave w
-  // moves pieces w, w + 8, ... of EVERY plane of both operands, so one address computation per operand and K step serves
-  // three DMA instructions (the planes differ by a uniform stride).  Everything that does not depend on the K step is kept
-  // in registers: inv[0..3] per piece.
+  // ---- LDS-DMA geometry.  A plane tile is BM / 16 one-KiB pieces (KC: 16 rows of 64 bytes; KM: 1024 / (2 BM) k rows).  The waves
+  // move pieces w, w + 8, ... of every plane of both operands: one address computation per operand piece serves three DMA
+  // instructions (the planes differ by a uniform stride); everything that does not depend on the K step is kept in
+  // registers (inv per piece).
   constexpr int PPA = BM / 16, PPB = BN / 16;         // pieces per plane
-  constexpr int UA = (PPA + NW - 1) / NW, UB = (PPB + NW - 1) / NW;
+  constexpr int NI = NW;                               // every wave moves its share of a tile
+  constexpr int UA = (PPA + NI - 1) / NI, UB = (PPB + NI - 1) / NI;
   struct Inv { long long off; int i0, i1, i2, i3; };
   // lane geometry inside a piece: KC -> (tile row r, source chunk offset c8 in elements); KM -> (k row kr, column offset col)
   auto kc_lane = [&](int pc, int* r, int* c8) __attribute__((always_inline)) {
@@ -166,11 +169,12 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
       return (long long)(k0 - (tap << g.lCc) + v.i3) * g.ldb + (long long)(ky * 4 + kx) * g.N + v.i2;
     }
   };
+  const int grp = wave >> 2, idx = wave;  // (grp: the ping-pong group, see the K loop)
   Inv inva[UA], invb[UB];
 #pragma unroll
-  for (int i = 0; i < UA; ++i) inva[i] = a_inv((wave + NW * i) % PPA);
+  for (int i = 0; i < UA; ++i) inva[i] = a_inv((idx + NI * i) % PPA);
 #pragma unroll
-  for (int i = 0; i < UB; ++i) invb[i] = b_inv((wave + NW * i) % PPB);
+  for (int i = 0; i < UB; ++i) invb[i] = b_inv((idx + NI * i) % PPB);
   auto dma3 = [&](const bf16r* base, long long ps, long long off, bool ok, int dst, int plane_bytes) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -189,8 +193,8 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   auto issue = [&](int buf, int k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < UA; ++i) {
-      const int pc = wave + NW * i;  // wave-uniform
-      if ((PPA % NW == 0 || pc < PPA) && !(dbg & 2)) {
+      const int pc = idx + NI * i;  // wave-uniform
+      if ((PPA % NI == 0 || pc < PPA) && !(dbg & 2)) {
         bool ok;
         const long long off = a_off(inva[i], k0, &ok);
         dma3(g.A, g.psa, off, ok, buf * SB + pc * 1024, PLA);
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
     }
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
-      const int pc = wave + NW * i;
-      if ((PPB % NW == 0 || pc < PPB) && !(dbg & 4)) {
+      const int pc = idx + NI * i;
+      if ((PPB % NI == 0 || pc < PPB) && !(dbg & 4)) {
         bool ok;
         const long long off = b_off(invb[i], k0, &ok);
         dma3(g.B, g.psb, off, ok, buf * SB + 3 * PLA + pc * 1024, PLB);
@@ -210,30 +214,40 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   // ---- fragments: lane l holds (tile row l & 15, k = 8 (l >> 4) .. + 7) of every 16-row block
   const int wm = (wave / WC) * WM, wn = (wave % WC) * WN;
   const int l15 = lane & 15, l4 = lane >> 4;
-  auto frag = [&](int buf, bool is_b, int blk16, int q) __attribute__((always_inline)) -> p3_bf16x8 {
-    // blk16: index of the 16-row block inside the operand tile
-    const int plane = buf * SB + (is_b ? 3 * PLA + q * PLB : q * PLA);
-    const bool km = is_b ? B_IS_KM : A_IS_KM;
-    if (!km) {
-      const int row = blk16 * 16 + l15;
-      const int slot = l4 ^ p3_h(l15 >> 2);
-      return *reinterpret_cast<const p3_bf16x8*>(lds + plane + row * 64 + slot * 16);
-    } else {
-      const int ROWB = (is_b ? BN : BM) * 2, CPR = (is_b ? BN : BM) / 16, RPB = 8 / CPR;
-      p3_s16x8 v;
+  // KC operand: ds_read_b128 at [row][chunk ^ h]: the lane part is the same for every 16-row block, plane and buffer
+  const int kc_lane_off = l15 * 64 + ((l4 ^ p3_h(l15 >> 2)) << 4);
+  // KM operand: two transposing reads per fragment (k rows 8 l4 + 4 t + (l15 >> 2), t = 0, 1); the lane part depends on the
+  // 16-row block through the XOR swizzle, so one address register per (block, t), kept over the whole K loop
+  unsigned kmA[A_IS_KM ? TM : 1][2], kmB[B_IS_KM ? TN : 1][2];
+  auto km_lane_off = [&](int rows, int blk16, int t) __attribute__((always_inline)) -> unsigned {
+    const int ROWB = rows * 2, CPR = rows / 16, RPB = 8 / CPR;
+    const int kr = 4 * (2 * l4 + t) + (l15 >> 2);
+    const int x = (kr / RPB) & (CPR - 1);
+    return lds0 + kr * ROWB + ((blk16 ^ x) << 5) + (l15 & 3) * 8;
+  };
+  if constexpr (A_IS_KM) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int kr = 4 * (2 * l4 + t) + (l15 >> 2);
-        const int x = (kr / RPB) & (CPR - 1);
-        const int addr = plane + kr * ROWB + ((blk16 ^ x) << 5) + (l15 & 3) * 8;
-        // inline asm: behind the builtin hipcc waits for EVERY LDS-DMA in flight (s_waitcnt vmcnt(0)) before the read, which would
-        // drain the tile that is being prefetched; the wait for these reads is the explicit lgkmcnt(0) in step()
-        p3_s16x4 h;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h) : "v"(lds0 + (unsigned)addr));
-        v[4 * t + 0] = h[0]; v[4 * t + 1] = h[1]; v[4 * t + 2] = h[2]; v[4 * t + 3] = h[3];
-      }
-      return __builtin_bit_cast(p3_bf16x8, v);
-    }
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) kmA[a][t] = km_lane_off(BM, (wm >> 4) + a, t);
+  }
+  if constexpr (B_IS_KM) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) kmB[b][t] = km_lane_off(BN, (wn >> 4) + b, t) + 3 * PLA;
+  }
+  // inline asm: behind the builtin hipcc waits for EVERY LDS-DMA in flight (s_waitcnt vmcnt(0)) before the read, which would
+  // drain the tiles being prefetched; the wait for these reads is the explicit lgkmcnt(0) of sync()
+#define MV_TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+  auto km_pair = [&](unsigned a0, unsigned a1, auto qoff) __attribute__((always_inline)) -> p3_bf16x8 {
+    p3_s16x4 h0, h1;
+    MV_TR_READ(h0, a0, decltype(qoff)::value);
+    MV_TR_READ(h1, a1, decltype(qoff)::value);
+    p3_s16x8 v;
+    v[0] = h0[0]; v[1] = h0[1]; v[2] = h0[2]; v[3] = h0[3];
+    v[4] = h1[0]; v[5] = h1[1]; v[6] = h1[2]; v[7] = h1[3];
+    return __builtin_bit_cast(p3_bf16x8, v);
   };
 
   f32x4 acc[TM][TN];
@@ -242,30 +256,56 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // DMA instructions this wave issues per tile (the count its s_waitcnt leaves in flight: the tile after the current one)
-  const int per_tile = 3 * ((PPA % NW == 0 ? UA : (wave < PPA ? 1 : 0)) + (PPB % NW == 0 ? UB : (wave < PPB ? 1 : 0)));
-  auto step = [&](int buf, int nbuf, int k_next) __attribute__((always_inline)) {
-    // [this wave's pieces of the current tile have landed | barrier: everybody's have, and every wave has left the previous
-    // step, whose buffer the DMA below overwrites | fragment reads | DMA of the tile NST - 1 steps ahead | MFMAs]
-    if (dbg & 1) asm volatile("s_barrier" ::: "memory");
-    else if (NST == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (per_tile == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else if (per_tile == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    p3_bf16x8 af[TM][3], bf[TN][3];
+  // ---- the K loop: two wave groups in PING-PONG.  A workgroup's waves are dealt to the four SIMDs cyclically, so wave w and
+  // wave w + 4 share a SIMD; group 0 = waves 0-3, group 1 = waves 4-7.  A step of a wave is two phases, each closed by a
+  // workgroup barrier: L (read the fragments of tile s from LDS, request this wave's share of tile s + 2 by LDS-DMA) and C
+  // (the 6 x TM x TN MFMAs of tile s).  Group 1 runs ONE PHASE BEHIND group 0 (an extra barrier at its start), so on every SIMD
+  // one wave multiplies while its partner loads: the LDS reads, the DMA requests (a wave stalls ~45 cycles in each while the
+  // CU's address path is busy) and the MFMAs of a CU overlap instead of following each other -- with all eight waves in the
+  // same phase they did not (tools/p3_dbg_sweep.sh: DMA 30 + reads 13 + barriers 3 + MFMA 23 us took 60 us for db1).
+  //   interval 2s    : group 0 in L_s      group 1 in C_{s-1}
+  //   interval 2s + 1: group 0 in C_s      group 1 in L_s
+  // Three LDS buffers: tile s + 2 goes where tile s - 1 was; its last reader is group 1 in L_{s-1} = interval 2s - 1, every L
+  // phase ends with lgkmcnt(0) before its barrier, and the earliest writer is group 0 in L_s = interval 2s.  Tile s + 1 is
+  // complete before its first reader (group 0, interval 2s + 2): a wave leaves at most its newest tile in flight (counted
+  // vmcnt) at the end of C_s (group 0) / L_s (group 1), both before the barrier that closes interval 2s + 1.
+  struct Frags {
+    p3_bf16x8 a[TM][3], b[TN][3];
+  };
+  auto load = [&](Frags& f, auto bufc) __attribute__((always_inline)) {
+    constexpr int BUFOFF = decltype(bufc)::value * SB;
+    if constexpr (!A_IS_KM) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) af[a][q] = frag(buf, false, (wm >> 4) + a, q);
+        for (int q = 0; q < 3; ++q)
+          f.a[a][q] = *reinterpret_cast<const p3_bf16x8*>(lds + BUFOFF + q * PLA + ((wm >> 4) + a) * 1024 + kc_lane_off);
+    } else {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) bf[b][q] = frag(buf, true, (wn >> 4) + b, q);
-    if (A_IS_KM || B_IS_KM) {  // the transposing reads are inline asm: their wait is ours
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int a = 0; a < TM; ++a) {
+        const unsigned a0 = kmA[a][0] + BUFOFF, a1 = kmA[a][1] + BUFOFF;
+        f.a[a][0] = km_pair(a0, a1, std::integral_constant<int, 0>{});
+        f.a[a][1] = km_pair(a0, a1, std::integral_constant<int, PLA>{});
+        f.a[a][2] = km_pair(a0, a1, std::integral_constant<int, 2 * PLA>{});
+      }
     }
-    issue(nbuf, k_next < ke ? k_next : kb);  // (past the end: a harmless re-read of the first tile, never consumed)
+    if constexpr (!B_IS_KM) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          f.b[b][q] = *reinterpret_cast<const p3_bf16x8*>(lds + BUFOFF + 3 * PLA + q * PLB + ((wn >> 4) + b) * 1024 + kc_lane_off);
+    } else {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const unsigned b0 = kmB[b][0] + BUFOFF, b1 = kmB[b][1] + BUFOFF;
+        f.b[b][0] = km_pair(b0, b1, std::integral_constant<int, 0>{});
+        f.b[b][1] = km_pair(b0, b1, std::integral_constant<int, PLB>{});
+        f.b[b][2] = km_pair(b0, b1, std::integral_constant<int, 2 * PLB>{});
+      }
+    }
+  };
+  auto mma = [&](const Frags& f) __attribute__((always_inline)) {
     // piece pairs from the smallest products up; operands swapped (B fragment first) so that a lane's four accumulator
     // values are four consecutive columns of one output row
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -273,11 +313,11 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(af[a][q]));
+        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.a[a][q]));
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(bf[b][q]));
+        for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.b[b][q]));
       return;
     }
 #pragma unroll
@@ -286,23 +326,52 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b][PB[t]], af[a][PA[t]], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[b][PB[t]], f.a[a][PA[t]], acc[a][b], 0, 0, 0);
   };
-
-  issue(0, kb);
-  if constexpr (NST == 2) {
-    for (int k0 = kb; k0 < ke; k0 += 64) {
-      step(0, 1, k0 + 32);
-      if (k0 + 32 < ke) step(1, 0, k0 + 64);
-    }
-  } else {
-    issue(1, kb + 32 < ke ? kb + 32 : kb);
-    for (int k0 = kb; k0 < ke; k0 += 96) {
-      step(0, 2, k0 + 64);
-      if (k0 + 32 < ke) step(1, 0, k0 + 96);
-      if (k0 + 64 < ke) step(2, 1, k0 + 128);
-    }
+  // DMA instructions this wave issues per tile (what its counted wait leaves in flight)
+  const int per_tile = 3 * ((PPA % NW == 0 ? UA : (wave < PPA ? 1 : 0)) + (PPB % NW == 0 ? UB : (wave < PPB ? 1 : 0)));
+  auto barrier = [&]() __attribute__((always_inline)) {
+    if (!(dbg & 32)) asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // (MFMAs touch no memory: the clobber alone would not keep them behind the barrier)
+  };
+  auto wait_dma = [&](bool all) __attribute__((always_inline)) {  // leave only the newest tile's requests in flight
+    if (dbg & 1) return;
+    if (all || per_tile == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (per_tile == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (per_tile == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  const int nsteps = (ke - kb + 31) >> 5;
+  auto tile_k = [&](int t) __attribute__((always_inline)) { return (t < nsteps && !(dbg & 16)) ? kb + 32 * t : kb; };  // (past the end: tile 0 again, never consumed)
+  static_assert(NST == 3, "the ping-pong loop cycles three LDS buffers");
+  Frags f;
+  issue(0, tile_k(0));
+  issue(1, tile_k(1));
+  wait_dma(true);
+  barrier();
+  if (grp == 1) barrier();  // group 1 starts one phase late
+  auto step = [&](int t, auto buf, auto buf_fill) __attribute__((always_inline)) {
+    // L: fragments of tile t, requests of tile t + 2
+    if (!(dbg & 64)) load(f, buf);
+    issue(decltype(buf_fill)::value, tile_k(t + 2));
+    if (grp == 1) wait_dma(false);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    // C
+    mma(f);
+    if (grp == 0) wait_dma(false);
+    barrier();
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
+  for (int t = 0; t < nsteps; t += 3) {
+    step(t, B0{}, B2{});
+    if (t + 1 < nsteps) step(t + 1, B1{}, B0{});
+    if (t + 2 < nsteps) step(t + 2, B2{}, B1{});
   }
+  if (grp == 0) barrier();  // (group 1's last phase)
+#undef MV_TR_READ
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (unused) DMA of the last step
   // ---- epilogue: lane holds row l15, columns 4 * l4 + r of every 16 x 16 tile

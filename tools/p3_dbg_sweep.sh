@@ -1,8 +1,8 @@
 #!/bin/bash
 # where the time of the plane kernels goes: the same launch with pieces switched off (-DMV_P3_DBG variant library)
 export MVAE_HIP_LIB=$(pwd)/mvae_amd/_variants/libmvae_hip_p3dbg.so
-for op in db1 dWe2 da1; do
-  for dbg in 0 1 2 4 6 8 9 14 15; do
+for op in ${OPS:-db1 da1}; do
+  for dbg in ${DBGS:-0 8 72 104 120 106 108 122 124 14}; do
     MV_P3_DBG=$dbg python - $op <<'PY'
 import os, sys, torch
 sys.argv = [sys.argv[0], sys.argv[1]]
@@ -15,7 +15,9 @@ e0.record()
 for _ in range(20):
     fn(); Cv._DEFERRED_WS.clear()
 e1.record(); torch.cuda.synchronize()
-print(op, "dbg", os.environ["MV_P3_DBG"], "us %.1f" % (e0.elapsed_time(e1) / 20 * 1e3))
+d = int(os.environ["MV_P3_DBG"])
+names = ["nowait", "noA", "noB", "noMFMA", "hot", "nobarrier", "noreads"]
+print(op, "dbg", d, "+".join(n for i, n in enumerate(names) if d >> i & 1) or "full", "us %.1f" % (e0.elapsed_time(e1) / 20 * 1e3))
 PY
   done
 done
