@@ -342,6 +342,10 @@ int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, const float*
  *    mode 0's, so forward values and masks are bit-identical to mode 0.
  * The entry points that serve both passes take `pass`; mvae_conv_k4s2p1_nhwc_wgrad, mvae_gemm_tn and
  * mvae_linear_forward_masked are backward by nature, mvae_linear_forward / _splitk forward. */
+/* Which kernel the exact-f32 contractions of whole-tile shapes (M % 128 == 0, N % 64 == 0, K % 32 == 0) take: 1 (default) the
+ * ping-pong LDS-DMA kernel of csrc/mvae_f32pp.hip, 0 the register-staged k_gemm_tiled; the results are BIT-IDENTICAL (same
+ * order of MFMA steps per output element).  Returns the previous value; a negative argument only queries. */
+int mvae_set_forward_kernel(int pingpong);
 #define MVAE_PASS_FORWARD 0
 #define MVAE_PASS_BACKWARD 1
 int mvae_set_contraction_mode(int mode);

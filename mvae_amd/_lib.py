@@ -92,6 +92,7 @@ PROTOTYPES = {
     "mvae_bce_forward_backward": (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
     "mvae_batch_stats": (C.c_int, [_P, _P, _P, _F, _I, _I, _P]),
     "mvae_set_contraction_mode": (C.c_int, [_I]),
+    "mvae_set_forward_kernel": (C.c_int, [_I]),
     "mvae_p3_supported": (C.c_int, [_I, _L, _I, _I, _I]),
     "mvae_split3_planes": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
     "mvae_conv_k4s2p1_nhwc_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),

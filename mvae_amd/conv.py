@@ -319,10 +319,10 @@ def _convT_to3(src: Tensor, W48: Tensor, bias: Tensor, R: int) -> Tensor:
 
 
 def _conv_e2(a1: Tensor, We2: Tensor, bias: Tensor, B: int) -> Tensor:
-    """The e2 layer forward (128 -> 512 channels on 8 x 8): with only B * 16 output pixels its patch matrix is small
-    (33 MB at B = 256), and patch matrix + plain contraction measured faster than the operand gather (12 + 83 us against
-    105 us, tools/bench_conv_gather.py); tiny batches keep the implicit form (the plain contraction wants >= 512 rows)."""
-    if B * 16 >= 512:
+    """The e2 layer forward (128 -> 512 channels on 8 x 8): the implicit contraction (operand gather in the LDS-DMA requests
+    of k_gemm_f32pp).  Until round 4 the patch matrix + plain contraction was faster on the register-staged kernel (12 + 83 us
+    against 105 us); MVAE_CONV_E2_IMPLICIT=0 restores that form (same bits: the same order of MFMA steps)."""
+    if B * 16 >= 512 and os.environ.get("MVAE_CONV_E2_IMPLICIT", "1") == "0":
         return Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True), We2, bias, relu=True)
     return _conv_nhwc(a1, We2, bias, None, B, 128, 8, True)
 
@@ -527,16 +527,23 @@ class ConvEngine:
         if planes:
             c["b1_p"] = _new_planes(R * 64, 256, self.device)
         c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True, FORWARD, c.get("b1_p"))   # [R*64, 256]
-        # (d2 and the backward-data of e2 keep the product + col2im form: measured 95 / 80 us against 98 / 96 us implicit,
-        #  tools/bench_conv_gather.py; d1 and the backward-data of e1 gain 11 / 10 us each)
-        c["b2"] = _col2im(_gemm_nn(c["b1"], c["Wd2"]), PV["d2.bias"], None, R, 64, 16, _nhwc(16, 64), True,
-                          (R * 256, 64), True)
+        c["b2"] = self._d2_forward(c["b1"], c["Wd2"], PV["d2.bias"], R)
         if self.direct:
             c["logits"] = _convT_to3(c["b2"], PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
         else:
             c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
             c["logits"] = _col2im(c["cT3"], PV["d3.bias"], None, R, 3, 32, _nchw(32, 3), False, (R, 3072))
         return c
+
+    @staticmethod
+    def _d2_forward(b1: Tensor, Wd2: Tensor, bias: Tensor, R: int) -> Tensor:
+        """ConvTranspose2d(256 -> 64) + ReLU (conv_vae.py:53,73): [R * 64, 256] -> [R * 256, 64].  Four implicit contractions,
+        one per output parity class (no [R * 64, 1024] product, no col2im): 0.86 -> 0.84 ms per step once the ping-pong
+        kernel took the gathers; MVAE_CONV_D2_IMPLICIT=0: product + col2im (rounding differs: that form adds the four taps of a
+        pixel after the contraction)."""
+        if os.environ.get("MVAE_CONV_D2_IMPLICIT", "1") != "0":
+            return _convT_nhwc(b1, Wd2, bias, None, R, 256, 8, 64, True)
+        return _col2im(_gemm_nn(b1, Wd2), bias, None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64), True)
 
     def _heads_channel_last(self):
         """(W_heads with its 8192 columns re-ordered from the reference's (c, y, x) to channel-last (y, x, c), b_heads)."""
@@ -564,8 +571,7 @@ class ConvEngine:
         d0o = Fn.linear_forward(zz, PV["d0.weight"], PV["d0.bias"], relu=True)
         t0 = _permute_rc(d0o, R, 128, 16).view(R * 16, 128)
         b1 = _convT_nhwc(t0, self.flat.matrix(self.params, "d1"), PV["d1.bias"], None, R, 128, 4, 256, True)
-        b2 = _col2im(_gemm_nn(b1, self.flat.matrix(self.params, "d2")), PV["d2.bias"], None, R, 64, 16,
-                     _nhwc(16, 64), True, (R * 256, 64), True)
+        b2 = self._d2_forward(b1, self.flat.matrix(self.params, "d2"), PV["d2.bias"], R)
         if self.direct:
             lo = _convT_to3(b2, PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
         else:

@@ -426,6 +426,9 @@ extern "C" int mvae_permute_rc(const float* in, float* out, int64_t B, int R, in
 //      [C_in, (ky, kx, oc)], and whose rows are scattered to the class's pixels by the epilogue.
 // A K step of 32 lies inside one tap (C % 32 == 0), so the tap of a step is uniform and a lane moves 16 contiguous bytes.
 // (struct ConvGeom: mvae_p3.hpp)
+bool f32pp_try(int form, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, bf16r* Cp,
+               long long psc, const float* bias, const float* mask, int relu, int M, int N, int K, ConvGeom cg,
+               hipStream_t s);  // mvae_f32pp.hip
 template <int BM, int BN, int BK, int NW, bool A_KC, bool B_KC, int GATHER = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm_tiled(const float* __restrict__ A, int64_t sai, int64_t sak,
                                                     const float* __restrict__ Bm, int64_t sbk, int64_t sbj,
@@ -978,6 +981,13 @@ static void launch_gemm_tiled(const float* A, int64_t sai, int64_t sak, const fl
                               int K, int slices, int k_per_slice, int64_t slice_stride, hipStream_t s, bool split,
                               ConvGeom cg = ConvGeom{0, 0, 0, 0, 0}, bf16r* Cp = nullptr, int64_t psc = 0) {
   if (Cp) split = false;  // planes come out of the f32-MFMA kernels' epilogue only (forward results, the small layers)
+  // exact f32 products, whole tiles, no K slices: the ping-pong LDS-DMA kernel (mvae_f32pp.hip; bit-identical to k_gemm_tiled)
+  if constexpr (A_KC && (GATHER == 0 || GATHER == 1 || GATHER == 3) && !(B_KC && GATHER == 3)) {
+    if (!split && (slices == 1 || GATHER == 3) && (GATHER != 0 || sak == 1) && (B_KC ? sbk == 1 : sbj == 1)) {
+      const int form = GATHER == 1 ? 1 : (GATHER == 3 ? 3 : (B_KC ? 0 : 2));
+      if (f32pp_try(form, A, sai, Bm, B_KC ? sbj : sbk, C, ldc, Cp, psc, bias, mask, relu, M, N, K, cg, s)) return;
+    }
+  }
   // 128 x 128 tiles need >= ~2 workgroups per CU to hide their own latencies; below that 64 x 64 tiles (4x the
   // workgroups, half the LDS reuse) win on every conv layer shape of the reference
   const int64_t wg128 = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * slices;

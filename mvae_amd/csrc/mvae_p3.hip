@@ -51,6 +51,14 @@ struct P3Args {
 __device__ __attribute__((aligned(16))) unsigned int g_p3_zero[4];
 
 __device__ __forceinline__ int p3_h(int x) { return (0x78 >> (2 * x)) & 3; }  // {0, 2, 3, 1}
+// Chunk swizzle of a contraction-major image ([32 k][rows] bf16, CPR = rows / 16 chunks of 32 bytes per k row): a 32-lane
+// service group of ds_read_b64_tr_b16 touches the k rows {4 t + i} and {8 + 4 t + i}, i = 0..3, of one 16-column block; with
+// x = (k & 7) the two halves met in the same banks (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE on the weight
+// gradients, gpurun_out/prof_p3_dWe2); this x sends the eight rows to eight different (bank-row half, chunk) places.
+__device__ __forceinline__ int p3_km_swz(int kr, int CPR) {
+  const int RPB = 8 / CPR;  // k rows per 256-byte bank row
+  return ((kr / RPB) & (CPR / 2 - 1)) + (CPR / 2) * ((kr >> 3) & 1);
+}
 
 template <int BM, int BN, int WR, int AF, int BF, int NST = 3>
 __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
@@ -89,10 +97,10 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
     *c8 = ((lane & 3) ^ p3_h((lane >> 4) & 3)) * 8;
   };
   auto km_lane = [&](int pc, int rows, int* kr, int* col) __attribute__((always_inline)) {
-    const int CPR = rows / 16, RPB = 8 / CPR;
+    const int CPR = rows / 16;
     const int off = pc * 1024 + lane * 16, inrow = off % (rows * 2);
     *kr = off / (rows * 2);
-    *col = (((inrow >> 5) ^ ((*kr / RPB) & (CPR - 1))) << 4) + ((inrow >> 4) & 1) * 8;
+    *col = (((inrow >> 5) ^ p3_km_swz(*kr, CPR)) << 4) + ((inrow >> 4) & 1) * 8;
   };
   auto a_inv = [&](int pc) __attribute__((always_inline)) -> Inv {
     Inv v{0, 0, 0, 0, 0};
@@ -220,9 +228,9 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   // 16-row block through the XOR swizzle, so one address register per (block, t), kept over the whole K loop
   unsigned kmA[A_IS_KM ? TM : 1][2], kmB[B_IS_KM ? TN : 1][2];
   auto km_lane_off = [&](int rows, int blk16, int t) __attribute__((always_inline)) -> unsigned {
-    const int ROWB = rows * 2, CPR = rows / 16, RPB = 8 / CPR;
+    const int ROWB = rows * 2, CPR = rows / 16;
     const int kr = 4 * (2 * l4 + t) + (l15 >> 2);
-    const int x = (kr / RPB) & (CPR - 1);
+    const int x = p3_km_swz(kr, CPR);
     return lds0 + kr * ROWB + ((blk16 ^ x) << 5) + (l15 & 3) * 8;
   };
   if constexpr (A_IS_KM) {

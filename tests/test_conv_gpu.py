@@ -654,7 +654,11 @@ def test_fused_conv_step_vs_the_generic_step(dev, monkeypatch, B, scalar):
     flips = _relu_flips(cf, cg)
     for (n, a), (_, b) in zip(ef.grad_views().items(), eg.grad_views().items()):
         if flips == 0 or n in ("d3.weight", "d3.bias"):  # (nothing downstream of a ReLU mask in the last layer's gradient)
-            assert_close(_cpu(a), _cpu(b), 2e-5, "grad " + n, atol_frac=2e-5)
+            # The head biases' gradients are column sums of dheads over the batch whose terms cancel (|sum| ~ 0.1 against a sum
+            # of magnitudes of tens): the two paths' per-row values agree to 1e-7 and the sums to that times the condition
+            # number -- a floor of 2e-4 of the tensor's scale for these 2-entry tensors (4.5e-5 observed at B = 48).
+            floor = 2e-4 if (n.endswith("fc_mean.bias") or n.endswith("fc_logvar.bias")) else 2e-5
+            assert_close(_cpu(a), _cpu(b), 2e-5, "grad " + n, atol_frac=floor)
         else:
             assert _rel_l2(_cpu(a), _cpu(b)) < 5e-3, (n, flips, _rel_l2(_cpu(a), _cpu(b)))
     # the arrival counters are re-armed: a second step gives the same statistics again
@@ -998,3 +1002,53 @@ def test_plane_backward_equals_in_kernel_split(dev, monkeypatch, B):
         assert torch.equal(o1[k], o0[k]), k
     for (n, a), (_, b) in zip(e1.grad_views().items(), e0.grad_views().items()):
         assert_close(_cpu(a), _cpu(b), 2e-5, "grad " + n, atol_frac=5e-6)
+
+
+def test_forward_pingpong_is_bit_identical(dev):
+    """csrc/mvae_f32pp.hip: the exact-f32 contractions of whole-tile shapes on the ping-pong LDS-DMA kernel
+    (mvae_set_forward_kernel(1), the default) against the register-staged k_gemm_tiled (0): the same order of MFMA steps per
+    output element, hence the SAME BITS -- plain NT with bias + ReLU (128 x 128 and 128 x 64 tiles), the gathered Conv2d, the NN
+    product, the transposed convolution per parity class with bias, mask and plane output -- and against float64 at the f32 bar."""
+    from mvae_amd import functional as Fn
+    from mvae_amd._lib import load
+    from mvae_amd.conv import _conv_nhwc, _convT_nhwc, _gemm_nn, _new_planes
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)  # noqa: E731
+    prev_mode = load().mvae_set_contraction_mode(0)
+    prev = load().mvae_set_forward_kernel(-1)
+
+    def both(fn):
+        outs = []
+        for k in (1, 0):
+            load().mvae_set_forward_kernel(k)
+            outs.append(fn())
+        return outs
+
+    try:
+        for M, N, K in ((4096, 512, 2048), (32768, 256, 256), (512, 64, 96), (1024, 192, 64)):
+            x, W, b = rnd(M, K), rnd(N, K) * 0.1, rnd(N)
+            y1, y0 = both(lambda: Fn.linear_forward(x, W, b, relu=True))
+            assert torch.equal(y1, y0), ("NT", M, N, K)
+            assert_close(_cpu(y1), _cpu(torch.relu(x.double() @ W.double().t() + b.double())), 2e-5, "NT vs float64", atol_frac=1e-5)
+        B, Cc, IH, OC = 16, 64, 16, 128
+        src, Wt, bias = rnd(B * IH * IH, Cc), rnd(OC, 16 * Cc) * 0.05, rnd(OC)
+        y1, y0 = both(lambda: _conv_nhwc(src, Wt, bias, None, B, Cc, IH, True))
+        assert torch.equal(y1, y0), "gathered conv"
+        x, Wn = rnd(2048, 256), rnd(256, 1024) * 0.1
+        y1, y0 = both(lambda: _gemm_nn(x, Wn))
+        assert torch.equal(y1, y0), "NN"
+        assert_close(_cpu(y1), _cpu(x.double() @ Wn.double()), 2e-5, "NN vs float64", atol_frac=1e-5)
+        for OC2 in (256, 64):
+            Bc, C2, I2 = 16, 128, 4
+            s2, W2, b2 = rnd(Bc * I2 * I2, C2), rnd(C2, 16 * OC2) * 0.05, rnd(OC2)
+            mk = rnd(Bc * 4 * I2 * I2, OC2)
+
+            def run():
+                p = _new_planes(Bc * 4 * I2 * I2, OC2, dev)
+                return _convT_nhwc(s2, W2, b2, mk, Bc, C2, I2, OC2, True, 0, p), p
+            (y1, p1), (y0, p0) = both(run)
+            assert torch.equal(y1, y0) and torch.equal(p1, p0), ("transposed conv", OC2)
+            assert torch.equal(_planes_sum(p1), y1)
+    finally:
+        load().mvae_set_forward_kernel(prev)
+        load().mvae_set_contraction_mode(prev_mode)
