@@ -45,6 +45,7 @@ struct P3Args {
   long long slice_stride;              // floats between the partial results of consecutive K slices (blockIdx.z)
   ConvGeom cg;
   int lCc;                             // log2(cg.Cc)
+  unsigned long long* dbgbuf;          // (-DMV_P3_DBG builds only) phase time stamps of workgroup 0
   int dbg;                             // (-DMV_P3_DBG builds only) bit 0: no DMA waits, 1: no A DMA, 2: no B DMA, 3: no MFMAs, 4: every step loads tile 0, 5: no barriers, 6: no fragment reads
 };
 
@@ -313,6 +314,77 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
       }
     }
   };
+  // The L phase: the fragment reads (LDS-bound: 72 KB per group and phase) and the DMA requests (bound by the CU's address
+  // path) use different units, but a wave issues in order -- written one after the other they took 436 + 448 cycles of a
+  // 1100-cycle phase (tools/p3_phase_times.py) against ~900 for the MFMA phase of the partner group.  So they alternate: one
+  // request, then the reads of one 16-row block, ...; sched_barrier keeps hipcc from re-clustering the reads.
+  // request number d of this wave for the tile at the given offsets: (operand, piece, plane)
+  auto dma1 = [&](int d, int fill_buf, const bool* oka, const long long* offa, const bool* okb, const long long* offb) __attribute__((always_inline)) {
+    if (d < 3 * UA) {
+      const int i = d / 3, q = d % 3, pc = idx + NI * i;
+      if ((PPA % NI == 0 || pc < PPA) && !(dbg & 2)) {
+        const bf16r* plane = g.A + (size_t)q * g.psa;
+        const long long zoff = (long long)((uintptr_t)zero - (uintptr_t)plane) >> 1;
+        __builtin_amdgcn_global_load_lds(plane + (oka[i] ? offa[i] : zoff),
+                                         (__attribute__((address_space(3))) void*)(lds + fill_buf * SB + pc * 1024 + q * PLA), 16, 0, 0);
+      }
+    } else if (d < 3 * (UA + UB)) {
+      const int e = d - 3 * UA, i = e / 3, q = e % 3, pc = idx + NI * i;
+      if ((PPB % NI == 0 || pc < PPB) && !(dbg & 4)) {
+        const bf16r* plane = g.B + (size_t)q * g.psb;
+        const long long zoff = (long long)((uintptr_t)zero - (uintptr_t)plane) >> 1;
+        __builtin_amdgcn_global_load_lds(plane + (okb[i] ? offb[i] : zoff),
+                                         (__attribute__((address_space(3))) void*)(lds + fill_buf * SB + 3 * PLA + pc * 1024 + q * PLB), 16, 0, 0);
+      }
+    }
+  };
+  auto load_and_issue = [&](Frags& f, auto bufc, int fill_buf, int k0) __attribute__((always_inline)) {
+    constexpr int BUFOFF = decltype(bufc)::value * SB;
+    // addresses of this wave's pieces first (VALU only)
+    bool oka[UA], okb[UB];
+    long long offa[UA], offb[UB];
+#pragma unroll
+    for (int i = 0; i < UA; ++i) offa[i] = a_off(inva[i], k0, &oka[i]);
+#pragma unroll
+    for (int i = 0; i < UB; ++i) offb[i] = b_off(invb[i], k0, &okb[i]);
+    constexpr int ND = 3 * (UA + UB), NPART = TM + TN;
+    constexpr int PER = (ND + NPART - 1) / NPART;  // requests in front of each block's reads
+    int d = 0;
+#pragma unroll
+    for (int part = 0; part < NPART; ++part) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (d < ND) dma1(d++, fill_buf, oka, offa, okb, offb);
+      if (!(dbg & 64)) {
+        if (part < TM) {
+          const int a = part;
+          if constexpr (!A_IS_KM) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              f.a[a][q] = *reinterpret_cast<const p3_bf16x8*>(lds + BUFOFF + q * PLA + ((wm >> 4) + a) * 1024 + kc_lane_off);
+          } else {
+            const unsigned a0 = kmA[a][0] + BUFOFF, a1 = kmA[a][1] + BUFOFF;
+            f.a[a][0] = km_pair(a0, a1, std::integral_constant<int, 0>{});
+            f.a[a][1] = km_pair(a0, a1, std::integral_constant<int, PLA>{});
+            f.a[a][2] = km_pair(a0, a1, std::integral_constant<int, 2 * PLA>{});
+          }
+        } else {
+          const int b = part - TM;
+          if constexpr (!B_IS_KM) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              f.b[b][q] = *reinterpret_cast<const p3_bf16x8*>(lds + BUFOFF + 3 * PLA + q * PLB + ((wn >> 4) + b) * 1024 + kc_lane_off);
+          } else {
+            const unsigned b0 = kmB[b][0] + BUFOFF, b1 = kmB[b][1] + BUFOFF;
+            f.b[b][0] = km_pair(b0, b1, std::integral_constant<int, 0>{});
+            f.b[b][1] = km_pair(b0, b1, std::integral_constant<int, PLB>{});
+            f.b[b][2] = km_pair(b0, b1, std::integral_constant<int, 2 * PLB>{});
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto mma = [&](const Frags& f) __attribute__((always_inline)) {
     // piece pairs from the smallest products up; operands swapped (B fragment first) so that a lane's four accumulator
     // values are four consecutive columns of one output row
@@ -358,17 +430,39 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   wait_dma(true);
   barrier();
   if (grp == 1) barrier();  // group 1 starts one phase late
+#ifdef MV_P3_DBG
+  // time stamps (s_memtime) of the phases of step 8 in waves 0 and 4 of workgroup (0, 0, 0): tools/p3_phase_times.py
+#define MV_P3_STAMP(i) do { if (stamp) ts[i] = __builtin_readcyclecounter(); } while (0)
+  unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define MV_P3_STAMP(i) do {} while (0)
+#endif
   auto step = [&](int t, auto buf, auto buf_fill) __attribute__((always_inline)) {
+#ifdef MV_P3_DBG
+    const bool stamp = g.dbgbuf && t == 8 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && (wave & 3) == 0;
+#endif
     // L: fragments of tile t, requests of tile t + 2
-    if (!(dbg & 64)) load(f, buf);
-    issue(decltype(buf_fill)::value, tile_k(t + 2));
+    MV_P3_STAMP(0);
+    load_and_issue(f, buf, decltype(buf_fill)::value, tile_k(t + 2));
+    MV_P3_STAMP(1);
+    MV_P3_STAMP(2);
     if (grp == 1) wait_dma(false);
+    MV_P3_STAMP(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MV_P3_STAMP(4);
     barrier();
+    MV_P3_STAMP(5);
     // C
     mma(f);
+    MV_P3_STAMP(6);
     if (grp == 0) wait_dma(false);
+    MV_P3_STAMP(7);
     barrier();
+    MV_P3_STAMP(8);
+#ifdef MV_P3_DBG
+    if (stamp && lane == 0)
+      for (int i = 0; i < 9; ++i) g.dbgbuf[grp * 16 + i] = ts[i];
+#endif
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -455,6 +549,13 @@ static int ilog2_exact(int v) {
 }
 static bool planes_ok(const void* p, long long ld, long long ps) { return p && ((uintptr_t)p & 15) == 0 && (ld & 7) == 0 && (ps & 7) == 0; }
 
+#ifdef MV_P3_DBG
+static unsigned long long* g_p3_dbgbuf = nullptr;
+extern "C" int mvae_p3_debug_stamps(unsigned long long* out32) {  // (debug builds) the stamps of the last launch
+  if (!g_p3_dbgbuf) return -1;
+  return (int)hipMemcpy(out32, g_p3_dbgbuf, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif
 #ifndef MV_P3_STAGES
 #define MV_P3_STAGES 3
 #endif
@@ -464,6 +565,10 @@ static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
 #ifdef MV_P3_DBG
   const char* e = getenv("MV_P3_DBG");
   a.dbg = e ? atoi(e) : 0;
+  static unsigned long long* dbuf = nullptr;
+  if (!dbuf) { (void)hipMalloc(&dbuf, 32 * sizeof(unsigned long long)); (void)hipMemset(dbuf, 0, 32 * sizeof(unsigned long long)); }
+  a.dbgbuf = dbuf;
+  g_p3_dbgbuf = dbuf;
 #endif
   dim3 grid(a.N / BN, a.M / BM, zdim);
   hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES>), grid, dim3(512), 0, s, a);
