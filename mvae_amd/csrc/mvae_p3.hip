@@ -697,7 +697,8 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, in
   a.B = Wt_planes; a.ldb = (long long)16 * OC; a.psb = w_ps;
   a.C = y; a.ldc = OC; a.Cp = y_planes; a.psc = y_ps; a.mask = mask;
   a.M = (int)M; a.N = OC; a.K = K; a.k_per_slice = K; a.slice_stride = 0;
-  if (OC % 128 == 0) launch_p3<128, 128, 2, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
+  // 128 x 128 tiles only where they still give every CU a workgroup
+  if (OC % 128 == 0 && (M / 128) * (OC / 128) * 4 >= 256) launch_p3<128, 128, 2, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
   else launch_p3<128, 64, 4, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
   LAUNCH_CHECK("plane transposed conv launch");
   return 0;
