@@ -22,6 +22,9 @@
 #include "mvae_common.hpp"
 #include "mvae_p3.hpp"
 
+#ifndef MV_F32PP_PRIO
+#define MV_F32PP_PRIO 1  // s_setprio(1) around the MFMA phase
+#endif
 enum { FA_KC = 0, FA_G1 = 1, FA_G3 = 2 };
 enum { FB_KC = 0, FB_KM = 1, FB_G3W = 3 };
 
@@ -247,7 +250,13 @@ __global__ __launch_bounds__(512) void k_gemm_f32pp(const F32Args g) {
     if (grp == 1) wait_dma(false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
+#if MV_F32PP_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     mma(f);                                           // C
+#if MV_F32PP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (grp == 0) wait_dma(false);
     barrier();
   };

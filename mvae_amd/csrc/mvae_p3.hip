@@ -32,6 +32,9 @@ typedef __bf16 p3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short p3_s16x4 __attribute__((ext_vector_type(4)));
 typedef short p3_s16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MV_P3_PRIO
+#define MV_P3_PRIO 1  // s_setprio(1) around the MFMA phase (A/B: tools/build_variant.py noprio -DMV_P3_PRIO=0)
+#endif
 enum { A_KC = 0, A_G1 = 1, A_G3 = 2, A_KM = 3 };
 enum { B_KC = 0, B_KM = 1, B_G2 = 2, B_G3W = 3 };
 
@@ -452,8 +455,14 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
     MV_P3_STAMP(4);
     barrier();
     MV_P3_STAMP(5);
-    // C
+    // C (MV_P3_PRIO: with priority over the partner wave's load phase on this SIMD)
+#if MV_P3_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     mma(f);
+#if MV_P3_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     MV_P3_STAMP(6);
     if (grp == 0) wait_dma(false);
     MV_P3_STAMP(7);
