@@ -39,6 +39,7 @@ struct F32Args {
   int M, N, K;
   ConvGeom cg;
   int lCc;
+  int gx;  // XCD-aware tile order: the 8 XCDs as gx column groups x 8 / gx row groups (0: dispatch order)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_f32pp_zero[4];
@@ -59,7 +60,19 @@ __global__ __launch_bounds__(512) void k_gemm_f32pp(const F32Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order.  Workgroup number L of a launch runs on XCD L % 8 (observed; only speed depends on it) and each XCD has
+  // its own L2.  In dispatch order the column tiles of one row block sit on 8 different XCDs, so every L2 fetches all of A
+  // (e2 forward: 8 x 8.4 MB for 12.6 MB of operands).  With the XCDs arranged as gx column groups x gy = 8 / gx row groups, XCD
+  // (xg, yg) runs the tiles (row block = yg + gy * rl, column tile = xg * cn + cl): A crosses the fabric gx times, the weight gy
+  // times (the host picks the gx that minimises gx |A| + gy |W|).
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if (g.gx > 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, j = lin >> 3;
+    const int gy = 8 / g.gx, cn = gridDim.x / g.gx;
+    tx = (xcd % g.gx) * cn + j % cn;
+    ty = xcd / g.gx + gy * (j / cn);
+  }
+  const int m0 = ty * BM, n0 = tx * BN;
   const int par_y = PARITY ? (int)(blockIdx.z >> 1) : 0, par_x = PARITY ? (int)(blockIdx.z & 1) : 0;
   const ConvGeom cg = g.cg;
   const float* zero = reinterpret_cast<const float*>(g_f32pp_zero);
@@ -318,8 +331,21 @@ static int ilog2_exact(int v) {
   return (1 << l) == v ? l : -1;
 }
 template <int BM, int BN, int WR, int AF, int BF, int KS = 32>
-static void launch_f32pp(const F32Args& a, int zdim, hipStream_t s) {
-  dim3 grid(a.N / BN, a.M / BM, zdim);
+static void launch_f32pp(const F32Args& a0, int zdim, hipStream_t s) {
+  F32Args a = a0;
+  const int nx = a.N / BN, ny = a.M / BM;
+  // gx: fabric bytes ~ gx * |A| + (8 / gx) * |B| with |A| ~ M, |B| ~ N (same K, same element size); whole groups only
+  static const bool xcd_off = getenv("MVAE_F32PP_NO_XCD") != nullptr;
+  a.gx = 0;
+  if (!xcd_off && (nx * ny) % 8 == 0) {
+    double best = 0;
+    for (int gx = 1; gx <= 8; gx *= 2) {
+      if (nx % gx || ny % (8 / gx)) continue;
+      const double cost = (double)gx * a.M * (AF == FA_KC ? 1.0 : 0.25) + (8.0 / gx) * a.N;  // (a gathered image is K / 4 wide)
+      if (a.gx == 0 || cost < best) { a.gx = gx; best = cost; }
+    }
+  }
+  dim3 grid(nx, ny, zdim);
   hipLaunchKernelGGL((k_gemm_f32pp<BM, BN, WR, AF, BF, KS>), grid, dim3(512), 0, s, a);
 }
 bool f32pp_try(int form, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, bf16r* Cp,

@@ -1,5 +1,5 @@
 """Dev tool: ONE backward contraction of the conv step at B = 256 on pre-split planes, repeated (for rocprofv3 --pmc runs):
-   python tools/p3_one.py db1|dt0|da1|da0|dWd2|dWd1|dWe2|dWe1 [b3]     (b3: the in-kernel-split kernel instead)"""
+   python tools/p3_one.py e1f|e2f|d1f|d2f|db1|dt0|da1|da0|dWd2|dWd1|dWe2|dWe1 [b3]     (b3: the in-kernel-split kernel instead)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,17 @@ load().mvae_set_contraction_mode(1 if b3 else 2)
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
 P = lambda t: Cv._split_planes([t])[0]  # noqa: E731
-if op in ("db1", "dt0"):
+if op in ("e1f", "e2f"):  # forward Conv2d layers on the exact f32 MFMA (implicit contraction)
+    load().mvae_set_contraction_mode(2)
+    Cc, IH, OC = (64, 16, 128) if op == "e1f" else (128, 8, 512)
+    src, Wt, bias = rnd(B * IH * IH, Cc), rnd(OC, 16 * Cc) * 0.05, rnd(OC)
+    fn = lambda: Cv._conv_nhwc(src, Wt, bias, None, B, Cc, IH, True)  # noqa: E731
+elif op in ("d1f", "d2f"):  # forward ConvTranspose2d layers (four parity classes)
+    load().mvae_set_contraction_mode(2)
+    Cc, IH, OC = (128, 4, 256) if op == "d1f" else (256, 8, 64)
+    src, Wt, bias = rnd(B * IH * IH, Cc), rnd(Cc, 16 * OC) * 0.05, rnd(OC)
+    fn = lambda: Cv._convT_nhwc(src, Wt, bias, None, B, Cc, IH, OC, True)  # noqa: E731
+elif op in ("db1", "dt0"):
     Cc, IH, OC, masked = (64, 16, 256, True) if op == "db1" else (256, 8, 128, False)
     src, Wt = rnd(B * IH * IH, Cc), rnd(OC, 16 * Cc) * 0.05
     mask = rnd(B * (IH // 2) ** 2, OC) if masked else None
