@@ -412,9 +412,11 @@ int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const
  * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180.
  * radius_trainable[i]: 0 fixed, 1 trainable radius, 3 trainable universal curvature -- the entries marked 3 form the
  * clip_grad_norm_(max_norm=1) group of vae.py:161-163 and are clipped IN PLACE in `grads` before the SGD step. */
+/* advance_cursor != 0: the launch also advances counters[8], the batch cursor of mvae_prepare_batch (the conv step, whose
+ * first launch does not do it the way the fused MLP step's does). */
 int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* adam_v, int64_t n_params,
                              int32_t* counters, int ncomp, const uint8_t* radius_trainable, double lr,
-                             double curvature_lr, int do_curvature_step, void* stream);
+                             double curvature_lr, int do_curvature_step, int advance_cursor, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Importance-sampled log-likelihood pieces.  ModelVAE.log_likelihood, vae.py:82-123 ("next" row f-1 of the scope table).
@@ -509,8 +511,9 @@ int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta,
 /* Device-side input pipeline (scope row f-2; reference: DataLoader workers + ImageDynamicBinarization,
  * mt/data/image_reconstruction.py:44-53,70-74, and the Normal.rsample draw inside the step).  Gathers batch number
  * (counters[8] % batches_per_epoch) of `images` (uint8 [n_images, D], HBM-resident) through `perm` (device int32
- * permutation, may be NULL = identity), writes x[B, D] = (pixel/255 > U(0,1)) (train != 0) or (pixel/255 > 0.5), and
- * eps[B, E] ~ N(0,1); both from Philox4x32-10 keyed by (seed, counters[8]).  counters = mvae_model_desc.step_count;
+ * permutation, may be NULL = identity), writes x[B, D] = (pixel/255 > U(0,1)) (train == 1: ImageDynamicBinarization),
+ * (pixel/255 > 0.5) (train == 0) or pixel/255 itself (train == 2: the CIFAR pipeline, ToTensor only,
+ * image_reconstruction.py:123-127), and eps[B, E] ~ N(0,1); both from Philox4x32-10 keyed by (seed, counters[8]).  counters = mvae_model_desc.step_count;
  * its entry 8 (the batch cursor) is advanced by the first launch of every step, so [prepare, step] pairs can be
  * captured into a HIP graph and replayed for a whole epoch without host work. */
 int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E, uint64_t seed,

@@ -109,7 +109,7 @@ PROTOTYPES = {
     "mvae_conv_latent_backward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _L, _P]),
     "mvae_optimizer_step_flat": (C.c_int, [_P, _P, _P, _P, _L, _P, _I, C.POINTER(C.c_uint8), C.c_double, C.c_double,
-                                           _I, _P]),
+                                           _I, _I, _P]),
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "mvae_loglik_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),

@@ -386,6 +386,7 @@ class ConvEngine:
         self.counters = z(32, torch.int32)
         self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
         self._arrive = z(32, torch.int32)  # arrival counters of mvae_conv_bce_stats (0 between launches)
+        self.generation = 0  # bumped by set_lr: graph caches are keyed on it (like StepEngine's)
         # Switches (environment, read once per engine; DESIGN section 4, conv architecture):
         # MVAE_CONV_FUSED (default 1): the loss end as one launch (mvae_conv_bce_stats), the last transposed convolution
         #   direct (mvae_convt_to3_k4s2p1_forward) and -- where the model's shapes fit, mvae_conv_latent_supported -- the
@@ -435,6 +436,7 @@ class ConvEngine:
         self.lr = float(lr)
         if curvature_lr is not None:
             self.curvature_lr = float(curvature_lr)
+        self.generation += 1  # captured graphs carry the learning rates in their kernel arguments (runner.EpochRunner)
 
     def _w(self, name: str) -> Tensor:
         return self.param_views()[name]
@@ -782,7 +784,7 @@ class ConvEngine:
         check(load().mvae_optimizer_step_flat(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
                                               self.flat.n_params, ptr(self.counters), self.layout.n,
                                               self._trainable_arr, self.lr, self.curvature_lr,
-                                              1 if do_curvature_step else 0, stream_ptr(self.device)))
+                                              1 if do_curvature_step else 0, 1, stream_ptr(self.device)))
 
     def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
         self.forward_backward(x, eps, beta)

@@ -2173,9 +2173,12 @@ __global__ __launch_bounds__(256) void k_prepare_batch(const unsigned char* imag
         if (e < B * D) {
           const int b = e / D, j = e - b * D;
           const int src = perm ? perm[(size_t)bi * B + b] : (bi * B + b);
-          const float pix = (float)images[(size_t)(src < n_images ? src : n_images - 1) * D + j] / 255.0f;
+          // ToTensor's x / 255 as the correctly rounded float32 quotient: through double (the build's -freciprocal-math may turn a
+          // float division into x * (1 / 255), one ulp off for some pixel values; the double product's error is 2^-29 of a float
+          // ulp and no pixel value lies that close to a rounding boundary -- tests/test_input_pipeline_gpu.py checks all 256)
+          const float pix = (float)((double)images[(size_t)(src < n_images ? src : n_images - 1) * D + j] * (1.0 / 255.0));
           const float u = (float)(r[t] >> 8) * (1.0f / 16777216.0f);  // [0,1)
-          x[e] = (train ? (pix > u) : (pix > 0.5f)) ? 1.0f : 0.0f;
+          x[e] = train == 2 ? pix : ((train ? (pix > u) : (pix > 0.5f)) ? 1.0f : 0.0f);
         }
       }
     } else {

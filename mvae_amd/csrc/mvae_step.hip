@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
       gv *= clip_coef(t, gsh);
       g[tid] = gv;
     }
-    if (do_curv) p[tid] = p[tid] + (float)(-curv_lr) * gv;  // SGD: param.add_(grad, alpha=-lr)
+    if (do_curv & 1) p[tid] = p[tid] + (float)(-curv_lr) * gv;  // SGD: param.add_(grad, alpha=-lr)
   }
   // The last workgroup to arrive advances the step counter.  Every other workgroup consumed counters[0] before its
   // own arrival (the value fed the __syncthreads above), so no fence is needed: the plain stores below only have to
@@ -1806,6 +1806,7 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
       if (atomicAdd(&counters[1], 1) == ngroups - 1) {
         counters[1] = 0;
         counters[0] = counters[0] + 1;
+        if (do_curv & 2) counters[8] = counters[8] + 1;  // (engines whose first launch does not: the conv step) batch cursor
       }
     }
   }
@@ -2064,7 +2065,7 @@ extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* str
   const int n4 = d.n_params / 4;
   const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
-                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, PeerSrc{});
+                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, PeerSrc{});
   LAUNCH_CHECK("optimizer launch");
   return 0;
 }
@@ -2085,7 +2086,7 @@ extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_cur
   const int n4 = d.n_params / 4;
   const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
-                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step, ps);
+                     d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, ps);
   LAUNCH_CHECK("peer optimizer launch");
   return 0;
 }
@@ -2133,7 +2134,7 @@ extern "C" int mvae_step_profile(mvae_ctx* c, const float* x, const float* eps, 
 extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* adam_v,
                                         int64_t n_params, int32_t* counters, int ncomp,
                                         const uint8_t* radius_trainable, double lr, double curvature_lr,
-                                        int do_curvature_step, void* stream) {
+                                        int do_curvature_step, int advance_cursor, void* stream) {
   if (!params || !grads || !adam_m || !adam_v || !counters || n_params < kRadiiRegion || (n_params & 3) ||
       ncomp < 0 || ncomp > kMaxComp)
     return fail(MVAE_E_BADARG, "null pointer / bad size%s", "");
@@ -2144,7 +2145,7 @@ extern "C" int mvae_optimizer_step_flat(float* params, float* grads, float* adam
   const int n4 = (int)(n_params / 4);
   const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, params, grads, adam_m, adam_v,
-                     n4, counters, lr, curvature_lr, do_curvature_step, PeerSrc{});
+                     n4, counters, lr, curvature_lr, (do_curvature_step ? 1 : 0) | (advance_cursor ? 2 : 0), PeerSrc{});
   LAUNCH_CHECK("flat optimizer launch");
   return 0;
 }

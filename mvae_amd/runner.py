@@ -163,8 +163,10 @@ class EpochRunner:
     Replaces the reference's DataLoader worker processes + per-step H2D copy + torch RNG draw
     (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
 
-    def __init__(self, eng: StepEngine, images: Tensor, batch: int, seed: int = 0, graph_steps: int = 32,
-                 shuffle: bool = True, dp: Optional[DataParallelStep] = None):
+    def __init__(self, eng, images: Tensor, batch: int, seed: int = 0, graph_steps: int = 32,
+                 shuffle: bool = True, dp: Optional[DataParallelStep] = None, binarize: bool = True):
+        """eng: a StepEngine (MLP) or a ConvEngine (conv architecture).  binarize: ImageDynamicBinarization (MNIST,
+        image_reconstruction.py:44-53) or, False, pixel / 255 as it is (CIFAR: ToTensor only, image_reconstruction.py:123-127)."""
         import ctypes as C
 
         from ._lib import check, load, ptr, stream_ptr
@@ -176,6 +178,7 @@ class EpochRunner:
             raise ValueError("data set smaller than one batch")
         self.E = eng.layout.eps_dim
         self.seed, self.shuffle = int(seed), shuffle
+        self.mode = 1 if binarize else 2  # mvae_prepare_batch's `train` argument
         self.gs = max(1, min(int(graph_steps), self.nb))
         dev = images.device
         self.x = torch.zeros(self.B, self.D, device=dev)
@@ -195,7 +198,8 @@ class EpochRunner:
     def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
         C, check, load, ptr, stream_ptr = self._c
         check(load().mvae_prepare_batch(ptr(self.images), ptr(self.perm), self.N, self.D, self.B, self.E,
-                                        C.c_uint64(self.seed), ptr(self.eng.counters), self.nb, 1 if train else 0,
+                                        C.c_uint64(self.seed), ptr(self.eng.counters), self.nb,
+                                        self.mode if train else (0 if self.mode == 1 else 2),
                                         ptr(self.x), ptr(self.eps), stream_ptr(self.images.device)))
         if self.dp is None:
             self.eng.train_step(self.x, self.eps, beta, do_curv)

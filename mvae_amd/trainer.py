@@ -179,12 +179,15 @@ class Trainer:
         epoch runs as HIP-graph replays of [mvae_prepare_batch, fused step] (runner.EpochRunner) -- no per-step host
         work.  A ragged last batch is fed through the ordinary train_step.  Returns False if the loader does not
         qualify (the caller then iterates it batch by batch)."""
+        from .conv import ConvEngine
         from .data import DeviceLoader
         from .engine import StepEngine
         from .runner import EpochRunner
         eng = self.model.engine
-        if not (isinstance(train_data, DeviceLoader) and train_data.train and train_data.binarize and
-                train_data.images.dtype == torch.uint8 and isinstance(eng, StepEngine) and
+        # MNIST on the MLP engine (dynamic binarisation) or CIFAR on the conv engine (pixel / 255, no binarisation)
+        if not (isinstance(train_data, DeviceLoader) and train_data.train and train_data.images.dtype == torch.uint8 and
+                ((isinstance(eng, StepEngine) and train_data.binarize) or
+                 (isinstance(eng, ConvEngine) and not train_data.binarize)) and
                 train_data.images.shape[0] >= train_data.batch_size):
             return False
         er = getattr(self, "_epoch_runner", None)
@@ -195,14 +198,16 @@ class Trainer:
                 int(train_data._gen.initial_seed())
             dp = getattr(self.model, "_dp", None)
             seed += 0 if dp is None else dp.rank  # every rank binarises / draws eps from its own Philox stream
-            er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed, dp=dp)
+            er = self._epoch_runner = EpochRunner(eng, train_data.images, train_data.batch_size, seed=seed, dp=dp,
+                                                  binarize=train_data.binarize)
         self.model._sync_trainable()
         self.global_step += er.run_epoch(beta, optimizer.curv_condition())
         tail = er.N - er.nb * er.B
         if tail:
             idx = er.perm[er.nb * er.B:].long()
             x = train_data.images[idx].to(torch.float32) / 255.0
-            x = (x > torch.rand(x.shape, device=x.device, generator=train_data._gen)).to(torch.float32)
+            if train_data.binarize:
+                x = (x > torch.rand(x.shape, device=x.device, generator=train_data._gen)).to(torch.float32)
             self.model.train_step(optimizer, x, beta=beta)
             self.global_step += 1
         return True

@@ -114,3 +114,81 @@ def test_split_step_keeps_cursor_and_counter(dev):
         torch.cuda.synchronize()
         assert int(eng.counters[0]) == k + 1 and int(eng.counters[8]) == k + 1
         assert int(eng.counters[1]) == 0 and int(eng.counters[16:].abs().sum()) == 0
+
+
+def test_prepare_batch_without_binarisation(dev):
+    """mvae_prepare_batch(train = 2): the CIFAR pipeline of the reference (ToTensor only, image_reconstruction.py:123-127): the
+    gathered rows as pixel / 255 -- bit-exact against torch's division --, the same eps stream as the binarising mode."""
+    N, D, B, E = 384, 3072, 64, 6
+    g = torch.Generator().manual_seed(1)
+    images = torch.randint(0, 256, (N, D), generator=g, dtype=torch.uint8)
+    images[:, :256] = torch.arange(256, dtype=torch.uint8)  # every pixel value in every row
+    images_d = images.to(dev)
+    perm = torch.randperm(N, generator=g).to(torch.int32).to(dev)
+    counters = torch.zeros(32, dtype=torch.int32, device=dev)
+    for cursor in (0, 2, 7):
+        counters[8] = cursor
+        x, eps = _prepare(images_d, perm, counters, B, E, 5, N // B, 2, dev)
+        rows = perm[(cursor % 6) * B:(cursor % 6 + 1) * B].long().cpu()
+        assert torch.equal(x.cpu(), images[rows].float() / 255.0)
+        _, eps1 = _prepare(images_d, perm, counters, B, E, 5, N // B, 1, dev)
+        assert torch.equal(eps, eps1)
+    # identity permutation (perm = NULL)
+    counters[8] = 1
+    x, _ = _prepare(images_d, None, counters, B, E, 5, N // B, 2, dev)
+    assert torch.equal(x.cpu(), images[B:2 * B].float() / 255.0)
+
+
+def test_conv_epoch_runner_graph_equals_eager(dev):
+    """Scope row f-2 for the conv architecture: whole CIFAR-shaped epochs as HIP-graph replays of [mvae_prepare_batch(train = 2),
+    ConvEngine.train_step] equal the same pairs launched eagerly bit for bit; the optimizer launch advances the batch cursor
+    (counters[8]) and the Adam counter by one per step; the first batch of the epoch is the gather the permutation says."""
+    from mvae_amd import synthetic
+    from mvae_amd.conv import ConvEngine
+    from mvae_amd.runner import EpochRunner
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.randint(0, 256, (400, 3072), generator=g, dtype=torch.uint8).to(dev)
+    results = []
+    for use_graphs in (True, False):
+        eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
+        shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
+        eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
+        er = EpochRunner(eng, imgs, batch=64, seed=9, graph_steps=2, binarize=False)
+        assert er.nb == 6 and er.mode == 2
+        for ep in range(2):
+            assert er.run_epoch(1.0, ep >= 1, use_graphs=use_graphs) == 6
+        torch.cuda.synchronize()
+        st = eng.read_stats()
+        assert st["sum"]["steps"] == 12 and int(eng.counters[0]) == 12 and int(eng.counters[8]) == 12
+        assert np.isfinite(st["last"]["elbo"])
+        # the LAST batch the pipeline prepared = batch 5 of the second epoch's permutation, unbinarised
+        rows = er.perm[5 * 64:6 * 64].long()
+        assert torch.equal(er.x.cpu(), imgs[rows].cpu().float() / 255.0)  # (ATen's device division by a scalar multiplies by 1/255)
+        results.append((eng.params.clone(), st))
+    assert torch.equal(results[0][0], results[1][0])
+    assert results[0][1]["sum"]["elbo"] == results[1][1]["sum"]["elbo"]
+
+
+def test_trainer_takes_the_device_pipeline_for_the_conv_architecture(dev, tmp_path):
+    """Trainer._train_epoch with a CIFAR-shaped uint8 DeviceLoader (no binarisation) and the ConvEngine: the epoch runs through
+    runner.EpochRunner (mode 2: pixel / 255), the ragged last batch through train_step, statistics count every sample."""
+    from mvae_amd import utils
+    from mvae_amd.data import DeviceLoader, VaeDataset
+    from mvae_amd.models import ConvolutionalVAE
+    from mvae_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (150, 3072), generator=g, dtype=torch.uint8).to(dev)
+    y = torch.zeros(150, dtype=torch.int64, device=dev)
+    train = DeviceLoader(x, y, 32, train=True, binarize=False, seed=1)
+    torch.manual_seed(0)
+    m = ConvolutionalVAE(8192, utils.parse_components("h2,s2,e2", False), VaeDataset(32, 3072, (3, 32, 32)), False).to(dev)
+    m.seed_sampler(3)
+    tr = Trainer(m, chkpt_dir=str(tmp_path))
+    opt = tr.build_optimizer(1e-3, fixed_curvature=False)
+    st = tr._train_epoch(opt, train, beta=1.0)
+    er = tr._epoch_runner
+    assert er.mode == 2 and er.nb == 4 and er.eng is m.engine
+    assert tr.global_step == 5  # four full batches through the pipeline + the 22-image tail
+    assert int(m.engine.counters[0]) == 5
+    d = st.to_print()
+    assert all(np.isfinite(v) for v in d.values()) and d["elbo"] < 0
