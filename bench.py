@@ -212,21 +212,24 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
     step_s = dt / steps
     scale = 1 if (strong and world > 1) else world  # units (256-row steps) all ranks processed per step of the job
     flops_step = CONV_FLOPS_B256 * (Bc * world / Bg)
-    # the dominant kernel, timed live with events on the launch stream: the e2 forward contraction
-    # ([B*16, 2048] x [512, 2048]^T, 2.15 GFLOP at B = 256), the largest single launch of the step
-    a = torch.randn(Bc * 16, 2048, device=dev)
-    w = torch.randn(512, 2048, device=dev)
+    # the dominant kernel, timed live with events on the launch stream: the e2 forward contraction as the step launches it
+    # (implicit form: [B*16, 16*128] patches gathered by the LDS-DMA requests of k_gemm_f32pp x [512, 2048]^T + bias + ReLU,
+    # 2.15 GFLOP at B = 256), the largest single launch of the step
+    from mvae_amd import conv as C
+    a1 = torch.randn(Bc * 64, 128, device=dev)   # NHWC activations of e1: [B, 8, 8, 128]
+    w = torch.randn(512, 2048, device=dev) * 0.02  # taps-major weight as the engine holds it
     b = torch.zeros(512, device=dev)
     for _ in range(5):
-        Fn.linear_forward(a, w, b, relu=True)
+        C._conv_e2(a1, w, b, Bc)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        Fn.linear_forward(a, w, b, relu=True)
+        C._conv_e2(a1, w, b, Bc)
     e1.record()
     torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / 20
     k_tf = 2.0 * Bc * 16 * 2048 * 512 / (k_ms * 1e-3) / 1e12
+    traffic, traffic_src = conv_kernel_traffic("e2f") if Bc == 256 else (None, "none: recorded at 256 rows only")
     tf = flops_step / step_s / 1e12 / world  # per GPU
     return {
         "metric": "ELBO-steps/sec (batch 256) CIFAR conv h2,s2,e2",
@@ -249,10 +252,35 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
                               "peak = those flops over the time the matrix pipes need at their dense peaks in this contraction "
                               "mode (f32-input MFMA 157.3 TF for the exact part; bf16 MFMA 2500 TF at six bf16 MACs per f32 "
                               "multiply-add for the split part)",
-                     "kernel": "k_gemm_tiled: e2 forward contraction [4096 x 2048] x [512 x 2048]^T + bias + ReLU",
+                     "kernel": "k_gemm_f32pp (gathered A operand): e2 forward contraction [4096 x 2048] x [512 x 2048]^T + bias "
+                               "+ ReLU, exact f32 MFMA in every contraction mode",
                      "kernel_ms": k_ms, "kernel_achieved_TFLOPs": k_tf, "kernel_mfma_frac": k_tf / F32_MFMA_PEAK_TF,
-                     "traffic": None},
+                     "kernel_algorithmic_bytes": Bc * 64 * 128 * 4 + 512 * 2048 * 4 + Bc * 16 * 512 * 4,
+                     "traffic": traffic, "traffic_source": traffic_src},
     }
+
+
+def conv_kernel_traffic(op):
+    """(bytes per launch, source) of one conv contraction from the newest profiles/r*_conv_pmc_traffic.json recorded from
+    THIS build of the kernels (tools/pmc_conv_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, one op per process;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note); (None, why) when there is none."""
+    import glob
+    from mvae_amd.build import source_hash
+    cur, stale = source_hash(), None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_pmc_traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("source_hash") != cur:
+            stale = stale or os.path.basename(path)
+            continue
+        k = doc.get("kernels", {}).get(op)
+        if k and "traffic_bytes" in k:
+            return int(k["traffic_bytes"]), "profiles/" + os.path.basename(path)
+    return None, (f"none: profiles/{stale} was recorded from another build of the kernels (source_hash mismatch)" if stale
+                  else "none: no profiles/r*_conv_pmc_traffic.json")
+
 
 
 def init_dist(force_dp):

@@ -23,11 +23,15 @@ MFMA="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
 timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- $PMCB > $OUT/pmc_mfma.log 2>&1
 timeout 600 rocprofv3 --pmc $MFMA --kernel-trace --output-format csv -d $OUT/pmc_mfma_conv -o conv -- python $ROOT/tools/bench_conv.py 256 5 > $OUT/pmc_mfma_conv.log 2>&1
 cd $ROOT
+# 4c. the conv contractions one by one: fabric traffic, L2 hit rate, MFMA-busy (-> conv_traffic.json)
+bash $ROOT/tools/pmc_conv_traffic.sh $TAG > $OUT/conv_traffic.log 2>&1
+cd $ROOT
 # 5. the un-profiled bench lines of the same build
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err   # the default invocation: configs [1] + the legs of [0], [3], [4] + CPU rows
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err   # as the driver calls it
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model 6h2,6s2,6e2 > $OUT/bench_prod36.json 2>&1   # learnable curvature, as golden mnist_prod36_learn
 timeout 600 python bench.py --no-cpu-baseline --config conv > $OUT/bench_conv.json 2>&1
+timeout 600 python bench.py --no-cpu-baseline --config conv --gpus 1 --steps 20 --warmup 5 > $OUT/bench_conv_driver.json 2>&1
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --force-dp > $OUT/bench_forced_dp.json 2>&1   # world 1, exchange forced (librccl)
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model h40 --steps 500 --warmup 50 > $OUT/bench_h40.json 2>&1

@@ -44,7 +44,7 @@ for sub, out in (("ktrace/**/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"
     if f:
         shutil.copy(f, os.path.join(dst, out))
         print("copied", out)
-for name in ("bench_line.json", "bench_driver.json", "bench_prod36.json", "bench_e6.json", "bench_conv.json",
+for name in ("bench_line.json", "bench_driver.json", "bench_prod36.json", "bench_e6.json", "bench_conv.json", "bench_conv_driver.json",
              "bench_forced_dp.json", "bench_h40.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
@@ -122,3 +122,47 @@ if mf or mfc:
     with open(os.path.join(dst, f"{tag}_pmc_mfma.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     print("wrote", f"{tag}_pmc_mfma.json")
+
+# the conv contractions, one op per process (tools/pmc_conv_traffic.sh): fabric traffic, L2 hit rate, MFMA-pipe busy fraction
+ct = os.path.join(src, "conv_traffic.json")
+if os.path.exists(ct):
+    raw = json.load(open(ct))
+    SHAPES = {  # op -> (what, algorithmic bytes at B = 256: operands read once + result written once; planes are 6 B per f32)
+        "e2f": ("e2 forward, implicit conv, f32", 256 * 64 * 128 * 4 + 512 * 2048 * 4 + 4096 * 512 * 4),
+        "d2f": ("d2 forward, implicit transposed conv, f32", 4096 * 512 * 4 + 512 * 2048 * 4 + 256 * 64 * 128 * 4),
+        "e1f": ("e1 forward (patch matrix form), f32", 16384 * 1024 * 4 + 128 * 1024 * 4 + 16384 * 128 * 4),
+        "d1f": ("d1 forward product, f32", 16384 * 128 * 4 + 1024 * 128 * 4 + 16384 * 1024 * 4),
+        "db1": ("backward-data of d2 (implicit conv on planes)", 256 * 64 * 128 * 6 + 512 * 2048 * 6 + 4096 * 512 * 10),
+        "da1": ("backward-data of e2 (product on planes)", 4096 * 512 * 6 + 512 * 2048 * 6 + 4096 * 2048 * 4),
+        "dWe2": ("weight gradient of e2 (planes, split over rows)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 512 * 2048 * 4),
+        "dWd2": ("weight gradient of d2 (planes, split over rows)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 512 * 2048 * 4),
+    }
+    kern = {}
+    for op, r in raw.items():
+        f, w = r.get("FETCH_SIZE"), r.get("WRITE_SIZE")
+        hit, miss = r.get("TCC_HIT_sum"), r.get("TCC_MISS_sum")
+        busy, act = r.get("SQ_VALU_MFMA_BUSY_CYCLES"), r.get("GRBM_GUI_ACTIVE")
+        e = {"kernel": r.get("kernel"), "what": SHAPES.get(op, ("", None))[0], "algorithmic_bytes": SHAPES.get(op, ("", None))[1],
+             "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "duration_us_under_pmc": r.get("duration_us_under_pmc")}
+        if f is not None and w is not None:
+            e["traffic_bytes"] = int(round((2.0 * f + w) * 1024))
+            if e["algorithmic_bytes"]:
+                e["traffic_over_algorithmic"] = round(e["traffic_bytes"] / e["algorithmic_bytes"], 2)
+        if hit is not None and miss is not None and hit + miss > 0:
+            e["l2_hit_rate"] = round(hit / (hit + miss), 3)
+        if busy is not None and act:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; busy cycles over the 1024 SIMDs
+            e["mfma_busy_frac"] = round(busy / (act / 8.0 * 1024), 4)
+        kern[op] = e
+    rec = {"source": "tools/pmc_conv_traffic.sh: rocprofv3 --pmc <one group> --kernel-trace, one contraction per process "
+                     "(tools/p3_one.py, B = 256, shapes of the conv step), groups FETCH_SIZE | WRITE_SIZE | TCC_HIT/MISS/"
+                     "EA0_RDREQ/REQ | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CU_CYCLES in separate passes; "
+                     "per-dispatch averages of the contraction kernel only",
+           "correction": "FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE "
+                         "as reported; both are L2<->fabric bytes, Infinity-Cache hits included (upper bound on HBM bytes)",
+           "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): the fraction of SIMD cycles "
+                             "with the matrix pipe busy (f32 MFMA 16x16x4: 32 cycles, bf16 16x16x32: 16 cycles per instruction)",
+           "source_hash": source_hash(), "kernels": kern}
+    with open(os.path.join(dst, f"{tag}_conv_pmc_traffic.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print("wrote", f"{tag}_conv_pmc_traffic.json")
