@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 8
+#define MVAE_ABI_VERSION 9
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -362,24 +362,42 @@ int mvae_p3_supported(int form, int64_t M, int N, int K, int C);
 /* planes[j] (3 x n[j] bf16, plane stride n[j]) of src[j] (n[j] floats, a multiple of 4), up to 12 tensors in ONE launch:
  * the conv weights after the optimizer step, activations whose producer does not write planes. */
 int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream);
-/* mvae_conv_k4s2p1_nhwc (backward-data of a ConvTranspose2d, conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of
- * Wt [OC, 16 C]; y f32, its planes too when y_planes != NULL (not together with a split-K workspace). */
+/* mvae_conv_k4s2p1_nhwc (a Conv2d forward, conv_vae.py:47-50,57-63, or the backward-data of a ConvTranspose2d,
+ * conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of Wt [OC, 16 C]; y = mask(relu(sum + bias)) (bias NULL: none;
+ * relu 0: none; mask NULL: none) in f32, its planes too when y_planes != NULL (not together with a split-K workspace, which
+ * only a call without bias / relu / mask uses). */
 int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
 int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
-                             const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int C, int IH, int IW, int OC,
-                             float* workspace, void* stream);
+                             const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes, int64_t y_ps, int B,
+                             int C, int IH, int IW, int OC, float* workspace, void* stream);
 /* mvae_gemm_nn on the planes of G [M, K] and W [K, N] (the product a Conv2d backward-data folds with mvae_col2im_k4s2p1). */
 int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uint16_t* W_planes, int64_t w_ps, float* out, int64_t M,
                     int K, int N, void* stream);
-/* mvae_conv_transpose_k4s2p1_nhwc (a Conv2d's backward-data, conv_vae.py:47-50,57-63) on the planes of src [B IH IW, C] and of
- * Wt [C, 16 OC]. */
+/* mvae_conv_transpose_k4s2p1_nhwc (a ConvTranspose2d forward, conv_vae.py:52-55,72-74, or a Conv2d's backward-data,
+ * conv_vae.py:47-50,57-63) on the planes of src [B IH IW, C] and of Wt [C, 16 OC]; epilogue as mvae_conv_k4s2p1_nhwc_p3. */
 int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
-                                       const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int C, int IH,
-                                       int IW, int OC, void* stream);
+                                       const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes,
+                                       int64_t y_ps, int B, int C, int IH, int IW, int OC, void* stream);
 /* mvae_conv_k4s2p1_nhwc_wgrad on the planes of dy [B OH OW, OC] and of src [B IH IW, C]. */
 int64_t mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(int B, int C, int IH, int IW, int OC);
 int mvae_conv_k4s2p1_nhwc_wgrad_p3(const uint16_t* dy_planes, int64_t dy_ps, const uint16_t* src_planes, int64_t src_ps,
                                    float* dWt, int B, int C, int IH, int IW, int OC, float* workspace, void* stream);
+/* The 3-channel layers at the image boundary without a patch matrix (csrc/mvae_edge.hip; fixed geometry C = 3, IH = IW = 32,
+ * F = 64, anything else: MVAE_E_UNSUPPORTED and the caller takes mvae_im2col_k4s2p1 + a contraction).
+ * mvae_conv3_k4s2p1_nchw: y[(b,oy,ox), f] = mask(relu(bias[f] + sum_{c,ky,kx} img[b,c,2oy-1+ky,2ox-1+kx] W[f, c*16+ky*4+kx])) --
+ * the forward pass of Conv2d(3, 64, 4, 2, 1) on the NCHW input (conv_vae.py:47,57; bias, relu = 1) and the backward-data of
+ * ConvTranspose2d(64, 3, 4, 2, 1) w.r.t. its channel-last input (conv_vae.py:54,74; img = the gradient of the NCHW logits,
+ * mask = the layer input whose ReLU the gradient passes).  y [B*256, 64] f32, + its bf16 planes when y_planes != NULL.  The
+ * same bits as mvae_im2col_k4s2p1 + mvae_linear_forward(_masked).
+ * mvae_conv3_k4s2p1_nchw_wgrad: dW[f, c*16+ky*4+kx] = sum_{b,oy,ox} act[(b,oy,ox), f] img[b,c,2oy-1+ky,2ox-1+kx] -- the weight
+ * gradient of both layers (act = dL/d(e0 output) and img = x; act = the d3 input and img = the gradient of the logits).
+ * Per-workgroup partial sums in `workspace` (mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats floats), added in index order by
+ * the slice sum (deferrable: mvae_slice_sums_defer). */
+int mvae_conv3_k4s2p1_nchw(const float* img, const float* W, const float* bias, const float* mask, int relu, float* y,
+                           uint16_t* y_planes, int64_t y_ps, int B, int C, int IH, int IW, int F, void* stream);
+int64_t mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(int B, int C, int IH, int IW, int F);
+int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, float* dW, int B, int C, int IH, int IW, int F,
+                                 float* workspace, void* stream);
 /* The loss end of the conv step in one launch: mvae_bce_forward_backward + mvae_batch_stats (vae.py:125-147) + the bias
  * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
  * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first

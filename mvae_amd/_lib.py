@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -95,10 +95,13 @@ PROTOTYPES = {
     "mvae_set_forward_kernel": (C.c_int, [_I]),
     "mvae_p3_supported": (C.c_int, [_I, _L, _I, _I, _I]),
     "mvae_split3_planes": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
+    "mvae_conv3_k4s2p1_nchw": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "mvae_conv3_k4s2p1_nchw_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_conv_k4s2p1_nhwc_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
-    "mvae_conv_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "mvae_conv_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_gemm_nn_p3": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
-    "mvae_conv_transpose_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_wgrad_p3": (C.c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_convt_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

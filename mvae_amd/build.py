@@ -1,6 +1,6 @@
 """Builds libmvae_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
 
-The library is seven translation units (csrc/mvae_api.hip, mvae_step.hip, mvae_conv.hip, mvae_p3.hip, mvae_f32pp.hip, mvae_peer.hip, mvae_rccl.hip) compiled in parallel into
+The library is eight translation units (csrc/mvae_api.hip, mvae_step.hip, mvae_conv.hip, mvae_p3.hip, mvae_f32pp.hip, mvae_edge.hip, mvae_peer.hip, mvae_rccl.hip) compiled in parallel into
 csrc/_obj/*.o and linked; a unit is recompiled only when it or a header is newer than its object.
 
     python -m mvae_amd.build [--force] [--timing]      (--timing: the -DMV_DBG_TIMING build used by tools/phase_timing.py,
@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["mvae_api", "mvae_step", "mvae_conv", "mvae_p3", "mvae_f32pp", "mvae_peer", "mvae_rccl"]
+UNITS = ["mvae_api", "mvae_step", "mvae_conv", "mvae_p3", "mvae_f32pp", "mvae_edge", "mvae_peer", "mvae_rccl"]
 HEADERS = [os.path.join(CSRC, h) for h in ("mvae_common.hpp", "mvae_math.hpp", "mvae_gemm.hpp", "mvae_fastmath.hpp", "mvae_step_blk.hpp", "mvae_coop.hpp", "mvae_p3.hpp")] + \
           [os.path.join(os.path.dirname(HERE), "include", "mvae_hip.h")]
 DEPS = [os.path.join(CSRC, u + ".hip") for u in UNITS] + HEADERS

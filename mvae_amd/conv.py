@@ -139,17 +139,19 @@ def _split_planes(tensors: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = 
 
 
 def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int,
-                  want_planes: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    """_conv_nhwc (backward-data of a ConvTranspose2d) on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] ->
-    (y [B*(IH/2)^2, OC] f32, its planes or None)."""
+                  want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
+                  out_planes: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """_conv_nhwc (a Conv2d forward with bias / relu, or the backward-data of a ConvTranspose2d with mask) on planes: src_p
+    [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] -> (y [B*(IH/2)^2, OC] f32, its planes or None)."""
     OC = Wt_p.shape[1]
     M = B * (IH // 2) * (IH // 2)
     y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
-    nws = int(load().mvae_conv_k4s2p1_nhwc_p3_workspace_floats(B, Cc, IH, IH, OC, 0 if mask is None else 1))
+    epilogue = mask is not None or bias is not None or relu
+    nws = int(load().mvae_conv_k4s2p1_nhwc_p3_workspace_floats(B, Cc, IH, IH, OC, 1 if epilogue else 0))
     ws = y.new_empty(nws) if nws > 0 else None  # split-K slices, added in index order right away (y is an intermediate)
-    yp = _new_planes(M, OC, y.device) if (want_planes and nws == 0) else None
-    check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(y), _pptr(yp), _ps(yp),
-                                          B, Cc, IH, IH, OC, ptr(ws), stream_ptr(y.device)))
+    yp = out_planes if out_planes is not None else (_new_planes(M, OC, y.device) if (want_planes and nws == 0) else None)
+    check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias), 1 if relu else 0,
+                                          ptr(y), _pptr(yp), _ps(yp), B, Cc, IH, IH, OC, ptr(ws), stream_ptr(y.device)))
     return y, yp
 
 
@@ -162,13 +164,16 @@ def _gemm_nn_p3(G_p: Tensor, W_p: Tensor) -> Tensor:
 
 
 def _convT_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, OC: int,
-                   want_planes: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    """_convT_nhwc (a Conv2d's backward-data, four parity classes) on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, Cc, 16 OC]."""
+                   want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
+                   out_planes: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """_convT_nhwc (a ConvTranspose2d forward with bias / relu, or a Conv2d's backward-data with mask; four parity classes)
+    on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, Cc, 16 OC]."""
     M = B * (2 * IH) * (2 * IH)
     y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
-    yp = _new_planes(M, OC, y.device) if want_planes else None
-    check(load().mvae_conv_transpose_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(y), _pptr(yp),
-                                                    _ps(yp), B, Cc, IH, IH, OC, stream_ptr(y.device)))
+    yp = out_planes if out_planes is not None else (_new_planes(M, OC, y.device) if want_planes else None)
+    check(load().mvae_conv_transpose_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias),
+                                                    1 if relu else 0, ptr(y), _pptr(yp), _ps(yp), B, Cc, IH, IH, OC,
+                                                    stream_ptr(y.device)))
     return y, yp
 
 
@@ -259,6 +264,30 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
     nws = load().mvae_gemm_tn_workspace_floats(M, NP, NQ)
     ws = _keep(P.new_empty(int(nws))) if nws > 0 else None
     check(load().mvae_gemm_tn(ptr(P), ptr(Q), ptr(out), M, NP, NQ, ptr(ws), stream_ptr(P.device)))
+    return out
+
+
+def _edge_direct() -> bool:
+    """The 3-channel boundary layers straight from the image (csrc/mvae_edge.hip, the default) or through the patch matrix
+    (MVAE_CONV_EDGE_DIRECT=0: mvae_im2col_k4s2p1 + generic contractions; same bits on the activation side)."""
+    return os.environ.get("MVAE_CONV_EDGE_DIRECT", "1") != "0"
+
+
+def _edge_conv(img: Tensor, W: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], relu: bool, B: int,
+               planes: Optional[Tensor] = None) -> Tensor:
+    """[B*256, 64] = mask(relu(patches(img [B, 3, 32, 32]) W[64, 48]^T + bias)): e0 forward / d3 backward-data, no patch matrix."""
+    y = img.new_empty(B * 256, 64)
+    check(load().mvae_conv3_k4s2p1_nchw(ptr(img), ptr(W), ptr(bias), ptr(mask), 1 if relu else 0, ptr(y), _pptr(planes),
+                                        _ps(planes), B, 3, 32, 32, 64, stream_ptr(img.device)))
+    return y
+
+
+def _edge_wgrad(act: Tensor, img: Tensor, out: Tensor, B: int) -> Tensor:
+    """out[64, 48] = act[B*256, 64]^T patches(img [B, 3, 32, 32]): the weight gradient of e0 / d3, no patch matrix."""
+    assert out.is_contiguous() and out.numel() == 64 * 48
+    nws = int(load().mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(B, 3, 32, 32, 64))
+    ws = _keep(act.new_empty(nws))
+    check(load().mvae_conv3_k4s2p1_nchw_wgrad(ptr(act), ptr(img), ptr(out), B, 3, 32, 32, 64, ptr(ws), stream_ptr(act.device)))
     return out
 
 
@@ -467,18 +496,26 @@ class ConvEngine:
             main.wait_event(ev)
         self._forked = []
 
-    def _use_p3(self, B: int) -> bool:
-        """Whether the backward pass of a B-row step runs on pre-split operands: contraction mode 2 (split products in the
-        backward pass), the switch on, no side streams, and every plane contraction's shape made of whole tiles."""
-        if not self.planes or self.overlap or load().mvae_set_contraction_mode(-1) != 2:
-            return False
+    def _use_p3(self, B: int) -> int:
+        """Which passes of a B-row step run on pre-split operands: 0 none, 2 the backward pass (contraction mode 2), 1 both
+        passes (contraction mode 1: split products everywhere).  Needs the switch on, no side streams, and every plane
+        contraction's shape made of whole tiles."""
+        mode = load().mvae_set_contraction_mode(-1)
+        if not self.planes or self.overlap or mode not in (1, 2):
+            return 0
         sup = load().mvae_p3_supported
-        return bool(sup(0, B * 64, 256, 1024, 64) and sup(0, B * 16, 128, 4096, 256) and sup(1, B * 16, 2048, 512, 0) and
-                    sup(2, B * 64, 64, 512, 128) and sup(3, B * 64, 256, 1024, 64) and sup(3, B * 16, 128, 4096, 256) and
-                    sup(3, B * 16, 512, 2048, 128) and sup(3, B * 64, 128, 1024, 64) and B * 256 >= 512)
+        ok = bool(sup(0, B * 64, 256, 1024, 64) and sup(0, B * 16, 128, 4096, 256) and sup(1, B * 16, 2048, 512, 0) and
+                  sup(2, B * 64, 64, 512, 128) and sup(3, B * 64, 256, 1024, 64) and sup(3, B * 16, 128, 4096, 256) and
+                  sup(3, B * 16, 512, 2048, 128) and sup(3, B * 64, 128, 1024, 64) and B * 256 >= 512)
+        if ok and mode == 1:  # the four forward layers
+            ok = bool(sup(0, B * 64, 128, 1024, 64) and sup(0, B * 16, 512, 2048, 128) and sup(2, B * 16, 256, 512, 128) and
+                      sup(2, B * 64, 64, 1024, 256))
+        return mode if ok else 0
 
     # ---- forward (keeps what backward needs)
-    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True, planes: bool = False):
+    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True, planes: bool = False, planes_forward: bool = False):
+        """planes: write the bf16 planes the backward pass on pre-split operands reads; planes_forward (with planes, fused
+        latent section): the four channel-last layers themselves run on planes (contraction mode 1)."""
         PV = self.param_views()
         lay = self.layout
         B = x.shape[0]
@@ -488,16 +525,27 @@ class ConvEngine:
         # channel-last layers in between run taps-major (coalesced gathers) against permuted weight matrices
         c["We1"], c["We2"] = self.flat.matrix(self.params, "e1"), self.flat.matrix(self.params, "e2")
         c["Wd1"], c["Wd2"] = self.flat.matrix(self.params, "d1"), self.flat.matrix(self.params, "d2")
-        c["col0"] = _im2col(x, None, B, 3, 32, _nchw(32, 3))
+        c["x"] = x
+        c["col0"] = None if _edge_direct() else _im2col(x, None, B, 3, 32, _nchw(32, 3))
         if planes:
             # the backward pass will run on pre-split operands: the epilogues below write the bf16 planes of the activations
             # its weight gradients gather (a0, a1) or contract with (t0, b1) next to the f32 tensors
             c["a0_p"], c["a1_p"] = _new_planes(B * 256, 64, self.device), _new_planes(B * 64, 128, self.device)
+        if c["col0"] is None:
+            c["a0"] = _edge_conv(x, PV["e0.weight"].view(64, 48), PV["e0.bias"], None, True, B, c.get("a0_p"))
+        elif planes:
             c["a0"] = _linear_forward_planes(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], True, c["a0_p"])
         else:
             c["a0"] = Fn.linear_forward(c["col0"], PV["e0.weight"].view(64, 48), PV["e0.bias"], relu=True)
-        c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True, FORWARD, c.get("a1_p"))   # [B*64, 128]
-        c["a2"] = _conv_e2(c["a1"], c["We2"], PV["e2.bias"], B)   # [B*16, 512]
+        planes_forward = planes_forward and planes and self.fused and want_kl and eps.dim() == 2
+        if planes_forward:
+            # planes of the four weight matrices from the CURRENT parameters (one launch; the backward pass reuses them)
+            c["W_p"] = _split_planes([c["We1"], c["We2"], c["Wd1"], c["Wd2"]])
+            c["a1"], _ = _conv_nhwc_p3(c["a0_p"], c["W_p"][0], None, B, 64, 16, bias=PV["e1.bias"], relu=True, out_planes=c["a1_p"])
+            c["a2"], _ = _conv_nhwc_p3(c["a1_p"], c["W_p"][1], None, B, 128, 8, bias=PV["e2.bias"], relu=True)
+        else:
+            c["a1"] = _conv_nhwc(c["a0"], c["We1"], PV["e1.bias"], None, B, 64, 16, True, FORWARD, c.get("a1_p"))   # [B*64, 128]
+            c["a2"] = _conv_e2(c["a1"], c["We2"], PV["e2.bias"], B)   # [B*16, 512]
         # The reference flattens NCHW (conv_vae.py:65: column c * 16 + p of the head matrices); the activation here is
         # channel-last (column p * 512 + c).  Re-ordering the head matrix (NH x 8192: 0.4 MB) instead of the activation
         # and its gradient (8 MB each) gives the same products.
@@ -528,8 +576,14 @@ class ConvEngine:
             c["t0"] = _permute_rc(c["d0o"], R, 128, 16).view(R * 16, 128)  # channel-last rows
         if planes:
             c["b1_p"] = _new_planes(R * 64, 256, self.device)
-        c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True, FORWARD, c.get("b1_p"))   # [R*64, 256]
-        c["b2"] = self._d2_forward(c["b1"], c["Wd2"], PV["d2.bias"], R)
+        if planes_forward:
+            c["t0_p"] = _split_planes([c["t0"]])[0]
+            c["b1"], _ = _convT_nhwc_p3(c["t0_p"], c["W_p"][2], None, R, 128, 4, 256, bias=PV["d1.bias"], relu=True,
+                                        out_planes=c["b1_p"])
+            c["b2"], _ = _convT_nhwc_p3(c["b1_p"], c["W_p"][3], None, R, 256, 8, 64, bias=PV["d2.bias"], relu=True)
+        else:
+            c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True, FORWARD, c.get("b1_p"))   # [R*64, 256]
+            c["b2"] = self._d2_forward(c["b1"], c["Wd2"], PV["d2.bias"], R)
         if self.direct:
             c["logits"] = _convT_to3(c["b2"], PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
         else:
@@ -585,8 +639,9 @@ class ConvEngine:
         x = x.contiguous()
         B = x.shape[0]
         lay = self.layout
-        use_p3 = self._use_p3(B) and eps.dim() == 2
-        c = self._forward(x, eps, planes=use_p3)
+        p3 = self._use_p3(B) if eps.dim() == 2 else 0
+        use_p3 = p3 != 0
+        c = self._forward(x, eps, planes=use_p3, planes_forward=(p3 == 1))
         c["p3"] = use_p3
         bce = x.new_empty(B)
         g = torch.empty_like(c["logits"])
@@ -645,9 +700,13 @@ class ConvEngine:
 
         if not c.get("d3_bias_done"):
             side(1, d3_bias)
-        dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
-        side(0, lambda: _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48)))
-        db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
+        if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
+            side(0, lambda: _edge_wgrad(c["b2"], g, GV["d3.weight"].view(64, 48), B))
+            db2 = _edge_conv(g, PV["d3.weight"].view(64, 48), None, c["b2"], False, B)
+        else:
+            dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
+            side(0, lambda: _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48)))
+            db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
         side(0, lambda: _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16))
         side(1, lambda: _colsum(db2, out=GV["d2.bias"]))
@@ -680,7 +739,10 @@ class ConvEngine:
         side(0, lambda: _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16))
         side(1, lambda: _colsum(da1, out=GV["e1.bias"]))
         da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False, BACKWARD)    # [B*256, 64], ReLU mask of a0
-        side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
+        if c["col0"] is None:
+            side(0, lambda: _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B))
+        else:
+            side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
         _colsum(da0, out=GV["e0.bias"])
         self._join()
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
@@ -715,18 +777,24 @@ class ConvEngine:
         dev = self.device
         # planes of the weights and of the one forward activation whose producer does not write them (t0: the fused latent
         # section), in ONE launch
-        W = [c["We1"], c["We2"], c["Wd1"], c["Wd2"], c["t0"]]
-        We1_p, We2_p, Wd1_p, Wd2_p, t0_p = _split_planes(W)
+        if "W_p" in c:  # (contraction mode 1: the forward pass ran on them already)
+            (We1_p, We2_p, Wd1_p, Wd2_p), t0_p = c["W_p"], c["t0_p"]
+        else:
+            We1_p, We2_p, Wd1_p, Wd2_p, t0_p = _split_planes([c["We1"], c["We2"], c["Wd1"], c["Wd2"], c["t0"]])
         # ---- decoder backward
         if not c.get("d3_bias_done"):
             check(load().mvae_slice_sums_defer(2))
             gpix = _colsum(g.view(B, 3072))
             check(load().mvae_slice_sums_defer(1))
             _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
-        dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
-        _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
         db2_p = _new_planes(B * 256, 64, dev)
-        db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"], planes=db2_p)  # ReLU mask in the epilogue
+        if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
+            _edge_wgrad(c["b2"], g, GV["d3.weight"].view(64, 48), B)
+            db2 = _edge_conv(g, PV["d3.weight"].view(64, 48), None, c["b2"], False, B, db2_p)
+        else:
+            dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
+            _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
+            db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"], planes=db2_p)  # ReLU mask in the epilogue
         _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
         _colsum(db2, out=GV["d2.bias"])
         db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True)  # [B*64, 256], ReLU mask of b1
@@ -752,7 +820,10 @@ class ConvEngine:
         _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
         _colsum(da1, out=GV["e1.bias"])
         da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64)  # [B*256, 64], ReLU mask of a0
-        _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
+        if c["col0"] is None:
+            _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B)
+        else:
+            _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
         _colsum(da0, out=GV["e0.bias"])
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
         _DEFERRED_WS.clear()

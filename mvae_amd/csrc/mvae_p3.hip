@@ -44,6 +44,7 @@ struct P3Args {
   float* C; long long ldc;
   bf16r* Cp; long long psc;            // planes of the result (NULL: none), same ldc
   const float* mask;                   // result zeroed where mask <= 0 (same layout as C), or NULL
+  const float* bias; int relu;         // forward epilogue: + bias[n] (or NULL), then max(., 0) -- before the mask
   int M, N, K, k_per_slice;
   long long slice_stride;              // floats between the partial results of consecutive K slices (blockIdx.z)
   ConvGeom cg;
@@ -498,6 +499,15 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
       const int n = n0 + wn + b * 16 + l4 * 4;
       f32x4 v = acc[a][b];
       const size_t o = (size_t)m * g.ldc + n;
+      if (g.bias) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if (g.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
       if (g.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + o);
 #pragma unroll
@@ -614,7 +624,7 @@ static int p3_conv_slices(int64_t M, int OC, int K, bool has_mask, int* kps) {
 extern "C" int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int Cc, int IH, int IW, int OC, int has_mask) {
   const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
   int kps;
-  const int slices = p3_conv_slices(M, OC, 16 * Cc, has_mask != 0, &kps);
+  const int slices = p3_conv_slices(M, OC, 16 * Cc, has_mask != 0, &kps);  // (has_mask: any epilogue -- mask, bias or ReLU)
   return slices > 1 ? (int64_t)slices * M * OC : 0;
 }
 
@@ -638,8 +648,8 @@ static int p3_geom(ConvGeom* g, int* lCc, int B, int Cc, int IH, int IW, bool ou
 // ConvTranspose2d (conv_vae.py:52-55) as mvae_conv_k4s2p1_nhwc computes it, on the planes of src [B*IH*IW, C] and of Wt
 // [OC, 16 C]; y f32 (+ its planes when y_planes != NULL).
 extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
-                                        const float* mask, float* y, uint16_t* y_planes, int64_t y_ps, int B, int Cc, int IH,
-                                        int IW, int OC, float* workspace, void* stream) {
+                                        const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes,
+                                        int64_t y_ps, int B, int Cc, int IH, int IW, int OC, float* workspace, void* stream) {
   if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
   const int K = 16 * Cc;
@@ -648,10 +658,12 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
   int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, true);
   if (rc) return rc;
   if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, K, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
-      (y_planes && !planes_ok(y_planes, OC, y_ps)))
+      (bias && !aligned16(bias)) || (y_planes && !planes_ok(y_planes, OC, y_ps)))
     return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
+  const bool fwd = bias != nullptr || relu != 0;  // a layer's forward pass: the epilogue needs the whole sum, no K slices
   int kps;
-  const int slices = workspace ? p3_conv_slices(M, OC, K, mask != nullptr, &kps) : 1;
+  const int slices = (workspace && !fwd) ? p3_conv_slices(M, OC, K, mask != nullptr, &kps) : 1;
+  a.bias = bias; a.relu = relu;
   a.A = src_planes; a.lda = Cc; a.psa = src_ps;
   a.B = Wt_planes; a.ldb = K; a.psb = w_ps;
   a.ldc = OC; a.M = (int)M; a.N = OC; a.K = K;
@@ -663,9 +675,11 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
     p3_sum_slices_now(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
   } else {
     a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0;
-    launch_p3<128, 128, 2, A_G1, B_KC>(a, 1, (hipStream_t)stream);
+    // 128 x 64 tiles where 128 x 128 ones would leave CUs without a workgroup (the forward layers: 128 tiles each)
+    if ((M / 128) * (OC / 128) >= 192) launch_p3<128, 128, 2, A_G1, B_KC>(a, 1, (hipStream_t)stream);
+    else launch_p3<128, 64, 4, A_G1, B_KC>(a, 1, (hipStream_t)stream);
   }
-  LAUNCH_CHECK("plane conv backward-data launch");
+  LAUNCH_CHECK("plane conv launch");
   return 0;
 }
 
@@ -690,8 +704,9 @@ extern "C" int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uin
 // The transposed convolution per output parity class (mvae_conv_transpose_k4s2p1_nhwc) on planes: src [B*IH*IW, C], Wt [C, 16 OC]
 // (columns (ky, kx, oc)); y [B * 2IH * 2IW, OC] f32 (+ planes), zeroed where mask <= 0.  A Conv2d's backward-data.
 extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes,
-                                                  int64_t w_ps, const float* mask, float* y, uint16_t* y_planes, int64_t y_ps,
-                                                  int B, int Cc, int IH, int IW, int OC, void* stream) {
+                                                  int64_t w_ps, const float* mask, const float* bias, int relu, float* y,
+                                                  uint16_t* y_planes, int64_t y_ps, int B, int Cc, int IH, int IW, int OC,
+                                                  void* stream) {
   if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const int64_t M = (int64_t)B * IH * IW;
   const int K = 4 * Cc;
@@ -700,11 +715,11 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, in
   int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, false);
   if (rc) return rc;
   if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, 16 * OC, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
-      (y_planes && !planes_ok(y_planes, OC, y_ps)) || 4 * M > 0x7fffffff)
+      (bias && !aligned16(bias)) || (y_planes && !planes_ok(y_planes, OC, y_ps)) || 4 * M > 0x7fffffff)
     return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
   a.A = src_planes; a.lda = Cc; a.psa = src_ps;
   a.B = Wt_planes; a.ldb = (long long)16 * OC; a.psb = w_ps;
-  a.C = y; a.ldc = OC; a.Cp = y_planes; a.psc = y_ps; a.mask = mask;
+  a.C = y; a.ldc = OC; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.bias = bias; a.relu = relu;
   a.M = (int)M; a.N = OC; a.K = K; a.k_per_slice = K; a.slice_stride = 0;
   // 128 x 128 tiles only where they still give every CU a workgroup
   if (OC % 128 == 0 && (M / 128) * (OC / 128) * 4 >= 256) launch_p3<128, 128, 2, A_G3, B_G3W>(a, 4, (hipStream_t)stream);

@@ -907,13 +907,16 @@ def test_planes_are_an_exact_split(dev):
         assert float((p[1].float().abs() > p[0].float().abs() * 2.0 ** -7).sum()) == 0  # |mid| < 2^-7 |hi|
 
 
-@pytest.mark.parametrize("case", ["d2_bwd_data", "d1_bwd_data_splitk", "nn", "convT64", "convT128", "wgrad64", "wgrad128"])
+@pytest.mark.parametrize("case", ["d2_bwd_data", "d1_bwd_data_splitk", "nn", "convT64", "convT128", "wgrad64", "wgrad128",
+                                  "e1_forward", "e2_forward", "d1_forward", "d2_forward"])
 def test_plane_contractions_vs_float64(dev, case):
     """csrc/mvae_p3.hip: every operand form of the plane contractions (LDS-DMA staging, ds_read_b128 / ds_read_b64_tr_b16
     fragments, six bf16 piece products per f32 product) against float64 at the float32 bar of the f32-input-MFMA kernels, on
     shapes of the conv step's backward pass scaled down in batch: gathered backward-data with mask and plane output, its
     split-K form, the NN product, the transposed convolution per parity class (128 x 64 and 128 x 128 tiles, mask, planes),
-    the gathered weight gradients (64 and 128 source channels: a 128-column tile spans two taps / lies inside one)."""
+    the gathered weight gradients (64 and 128 source channels: a 128-column tile spans two taps / lies inside one); the four
+    channel-last layers' FORWARD passes as contraction mode 1 runs them (bias + ReLU epilogue, plane output, 128 x 64 tiles
+    where 128 x 128 ones would be too few)."""
     import torch.nn.functional as F
     from mvae_amd.conv import (_conv_nhwc_p3, _conv_nhwc_wgrad_p3, _convT_nhwc_p3, _gemm_nn_p3, _taps_major)
     gen = torch.Generator().manual_seed(hash(case) % 1000)
@@ -940,6 +943,27 @@ def test_plane_contractions_vs_float64(dev, case):
         close(y, ref, case)
         if case == "d2_bwd_data":
             assert yp is not None and torch.equal(_planes_sum(yp), y), "planes of the result are not its exact split"
+    elif case in ("e1_forward", "e2_forward"):
+        B, Cc, IH, OC = (8, 64, 16, 128) if case == "e1_forward" else (32, 128, 8, 512)
+        x, W, bias = rnd(B, Cc, IH, IH), rnd(OC, Cc, 4, 4) * 0.05, rnd(OC)
+        ref = F.relu(F.conv2d(x.double(), W.double(), bias.double(), stride=2, padding=1)).permute(0, 2, 3, 1).reshape(-1, OC)
+        src = x.permute(0, 2, 3, 1).contiguous().view(B * IH * IH, Cc).to(dev)
+        y, yp = _conv_nhwc_p3(_planes_of(src), _planes_of(_taps_major(W.to(dev), OC, Cc)), None, B, Cc, IH, want_planes=True,
+                              bias=bias.to(dev), relu=True)
+        close(y, ref, case)
+        assert float((y == 0).float().mean()) > 0.3, "the ReLU did nothing"
+        assert yp is not None and torch.equal(_planes_sum(yp), y)
+    elif case in ("d1_forward", "d2_forward"):
+        B, Cc, IH, OC = (16, 128, 4, 256) if case == "d1_forward" else (8, 256, 8, 64)
+        x, Wtr, bias = rnd(B, Cc, IH, IH), rnd(Cc, OC, 4, 4) * 0.05, rnd(OC)
+        ref = F.relu(F.conv_transpose2d(x.double(), Wtr.double(), bias.double(), stride=2, padding=1))
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, OC)
+        src = x.permute(0, 2, 3, 1).contiguous().view(B * IH * IH, Cc).to(dev)
+        y, yp = _convT_nhwc_p3(_planes_of(src), _planes_of(_taps_major(Wtr.to(dev), Cc, OC)), None, B, Cc, IH, OC,
+                               want_planes=True, bias=bias.to(dev), relu=True)
+        close(y, ref, case)
+        assert float((y == 0).float().mean()) > 0.3
+        assert torch.equal(_planes_sum(yp), y)
     elif case == "nn":
         M, K, N = 512, 512, 384
         x, Wn = rnd(M, K), rnd(K, N) * 0.1
@@ -974,6 +998,42 @@ def test_plane_contractions_vs_float64(dev, case):
         close(out, ref, case)
 
 
+@pytest.mark.parametrize("B", [8, 256, 300])
+def test_edge_layers_without_patch_matrix(dev, B):
+    """csrc/mvae_edge.hip against the patch-matrix route it replaces (mvae_im2col_k4s2p1 + a contraction) and float64:
+    the activation side -- e0 forward (bias + ReLU) and d3 backward-data (ReLU mask), with plane output -- runs the same
+    sequence of f32 MFMA steps per output element, hence the SAME BITS; the weight gradients sum their pixels in another order
+    (per-image partial sums, added in index order) and are held to the float32 bar against float64."""
+    import torch.nn.functional as F
+    from mvae_amd import functional as Fn
+    from mvae_amd._lib import load
+    from mvae_amd.conv import (_edge_conv, _edge_wgrad, _im2col, _linear_masked, _nchw, _new_planes)
+    gen = torch.Generator().manual_seed(11 + B)
+    img = torch.rand(B, 3072, generator=gen).to(dev)
+    W = (torch.randn(64, 48, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(64, generator=gen).to(dev)
+    mask = torch.randn(B * 256, 64, generator=gen).to(dev)
+    col = _im2col(img, None, B, 3, 32, _nchw(32, 3))
+    # forward of e0
+    yp = _new_planes(B * 256, 64, dev)
+    y = _edge_conv(img, W, bias, None, True, B, yp)
+    assert_close(_cpu(y), _cpu(Fn.linear_forward(col, W, bias, relu=True)), 2e-6, "e0 forward vs the patch-matrix route", atol_frac=2e-6)
+    assert torch.equal(_planes_sum(yp), y)
+    ref = F.relu(F.conv2d(img.view(B, 3, 32, 32).double().cpu(), W.view(64, 3, 4, 4).double().cpu(), bias.double().cpu(),
+                          stride=2, padding=1)).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert_close(_cpu(y), ref.numpy(), 2e-5, "e0 forward", atol_frac=1e-5)
+    # backward-data of d3 (no bias, mask, no planes)
+    assert_close(_cpu(_edge_conv(img, W, None, mask, False, B)), _cpu(_linear_masked(col, W, mask)), 2e-6,
+                 "d3 backward-data vs the patch-matrix route", atol_frac=2e-6)
+    # weight gradient
+    act = torch.randn(B * 256, 64, generator=gen).to(dev)
+    out = torch.empty(64, 48, device=dev)
+    _edge_wgrad(act, img, out, B)
+    load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
+    refw = act.double().cpu().t() @ col.double().cpu()
+    assert_close(_cpu(out), refw.numpy(), 2e-5, "edge weight gradient", atol_frac=1e-5)
+
+
 @pytest.mark.parametrize("B", [32, 256])
 def test_plane_backward_equals_in_kernel_split(dev, monkeypatch, B):
     """Contraction mode 2 with the backward pass on pre-split operands (MVAE_CONV_PLANES=1, the default: planes written by the
@@ -991,7 +1051,7 @@ def test_plane_backward_equals_in_kernel_split(dev, monkeypatch, B):
         eng = ConvEngine(comps, dev, radius_trainable=[True] * 3)
         shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
         eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
-        assert eng._use_p3(B) == (planes == "1")
+        assert bool(eng._use_p3(B)) == (planes == "1")
         out = eng.forward_backward(x, eps, 1.0, want_outputs=True)
         torch.cuda.synchronize()
         return eng, out
