@@ -414,18 +414,20 @@ int mvae_conv_bce_stats(const float* logits, const float* x, float* bce, float* 
  * (mvae_conv_latent_supported; other models use the generic operators above).  workspace:
  * mvae_conv_latent_workspace_floats(B, ncomp) floats, 16-byte aligned, scratch of one call.  Forward writes heads [B, heads_dim], z [B, z_dim],
  * kl [ncomp, B], t0.  Backward (loss = <dt0, t0> + beta * sum kl) writes dW_heads, db_heads, da2 (already masked by the
- * encoder's last ReLU), dW_d0, db_d0, dradii [ncomp] (0 for Euclidean components; fixed-order sums) and dheads [B, heads_dim]. */
+ * encoder's last ReLU), dW_d0, db_d0, dradii [ncomp] (0 for Euclidean components; fixed-order sums) and dheads [B, heads_dim]. 
+ * t0_planes / da2_planes (NULL: none): the bf16 planes (mvae_split3_planes layout, plane stride *_ps elements) of t0 and da2,
+ * written by the same launches for the plane contractions that consume them. */
 int mvae_conv_latent_supported(const mvae_component_desc* comps, int ncomp);
 int64_t mvae_conv_latent_workspace_floats(int64_t B, int ncomp);
 int mvae_conv_latent_forward(const mvae_component_desc* comps, int ncomp, const float* a2, const float* W_heads,
                              const float* b_heads, const float* eps, int eps_ld, const float* radii, const float* W_d0,
-                             const float* b_d0, float* heads, float* z, float* kl, float* t0, float* workspace,
-                             int64_t B, void* stream);
+                             const float* b_d0, float* heads, float* z, float* kl, float* t0, uint16_t* t0_planes,
+                             int64_t t0_ps, float* workspace, int64_t B, void* stream);
 int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const float* a2, const float* W_heads,
                               const float* heads, const float* eps, int eps_ld, const float* radii, const float* z,
                               const float* W_d0, const float* t0, const float* dt0, float beta, float* dW_heads,
-                              float* db_heads, float* da2, float* dW_d0, float* db_d0, float* dradii, float* dheads,
-                              float* workspace, int64_t B, void* stream);
+                              float* db_heads, float* da2, uint16_t* da2_planes, int64_t da2_ps, float* dW_d0,
+                              float* db_d0, float* dradii, float* dheads, float* workspace, int64_t B, void* stream);
 /* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable
  * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180.
  * radius_trainable[i]: 0 fixed, 1 trainable radius, 3 trainable universal curvature -- the entries marked 3 form the

@@ -555,13 +555,15 @@ class ConvEngine:
             c["heads"] = x.new_empty(B, NH)
             c["z"], c["kl"] = x.new_empty(B, lay.z_dim), x.new_empty(lay.n, B)
             c["t0"] = x.new_empty(B * 16, 128)
+            if planes:
+                c["t0_p"] = _new_planes(B * 16, 128, self.device)  # written by the same launch
             ws = x.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
             eps = eps.contiguous()
             check(load().mvae_conv_latent_forward(lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]),
                                                   ptr(self.params[ob:ob + NH]), ptr(eps), eps.shape[1],
                                                   ptr(self.params[:lay.n]), ptr(PV["d0.weight"]), ptr(PV["d0.bias"]),
-                                                  ptr(c["heads"]), ptr(c["z"]), ptr(c["kl"]), ptr(c["t0"]), ptr(ws), B,
-                                                  stream_ptr(self.device)))
+                                                  ptr(c["heads"]), ptr(c["z"]), ptr(c["kl"]), ptr(c["t0"]), _pptr(c.get("t0_p")),
+                                                  _ps(c.get("t0_p")), ptr(ws), B, stream_ptr(self.device)))
             c["co"], c["fused"] = None, True
             R = B
         else:
@@ -577,7 +579,6 @@ class ConvEngine:
         if planes:
             c["b1_p"] = _new_planes(R * 64, 256, self.device)
         if planes_forward:
-            c["t0_p"] = _split_planes([c["t0"]])[0]
             c["b1"], _ = _convT_nhwc_p3(c["t0_p"], c["W_p"][2], None, R, 128, 4, 256, bias=PV["d1.bias"], relu=True,
                                         out_planes=c["b1_p"])
             c["b2"], _ = _convT_nhwc_p3(c["b1_p"], c["W_p"][3], None, R, 256, 8, 64, bias=PV["d2.bias"], relu=True)
@@ -725,7 +726,7 @@ class ConvEngine:
             check(load().mvae_conv_latent_backward(
                 lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
                 epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
-                float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat),
+                float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), None, 0,
                 ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
                 stream_ptr(self.device)))
         else:
@@ -751,8 +752,9 @@ class ConvEngine:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None
 
-    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side):
-        """Decoder fc backward, the components, the heads' backward: -> dhflat = the gradient of the channel-last a2."""
+    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side, planes=None):
+        """Decoder fc backward, the components, the heads' backward: -> dhflat = the gradient of the channel-last a2 (+ its
+        bf16 planes into `planes` [3, B*16, 512], fused latent section only)."""
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
         if not c.get("fused"):
@@ -764,8 +766,8 @@ class ConvEngine:
         check(load().mvae_conv_latent_backward(
             lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
             epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
-            float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat),
-            ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
+            float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), _pptr(planes),
+            _ps(planes), ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
             stream_ptr(self.device)))
         return dhflat
 
@@ -778,9 +780,10 @@ class ConvEngine:
         # planes of the weights and of the one forward activation whose producer does not write them (t0: the fused latent
         # section), in ONE launch
         if "W_p" in c:  # (contraction mode 1: the forward pass ran on them already)
-            (We1_p, We2_p, Wd1_p, Wd2_p), t0_p = c["W_p"], c["t0_p"]
+            We1_p, We2_p, Wd1_p, Wd2_p = c["W_p"]
         else:
-            We1_p, We2_p, Wd1_p, Wd2_p, t0_p = _split_planes([c["We1"], c["We2"], c["Wd1"], c["Wd2"], c["t0"]])
+            We1_p, We2_p, Wd1_p, Wd2_p = _split_planes([c["We1"], c["We2"], c["Wd1"], c["Wd2"]])
+        t0_p = c["t0_p"] if "t0_p" in c else _split_planes([c["t0"]])[0]
         # ---- decoder backward
         if not c.get("d3_bias_done"):
             check(load().mvae_slice_sums_defer(2))
@@ -802,10 +805,12 @@ class ConvEngine:
         _colsum(db1, out=GV["d1.bias"])
         dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8)  # [B*16, 128]
         # ---- latent section
-        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side)
+        da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None
+        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p)
         # ---- encoder backward
         da2 = dhflat.view(B * 16, 512)
-        da2_p = _split_planes([da2])[0]
+        if da2_p is None:
+            da2_p = _split_planes([da2])[0]
         _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
         if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "0") == "1" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):

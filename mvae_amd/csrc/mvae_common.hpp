@@ -7,6 +7,7 @@
 //   mvae_conv.hip  building blocks of the conv architecture, the LDS-tiled contraction, the device-side input pipeline
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mvae_p3.hpp"
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -659,7 +660,8 @@ __device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L
 constexpr int kSknN = 16;
 template <int NN, bool CL>  // NN = N rounded up to a multiple of 4
 __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, const float* W, const float* dy, float* dW,
-                                                   float* db, float* dx, int M, int N, int K, int relu_in) {
+                                                   float* db, float* dx, int M, int N, int K, int relu_in,
+                                                   unsigned short* dx_planes = nullptr, long long dx_ps = 0) {
   __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
   __shared__ f32x4 sm[32][9];
   const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
@@ -737,6 +739,8 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
           for (int j = 0; j < 4; ++j) dxv[j] = (xv[u][j] > 0.f) ? dxv[j] : 0.f;
         }
         *reinterpret_cast<f32x4*>(dx + (size_t)(m0 + r) * K + col) = dxv;
+        if (dx_planes)  // the bf16 planes of dx for a consumer on pre-split operands (mvae_p3.hpp)
+          store_planes4(dx_planes, dx_ps, (size_t)(m0 + r) * K + col, dxv[0], dxv[1], dxv[2], dxv[3]);
       }
     }
   }

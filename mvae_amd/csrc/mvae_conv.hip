@@ -1786,7 +1786,8 @@ __global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float*
                                                        const float* __restrict__ radii, const float* __restrict__ W_d0,
                                                        const float* __restrict__ b_d0, int Z, float* __restrict__ heads,
                                                        float* __restrict__ z, float* __restrict__ kl,
-                                                       float* __restrict__ t0, int B) {
+                                                       float* __restrict__ t0, bf16r* __restrict__ t0p, long long t0ps,
+                                                       int B) {
   __shared__ float hp[16][17];
   __shared__ float heads_s[16], z_s[16];
   __shared__ float t0_s[kPix * (kDecC + 1)];
@@ -1852,6 +1853,7 @@ __global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float*
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = t0_s[pp * (kDecC + 1) + cc + e];
     *reinterpret_cast<f32x4*>(t0 + (size_t)r * kD0 + idx) = v;
+    if (t0p) store_planes4(t0p, t0ps, (size_t)r * kD0 + idx, v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -1948,7 +1950,8 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
                                                             const float* __restrict__ W_heads,
                                                             const float* __restrict__ dheads, int NH,
                                                             float* __restrict__ dW_heads, float* __restrict__ db_heads,
-                                                            float* __restrict__ da2, const float* __restrict__ dd0,
+                                                            float* __restrict__ da2, bf16r* __restrict__ da2p,
+                                                            long long da2ps, const float* __restrict__ dd0,
                                                             const float* __restrict__ z, int Z,
                                                             float* __restrict__ dW_d0, float* __restrict__ db_d0,
                                                             const float* __restrict__ drad_rows,
@@ -1958,7 +1961,7 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
   const int nshort = kD0 / 32 + 1;
   int blk = blockIdx.x;
   if (blk >= nshort) {
-    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1);
+    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1, da2p, da2ps);
     return;
   }
   const int tid = threadIdx.x;
@@ -2066,7 +2069,8 @@ extern "C" int64_t mvae_conv_latent_workspace_floats(int64_t B, int ncomp) {
 extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int ncomp, const float* a2,
                                         const float* W_heads, const float* b_heads, const float* eps, int eps_ld,
                                         const float* radii, const float* W_d0, const float* b_d0, float* heads, float* z,
-                                        float* kl, float* t0, float* workspace, int64_t B, void* stream) {
+                                        float* kl, float* t0, uint16_t* t0_planes, int64_t t0_ps, float* workspace,
+                                        int64_t B, void* stream) {
   if (!a2 || !W_heads || !b_heads || !eps || !W_d0 || !b_d0 || !heads || !z || !kl || !t0 || !workspace || B < 1 ||
       B > 0x3fffff)
     return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
@@ -2076,6 +2080,7 @@ extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int nc
   if (eps_ld < ed) return fail(MVAE_E_BADARG, "eps_ld smaller than the components' eps columns%s", "");
   if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)workspace) | ((uintptr_t)W_d0)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned a2 / t0 / W_d0 / workspace%s", "");
+  if (t0_planes && ((((uintptr_t)t0_planes) & 7) || (t0_ps & 3))) return fail(MVAE_E_ALIGN, "t0 planes: 8-byte aligned%s", "");
   CompTable t;
   unsigned char all[kMaxComp];
   memset(all, 1, sizeof(all));
@@ -2090,7 +2095,8 @@ extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int nc
   const dim3 gridA(kClSlices, (unsigned)((B + 63) / 64));
   MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_heads_part<NN>), gridA, dim3(256), 0, s, a2, W_heads, workspace, (int)B, NH));
   MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_fwd<DM>), dim3((unsigned)B), dim3(256), 0, s, t, workspace,
-                                             b_heads, NH, eps, eps_ld, radii, W_d0, b_d0, Z, heads, z, kl, t0, (int)B));
+                                             b_heads, NH, eps, eps_ld, radii, W_d0, b_d0, Z, heads, z, kl, t0, t0_planes,
+                                             (long long)t0_ps, (int)B));
   LAUNCH_CHECK("fused conv latent forward launch");
   return 0;
 }
@@ -2099,8 +2105,8 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
                                          const float* W_heads, const float* heads, const float* eps, int eps_ld,
                                          const float* radii, const float* z, const float* W_d0, const float* t0,
                                          const float* dt0, float beta, float* dW_heads, float* db_heads, float* da2,
-                                         float* dW_d0, float* db_d0, float* dradii, float* dheads, float* workspace,
-                                         int64_t B, void* stream) {
+                                         uint16_t* da2_planes, int64_t da2_ps, float* dW_d0, float* db_d0, float* dradii,
+                                         float* dheads, float* workspace, int64_t B, void* stream) {
   if (!a2 || !W_heads || !heads || !eps || !z || !W_d0 || !t0 || !dt0 || !dW_heads || !db_heads || !da2 || !dW_d0 ||
       !db_d0 || !dradii || !dheads || !workspace || B < 1 || B > 0x3fffff)
     return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
@@ -2111,6 +2117,7 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
   if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)dt0) | ((uintptr_t)da2) | ((uintptr_t)workspace) |
         ((uintptr_t)W_d0)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned activations / W_d0 / workspace%s", "");
+  if (da2_planes && ((((uintptr_t)da2_planes) & 7) || (da2_ps & 3))) return fail(MVAE_E_ALIGN, "da2 planes: 8-byte aligned%s", "");
   CompTable t;
   unsigned char tr[kMaxComp];
   memset(tr, 1, sizeof(tr));
@@ -2129,7 +2136,8 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
                                              eps, eps_ld, radii, W_d0, Z, t0, dt0, beta, dd0, dheads, drad_rows, (int)B));
   const unsigned grid = kFlat / 32 + 1 + kD0 / 32 + 1;
   MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_latent_bwd_cols<NN>), dim3(grid), dim3(256), 0, s, t, a2, W_heads, dheads,
-                                         NH, dW_heads, db_heads, da2, dd0, z, Z, dW_d0, db_d0, drad_rows, dradii, (int)B));
+                                         NH, dW_heads, db_heads, da2, da2_planes, (long long)da2_ps, dd0, z, Z, dW_d0, db_d0,
+                                         drad_rows, dradii, (int)B));
   LAUNCH_CHECK("fused conv latent backward launch");
   return 0;
 }

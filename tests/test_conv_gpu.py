@@ -606,15 +606,20 @@ def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
     new = lambda *shape: torch.empty(*shape, device=dev)  # noqa: E731
     ws = new(int(load().mvae_conv_latent_workspace_floats(B, n)))
     heads, z, kl, t0 = new(B, NH), new(B, Z), new(n, B), new(B * 16, 128)
+    t0_p = torch.empty(3, B * 16, 128, dtype=torch.bfloat16, device=dev)
     check(load().mvae_conv_latent_forward(lay.descs, n, ptr(a2), ptr(W), ptr(b), ptr(eps), lay.eps_dim, ptr(radii),
-                                          ptr(Wd), ptr(bd), ptr(heads), ptr(z), ptr(kl), ptr(t0), ptr(ws), B,
-                                          stream_ptr(dev)))
+                                          ptr(Wd), ptr(bd), ptr(heads), ptr(z), ptr(kl), ptr(t0), t0_p.data_ptr(),
+                                          t0_p[0].numel(), ptr(ws), B, stream_ptr(dev)))
+    assert torch.equal(_planes_sum(t0_p), t0), "t0 planes are not the exact split of t0"
     for got, want, nm in [(heads, heads_g, "heads"), (z, co["z"], "z"), (kl, co["kl"], "kl"), (t0, t0_g, "t0")]:
         assert_close(_cpu(got), _cpu(want), 2e-5, nm, atol_frac=2e-5)
     dW, dbh, da2, dWd, dbd, drad, dheads = new(NH, 8192), new(NH), new(B, 8192), new(2048, Z), new(2048), new(n), new(B, NH)
+    da2_p = torch.empty(3, B, 8192, dtype=torch.bfloat16, device=dev)
     check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
                                            ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), beta, ptr(dW), ptr(dbh), ptr(da2),
-                                           ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads), ptr(ws), B, stream_ptr(dev)))
+                                           da2_p.data_ptr(), da2_p[0].numel(), ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads),
+                                           ptr(ws), B, stream_ptr(dev)))
+    assert torch.equal(_planes_sum(da2_p), da2), "da2 planes are not the exact split of da2"
     for got, want, nm in [(dheads, dheads_g, "dheads"), (drad, drad_g, "dradii"), (dW, dW_g, "dW_heads"),
                           (dbh, dbh_g, "db_heads"), (da2, dh_g, "da2"), (dWd, dWd_g, "dW_d0"), (dbd, dbd_g, "db_d0")]:
         assert_close(_cpu(got), _cpu(want), 2e-5, nm, atol_frac=2e-5)

@@ -42,10 +42,14 @@ def test_argument_validation_without_gpu():
     assert lib.mvae_exp_map_mu0(1, 16, 16, 4, 100, 16, None) == -2  # true_dim > MVAE_MAX_TRUE_DIM
     assert lib.mvae_linear_forward(None, None, None, None, 4, 4, 4, 0, None) == -1
     # the conv architecture's fused entry points: NULL pointers, unsupported geometries and shapes
-    assert lib.mvae_conv_latent_forward(None, 1, None, None, None, None, 6, None, None, None, None, None, None, None, None, 4,
-                                        None) == -1
+    assert lib.mvae_conv_latent_forward(None, 1, None, None, None, None, 6, None, None, None, None, None, None, None, None, 0,
+                                        None, 4, None) == -1
     assert lib.mvae_conv_latent_backward(None, 1, None, None, None, None, 6, None, None, None, None, None, 1.0, None, None,
-                                         None, None, None, None, None, None, 4, None) == -1
+                                         None, None, 0, None, None, None, None, None, 4, None) == -1
+    assert lib.mvae_conv3_k4s2p1_nchw(None, None, None, None, 1, None, None, 0, 4, 3, 32, 32, 64, None) == -1
+    assert lib.mvae_conv3_k4s2p1_nchw(16, 16, None, None, 1, 16, None, 0, 4, 3, 64, 64, 64, None) == -2  # 3 x 32 x 32 only
+    assert lib.mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(256, 3, 32, 32, 64) == 256 * 64 * 48
+    assert lib.mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(300, 3, 32, 32, 64) == 150 * 64 * 48
     assert lib.mvae_conv_bce_stats(None, None, None, None, None, None, 1.0, 4, 3072, 1024, 3, None, None, None, None) == -1
     assert lib.mvae_conv_bce_stats(16, 16, 16, 16, 16, 16, 1.0, 4, 3072, 1000, 3, 16, 16, 16, None) == -2  # HW % 1024
     assert lib.mvae_convt_to3_k4s2p1_forward(None, None, None, None, 4, 64, 16, 16, 3, None) == -1

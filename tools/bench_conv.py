@@ -18,9 +18,20 @@ eps = synthetic.eps_batches(4, B, 6).to(dev)
 for i in range(5):
     eng.train_step(xs[i % 4], eps[i % 4], 1.0, True)
 torch.cuda.synchronize()
+graph = None
+if os.environ.get("GRAPH") == "1":  # the timed region as ONE HIP graph (what bench.py times), replayed twice: warm-up + timed
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(steps):
+            eng.train_step(xs[i % 4], eps[i % 4], 1.0, True)
+    graph.replay()
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
-for i in range(steps):
-    eng.train_step(xs[i % 4], eps[i % 4], 1.0, True)
+if graph is not None:
+    graph.replay()
+else:
+    for i in range(steps):
+        eng.train_step(xs[i % 4], eps[i % 4], 1.0, True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 elbo = eng.read_stats()["last"]["elbo"] / B
