@@ -406,6 +406,13 @@ int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, float* dW, 
 int mvae_conv_bce_stats(const float* logits, const float* x, float* bce, float* g, const float* kl, float* stats,
                         float beta, int64_t B, int D, int HW, int ncomp, float* chan_part, float* dbias,
                         int32_t* counter, void* stream);
+/* mvae_convt_to3_k4s2p1_forward + mvae_conv_bce_stats in ONE launch (the training step's loss end: conv_vae.py:54,74, then
+ * vae.py:125-147): the logits of image b = ConvTranspose2d(64, 3, 4, 2, 1)(src [B IH IW, 64] channel-last) + bias on the matrix
+ * cores, written to `logits` [B, 3, 2 IH, 2 IW]; then everything mvae_conv_bce_stats does with them (same arguments, same
+ * counter protocol).  Fixed geometry F = 64, IH = IW = 16, C = 3. */
+int mvae_convt_to3_bce_stats(const float* src, const float* W, const float* bias, const float* x, float* logits, float* bce,
+                             float* g, const float* kl, float* stats, float beta, int64_t B, int F, int IH, int IW, int C,
+                             int ncomp, float* chan_part, float* dbias, int32_t* counter, void* stream);
 /* The latent section of the conv architecture, conv_vae.py:65-71: the encoder's flatten -> fc_mean / fc_logvar of every
  * component (component.py:52-57) -> rsample + KL (component.py:59-78) -> decoder fc + ReLU -> view(-1, 128, 4, 4), in two
  * launches, and its backward in two.  a2 [B, 16, 512] and t0 [B, 16, 128] are the CHANNEL-LAST activations next to the

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "mvae_conv_k4s2p1_nhwc_wgrad_p3": (C.c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_convt_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mvae_conv_bce_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "mvae_convt_to3_bce_stats": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mvae_conv_latent_supported": (C.c_int, [_P, _I]),
     "mvae_conv_latent_workspace_floats": (_L, [_L, _I]),
     "mvae_conv_latent_forward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),

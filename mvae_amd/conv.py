@@ -513,7 +513,8 @@ class ConvEngine:
         return mode if ok else 0
 
     # ---- forward (keeps what backward needs)
-    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True, planes: bool = False, planes_forward: bool = False):
+    def _forward(self, x: Tensor, eps: Tensor, want_kl: bool = True, planes: bool = False, planes_forward: bool = False,
+                 defer_logits: bool = False):
         """planes: write the bf16 planes the backward pass on pre-split operands reads; planes_forward (with planes, fused
         latent section): the four channel-last layers themselves run on planes (contraction mode 1)."""
         PV = self.param_views()
@@ -585,7 +586,9 @@ class ConvEngine:
         else:
             c["b1"] = _convT_nhwc(c["t0"], c["Wd1"], PV["d1.bias"], None, R, 128, 4, 256, True, FORWARD, c.get("b1_p"))   # [R*64, 256]
             c["b2"] = self._d2_forward(c["b1"], c["Wd2"], PV["d2.bias"], R)
-        if self.direct:
+        if self.direct and defer_logits and R == B:
+            c["logits"] = None  # forward_backward computes them in the launch of the loss end (mvae_convt_to3_bce_stats)
+        elif self.direct:
             c["logits"] = _convT_to3(c["b2"], PV["d3.weight"].view(64, 48), PV["d3.bias"], R)
         else:
             c["cT3"] = _gemm_nn(c["b2"], PV["d3.weight"].view(64, 3 * 16))
@@ -642,11 +645,21 @@ class ConvEngine:
         lay = self.layout
         p3 = self._use_p3(B) if eps.dim() == 2 else 0
         use_p3 = p3 != 0
-        c = self._forward(x, eps, planes=use_p3, planes_forward=(p3 == 1))
+        fuse_d3 = self.direct and os.environ.get("MVAE_CONV_D3_FUSED", "1") != "0"
+        c = self._forward(x, eps, planes=use_p3, planes_forward=(p3 == 1), defer_logits=fuse_d3)
         c["p3"] = use_p3
         bce = x.new_empty(B)
-        g = torch.empty_like(c["logits"])
-        if self.direct:
+        if c["logits"] is None:
+            # the last transposed convolution, BCE + its gradient, the batch statistics and d3.bias in ONE launch
+            PV = self.param_views()
+            c["logits"], g, chan = x.new_empty(B, 3072), x.new_empty(B, 3072), x.new_empty(B, 3)
+            check(load().mvae_convt_to3_bce_stats(ptr(c["b2"]), ptr(PV["d3.weight"]), ptr(PV["d3.bias"]), ptr(x), ptr(c["logits"]),
+                                                  ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats), float(beta), B, 64, 16, 16, 3,
+                                                  lay.n, ptr(chan), ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
+                                                  stream_ptr(self.device)))
+            c["d3_bias_done"] = True
+        elif self.direct:
+            g = torch.empty_like(c["logits"])
             # BCE + its gradient, the batch statistics and the bias gradient of d3 (sum of g per channel) in one launch
             chan = x.new_empty(B, 3)
             check(load().mvae_conv_bce_stats(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats),
@@ -655,6 +668,7 @@ class ConvEngine:
                                              stream_ptr(self.device)))
             c["d3_bias_done"] = True
         else:
+            g = torch.empty_like(c["logits"])
             check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
                                                    stream_ptr(self.device)))
             check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,

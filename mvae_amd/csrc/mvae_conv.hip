@@ -1704,6 +1704,150 @@ extern "C" int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, c
   return 0;
 }
 
+// The last decoder layer AND the loss end in one launch (conv_vae.py:54,74 + vae.py:125-147): workgroup b computes image b's
+// logits on the matrix cores -- P[256 pixels][48 = (c, ky, kx)] = b2[b] [256 x 64] W [64 x 48], 768 v_mfma_f32_16x16x4_f32, kept
+// in LDS --, folds the four taps of every output pixel (the col2im of the transposed convolution: no [B * 256, 48] product in
+// memory), adds the bias, writes the logits and continues exactly as k_bce_stats (BCE, its gradient, the per-image sums, the
+// arrival-counted batch statistics and d3.bias).  Replaces k_convT_to3_fwd (VALU dot products, 20 us) + k_bce_stats (14 us)
+// in the training step; the contraction index runs in the order (16 j + 4 (lane >> 4) + e), j, e = 0..3, so that ONE 16-byte
+// load per lane and j feeds four MFMA steps.  Fixed geometry as k_convT_to3_fwd.
+constexpr int kPS = kBK + 1;  // LDS row stride of P (floats)
+__global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ src, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ x,
+                                                      float* __restrict__ logits, float* bce, float* g, const float* kl,
+                                                      float* stats, float beta, int B, int ncomp, float* chan_part,
+                                                      float* dbias, int* counter) {
+  __shared__ float Ps[kBO * kBO * kPS];  // 50 KB
+  __shared__ float sm[4];
+  __shared__ float chs[4][8];
+  __shared__ int last_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int r = blockIdx.x;
+  float wf[kBC][16];
+#pragma unroll
+  for (int u = 0; u < kBC; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wf[u][4 * j + e] = W[(16 * j + 4 * l4 + e) * kBK + 16 * u + l15];
+  f32x4 av[4][4];
+#pragma unroll
+  for (int gI = 0; gI < 4; ++gI) {
+    const int px = (wave * 4 + gI) * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      av[gI][j] = *reinterpret_cast<const f32x4*>(src + ((size_t)r * (kBO * kBO) + px) * kBF + 16 * j + 4 * l4);
+  }
+#pragma unroll
+  for (int gI = 0; gI < 4; ++gI) {
+    f32x4 acc[kBC];
+#pragma unroll
+    for (int u = 0; u < kBC; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < kBC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gI][j][e], wf[u][4 * j + e], acc[u], 0, 0, 0);
+    // lane holds pixels 4 l4 + rr of the group, column 16 u + l15
+#pragma unroll
+    for (int u = 0; u < kBC; ++u)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ps[((wave * 4 + gI) * 16 + 4 * l4 + rr) * kPS + 16 * u + l15] = acc[u][rr];
+  }
+  __syncthreads();
+  constexpr int HW = kBH * kBH, D = kBC * HW;
+  const float* tl = x + (size_t)r * D;
+  float* gl = g + (size_t)r * D;
+  float* ll = logits + (size_t)r * D;
+  const int idx = tid * 4, Y = idx >> 5, X0 = idx & 31, ky0 = (Y + 1) & 1;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kBC; ++c) {
+    const float bc = bias ? bias[c] : 0.f;
+    f32x4 y;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int X = X0 + u, kx0 = (X + 1) & 1;
+      float a = 0.f;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const int ky = ky0 + 2 * ty, yy = (Y + 1 - ky) >> 1;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          const int kx = kx0 + 2 * tx, xx = (X + 1 - kx) >> 1;
+          if (yy >= 0 && yy < kBO && xx >= 0 && xx < kBO) a += Ps[(yy * kBO + xx) * kPS + c * 16 + ky * 4 + kx];
+        }
+      }
+      y[u] = a + bc;
+    }
+    const f32x4 t = *reinterpret_cast<const f32x4*>(tl + c * HW + idx);
+    f32x4 gv;
+    float cs = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e = mvf::fexp(-fabsf(y[u]));
+      gv[u] = ((y[u] >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t[u];
+      s += (1.f - t[u]) * y[u] - (fminf(y[u], 0.f) - mvf::log1p_pos(e));
+      cs += gv[u];
+    }
+    *reinterpret_cast<f32x4*>(ll + c * HW + idx) = y;
+    *reinterpret_cast<f32x4*>(gl + c * HW + idx) = gv;
+    cs = wave_sum(cs);
+    if (lane == 0) chs[wave][c] = cs;
+  }
+  s = wave_sum(s);
+  if (lane == 0) sm[wave] = s;
+  __syncthreads();
+  // (from here on: k_bce_stats, see there)
+  if (tid == 0) store4_wt(bce, (size_t)r, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+  if (tid < kBC) store4_wt(chan_part, (size_t)r * kBC + tid, (chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    constexpr int NG = 16;
+    const int grp = r % NG, gsize = (B - grp + NG - 1) / NG, ngroups = B < NG ? B : NG;
+    int last = 0;
+    if (atomicAdd(&counter[grp], 1) == gsize - 1) {
+      counter[grp] = 0;
+      if (atomicAdd(&counter[NG], 1) == ngroups - 1) {
+        counter[NG] = 0;
+        last = 1;
+      }
+    }
+    last_s = last;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid < 64) {
+    for (int c = 0; c < kBC; ++c) {
+      float a = 0.f;
+      for (int rr = tid; rr < B; rr += 64) a += chan_part[(size_t)rr * kBC + c];
+      a = wave_sum(a);
+      if (tid == 0) dbias[c] = a;
+    }
+  }
+  batch_stats_body(bce, kl, stats, beta, B, ncomp);
+}
+
+extern "C" int mvae_convt_to3_bce_stats(const float* src, const float* W, const float* bias, const float* x, float* logits,
+                                        float* bce, float* g, const float* kl, float* stats, float beta, int64_t B, int F,
+                                        int IH, int IW, int C, int ncomp, float* chan_part, float* dbias, int32_t* counter,
+                                        void* stream) {
+  if (!src || !W || !x || !logits || !bce || !g || !kl || !stats || !chan_part || !dbias || !counter || B < 1 ||
+      B > 0x7fffff || ncomp < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (!boundary_geometry(C, 2 * IH, 2 * IW, F))
+    return fail(MVAE_E_UNSUPPORTED, "fused last layer + loss end: 64 features to 3 x 32 x 32%s", "");
+  if (((((uintptr_t)src) | ((uintptr_t)x) | ((uintptr_t)logits) | ((uintptr_t)g)) & 15) != 0)
+    return fail(MVAE_E_ALIGN, "mvae_convt_to3_bce_stats needs 16-byte aligned src / x / logits / g%s", "");
+  hipLaunchKernelGGL(k_d3_bce_stats, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, src, W, bias, x, logits, bce, g, kl,
+                     stats, beta, (int)B, ncomp, chan_part, dbias, counter);
+  LAUNCH_CHECK("fused last layer + loss end launch");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ conv architecture: the latent section in four launches
 // conv_vae.py:65-71 between the last encoder convolution and the first decoder convolution:
 //   h = a2.view(bs, -1)  (NCHW flatten: column c * 16 + p)  ->  fc_mean / fc_logvar of every component (component.py:52-57)

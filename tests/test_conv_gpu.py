@@ -1003,6 +1003,45 @@ def test_plane_contractions_vs_float64(dev, case):
         close(out, ref, case)
 
 
+@pytest.mark.parametrize("B", [5, 256])
+def test_fused_last_layer_and_loss_end(dev, B):
+    """mvae_convt_to3_bce_stats (the last transposed convolution on the matrix cores + BCE, its gradient, per-image sums, batch
+    statistics and d3.bias in one launch) against the two launches it replaces in the training step
+    (mvae_convt_to3_k4s2p1_forward, mvae_conv_bce_stats) and against float64 for the logits."""
+    import torch.nn.functional as F
+    from mvae_amd._lib import check, load, ptr, stream_ptr
+    from mvae_amd.conv import _convT_to3
+    gen = torch.Generator().manual_seed(5 + B)
+    b2 = torch.relu(torch.randn(B * 256, 64, generator=gen)).to(dev)
+    W = (torch.randn(64, 48, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(3, generator=gen).to(dev)
+    x = torch.rand(B, 3072, generator=gen).to(dev)
+    kl = torch.rand(3, B, generator=gen).to(dev)
+    new = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+
+    def run(fused):
+        logits = new(B, 3072) if fused else _convT_to3(b2, W, bias, B)
+        bce, g, chan, dbias = new(B), new(B, 3072), new(B, 3), new(3)
+        stats, arrive = torch.zeros(64, device=dev), torch.zeros(17, dtype=torch.int32, device=dev)
+        if fused:
+            check(load().mvae_convt_to3_bce_stats(ptr(b2), ptr(W), ptr(bias), ptr(x), ptr(logits), ptr(bce), ptr(g), ptr(kl),
+                                                  ptr(stats), 0.7, B, 64, 16, 16, 3, 3, ptr(chan), ptr(dbias), ptr(arrive),
+                                                  stream_ptr(dev)))
+        else:
+            check(load().mvae_conv_bce_stats(ptr(logits), ptr(x), ptr(bce), ptr(g), ptr(kl), ptr(stats), 0.7, B, 3072, 1024, 3,
+                                             ptr(chan), ptr(dbias), ptr(arrive), stream_ptr(dev)))
+        torch.cuda.synchronize()
+        assert int(arrive.abs().sum()) == 0, "arrival counters not re-armed"
+        return logits, bce, g, dbias, stats
+
+    got, want = run(True), run(False)
+    ref = F.conv_transpose2d(b2.view(B, 16, 16, 64).permute(0, 3, 1, 2).double().cpu(), W.view(64, 3, 4, 4).double().cpu(),
+                             bias.double().cpu(), stride=2, padding=1).reshape(B, 3072)
+    assert_close(_cpu(got[0]), ref.numpy(), 2e-5, "logits vs float64", atol_frac=1e-5)
+    for a, b, nm in zip(got, want, ("logits", "bce", "g", "d3.bias", "stats")):
+        assert_close(_cpu(a), _cpu(b), 2e-5, nm + " vs the two-launch route", atol_frac=1e-5)
+
+
 @pytest.mark.parametrize("B", [8, 256, 300])
 def test_edge_layers_without_patch_matrix(dev, B):
     """csrc/mvae_edge.hip against the patch-matrix route it replaces (mvae_im2col_k4s2p1 + a contraction) and float64:
