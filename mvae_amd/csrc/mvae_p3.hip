@@ -50,6 +50,7 @@ struct P3Args {
   ConvGeom cg;
   int lCc;                             // log2(cg.Cc)
   unsigned long long* dbgbuf;          // (-DMV_P3_DBG builds only) phase time stamps of workgroup 0
+  int xcd;                             // XCD-aware tile order on (the host checked the divisibility it needs)
   int dbg;                             // (-DMV_P3_DBG builds only) bit 0: no DMA waits, 1: no A DMA, 2: no B DMA, 3: no MFMAs, 4: every step loads tile 0, 5: no barriers, 6: no fragment reads
 };
 
@@ -80,11 +81,41 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of the image
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kb = PARITY ? 0 : (int)blockIdx.z * g.k_per_slice;
+  // XCD-aware tile order.  Workgroup number L of a launch (x fastest, then y, then z) runs on XCD L % 8 (observed; only speed
+  // depends on it) and each XCD has its own L2: in dispatch order the tiles sharing an operand panel -- the column tiles of a
+  // row block, the tiles of one K slice -- sit on 8 different XCDs and every L2 fetches every panel.  Here an XCD takes tiles
+  // that share: whole K slices when there are >= 8 of them (weight gradients), 8 / nz contiguous tile ranges of a slice when
+  // there are 2 or 4, a contiguous eighth of the tiles (whole row blocks) of an unsliced product or of a parity class.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd) {
+    const int nx = gridDim.x, nz = gridDim.z, T = nx * (int)gridDim.y;
+    const int L = bx + nx * (by + (int)gridDim.y * bz), xcd = L & 7;
+    int t;
+    if (!PARITY && nz == 1) {
+      // g.xcd = gx: the XCDs as gx column groups x gy = 8 / gx row groups, each a contiguous range of column tiles x a
+      // contiguous range of row blocks -- A crosses the fabric gx times, B gy times, and an XCD's share of B stays in its L2
+      const int gy = 8 / g.xcd, cn = nx / g.xcd, j = L >> 3;
+      t = ((xcd / g.xcd) * ((int)gridDim.y / gy) + j / cn) * nx + (xcd % g.xcd) * cn + j % cn;
+    } else if (PARITY) {
+      const int Lt = L - bz * T;  // (T % 8 == 0)
+      t = (Lt & 7) * (T >> 3) + (Lt >> 3);
+    } else if (nz >= 8) {  // (nz % 8 == 0)
+      const int j = L >> 3;
+      bz = xcd + 8 * (j / T);
+      t = j % T;
+    } else {  // nz = 2 or 4, T % (8 / nz) == 0
+      const int q = 8 / nz;
+      bz = xcd / q;
+      t = (xcd % q) * (T / q) + (L >> 3);
+    }
+    bx = t % nx;
+    by = t / nx;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kb = PARITY ? 0 : bz * g.k_per_slice;
   const int ke = PARITY ? g.K : ((kb + g.k_per_slice < g.K) ? kb + g.k_per_slice : g.K);
-  float* __restrict__ C = g.C + (PARITY ? 0 : (size_t)blockIdx.z * g.slice_stride);
-  const int par_y = PARITY ? (int)(blockIdx.z >> 1) : 0, par_x = PARITY ? (int)(blockIdx.z & 1) : 0;
+  float* __restrict__ C = g.C + (PARITY ? 0 : (size_t)bz * g.slice_stride);
+  const int par_y = PARITY ? (bz >> 1) : 0, par_x = PARITY ? (bz & 1) : 0;
   const ConvGeom cg = g.cg;
   const bf16r* zero = reinterpret_cast<const bf16r*>(g_p3_zero);
 
@@ -590,6 +621,19 @@ static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
   g_p3_dbgbuf = dbuf;
 #endif
   dim3 grid(a.N / BN, a.M / BM, zdim);
+  static const bool xcd_off = getenv("MVAE_P3_NO_XCD") != nullptr;
+  const int T = (int)(grid.x * grid.y);
+  const bool per_class = AF == A_G3 || zdim == 1;
+  a.xcd = !xcd_off && (per_class ? (T % 8 == 0) : (zdim >= 8 ? (zdim % 8 == 0) : ((zdim == 2 || zdim == 4) && T % (8 / zdim) == 0)));
+  if (a.xcd && AF != A_G3 && zdim == 1) {  // the gx that minimises the fabric bytes gx |A| + (8 / gx) |B| (a gathered image is K / 4 wide)
+    double best = 0;
+    a.xcd = 0;
+    for (int gx = 1; gx <= 8; gx *= 2) {
+      if (grid.x % gx || grid.y % (8 / gx)) continue;
+      const double cost = (double)gx * a.M * (AF == A_G1 ? 0.25 : 1.0) + (8.0 / gx) * a.N;
+      if (a.xcd == 0 || cost < best) { a.xcd = gx; best = cost; }
+    }
+  }
   hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES>), grid, dim3(512), 0, s, a);
 }
 
