@@ -66,9 +66,12 @@ __device__ __forceinline__ int p3_km_swz(int kr, int CPR) {
   return ((kr / RPB) & (CPR / 2 - 1)) + (CPR / 2) * ((kr >> 3) & 1);
 }
 
-template <int BM, int BN, int WR, int AF, int BF, int NST = 3>
+// KALT: the two wave groups take ALTERNATE K steps of the whole tile (wave tiles twice as large: half the fragment reads per
+// MFMA, one barrier interval per K step instead of two) and add their partial sums through LDS before the epilogue; WR then
+// counts the rows of the 4-wave grid of one group.
+template <int BM, int BN, int WR, int AF, int BF, int NST = 3, bool KALT = false>
 __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
-  constexpr int NW = 8, WC = NW / WR, WM = BM / WR, WN = BN / WC, TM = WM / 16, TN = WN / 16;
+  constexpr int NW = 8, NWT = KALT ? 4 : 8, WC = NWT / WR, WM = BM / WR, WN = BN / WC, TM = WM / 16, TN = WN / 16;
   constexpr int PLA = BM * 64, PLB = BN * 64;  // bytes per plane tile (32 k x 2 bytes per row)
   constexpr int SB = 3 * (PLA + PLB);          // bytes per LDS buffer
   constexpr int NPA = 3 * BM / 16, NPB = 3 * BN / 16, NP = NPA + NPB;  // 1-KiB DMA pieces per K step
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   // instructions (the planes differ by a uniform stride); everything that does not depend on the K step is kept in
   // registers (inv per piece).
   constexpr int PPA = BM / 16, PPB = BN / 16;         // pieces per plane
-  constexpr int NI = NW;                               // every wave moves its share of a tile
+  constexpr int NI = NWT;                              // the waves that move a tile: all eight, or (KALT) the group that consumes it
   constexpr int UA = (PPA + NI - 1) / NI, UB = (PPB + NI - 1) / NI;
   struct Inv { long long off; int i0, i1, i2, i3; };
   // lane geometry inside a piece: KC -> (tile row r, source chunk offset c8 in elements); KM -> (k row kr, column offset col)
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
       return (long long)(k0 - (tap << g.lCc) + v.i3) * g.ldb + (long long)(ky * 4 + kx) * g.N + v.i2;
     }
   };
-  const int grp = wave >> 2, idx = wave;  // (grp: the ping-pong group, see the K loop)
+  const int grp = wave >> 2, idx = KALT ? (wave & 3) : wave;  // (grp: the ping-pong group, see the K loop)
   Inv inva[UA], invb[UB];
 #pragma unroll
   for (int i = 0; i < UA; ++i) inva[i] = a_inv((idx + NI * i) % PPA);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   };
 
   // ---- fragments: lane l holds (tile row l & 15, k = 8 (l >> 4) .. + 7) of every 16-row block
-  const int wm = (wave / WC) * WM, wn = (wave % WC) * WN;
+  const int wm = (idx / WC) * WM, wn = (idx % WC) * WN;
   const int l15 = lane & 15, l4 = lane >> 4;
   // KC operand: ds_read_b128 at [row][chunk ^ h]: the lane part is the same for every 16-row block, plane and buffer
   const int kc_lane_off = l15 * 64 + ((l4 ^ p3_h(l15 >> 2)) << 4);
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[b][PB[t]], f.a[a][PA[t]], acc[a][b], 0, 0, 0);
   };
   // DMA instructions this wave issues per tile (what its counted wait leaves in flight)
-  const int per_tile = 3 * ((PPA % NW == 0 ? UA : (wave < PPA ? 1 : 0)) + (PPB % NW == 0 ? UB : (wave < PPB ? 1 : 0)));
+  const int per_tile = 3 * ((PPA % NI == 0 ? UA : (idx < PPA ? 1 : 0)) + (PPB % NI == 0 ? UB : (idx < PPB ? 1 : 0)));
   auto barrier = [&]() __attribute__((always_inline)) {
     if (!(dbg & 32)) asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);  // (MFMAs touch no memory: the clobber alone would not keep them behind the barrier)
@@ -460,8 +463,12 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   auto tile_k = [&](int t) __attribute__((always_inline)) { return (t < nsteps && !(dbg & 16)) ? kb + 32 * t : kb; };  // (past the end: tile 0 again, never consumed)
   static_assert(NST == 3, "the ping-pong loop cycles three LDS buffers");
   Frags f;
-  issue(0, tile_k(0));
-  issue(1, tile_k(1));
+  if constexpr (KALT) {
+    issue(grp, tile_k(grp));  // each group fetches (and later consumes) its own tiles: grp, grp + 2, ...
+  } else {
+    issue(0, tile_k(0));
+    issue(1, tile_k(1));
+  }
   wait_dma(true);
   barrier();
   if (grp == 1) barrier();  // group 1 starts one phase late
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
     load_and_issue(f, buf, decltype(buf_fill)::value, tile_k(t + 2));
     MV_P3_STAMP(1);
     MV_P3_STAMP(2);
-    if (grp == 1) wait_dma(false);
+    if (!KALT && grp == 1) wait_dma(false);
     MV_P3_STAMP(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MV_P3_STAMP(4);
@@ -496,7 +503,8 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
     __builtin_amdgcn_s_setprio(0);
 #endif
     MV_P3_STAMP(6);
-    if (grp == 0) wait_dma(false);
+    if (KALT) wait_dma(true);  // the group's next tile (requested in this step's L phase) before the barrier its L phase follows
+    else if (grp == 0) wait_dma(false);
     MV_P3_STAMP(7);
     barrier();
     MV_P3_STAMP(8);
@@ -508,19 +516,65 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   using B2 = std::integral_constant<int, 2>;
-  for (int t = 0; t < nsteps; t += 3) {
-    step(t, B0{}, B2{});
-    if (t + 1 < nsteps) step(t + 1, B1{}, B0{});
-    if (t + 2 < nsteps) step(t + 2, B2{}, B1{});
+  if constexpr (KALT) {
+    // interval i: group i & 1 in L_i (fragments of tile i, requests of tile i + 2 into the buffer tile i - 1 left at the previous
+    // barrier), the other group in C_{i-1}.  A group's tiles cycle the three buffers with period three of ITS steps.
+    if (grp == 0) {
+      for (int t = 0; t < nsteps; t += 6) {
+        step(t, B0{}, B2{});
+        if (t + 2 < nsteps) step(t + 2, B2{}, B1{});
+        if (t + 4 < nsteps) step(t + 4, B1{}, B0{});
+      }
+    } else {
+      for (int t = 1; t < nsteps; t += 6) {
+        step(t, B1{}, B0{});
+        if (t + 2 < nsteps) step(t + 2, B0{}, B2{});
+        if (t + 4 < nsteps) step(t + 4, B2{}, B1{});
+      }
+    }
+    if ((grp == 0) == ((nsteps & 1) == 0)) barrier();  // (the other group's last phase)
+  } else {
+    for (int t = 0; t < nsteps; t += 3) {
+      step(t, B0{}, B2{});
+      if (t + 1 < nsteps) step(t + 1, B1{}, B0{});
+      if (t + 2 < nsteps) step(t + 2, B2{}, B1{});
+    }
+    if (grp == 0) barrier();  // (group 1's last phase)
   }
-  if (grp == 0) barrier();  // (group 1's last phase)
 #undef MV_TR_READ
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (unused) DMA of the last step
+  // ---- KALT: the two groups hold partial sums of the SAME wave tiles (wave w and w + 4).  Each wave keeps one half of its
+  // rows (group 0 the upper TM / 2 blocks, group 1 the lower), hands the other half to its partner through LDS and adds what
+  // it receives: own + partner on both sides, so the result does not depend on which group computed which K steps' sum first
+  // beyond the (fixed) even / odd partition.
+  constexpr int TMK = KALT ? TM / 2 : TM;  // row blocks this wave writes
+  if constexpr (KALT) {
+    static_assert(!KALT || (TM % 2 == 0 && 8 * (TM / 2) * TN * 1024 <= NST * SB), "exchange area");
+    barrier();  // every wave has left the K loop: the tile buffers are free
+    f32x4* xch = reinterpret_cast<f32x4*>(lds) + (size_t)wave * (TMK * TN * 64) + lane;
+    const f32x4* xin = reinterpret_cast<const f32x4*>(lds) + (size_t)(wave ^ 4) * (TMK * TN * 64) + lane;
+    auto swap_half = [&](auto keep0, auto send0) __attribute__((always_inline)) {
+      constexpr int K0 = decltype(keep0)::value, S0 = decltype(send0)::value;
+#pragma unroll
+      for (int a = 0; a < TMK; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) xch[(a * TN + b) * 64] = acc[S0 + a][b];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();
+#pragma unroll
+      for (int a = 0; a < TMK; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = acc[K0 + a][b] + xin[(a * TN + b) * 64];  // (kept half moved to blocks 0 .. TMK - 1)
+    };
+    if (grp == 0) swap_half(std::integral_constant<int, 0>{}, std::integral_constant<int, TM / 2>{});
+    else swap_half(std::integral_constant<int, TM / 2>{}, std::integral_constant<int, 0>{});
+  }
+  const int row_half = KALT ? grp * (TM / 2) * 16 : 0;
   // ---- epilogue: lane holds row l15, columns 4 * l4 + r of every 16 x 16 tile
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    int m = m0 + wm + a * 16 + l15;
+  for (int a = 0; a < TMK; ++a) {
+    int m = m0 + wm + row_half + a * 16 + l15;
     if (PARITY) {  // row of the parity class -> its pixel of the (2 IH) x (2 IW) output
       const int ox = m & ((1 << cg.lOW) - 1), oy = (m & ((1 << cg.lOHW) - 1)) >> cg.lOW, bb = m >> cg.lOHW;
       m = (bb * 2 * cg.IH + 2 * oy + par_y) * 2 * cg.IW + 2 * ox + par_x;
@@ -611,6 +665,11 @@ extern "C" int mvae_p3_debug_stamps(unsigned long long* out32) {  // (debug buil
 #endif
 template <int BM, int BN, int WR, int AF, int BF>
 static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
+  // alternating K steps where they measured faster (tools/bench_p3.py, us with / without: weight gradients 47.3 / 48.7, 48.4 /
+  // 53.9, transposed convolution 30.5 / 34.3) -- not for the gathered / plain KC forms (56.0 / 49.9, 34.8 / 32.9, 49.7 / 48.0);
+  // MVAE_P3_KALT=0 / 1 forces one form for all
+  static const int kalt_env = getenv("MVAE_P3_KALT") ? atoi(getenv("MVAE_P3_KALT")) : -1;
+  const bool kalt = kalt_env >= 0 ? kalt_env != 0 : (AF == A_KM || AF == A_G3);
   P3Args a = a0;
 #ifdef MV_P3_DBG
   const char* e = getenv("MV_P3_DBG");
@@ -634,7 +693,8 @@ static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
       if (a.xcd == 0 || cost < best) { a.xcd = gx; best = cost; }
     }
   }
-  hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES>), grid, dim3(512), 0, s, a);
+  if (kalt) hipLaunchKernelGGL((k_gemm_p3<BM, BN, 2, AF, BF, MV_P3_STAGES, true>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES, false>), grid, dim3(512), 0, s, a);
 }
 
 // Which shapes the plane kernels take (the callers fall back to the f32-operand kernels otherwise): whole tiles only.
