@@ -362,6 +362,11 @@ int mvae_p3_supported(int form, int64_t M, int N, int K, int C);
 /* planes[j] (3 x n[j] bf16, plane stride n[j]) of src[j] (n[j] floats, a multiple of 4), up to 12 tensors in ONE launch:
  * the conv weights after the optimizer step, activations whose producer does not write planes. */
 int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream);
+/* Grouped launches: between mvae_p3_group(1, stream) and mvae_p3_group(0, stream) up to two plane contractions are queued
+ * instead of launched; group(0) launches them -- a weight gradient (mvae_conv_k4s2p1_nhwc_wgrad_p3) and the backward-data of the
+ * same layer (the other three entry points) as ONE kernel whose workgroups of the second start as those of the first finish --
+ * followed by the slice sums that were waiting for them.  The two must be independent (neither reads the other's result). */
+int mvae_p3_group(int on, void* stream);
 /* mvae_conv_k4s2p1_nhwc (a Conv2d forward, conv_vae.py:47-50,57-63, or the backward-data of a ConvTranspose2d,
  * conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of Wt [OC, 16 C]; y = mask(relu(sum + bias)) (bias NULL: none;
  * relu 0: none; mask NULL: none) in f32, its planes too when y_planes != NULL (not together with a split-K workspace, which

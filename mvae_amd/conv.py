@@ -138,6 +138,21 @@ def _split_planes(tensors: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = 
     return list(outs)
 
 
+class _p3_group:
+    """with _p3_group(device): a layer's weight gradient and its backward-data (independent plane contractions) leave as ONE
+    launch (mvae_p3_group); MVAE_P3_NO_PAIR=1: one after the other as before."""
+
+    def __init__(self, device):
+        self.stream = stream_ptr(device)
+
+    def __enter__(self):
+        check(load().mvae_p3_group(1, self.stream))
+
+    def __exit__(self, *exc):
+        check(load().mvae_p3_group(0, self.stream))
+        return False
+
+
 def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int,
                   want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
                   out_planes: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
@@ -812,12 +827,15 @@ class ConvEngine:
             dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
             _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
             db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"], planes=db2_p)  # ReLU mask in the epilogue
-        _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
+        # each layer's weight gradient and backward-data read the same incoming gradient and not each other: ONE launch per pair
+        with _p3_group(dev):
+            _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
+            db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True)  # [B*64, 256], ReLU mask of b1
         _colsum(db2, out=GV["d2.bias"])
-        db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True)  # [B*64, 256], ReLU mask of b1
-        _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
+        with _p3_group(dev):
+            _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
+            dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8)  # [B*16, 128]
         _colsum(db1, out=GV["d1.bias"])
-        dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8)  # [B*16, 128]
         # ---- latent section
         da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None
         dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p)
@@ -825,20 +843,23 @@ class ConvEngine:
         da2 = dhflat.view(B * 16, 512)
         if da2_p is None:
             da2_p = _split_planes([da2])[0]
-        _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
         _colsum(da2, out=GV["e2.bias"])
         if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "0") == "1" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
+            _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
             # backward-data of e2 as four implicit contractions per output parity class (no [B * 16, 2048] product, no col2im):
             # measured 0.836 / 0.830 against 0.839 / 0.833 ms per step for the product + col2im form -- inside the noise, so the
             # product form (whose summation order the reference-step test margins were recorded with) stays the default
             da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True)
         else:
             da1_p = _new_planes(B * 64, 128, dev)
-            da1 = _col2im(_gemm_nn_p3(da2_p, We2_p), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True,
-                          planes=da1_p)
-        _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
+            with _p3_group(dev):
+                _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
+                prod = _gemm_nn_p3(da2_p, We2_p)
+            da1 = _col2im(prod, None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True, planes=da1_p)
+        with _p3_group(dev):
+            _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
+            da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64)  # [B*256, 64], ReLU mask of a0
         _colsum(da1, out=GV["e1.bias"])
-        da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64)  # [B*256, 64], ReLU mask of a0
         if c["col0"] is None:
             _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B)
         else:

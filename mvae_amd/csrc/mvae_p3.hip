@@ -69,8 +69,13 @@ __device__ __forceinline__ int p3_km_swz(int kr, int CPR) {
 // KALT: the two wave groups take ALTERNATE K steps of the whole tile (wave tiles twice as large: half the fragment reads per
 // MFMA, one barrier interval per K step instead of two) and add their partial sums through LDS before the epilogue; WR then
 // counts the rows of the 4-wave grid of one group.
+// The body is a device function so that TWO contractions can share one launch (k_gemm_p3_pair below): L = the workgroup's number
+// within its contraction's (nx, ny, nz) grid, x fastest; lds = the workgroup's whole LDS allocation.
+template <int BM, int BN>
+constexpr int p3_lds_bytes(int nst = 3) { return nst * 3 * (BM * 64 + BN * 64); }
 template <int BM, int BN, int WR, int AF, int BF, int NST = 3, bool KALT = false>
-__global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
+__device__ __forceinline__ void p3_body(const P3Args& g, unsigned char* __restrict__ lds, const int L0, const int nx, const int ny,
+                                        const int nz) {
   constexpr int NW = 8, NWT = KALT ? 4 : 8, WC = NWT / WR, WM = BM / WR, WN = BN / WC, TM = WM / 16, TN = WN / 16;
   constexpr int PLA = BM * 64, PLB = BN * 64;  // bytes per plane tile (32 k x 2 bytes per row)
   constexpr int SB = 3 * (PLA + PLB);          // bytes per LDS buffer
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   constexpr bool PARITY = AF == A_G3;
   static_assert(TM >= 1 && TN >= 1 && WM % 16 == 0 && WN % 16 == 0, "wave tile");
   static_assert(NST == 2 || NST == 3, "LDS stages");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * SB];
+  static_assert(NST * SB == p3_lds_bytes<BM, BN>(NST), "LDS size");
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of the image
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,16 +94,16 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   // row block, the tiles of one K slice -- sit on 8 different XCDs and every L2 fetches every panel.  Here an XCD takes tiles
   // that share: whole K slices when there are >= 8 of them (weight gradients), 8 / nz contiguous tile ranges of a slice when
   // there are 2 or 4, a contiguous eighth of the tiles (whole row blocks) of an unsliced product or of a parity class.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  int bx = L0 % nx, by = (L0 / nx) % ny, bz = L0 / (nx * ny);
   if (g.xcd) {
-    const int nx = gridDim.x, nz = gridDim.z, T = nx * (int)gridDim.y;
-    const int L = bx + nx * (by + (int)gridDim.y * bz), xcd = L & 7;
+    const int T = nx * ny;
+    const int L = L0, xcd = L & 7;
     int t;
     if (!PARITY && nz == 1) {
       // g.xcd = gx: the XCDs as gx column groups x gy = 8 / gx row groups, each a contiguous range of column tiles x a
       // contiguous range of row blocks -- A crosses the fabric gx times, B gy times, and an XCD's share of B stays in its L2
       const int gy = 8 / g.xcd, cn = nx / g.xcd, j = L >> 3;
-      t = ((xcd / g.xcd) * ((int)gridDim.y / gy) + j / cn) * nx + (xcd % g.xcd) * cn + j % cn;
+      t = ((xcd / g.xcd) * (ny / gy) + j / cn) * nx + (xcd % g.xcd) * cn + j % cn;
     } else if (PARITY) {
       const int Lt = L - bz * T;  // (T % 8 == 0)
       t = (Lt & 7) * (T >> 3) + (Lt >> 3);
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
 #endif
   auto step = [&](int t, auto buf, auto buf_fill) __attribute__((always_inline)) {
 #ifdef MV_P3_DBG
-    const bool stamp = g.dbgbuf && t == 8 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && (wave & 3) == 0;
+    const bool stamp = g.dbgbuf && t == 8 && L0 == 0 && (wave & 3) == 0;
 #endif
     // L: fragments of tile t, requests of tile t + 2
     MV_P3_STAMP(0);
@@ -604,6 +609,27 @@ __global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
   }
 }
 
+template <int BM, int BN, int WR, int AF, int BF, int NST = 3, bool KALT = false>
+__global__ __launch_bounds__(512) void k_gemm_p3(const P3Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[p3_lds_bytes<BM, BN>(NST)];
+  p3_body<BM, BN, WR, AF, BF, NST, KALT>(g, lds, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)gridDim.x,
+                                         (int)gridDim.y, (int)gridDim.z);
+}
+
+// Two INDEPENDENT contractions in one launch (a layer's weight gradient and its backward-data: both read the same incoming
+// gradient, neither reads the other's result): workgroups 0 .. n1 - 1 are the first one's, the rest the second's.  A CU that
+// finishes a workgroup of the first takes one of the second -- the epilogue of one (57 MB of stores for db1) and the prologue of
+// the other (two tiles' DMA latency) run under the other's K loop instead of at a kernel boundary where the whole chip waits.
+template <int BM1, int BN1, int WR1, int AF1, int BF1, bool KALT1, int BM2, int BN2, int WR2, int AF2, int BF2, bool KALT2>
+__global__ __launch_bounds__(512) void k_gemm_p3_pair(const P3Args g1, const P3Args g2, const int n1, const int nx1, const int ny1,
+                                                      const int nz1, const int nx2, const int ny2, const int nz2) {
+  constexpr int LB = p3_lds_bytes<BM1, BN1>() > p3_lds_bytes<BM2, BN2>() ? p3_lds_bytes<BM1, BN1>() : p3_lds_bytes<BM2, BN2>();
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LB];
+  const int L = blockIdx.x;
+  if (L < n1) p3_body<BM1, BN1, WR1, AF1, BF1, 3, KALT1>(g1, lds, L, nx1, ny1, nz1);
+  else p3_body<BM2, BN2, WR2, AF2, BF2, 3, KALT2>(g2, lds, L - n1, nx2, ny2, nz2);
+}
+
 // ---- planes of an existing f32 tensor (weights after the optimizer step; activations whose producer does not emit them)
 constexpr int kMaxSplitJobs = 12;
 struct SplitJobs {
@@ -663,6 +689,89 @@ extern "C" int mvae_p3_debug_stamps(unsigned long long* out32) {  // (debug buil
 #ifndef MV_P3_STAGES
 #define MV_P3_STAGES 3
 #endif
+void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);      // mvae_conv.hip (honours deferral)
+void p3_sum_slices_now(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (immediate)
+
+// ---- grouped launches (mvae_p3_group): between group(1) and group(0) the plane contractions are QUEUED; group(0) launches two
+// queued ones that form a known pair as ONE kernel (k_gemm_p3_pair), anything else one after the other, then the slice sums that
+// were waiting for them.
+enum { P3_OTHER = 0, P3_WGRAD = 1, P3_DGRAD_CONV = 2, P3_NN = 3, P3_DGRAD_CONVT = 4 };
+template <int BM, int BN, int WR, int AF, int BF, bool KALT>
+constexpr int p3_cfg_id() {
+  if (BM == 128 && BN == 128 && AF == A_KM && BF == B_G2 && KALT) return P3_WGRAD;
+  if (BM == 128 && BN == 128 && AF == A_G1 && BF == B_KC && !KALT) return P3_DGRAD_CONV;
+  if (BM == 128 && BN == 128 && AF == A_KC && BF == B_KM && !KALT) return P3_NN;
+  if (BM == 128 && BN == 64 && AF == A_G3 && BF == B_G3W && KALT) return P3_DGRAD_CONVT;
+  return P3_OTHER;
+}
+struct P3Queued {
+  int id;
+  P3Args a;
+  dim3 grid;
+  void (*single)(const P3Args&, dim3, hipStream_t);
+};
+struct P3Post { const float* part; float* out; int64_t n; int slices; };
+static thread_local bool g_p3_group = false;
+static thread_local int g_p3_nq = 0, g_p3_npost = 0;
+static thread_local P3Queued g_p3_q[2];
+static thread_local P3Post g_p3_post[2];
+
+template <int BM, int BN, int WR, int AF, int BF, bool KALT>
+static void p3_single(const P3Args& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES, KALT>), grid, dim3(512), 0, s, a);
+}
+template <int BM, int BN, int WR, int AF, int BF, bool KALT>
+static void p3_submit(const P3Args& a, dim3 grid, hipStream_t s) {
+  if (g_p3_group && g_p3_nq < 2) {
+    g_p3_q[g_p3_nq++] = P3Queued{p3_cfg_id<BM, BN, WR, AF, BF, KALT>(), a, grid, &p3_single<BM, BN, WR, AF, BF, KALT>};
+    return;
+  }
+  p3_single<BM, BN, WR, AF, BF, KALT>(a, grid, s);
+}
+// the immediate slice sum of a split-K backward-data result: after the (possibly queued) launch that writes the slices
+static void p3_sum_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
+  if (g_p3_group && g_p3_npost < 2) {
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices};
+    return;
+  }
+  p3_sum_slices_now(part, out, n, slices, s);
+}
+template <int BM2, int BN2, int WR2, int AF2, int BF2, bool KALT2>
+static void p3_launch_pair(const P3Queued& w, const P3Queued& d, hipStream_t s) {  // w: the weight gradient (P3_WGRAD)
+  const int n1 = (int)(w.grid.x * w.grid.y * w.grid.z), n2 = (int)(d.grid.x * d.grid.y * d.grid.z);
+  hipLaunchKernelGGL((k_gemm_p3_pair<128, 128, 2, A_KM, B_G2, true, BM2, BN2, WR2, AF2, BF2, KALT2>), dim3((unsigned)(n1 + n2)),
+                     dim3(512), 0, s, w.a, d.a, n1, (int)w.grid.x, (int)w.grid.y, (int)w.grid.z, (int)d.grid.x, (int)d.grid.y,
+                     (int)d.grid.z);
+}
+extern "C" int mvae_p3_group(int on, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (on) {
+    g_p3_group = true;
+    g_p3_nq = g_p3_npost = 0;
+    return 0;
+  }
+  g_p3_group = false;
+  static const bool pair_off = getenv("MVAE_P3_NO_PAIR") != nullptr;
+  bool paired = false;
+  if (g_p3_nq == 2 && !pair_off) {
+    const int wi = g_p3_q[0].id == P3_WGRAD ? 0 : (g_p3_q[1].id == P3_WGRAD ? 1 : -1);
+    if (wi >= 0 && (((g_p3_q[wi].grid.x * g_p3_q[wi].grid.y * g_p3_q[wi].grid.z) & 7) == 0)) {
+      const P3Queued &w = g_p3_q[wi], &d = g_p3_q[1 - wi];
+      paired = true;
+      if (d.id == P3_DGRAD_CONV) p3_launch_pair<128, 128, 2, A_G1, B_KC, false>(w, d, s);
+      else if (d.id == P3_NN) p3_launch_pair<128, 128, 2, A_KC, B_KM, false>(w, d, s);
+      else if (d.id == P3_DGRAD_CONVT) p3_launch_pair<128, 64, 2, A_G3, B_G3W, true>(w, d, s);
+      else paired = false;
+    }
+  }
+  if (!paired)
+    for (int i = 0; i < g_p3_nq; ++i) g_p3_q[i].single(g_p3_q[i].a, g_p3_q[i].grid, s);
+  for (int i = 0; i < g_p3_npost; ++i) p3_sum_slices_now(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
+  g_p3_nq = g_p3_npost = 0;
+  LAUNCH_CHECK("grouped plane contraction launch");
+  return 0;
+}
+
 template <int BM, int BN, int WR, int AF, int BF>
 static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
   // alternating K steps where they measured faster (tools/bench_p3.py, us with / without: weight gradients 47.3 / 48.7, 48.4 /
@@ -693,8 +802,8 @@ static void launch_p3(const P3Args& a0, int zdim, hipStream_t s) {
       if (a.xcd == 0 || cost < best) { a.xcd = gx; best = cost; }
     }
   }
-  if (kalt) hipLaunchKernelGGL((k_gemm_p3<BM, BN, 2, AF, BF, MV_P3_STAGES, true>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES, false>), grid, dim3(512), 0, s, a);
+  if (kalt) p3_submit<BM, BN, 2, AF, BF, true>(a, grid, s);
+  else p3_submit<BM, BN, WR, AF, BF, false>(a, grid, s);
 }
 
 // Which shapes the plane kernels take (the callers fall back to the f32-operand kernels otherwise): whole tiles only.
@@ -732,8 +841,6 @@ extern "C" int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int Cc, int 
   return slices > 1 ? (int64_t)slices * M * OC : 0;
 }
 
-void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);      // mvae_conv.hip (honours deferral)
-void p3_sum_slices_now(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (immediate)
 
 static int p3_geom(ConvGeom* g, int* lCc, int B, int Cc, int IH, int IW, bool out_is_half) {
   const int l = ilog2_exact(Cc);
@@ -776,7 +883,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
     a.C = workspace; a.Cp = nullptr; a.psc = 0; a.mask = nullptr; a.k_per_slice = kps; a.slice_stride = M * OC;
     launch_p3<128, 128, 2, A_G1, B_KC>(a, slices, (hipStream_t)stream);
     if (y_planes) return fail(MVAE_E_UNSUPPORTED, "planes of a split-K result are not produced%s", "");
-    p3_sum_slices_now(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
+    p3_sum_after(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
   } else {
     a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0;
     // 128 x 64 tiles where 128 x 128 ones would leave CUs without a workgroup (the forward layers: 128 tiles each)
