@@ -306,6 +306,17 @@ def _edge_wgrad(act: Tensor, img: Tensor, out: Tensor, B: int) -> Tensor:
     return out
 
 
+def _edge_backward(act: Tensor, img: Tensor, W: Tensor, out_dW: Tensor, B: int, planes: Optional[Tensor] = None) -> Tensor:
+    """_edge_wgrad(act, img, out_dW) and _edge_conv(img, W, None, act, False) in ONE launch: the backward pass of d3."""
+    assert out_dW.is_contiguous() and out_dW.numel() == 64 * 48
+    nws = int(load().mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(B, 3, 32, 32, 64))
+    ws = _keep(act.new_empty(nws))
+    y = img.new_empty(B * 256, 64)
+    check(load().mvae_conv3_k4s2p1_nchw_backward(ptr(act), ptr(img), ptr(W), ptr(out_dW), ptr(y), _pptr(planes), _ps(planes), B, 3,
+                                                 32, 32, 64, ptr(ws), stream_ptr(act.device)))
+    return y
+
+
 FORWARD, BACKWARD = 0, 1  # MVAE_PASS_FORWARD / MVAE_PASS_BACKWARD: which pass a shared contraction belongs to
 
 
@@ -821,8 +832,7 @@ class ConvEngine:
             _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
         db2_p = _new_planes(B * 256, 64, dev)
         if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
-            _edge_wgrad(c["b2"], g, GV["d3.weight"].view(64, 48), B)
-            db2 = _edge_conv(g, PV["d3.weight"].view(64, 48), None, c["b2"], False, B, db2_p)
+            db2 = _edge_backward(c["b2"], g, PV["d3.weight"].view(64, 48), GV["d3.weight"].view(64, 48), B, db2_p)
         else:
             dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
             _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))

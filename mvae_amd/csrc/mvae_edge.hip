@@ -28,10 +28,9 @@ constexpr int kEC = 3, kEH = 32, kEO = 16, kEF = 64, kEK = kEC * 16;  // channel
 constexpr int kEWS = kEK + 1;   // LDS row stride of W (floats): 49 is odd, the 16 rows of a fragment fall into 16 banks
 constexpr int kETS = kEF + 4;   // LDS row stride of a wave's result tile (floats)
 template <int G, int NW>
-__global__ __launch_bounds__(64 * NW) void k_edge3_nt(const float* __restrict__ img, const float* __restrict__ W,
-                                                  const float* __restrict__ bias, const float* __restrict__ mask, const int relu,
-                                                  float* __restrict__ y, bf16r* __restrict__ yp, const long long ps,
-                                                  const int nrows) {
+__device__ __forceinline__ void edge3_nt_body(const int blk, const float* __restrict__ img, const float* __restrict__ W,
+                                              const float* __restrict__ bias, const float* __restrict__ mask, const int relu,
+                                              float* __restrict__ y, bf16r* __restrict__ yp, const long long ps, const int nrows) {
   __shared__ float sW[kEF * kEWS];
   __shared__ __attribute__((aligned(16))) float sT[NW][16 * kETS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(64 * NW) void k_edge3_nt(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sW[n * kEWS + k + r] = v[r];
   }
-  const int row0 = ((int)blockIdx.x * NW + wave) * G;
+  const int row0 = (blk * NW + wave) * G;
   const int ix = 2 * l15 - 1 + l4;
   const bool okx = ix >= 0 && ix < kEH;
   float pf[G][12];
@@ -105,12 +104,20 @@ __global__ __launch_bounds__(64 * NW) void k_edge3_nt(const float* __restrict__ 
   }
 }
 
+template <int G, int NW>
+__global__ __launch_bounds__(64 * NW) void k_edge3_nt(const float* __restrict__ img, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, const float* __restrict__ mask, const int relu,
+                                                  float* __restrict__ y, bf16r* __restrict__ yp, const long long ps,
+                                                  const int nrows) {
+  edge3_nt_body<G, NW>((int)blockIdx.x, img, W, bias, mask, relu, y, yp, ps, nrows);
+}
+
 // part[wg][n, k] = sum over the workgroup's pixels of act[p, n] patch(p; k): 8 waves x 32 pixels of one image per pass, the
 // contraction index is the pixel.  Tile t of the "a" operand takes row i from feature 4 i + t, so ONE 16-byte load per lane
 // (act[p][4 l15 .. + 3], p = p0 + 4 s + l4) feeds the four feature tiles of a step; tile u of "b" is image channel u, column
 // j = (ky, kx).  The eight waves' sums are added through LDS in a fixed order, the workgroups' by the (deferrable) slice sum.
-__global__ __launch_bounds__(512) void k_edge3_tn(const float* __restrict__ act, const float* __restrict__ img,
-                                                  float* __restrict__ part, const int B, const int img_per_wg) {
+__device__ __forceinline__ void edge3_tn_body(const int blk, const float* __restrict__ act, const float* __restrict__ img,
+                                              float* __restrict__ part, const int B, const int img_per_wg) {
   __shared__ __attribute__((aligned(16))) float red[4][kEF * kEK];  // 48 KB
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   const int ky = l15 >> 2, kx = l15 & 3;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512) void k_edge3_tn(const float* __restrict__ act,
 #pragma unroll
     for (int u = 0; u < 3; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ii = 0; ii < img_per_wg; ++ii) {
-    const int b = (int)blockIdx.x * img_per_wg + ii;
+    const int b = blk * img_per_wg + ii;
     if (b >= B) break;
     f32x4 af[8];
     float bf[8][3];
@@ -163,8 +170,23 @@ __global__ __launch_bounds__(512) void k_edge3_tn(const float* __restrict__ act,
         }
   }
   __syncthreads();
-  float* dst = part + (size_t)blockIdx.x * (kEF * kEK);
+  float* dst = part + (size_t)blk * (kEF * kEK);
   for (int e = threadIdx.x; e < kEF * kEK; e += 512) dst[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+}
+
+__global__ __launch_bounds__(512) void k_edge3_tn(const float* __restrict__ act, const float* __restrict__ img,
+                                                  float* __restrict__ part, const int B, const int img_per_wg) {
+  edge3_tn_body((int)blockIdx.x, act, img, part, B, img_per_wg);
+}
+// both backward contractions of d3 in one launch (they read the same gradient image and not each other): workgroups
+// 0 .. n_tn - 1 the weight gradient, the rest the backward-data
+__global__ __launch_bounds__(512) void k_edge3_bwd(const float* __restrict__ act, const float* __restrict__ img,
+                                                   float* __restrict__ part, const int B, const int img_per_wg, const int n_tn,
+                                                   const float* __restrict__ W, const float* __restrict__ mask,
+                                                   float* __restrict__ y, bf16r* __restrict__ yp, const long long ps,
+                                                   const int nrows) {
+  if ((int)blockIdx.x < n_tn) edge3_tn_body((int)blockIdx.x, act, img, part, B, img_per_wg);
+  else edge3_nt_body<1, 8>((int)blockIdx.x - n_tn, img, W, nullptr, mask, 0, y, yp, ps, nrows);
 }
 
 void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (honours deferral)
@@ -203,5 +225,24 @@ extern "C" int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, 
   hipLaunchKernelGGL(k_edge3_tn, dim3((unsigned)wgs), dim3(512), 0, (hipStream_t)stream, act, img, workspace, B, ipw);
   p3_sum_slices(workspace, dW, (int64_t)kEF * kEK, wgs, (hipStream_t)stream);
   LAUNCH_CHECK("direct boundary weight gradient launch");
+  return 0;
+}
+
+// mvae_conv3_k4s2p1_nchw_wgrad(act, img, dW) and mvae_conv3_k4s2p1_nchw(img, W, NULL, mask, 0, y, y_planes) in ONE launch: the
+// backward pass of ConvTranspose2d(64, 3, 4, 2, 1) (conv_vae.py:54,74) -- img = the gradient of the logits, act = mask = the
+// layer's input b2 (whose ReLU the backward-data passes through).
+extern "C" int mvae_conv3_k4s2p1_nchw_backward(const float* act, const float* img, const float* W, float* dW, float* y,
+                                               uint16_t* y_planes, int64_t y_ps, int B, int C, int IH, int IW, int F,
+                                               float* workspace, void* stream) {
+  if (!act || !img || !W || !dW || !y || !workspace || B < 1) return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+  if (!edge_geometry(C, IH, IW, F)) return fail(MVAE_E_UNSUPPORTED, "direct boundary backward: 3 x 32 x 32, 64 features%s", "");
+  if (!aligned16(act) || !aligned16(workspace) || !aligned16(dW) || !aligned16(y) ||
+      (y_planes && (((uintptr_t)y_planes & 7) || (y_ps & 3))))
+    return fail(MVAE_E_ALIGN, "direct boundary backward: 16-byte aligned operands, 8-byte aligned planes%s", "");
+  const int ipw = edge_img_per_wg(B), wgs = (B + ipw - 1) / ipw, nrows = B * kEO;
+  hipLaunchKernelGGL(k_edge3_bwd, dim3((unsigned)(wgs + (nrows + 7) / 8)), dim3(512), 0, (hipStream_t)stream, act, img, workspace,
+                     B, ipw, wgs, W, act, y, y_planes, (long long)y_ps, nrows);
+  p3_sum_slices(workspace, dW, (int64_t)kEF * kEK, wgs, (hipStream_t)stream);
+  LAUNCH_CHECK("direct boundary backward launch");
   return 0;
 }

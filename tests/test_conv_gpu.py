@@ -1076,6 +1076,13 @@ def test_edge_layers_without_patch_matrix(dev, B):
     load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
     refw = act.double().cpu().t() @ col.double().cpu()
     assert_close(_cpu(out), refw.numpy(), 2e-5, "edge weight gradient", atol_frac=1e-5)
+    # both backward contractions of d3 in one launch: the same bits as the two launches
+    from mvae_amd.conv import _edge_backward
+    out2, yp2 = torch.empty(64, 48, device=dev), _new_planes(B * 256, 64, dev)
+    y2 = _edge_backward(act, img, W, out2, B, yp2)
+    load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out2, out)
+    assert torch.equal(y2, _edge_conv(img, W, None, act, False, B)) and torch.equal(_planes_sum(yp2), y2)
 
 
 @pytest.mark.parametrize("B", [32, 256])
