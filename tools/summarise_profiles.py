@@ -129,13 +129,17 @@ if os.path.exists(ct):
     raw = json.load(open(ct))
     SHAPES = {  # op -> (what, algorithmic bytes at B = 256: operands read once + result written once; planes are 6 B per f32)
         "e2f": ("e2 forward, implicit conv, f32", 256 * 64 * 128 * 4 + 512 * 2048 * 4 + 4096 * 512 * 4),
-        "d2f": ("d2 forward, implicit transposed conv, f32", 4096 * 512 * 4 + 512 * 2048 * 4 + 256 * 64 * 128 * 4),
-        "e1f": ("e1 forward (patch matrix form), f32", 16384 * 1024 * 4 + 128 * 1024 * 4 + 16384 * 128 * 4),
-        "d1f": ("d1 forward product, f32", 16384 * 128 * 4 + 1024 * 128 * 4 + 16384 * 1024 * 4),
-        "db1": ("backward-data of d2 (implicit conv on planes)", 256 * 64 * 128 * 6 + 512 * 2048 * 6 + 4096 * 512 * 10),
+        "d2f": ("d2 forward, implicit transposed conv, f32", 16384 * 256 * 4 + 256 * 1024 * 4 + 65536 * 64 * 4),
+        "e1f": ("e1 forward, implicit conv, f32", 256 * 256 * 64 * 4 + 128 * 1024 * 4 + 16384 * 128 * 4),
+        "d1f": ("d1 forward, implicit transposed conv, f32", 4096 * 128 * 4 + 128 * 4096 * 4 + 16384 * 256 * 4),
+        "db1": ("backward-data of d2 (implicit conv on planes)", 65536 * 64 * 6 + 256 * 1024 * 6 + 16384 * 256 * 10),
         "da1": ("backward-data of e2 (product on planes)", 4096 * 512 * 6 + 512 * 2048 * 6 + 4096 * 2048 * 4),
-        "dWe2": ("weight gradient of e2 (planes, split over rows)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 512 * 2048 * 4),
-        "dWd2": ("weight gradient of d2 (planes, split over rows)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 512 * 2048 * 4),
+        "dt0": ("backward-data of d1 (implicit conv on planes, 8 K slices)", 16384 * 256 * 6 + 128 * 4096 * 6 + 8 * 4096 * 128 * 4),
+        "da0": ("backward-data of e1 (implicit transposed conv on planes)", 16384 * 128 * 6 + 128 * 1024 * 6 + 65536 * 64 * 4),
+        "dWd1": ("weight gradient of d1 (planes, split over rows)", 4096 * 128 * 6 + 16384 * 256 * 6 + 8 * 128 * 4096 * 4),
+        "dWe1": ("weight gradient of e1 (planes, split over rows)", 16384 * 128 * 6 + 65536 * 64 * 6 + 32 * 128 * 1024 * 4),
+        "dWe2": ("weight gradient of e2 (planes, 4 row slices)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 4 * 512 * 2048 * 4),
+        "dWd2": ("weight gradient of d2 (planes, 16 row slices)", 16384 * 256 * 6 + 65536 * 64 * 6 + 16 * 256 * 1024 * 4),
     }
     kern = {}
     for op, r in raw.items():
