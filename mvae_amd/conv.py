@@ -854,12 +854,14 @@ class ConvEngine:
         if da2_p is None:
             da2_p = _split_planes([da2])[0]
         _colsum(da2, out=GV["e2.bias"])
-        if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "0") == "1" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
-            _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
-            # backward-data of e2 as four implicit contractions per output parity class (no [B * 16, 2048] product, no col2im):
-            # measured 0.836 / 0.830 against 0.839 / 0.833 ms per step for the product + col2im form -- inside the noise, so the
-            # product form (whose summation order the reference-step test margins were recorded with) stays the default
-            da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True)
+        if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "1") != "0" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
+            # backward-data of e2 as four implicit contractions per output parity class (no [B * 16, 2048] product, no col2im:
+            # 256 workgroups with 64 K steps each instead of two rounds of 16-step ones).  Equal to the product form until the
+            # transposed-convolution kernels took alternate K steps; now 0.744 -> 0.717 ms (mode 2), 0.631 -> 0.609 (mode 1).
+            # MVAE_CONV_DA1_IMPLICIT=0: product + col2im.
+            with _p3_group(dev):
+                _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
+                da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True)
         else:
             da1_p = _new_planes(B * 64, 128, dev)
             with _p3_group(dev):
