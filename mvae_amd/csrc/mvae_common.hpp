@@ -663,14 +663,14 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
                                                    float* db, float* dx, int M, int N, int K, int relu_in,
                                                    unsigned short* dx_planes = nullptr, long long dx_ps = 0) {
   __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
-  __shared__ f32x4 sm[32][9];
+  __shared__ f32x4 smn[NN][32][9];
   const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
   if (blk == K / 32) {  // db[n] = sum_m dy[m][n]
     const int cn = tid & 15, gn = tid >> 4;
     float s = 0.f;
     if (cn < N)
       for (int m = gn; m < M; m += 16) s += dy[(size_t)m * N + cn];
-    float* sf = reinterpret_cast<float*>(&sm[0][0]);
+    float* sf = reinterpret_cast<float*>(&smn[0][0][0]);
     sf[gn * 17 + cn] = s;
     __syncthreads();
     if (gn == 0 && cn < N) {
@@ -744,19 +744,24 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
       }
     }
   }
+  // the 32 row groups' partial dW rows meet in LDS: all NN outputs at once (one barrier; NN x 8 threads add their (output, column
+  // quad) over the groups in group order -- the same additions as one output per barrier pair, which cost 2 NN barriers)
+  __syncthreads();  // (the last chunk's readers of dy_s are done: smn may alias nothing, but keep the phases apart)
 #pragma unroll
-  for (int n = 0; n < NN; ++n) {  // (no early exit: a `break` keeps the loop rolled and acc[] in scratch memory)
-    __syncthreads();
-    sm[g][c] = acc[n];
-    __syncthreads();
-    if (g == 0 && n < N) {
+  for (int n = 0; n < NN; ++n) smn[n][g][c] = acc[n];
+  __syncthreads();
+  if (tid < NN * 8) {
+    const int n = tid >> 3, c2 = tid & 7;
+    if (n < N) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < 32; ++q) t += sm[q][c];
+      for (int q = 0; q < 32; ++q) t += smn[n][q][c2];
+      const int col2 = blk * 32 + c2 * 4;
       if (CL) {
+        const int wp2 = col2 / Cch, wc2 = col2 - wp2 * Cch;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dW[(size_t)n * K + (wc + j) * 16 + wp] = t[j];
+        for (int j = 0; j < 4; ++j) dW[(size_t)n * K + (wc2 + j) * 16 + wp2] = t[j];
       } else {
-        *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col) = t;
+        *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col2) = t;
       }
     }
   }

@@ -230,7 +230,7 @@ __device__ __forceinline__ void batch_stats_body(const float* bce, const float* 
     return r;
   };
   float b = 0.f, e = 0.f;
-  for (int r = tid; r < B; r += 256) {
+  for (int r = tid; r < B && tid < 256; r += 256) {  // (the first four waves: callers may run with eight)
     float klr = kl[r];
     int i = 1;
     for (; i + 7 < ncomp; i += 8) {  // 8 loads in flight, added in index order
@@ -249,7 +249,7 @@ __device__ __forceinline__ void batch_stats_body(const float* bce, const float* 
   float kt = 0.f;
   for (int i = 0; i < ncomp; ++i) {
     float a = 0.f;
-    for (int r = tid; r < B; r += 256) a += kl[(size_t)i * B + r];
+    for (int r = tid; r < B && tid < 256; r += 256) a += kl[(size_t)i * B + r];
     const float sres = block_sum(a);
     kt += sres;
     if (tid == 0) {
@@ -1712,14 +1712,14 @@ extern "C" int mvae_convt_to3_k4s2p1_forward(const float* src, const float* W, c
 // in the training step; the contraction index runs in the order (16 j + 4 (lane >> 4) + e), j, e = 0..3, so that ONE 16-byte
 // load per lane and j feeds four MFMA steps.  Fixed geometry as k_convT_to3_fwd.
 constexpr int kPS = kBK + 1;  // LDS row stride of P (floats)
-__global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ src, const float* __restrict__ W,
+__global__ __launch_bounds__(512) void k_d3_bce_stats(const float* __restrict__ src, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ x,
                                                       float* __restrict__ logits, float* bce, float* g, const float* kl,
                                                       float* stats, float beta, int B, int ncomp, float* chan_part,
                                                       float* dbias, int* counter) {
   __shared__ float Ps[kBO * kBO * kPS];  // 50 KB
-  __shared__ float sm[4];
-  __shared__ float chs[4][8];
+  __shared__ float sm[8];
+  __shared__ float chs[8][8];
   __shared__ int last_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int r = blockIdx.x;
@@ -1730,16 +1730,17 @@ __global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) wf[u][4 * j + e] = W[(16 * j + 4 * l4 + e) * kBK + 16 * u + l15];
-  f32x4 av[4][4];
+  constexpr int GW = 2;  // 16-pixel groups per wave (8 waves: two per SIMD, one multiplies while the other loads / folds)
+  f32x4 av[GW][4];
 #pragma unroll
-  for (int gI = 0; gI < 4; ++gI) {
-    const int px = (wave * 4 + gI) * 16 + l15;
+  for (int gI = 0; gI < GW; ++gI) {
+    const int px = (wave * GW + gI) * 16 + l15;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       av[gI][j] = *reinterpret_cast<const f32x4*>(src + ((size_t)r * (kBO * kBO) + px) * kBF + 16 * j + 4 * l4);
   }
 #pragma unroll
-  for (int gI = 0; gI < 4; ++gI) {
+  for (int gI = 0; gI < GW; ++gI) {
     f32x4 acc[kBC];
 #pragma unroll
     for (int u = 0; u < kBC; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1753,21 +1754,21 @@ __global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < kBC; ++u)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Ps[((wave * 4 + gI) * 16 + 4 * l4 + rr) * kPS + 16 * u + l15] = acc[u][rr];
+      for (int rr = 0; rr < 4; ++rr) Ps[((wave * GW + gI) * 16 + 4 * l4 + rr) * kPS + 16 * u + l15] = acc[u][rr];
   }
   __syncthreads();
   constexpr int HW = kBH * kBH, D = kBC * HW;
   const float* tl = x + (size_t)r * D;
   float* gl = g + (size_t)r * D;
   float* ll = logits + (size_t)r * D;
-  const int idx = tid * 4, Y = idx >> 5, X0 = idx & 31, ky0 = (Y + 1) & 1;
+  const int idx = tid * 2, Y = idx >> 5, X0 = idx & 31, ky0 = (Y + 1) & 1;  // two consecutive outputs per thread and channel
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < kBC; ++c) {
     const float bc = bias ? bias[c] : 0.f;
-    f32x4 y;
+    float y[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int X = X0 + u, kx0 = (X + 1) & 1;
       float a = 0.f;
 #pragma unroll
@@ -1781,18 +1782,19 @@ __global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ 
       }
       y[u] = a + bc;
     }
-    const f32x4 t = *reinterpret_cast<const f32x4*>(tl + c * HW + idx);
-    f32x4 gv;
+    const float2 t2 = *reinterpret_cast<const float2*>(tl + c * HW + idx);
+    const float t[2] = {t2.x, t2.y};
+    float gv[2];
     float cs = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const float e = mvf::fexp(-fabsf(y[u]));
       gv[u] = ((y[u] >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e)) - t[u];
       s += (1.f - t[u]) * y[u] - (fminf(y[u], 0.f) - mvf::log1p_pos(e));
       cs += gv[u];
     }
-    *reinterpret_cast<f32x4*>(ll + c * HW + idx) = y;
-    *reinterpret_cast<f32x4*>(gl + c * HW + idx) = gv;
+    *reinterpret_cast<float2*>(ll + c * HW + idx) = float2{y[0], y[1]};
+    *reinterpret_cast<float2*>(gl + c * HW + idx) = float2{gv[0], gv[1]};
     cs = wave_sum(cs);
     if (lane == 0) chs[wave][c] = cs;
   }
@@ -1800,8 +1802,10 @@ __global__ __launch_bounds__(256) void k_d3_bce_stats(const float* __restrict__ 
   if (lane == 0) sm[wave] = s;
   __syncthreads();
   // (from here on: k_bce_stats, see there)
-  if (tid == 0) store4_wt(bce, (size_t)r, (sm[0] + sm[1]) + (sm[2] + sm[3]));
-  if (tid < kBC) store4_wt(chan_part, (size_t)r * kBC + tid, (chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid]));
+  if (tid == 0) store4_wt(bce, (size_t)r, ((sm[0] + sm[1]) + (sm[2] + sm[3])) + ((sm[4] + sm[5]) + (sm[6] + sm[7])));
+  if (tid < kBC)
+    store4_wt(chan_part, (size_t)r * kBC + tid, ((chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid])) +
+                                                    ((chs[4][tid] + chs[5][tid]) + (chs[6][tid] + chs[7][tid])));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -1842,7 +1846,7 @@ extern "C" int mvae_convt_to3_bce_stats(const float* src, const float* W, const 
     return fail(MVAE_E_UNSUPPORTED, "fused last layer + loss end: 64 features to 3 x 32 x 32%s", "");
   if (((((uintptr_t)src) | ((uintptr_t)x) | ((uintptr_t)logits) | ((uintptr_t)g)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "mvae_convt_to3_bce_stats needs 16-byte aligned src / x / logits / g%s", "");
-  hipLaunchKernelGGL(k_d3_bce_stats, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, src, W, bias, x, logits, bce, g, kl,
+  hipLaunchKernelGGL(k_d3_bce_stats, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, src, W, bias, x, logits, bce, g, kl,
                      stats, beta, (int)B, ncomp, chan_part, dbias, counter);
   LAUNCH_CHECK("fused last layer + loss end launch");
   return 0;
