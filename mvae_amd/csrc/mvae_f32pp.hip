@@ -40,9 +40,20 @@ struct F32Args {
   ConvGeom cg;
   int lCc;
   int gx;  // XCD-aware tile order: the 8 XCDs as gx column groups x 8 / gx row groups (0: dispatch order)
+  int dbg; // (-DMV_F32PP_DBG builds) bit 1: no DMA, bit 3: no MFMAs, bit 6: no fragment reads (env MV_F32PP_DBG)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_f32pp_zero[4];
+#ifdef MV_F32PP_DBG
+// (debug builds) cycle stamps of the phases of K step 8 in waves 0 and 4 of workgroup 0: tools/f32pp_phase_times.py
+__device__ unsigned long long g_f32pp_stamps[32];
+extern "C" int mvae_f32pp_debug_stamps(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_f32pp_stamps), 32 * sizeof(unsigned long long));
+}
+#define MV_F32PP_STAMP(i) do { if (stamp) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MV_F32PP_STAMP(i) do {} while (0)
+#endif
 
 template <int BM, int BN, int WR, int AF, int BF, int KS = 32>
 __global__ __launch_bounds__(512) void k_gemm_f32pp(const F32Args g) {
@@ -146,23 +157,42 @@ __global__ __launch_bounds__(512) void k_gemm_f32pp(const F32Args g) {
   for (int i = 0; i < UA; ++i) inva[i] = a_inv(wave + NW * i);
 #pragma unroll
   for (int i = 0; i < UB; ++i) invb[i] = b_inv(wave + NW * i);
-  auto dma = [&](const float* base, long long off, bool ok, int dst) __attribute__((always_inline)) {
-    const long long zoff = (long long)((uintptr_t)zero - (uintptr_t)base) >> 2;  // (outside the image: 16 zero bytes)
-    const float* src = base + (ok ? off : zoff);
+  // The address of a piece's 16 bytes per lane.  The f32-input MFMA of the partner wave leaves the load phase almost no issue
+  // slots (tools/f32pp_phase_times.py: a load phase with NOTHING in it but its address arithmetic takes 1004 cycles next to the
+  // partner's 1068-cycle MFMA phase, 464 without it: unlike the bf16 MFMA, the 8-pass f32 MFMA does not co-issue with another
+  // wave's VALU work), so every VALU instruction of this phase is step time.  Hence: the full gather arithmetic (pixel, bounds,
+  // 64-bit address: ~14 VALU per piece, several of them 64-bit) runs only when the K step enters a new TAP; within a tap the
+  // source advances by KS floats, one select + one 64-bit add per piece.
+  const float* pa[UA];
+  bool oka[UA];
+  const float* pb[UB];
+  auto dma = [&](const float* src, int dst) __attribute__((always_inline)) {
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(lds + dst), 16, 0, 0);
   };
   auto issue = [&](int buf, int k0) __attribute__((always_inline)) {
+    const bool fresh = AF == FA_KC ? true : ((k0 & ((1 << g.lCc) - 1)) == 0);  // uniform
 #pragma unroll
     for (int i = 0; i < UA; ++i) {
-      bool ok;
-      const long long off = a_off(inva[i], k0, &ok);
-      dma(g.A, off, ok, buf * SB + (wave + NW * i) * 1024);
+      if (fresh) {
+        bool ok;
+        const long long off = a_off(inva[i], k0, &ok);
+        oka[i] = ok;
+        pa[i] = ok ? g.A + off : zero;
+      } else {
+        pa[i] += oka[i] ? KS : 0;
+      }
+      dma(pa[i], buf * SB + (wave + NW * i) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
-      bool ok;
-      const long long off = b_off(invb[i], k0, &ok);
-      dma(g.B, off, ok, buf * SB + PLA + (wave + NW * i) * 1024);
+      if (BF != FB_G3W || fresh) {
+        bool ok;
+        const long long off = b_off(invb[i], k0, &ok);
+        pb[i] = g.B + off;
+      } else {
+        pb[i] += (long long)KS * g.ldb;  // (the same tap: KS rows further down the same column block)
+      }
+      dma(pb[i], buf * SB + PLA + (wave + NW * i) * 1024);
     }
   };
 
@@ -257,21 +287,47 @@ __global__ __launch_bounds__(512) void k_gemm_f32pp(const F32Args g) {
   wait_dma(true);
   barrier();
   if (grp == 1) barrier();  // group 1 starts one phase late
+#ifdef MV_F32PP_DBG
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   auto step = [&](int t, auto buf, auto buf_fill) __attribute__((always_inline)) {
+#ifdef MV_F32PP_DBG
+    const bool stamp = t == 8 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && (wave & 3) == 0;
+#endif
+    MV_F32PP_STAMP(0);
+#ifdef MV_F32PP_DBG
+    if (!(g.dbg & 64)) load(f, buf);
+    if (!(g.dbg & 2)) issue(decltype(buf_fill)::value, tile_k(t + 2));
+#else
     load(f, buf);                                     // L: fragments of tile t, requests of tile t + 2
     issue(decltype(buf_fill)::value, tile_k(t + 2));
+#endif
+    MV_F32PP_STAMP(1);
     if (grp == 1) wait_dma(false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MV_F32PP_STAMP(2);
     barrier();
+    MV_F32PP_STAMP(3);
 #if MV_F32PP_PRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef MV_F32PP_DBG
+    if (!(g.dbg & 8)) mma(f);
+#else
     mma(f);                                           // C
+#endif
 #if MV_F32PP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+    MV_F32PP_STAMP(4);
     if (grp == 0) wait_dma(false);
+    MV_F32PP_STAMP(5);
     barrier();
+    MV_F32PP_STAMP(6);
+#ifdef MV_F32PP_DBG
+    if (stamp && lane == 0)
+      for (int i = 0; i < 7; ++i) g_f32pp_stamps[grp * 16 + i] = ts[i];
+#endif
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -346,6 +402,9 @@ static void launch_f32pp(const F32Args& a0, int zdim, hipStream_t s) {
     }
   }
   dim3 grid(nx, ny, zdim);
+#ifdef MV_F32PP_DBG
+  a.dbg = getenv("MV_F32PP_DBG") ? atoi(getenv("MV_F32PP_DBG")) : 0;
+#endif
   hipLaunchKernelGGL((k_gemm_f32pp<BM, BN, WR, AF, BF, KS>), grid, dim3(512), 0, s, a);
 }
 bool f32pp_try(int form, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, bf16r* Cp,
