@@ -370,7 +370,8 @@ int mvae_p3_group(int on, void* stream);
 /* mvae_conv_k4s2p1_nhwc (a Conv2d forward, conv_vae.py:47-50,57-63, or the backward-data of a ConvTranspose2d,
  * conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of Wt [OC, 16 C]; y = mask(relu(sum + bias)) (bias NULL: none;
  * relu 0: none; mask NULL: none) in f32, its planes too when y_planes != NULL (not together with a split-K workspace, which
- * only a call without bias / relu / mask uses). */
+ * only a call without bias / relu / mask uses).  y = NULL with a workspace that holds K slices: they are left there un-added (slice
+ * count = workspace floats / (B OH OW OC)) for a consumer that adds them itself, mvae_conv_latent_backward. */
 int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
 int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
                              const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes, int64_t y_ps, int B,
@@ -432,6 +433,8 @@ int mvae_convt_to3_bce_stats(const float* src, const float* W, const float* bias
  * mvae_conv_latent_workspace_floats(B, ncomp) floats, 16-byte aligned, scratch of one call.  Forward writes heads [B, heads_dim], z [B, z_dim],
  * kl [ncomp, B], t0.  Backward (loss = <dt0, t0> + beta * sum kl) writes dW_heads, db_heads, da2 (already masked by the
  * encoder's last ReLU), dW_d0, db_d0, dradii [ncomp] (0 for Euclidean components; fixed-order sums) and dheads [B, heads_dim]. 
+ * dt0_slices > 1: dt0 points at that many partial results dt0_slice_stride floats apart (the K slices mvae_conv_k4s2p1_nhwc_p3
+ * leaves in its workspace when called with y = NULL), added in mvae's slice-sum order while they are read; <= 1: one tensor.
  * t0_planes / da2_planes (NULL: none): the bf16 planes (mvae_split3_planes layout, plane stride *_ps elements) of t0 and da2,
  * written by the same launches for the plane contractions that consume them. */
 int mvae_conv_latent_supported(const mvae_component_desc* comps, int ncomp);
@@ -442,7 +445,8 @@ int mvae_conv_latent_forward(const mvae_component_desc* comps, int ncomp, const 
                              int64_t t0_ps, float* workspace, int64_t B, void* stream);
 int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const float* a2, const float* W_heads,
                               const float* heads, const float* eps, int eps_ld, const float* radii, const float* z,
-                              const float* W_d0, const float* t0, const float* dt0, float beta, float* dW_heads,
+                              const float* W_d0, const float* t0, const float* dt0, int dt0_slices,
+                              int64_t dt0_slice_stride, float beta, float* dW_heads,
                               float* db_heads, float* da2, uint16_t* da2_planes, int64_t da2_ps, float* dW_d0,
                               float* db_d0, float* dradii, float* dheads, float* workspace, int64_t B, void* stream);
 /* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable

@@ -155,14 +155,20 @@ class _p3_group:
 
 def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int,
                   want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
-                  out_planes: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+                  out_planes: Optional[Tensor] = None, keep_slices: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     """_conv_nhwc (a Conv2d forward with bias / relu, or the backward-data of a ConvTranspose2d with mask) on planes: src_p
-    [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] -> (y [B*(IH/2)^2, OC] f32, its planes or None)."""
+    [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] -> (y [B*(IH/2)^2, OC] f32, its planes or None).  keep_slices: when the call cuts K
+    into slices, return them un-added, [slices, M, OC], for a consumer that adds them while reading (the latent backward)."""
     OC = Wt_p.shape[1]
     M = B * (IH // 2) * (IH // 2)
-    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
     epilogue = mask is not None or bias is not None or relu
     nws = int(load().mvae_conv_k4s2p1_nhwc_p3_workspace_floats(B, Cc, IH, IH, OC, 1 if epilogue else 0))
+    if keep_slices and nws > 0:
+        ws = torch.empty(nws // (M * OC), M, OC, dtype=torch.float32, device=src_p.device)
+        check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), None, None, 0, None, None, 0,
+                                              B, Cc, IH, IH, OC, ptr(ws), stream_ptr(ws.device)))
+        return ws, None
+    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
     ws = y.new_empty(nws) if nws > 0 else None  # split-K slices, added in index order right away (y is an intermediate)
     yp = out_planes if out_planes is not None else (_new_planes(M, OC, y.device) if (want_planes and nws == 0) else None)
     check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias), 1 if relu else 0,
@@ -765,7 +771,7 @@ class ConvEngine:
             epsc = eps.contiguous()
             check(load().mvae_conv_latent_backward(
                 lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
-                epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
+                epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0), 1, 0,
                 float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), None, 0,
                 ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
                 stream_ptr(self.device)))
@@ -806,7 +812,7 @@ class ConvEngine:
         check(load().mvae_conv_latent_backward(
             lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
             epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
-            float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), _pptr(planes),
+            dt0.shape[0] if dt0.dim() == 3 else 1, dt0[0].numel() if dt0.dim() == 3 else 0, float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), _pptr(planes),
             _ps(planes), ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
             stream_ptr(self.device)))
         return dhflat
@@ -844,7 +850,8 @@ class ConvEngine:
         _colsum(db2, out=GV["d2.bias"])
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
-            dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8)  # [B*16, 128]
+            # [B*16, 128]; with the fused latent section its K slices stay un-added (the latent backward adds them as it reads)
+            dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8, keep_slices=bool(c.get("fused")) and os.environ.get("MVAE_CONV_DT0_SLICES", "1") != "0")
         _colsum(db1, out=GV["d1.bias"])
         # ---- latent section
         da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None

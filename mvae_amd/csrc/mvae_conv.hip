@@ -2014,6 +2014,7 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
                                                             const float* __restrict__ radii,
                                                             const float* __restrict__ W_d0, int Z,
                                                             const float* __restrict__ t0, const float* __restrict__ dt0,
+                                                            const int dt0_slices, const long long dt0_stride,
                                                             float beta, float* __restrict__ dd0,
                                                             float* __restrict__ dheads, float* __restrict__ drad_rows,
                                                             int B) {
@@ -2035,7 +2036,20 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid * 4 + 1024 * i, pp = idx >> 7, cc = idx & 127;
-    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dt0 + (size_t)r * kD0 + idx);
+    f32x4 d4;
+    if (dt0_slices <= 1) {
+      d4 = *reinterpret_cast<const f32x4*>(dt0 + (size_t)r * kD0 + idx);
+    } else {
+      // dt0 arrives as the K slices of its contraction: added here in k_sum_slices' order (four partial sums over the slices
+      // k = w, w + 4, ..., then (p0 + p1) + (p2 + p3)) instead of by a launch of its own
+      f32x4 ps[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        ps[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = w; k < dt0_slices; k += 4) ps[w] += *reinterpret_cast<const f32x4*>(dt0 + (size_t)k * dt0_stride + (size_t)r * kD0 + idx);
+      }
+      d4 = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    }
     const f32x4 m4 = *reinterpret_cast<const f32x4*>(t0 + (size_t)r * kD0 + idx);
     f32x4 v;
 #pragma unroll
@@ -2252,7 +2266,8 @@ extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int nc
 extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const float* a2,
                                          const float* W_heads, const float* heads, const float* eps, int eps_ld,
                                          const float* radii, const float* z, const float* W_d0, const float* t0,
-                                         const float* dt0, float beta, float* dW_heads, float* db_heads, float* da2,
+                                         const float* dt0, int dt0_slices, int64_t dt0_slice_stride, float beta,
+                                         float* dW_heads, float* db_heads, float* da2,
                                          uint16_t* da2_planes, int64_t da2_ps, float* dW_d0, float* db_d0, float* dradii,
                                          float* dheads, float* workspace, int64_t B, void* stream) {
   if (!a2 || !W_heads || !heads || !eps || !z || !W_d0 || !t0 || !dt0 || !dW_heads || !db_heads || !da2 || !dW_d0 ||
@@ -2281,7 +2296,8 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
   float* dd0 = workspace;
   float* drad_rows = workspace + (size_t)B * kD0;
   MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_bwd_rows<DM>), dim3((unsigned)B), dim3(256), 0, s, t, heads, NH,
-                                             eps, eps_ld, radii, W_d0, Z, t0, dt0, beta, dd0, dheads, drad_rows, (int)B));
+                                             eps, eps_ld, radii, W_d0, Z, t0, dt0, dt0_slices,
+                                             (long long)dt0_slice_stride, beta, dd0, dheads, drad_rows, (int)B));
   const unsigned grid = kFlat / 32 + 1 + kD0 / 32 + 1;
   MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_latent_bwd_cols<NN>), dim3(grid), dim3(256), 0, s, t, a2, W_heads, dheads,
                                          NH, dW_heads, db_heads, da2, da2_planes, (long long)da2_ps, dd0, z, Z, dW_d0, db_d0,

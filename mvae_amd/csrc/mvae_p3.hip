@@ -861,20 +861,22 @@ static int p3_geom(ConvGeom* g, int* lCc, int B, int Cc, int IH, int IW, bool ou
 extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
                                         const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes,
                                         int64_t y_ps, int B, int Cc, int IH, int IW, int OC, float* workspace, void* stream) {
-  if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (!src_planes || !Wt_planes) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
   const int K = 16 * Cc;
   if (!mvae_p3_supported(0, M, OC, K, Cc)) return fail(MVAE_E_UNSUPPORTED, "mvae_conv_k4s2p1_nhwc_p3: whole 128 x 128 tiles only%s", "");
   P3Args a{};
   int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, true);
   if (rc) return rc;
-  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, K, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
+  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, K, w_ps) || (y && !aligned16(y)) || (mask && !aligned16(mask)) ||
       (bias && !aligned16(bias)) || (y_planes && !planes_ok(y_planes, OC, y_ps)))
     return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
   const bool fwd = bias != nullptr || relu != 0;  // a layer's forward pass: the epilogue needs the whole sum, no K slices
   int kps;
   const int slices = (workspace && !fwd) ? p3_conv_slices(M, OC, K, mask != nullptr, &kps) : 1;
   a.bias = bias; a.relu = relu;
+  // y == NULL: the K slices stay in the workspace for a consumer that adds them itself (mvae_conv_latent_backward's dt0)
+  if (!y && slices < 2) return fail(MVAE_E_BADARG, "y may only be NULL when the call leaves K slices in its workspace%s", "");
   a.A = src_planes; a.lda = Cc; a.psa = src_ps;
   a.B = Wt_planes; a.ldb = K; a.psb = w_ps;
   a.ldc = OC; a.M = (int)M; a.N = OC; a.K = K;
@@ -883,7 +885,7 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
     a.C = workspace; a.Cp = nullptr; a.psc = 0; a.mask = nullptr; a.k_per_slice = kps; a.slice_stride = M * OC;
     launch_p3<128, 128, 2, A_G1, B_KC>(a, slices, (hipStream_t)stream);
     if (y_planes) return fail(MVAE_E_UNSUPPORTED, "planes of a split-K result are not produced%s", "");
-    p3_sum_after(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
+    if (y) p3_sum_after(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
   } else {
     a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0;
     // 128 x 64 tiles where 128 x 128 ones would leave CUs without a workgroup (the forward layers: 128 tiles each)

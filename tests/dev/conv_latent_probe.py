@@ -51,7 +51,7 @@ dWd = torch.empty_like(Wd); dbd = torch.empty(2048, device=dev); drad = torch.em
 dheads = torch.empty(B, NH, device=dev)
 # feed the GENERIC forward values so that only the backward kernels are compared
 check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
-                                       ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), beta, ptr(dW), ptr(dbh), ptr(da2),
+                                       ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), 1, 0, beta, ptr(dW), ptr(dbh), ptr(da2),
                                        None, 0, ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads), ptr(ws), B, stream_ptr(dev)))
 torch.cuda.synchronize()
 print("dheads", rel(dheads, dheads_g), "drad", rel(drad, drad_g), "dW_heads", rel(dW, dW_g), "db_heads", rel(dbh, dbh_g),

@@ -616,10 +616,24 @@ def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
     dW, dbh, da2, dWd, dbd, drad, dheads = new(NH, 8192), new(NH), new(B, 8192), new(2048, Z), new(2048), new(n), new(B, NH)
     da2_p = torch.empty(3, B, 8192, dtype=torch.bfloat16, device=dev)
     check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
-                                           ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), beta, ptr(dW), ptr(dbh), ptr(da2),
+                                           ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), 1, 0, beta, ptr(dW), ptr(dbh), ptr(da2),
                                            da2_p.data_ptr(), da2_p[0].numel(), ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads),
                                            ptr(ws), B, stream_ptr(dev)))
     assert torch.equal(_planes_sum(da2_p), da2), "da2 planes are not the exact split of da2"
+    # dt0 handed over as the un-added K slices of its contraction: [a, 0, 0, 0, b, 0] with a + b = dt0 exactly (a = dt0 with its
+    # low 12 mantissa bits cleared) must give the same bits as dt0 itself -- the kernel adds slices k = w, w + 4, ... like
+    # k_sum_slices
+    a_part = (dt0.view(torch.int32) & ~0xFFF).view(torch.float32)
+    sl = torch.zeros(6, *dt0.shape, device=dev)
+    sl[0], sl[4] = a_part, dt0 - a_part
+    assert torch.equal(sl[0] + sl[4], dt0)
+    outs2 = [torch.empty_like(x) for x in (dW, dbh, da2, dWd, dbd, drad, dheads)]
+    check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
+                                           ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(sl), 6, sl[0].numel(), beta, ptr(outs2[0]),
+                                           ptr(outs2[1]), ptr(outs2[2]), None, 0, ptr(outs2[3]), ptr(outs2[4]), ptr(outs2[5]),
+                                           ptr(outs2[6]), ptr(ws), B, stream_ptr(dev)))
+    for x, y_, nm in zip((dW, dbh, da2, dWd, dbd, drad, dheads), outs2, ("dW", "dbh", "da2", "dWd", "dbd", "drad", "dheads")):
+        assert torch.equal(x, y_), nm + " differs when dt0 arrives as slices"
     for got, want, nm in [(dheads, dheads_g, "dheads"), (drad, drad_g, "dradii"), (dW, dW_g, "dW_heads"),
                           (dbh, dbh_g, "db_heads"), (da2, dh_g, "da2"), (dWd, dWd_g, "dW_d0"), (dbd, dbd_g, "db_d0")]:
         assert_close(_cpu(got), _cpu(want), 2e-5, nm, atol_frac=2e-5)
