@@ -227,6 +227,17 @@ int mvae_component_backward(const mvae_component_desc* comps, int ncomp, const f
                             const float* eps, int eps_ld, const float* radii, const float* dz, int z_ld,
                             const float* dkl, float dkl_scalar, float* dheads, float* dradii, float* workspace,
                             int64_t rows, void* stream);
+/* The two operators above with every intermediate of the latent chain in FLOAT64 (the reference CLI's default numerics,
+ * run.py:77,98-101) between float32 tensors: heads / eps / radii in, z / kl / log-probabilities / gradients out are float32,
+ * softplus, exp map, transport, log map, log-det, log-probabilities and their derivatives are evaluated in double (libm).  Same
+ * arguments and error behaviour; true dimensions <= 8 (MVAE_E_UNSUPPORTED above).  In float32 the sphere's <mu, z> / R^2 and
+ * the hyperboloid's Lorentz product lose 3-4 digits at the warm-up radii and acos' needs a cap at |x| = 1; here neither. */
+int mvae_component_forward_f64(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld, const float* eps,
+                               int eps_ld, const float* radii, float* z, int z_ld, float* kl, float* log_q, float* log_p,
+                               float* mu, float* sd, int64_t rows, int64_t head_rows, void* stream);
+int mvae_component_backward_f64(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld, const float* eps,
+                                int eps_ld, const float* radii, const float* dz, int z_ld, const float* dkl, float dkl_scalar,
+                                float* dheads, float* dradii, float* workspace, int64_t rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Dense layers (torch.nn.Linear semantics: y = x W^T + b, W is [N, K]).  FeedForwardVAE.encode / decode,

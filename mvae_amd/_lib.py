@@ -68,6 +68,10 @@ PROTOTYPES = {
     "mvae_component_backward_workspace_floats": (C.c_int64, [_I, _L]),
     "mvae_component_backward": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _F, _P, _P, _P,
                                           _L, _P]),
+    "mvae_component_forward_f64": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P,
+                                         _L, _L, _P]),
+    "mvae_component_backward_f64": (C.c_int, [C.POINTER(ComponentDesc), _I, _P, _I, _P, _I, _P, _P, _I, _P, _F, _P, _P, _P,
+                                          _L, _P]),
     "mvae_scale_rows": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "mvae_linear_forward": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mvae_linear_forward_masked": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P]),

@@ -751,6 +751,108 @@ extern "C" int mvae_component_backward(const mvae_component_desc* comps, int nco
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ component kernels, float64 chain
+// run.py:77,98-101: the reference's CLI default computes in float64.  These are mvae_component_forward / _backward with every
+// intermediate of the latent chain in float64 (mvae_math.hpp "float64 number types"); heads, eps, radii, z, kl, the
+// gradients stay float32 tensors, i.e. the dense layers on either side are float32.  What it buys: in float32 the sphere's
+// alpha = <mu, z> / R^2 and the hyperboloid's <mu, z>_L / R^2 lose 3-4 digits at the warm-up radii and the
+// acos derivative needs its cap; here neither happens.  True dimensions <= 8 (the per-thread templates; no cooperative form).
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_comp_fwd64(CompTable t, const float* heads, int heads_ld, const float* eps, int eps_ld,
+                                                    const float* radii, float* z, int z_ld, float* kl, float* lq, float* lp,
+                                                    float* mu, float* sd, int64_t rows, int64_t head_rows) {
+  const int64_t items = rows * t.n;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t r = it % rows;
+    const int ci = (int)(it / rows);
+    const int64_t hr = r % head_rows;
+    const bool first = r < head_rows;
+    comp_fwd_row64<DMAX>(t.c[ci], heads + hr * heads_ld, eps + r * eps_ld, radii, z + r * z_ld,
+                         kl ? kl + (int64_t)ci * rows + r : nullptr, lq ? lq + (int64_t)ci * rows + r : nullptr,
+                         lp ? lp + (int64_t)ci * rows + r : nullptr, (mu && first) ? mu + hr * z_ld : nullptr,
+                         (sd && first) ? sd + hr * eps_ld : nullptr);
+  }
+}
+template <int DMAX>
+__global__ __launch_bounds__(256) void k_comp_bwd64(CompTable t, const float* heads, int heads_ld, const float* eps, int eps_ld,
+                                                    const float* radii, const float* dz, int z_ld, const float* dkl,
+                                                    float dkl_scalar, float* dheads, float* drad_rows, int64_t rows) {
+  const int64_t items = rows * t.total_dirs;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t r = it / t.total_dirs;
+    const int gd = (int)(it % t.total_dirs);
+    int ci = 0;
+    while (gd >= t.dir_off[ci + 1]) ++ci;
+    const int dir = gd - t.dir_off[ci];
+    const mvae_component_desc& c = t.c[ci];
+    const float w = dkl ? dkl[(int64_t)ci * rows + r] : dkl_scalar;
+    float g = comp_bwd_dir64<DMAX>(c, heads + r * heads_ld, eps + r * eps_ld, radii, dz + r * z_ld, w, dir);
+    if (dir < c.true_dim) dheads[r * heads_ld + c.mean_col + dir] = g;
+    else if (dir < c.true_dim + c.logvar_dim) dheads[r * heads_ld + c.logvar_col + (dir - c.true_dim)] = g;
+    else drad_rows[(int64_t)c.radius_idx * rows + r] = g;
+  }
+}
+#define DMAX_SWITCH64(dmax, ...)                                  \
+  if (bucket_of(dmax) <= 2) { constexpr int DM = 2; __VA_ARGS__; } \
+  else if (bucket_of(dmax) <= 4) { constexpr int DM = 4; __VA_ARGS__; } \
+  else { constexpr int DM = 8; __VA_ARGS__; }
+
+extern "C" int mvae_component_forward_f64(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                                          const float* eps, int eps_ld, const float* radii, float* z, int z_ld, float* kl,
+                                          float* log_q, float* log_p, float* mu, float* sd, int64_t rows, int64_t head_rows,
+                                          void* stream) {
+  if (!heads || !eps || !z || rows < 0 || head_rows < 1) return fail(MVAE_E_BADARG, "null pointer / bad rows%s", "");
+  if ((log_q == nullptr) != (log_p == nullptr)) return fail(MVAE_E_BADARG, "log_q and log_p go together%s", "");
+  CompTable t;
+  int dmax;
+  unsigned char all[kMaxComp];
+  memset(all, 1, sizeof(all));
+  int rc = fill_table(&t, comps, ncomp, all, &dmax);
+  if (rc) return rc;
+  if (bucket_of(dmax) > 8) return fail(MVAE_E_UNSUPPORTED, "float64 component chain: true dimensions <= 8%s", "");
+  for (int i = 0; i < ncomp; ++i)
+    if (comps[i].kind != MVAE_EUCLIDEAN && !radii) return fail(MVAE_E_BADARG, "radii is NULL%s", "");
+  if (rows == 0) return 0;
+  int grid = (int)((rows * ncomp + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  DMAX_SWITCH64(dmax, hipLaunchKernelGGL((k_comp_fwd64<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld, radii,
+                                         z, z_ld, kl, log_q, log_p, mu, sd, rows, head_rows));
+  LAUNCH_CHECK("float64 component forward launch");
+  return 0;
+}
+
+extern "C" int mvae_component_backward_f64(const mvae_component_desc* comps, int ncomp, const float* heads, int heads_ld,
+                                           const float* eps, int eps_ld, const float* radii, const float* dz, int z_ld,
+                                           const float* dkl, float dkl_scalar, float* dheads, float* dradii, float* workspace,
+                                           int64_t rows, void* stream) {
+  if (!heads || !eps || !dz || !dheads || rows < 0) return fail(MVAE_E_BADARG, "null pointer / bad rows%s", "");
+  if (dradii && !workspace) return fail(MVAE_E_BADARG, "dradii needs the [ncomp, rows] workspace%s", "");
+  CompTable t;
+  int dmax;
+  unsigned char tr[kMaxComp];
+  memset(tr, dradii ? 1 : 0, sizeof(tr));
+  int rc = fill_table(&t, comps, ncomp, tr, &dmax);
+  if (rc) return rc;
+  if (bucket_of(dmax) > 8) return fail(MVAE_E_UNSUPPORTED, "float64 component chain: true dimensions <= 8%s", "");
+  for (int i = 0; i < ncomp; ++i)
+    if (comps[i].radius_idx < 0 || comps[i].radius_idx >= ncomp)
+      return fail(MVAE_E_BADARG, "radius_idx out of range%s (%lld)", "", comps[i].radius_idx);
+  if (rows == 0) return 0;
+  int grid = (int)((rows * t.total_dirs + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dradii) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)ncomp * (size_t)rows, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+  }
+  DMAX_SWITCH64(dmax, hipLaunchKernelGGL((k_comp_bwd64<DM>), dim3(grid), dim3(256), 0, s, t, heads, heads_ld, eps, eps_ld, radii,
+                                         dz, z_ld, dkl, dkl_scalar, dheads, workspace, rows));
+  if (dradii) hipLaunchKernelGGL(k_rowsum_fixed, dim3(ncomp), dim3(256), 0, s, workspace, dradii, rows);
+  LAUNCH_CHECK("float64 component backward launch");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ dense layers (API)
 
 extern "C" int mvae_linear_forward(const float* x, const float* W, const float* b, float* y, int64_t M, int N, int K,

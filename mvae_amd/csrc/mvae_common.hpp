@@ -294,6 +294,60 @@ __device__ __forceinline__ float comp_bwd_dir(const mvae_component_desc& c, cons
   return g;
 }
 
+// ---- the same two in float64 (the latent chain between float32 dense layers; mvae_math.hpp "float64 number types"): inputs
+// and outputs stay float32 tensors, every intermediate of the chain is a double
+template <int DMAX>
+__device__ __forceinline__ void comp_fwd_row64(const mvae_component_desc& c, const float* heads_row, const float* eps_row,
+                                               const float* radii, float* z_row, float* kl, float* lq, float* lp,
+                                               float* mu_row, float* std_row) {
+  MV_BOUNDS(DMAX + 1);
+  double m[kN], l[kN], z[kN], mu[kN], sg[kN];
+  float e[kN];
+  const int d = c.true_dim, lvd = c.logvar_dim;
+  MV_FOR(i, 0, d) {
+    m[i] = (double)heads_row[c.mean_col + i];
+    e[i] = eps_row[c.eps_col + i];
+  }
+  MV_FOR(i, 0, lvd) l[i] = (double)heads_row[c.logvar_col + i];
+  double rp = (c.kind == kEuclidean) ? 0.0 : (double)radii[c.radius_idx];
+  double klv = 0.0, lqv = 0.0, lpv = 0.0;
+  comp_eval<DMAX, double>(c.kind, m, l, lvd, e, d, rp, z, kl ? &klv : nullptr, lq ? &lqv : nullptr, lq ? &lpv : nullptr,
+                          mu_row ? mu : nullptr, std_row ? sg : nullptr);
+  const int A = ambient_dim(c.kind, d);
+  MV_FOR(i, 0, A) z_row[c.z_col + i] = (float)z[i];
+  if (kl) *kl = (float)klv;
+  if (lq) {
+    *lq = (float)lqv;
+    *lp = (float)lpv;
+  }
+  if (mu_row) {
+    MV_FOR(i, 0, A) mu_row[c.z_col + i] = (float)mu[i];
+  }
+  if (std_row) {
+    MV_FOR(i, 0, lvd) std_row[c.eps_col + i] = (float)sg[i];
+  }
+}
+template <int DMAX>
+__device__ __forceinline__ float comp_bwd_dir64(const mvae_component_desc& c, const float* heads_row, const float* eps_row,
+                                                const float* radii, const float* dz_row, float dkl, int dir) {
+  MV_BOUNDS(DMAX + 1);
+  DualD m[kN], l[kN], z[kN];
+  float e[kN];
+  const int d = c.true_dim, lvd = c.logvar_dim;
+  MV_FOR(i, 0, d) {
+    m[i] = DualD{(double)heads_row[c.mean_col + i], (dir == i) ? 1.0 : 0.0};
+    e[i] = eps_row[c.eps_col + i];
+  }
+  MV_FOR(i, 0, lvd) l[i] = DualD{(double)heads_row[c.logvar_col + i], (dir == d + i) ? 1.0 : 0.0};
+  DualD rp = DualD{(c.kind == kEuclidean) ? 0.0 : (double)radii[c.radius_idx], (dir == d + lvd) ? 1.0 : 0.0};
+  DualD kl;
+  comp_eval<DMAX, DualD>(c.kind, m, l, lvd, e, d, rp, z, &kl, nullptr, nullptr, nullptr, nullptr);
+  const int A = ambient_dim(c.kind, d);
+  double g = (double)dkl * kl.d;
+  MV_FOR(i, 0, A) g += (double)dz_row[c.z_col + i] * z[i].d;
+  return (float)g;
+}
+
 // ------------------------------------------------------------------------------------------------ tile jobs
 // y tile = act(x W^T + b); all 256 threads of the workgroup participate.
 template <bool RELU>

@@ -151,6 +151,181 @@ __device__ __forceinline__ Dual t_softplus(Dual x) {
   return {lin ? x.v : mvf::log1p_pos(e), lin ? x.d : x.d * e / (e + 1.0f)};
 }
 
+// =================================================================================================== float64 number types
+// The reference's CLI default is float64 (`--doubles True`, run.py:77,98-101).  The manifold templates below are generic over the
+// number type; these are the overload sets they resolve against for T = double (values) and T = DualD (value + derivative along
+// one input direction), so that the stand-alone component operators can run the whole latent chain -- softplus, exp map,
+// parallel transport, log map, log-det, log-probabilities, KL -- in float64 between float32 dense layers
+// (mvae_component_forward_f64 / _backward_f64).  libm's double functions, no fast-math substitutes; bounds of the reference's
+// clamps are the same numbers (they are exact in both precisions or far from any value that matters).
+struct DualD {
+  double v, d;
+};
+__device__ __forceinline__ double val(double x) { return x; }
+__device__ __forceinline__ double val(DualD x) { return x.v; }
+template <> __device__ __forceinline__ double make<double>(float v, float) { return (double)v; }
+template <> __device__ __forceinline__ DualD make<DualD>(float v, float d) { return DualD{(double)v, (double)d}; }
+__device__ __forceinline__ double tan_of(double) { return 0.0; }
+__device__ __forceinline__ double tan_of(DualD x) { return x.d; }
+__device__ __forceinline__ float log_sqrt_2pi(float) { return kLogSqrt2Pi; }
+__device__ __forceinline__ float log_sqrt_2pi(Dual) { return kLogSqrt2Pi; }
+__device__ __forceinline__ double log_sqrt_2pi(double) { return 0.91893853320467274178; }
+__device__ __forceinline__ double log_sqrt_2pi(DualD) { return 0.91893853320467274178; }
+__device__ __forceinline__ float ln2_of(float) { return kLn2; }
+__device__ __forceinline__ float ln2_of(Dual) { return kLn2; }
+__device__ __forceinline__ double ln2_of(double) { return 0.69314718055994530942; }
+__device__ __forceinline__ double ln2_of(DualD) { return 0.69314718055994530942; }
+
+__device__ __forceinline__ DualD operator+(DualD a, DualD b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ DualD operator-(DualD a, DualD b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ DualD operator*(DualD a, DualD b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ DualD operator/(DualD a, DualD b) {
+  double q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ DualD operator-(DualD a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ DualD operator+(DualD a, double b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ DualD operator+(double a, DualD b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ DualD operator-(DualD a, double b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ DualD operator-(double a, DualD b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ DualD operator*(DualD a, double b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ DualD operator*(double a, DualD b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ DualD operator/(DualD a, double b) { return {a.v / b, a.d / b}; }
+__device__ __forceinline__ DualD operator/(double a, DualD b) {
+  double q = a / b.v;
+  return {q, -q * b.d / b.v};
+}
+
+__device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ DualD t_sqrt(DualD x) {
+  double s = sqrt(x.v);
+  return {s, x.d / (2.0 * s)};
+}
+__device__ __forceinline__ double t_exp(double x) { return exp(x); }
+__device__ __forceinline__ DualD t_exp(DualD x) {
+  double e = exp(x.v);
+  return {e, e * x.d};
+}
+__device__ __forceinline__ double t_log(double x) { return log(x); }
+__device__ __forceinline__ DualD t_log(DualD x) { return {log(x.v), x.d / x.v}; }
+__device__ __forceinline__ double t_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ DualD t_cosh(DualD x) { return {cosh(x.v), sinh(x.v) * x.d}; }
+__device__ __forceinline__ double t_sinh(double x) { return sinh(x); }
+__device__ __forceinline__ DualD t_sinh(DualD x) { return {sinh(x.v), cosh(x.v) * x.d}; }
+__device__ __forceinline__ double t_cos(double x) { return cos(x); }
+__device__ __forceinline__ DualD t_cos(DualD x) { return {cos(x.v), -sin(x.v) * x.d}; }
+__device__ __forceinline__ double t_sin(double x) { return sin(x); }
+__device__ __forceinline__ DualD t_sin(DualD x) { return {sin(x.v), cos(x.v) * x.d}; }
+__device__ __forceinline__ double t_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ DualD t_tanh(DualD x) {
+  double t = tanh(x.v);
+  return {t, (1.0 - t * t) * x.d};
+}
+__device__ __forceinline__ double t_tan(double x) { return tan(x); }
+__device__ __forceinline__ DualD t_tan(DualD x) {
+  const double t = tan(x.v);
+  return {t, (1.0 + t * t) * x.d};
+}
+__device__ __forceinline__ double t_atan(double x) { return atan(x); }
+__device__ __forceinline__ DualD t_atan(DualD x) { return {atan(x.v), x.d / (1.0 + x.v * x.v)}; }
+__device__ __forceinline__ double t_acos(double x) { return acos(x); }
+// ATen's rule as it stands (-inf at |x| = 1): in float64 <mu, z> / R^2 does not round to 1 (see the float version's comment)
+__device__ __forceinline__ DualD t_acos(DualD x) { return {acos(x.v), x.d * -(1.0 / sqrt(1.0 - x.v * x.v))}; }
+__device__ __forceinline__ double t_abs(double x) { return fabs(x); }
+__device__ __forceinline__ DualD t_abs(DualD x) {
+  double s = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0);
+  return {fabs(x.v), x.d * s};
+}
+__device__ __forceinline__ double t_relu(double x) { return x < 0.0 ? 0.0 : x; }
+__device__ __forceinline__ DualD t_relu(DualD x) { return x.v > 0.0 ? x : DualD{x.v < 0.0 ? 0.0 : x.v, 0.0}; }
+__device__ __forceinline__ double nclampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// (float bounds in the signatures: the templates pass float literals, and a (double, double, double) overload would make those
+// calls ambiguous with the float one)
+__device__ __forceinline__ double hard_clamp(double x, float lo, float hi) { return nclampd(x, lo, hi); }
+__device__ __forceinline__ DualD hard_clamp(DualD x, float lo, float hi) {
+  bool in = (x.v >= lo) && (x.v <= hi);
+  return {nclampd(x.v, lo, hi), in ? x.d : 0.0};
+}
+__device__ __forceinline__ double leaky_clamp(double x, float lo, float hi) { return nclampd(x, lo, hi); }
+__device__ __forceinline__ DualD leaky_clamp(DualD x, float lo, float hi) {
+  bool in = (x.v >= lo) && (x.v <= hi);
+  return {nclampd(x.v, lo, hi), in ? x.d : x.d * (double)kEps};
+}
+__device__ __forceinline__ double t_softplus(double x) { return x > 20.0 ? x : log1p(exp(x)); }
+__device__ __forceinline__ DualD t_softplus(DualD x) {
+  const double e = exp(x.v > 20.0 ? 20.0 : x.v);
+  const bool lin = x.v > 20.0;
+  return {lin ? x.v : log1p(e), lin ? x.d : x.d * e / (e + 1.0)};
+}
+__device__ __forceinline__ void g_cosh_sinh(double x, double* c, double* s) {
+  const double xc = nclampd(x, -kMaxNorm, kMaxNorm);
+  *c = cosh(xc);
+  *s = sinh(xc);
+}
+__device__ __forceinline__ void g_cosh_sinh(DualD x, DualD* c, DualD* s) {
+  const DualD xc = leaky_clamp(x, -kMaxNorm, kMaxNorm);
+  const double sh = sinh(xc.v), ch = cosh(xc.v);
+  *c = DualD{ch, sh * xc.d};
+  *s = DualD{sh, ch * xc.d};
+}
+__device__ __forceinline__ void t_cos_sin(double x, double* c, double* s) {
+  *s = sin(x);
+  *c = cos(x);
+}
+__device__ __forceinline__ void t_cos_sin(DualD x, DualD* c, DualD* s) {
+  const double sv = sin(x.v), cv = cos(x.v);
+  *c = DualD{cv, -sv * x.d};
+  *s = DualD{sv, cv * x.d};
+}
+__device__ __forceinline__ double g_acosh_parts(double x, double* z_out) {  // common.py:76-94 in float64: 1 + 1e-8 IS above 1
+  double xc = nclampd(x, 1.0 + (double)kEps, INFINITY);
+  double z = sqrt(nclampd(xc * xc - 1.0, 1e-9, INFINITY));
+  *z_out = z;
+  return log(xc + z);
+}
+__device__ __forceinline__ double g_acosh(double x) {
+  double z;
+  return g_acosh_parts(x, &z);
+}
+__device__ __forceinline__ DualD g_acosh(DualD x) {
+  double z;
+  double y = g_acosh_parts(x.v, &z);
+  return {y, x.d / z};
+}
+__device__ __forceinline__ double g_atanh(double x) {
+  double xc = nclampd(x, -1.0 + 4.0 * (double)kEps, 1.0 - 4.0 * (double)kEps);
+  return (log(1.0 + xc) - log(1.0 - xc)) * 0.5;
+}
+__device__ __forceinline__ DualD g_atanh(DualD x) {
+  double xc = nclampd(x.v, -1.0 + 4.0 * (double)kEps, 1.0 - 4.0 * (double)kEps);
+  return {(log(1.0 + xc) - log(1.0 - xc)) * 0.5, x.d / (1.0 - xc * xc)};
+}
+__device__ __forceinline__ double p_artanh(double x) {
+  double xc = nclampd(x, -1.0 + 1e-5, 1.0 - 1e-5);
+  return (log(1.0 + xc) - log(1.0 - xc)) * 0.5;
+}
+__device__ __forceinline__ DualD p_artanh(DualD x) {
+  double xc = nclampd(x.v, -1.0 + 1e-5, 1.0 - 1e-5);
+  return {(log(1.0 + xc) - log(1.0 - xc)) * 0.5, x.d / (1.0 - xc * xc)};
+}
+template <int NMAX> __device__ __forceinline__ double norm2(const double* x, int n) {
+  MV_BOUNDS(NMAX);
+  double s = x[0] * x[0];
+  MV_FOR(i, 1, n) s = s + x[i] * x[i];
+  return sqrt(s);
+}
+template <int NMAX> __device__ __forceinline__ DualD norm2(const DualD* x, int n) {
+  MV_BOUNDS(NMAX);
+  double s = x[0].v * x[0].v;
+  double sd = x[0].v * x[0].d;
+  MV_FOR(i, 1, n) {
+    s = s + x[i].v * x[i].v;
+    sd += x[i].v * x[i].d;
+  }
+  double nv = sqrt(s);
+  return {nv, nv == 0.0 ? 0.0 : sd / nv};
+}
+
 // ---- the reference's guarded functions
 template <typename T> __device__ __forceinline__ T g_sqrt(T x) { return t_sqrt(leaky_clamp(x, 1e-9f, INFINITY)); }
 template <typename T> __device__ __forceinline__ T g_cosh(T x) { return t_cosh(leaky_clamp(x, -kMaxNorm, kMaxNorm)); }
@@ -210,15 +385,15 @@ template <typename T> __device__ __forceinline__ T g_logsinh(T x) {
   T b = -2.0f * x;
   T m = (val(a) >= val(b)) ? a : b;
   T s = 1.0f * t_exp(a - m) + (-1.0f) * t_exp(b - m);
-  return x + (m + t_log(leaky_clamp(s, kEps, INFINITY))) - kLn2;
+  return x + (m + t_log(leaky_clamp(s, kEps, INFINITY))) - ln2_of(x);
 }
 template <typename T> __device__ __forceinline__ T g_logcosh(T x) {  // common.py:131-136 (torch.logsumexp)
   T a = cst<T>(0.0f);
   T b = -2.0f * x;
   T m = (val(a) >= val(b)) ? a : b;
-  float mv = val(m);  // torch.logsumexp detaches the max
+  const auto mv = val(m);  // torch.logsumexp detaches the max
   T s = t_exp(a - mv) + t_exp(b - mv);
-  return x + (t_log(s) + mv) - kLn2;
+  return x + (t_log(s) + mv) - ln2_of(x);
 }
 
 // RadiusManifold.radius (manifold.py:73-75)
@@ -261,7 +436,7 @@ template <int NMAX, typename T> __device__ __forceinline__ T dot(const T* x, con
 // sum_i log N(v_i; 0, sigma_i) as torch.distributions.Normal.log_prob evaluates it, summed in index order
 template <typename T> __device__ __forceinline__ T normal_logprob_term(T v, T sigma) {
   T var = sigma * sigma;
-  return -(v * v) / (2.0f * var) - t_log(sigma) - kLogSqrt2Pi;
+  return -(v * v) / (2.0f * var) - t_log(sigma) - log_sqrt_2pi(v);
 }
 
 // =================================================================================================== manifolds

@@ -380,6 +380,33 @@ class ComponentLayout:
         self.n = n
 
 
+# ---- float64 latent chain (the reference CLI's default numerics, run.py:77,98-101): while the switch is on, the component
+# operators evaluate softplus / exp map / transport / log map / log-det / log-probabilities and their derivatives in double
+# between float32 tensors (mvae_component_forward_f64 / _backward_f64).  Dense layers stay float32.
+_FLOAT64_CHAIN = False
+
+
+def set_float64_chain(on: bool) -> bool:
+    """Switch the component operators to the float64 chain (process-wide); returns the previous setting."""
+    global _FLOAT64_CHAIN
+    prev, _FLOAT64_CHAIN = _FLOAT64_CHAIN, bool(on)
+    return prev
+
+
+class float64_chain:
+    """with float64_chain(): ... -- the component operators inside run their chain in float64."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = set_float64_chain(self.on)
+
+    def __exit__(self, *exc):
+        set_float64_chain(self.prev)
+        return False
+
+
 def component_forward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii: Optional[Tensor],
                       want_kl: bool = True, want_log_probs: bool = False, want_params: bool = False):
     """heads [B, heads_dim]; eps [B, eps_dim] or [n, B, eps_dim].  Returns dict(z, kl, log_q, log_p, mu, std)."""
@@ -394,9 +421,9 @@ def component_forward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radii
     mu = heads.new_empty(head_rows, layout.z_dim) if want_params else None
     sd = heads.new_zeros(head_rows, layout.eps_dim) if want_params else None
     radii = None if radii is None else _f32c(radii)
-    check(load().mvae_component_forward(layout.descs, layout.n, ptr(heads), heads.shape[-1], ptr(eps), layout.eps_dim,
-                                        ptr(radii), ptr(z), layout.z_dim, ptr(kl), ptr(lq), ptr(lp), ptr(mu), ptr(sd),
-                                        rows, head_rows, stream_ptr(heads.device)))
+    fn = load().mvae_component_forward_f64 if _FLOAT64_CHAIN else load().mvae_component_forward
+    check(fn(layout.descs, layout.n, ptr(heads), heads.shape[-1], ptr(eps), layout.eps_dim, ptr(radii), ptr(z), layout.z_dim,
+             ptr(kl), ptr(lq), ptr(lp), ptr(mu), ptr(sd), rows, head_rows, stream_ptr(heads.device)))
     return {"z": z, "kl": kl, "log_q": lq, "log_p": lp, "mu": mu, "std": sd}
 
 
@@ -414,10 +441,10 @@ def component_backward(layout: ComponentLayout, heads: Tensor, eps: Tensor, radi
         workspace = heads.new_empty(max(1, layout.n * rows))
     dkl = None if dkl is None else _f32c(dkl)
     radii = None if radii is None else _f32c(radii)
-    check(load().mvae_component_backward(layout.descs, layout.n, ptr(heads), heads.shape[-1], ptr(eps), layout.eps_dim,
-                                         ptr(radii), ptr(dz), layout.z_dim, ptr(dkl), float(dkl_scalar), ptr(dheads),
-                                         ptr(dradii), ptr(workspace if want_dradii else None), rows,
-                                         stream_ptr(heads.device)))
+    fn = load().mvae_component_backward_f64 if _FLOAT64_CHAIN else load().mvae_component_backward
+    check(fn(layout.descs, layout.n, ptr(heads), heads.shape[-1], ptr(eps), layout.eps_dim, ptr(radii), ptr(dz), layout.z_dim,
+             ptr(dkl), float(dkl_scalar), ptr(dheads), ptr(dradii), ptr(workspace if want_dradii else None), rows,
+             stream_ptr(heads.device)))
     return dheads, dradii
 
 
@@ -430,6 +457,7 @@ class _ComponentFn(torch.autograd.Function):
         out = component_forward(layout, heads.detach(), eps, radii.detach(), want_kl=True)
         ctx.save_for_backward(heads.detach(), radii.detach(), eps)
         ctx.layout = layout
+        ctx.f64 = _FLOAT64_CHAIN  # the backward pass differentiates the chain the forward pass ran
         return out["z"], out["kl"]
 
     @staticmethod
@@ -438,7 +466,8 @@ class _ComponentFn(torch.autograd.Function):
         lay = ctx.layout
         dz = torch.zeros(heads.shape[0], lay.z_dim, device=heads.device) if dz is None else dz
         dkl = torch.zeros(lay.n, heads.shape[0], device=heads.device) if dkl is None else dkl
-        dheads, dradii = component_backward(lay, heads, eps, radii, dz, dkl, want_dradii=ctx.needs_input_grad[1])
+        with float64_chain(ctx.f64):
+            dheads, dradii = component_backward(lay, heads, eps, radii, dz, dkl, want_dradii=ctx.needs_input_grad[1])
         return (dheads if ctx.needs_input_grad[0] else None), dradii, None, None
 
 

@@ -195,7 +195,15 @@ class ModelVAE(nn.Module):
         radii = torch.cat([c._radii_tensor() for c in self.components], dim=0)
         return W, b, radii
 
+    float64_chain = False  # run.py --doubles True: the components' latent chain in float64 (Fn.float64_chain), autograd step
+
     def forward(self, x: Tensor, eps: Optional[Tensor] = None) -> Outputs:  # vae.py:69-80
+        if self.float64_chain and not Fn._FLOAT64_CHAIN:
+            with Fn.float64_chain(True):
+                return self._forward(x, eps)
+        return self._forward(x, eps)
+
+    def _forward(self, x: Tensor, eps: Optional[Tensor] = None) -> Outputs:
         """With gradients enabled every dense layer / the component operator runs as a torch.autograd.Function over the
         HIP kernels, so the reference's own sequence works: `stats = compute_batch_stats(...); (-stats.elbo).backward();
         optimizer.step()` (vae.py:154-164).  ModelVAE.train_step does all of that as one fused launch sequence instead."""
@@ -226,6 +234,9 @@ class ModelVAE(nn.Module):
         return self._wrap_outputs(out)
 
     def log_likelihood(self, x: Tensor, n: int = 500, eps: Optional[Tensor] = None):  # vae.py:82-123
+        if self.float64_chain and not Fn._FLOAT64_CHAIN:
+            with Fn.float64_chain(True):
+                return self.log_likelihood(x, n, eps)
         eng = self._need_engine()
         x = x.to(self.device, torch.float32)
         B = x.shape[0]
@@ -255,9 +266,35 @@ class ModelVAE(nn.Module):
             ll, mi, cn = self.log_likelihood(x_mb, n=likelihood_n)
         return BatchStats(bce, kl, beta, ll, mi, cn)
 
+    def _train_step_float64_chain(self, optimizer, x_mb: Tensor, beta: float, eps: Optional[Tensor]):
+        """vae.py:149-166 as the reference writes it -- zero_grad, forward, ELBO, backward, optimizer.step through the autograd
+        operators -- with the latent chain of every component in float64 (`--doubles True`: Fn.float64_chain).  The fused
+        step's kernels are float32 throughout; this path trades their speed for the reference's default numerics."""
+        self._need_engine()
+        x = x_mb.to(self.device, torch.float32)
+        eps = self._eps(x.shape[0]) if eps is None else eps
+        optimizer.bind(self)
+        self._sync_trainable()
+        optimizer.zero_grad()
+        with Fn.float64_chain(True), torch.enable_grad():
+            reparametrized, concat_z, x_mb_ = self(x, eps=eps)
+            stats = self.compute_batch_stats(x, x_mb_, reparametrized, beta)
+            (-stats.elbo).backward()
+        optimizer.step()
+        # the engine's device-side running sums are what Trainer._train_epoch reads: add this step like the fused step does
+        from ._lib import check, load, ptr, stream_ptr
+        eng = self.engine
+        bce_rows, kl_rows = stats._bce.detach().contiguous(), stats._component_kl.detach().contiguous()
+        check(load().mvae_batch_stats(ptr(bce_rows), ptr(kl_rows), ptr(eng.stats), float(beta), x.shape[0], eng.layout.n,
+                                      stream_ptr(self.device)))
+        return stats.convert_to_float(), (reparametrized, concat_z, x_mb_)
+
     def train_step(self, optimizer, x_mb: Tensor, beta: float, eps: Optional[Tensor] = None):  # vae.py:149-166
         """zero_grad -> forward -> ELBO -> backward -> optimizer.step as ONE fused launch sequence.  Returns a lazy
-        BatchStatsFloat (no device sync until a field is read) and an empty outputs tuple."""
+        BatchStatsFloat (no device sync until a field is read) and an empty outputs tuple.  With `self.float64_chain` set
+        (run.py --doubles True) the step runs through the autograd operators with the latent chain in float64 instead."""
+        if self.float64_chain:
+            return self._train_step_float64_chain(optimizer, x_mb, beta, eps)
         eng = self._need_engine()
         x = x_mb.to(self.device, torch.float32)
         eps = self._eps(x.shape[0]) if eps is None else eps

@@ -56,8 +56,8 @@ def main(argv=None) -> None:
     if not torch.cuda.is_available():
         raise SystemExit("mvae_amd needs a HIP device: the MI355X path has no CPU fallback "
                          "(the reference falls back to cpu here, run.py:91-93).")
-    if args.doubles:
-        raise SystemExit("--doubles=True is not supported: the HIP path computes in float32.")
+    # --doubles True (the reference's default, run.py:77): the latent chain of every component runs in float64 between
+    # float32 dense layers, through the autograd operators instead of the fused step (models.ModelVAE.float64_chain)
     # Data-parallel training (new functionality; the reference is single-device): under
     #   python -m torch.distributed.run --nproc-per-node N -m mvae_amd.run ...
     # --batch_size stays the GLOBAL batch: every rank trains on its own 1/N of the training set with batch_size / N
@@ -95,6 +95,10 @@ def main(argv=None) -> None:
                       scalar_parametrization=args.scalar_parametrization).to(device)
     if args.seed:
         model.seed_sampler(args.seed + rank)
+    if args.doubles:
+        if world > 1 or args.architecture != "ff":
+            raise SystemExit("--doubles=True (float64 latent chain) is built for the single-device ff architecture")
+        model.float64_chain = True
     if world > 1:
         model.enable_data_parallel()
     trainer = Trainer(model, img_dims=dataset.img_dims, chkpt_dir=chkpt_dir, train_statistics=args.train_statistics,

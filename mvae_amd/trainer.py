@@ -184,6 +184,8 @@ class Trainer:
         from .engine import StepEngine
         from .runner import EpochRunner
         eng = self.model.engine
+        if getattr(self.model, "float64_chain", False):  # --doubles True: the autograd step, batch by batch
+            return False
         # MNIST on the MLP engine (dynamic binarisation) or CIFAR on the conv engine (pixel / 255, no binarisation)
         if not (isinstance(train_data, DeviceLoader) and train_data.train and train_data.images.dtype == torch.uint8 and
                 ((isinstance(eng, StepEngine) and train_data.binarize) or
