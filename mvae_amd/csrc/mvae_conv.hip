@@ -1723,13 +1723,16 @@ __global__ __launch_bounds__(512) void k_d3_bce_stats(const float* __restrict__ 
   __shared__ int last_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int r = blockIdx.x;
-  float wf[kBC][16];
+  // W (12 KB) once per workgroup through LDS (96 lines) instead of 48 four-row gathers per lane in each of the eight waves
+  // (~2300 line accesses); row stride 52 floats: the four k rows of a fragment fall into four different bank quarters
+  constexpr int kWS = 52;
+  __shared__ float sWd[kBF * kWS];
+  for (int e = tid; e < kBF * kBK / 4; e += 512) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + 4 * e);
+    const int k = (4 * e) / kBK, n = (4 * e) % kBK;
 #pragma unroll
-  for (int u = 0; u < kBC; ++u)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) wf[u][4 * j + e] = W[(16 * j + 4 * l4 + e) * kBK + 16 * u + l15];
+    for (int i = 0; i < 4; ++i) sWd[k * kWS + n + i] = v[i];
+  }
   constexpr int GW = 2;  // 16-pixel groups per wave (8 waves: two per SIMD, one multiplies while the other loads / folds)
   f32x4 av[GW][4];
 #pragma unroll
@@ -1739,6 +1742,14 @@ __global__ __launch_bounds__(512) void k_d3_bce_stats(const float* __restrict__ 
     for (int j = 0; j < 4; ++j)
       av[gI][j] = *reinterpret_cast<const f32x4*>(src + ((size_t)r * (kBO * kBO) + px) * kBF + 16 * j + 4 * l4);
   }
+  __syncthreads();
+  float wf[kBC][16];
+#pragma unroll
+  for (int u = 0; u < kBC; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wf[u][4 * j + e] = sWd[(16 * j + 4 * l4 + e) * kWS + 16 * u + l15];
 #pragma unroll
   for (int gI = 0; gI < GW; ++gI) {
     f32x4 acc[kBC];
@@ -1889,13 +1900,24 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 template <int NN>
 __global__ __launch_bounds__(256) void k_cl_heads_part(const float* __restrict__ a2, const float* __restrict__ W,
                                                        float* __restrict__ part, int B, int N) {
+  // The workgroup's NN x 128 weights sit 64 bytes apart in W (the reference's column order c * 16 + p).  Fetched per thread
+  // (4 x NN scalar loads, 32 different 128-byte lines per wave-level load) they cost 6144 line accesses per workgroup -- 7 us of
+  // the CU's address path for 6 KB; staged once through LDS, 64 consecutive channels per wave-level load, 768.
+  __shared__ __attribute__((aligned(16))) float sW[NN][128];
   const int tid = threadIdx.x, l = tid & 31, g = tid >> 5;
-  const int s = blockIdx.x, p = s >> 2, c = ((s & 3) << 7) + (l << 2);
+  const int s = blockIdx.x, p = s >> 2, c0 = (s & 3) << 7, c = c0 + (l << 2);
+  for (int e = tid; e < NN * 128; e += 256) {
+    const int n = e >> 7, cc = e & 127;
+    sW[n][cc] = W[(size_t)(n < N ? n : 0) * kFlat + (c0 + cc) * kPix + p];
+  }
+  __syncthreads();
   float w[NN][4];
 #pragma unroll
-  for (int n = 0; n < NN; ++n)
+  for (int n = 0; n < NN; ++n) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(&sW[n][l << 2]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[n][i] = W[(size_t)(n < N ? n : 0) * kFlat + (c + i) * kPix + p];
+    for (int i = 0; i < 4; ++i) w[n][i] = wv[i];
+  }
   const int r0 = blockIdx.y * 64;
   f32x4 xv[8];
 #pragma unroll
