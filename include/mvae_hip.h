@@ -382,11 +382,15 @@ int mvae_p3_group(int on, void* stream);
  * conv_vae.py:52-55,72-74) on the planes of src [B IH IW, C] and of Wt [OC, 16 C]; y = mask(relu(sum + bias)) (bias NULL: none;
  * relu 0: none; mask NULL: none) in f32, its planes too when y_planes != NULL (not together with a split-K workspace, which
  * only a call without bias / relu / mask uses).  y = NULL with a workspace that holds K slices: they are left there un-added (slice
- * count = workspace floats / (B OH OW OC)) for a consumer that adds them itself, mvae_conv_latent_backward. */
+ * count = workspace floats / (B OH OW OC)) for a consumer that adds them itself, mvae_conv_latent_backward.  colsum_out [OC] +
+ * colsum_part [(B OH OW / 128) OC] (both or neither; unsliced calls): the column sums of the result -- the bias gradient of the
+ * layer whose backward-data this is -- leave the epilogue as per-row-tile partial sums and are added in index order by the
+ * (deferrable) slice sum; with them and y_planes, y may be NULL: the f32 result is then not written at all. */
 int64_t mvae_conv_k4s2p1_nhwc_p3_workspace_floats(int B, int C, int IH, int IW, int OC, int has_mask);
 int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
-                             const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes, int64_t y_ps, int B,
-                             int C, int IH, int IW, int OC, float* workspace, void* stream);
+                             const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes, int64_t y_ps,
+                             float* colsum_out, float* colsum_part, int B, int C, int IH, int IW, int OC, float* workspace,
+                             void* stream);
 /* mvae_gemm_nn on the planes of G [M, K] and W [K, N] (the product a Conv2d backward-data folds with mvae_col2im_k4s2p1). */
 int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uint16_t* W_planes, int64_t w_ps, float* out, int64_t M,
                     int K, int N, void* stream);

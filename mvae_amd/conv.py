@@ -155,10 +155,13 @@ class _p3_group:
 
 def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int,
                   want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
-                  out_planes: Optional[Tensor] = None, keep_slices: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+                  out_planes: Optional[Tensor] = None, keep_slices: bool = False,
+                  colsum_out: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """_conv_nhwc (a Conv2d forward with bias / relu, or the backward-data of a ConvTranspose2d with mask) on planes: src_p
     [3, B*IH*IH, Cc], Wt_p [3, OC, 16 Cc] -> (y [B*(IH/2)^2, OC] f32, its planes or None).  keep_slices: when the call cuts K
-    into slices, return them un-added, [slices, M, OC], for a consumer that adds them while reading (the latent backward)."""
+    into slices, return them un-added, [slices, M, OC], for a consumer that adds them while reading (the latent backward).
+    colsum_out [OC] (with planes, unsliced): the column sums of y -- a bias gradient -- from the epilogue's per-tile partial
+    sums (added by the deferred slice sum); the f32 y is then not written and None is returned for it."""
     OC = Wt_p.shape[1]
     M = B * (IH // 2) * (IH // 2)
     epilogue = mask is not None or bias is not None or relu
@@ -166,13 +169,20 @@ def _conv_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, C
     if keep_slices and nws > 0:
         ws = torch.empty(nws // (M * OC), M, OC, dtype=torch.float32, device=src_p.device)
         check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), None, None, 0, None, None, 0,
-                                              B, Cc, IH, IH, OC, ptr(ws), stream_ptr(ws.device)))
+                                              None, None, B, Cc, IH, IH, OC, ptr(ws), stream_ptr(ws.device)))
         return ws, None
+    if colsum_out is not None and nws == 0 and (want_planes or out_planes is not None):
+        yp = out_planes if out_planes is not None else _new_planes(M, OC, src_p.device)
+        part = _keep(torch.empty(M // 128, OC, dtype=torch.float32, device=src_p.device))
+        check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias),
+                                              1 if relu else 0, None, _pptr(yp), _ps(yp), ptr(colsum_out), ptr(part), B, Cc, IH, IH,
+                                              OC, None, stream_ptr(src_p.device)))
+        return None, yp
     y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
     ws = y.new_empty(nws) if nws > 0 else None  # split-K slices, added in index order right away (y is an intermediate)
     yp = out_planes if out_planes is not None else (_new_planes(M, OC, y.device) if (want_planes and nws == 0) else None)
     check(load().mvae_conv_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias), 1 if relu else 0,
-                                          ptr(y), _pptr(yp), _ps(yp), B, Cc, IH, IH, OC, ptr(ws), stream_ptr(y.device)))
+                                          ptr(y), _pptr(yp), _ps(yp), None, None, B, Cc, IH, IH, OC, ptr(ws), stream_ptr(y.device)))
     return y, yp
 
 
@@ -846,13 +856,18 @@ class ConvEngine:
         # each layer's weight gradient and backward-data read the same incoming gradient and not each other: ONE launch per pair
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
-            db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True)  # [B*64, 256], ReLU mask of b1
+            # [B*64, 256], ReLU mask of b1; only its planes and its column sums (d1.bias) are ever read: the epilogue delivers
+            # both and the f32 tensor is not written (MVAE_CONV_EPI_COLSUM=0: f32 result + the batched column sum)
+            epi = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"
+            db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True,
+                                       colsum_out=GV["d1.bias"] if epi else None)
         _colsum(db2, out=GV["d2.bias"])
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
             # [B*16, 128]; with the fused latent section its K slices stay un-added (the latent backward adds them as it reads)
             dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8, keep_slices=bool(c.get("fused")) and os.environ.get("MVAE_CONV_DT0_SLICES", "1") != "0")
-        _colsum(db1, out=GV["d1.bias"])
+        if db1 is not None:
+            _colsum(db1, out=GV["d1.bias"])
         # ---- latent section
         da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None
         dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p)

@@ -45,6 +45,7 @@ struct P3Args {
   bf16r* Cp; long long psc;            // planes of the result (NULL: none), same ldc
   const float* mask;                   // result zeroed where mask <= 0 (same layout as C), or NULL
   const float* bias; int relu;         // forward epilogue: + bias[n] (or NULL), then max(., 0) -- before the mask
+  float* colpart;                      // (two-phase form, no parity) per-row-tile column sums of the result: [M / BM][N], or NULL
   int M, N, K, k_per_slice;
   long long slice_stride;              // floats between the partial results of consecutive K slices (blockIdx.z)
   ConvGeom cg;
@@ -56,6 +57,17 @@ struct P3Args {
 
 __device__ __attribute__((aligned(16))) unsigned int g_p3_zero[4];
 
+// sum over the 16 lanes of a DPP row, every lane of the row receives it (fixed order)
+__device__ __forceinline__ float p3_row16_sum(float v) {
+  int x = __float_as_int(v);
+#define MV_P3_DPP_ADD(CTRL) x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true)));
+  MV_P3_DPP_ADD(0xB1)   // quad_perm [1,0,3,2]
+  MV_P3_DPP_ADD(0x4E)   // quad_perm [2,3,0,1]
+  MV_P3_DPP_ADD(0x141)  // row_half_mirror
+  MV_P3_DPP_ADD(0x140)  // row_mirror
+#undef MV_P3_DPP_ADD
+  return __int_as_float(x);
+}
 __device__ __forceinline__ int p3_h(int x) { return (0x78 >> (2 * x)) & 3; }  // {0, 2, 3, 1}
 // Chunk swizzle of a contraction-major image ([32 k][rows] bf16, CPR = rows / 16 chunks of 32 bytes per k row): a 32-lane
 // service group of ds_read_b64_tr_b16 touches the k rows {4 t + i} and {8 + 4 t + i}, i = 0..3, of one 16-column block; with
@@ -577,6 +589,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, unsigned char* __restri
   }
   const int row_half = KALT ? grp * (TM / 2) * 16 : 0;
   // ---- epilogue: lane holds row l15, columns 4 * l4 + r of every 16 x 16 tile
+  float cs[TN][4];
 #pragma unroll
   for (int a = 0; a < TMK; ++a) {
     int m = m0 + wm + row_half + a * 16 + l15;
@@ -603,8 +616,38 @@ __device__ __forceinline__ void p3_body(const P3Args& g, unsigned char* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(C + o) = v;
+      if (g.C) *reinterpret_cast<f32x4*>(C + o) = v;
       if (g.Cp) store_planes4(g.Cp, g.psc, o, v[0], v[1], v[2], v[3]);
+      if constexpr (!KALT && !PARITY) {
+        if (g.colpart) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[b][r] = (a == 0) ? v[r] : cs[b][r] + v[r];
+        }
+      }
+    }
+  }
+  // ---- column sums of the tile (the bias gradient of the layer whose backward-data this is: its f32 result then need not be
+  // written at all).  Rows of a wave: in-lane over its 16-row blocks, then the 16 lanes of a DPP row; waves: through LDS in
+  // wave order; row tiles: by the caller's slice sum in index order.
+  if constexpr (!KALT && !PARITY) {
+    if (g.colpart) {
+      barrier();  // (every wave has left the K loop: the tile buffers are free)
+      float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = p3_row16_sum(cs[b][r]);
+          if (l15 == 0) red[(idx / WC) * BN + wn + b * 16 + l4 * 4 + r] = t;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();
+      if (tid < BN) {
+        float t = red[tid];
+#pragma unroll
+        for (int w = 1; w < WR; ++w) t += red[w * BN + tid];
+        g.colpart[(size_t)(m0 / BM) * g.N + n0 + tid] = t;
+      }
     }
   }
 }
@@ -710,7 +753,7 @@ struct P3Queued {
   dim3 grid;
   void (*single)(const P3Args&, dim3, hipStream_t);
 };
-struct P3Post { const float* part; float* out; int64_t n; int slices; };
+struct P3Post { const float* part; float* out; int64_t n; int slices; bool deferrable; };
 static thread_local bool g_p3_group = false;
 static thread_local int g_p3_nq = 0, g_p3_npost = 0;
 static thread_local P3Queued g_p3_q[2];
@@ -731,10 +774,18 @@ static void p3_submit(const P3Args& a, dim3 grid, hipStream_t s) {
 // the immediate slice sum of a split-K backward-data result: after the (possibly queued) launch that writes the slices
 static void p3_sum_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
   if (g_p3_group && g_p3_npost < 2) {
-    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices};
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, false};
     return;
   }
   p3_sum_slices_now(part, out, n, slices, s);
+}
+// a deferrable slice sum (final gradients: bias column sums) of a result whose launch may still be queued
+static void p3_sum_deferrable_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
+  if (g_p3_group && g_p3_npost < 2) {
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, true};
+    return;
+  }
+  p3_sum_slices(part, out, n, slices, s);
 }
 template <int BM2, int BN2, int WR2, int AF2, int BF2, bool KALT2>
 static void p3_launch_pair(const P3Queued& w, const P3Queued& d, hipStream_t s) {  // w: the weight gradient (P3_WGRAD)
@@ -766,7 +817,10 @@ extern "C" int mvae_p3_group(int on, void* stream) {
   }
   if (!paired)
     for (int i = 0; i < g_p3_nq; ++i) g_p3_q[i].single(g_p3_q[i].a, g_p3_q[i].grid, s);
-  for (int i = 0; i < g_p3_npost; ++i) p3_sum_slices_now(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
+  for (int i = 0; i < g_p3_npost; ++i) {
+    if (g_p3_post[i].deferrable) p3_sum_slices(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
+    else p3_sum_slices_now(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
+  }
   g_p3_nq = g_p3_npost = 0;
   LAUNCH_CHECK("grouped plane contraction launch");
   return 0;
@@ -860,7 +914,8 @@ static int p3_geom(ConvGeom* g, int* lCc, int B, int Cc, int IH, int IW, bool ou
 // [OC, 16 C]; y f32 (+ its planes when y_planes != NULL).
 extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
                                         const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes,
-                                        int64_t y_ps, int B, int Cc, int IH, int IW, int OC, float* workspace, void* stream) {
+                                        int64_t y_ps, float* colsum_out, float* colsum_part, int B, int Cc, int IH, int IW,
+                                        int OC, float* workspace, void* stream) {
   if (!src_planes || !Wt_planes) return fail(MVAE_E_BADARG, "null pointer%s", "");
   const int64_t M = (int64_t)B * (IH / 2) * (IW / 2);
   const int K = 16 * Cc;
@@ -875,8 +930,11 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
   int kps;
   const int slices = (workspace && !fwd) ? p3_conv_slices(M, OC, K, mask != nullptr, &kps) : 1;
   a.bias = bias; a.relu = relu;
-  // y == NULL: the K slices stay in the workspace for a consumer that adds them itself (mvae_conv_latent_backward's dt0)
-  if (!y && slices < 2) return fail(MVAE_E_BADARG, "y may only be NULL when the call leaves K slices in its workspace%s", "");
+  // y == NULL: the K slices stay in the workspace for a consumer that adds them itself (mvae_conv_latent_backward's dt0), or
+  // (one slice) only the planes and the column sums of the result are wanted
+  if (!y && slices < 2 && !(y_planes && colsum_out)) return fail(MVAE_E_BADARG, "y may only be NULL with K slices or planes + column sums%s", "");
+  if ((colsum_out == nullptr) != (colsum_part == nullptr) || (colsum_out && slices > 1))
+    return fail(MVAE_E_BADARG, "colsum_out and colsum_part go together (unsliced calls only)%s", "");
   a.A = src_planes; a.lda = Cc; a.psa = src_ps;
   a.B = Wt_planes; a.ldb = K; a.psb = w_ps;
   a.ldc = OC; a.M = (int)M; a.N = OC; a.K = K;
@@ -887,10 +945,11 @@ extern "C" int mvae_conv_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_
     if (y_planes) return fail(MVAE_E_UNSUPPORTED, "planes of a split-K result are not produced%s", "");
     if (y) p3_sum_after(workspace, y, M * OC, slices, (hipStream_t)stream);  // (an intermediate: the next launch reads it)
   } else {
-    a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0;
+    a.C = y; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.k_per_slice = K; a.slice_stride = 0; a.colpart = colsum_part;
     // 128 x 64 tiles where 128 x 128 ones would leave CUs without a workgroup (the forward layers: 128 tiles each)
     if ((M / 128) * (OC / 128) >= 192) launch_p3<128, 128, 2, A_G1, B_KC>(a, 1, (hipStream_t)stream);
     else launch_p3<128, 64, 4, A_G1, B_KC>(a, 1, (hipStream_t)stream);
+    if (colsum_out) p3_sum_deferrable_after(colsum_part, colsum_out, OC, (int)(M / 128), (hipStream_t)stream);
   }
   LAUNCH_CHECK("plane conv launch");
   return 0;

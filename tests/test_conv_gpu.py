@@ -962,6 +962,12 @@ def test_plane_contractions_vs_float64(dev, case):
         close(y, ref, case)
         if case == "d2_bwd_data":
             assert yp is not None and torch.equal(_planes_sum(yp), y), "planes of the result are not its exact split"
+            # the same call delivering only the planes and the column sums of the result (a bias gradient) from the epilogue
+            cs = torch.empty(OC, device=dev)
+            y2, yp2 = _conv_nhwc_p3(_planes_of(src), _planes_of(Wt), mask, B, Cc, IH, want_planes=True, colsum_out=cs)
+            load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
+            assert y2 is None and torch.equal(yp2, yp)
+            assert_close(_cpu(cs), y.double().sum(0).cpu().numpy(), 2e-5, "epilogue column sums", atol_frac=2e-6)
     elif case in ("e1_forward", "e2_forward"):
         B, Cc, IH, OC = (8, 64, 16, 128) if case == "e1_forward" else (32, 128, 8, 512)
         x, W, bias = rnd(B, Cc, IH, IH), rnd(OC, Cc, 4, 4) * 0.05, rnd(OC)
