@@ -421,9 +421,13 @@ int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, float* dW, 
                                  float* workspace, void* stream);
 /* The backward pass of ConvTranspose2d(64, 3, 4, 2, 1) in ONE launch: mvae_conv3_k4s2p1_nchw_wgrad(act, img, dW) and
  * mvae_conv3_k4s2p1_nchw(img, W, NULL, mask = act, 0, y, y_planes) with img = the gradient of the NCHW logits and act = the
- * layer's channel-last input (same workspace as the weight gradient alone). */
+ * layer's channel-last input (same workspace as the weight gradient alone).  colsum_out [64] + colsum_ws
+ * (mvae_conv3_k4s2p1_nchw_backward_colsum_floats floats; both or neither): the column sums of y -- the bias gradient of the layer
+ * below -- from per-workgroup partial sums added by the (deferrable) column sum; with them and y_planes, y may be NULL. */
 int mvae_conv3_k4s2p1_nchw_backward(const float* act, const float* img, const float* W, float* dW, float* y, uint16_t* y_planes,
-                                    int64_t y_ps, int B, int C, int IH, int IW, int F, float* workspace, void* stream);
+                                    int64_t y_ps, float* colsum_out, float* colsum_ws, int B, int C, int IH, int IW, int F,
+                                    float* workspace, void* stream);
+int64_t mvae_conv3_k4s2p1_nchw_backward_colsum_floats(int B);
 /* The loss end of the conv step in one launch: mvae_bce_forward_backward + mvae_batch_stats (vae.py:125-147) + the bias
  * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
  * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first

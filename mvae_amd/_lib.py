@@ -102,7 +102,8 @@ PROTOTYPES = {
     "mvae_conv3_k4s2p1_nchw": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv3_k4s2p1_nchw_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "mvae_conv3_k4s2p1_nchw_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "mvae_conv3_k4s2p1_nchw_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mvae_conv3_k4s2p1_nchw_backward_colsum_floats": (C.c_int64, [_I]),
     "mvae_p3_group": (C.c_int, [_I, _P]),
     "mvae_conv_k4s2p1_nhwc_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -322,14 +322,21 @@ def _edge_wgrad(act: Tensor, img: Tensor, out: Tensor, B: int) -> Tensor:
     return out
 
 
-def _edge_backward(act: Tensor, img: Tensor, W: Tensor, out_dW: Tensor, B: int, planes: Optional[Tensor] = None) -> Tensor:
-    """_edge_wgrad(act, img, out_dW) and _edge_conv(img, W, None, act, False) in ONE launch: the backward pass of d3."""
+def _edge_backward(act: Tensor, img: Tensor, W: Tensor, out_dW: Tensor, B: int, planes: Optional[Tensor] = None,
+                   colsum_out: Optional[Tensor] = None) -> Optional[Tensor]:
+    """_edge_wgrad(act, img, out_dW) and _edge_conv(img, W, None, act, False) in ONE launch: the backward pass of d3.
+    colsum_out [64] (with planes): the column sums of the backward-data result (the bias gradient of the layer below) from
+    per-workgroup partial sums; the f32 result is then not written and None is returned."""
     assert out_dW.is_contiguous() and out_dW.numel() == 64 * 48
     nws = int(load().mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(B, 3, 32, 32, 64))
     ws = _keep(act.new_empty(nws))
-    y = img.new_empty(B * 256, 64)
-    check(load().mvae_conv3_k4s2p1_nchw_backward(ptr(act), ptr(img), ptr(W), ptr(out_dW), ptr(y), _pptr(planes), _ps(planes), B, 3,
-                                                 32, 32, 64, ptr(ws), stream_ptr(act.device)))
+    cws = None
+    if colsum_out is not None and planes is not None:
+        cws = _keep(act.new_empty(int(load().mvae_conv3_k4s2p1_nchw_backward_colsum_floats(B))))
+    y = None if cws is not None else img.new_empty(B * 256, 64)
+    check(load().mvae_conv3_k4s2p1_nchw_backward(ptr(act), ptr(img), ptr(W), ptr(out_dW), ptr(y), _pptr(planes), _ps(planes),
+                                                 ptr(colsum_out) if cws is not None else None, ptr(cws), B, 3, 32, 32, 64, ptr(ws),
+                                                 stream_ptr(act.device)))
     return y
 
 
@@ -848,7 +855,9 @@ class ConvEngine:
             _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
         db2_p = _new_planes(B * 256, 64, dev)
         if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
-            db2 = _edge_backward(c["b2"], g, PV["d3.weight"].view(64, 48), GV["d3.weight"].view(64, 48), B, db2_p)
+            epi2 = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") == "1"  # d2.bias from the same launch, no f32 db2 ("2": db1 only)
+            db2 = _edge_backward(c["b2"], g, PV["d3.weight"].view(64, 48), GV["d3.weight"].view(64, 48), B, db2_p,
+                                 colsum_out=GV["d2.bias"] if epi2 else None)
         else:
             dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
             _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
@@ -861,7 +870,8 @@ class ConvEngine:
             epi = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"
             db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True,
                                        colsum_out=GV["d1.bias"] if epi else None)
-        _colsum(db2, out=GV["d2.bias"])
+        if db2 is not None:
+            _colsum(db2, out=GV["d2.bias"])
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
             # [B*16, 128]; with the fused latent section its K slices stay un-added (the latent backward adds them as it reads)

@@ -1602,6 +1602,27 @@ extern "C" int mvae_colsum(const float* G, float* out, int64_t M, int N, float* 
   return 0;
 }
 
+// mvae_colsum for a caller inside the library (the per-workgroup partial column sums of mvae_edge.hip): queued like the tall
+// ones whenever deferral is on, whatever M is; ws: ceil(M / 512) * N floats.
+void p3_colsum_deferrable(const float* G, float* out, int64_t M, int N, float* ws, hipStream_t s) {
+  const int ncb = (N + kColsPerBlock - 1) / kColsPerBlock;
+  const int slices = (int)((M + kColSlice - 1) / kColSlice);
+  if (g_defer && (N & 3) == 0 && ((((uintptr_t)G) | ((uintptr_t)ws)) & 15) == 0) {
+    if (g_cols.njobs == kMaxColJobs) flush_sums(s);
+    const int j = g_cols.njobs++;
+    if (j == 0) g_cols.blk0[0] = 0;
+    g_cols.G[j] = G;
+    g_cols.part[j] = ws;
+    g_cols.M[j] = (int)M;
+    g_cols.N[j] = N;
+    g_cols.ncb[j] = (N + 63) / 64;
+    g_cols.blk0[j + 1] = g_cols.blk0[j] + g_cols.ncb[j] * slices;
+  } else {
+    hipLaunchKernelGGL(k_colsum_sliced, dim3((unsigned)(ncb * slices)), dim3(256), 0, s, G, ws, (int)M, N, ncb);
+  }
+  sum_slices(ws, out, (int64_t)N, slices, s);
+}
+
 extern "C" int mvae_bce_forward_backward(const float* logits, const float* x, float* bce, float* g, int64_t rows,
                                          int D, void* stream) {
   if (!logits || !x || !bce || !g || rows < 1 || D < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");

@@ -30,9 +30,11 @@ constexpr int kETS = kEF + 4;   // LDS row stride of a wave's result tile (float
 template <int G, int NW>
 __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __restrict__ img, const float* __restrict__ W,
                                               const float* __restrict__ bias, const float* __restrict__ mask, const int relu,
-                                              float* __restrict__ y, bf16r* __restrict__ yp, const long long ps, const int nrows) {
+                                              float* __restrict__ y, bf16r* __restrict__ yp, const long long ps, const int nrows,
+                                              float* __restrict__ colpart = nullptr) {
   __shared__ float sW[kEF * kEWS];
   __shared__ __attribute__((aligned(16))) float sT[NW][16 * kETS];
+  __shared__ __attribute__((aligned(16))) float sC[NW][kEF];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   for (int e = threadIdx.x; e < kEF * kEK / 4; e += 64 * NW) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(W + 4 * e);
@@ -56,7 +58,7 @@ __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __rest
     }
   }
   __syncthreads();
-  if (row0 >= nrows) return;
+  if (row0 >= nrows && !colpart) return;
   // weight fragments for the whole life of the wave: operand "a" of tile t, step s = W[16 t + l15][4 s + l4]
   float wf[4][12];
 #pragma unroll
@@ -67,6 +69,7 @@ __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __rest
   f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * l15);
   float* tile = sT[wave];
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};  // column sums of this wave's rows: features 4 l15 .. + 3 (pixels l4 + 4 i)
 #pragma unroll
   for (int gI = 0; gI < G; ++gI) {
     const int row = row0 + gI;
@@ -98,8 +101,26 @@ __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(y + o) = v;
+      if (y) *reinterpret_cast<f32x4*>(y + o) = v;
       if (yp) store_planes4(yp, ps, o, v[0], v[1], v[2], v[3]);
+      cs += v;
+    }
+  }
+  // column sums of the workgroup's rows (the bias gradient of the layer whose backward-data this is): the four pixel groups of
+  // a wave by two lane exchanges, the waves through LDS in wave order; the workgroups by the caller's (deferred) column sum
+  if (colpart) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = cs[r] + __shfl_xor(cs[r], 16);
+      cs[r] = t + __shfl_xor(t, 32);
+    }
+    if (l4 == 0) *reinterpret_cast<f32x4*>(&sC[wave][4 * l15]) = cs;
+    __syncthreads();
+    if (threadIdx.x < kEF) {
+      float t = sC[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += sC[w][threadIdx.x];
+      colpart[(size_t)blk * kEF + threadIdx.x] = t;
     }
   }
 }
@@ -184,9 +205,9 @@ __global__ __launch_bounds__(512) void k_edge3_bwd(const float* __restrict__ act
                                                    float* __restrict__ part, const int B, const int img_per_wg, const int n_tn,
                                                    const float* __restrict__ W, const float* __restrict__ mask,
                                                    float* __restrict__ y, bf16r* __restrict__ yp, const long long ps,
-                                                   const int nrows) {
+                                                   const int nrows, float* __restrict__ colpart) {
   if ((int)blockIdx.x < n_tn) edge3_tn_body((int)blockIdx.x, act, img, part, B, img_per_wg);
-  else edge3_nt_body<1, 8>((int)blockIdx.x - n_tn, img, W, nullptr, mask, 0, y, yp, ps, nrows);
+  else edge3_nt_body<1, 8>((int)blockIdx.x - n_tn, img, W, nullptr, mask, 0, y, yp, ps, nrows, colpart);
 }
 
 void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (honours deferral)
@@ -231,18 +252,29 @@ extern "C" int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, 
 // mvae_conv3_k4s2p1_nchw_wgrad(act, img, dW) and mvae_conv3_k4s2p1_nchw(img, W, NULL, mask, 0, y, y_planes) in ONE launch: the
 // backward pass of ConvTranspose2d(64, 3, 4, 2, 1) (conv_vae.py:54,74) -- img = the gradient of the logits, act = mask = the
 // layer's input b2 (whose ReLU the backward-data passes through).
+void p3_colsum_deferrable(const float* G, float* out, int64_t M, int N, float* ws, hipStream_t s);  // mvae_conv.hip
+
+// floats of mvae_conv3_k4s2p1_nchw_backward's colsum_ws: the per-workgroup column sums + the column sum's own slice partials
+extern "C" int64_t mvae_conv3_k4s2p1_nchw_backward_colsum_floats(int B) {
+  if (B < 1) return 0;
+  const int64_t wgs = ((int64_t)B * kEO + 7) / 8;
+  return (wgs + (wgs + 511) / 512) * kEF;
+}
 extern "C" int mvae_conv3_k4s2p1_nchw_backward(const float* act, const float* img, const float* W, float* dW, float* y,
-                                               uint16_t* y_planes, int64_t y_ps, int B, int C, int IH, int IW, int F,
-                                               float* workspace, void* stream) {
-  if (!act || !img || !W || !dW || !y || !workspace || B < 1) return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+                                               uint16_t* y_planes, int64_t y_ps, float* colsum_out, float* colsum_ws, int B,
+                                               int C, int IH, int IW, int F, float* workspace, void* stream) {
+  if (!act || !img || !W || !dW || !workspace || B < 1) return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
+  if (!y && !(y_planes && colsum_out)) return fail(MVAE_E_BADARG, "y may only be NULL with planes + column sums%s", "");
+  if ((colsum_out == nullptr) != (colsum_ws == nullptr)) return fail(MVAE_E_BADARG, "colsum_out and colsum_ws go together%s", "");
   if (!edge_geometry(C, IH, IW, F)) return fail(MVAE_E_UNSUPPORTED, "direct boundary backward: 3 x 32 x 32, 64 features%s", "");
-  if (!aligned16(act) || !aligned16(workspace) || !aligned16(dW) || !aligned16(y) ||
+  if (!aligned16(act) || !aligned16(workspace) || !aligned16(dW) || (y && !aligned16(y)) || (colsum_ws && !aligned16(colsum_ws)) ||
       (y_planes && (((uintptr_t)y_planes & 7) || (y_ps & 3))))
     return fail(MVAE_E_ALIGN, "direct boundary backward: 16-byte aligned operands, 8-byte aligned planes%s", "");
-  const int ipw = edge_img_per_wg(B), wgs = (B + ipw - 1) / ipw, nrows = B * kEO;
-  hipLaunchKernelGGL(k_edge3_bwd, dim3((unsigned)(wgs + (nrows + 7) / 8)), dim3(512), 0, (hipStream_t)stream, act, img, workspace,
-                     B, ipw, wgs, W, act, y, y_planes, (long long)y_ps, nrows);
+  const int ipw = edge_img_per_wg(B), wgs = (B + ipw - 1) / ipw, nrows = B * kEO, nt_wgs = (nrows + 7) / 8;
+  hipLaunchKernelGGL(k_edge3_bwd, dim3((unsigned)(wgs + nt_wgs)), dim3(512), 0, (hipStream_t)stream, act, img, workspace, B, ipw,
+                     wgs, W, act, y, y_planes, (long long)y_ps, nrows, colsum_ws);
   p3_sum_slices(workspace, dW, (int64_t)kEF * kEK, wgs, (hipStream_t)stream);
+  if (colsum_out) p3_colsum_deferrable(colsum_ws, colsum_out, nt_wgs, kEF, colsum_ws + (size_t)nt_wgs * kEF, (hipStream_t)stream);
   LAUNCH_CHECK("direct boundary backward launch");
   return 0;
 }

@@ -1103,6 +1103,12 @@ def test_edge_layers_without_patch_matrix(dev, B):
     load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
     assert torch.equal(out2, out)
     assert torch.equal(y2, _edge_conv(img, W, None, act, False, B)) and torch.equal(_planes_sum(yp2), y2)
+    # ... and delivering only the planes + the column sums of the backward-data result (the bias gradient of the layer below)
+    out3, yp3, cs = torch.empty(64, 48, device=dev), _new_planes(B * 256, 64, dev), torch.empty(64, device=dev)
+    assert _edge_backward(act, img, W, out3, B, yp3, colsum_out=cs) is None
+    load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out3, out) and torch.equal(yp3, yp2)
+    assert_close(_cpu(cs), y2.double().sum(0).cpu().numpy(), 2e-5, "column sums from the edge kernel", atol_frac=2e-6)
 
 
 @pytest.mark.parametrize("B", [32, 256])
