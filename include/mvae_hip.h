@@ -398,7 +398,11 @@ int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uint16_t* W_pl
  * conv_vae.py:47-50,57-63) on the planes of src [B IH IW, C] and of Wt [C, 16 OC]; epilogue as mvae_conv_k4s2p1_nhwc_p3. */
 int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes, int64_t w_ps,
                                        const float* mask, const float* bias, int relu, float* y, uint16_t* y_planes,
-                                       int64_t y_ps, int B, int C, int IH, int IW, int OC, void* stream);
+                                       int64_t y_ps, float* colsum_out, float* colsum_ws, int B, int C, int IH, int IW, int OC,
+                                       void* stream);
+/* floats of colsum_ws above (per-tile column sums of the four parity classes + the column sum's slice partials); colsum_out [OC]
+ * + colsum_ws: as in mvae_conv_k4s2p1_nhwc_p3 (y may then be NULL when y_planes is given). */
+int64_t mvae_conv_transpose_k4s2p1_nhwc_p3_colsum_floats(int B, int IH, int IW, int OC);
 /* mvae_conv_k4s2p1_nhwc_wgrad on the planes of dy [B OH OW, OC] and of src [B IH IW, C]. */
 int64_t mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(int B, int C, int IH, int IW, int OC);
 int mvae_conv_k4s2p1_nhwc_wgrad_p3(const uint16_t* dy_planes, int64_t dy_ps, const uint16_t* src_planes, int64_t src_ps,

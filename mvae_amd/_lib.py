@@ -108,7 +108,8 @@ PROTOTYPES = {
     "mvae_conv_k4s2p1_nhwc_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_gemm_nn_p3": (C.c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
-    "mvae_conv_transpose_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc_p3": (C.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mvae_conv_transpose_k4s2p1_nhwc_p3_colsum_floats": (C.c_int64, [_I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv_k4s2p1_nhwc_wgrad_p3": (C.c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mvae_convt_to3_k4s2p1_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

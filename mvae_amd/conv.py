@@ -196,15 +196,22 @@ def _gemm_nn_p3(G_p: Tensor, W_p: Tensor) -> Tensor:
 
 def _convT_nhwc_p3(src_p: Tensor, Wt_p: Tensor, mask: Optional[Tensor], B: int, Cc: int, IH: int, OC: int,
                    want_planes: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
-                   out_planes: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+                   out_planes: Optional[Tensor] = None, colsum_out: Optional[Tensor] = None,
+                   want_y: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """_convT_nhwc (a ConvTranspose2d forward with bias / relu, or a Conv2d's backward-data with mask; four parity classes)
-    on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, Cc, 16 OC]."""
+    on planes: src_p [3, B*IH*IH, Cc], Wt_p [3, Cc, 16 OC].  colsum_out [OC]: the column sums of the result (a bias gradient)
+    from the epilogue's per-tile partial sums; want_y=False (with planes and colsum_out): the f32 result is not written."""
     M = B * (2 * IH) * (2 * IH)
-    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device)
-    yp = out_planes if out_planes is not None else (_new_planes(M, OC, y.device) if want_planes else None)
+    yp = out_planes if out_planes is not None else (_new_planes(M, OC, src_p.device) if want_planes else None)
+    cws = None
+    if colsum_out is not None:
+        cws = _keep(torch.empty(int(load().mvae_conv_transpose_k4s2p1_nhwc_p3_colsum_floats(B, IH, IH, OC)),
+                                dtype=torch.float32, device=src_p.device))
+    y = torch.empty(M, OC, dtype=torch.float32, device=src_p.device) if (want_y or cws is None or yp is None) else None
     check(load().mvae_conv_transpose_k4s2p1_nhwc_p3(_pptr(src_p), _ps(src_p), _pptr(Wt_p), _ps(Wt_p), ptr(mask), ptr(bias),
-                                                    1 if relu else 0, ptr(y), _pptr(yp), _ps(yp), B, Cc, IH, IH, OC,
-                                                    stream_ptr(y.device)))
+                                                    1 if relu else 0, ptr(y), _pptr(yp), _ps(yp),
+                                                    ptr(colsum_out) if cws is not None else None, ptr(cws), B, Cc, IH, IH, OC,
+                                                    stream_ptr(src_p.device)))
     return y, yp
 
 
@@ -893,7 +900,9 @@ class ConvEngine:
             # MVAE_CONV_DA1_IMPLICIT=0: product + col2im.
             with _p3_group(dev):
                 _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
-                da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True)
+                epi = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e1.bias from the epilogue, no f32 da1
+                da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True,
+                                            colsum_out=GV["e1.bias"] if epi else None, want_y=not epi)
         else:
             da1_p = _new_planes(B * 64, 128, dev)
             with _p3_group(dev):
@@ -902,13 +911,17 @@ class ConvEngine:
             da1 = _col2im(prod, None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True, planes=da1_p)
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
-            da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64)  # [B*256, 64], ReLU mask of a0
-        _colsum(da1, out=GV["e1.bias"])
+            epi0 = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e0.bias from the epilogue (da0 itself is still read)
+            da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64,
+                                    colsum_out=GV["e0.bias"] if epi0 else None)  # [B*256, 64], ReLU mask of a0
+        if da1 is not None:
+            _colsum(da1, out=GV["e1.bias"])
         if c["col0"] is None:
             _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B)
         else:
             _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
-        _colsum(da0, out=GV["e0.bias"])
+        if not epi0:
+            _colsum(da0, out=GV["e0.bias"])
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
         _DEFERRED_WS.clear()
         if want_outputs:

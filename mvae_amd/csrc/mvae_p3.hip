@@ -618,36 +618,34 @@ __device__ __forceinline__ void p3_body(const P3Args& g, unsigned char* __restri
       }
       if (g.C) *reinterpret_cast<f32x4*>(C + o) = v;
       if (g.Cp) store_planes4(g.Cp, g.psc, o, v[0], v[1], v[2], v[3]);
-      if constexpr (!KALT && !PARITY) {
-        if (g.colpart) {
+      if (g.colpart) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cs[b][r] = (a == 0) ? v[r] : cs[b][r] + v[r];
-        }
+        for (int r = 0; r < 4; ++r) cs[b][r] = (a == 0) ? v[r] : cs[b][r] + v[r];
       }
     }
   }
   // ---- column sums of the tile (the bias gradient of the layer whose backward-data this is: its f32 result then need not be
-  // written at all).  Rows of a wave: in-lane over its 16-row blocks, then the 16 lanes of a DPP row; waves: through LDS in
-  // wave order; row tiles: by the caller's slice sum in index order.
-  if constexpr (!KALT && !PARITY) {
-    if (g.colpart) {
-      barrier();  // (every wave has left the K loop: the tile buffers are free)
-      float* red = reinterpret_cast<float*>(lds);
+  // written at all).  Rows of a wave: in-lane over its 16-row blocks, then the 16 lanes of a DPP row; waves (and, with alternate
+  // K steps, the two groups' row halves): through LDS in a fixed order; row tiles / parity classes: by the caller's deferred sum.
+  if (g.colpart) {
+    constexpr int NS = KALT ? 2 * WR : WR;  // partial sums per column
+    barrier();  // (every wave has left the K loop / the exchange: LDS is free)
+    float* red = reinterpret_cast<float*>(lds);
+    const int slot = KALT ? (idx / WC) * 2 + grp : idx / WC;
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = p3_row16_sum(cs[b][r]);
-          if (l15 == 0) red[(idx / WC) * BN + wn + b * 16 + l4 * 4 + r] = t;
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      barrier();
-      if (tid < BN) {
-        float t = red[tid];
-#pragma unroll
-        for (int w = 1; w < WR; ++w) t += red[w * BN + tid];
-        g.colpart[(size_t)(m0 / BM) * g.N + n0 + tid] = t;
+      for (int r = 0; r < 4; ++r) {
+        const float t = p3_row16_sum(cs[b][r]);
+        if (l15 == 0) red[slot * BN + wn + b * 16 + l4 * 4 + r] = t;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    if (tid < BN) {
+      float t = red[tid];
+#pragma unroll
+      for (int w = 1; w < NS; ++w) t += red[w * BN + tid];
+      g.colpart[(size_t)((PARITY ? bz * ny : 0) + m0 / BM) * g.N + n0 + tid] = t;
     }
   }
 }
@@ -753,7 +751,7 @@ struct P3Queued {
   dim3 grid;
   void (*single)(const P3Args&, dim3, hipStream_t);
 };
-struct P3Post { const float* part; float* out; int64_t n; int slices; bool deferrable; };
+struct P3Post { const float* part; float* out; int64_t n; int slices; bool deferrable; float* colws; };  // colws != NULL: a column sum of part [slices, n]
 static thread_local bool g_p3_group = false;
 static thread_local int g_p3_nq = 0, g_p3_npost = 0;
 static thread_local P3Queued g_p3_q[2];
@@ -774,7 +772,7 @@ static void p3_submit(const P3Args& a, dim3 grid, hipStream_t s) {
 // the immediate slice sum of a split-K backward-data result: after the (possibly queued) launch that writes the slices
 static void p3_sum_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
   if (g_p3_group && g_p3_npost < 2) {
-    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, false};
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, false, nullptr};
     return;
   }
   p3_sum_slices_now(part, out, n, slices, s);
@@ -782,7 +780,7 @@ static void p3_sum_after(const float* part, float* out, int64_t n, int slices, h
 // a deferrable slice sum (final gradients: bias column sums) of a result whose launch may still be queued
 static void p3_sum_deferrable_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
   if (g_p3_group && g_p3_npost < 2) {
-    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, true};
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, true, nullptr};
     return;
   }
   p3_sum_slices(part, out, n, slices, s);
@@ -793,6 +791,19 @@ static void p3_launch_pair(const P3Queued& w, const P3Queued& d, hipStream_t s) 
   hipLaunchKernelGGL((k_gemm_p3_pair<128, 128, 2, A_KM, B_G2, true, BM2, BN2, WR2, AF2, BF2, KALT2>), dim3((unsigned)(n1 + n2)),
                      dim3(512), 0, s, w.a, d.a, n1, (int)w.grid.x, (int)w.grid.y, (int)w.grid.z, (int)d.grid.x, (int)d.grid.y,
                      (int)d.grid.z);
+}
+void p3_colsum_deferrable(const float* G, float* out, int64_t M, int N, float* ws, hipStream_t s);  // mvae_conv.hip
+// the (deferrable) column sum of per-tile partial sums [rows, n] whose launch may still be queued
+static void p3_colsum_after(float* part, float* out, int64_t rows, int n, float* ws, hipStream_t s) {
+  if (g_p3_group && g_p3_npost < 2) {
+    g_p3_post[g_p3_npost++] = P3Post{part, out, n, (int)rows, true, ws};
+    return;
+  }
+  p3_colsum_deferrable(part, out, rows, n, ws, s);
+}
+extern "C" int64_t mvae_conv_transpose_k4s2p1_nhwc_p3_colsum_floats(int B, int IH, int IW, int OC) {
+  const int64_t rows = 4 * (((int64_t)B * IH * IW) / 128);
+  return (rows + (rows + 511) / 512) * OC;
 }
 extern "C" int mvae_p3_group(int on, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -818,7 +829,8 @@ extern "C" int mvae_p3_group(int on, void* stream) {
   if (!paired)
     for (int i = 0; i < g_p3_nq; ++i) g_p3_q[i].single(g_p3_q[i].a, g_p3_q[i].grid, s);
   for (int i = 0; i < g_p3_npost; ++i) {
-    if (g_p3_post[i].deferrable) p3_sum_slices(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
+    if (g_p3_post[i].colws) p3_colsum_deferrable(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].slices, (int)g_p3_post[i].n, g_p3_post[i].colws, s);
+    else if (g_p3_post[i].deferrable) p3_sum_slices(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
     else p3_sum_slices_now(g_p3_post[i].part, g_p3_post[i].out, g_p3_post[i].n, g_p3_post[i].slices, s);
   }
   g_p3_nq = g_p3_npost = 0;
@@ -977,16 +989,19 @@ extern "C" int mvae_gemm_nn_p3(const uint16_t* G_planes, int64_t g_ps, const uin
 // (columns (ky, kx, oc)); y [B * 2IH * 2IW, OC] f32 (+ planes), zeroed where mask <= 0.  A Conv2d's backward-data.
 extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, int64_t src_ps, const uint16_t* Wt_planes,
                                                   int64_t w_ps, const float* mask, const float* bias, int relu, float* y,
-                                                  uint16_t* y_planes, int64_t y_ps, int B, int Cc, int IH, int IW, int OC,
-                                                  void* stream) {
-  if (!src_planes || !Wt_planes || !y) return fail(MVAE_E_BADARG, "null pointer%s", "");
+                                                  uint16_t* y_planes, int64_t y_ps, float* colsum_out, float* colsum_ws, int B,
+                                                  int Cc, int IH, int IW, int OC, void* stream) {
+  if (!src_planes || !Wt_planes) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (!y && !(y_planes && colsum_out)) return fail(MVAE_E_BADARG, "y may only be NULL with planes + column sums%s", "");
+  if ((colsum_out == nullptr) != (colsum_ws == nullptr)) return fail(MVAE_E_BADARG, "colsum_out and colsum_ws go together%s", "");
   const int64_t M = (int64_t)B * IH * IW;
   const int K = 4 * Cc;
   if (!mvae_p3_supported(2, M, OC, K, Cc)) return fail(MVAE_E_UNSUPPORTED, "mvae_conv_transpose_k4s2p1_nhwc_p3: whole tiles only%s", "");
   P3Args a{};
   int rc = p3_geom(&a.cg, &a.lCc, B, Cc, IH, IW, false);
   if (rc) return rc;
-  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, 16 * OC, w_ps) || !aligned16(y) || (mask && !aligned16(mask)) ||
+  if (!planes_ok(src_planes, Cc, src_ps) || !planes_ok(Wt_planes, 16 * OC, w_ps) || (y && !aligned16(y)) || (mask && !aligned16(mask)) ||
+      (colsum_ws && !aligned16(colsum_ws)) ||
       (bias && !aligned16(bias)) || (y_planes && !planes_ok(y_planes, OC, y_ps)) || 4 * M > 0x7fffffff)
     return fail(MVAE_E_ALIGN, "plane operands must be 16-byte aligned%s", "");
   a.A = src_planes; a.lda = Cc; a.psa = src_ps;
@@ -994,8 +1009,13 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, in
   a.C = y; a.ldc = OC; a.Cp = y_planes; a.psc = y_ps; a.mask = mask; a.bias = bias; a.relu = relu;
   a.M = (int)M; a.N = OC; a.K = K; a.k_per_slice = K; a.slice_stride = 0;
   // 128 x 128 tiles only where they still give every CU a workgroup
+  a.colpart = colsum_ws;  // [4 parity classes x M / 128 row tiles][OC], then the column sum's own slice partials
   if (OC % 128 == 0 && (M / 128) * (OC / 128) * 4 >= 256) launch_p3<128, 128, 2, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
   else launch_p3<128, 64, 4, A_G3, B_G3W>(a, 4, (hipStream_t)stream);
+  if (colsum_out) {
+    const int64_t rows = 4 * (M / 128);
+    p3_colsum_after(colsum_ws, colsum_out, rows, OC, colsum_ws + rows * OC, (hipStream_t)stream);
+  }
   LAUNCH_CHECK("plane transposed conv launch");
   return 0;
 }

@@ -1006,6 +1006,14 @@ def test_plane_contractions_vs_float64(dev, case):
         y, yp = _convT_nhwc_p3(_planes_of(src), _planes_of(Wt), mask.to(dev), B, Cc, IH, OC, want_planes=True)
         close(y, ref, case)
         assert torch.equal(_planes_sum(yp), y)
+        # planes + column sums only (a bias gradient from the epilogue of the alternate-K-step / parity-class kernel)
+        from mvae_amd._lib import load
+        cs = torch.empty(OC, device=dev)
+        y2, yp2 = _convT_nhwc_p3(_planes_of(src), _planes_of(Wt), mask.to(dev), B, Cc, IH, OC, want_planes=True, colsum_out=cs,
+                                 want_y=False)
+        load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
+        assert y2 is None and torch.equal(yp2, yp)
+        assert_close(_cpu(cs), y.double().sum(0).cpu().numpy(), 2e-5, "epilogue column sums", atol_frac=2e-6)
     else:
         B, Cc, IH, OC = (16, 64, 16, 128) if case == "wgrad64" else (32, 128, 8, 256)
         x = rnd(B, Cc, IH, IH)
