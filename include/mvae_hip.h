@@ -458,6 +458,8 @@ int mvae_convt_to3_bce_stats(const float* src, const float* W, const float* bias
  * encoder's last ReLU), dW_d0, db_d0, dradii [ncomp] (0 for Euclidean components; fixed-order sums) and dheads [B, heads_dim]. 
  * dt0_slices > 1: dt0 points at that many partial results dt0_slice_stride floats apart (the K slices mvae_conv_k4s2p1_nhwc_p3
  * leaves in its workspace when called with y = NULL), added in mvae's slice-sum order while they are read; <= 1: one tensor.
+ * da2_chansum [512] + da2_chansum_ws [8192] (both or neither): sum of da2 over rows and pixels per channel (the bias gradient of
+ * the last encoder convolution) from the same launch; with them and da2_planes, da2 may be NULL.
  * t0_planes / da2_planes (NULL: none): the bf16 planes (mvae_split3_planes layout, plane stride *_ps elements) of t0 and da2,
  * written by the same launches for the plane contractions that consume them. */
 int mvae_conv_latent_supported(const mvae_component_desc* comps, int ncomp);
@@ -470,8 +472,9 @@ int mvae_conv_latent_backward(const mvae_component_desc* comps, int ncomp, const
                               const float* heads, const float* eps, int eps_ld, const float* radii, const float* z,
                               const float* W_d0, const float* t0, const float* dt0, int dt0_slices,
                               int64_t dt0_slice_stride, float beta, float* dW_heads,
-                              float* db_heads, float* da2, uint16_t* da2_planes, int64_t da2_ps, float* dW_d0,
-                              float* db_d0, float* dradii, float* dheads, float* workspace, int64_t B, void* stream);
+                              float* db_heads, float* da2, uint16_t* da2_planes, int64_t da2_ps, float* da2_chansum,
+                              float* da2_chansum_ws, float* dW_d0, float* db_d0, float* dradii, float* dheads,
+                              float* workspace, int64_t B, void* stream);
 /* torch-Adam over a flat buffer laid out like mvae_model_desc's (first 64 floats = raw radii, SGD on the trainable
  * ones iff do_curvature_step); counters as mvae_model_desc.step_count.  CurvatureOptimizer.step, utils.py:174-180.
  * radius_trainable[i]: 0 fixed, 1 trainable radius, 3 trainable universal curvature -- the entries marked 3 form the

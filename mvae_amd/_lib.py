@@ -119,7 +119,7 @@ PROTOTYPES = {
     "mvae_conv_latent_workspace_floats": (_L, [_L, _I]),
     "mvae_conv_latent_forward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "mvae_conv_latent_backward": (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P, _L, _P, _P,
-                                            _P, _P, _P, _L, _P]),
+                                            _P, _P, _P, _P, _P, _L, _P]),
     "mvae_optimizer_step_flat": (C.c_int, [_P, _P, _P, _P, _L, _P, _I, C.POINTER(C.c_uint8), C.c_double, C.c_double,
                                            _I, _I, _P]),
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),

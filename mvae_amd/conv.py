@@ -796,7 +796,7 @@ class ConvEngine:
             check(load().mvae_conv_latent_backward(
                 lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
                 epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0), 1, 0,
-                float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), None, 0,
+                float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), None, 0, None, None,
                 ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
                 stream_ptr(self.device)))
         else:
@@ -822,23 +822,28 @@ class ConvEngine:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None
 
-    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side, planes=None):
+    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side, planes=None, chansum_out=None):
         """Decoder fc backward, the components, the heads' backward: -> dhflat = the gradient of the channel-last a2 (+ its
-        bf16 planes into `planes` [3, B*16, 512], fused latent section only)."""
+        bf16 planes into `planes` [3, B*16, 512], fused latent section only).  chansum_out [512] (with planes): the sum of that
+        gradient over rows and pixels per channel (e2.bias) from the same launch; the f32 gradient is then not written and None
+        is returned."""
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
         if not c.get("fused"):
             return self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay, side)
-        dhflat = torch.empty_like(c["hflat"])
+        skip = planes is not None and chansum_out is not None
+        dhflat = None if skip else torch.empty_like(c["hflat"])
+        cws = _keep(dt0.new_empty(H_DIM)) if skip else None
         dheads = dt0.new_empty(B, NH)
         ws = dt0.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
         epsc = eps.contiguous()
         check(load().mvae_conv_latent_backward(
             lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]), ptr(c["heads"]), ptr(epsc),
             epsc.shape[1], ptr(self.params[:lay.n]), ptr(c["z"]), ptr(PV["d0.weight"]), ptr(c["t0"]), ptr(dt0),
-            dt0.shape[0] if dt0.dim() == 3 else 1, dt0[0].numel() if dt0.dim() == 3 else 0, float(beta), ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), _pptr(planes),
-            _ps(planes), ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
-            stream_ptr(self.device)))
+            dt0.shape[0] if dt0.dim() == 3 else 1, dt0[0].numel() if dt0.dim() == 3 else 0, float(beta),
+            ptr(self.grads[ow:ow + NH * H_DIM]), ptr(self.grads[ob:ob + NH]), ptr(dhflat), _pptr(planes), _ps(planes),
+            ptr(chansum_out) if skip else None, ptr(cws), ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]),
+            ptr(dheads), ptr(ws), B, stream_ptr(self.device)))
         return dhflat
 
     def _backward_body_p3(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side):
@@ -887,12 +892,15 @@ class ConvEngine:
             _colsum(db1, out=GV["d1.bias"])
         # ---- latent section
         da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None
-        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p)
+        epi_l = da2_p is not None and os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e2.bias from the latent launch
+        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p,
+                                       chansum_out=GV["e2.bias"] if epi_l else None)
         # ---- encoder backward
-        da2 = dhflat.view(B * 16, 512)
-        if da2_p is None:
-            da2_p = _split_planes([da2])[0]
-        _colsum(da2, out=GV["e2.bias"])
+        if dhflat is not None:
+            da2 = dhflat.view(B * 16, 512)
+            if da2_p is None:
+                da2_p = _split_planes([da2])[0]
+            _colsum(da2, out=GV["e2.bias"])
         if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "1") != "0" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
             # backward-data of e2 as four implicit contractions per output parity class (no [B * 16, 2048] product, no col2im:
             # 256 workgroups with 64 K steps each instead of two rounds of 16-step ones).  Equal to the product form until the

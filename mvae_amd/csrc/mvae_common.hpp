@@ -715,7 +715,8 @@ constexpr int kSknN = 16;
 template <int NN, bool CL>  // NN = N rounded up to a multiple of 4
 __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, const float* W, const float* dy, float* dW,
                                                    float* db, float* dx, int M, int N, int K, int relu_in,
-                                                   unsigned short* dx_planes = nullptr, long long dx_ps = 0) {
+                                                   unsigned short* dx_planes = nullptr, long long dx_ps = 0,
+                                                   float* dx_colsum = nullptr) {
   __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
   __shared__ f32x4 smn[NN][32][9];
   const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
@@ -739,6 +740,7 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
   // Latency, not bandwidth, bounds this kernel (one wave per SIMD, 16 MB moved): EVERY request of a 256-row chunk -- the
   // dy block, the W columns, the 8 rows of x -- is issued before the first use, so a chunk costs one memory round trip.
   f32x4 acc[NN], wr[NN];
+  f32x4 dxs = {0.f, 0.f, 0.f, 0.f};  // column sums of dx over this thread's rows (dx_colsum)
 #pragma unroll
   for (int n = 0; n < NN; ++n) {
     acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -787,14 +789,15 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
           if (n4 + j < N) dxv += d[j] * wr[n4 + j];  // (uniform; rows of W past N were clamped to row 0)
         }
       }
-      if (dx) {
+      if (dx || dx_planes || dx_colsum) {
         if (relu_in) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) dxv[j] = (xv[u][j] > 0.f) ? dxv[j] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(dx + (size_t)(m0 + r) * K + col) = dxv;
+        if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)(m0 + r) * K + col) = dxv;
         if (dx_planes)  // the bf16 planes of dx for a consumer on pre-split operands (mvae_p3.hpp)
           store_planes4(dx_planes, dx_ps, (size_t)(m0 + r) * K + col, dxv[0], dxv[1], dxv[2], dxv[3]);
+        dxs += dxv;  // (this thread's rows in order; the 32 row groups meet below)
       }
     }
   }
@@ -817,6 +820,16 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
       } else {
         *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col2) = t;
       }
+    }
+  }
+  if (dx_colsum) {  // sum_m dx[m][col .. col + 3]: this workgroup owns its 32 columns over ALL rows, so this is the whole sum
+    __syncthreads();
+    smn[0][g][c] = dxs;
+    __syncthreads();
+    if (tid < 8) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 32; ++q) t += smn[0][q][tid];
+      *reinterpret_cast<f32x4*>(dx_colsum + blk * 32 + tid * 4) = t;
     }
   }
 }

@@ -2156,7 +2156,8 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
                                                             const float* __restrict__ dheads, int NH,
                                                             float* __restrict__ dW_heads, float* __restrict__ db_heads,
                                                             float* __restrict__ da2, bf16r* __restrict__ da2p,
-                                                            long long da2ps, const float* __restrict__ dd0,
+                                                            long long da2ps, float* __restrict__ da2cs,
+                                                            const float* __restrict__ dd0,
                                                             const float* __restrict__ z, int Z,
                                                             float* __restrict__ dW_d0, float* __restrict__ db_d0,
                                                             const float* __restrict__ drad_rows,
@@ -2166,7 +2167,7 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
   const int nshort = kD0 / 32 + 1;
   int blk = blockIdx.x;
   if (blk >= nshort) {
-    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1, da2p, da2ps);
+    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1, da2p, da2ps, da2cs);
     return;
   }
   const int tid = threadIdx.x;
@@ -2311,9 +2312,12 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
                                          const float* radii, const float* z, const float* W_d0, const float* t0,
                                          const float* dt0, int dt0_slices, int64_t dt0_slice_stride, float beta,
                                          float* dW_heads, float* db_heads, float* da2,
-                                         uint16_t* da2_planes, int64_t da2_ps, float* dW_d0, float* db_d0, float* dradii,
-                                         float* dheads, float* workspace, int64_t B, void* stream) {
-  if (!a2 || !W_heads || !heads || !eps || !z || !W_d0 || !t0 || !dt0 || !dW_heads || !db_heads || !da2 || !dW_d0 ||
+                                         uint16_t* da2_planes, int64_t da2_ps, float* da2_chansum, float* da2_chansum_ws,
+                                         float* dW_d0, float* db_d0, float* dradii, float* dheads, float* workspace, int64_t B,
+                                         void* stream) {
+  if ((da2_chansum == nullptr) != (da2_chansum_ws == nullptr)) return fail(MVAE_E_BADARG, "da2_chansum and its workspace go together%s", "");
+  if (!da2 && !(da2_planes && da2_chansum)) return fail(MVAE_E_BADARG, "da2 may only be NULL with planes + channel sums%s", "");
+  if (!a2 || !W_heads || !heads || !eps || !z || !W_d0 || !t0 || !dt0 || !dW_heads || !db_heads || !dW_d0 ||
       !db_d0 || !dradii || !dheads || !workspace || B < 1 || B > 0x3fffff)
     return fail(MVAE_E_BADARG, "null pointer / bad batch%s", "");
   int NH, Z, ed, dmax;
@@ -2321,7 +2325,7 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
     return fail(MVAE_E_UNSUPPORTED, "fused conv latent section: heads_dim, z_dim <= 16 and true dimensions <= 8%s", "");
   if (eps_ld < ed) return fail(MVAE_E_BADARG, "eps_ld smaller than the components' eps columns%s", "");
   if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)dt0) | ((uintptr_t)da2) | ((uintptr_t)workspace) |
-        ((uintptr_t)W_d0)) & 15) != 0)
+        ((uintptr_t)W_d0) | ((uintptr_t)da2_chansum_ws)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned activations / W_d0 / workspace%s", "");
   if (da2_planes && ((((uintptr_t)da2_planes) & 7) || (da2_ps & 3))) return fail(MVAE_E_ALIGN, "da2 planes: 8-byte aligned%s", "");
   CompTable t;
@@ -2343,8 +2347,10 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
                                              (long long)dt0_slice_stride, beta, dd0, dheads, drad_rows, (int)B));
   const unsigned grid = kFlat / 32 + 1 + kD0 / 32 + 1;
   MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_latent_bwd_cols<NN>), dim3(grid), dim3(256), 0, s, t, a2, W_heads, dheads,
-                                         NH, dW_heads, db_heads, da2, da2_planes, (long long)da2_ps, dd0, z, Z, dW_d0, db_d0,
-                                         drad_rows, dradii, (int)B));
+                                         NH, dW_heads, db_heads, da2, da2_planes, (long long)da2_ps, da2_chansum_ws, dd0, z, Z,
+                                         dW_d0, db_d0, drad_rows, dradii, (int)B));
+  // the 16 pixels of a channel: added in pixel order by the (deferrable) slice sum
+  if (da2_chansum) sum_slices(da2_chansum_ws, da2_chansum, kEncC, kPix, s);
   LAUNCH_CHECK("fused conv latent backward launch");
   return 0;
 }

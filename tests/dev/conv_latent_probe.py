@@ -52,7 +52,7 @@ dheads = torch.empty(B, NH, device=dev)
 # feed the GENERIC forward values so that only the backward kernels are compared
 check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
                                        ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), 1, 0, beta, ptr(dW), ptr(dbh), ptr(da2),
-                                       None, 0, ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads), ptr(ws), B, stream_ptr(dev)))
+                                       None, 0, None, None, ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads), ptr(ws), B, stream_ptr(dev)))
 torch.cuda.synchronize()
 print("dheads", rel(dheads, dheads_g), "drad", rel(drad, drad_g), "dW_heads", rel(dW, dW_g), "db_heads", rel(dbh, dbh_g),
       "da2", rel(da2, dh_g), "dW_d0", rel(dWd, dWd_g), "db_d0", rel(dbd, dbd_g))

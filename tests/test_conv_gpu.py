@@ -617,7 +617,7 @@ def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
     da2_p = torch.empty(3, B, 8192, dtype=torch.bfloat16, device=dev)
     check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
                                            ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), 1, 0, beta, ptr(dW), ptr(dbh), ptr(da2),
-                                           da2_p.data_ptr(), da2_p[0].numel(), ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads),
+                                           da2_p.data_ptr(), da2_p[0].numel(), None, None, ptr(dWd), ptr(dbd), ptr(drad), ptr(dheads),
                                            ptr(ws), B, stream_ptr(dev)))
     assert torch.equal(_planes_sum(da2_p), da2), "da2 planes are not the exact split of da2"
     # dt0 handed over as the un-added K slices of its contraction: [a, 0, 0, 0, b, 0] with a + b = dt0 exactly (a = dt0 with its
@@ -630,10 +630,19 @@ def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
     outs2 = [torch.empty_like(x) for x in (dW, dbh, da2, dWd, dbd, drad, dheads)]
     check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
                                            ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(sl), 6, sl[0].numel(), beta, ptr(outs2[0]),
-                                           ptr(outs2[1]), ptr(outs2[2]), None, 0, ptr(outs2[3]), ptr(outs2[4]), ptr(outs2[5]),
-                                           ptr(outs2[6]), ptr(ws), B, stream_ptr(dev)))
+                                           ptr(outs2[1]), ptr(outs2[2]), None, 0, None, None, ptr(outs2[3]), ptr(outs2[4]),
+                                           ptr(outs2[5]), ptr(outs2[6]), ptr(ws), B, stream_ptr(dev)))
     for x, y_, nm in zip((dW, dbh, da2, dWd, dbd, drad, dheads), outs2, ("dW", "dbh", "da2", "dWd", "dbd", "drad", "dheads")):
         assert torch.equal(x, y_), nm + " differs when dt0 arrives as slices"
+    # planes + per-channel sums of da2 only (e2.bias from the same launch, no f32 da2)
+    da2_p3, chs, chws = torch.empty_like(da2_p), torch.empty(512, device=dev), torch.empty(8192, device=dev)
+    outs3 = [torch.empty_like(x) for x in (dW, dbh, dWd, dbd, drad, dheads)]
+    check(load().mvae_conv_latent_backward(lay.descs, n, ptr(a2), ptr(W), ptr(heads_g), ptr(eps), lay.eps_dim, ptr(radii),
+                                           ptr(co["z"]), ptr(Wd), ptr(t0_g), ptr(dt0), 1, 0, beta, ptr(outs3[0]), ptr(outs3[1]),
+                                           None, da2_p3.data_ptr(), da2_p3[0].numel(), ptr(chs), ptr(chws), ptr(outs3[2]),
+                                           ptr(outs3[3]), ptr(outs3[4]), ptr(outs3[5]), ptr(ws), B, stream_ptr(dev)))
+    assert torch.equal(da2_p3, da2_p)
+    assert_close(_cpu(chs), da2.double().view(B, 16, 512).sum((0, 1)).cpu().numpy(), 2e-5, "channel sums of da2", atol_frac=2e-6)
     for got, want, nm in [(dheads, dheads_g, "dheads"), (drad, drad_g, "dradii"), (dW, dW_g, "dW_heads"),
                           (dbh, dbh_g, "db_heads"), (da2, dh_g, "da2"), (dWd, dWd_g, "dW_d0"), (dbd, dbd_g, "db_d0")]:
         assert_close(_cpu(got), _cpu(want), 2e-5, nm, atol_frac=2e-5)

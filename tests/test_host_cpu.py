@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     assert lib.mvae_conv_latent_forward(None, 1, None, None, None, None, 6, None, None, None, None, None, None, None, None, 0,
                                         None, 4, None) == -1
     assert lib.mvae_conv_latent_backward(None, 1, None, None, None, None, 6, None, None, None, None, None, 1, 0, 1.0, None, None,
-                                         None, None, 0, None, None, None, None, None, 4, None) == -1
+                                         None, None, 0, None, None, None, None, None, None, None, 4, None) == -1
     assert lib.mvae_conv3_k4s2p1_nchw(None, None, None, None, 1, None, None, 0, 4, 3, 32, 32, 64, None) == -1
     assert lib.mvae_conv3_k4s2p1_nchw(16, 16, None, None, 1, 16, None, 0, 4, 3, 64, 64, 64, None) == -2  # 3 x 32 x 32 only
     assert lib.mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats(256, 3, 32, 32, 64) == 256 * 64 * 48
