@@ -1025,7 +1025,11 @@ extern "C" int mvae_conv_transpose_k4s2p1_nhwc_p3(const uint16_t* src_planes, in
 // are added in index order; workspace = mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats floats.
 static int p3_wgrad_slices(int64_t M, int NP, int NQ, int* kps) {
   const int wg = (NP / 128) * (NQ / 128);
-  int slices = (256 + wg - 1) / wg;
+  // 128 workgroups, not one per CU: a weight gradient leaves in ONE launch with its layer's backward-data (mvae_p3_group), whose
+  // 256-512 workgroups fill the other CUs; half the row slices are half the partial results to write and to add (67 -> 34 MB per
+  // step) and twice the K loop per workgroup.  Step, same box: 0.657 (256) / 0.663 (192) / 0.644 (128) / 0.700 (64) ms.
+  static const int target = getenv("MVAE_P3_WGRAD_WGS") ? atoi(getenv("MVAE_P3_WGRAD_WGS")) : 128;
+  int slices = (target + wg - 1) / wg;
   const int max_slices = (int)(M / 256);
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;
