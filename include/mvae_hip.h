@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 9
+#define MVAE_ABI_VERSION 10
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -585,6 +585,20 @@ int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta,
  * captured into a HIP graph and replayed for a whole epoch without host work. */
 int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E, uint64_t seed,
                        const int32_t* counters, int batches_per_epoch, int train, float* x, float* eps, void* stream);
+
+/* The same preparation WITHOUT a launch of its own ("fused into the step", scope row f-2): arms `ctx` so that the NEXT step
+ * launched on it (mvae_train_step, mvae_step_forward_backward[_parts HEAD], mvae_step_profile) also prepares, on spare
+ * workgroups of its launch 4, the batch its successor will consume -- batch number counters[8] AFTER that step's launch 1
+ * has advanced the cursor -- into x_next[B, D] / eps_next[B, E]: bit for bit what mvae_prepare_batch would write if it were
+ * called after that step with the same arguments.  x_next / eps_next must not be the buffers that step itself reads (callers
+ * alternate between two pairs); the first batch of a sequence comes from mvae_prepare_batch.  One-shot: the step
+ * consumes the arming; images == NULL disarms.  Host-side state only (no launch, no stream): under graph capture every
+ * captured step carries its own arming.  Why the next batch rather than "in the first layer's operand load": the encoder
+ * layer's 16-row operand panel is loaded by every one of its H / 16 column-tile workgroups, each of which would repeat the
+ * ten Philox rounds per four pixels (quarter-rate 32-bit multiplies) on its critical path; on launch 4's spare workgroups
+ * the same work runs once, beside the tiles. */
+int mvae_set_next_batch_feed(mvae_ctx* ctx, const uint8_t* images, const int32_t* perm, int n_images, uint64_t seed,
+                             int batches_per_epoch, int train, float* x_next, float* eps_next);
 
 /* Measurement aid (never captured into a graph, synchronises): runs `iters` full steps on `stream` with a HIP event
  * between consecutive launches and writes the average duration of each of the MVAE_STEP_KERNELS launches, in

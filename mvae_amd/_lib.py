@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -133,6 +133,7 @@ PROTOTYPES = {
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),
+    "mvae_set_next_batch_feed": (C.c_int, [_P, _P, _P, _I, C.c_uint64, _I, _I, _P, _P]),
     "mvae_slice_sums_defer": (C.c_int, [_I]),
     "mvae_slice_sums_flush": (C.c_int, [_P]),
     "mvae_step_kernel_path": (C.c_int, [_P]),

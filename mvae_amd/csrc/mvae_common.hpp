@@ -834,3 +834,103 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ device-side input pipeline
+// Row f-2 of the scope table: the reference feeds the step from 8 DataLoader worker processes that binarise every image
+// on the CPU (mt/data/image_reconstruction.py:44-53,70-74) plus a host->device copy, and draws eps with the torch RNG
+// inside the step.  Here the data set lives in HBM as uint8; a batch is gathered by a device-resident permutation,
+// binarised dynamically (x = pixel/255 > U(0,1)) and eps ~ N(0,1) is drawn, both from a counter-based Philox4x32-10
+// stream keyed by (seed, batch cursor) -- no host work, so a whole epoch can be replayed as HIP graphs.  The work is
+// cut into ITEMS of four consecutive values (one Philox call each); who runs the items is the caller's choice: the
+// stand-alone launch of mvae_prepare_batch (mvae_conv.hip) or spare workgroups of launch 4 of the PREVIOUS step
+// (mvae_set_next_batch_feed, mvae_step.hip), which write the same bits.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct FeedArgs {
+  const unsigned char* images;  // [n_images][D] uint8; NULL: no feed
+  const int* perm;              // device permutation or NULL
+  const int* counters;          // counters[8] = batch cursor
+  float* x;                     // [B][D]
+  float* eps;                   // [B][E]
+  unsigned long long seed;
+  int n_images, D, B, E, batches_per_epoch, mode, n_wg;
+};
+
+__device__ __forceinline__ int feed_items(const FeedArgs& f) { return (f.B * f.D + 3) / 4 + (f.B * f.E + 3) / 4; }
+
+// ToTensor's x / 255 as the correctly rounded float32 quotient: through double (the build's -freciprocal-math may turn a
+// float division into x * (1 / 255), one ulp off for some pixel values; the double product's error is 2^-29 of a float
+// ulp and no pixel value lies that close to a rounding boundary -- tests/test_input_pipeline_gpu.py checks all 256)
+__device__ __forceinline__ float feed_pixel(unsigned char v) { return (float)((double)v * (1.0 / 255.0)); }
+
+__device__ __forceinline__ float feed_value(int mode, float pix, unsigned r) {
+  const float u = (float)(r >> 8) * (1.0f / 16777216.0f);  // [0,1)
+  return mode == 2 ? pix : ((mode ? (pix > u) : (pix > 0.5f)) ? 1.0f : 0.0f);
+}
+
+__device__ __forceinline__ void feed_item(const FeedArgs& f, unsigned cursor, int i) {
+  const int bi = (int)(cursor % (unsigned)f.batches_per_epoch);
+  const unsigned k0 = (unsigned)f.seed, k1 = (unsigned)(f.seed >> 32);
+  const int nx4 = (f.B * f.D + 3) / 4, D = f.D;
+  unsigned r[4];
+  if (i < nx4) {
+    philox4x32_10((unsigned)i, cursor, 0u, 0u, k0, k1, r);  // stream 0: binarisation
+    const int e0 = i * 4;
+    if ((D & 3) == 0 && (((size_t)f.images | (size_t)f.x) & 3) == 0) {  // the four values lie in one row: one request each way
+      const int b = e0 / D, j = e0 - b * D;
+      const int src = f.perm ? f.perm[(size_t)bi * f.B + b] : (bi * f.B + b);
+      const unsigned pk =
+          *reinterpret_cast<const unsigned*>(f.images + (size_t)(src < f.n_images ? src : f.n_images - 1) * D + j);
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = feed_value(f.mode, feed_pixel((unsigned char)(pk >> (8 * t))), r[t]);
+      if ((((size_t)f.x) & 15) == 0) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(f.x + e0) = o;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.x[e0 + t] = v[t];
+      }
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = e0 + t;
+      if (e < f.B * D) {
+        const int b = e / D, j = e - b * D;
+        const int src = f.perm ? f.perm[(size_t)bi * f.B + b] : (bi * f.B + b);
+        const float pix = feed_pixel(f.images[(size_t)(src < f.n_images ? src : f.n_images - 1) * D + j]);
+        f.x[e] = feed_value(f.mode, pix, r[t]);
+      }
+    }
+  } else {
+    const int q = i - nx4;
+    philox4x32_10((unsigned)q, cursor, 1u, 0u, k0, k1, r);  // stream 1: eps
+    float n[4];  // Box-Muller on two pairs
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float u1 = ((float)(r[2 * t] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+      const float u2 = (float)(r[2 * t + 1] >> 8) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      n[2 * t] = rad * cs;
+      n[2 * t + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (q * 4 + t < f.B * f.E) f.eps[q * 4 + t] = n[t];
+  }
+}

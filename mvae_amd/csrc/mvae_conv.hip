@@ -2356,72 +2356,11 @@ extern "C" int mvae_conv_latent_backward(const mvae_component_desc* comps, int n
 }
 
 // ------------------------------------------------------------------------------------------------ device-side input pipeline
-// Row f-2 of the scope table: the reference feeds the step from 8 DataLoader worker processes that binarise every image
-// on the CPU (mt/data/image_reconstruction.py:44-53,70-74) plus a host->device copy, and draws eps with the torch RNG
-// inside the step.  Here the data set lives in HBM as uint8, and ONE small launch per step gathers the next batch by
-// a device-resident permutation, binarises it dynamically (x = pixel/255 > U(0,1)) and draws eps ~ N(0,1), both from
-// a counter-based Philox4x32-10 stream keyed by (seed, batch cursor) -- no host work, so a whole epoch can be
-// replayed as HIP graphs.  The cursor lives in counters[8] and is advanced by launch 1 of the step.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                              unsigned k1, unsigned out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__global__ __launch_bounds__(256) void k_prepare_batch(const unsigned char* images, const int* perm, int n_images,
-                                                       int D, int B, int E, unsigned long long seed,
-                                                       const int* counters, int batches_per_epoch, int train,
-                                                       float* x, float* eps) {
-  const unsigned cursor = (unsigned)counters[8];
-  const int bi = (int)(cursor % (unsigned)batches_per_epoch);
-  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-  const int nx4 = (B * D + 3) / 4, ne4 = (B * E + 3) / 4;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < nx4 + ne4; i += gridDim.x * 256) {
-    unsigned r[4];
-    if (i < nx4) {
-      philox4x32_10((unsigned)i, cursor, 0u, 0u, k0, k1, r);  // stream 0: binarisation
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int e = i * 4 + t;
-        if (e < B * D) {
-          const int b = e / D, j = e - b * D;
-          const int src = perm ? perm[(size_t)bi * B + b] : (bi * B + b);
-          // ToTensor's x / 255 as the correctly rounded float32 quotient: through double (the build's -freciprocal-math may turn a
-          // float division into x * (1 / 255), one ulp off for some pixel values; the double product's error is 2^-29 of a float
-          // ulp and no pixel value lies that close to a rounding boundary -- tests/test_input_pipeline_gpu.py checks all 256)
-          const float pix = (float)((double)images[(size_t)(src < n_images ? src : n_images - 1) * D + j] * (1.0 / 255.0));
-          const float u = (float)(r[t] >> 8) * (1.0f / 16777216.0f);  // [0,1)
-          x[e] = train == 2 ? pix : ((train ? (pix > u) : (pix > 0.5f)) ? 1.0f : 0.0f);
-        }
-      }
-    } else {
-      const int q = i - nx4;
-      philox4x32_10((unsigned)q, cursor, 1u, 0u, k0, k1, r);  // stream 1: eps
-      // Box-Muller on two pairs
-      float n[4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float u1 = ((float)(r[2 * t] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
-        const float u2 = (float)(r[2 * t + 1] >> 8) * (1.0f / 16777216.0f);
-        const float rad = sqrtf(-2.0f * logf(u1));
-        float sn, cs;
-        sincosf(6.283185307179586f * u2, &sn, &cs);
-        n[2 * t] = rad * cs;
-        n[2 * t + 1] = rad * sn;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (q * 4 + t < B * E) eps[q * 4 + t] = n[t];
-    }
-  }
+// (items and their arithmetic: mvae_common.hpp, "device-side input pipeline")
+__global__ __launch_bounds__(256) void k_prepare_batch(FeedArgs f) {
+  const unsigned cursor = (unsigned)f.counters[8];
+  const int n = feed_items(f);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) feed_item(f, cursor, i);
 }
 
 extern "C" int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E,
@@ -2430,8 +2369,8 @@ extern "C" int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, in
   if (!images || !counters || !x || !eps || n_images < 1 || D < 1 || B < 1 || E < 1 || batches_per_epoch < 1)
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   const int work = (B * D + 3) / 4 + (B * E + 3) / 4;
-  hipLaunchKernelGGL(k_prepare_batch, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream, images, perm,
-                     n_images, D, B, E, (unsigned long long)seed, counters, batches_per_epoch, train, x, eps);
+  FeedArgs f = {images, perm, counters, x, eps, (unsigned long long)seed, n_images, D, B, E, batches_per_epoch, train, 0};
+  hipLaunchKernelGGL(k_prepare_batch, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream, f);
   LAUNCH_CHECK("prepare batch launch");
   return 0;
 }

@@ -42,6 +42,7 @@ struct mvae_ctx {
   bool blk_small;        // MVAE_BLK_SMALL=1: the block backward kernel also for z_dim <= 16 (the fused-forward configs)
   bool blk_fwd;          // block kernels in the forward launches as well (MVAE_BLK_FWD=0: per-row forward, A/B measurements)
   bool coop;             // large components (true dim >= 9): wave-cooperative kernels (MVAE_NO_COOP=1: off)
+  FeedArgs feed;         // mvae_set_next_batch_feed: the batch launch 4 of the NEXT step prepares (images == NULL: none)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
@@ -1077,7 +1078,7 @@ template <bool ADAM, bool FULL, int DUAL>
 __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
-                                                  int n_db, AdamArgs ab, DualArgs da) {
+                                                  int n_db, AdamArgs ab, DualArgs da, FeedArgs fd) {
   __shared__ float red[kW8][16][17];
   // Workgroup order: the short jobs first (statistics, bias column sums, padded to a multiple of 8 so that the tile
   // workgroups keep L % 8 == XCD), then the dhd tiles.  The grid is larger than the chip: workgroups dispatched last
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
   const int n_dual = DUAL > 0 ? da.n_dual : 0;
-  const int n_short = (n_dual + 1 + n_db + 7) & ~7;
+  const int n_short = (n_dual + 1 + n_db + fd.n_wg + 7) & ~7;
   MV_SPAN_BEGIN(3);
   if (DUAL > 0 && b < n_dual) {  // the longest chains of the launch: dispatched first, ONE wave per workgroup (= per CU)
     if (threadIdx.x < 64)
@@ -1112,7 +1113,18 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     MV_SPAN_END(3, 1);
     return;
   }
-  if (b > n_db) return;  // padding
+  if (b > n_db) {
+    // Input pipeline (mvae_set_next_batch_feed): spare workgroups gather, binarise and draw the NEXT step's batch while the
+    // dhd tiles run -- launch 1 of this step has already advanced the cursor, so counters[8] names that batch.  Nothing in
+    // this step reads the buffers written here (the caller alternates between two).
+    const int fb = b - n_db - 1;
+    if (fb < fd.n_wg) {
+      const unsigned cursor = (unsigned)fd.counters[8];
+      const int n = feed_items(fd);
+      for (int i = fb * (int)blockDim.x + (int)threadIdx.x; i < n; i += fd.n_wg * (int)blockDim.x) feed_item(fd, cursor, i);
+    }
+    return;  // (the rest: padding)
+  }
   if (b >= 1) {
     b -= 1;
     job_colsum_opt<ADAM>(&red[0][0][0], g, D, B, D, b * kColsPerBlock, db, ab);
@@ -1983,11 +1995,13 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     DualArgs da = {heads, eps, P + d.off_radii, duals, c->ldh, d.eps_dim, NH, 0};
     const bool duals_in_l4 = false;  // the fused forward's dual workgroups produce the records (job_duals stays available)
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
-    const int n_short = (da.n_dual + 1 + n_db + 7) & ~7;
+    const FeedArgs fd = c->feed;  // one-shot: consumed by this step
+    c->feed = FeedArgs{};
+    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + 7) & ~7;
 #define DB(AD, FU, DU)                                                                                         \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits,     \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
-              at(d.off_b_logits), da)
+              at(d.off_b_logits), da, fd)
     if (fwd23 && duals_in_l4) {  // full && dmax bucket in {2, 4, 8}
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) DB(true, true, 2); else if (bk == 4) DB(true, true, 4); else DB(true, true, 8); }
@@ -2045,6 +2059,27 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   }
 #undef STEP_LAUNCH
   LAUNCH_CHECK("step launch");
+  return 0;
+}
+
+extern "C" int mvae_set_next_batch_feed(mvae_ctx* c, const uint8_t* images, const int32_t* perm, int n_images, uint64_t seed,
+                                        int batches_per_epoch, int train, float* x_next, float* eps_next) {
+  if (!c) return fail(MVAE_E_BADARG, "null ctx%s", "");
+  if (!images) {
+    c->feed = FeedArgs{};
+    return 0;
+  }
+  if (!x_next || !eps_next || n_images < 1 || batches_per_epoch < 1 || train < 0 || train > 2)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const mvae_model_desc& d = c->d;
+  FeedArgs f = {images, perm, d.step_count, x_next, eps_next, (unsigned long long)seed, n_images, d.in_dim, d.batch,
+                d.eps_dim, batches_per_epoch, train, 0};
+  // two items (of four values) per thread of a 512-thread workgroup; the workgroups join launch 4's short jobs
+  static const int per_thread = [] { const char* e = getenv("MVAE_FEED_ITEMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+  const int items = (d.batch * d.in_dim + 3) / 4 + (d.batch * d.eps_dim + 3) / 4;
+  f.n_wg = (items + 512 * per_thread - 1) / (512 * per_thread);
+  if (f.n_wg > 128) f.n_wg = 128;
+  c->feed = f;
   return 0;
 }
 

@@ -260,6 +260,23 @@ class StepEngine:
         check(load().mvae_train_step(self._context(B), ptr(x), ptr(eps), float(beta),
                                      1 if do_curvature_step else 0, stream_ptr(self.device)))
 
+    def set_next_batch_feed(self, batch: int, images: Optional[Tensor], perm: Optional[Tensor] = None, seed: int = 0,
+                            batches_per_epoch: int = 1, mode: int = 1, x_next: Optional[Tensor] = None,
+                            eps_next: Optional[Tensor] = None) -> None:
+        """Arms the context of batch size `batch`: its next step also prepares the batch AFTER it into x_next / eps_next on
+        spare workgroups of launch 4 (mvae_set_next_batch_feed; images None disarms).  One-shot."""
+        import ctypes
+        if images is None:
+            check(load().mvae_set_next_batch_feed(self._context(batch), None, None, 0, ctypes.c_uint64(0), 1, 0, None, None))
+            return
+        if images.dtype != torch.uint8 or images.dim() != 2 or images.shape[1] != self.in_dim or not images.is_contiguous():
+            raise ValueError(f"images must be contiguous uint8 [N, {self.in_dim}]")
+        if tuple(x_next.shape) != (batch, self.in_dim) or tuple(eps_next.shape) != (batch, self.layout.eps_dim):
+            raise ValueError("x_next / eps_next do not match the batch")
+        check(load().mvae_set_next_batch_feed(self._context(batch), ptr(images), ptr(perm), int(images.shape[0]),
+                                              ctypes.c_uint64(int(seed)), int(batches_per_epoch), int(mode), ptr(x_next),
+                                              ptr(eps_next)))
+
     def kernel_path(self, batch: int = None) -> str:
         """"row" | "fused" | "block": which latent kernels the step takes at this batch size (mvae_step_kernel_path)."""
         B = int(batch) if batch is not None else (self._last_batch or 128)

@@ -156,18 +156,23 @@ class StepRunner:
 
 
 class EpochRunner:
-    """A training epoch with NO per-step host work: the data set lives in HBM as uint8, every step is the pair
-    [mvae_prepare_batch (gather + dynamic binarisation + eps draw, Philox), fused train step], and the pairs are replayed
-    as HIP graphs of `graph_steps` steps.  The batch cursor and the Adam step counter are device-resident, so one
-    captured graph serves every position of every epoch; only a change of (beta, curvature gate, trainable flags) re-captures.
-    Replaces the reference's DataLoader worker processes + per-step H2D copy + torch RNG draw
-    (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
+    """A training epoch with NO per-step host work: the data set lives in HBM as uint8, every step prepares its
+    successor's batch (gather + dynamic binarisation + eps draw, Philox) on spare workgroups of its own launch 4
+    (mvae_set_next_batch_feed; two buffer pairs in alternation, the first batch of an epoch from one mvae_prepare_batch
+    launch), and the steps are replayed as HIP graphs of `graph_steps` steps.  Engines without that hook (the conv
+    architecture; fold=False) run [mvae_prepare_batch, step] pairs instead -- the same bits either way.  The batch cursor
+    and the Adam step counter are device-resident, so one captured graph serves every position of every epoch; only a
+    change of (beta, curvature gate, trainable flags) re-captures.  Replaces the reference's DataLoader worker processes +
+    per-step H2D copy + torch RNG draw (mt/data/image_reconstruction.py:44-53,70-74; vae.py:153)."""
 
     def __init__(self, eng, images: Tensor, batch: int, seed: int = 0, graph_steps: int = 32,
-                 shuffle: bool = True, dp: Optional[DataParallelStep] = None, binarize: bool = True):
+                 shuffle: bool = True, dp: Optional[DataParallelStep] = None, binarize: bool = True,
+                 fold: Optional[bool] = None):
         """eng: a StepEngine (MLP) or a ConvEngine (conv architecture).  binarize: ImageDynamicBinarization (MNIST,
-        image_reconstruction.py:44-53) or, False, pixel / 255 as it is (CIFAR: ToTensor only, image_reconstruction.py:123-127)."""
+        image_reconstruction.py:44-53) or, False, pixel / 255 as it is (CIFAR: ToTensor only, image_reconstruction.py:123-127).
+        fold: prepare batch n + 1 inside step n (default: whenever the engine can; MVAE_FEED_FOLD=0 turns it off)."""
         import ctypes as C
+        import os
 
         from ._lib import check, load, ptr, stream_ptr
         assert images.dtype == torch.uint8 and images.dim() == 2 and images.is_cuda
@@ -181,8 +186,16 @@ class EpochRunner:
         self.mode = 1 if binarize else 2  # mvae_prepare_batch's `train` argument
         self.gs = max(1, min(int(graph_steps), self.nb))
         dev = images.device
-        self.x = torch.zeros(self.B, self.D, device=dev)
-        self.eps = torch.zeros(self.B, self.E, device=dev)
+        can_fold = hasattr(eng, "set_next_batch_feed")
+        if fold is None:
+            fold = can_fold and os.environ.get("MVAE_FEED_FOLD", "1") != "0"
+        if fold and not can_fold:
+            raise ValueError("this engine has no in-step input preparation")
+        self.fold = bool(fold)
+        # two (x, eps) pairs in alternation when the step prepares its successor's batch; `par` = the pair the next step reads
+        self._bufs = [(torch.zeros(self.B, self.D, device=dev), torch.zeros(self.B, self.E, device=dev))
+                      for _ in range(2 if self.fold else 1)]
+        self.par = 0
         self.perm = torch.arange(self.N, device=dev, dtype=torch.int32)
         self._gen = torch.Generator(device=dev).manual_seed(self.seed)
         self._graphs = {}
@@ -195,26 +208,50 @@ class EpochRunner:
             # (the direct RCCL route and the peer routes are capturable under any process-group backend)
             self.capturable = self.dp.capturable
 
-    def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
+    @property
+    def x(self) -> Tensor:
+        """The batch the next step reads (after a step: the one prepared for its successor)."""
+        return self._bufs[self.par][0]
+
+    @property
+    def eps(self) -> Tensor:
+        return self._bufs[self.par][1]
+
+    def _prepare(self, train: bool = True) -> None:
+        """One mvae_prepare_batch launch: the batch at the cursor into the pair the next step reads."""
         C, check, load, ptr, stream_ptr = self._c
+        x, eps = self._bufs[self.par]
         check(load().mvae_prepare_batch(ptr(self.images), ptr(self.perm), self.N, self.D, self.B, self.E,
                                         C.c_uint64(self.seed), ptr(self.eng.counters), self.nb,
                                         self.mode if train else (0 if self.mode == 1 else 2),
-                                        ptr(self.x), ptr(self.eps), stream_ptr(self.images.device)))
-        if self.dp is None:
-            self.eng.train_step(self.x, self.eps, beta, do_curv)
+                                        ptr(x), ptr(eps), stream_ptr(self.images.device)))
+
+    def _pair(self, beta: float, do_curv: bool, train: bool = True) -> None:
+        x, eps = self._bufs[self.par]
+        if self.fold:
+            nx, ne = self._bufs[self.par ^ 1]
+            self.eng.set_next_batch_feed(self.B, self.images, self.perm, self.seed, self.nb,
+                                         self.mode if train else (0 if self.mode == 1 else 2), nx, ne)
+            self.par ^= 1
         else:
-            self.dp.train_step(self.x, self.eps, beta, do_curv)
+            self._prepare(train)
+        if self.dp is None:
+            self.eng.train_step(x, eps, beta, do_curv)
+        else:
+            self.dp.train_step(x, eps, beta, do_curv)
 
     def _graph(self, beta: float, do_curv: bool) -> torch.cuda.CUDAGraph:
-        # the trainable flags travel in the kernel arguments, so a requires_grad toggle needs a fresh capture
-        key = (float(beta), bool(do_curv), tuple(self.eng.radius_trainable), self.eng.generation)
+        # the trainable flags travel in the kernel arguments, so a requires_grad toggle needs a fresh capture; so do the
+        # buffer pointers: a graph is captured for the pair its first step reads
+        key = (float(beta), bool(do_curv), tuple(self.eng.radius_trainable), self.eng.generation, self.par)
         if key not in self._graphs:
             # graphs of an older engine generation reference freed workspaces / a stale lr: drop them
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == self.eng.generation}
             g, failed = None, False
             eng = self.eng
+            par0 = self.par
             keep = [t.clone() for t in (eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats)]
+            keep_in = [t.clone() for t in self._bufs[par0]]
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -222,6 +259,7 @@ class EpochRunner:
                     self._pair(beta, do_curv)  # warm-up outside capture
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                self.par = par0
                 g = torch.cuda.CUDAGraph()
                 mode = "thread_local" if self.dp is not None else "global"  # see StepRunner._capture_mode
                 with torch.cuda.graph(g, capture_error_mode=mode):
@@ -236,9 +274,14 @@ class EpochRunner:
                       file=sys.stderr, flush=True)
                 failed = True
                 _clear_hip_error()
-            finally:  # capturing (or failing to) has no net effect on the model
+            finally:  # capturing (or failing to) has no net effect on the model or on the batch waiting to be read
                 for dst, src in zip((eng.params, eng.adam_m, eng.adam_v, eng.counters, eng.stats), keep):
                     dst.copy_(src)
+                for dst, src in zip(self._bufs[par0], keep_in):
+                    dst.copy_(src)
+                self.par = par0
+                if self.fold:
+                    eng.set_next_batch_feed(self.B, None)  # a failed capture may leave the context armed
             # every rank takes the same route (see StepRunner.__init__): any failure -> all run this key eagerly
             if self.dp is not None and agree_any(failed, self.dp.group, "epochrunner-capture"):
                 g = None
@@ -253,11 +296,17 @@ class EpochRunner:
         cur = int(self.eng.counters[8].item())
         if cur % self.nb:
             self.eng.counters[8] = cur + (self.nb - cur % self.nb)
+        if self.fold:
+            self._prepare()  # the epoch's first batch (what the previous epoch's last step prepared used the old permutation)
         left = self.nb
         if use_graphs and self.capturable:
-            g = self._graph(beta, do_curv)  # None: this configuration could not be captured (agreed across ranks)
-            while g is not None and left >= self.gs:
+            while left >= self.gs:
+                g = self._graph(beta, do_curv)  # None: this configuration could not be captured (agreed across ranks)
+                if g is None:
+                    break
                 g.replay()
+                if self.fold and (self.gs & 1):
+                    self.par ^= 1
                 left -= self.gs
         for _ in range(left):
             self._pair(beta, do_curv)

@@ -192,3 +192,68 @@ def test_trainer_takes_the_device_pipeline_for_the_conv_architecture(dev, tmp_pa
     assert int(m.engine.counters[0]) == 5
     d = st.to_print()
     assert all(np.isfinite(v) for v in d.values()) and d["elbo"] < 0
+
+
+@pytest.mark.parametrize("comps,mode", [("h2,s2,e2", 1), ("h2,s2,e2", 0), ("h2,s2,e2", 2), ("6h2,6s2,6e2", 1), ("e5", 1)])
+def test_next_batch_feed_equals_prepare_batch(dev, comps, mode):
+    """mvae_set_next_batch_feed: a step that also prepares its successor's batch (spare workgroups of launch 4) writes the
+    bits mvae_prepare_batch writes when called after the step, advances nothing else, and is one-shot; fused step and
+    gradients-only step; every kernel path (fused forward, block kernels, per-row)."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    spec = {"h2,s2,e2": [("h", 2), ("s", 2), ("e", 2)], "6h2,6s2,6e2": [("h", 2)] * 6 + [("s", 2)] * 6 + [("e", 2)] * 6,
+            "e5": [("e", 5)]}[comps]
+    N, D, B = 1024, 784, 128
+    g = torch.Generator().manual_seed(5)
+    images = torch.randint(0, 256, (N, D), generator=g, dtype=torch.uint8).to(dev)
+    perm = torch.randperm(N, generator=g).to(torch.int32).to(dev)
+    res = []
+    for armed in (True, False):
+        eng = StepEngine(spec, D, 400, dev)
+        eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=1.5))
+        E = eng.layout.eps_dim
+        eng.counters[8] = 5
+        x, eps = _prepare(images, perm, eng.counters, B, E, 11, N // B, mode, dev)
+        nx, ne = torch.full((B, D), -7.0, device=dev), torch.full((B, E), -7.0, device=dev)
+        for k in range(2):  # k = 0: fused step, k = 1: gradients + optimizer
+            if armed:
+                eng.set_next_batch_feed(B, images, perm, 11, N // B, mode, nx, ne)
+            if k == 0:
+                eng.train_step(x, eps, 1.0, True)
+            else:
+                eng.forward_backward(x, eps, 1.0)
+                eng.optimizer_step(True)
+            torch.cuda.synchronize()
+            assert int(eng.counters[8]) == 6 + k
+            wx, we = _prepare(images, perm, eng.counters, B, E, 11, N // B, mode, dev)
+            if armed:
+                assert torch.equal(nx, wx) and torch.equal(ne, we)
+                nx.fill_(-7.0), ne.fill_(-7.0)
+        # one-shot: an un-armed step leaves the buffers alone
+        eng.train_step(x, eps, 1.0, False)
+        torch.cuda.synchronize()
+        assert float(nx.max()) == -7.0 and float(ne.max()) == -7.0
+        res.append((eng.params.clone(), eng.stats.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("gs", [2, 3])
+def test_epoch_runner_in_step_preparation_equals_pairs(dev, gs):
+    """EpochRunner with the batch prepared inside the previous step == [mvae_prepare_batch, step] pairs: bit-identical
+    parameters and statistics over two epochs, for even and odd graph lengths (odd: the graphs of both buffer parities)."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import EpochRunner
+    imgs = (synthetic.digits_like_batches(10, 100).reshape(-1, 784) * 230 + 12).to(torch.uint8).to(dev)  # 1000 images
+    results = []
+    for fold in (True, False):
+        eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+        eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+        er = EpochRunner(eng, imgs, batch=128, seed=3, graph_steps=gs, fold=fold)
+        assert er.fold == fold
+        for ep in range(3):
+            assert er.run_epoch(1.0, ep >= 1) == 7
+        torch.cuda.synchronize()
+        assert int(eng.counters[0]) == 21 and int(eng.counters[8]) == 21
+        results.append((eng.params.clone(), eng.stats.clone()))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
