@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float* x, const float*
 template <int NN>  // NN = N rounded up to a multiple of 4
 __global__ __launch_bounds__(256) void k_linear_bwd_skn(const float* x, const float* W, const float* dy, float* dW,
                                                         float* db, float* dx, int M, int N, int K, int relu_in) {
-  job_linear_bwd_skn<NN, false>((int)blockIdx.x, x, W, dy, dW, db, dx, M, N, K, relu_in);
+  __shared__ SknLds<NN> lds;
+  job_linear_bwd_skn<NN, false>(lds, (int)blockIdx.x, x, W, dy, dW, db, dx, M, N, K, relu_in);
 }
 
 // ------------------------------------------------------------------------------------------------ primitives (API)

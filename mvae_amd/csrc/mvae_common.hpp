@@ -440,6 +440,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// the value of the neighbouring lane (lane ^ 1): one DPP quad_perm [1,0,3,2], no LDS crossbar
+__device__ __forceinline__ float lane_swap1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
 #define DMAX_SWITCH(dmax, ...) \
   switch (bucket_of(dmax)) {    \
     case 2: { constexpr int DM = 2; __VA_ARGS__; } break;   \
@@ -712,13 +717,21 @@ __device__ __forceinline__ bool xcd_tile(int NT, int MT, int* nt, int* mt, int L
 // the workgroup's 32 columns lie inside one pixel, a thread's quad is 4 consecutive channels, i.e. 4 entries of a row of W
 // that are 16 floats apart.  (Re-ordering the 0.4 MB matrix per step instead cost two extra launches.)
 constexpr int kSknN = 16;
+// LDS of job_linear_bwd_skn (declared by the calling kernel, so that a kernel with several job classes can overlay them)
+template <int NN>
+struct SknLds {
+  __attribute__((aligned(16))) float dy_s[256][NN];
+  f32x4 smn[NN][32][9];
+  __attribute__((aligned(16))) float w_s[NN][32];
+};
+
 template <int NN, bool CL>  // NN = N rounded up to a multiple of 4
-__device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, const float* W, const float* dy, float* dW,
-                                                   float* db, float* dx, int M, int N, int K, int relu_in,
+__device__ __forceinline__ void job_linear_bwd_skn(SknLds<NN>& L, int blk, const float* x, const float* W, const float* dy,
+                                                   float* dW, float* db, float* dx, int M, int N, int K, int relu_in,
                                                    unsigned short* dx_planes = nullptr, long long dx_ps = 0,
                                                    float* dx_colsum = nullptr) {
-  __shared__ __attribute__((aligned(16))) float dy_s[256][NN];
-  __shared__ f32x4 smn[NN][32][9];
+  auto& dy_s = L.dy_s;
+  auto& smn = L.smn;
   const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;
   if (blk == K / 32) {  // db[n] = sum_m dy[m][n]
     const int cn = tid & 15, gn = tid >> 4;
@@ -739,19 +752,26 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
   const int Cch = K >> 4, wp = CL ? col / Cch : 0, wc = CL ? col - wp * Cch : 0;  // CL: pixel and first channel of the quad
   // Latency, not bandwidth, bounds this kernel (one wave per SIMD, 16 MB moved): EVERY request of a 256-row chunk -- the
   // dy block, the W columns, the 8 rows of x -- is issued before the first use, so a chunk costs one memory round trip.
+  // The workgroup's NN x 32 weights: in the channel-last form they sit 64 bytes apart in W (the reference's column order
+  // c * 16 + p); fetched per thread (4 NN scalar loads, 8 lines per wave-level request: 1536 line accesses per workgroup,
+  // ~1 us of the CU's address path in front of everything else) -- staged once through LDS, 2 requests per wave.
   f32x4 acc[NN], wr[NN];
   f32x4 dxs = {0.f, 0.f, 0.f, 0.f};  // column sums of dx over this thread's rows (dx_colsum)
+  constexpr int kWPer = (NN * 32 + 255) / 256;
+  float wst[kWPer];
 #pragma unroll
-  for (int n = 0; n < NN; ++n) {
-    acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wrow = W + (size_t)(n < N ? n : 0) * K;
-    if (CL) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wr[n][j] = wrow[(wc + j) * 16 + wp];
-    } else {
-      wr[n] = *reinterpret_cast<const f32x4*>(wrow + col);
+  for (int q = 0; q < kWPer; ++q) {
+    const int e = tid + 256 * q, n = e >> 5, j = e & 31;  // j: column blk * 32 + j
+    wst[q] = 0.f;
+    if (e < NN * 32) {
+      const int cj = blk * 32 + j;
+      const float* wrow = W + (size_t)(n < N ? n : 0) * K;
+      wst[q] = CL ? wrow[(cj - (cj / Cch) * Cch) * 16 + cj / Cch] : wrow[cj];
     }
   }
+#pragma unroll
+  for (int n = 0; n < NN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  (void)wp; (void)wc;
   constexpr int kDyPer = NN;  // 256 rows x NN entries / 256 threads
   for (int m0 = 0; m0 < M; m0 += 256) {
     const int rows = (M - m0) < 256 ? (M - m0) : 256;
@@ -774,7 +794,18 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
       const int e = tid + 256 * q, r = e / NN, n = e - r * NN;
       dy_s[r][n] = (r < rows && n < N) ? dyv[q] : 0.f;
     }
+    if (m0 == 0) {
+#pragma unroll
+      for (int q = 0; q < kWPer; ++q) {
+        const int e = tid + 256 * q;
+        if (e < NN * 32) L.w_s[e >> 5][e & 31] = wst[q];
+      }
+    }
     __syncthreads();
+    if (m0 == 0) {
+#pragma unroll
+      for (int n = 0; n < NN; ++n) wr[n] = *reinterpret_cast<const f32x4*>(&L.w_s[n][c * 4]);
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int r = g + 32 * u;
@@ -801,24 +832,28 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
       }
     }
   }
-  // the 32 row groups' partial dW rows meet in LDS: all NN outputs at once (one barrier; NN x 8 threads add their (output, column
-  // quad) over the groups in group order -- the same additions as one output per barrier pair, which cost 2 NN barriers)
+  // the 32 row groups' partial dW rows meet in LDS: all NN outputs at once (one barrier); two threads per (output, column
+  // quad) add 16 row groups each in group order and meet by a lane swap (96 threads adding 32 groups each were a 1.3 us tail)
   __syncthreads();  // (the last chunk's readers of dy_s are done: smn may alias nothing, but keep the phases apart)
 #pragma unroll
   for (int n = 0; n < NN; ++n) smn[n][g][c] = acc[n];
   __syncthreads();
-  if (tid < NN * 8) {
-    const int n = tid >> 3, c2 = tid & 7;
-    if (n < N) {
+  for (int o0 = 0; o0 < NN; o0 += 16) {
+    const int n = o0 + (tid >> 4), c2 = (tid >> 1) & 7, hsel = tid & 1;
+    if (n < NN) {  // (pairs of lanes share n)
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < 32; ++q) t += smn[n][q][c2];
-      const int col2 = blk * 32 + c2 * 4;
-      if (CL) {
-        const int wp2 = col2 / Cch, wc2 = col2 - wp2 * Cch;
+      for (int q = 0; q < 16; ++q) t += smn[n][hsel * 16 + q][c2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dW[(size_t)n * K + (wc2 + j) * 16 + wp2] = t[j];
-      } else {
-        *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col2) = t;
+      for (int e = 0; e < 4; ++e) t[e] += lane_swap1(t[e]);
+      if (hsel == 0 && n < N) {
+        const int col2 = blk * 32 + c2 * 4;
+        if (CL) {
+          const int wp2 = col2 / Cch, wc2 = col2 - wp2 * Cch;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dW[(size_t)n * K + (wc2 + j) * 16 + wp2] = t[j];
+        } else {
+          *reinterpret_cast<f32x4*>(dW + (size_t)n * K + col2) = t;
+        }
       }
     }
   }
@@ -826,14 +861,16 @@ __device__ __forceinline__ void job_linear_bwd_skn(int blk, const float* x, cons
     __syncthreads();
     smn[0][g][c] = dxs;
     __syncthreads();
-    if (tid < 8) {
+    if (tid < 16) {
+      const int c2 = tid >> 1, hsel = tid & 1;
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < 32; ++q) t += smn[0][q][tid];
-      *reinterpret_cast<f32x4*>(dx_colsum + blk * 32 + tid * 4) = t;
+      for (int q = 0; q < 16; ++q) t += smn[0][hsel * 16 + q][c2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += lane_swap1(t[e]);
+      if (hsel == 0) *reinterpret_cast<f32x4*>(dx_colsum + blk * 32 + c2 * 4) = t;
     }
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------ device-side input pipeline
 // Row f-2 of the scope table: the reference feeds the step from 8 DataLoader worker processes that binarise every image

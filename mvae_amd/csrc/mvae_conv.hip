@@ -1981,9 +1981,14 @@ __global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float*
                                                        int B) {
   __shared__ float hp[16][17];
   __shared__ float heads_s[16], z_s[16];
+  __shared__ float eps_s[16], rad_s[16];
   __shared__ float t0_s[kPix * (kDecC + 1)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = blockIdx.x;
+  // the row's eps and the radii travel with the first requests and wait in LDS: read from global memory inside the component
+  // chain they put a memory round trip (~2 us) on its critical path
+  if (tid >= 64 && tid < 80) eps_s[tid - 64] = (tid - 64) < eps_ld ? eps[(size_t)r * eps_ld + (tid - 64)] : 0.f;
+  if (tid >= 128 && tid < 144) rad_s[tid - 128] = (tid - 128) < t.n ? radii[tid - 128] : 0.f;
   // this thread's 8 rows of W_d0 are requested now and used after the component chain (Z = 8: the BASELINE model)
   f32x4 wq[8][2];
   float bq[8];
@@ -2015,11 +2020,17 @@ __global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float*
     }
     __syncthreads();
   }
+#ifdef MV_CL_DBG
+  if (!(MV_CL_DBG & 32))
+#endif
   for (int ci = 0; ci < t.n; ++ci)
     if (t.wave_of[ci] == wave && t.lane_of[ci] == lane)
-      comp_fwd_row<DMAX>(t.c[ci], heads_s, eps + (size_t)r * eps_ld, radii, z_s, z + (size_t)r * Z,
-                         kl + (size_t)ci * B + r, nullptr, nullptr, nullptr, nullptr);
+      comp_fwd_row<DMAX>(t.c[ci], heads_s, eps_s, rad_s, z_s, z + (size_t)r * Z, kl + (size_t)ci * B + r, nullptr, nullptr,
+                         nullptr, nullptr);
   __syncthreads();
+#ifdef MV_CL_DBG
+  if (MV_CL_DBG & 64) return;
+#endif
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n = tid + 256 * i;
@@ -2063,11 +2074,15 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
                                                             int B) {
   __shared__ float dd_s[kPix * (kDecC + 1)];
   __shared__ float red_s[4][16];
-  __shared__ float dz_s[16], heads_s[16];
+  __shared__ float dz_s[16], heads_s[16], eps_s[16], rad_s[16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = blockIdx.x;
-  if (tid < 16) heads_s[tid] = tid < NH ? heads[(size_t)r * NH + tid] : 0.f;
-  f32x4 wq[8][2];  // this thread's 8 rows of W_d0, requested with the first loads (Z = 8)
+  // ---- every request of the row first: the chain's small operands (into LDS), W_d0, the dt0 slices and the mask
+  float hv = 0.f, ev = 0.f, rv = 0.f;
+  if (tid < 16) hv = tid < NH ? heads[(size_t)r * NH + tid] : 0.f;
+  if (tid >= 64 && tid < 80) ev = (tid - 64) < eps_ld ? eps[(size_t)r * eps_ld + (tid - 64)] : 0.f;
+  if (tid >= 128 && tid < 144) rv = (tid - 128) < t.n ? radii[tid - 128] : 0.f;
+  f32x4 wq[8][2];  // this thread's 8 rows of W_d0 (Z = 8)
   if (Z == 8) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -2076,15 +2091,62 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
       wq[i][1] = *reinterpret_cast<const f32x4*>(W_d0 + (size_t)n * 8 + 4);
     }
   }
+  f32x4 dsl[2][4], m4v[2];  // up to four K slices of dt0 per 16-byte piece, held until after the dual chain
+  const bool few = dt0_slices <= 4;  // uniform
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid * 4 + 1024 * i;
+    m4v[i] = *reinterpret_cast<const f32x4*>(t0 + (size_t)r * kD0 + idx);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      dsl[i][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (few && w < (dt0_slices < 1 ? 1 : dt0_slices))
+        dsl[i][w] = *reinterpret_cast<const f32x4*>(dt0 + (size_t)w * dt0_stride + (size_t)r * kD0 + idx);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid < 16) heads_s[tid] = hv;
+  if (tid >= 64 && tid < 80) eps_s[tid - 64] = ev;
+  if (tid >= 128 && tid < 144) rad_s[tid - 128] = rv;
+  __syncthreads();
+  // ---- the forward-mode dual chain of this lane's (component, input direction): needs no upstream gradient, so it runs
+  // while the large requests above travel (after the dz reduction it was 6 of the kernel's 13.5 us, back to back with them)
+  // (the (component, direction) pairs of a wave's components lie side by side on its lanes: heads_dim <= 16 keeps them under 64)
+  float zd[DMAX + 2], kld = 0.f;
+  int my_ci = -1, my_dir = 0, my_A = 0, my_zcol = 0, my_out = 0;  // my_out: column of dheads, or -1: the radius direction
+#pragma unroll
+  for (int i = 0; i < DMAX + 2; ++i) zd[i] = 0.f;
+#ifdef MV_CL_DBG
+  if (!(MV_CL_DBG & 8))
+#endif
+  {
+    int off = 0;
+    for (int ci = 0; ci < t.n; ++ci) {
+      if (t.wave_of[ci] != wave) continue;  // uniform per wave
+      const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
+      if (lane >= off && lane < off + ndir) {
+        const mvae_component_desc& c = t.c[ci];
+        my_ci = ci;
+        my_dir = lane - off;
+        my_A = ambient_dim(c.kind, c.true_dim);
+        my_zcol = c.z_col;
+        my_out = my_dir < c.true_dim ? c.mean_col + my_dir
+                                     : (my_dir < c.true_dim + c.logvar_dim ? c.logvar_col + (my_dir - c.true_dim) : -1);
+        kld = comp_dual_dir<DMAX>(c, heads_s, eps_s, rad_s, my_dir, zd);
+      }
+      off += ndir;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- dd0 = dt0 * [t0 > 0] (dt0 = the sum of its K slices, in k_sum_slices' order: four partial sums over the slices
+  // k = w, w + 4, ..., then (p0 + p1) + (p2 + p3)), kept in LDS for the dz contraction
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid * 4 + 1024 * i, pp = idx >> 7, cc = idx & 127;
     f32x4 d4;
-    if (dt0_slices <= 1) {
-      d4 = *reinterpret_cast<const f32x4*>(dt0 + (size_t)r * kD0 + idx);
+    if (few) {
+      d4 = dt0_slices <= 1 ? dsl[i][0] : (dsl[i][0] + dsl[i][1]) + (dsl[i][2] + dsl[i][3]);
     } else {
-      // dt0 arrives as the K slices of its contraction: added here in k_sum_slices' order (four partial sums over the slices
-      // k = w, w + 4, ..., then (p0 + p1) + (p2 + p3)) instead of by a launch of its own
       f32x4 ps[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -2093,11 +2155,10 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
       }
       d4 = (ps[0] + ps[1]) + (ps[2] + ps[3]);
     }
-    const f32x4 m4 = *reinterpret_cast<const f32x4*>(t0 + (size_t)r * kD0 + idx);
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[e] = (m4[e] > 0.f) ? d4[e] : 0.f;
+      v[e] = (m4v[i][e] > 0.f) ? d4[e] : 0.f;
       dd_s[pp * (kDecC + 1) + cc + e] = v[e];
     }
     *reinterpret_cast<f32x4*>(dd0 + (size_t)r * kD0 + idx) = v;
@@ -2132,16 +2193,14 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_rows(CompTable t, const f
   __syncthreads();
   if (tid < Z) dz_s[tid] = (red_s[0][tid] + red_s[1][tid]) + (red_s[2][tid] + red_s[3][tid]);
   __syncthreads();
-  for (int ci = 0; ci < t.n; ++ci) {
-    if (t.wave_of[ci] != wave) continue;  // uniform per wave
-    const int ndir = t.dir_off[ci + 1] - t.dir_off[ci];
-    if (lane < ndir) {
-      const mvae_component_desc& c = t.c[ci];
-      const float gval = comp_bwd_dir<DMAX>(c, heads_s, eps + (size_t)r * eps_ld, radii, dz_s, beta, lane);
-      if (lane < c.true_dim) dheads[(size_t)r * NH + c.mean_col + lane] = gval;
-      else if (lane < c.true_dim + c.logvar_dim) dheads[(size_t)r * NH + c.logvar_col + (lane - c.true_dim)] = gval;
-      else drad_rows[(size_t)ci * B + r] = gval;
-    }
+  // ---- d(loss) / d(direction) = beta * d kl + <dz, d z>   (comp_bwd_dir's sum)
+  if (my_ci >= 0) {
+    float gval = beta * kld;
+#pragma unroll
+    for (int i = 0; i < DMAX + 1; ++i)
+      if (i < my_A) gval += dz_s[my_zcol + i] * zd[i];
+    if (my_out >= 0) dheads[(size_t)r * NH + my_out] = gval;
+    else drad_rows[(size_t)my_ci * B + r] = gval;
   }
 }
 
@@ -2164,15 +2223,32 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
                                                             float* __restrict__ dradii, int B) {
   // order: the 64 + 1 short jobs first, then the 257 workgroups of the heads -- the grid has 66 more workgroups than the chip
   // has CUs, and a short job sharing a CU with a heads workgroup costs less at the front than as the kernel's tail
+  // one LDS block, overlaid by the job classes (two workgroups share a CU)
+  struct Dd0Lds {
+    f32x4 sm[9][32][9];
+    __attribute__((aligned(16))) float z_sh[256][16];
+  };
+  constexpr size_t kLds = sizeof(SknLds<NN>) > sizeof(Dd0Lds) ? sizeof(SknLds<NN>) : sizeof(Dd0Lds);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kLds];
   const int nshort = kD0 / 32 + 1;
   int blk = blockIdx.x;
+#ifdef MV_CL_DBG  // A/B builds (tools/build_variant.py): which job class bounds the launch
+  if ((MV_CL_DBG & 1) && blk < kD0 / 32) return;
+  if ((MV_CL_DBG & 2) && blk >= nshort) return;
+  if ((MV_CL_DBG & 4) && blk == kD0 / 32) return;
+#endif
   if (blk >= nshort) {
-    job_linear_bwd_skn<NN, true>(blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1, da2p, da2ps, da2cs);
+    job_linear_bwd_skn<NN, true>(*reinterpret_cast<SknLds<NN>*>(lds_raw), blk - nshort, a2, W_heads, dheads, dW_heads, db_heads, da2, B, NH, kFlat, 1, da2p, da2ps, da2cs);
     return;
   }
   const int tid = threadIdx.x;
   if (blk < kD0 / 32) {
-    __shared__ f32x4 sm[32][9];
+    // dW_d0[n][k] = sum_m dd0[m][n] z[m][k], db_d0[n] = sum_m dd0[m][n] for 32 columns n.  Latency-bound: every request of a
+    // 256-row chunk (dd0 and the chunk's z rows, through LDS: one coalesced request per thread instead of Z scalar loads per
+    // row inside the loop) is in flight before the first use, and the 32 row groups meet in LDS with ONE barrier per 9 outputs.
+    Dd0Lds& D = *reinterpret_cast<Dd0Lds*>(lds_raw);
+    auto& sm = D.sm;
+    auto& z_sh = D.z_sh;
     const int c8 = tid & 7, g = tid >> 3;
     const int idx = blk * 32 + c8 * 4, pp = idx >> 7, cc = idx & 127;
     f32x4 acc[17];  // [k < Z]: dW_d0 column k; [16]: the bias gradient
@@ -2185,34 +2261,64 @@ __global__ __launch_bounds__(256) void k_cl_latent_bwd_cols(CompTable t, const f
         const int m = m0 + g + 32 * u;
         dv[u] = *reinterpret_cast<const f32x4*>(dd0 + (size_t)(m < B ? m : B - 1) * kD0 + idx);
       }
+      float zv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // 256 rows x Z values, consecutive threads consecutive addresses
+        const int e = tid + 256 * q;
+        zv[q] = 0.f;
+        if (q < Z) {  // uniform
+          const int m = m0 + e / Z;
+          zv[q] = z[(size_t)(m < B ? m : B - 1) * Z + (e - (e / Z) * Z)];
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // the previous chunk's readers of z_sh are done
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < Z) {
+          const int e = tid + 256 * q, r = e / Z;
+          z_sh[r][e - r * Z] = zv[q];
+        }
+      __syncthreads();
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int m = m0 + g + 32 * u;
-        if (m >= B) continue;
+        const int r = g + 32 * u;
+        if (m0 + r >= B) continue;
         acc[16] += dv[u];
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          if (k < Z) acc[k] += z[(size_t)m * Z + k] * dv[u];
+          if (k < Z) acc[k] += z_sh[r][k] * dv[u];
       }
     }
+    const int nout = Z + 1;  // outputs 0 .. Z - 1: columns of dW_d0; output Z: the bias gradient
+    for (int k0 = 0; k0 < nout; k0 += 9) {
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 17; ++k) {
-      if (k < 16 && k >= Z) continue;  // uniform
+      for (int k = 0; k < 17; ++k) {
+        const int o = (k == 16 ? Z : k) - k0;
+        if ((k < Z || k == 16) && o >= 0 && o < 9) sm[o][g][c8] = acc[k];  // uniform conditions
+      }
       __syncthreads();
-      sm[g][c8] = acc[k];
-      __syncthreads();
-      if (g == 0) {
+      // two threads per (output, column quad): each adds 16 of the 32 row groups in group order, the halves meet by a lane swap
+      const int o = tid >> 4, c2 = (tid >> 1) & 7, hsel = tid & 1;
+      if (o < 9 && k0 + o < nout) {
         f32x4 tt = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < 32; ++q) tt += sm[q][c8];
+        for (int q = 0; q < 16; ++q) tt += sm[o][hsel * 16 + q][c2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = (cc + e) * kPix + pp;
-          if (k < 16) dW_d0[(size_t)n * Z + k] = tt[e];
-          else db_d0[n] = tt[e];
+        for (int e = 0; e < 4; ++e) tt[e] += lane_swap1(tt[e]);
+        if (hsel == 0) {
+          const int k = k0 + o;
+          const int idx2 = blk * 32 + c2 * 4, pp2 = idx2 >> 7, cc2 = idx2 & 127;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = (cc2 + e) * kPix + pp2;
+            if (k < Z) dW_d0[(size_t)n * Z + k] = tt[e];
+            else db_d0[n] = tt[e];
+          }
         }
       }
     }
+    (void)pp; (void)cc;
     return;
   }
   __shared__ float sw[4];
@@ -2284,6 +2390,9 @@ extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int nc
   if (!mvae_conv_latent_supported(comps, ncomp) || !conv_latent_dims(comps, ncomp, &NH, &Z, &ed, &dmax))
     return fail(MVAE_E_UNSUPPORTED, "fused conv latent section: heads_dim, z_dim <= 16 and true dimensions <= 8%s", "");
   if (eps_ld < ed) return fail(MVAE_E_BADARG, "eps_ld smaller than the components' eps columns%s", "");
+  for (int i = 0; i < ncomp; ++i)
+    if (comps[i].radius_idx < 0 || comps[i].radius_idx >= ncomp)
+      return fail(MVAE_E_BADARG, "radius_idx out of range%s (%lld)", "", comps[i].radius_idx);
   if (((((uintptr_t)a2) | ((uintptr_t)t0) | ((uintptr_t)workspace) | ((uintptr_t)W_d0)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "fused conv latent section needs 16-byte aligned a2 / t0 / W_d0 / workspace%s", "");
   if (t0_planes && ((((uintptr_t)t0_planes) & 7) || (t0_ps & 3))) return fail(MVAE_E_ALIGN, "t0 planes: 8-byte aligned%s", "");

@@ -569,7 +569,8 @@ def test_conv_backward_on_side_streams_is_the_same_step(dev, monkeypatch):
     assert torch.equal(one.grads, graphed.grads) and torch.equal(one.params, graphed.params)
 
 
-@pytest.mark.parametrize("model,B", [("h2,s2,e2", 256), ("h2,s2,e2", 77), ("p2,d2,u2", 40), ("s8", 300), ("e3,h2", 640)])
+@pytest.mark.parametrize("model,B", [("h2,s2,e2", 256), ("h2,s2,e2", 77), ("p2,d2,u2", 40), ("s8", 300), ("e3,h2", 640),
+                                     ("h2,h2,s3", 96), ("e2,e1,e2,h2", 64)])
 def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
     """mvae_conv_latent_forward / _backward on random operands against the generic operator sequence they replace
     (re-order W_heads, split-K heads, components, fc + ReLU, re-order | re-order, ReLU mask, fc backward, components,

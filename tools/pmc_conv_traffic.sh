@@ -2,7 +2,7 @@
 # Fabric traffic and L2 hit rate of the largest contractions of the conv step (one op per process, tools/p3_one.py):
 #   tools/pmc_conv_traffic.sh TAG   ->  gpurun_out/prof_TAG/conv_traffic.json   (summarised into profiles/ by tools/summarise_profiles.py)
 TAG=${1:-r04}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG/conv_traffic; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-for op in ${OPS:-e2f d2f e1f d1f db1 da1 dWe2 dWd2}; do
+for op in ${OPS:-e2f d2f e1f d1f pd2 pd1 pe2 pe1}; do
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CU_CYCLES"; do
     d=$OUT/${op}_$(echo $grp | tr ' ' '_' | cut -c1-24)
     env $EXTRA_ENV timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -o g -- python $ROOT/tools/p3_one.py $op > $d.log 2>&1

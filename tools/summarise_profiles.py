@@ -53,6 +53,13 @@ for name in ("bench_line.json", "bench_driver.json", "bench_prod36.json", "bench
             with open(os.path.join(dst, f"{tag}_{name}"), "w") as fh:
                 fh.write(lines[-1] + "\n")
             print("copied", name)
+for name in ("bench_epoch.txt", "bench_epoch_pairs.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        lines = [l for l in open(f).read().splitlines() if l.startswith("epoch of")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_{name}"), "w").write(lines[-1] + "\n")
+            print("copied", name)
 convlog = os.path.join(src, "conv.log")
 if os.path.exists(convlog):
     lines = [l for l in open(convlog).read().splitlines() if l.startswith("{")]
@@ -140,6 +147,16 @@ if os.path.exists(ct):
         "dWe1": ("weight gradient of e1 (planes, split over rows)", 16384 * 128 * 6 + 65536 * 64 * 6 + 32 * 128 * 1024 * 4),
         "dWe2": ("weight gradient of e2 (planes, 4 row slices)", 4096 * 512 * 6 + 256 * 64 * 128 * 6 + 4 * 512 * 2048 * 4),
         "dWd2": ("weight gradient of d2 (planes, 16 row slices)", 16384 * 256 * 6 + 65536 * 64 * 6 + 16 * 256 * 1024 * 4),
+        # the step's paired launches: operands as planes (6 B per value) read once, results written once (planes 6 B, f32 4 B,
+        # weight-gradient slices as the launch writes them)
+        "pd2": ("d2: weight gradient (8 row slices) + backward-data (planes + column sums), ONE launch",
+                16384 * 256 * 6 + 2 * 65536 * 64 * 6 + 256 * 1024 * 6 + 8 * 256 * 1024 * 4 + 16384 * 256 * 6),
+        "pd1": ("d1: weight gradient + backward-data in 4 K slices, ONE launch",
+                4096 * 128 * 6 + 2 * 16384 * 256 * 6 + 128 * 4096 * 6 + 4 * 128 * 4096 * 4 + 4 * 4096 * 128 * 4),
+        "pe2": ("e2: weight gradient + implicit backward-data (planes + column sums), ONE launch",
+                2 * 4096 * 512 * 6 + 16384 * 128 * 6 + 512 * 2048 * 6 + 2 * 512 * 2048 * 4 + 16384 * 128 * 6),
+        "pe1": ("e1: weight gradient + backward-data (f32 + column sums), ONE launch",
+                2 * 16384 * 128 * 6 + 65536 * 64 * 6 + 128 * 1024 * 6 + 16 * 128 * 1024 * 4 + 65536 * 64 * 4),
     }
     kern = {}
     for op, r in raw.items():
