@@ -36,6 +36,7 @@ timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model e6 --fi
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --force-dp > $OUT/bench_forced_dp.json 2>&1   # world 1, exchange forced (librccl)
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model h40 --steps 500 --warmup 50 > $OUT/bench_h40.json 2>&1
 # keep only the small summaries (the traces are large)
+(cd /tmp && rm -rf $OUT/epoch && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/epoch -o epoch -- python $ROOT/tools/bench_epoch.py > $OUT/epoch.log 2>&1)   # launch list of an epoch: no prepare launch per step
 timeout 300 python tools/bench_epoch.py > $OUT/bench_epoch.txt 2>&1   # a 60000-image MNIST epoch through the device-side input pipeline
 MVAE_FEED_FOLD=0 timeout 300 python tools/bench_epoch.py > $OUT/bench_epoch_pairs.txt 2>&1   # the same as [prepare, step] pairs
 find $OUT -name '*kernel_trace.csv' -size +20M -delete

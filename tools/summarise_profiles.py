@@ -39,7 +39,8 @@ def pmc_average(path, counter):
 
 for sub, out in (("ktrace/**/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
                  ("ktrace/**/*domain_stats.csv", f"{tag}_bench_domain_stats.csv"),
-                 ("conv/**/*kernel_stats.csv", f"{tag}_conv_b256_kernel_stats.csv")):
+                 ("conv/**/*kernel_stats.csv", f"{tag}_conv_b256_kernel_stats.csv"),
+                 ("epoch/**/*kernel_stats.csv", f"{tag}_epoch_kernel_stats.csv")):
     f = first(sub)
     if f:
         shutil.copy(f, os.path.join(dst, out))
