@@ -10,7 +10,7 @@ backward, Adam + SGD on the radii (+ gradient all-reduce when N > 1).  Inputs (b
 (mvae_amd/synthetic.py: MNIST-shaped stroke images, dynamically binarised) and resident in HBM before the timed
 region; weights are the synthetic init.
 Prints ONE JSON line on rank 0.  The top-level fields are configs[1]; at N = 1 the default invocation also times short
-legs of the other single-GPU BASELINE configs and reports them under "configs": {"e6", "prod36", "conv"}
+legs of the other single-GPU BASELINE configs and reports them under "configs": {"e6", "prod36", "conv", "epoch_pipeline"}
 (configs[0], [3], [4]); `--no-extra-configs` skips them.
 """
 import argparse
@@ -445,6 +445,40 @@ def mlp_leg(model, fixed, steps, warmup, dev):
                                               "step_hbm_frac", "step_mfma_frac")}}
 
 
+def epoch_pipeline_leg(dev, epochs=3):
+    """Scope row f-2 measured where the driver looks: whole training epochs of BASELINE configs[1] through the device-side
+    input pipeline -- a 60000 x 784 uint8 synthetic set resident in HBM, batches gathered by a device permutation, dynamic
+    binarisation and the eps draw (Philox) done by spare workgroups of the PREVIOUS step (mvae_set_next_batch_feed), steps
+    replayed as HIP graphs.  Unlike the headline (inputs already prepared in HBM), every timed step here includes preparing its
+    successor's inputs; the per-epoch permutation and one mvae_prepare_batch launch per epoch are inside the timed region."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import EpochRunner
+    comps = parse_model(MODEL)
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * len(comps), lr=1e-3)
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+    images = (torch.rand(60000, D, device=dev) ** 3 * 255).to(torch.uint8)
+    er = EpochRunner(eng, images, B, seed=1)
+    for _ in range(2):
+        n = er.run_epoch(1.0, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        n = er.run_epoch(1.0, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = eng.read_stats()
+    assert stats["sum"]["steps"] == (2 + epochs) * n, stats["sum"]["steps"]  # (capture warm-ups restore the statistics)
+    assert stats["last"]["elbo"] == stats["last"]["elbo"], "non-finite ELBO"
+    return {"metric": f"ELBO-steps/sec (batch 128) MNIST {MODEL}, whole epochs through the device-side input pipeline",
+            "value": n * epochs / dt, "unit": "ELBO-steps/sec", "ms_per_step": dt / (n * epochs) * 1e3,
+            "steps": n * epochs, "epochs": epochs, "steps_per_epoch": n, "dtype": "f32",
+            "workload": "60000 x 784 uint8 synthetic images in HBM; per step: gather by a device permutation + dynamic "
+                        "binarisation + eps draw (Philox4x32-10) for the NEXT step inside launch 4, fused train step; "
+                        f"HIP graphs of {er.gs} steps; in_step_preparation={er.fold}",
+            "baseline_config": "configs[1] with the reference's DataLoader + ImageDynamicBinarization replaced (SURVEY 8 f-2)"}
+
+
 def conv_short_leg(mode):
     """A 20-step leg of the conv config in contraction mode `mode` (None: the library's current one), reduced to the fields
     the `configs` block of the headline line carries."""
@@ -692,6 +726,10 @@ def main():
                 extra[key] = conv_short_leg(m)
             except Exception as e:  # noqa: BLE001
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            extra["epoch_pipeline"] = epoch_pipeline_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            extra["epoch_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
         extra["e6"].setdefault("baseline_config", "configs[0]: MNIST e6, fixed curvature")
         extra["prod36"].setdefault("baseline_config", "configs[3]: 6h2,6s2,6e2 (36-dim latent), learnable curvature")
         extra["conv"].setdefault("baseline_config", "configs[4] on ONE GPU: CIFAR conv h_dim=8192, batch 256")

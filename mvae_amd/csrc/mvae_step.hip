@@ -1870,6 +1870,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, __VA_ARGS__);                                          \
   } while (0)
   if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if ((parts & MVAE_STEP_HEAD) && c->feed.images && (c->feed.x == x || c->feed.eps == eps)) {
+    c->feed = FeedArgs{};  // launch 4 would overwrite what launches 4-6 read
+    return fail(MVAE_E_BADARG, "mvae_set_next_batch_feed: x_next / eps_next are the buffers this step reads%s", "");
+  }
   const mvae_model_desc& d = c->d;
   const int B = d.batch, H = d.h_dim, D = d.in_dim, NH = d.heads_dim, Z = d.z_dim;
   hipStream_t s = (hipStream_t)stream;

@@ -48,6 +48,10 @@ def test_bench_line_schema():
         leg = d["configs"][key]
         assert "error" not in leg, leg
         assert leg["value"] > 100 and leg["ms_per_step"] > 0 and 0 < leg["roofline"]["frac"] < 1, leg
+    # whole epochs through the device-side input pipeline (scope row f-2): every step prepares its successor's inputs
+    ep = d["configs"]["epoch_pipeline"]
+    assert "error" not in ep, ep
+    assert ep["value"] > 1000 and ep["steps"] == ep["epochs"] * ep["steps_per_epoch"] and "in_step_preparation=True" in ep["workload"]
 
 
 def test_bench_forced_exchange_route():

@@ -257,3 +257,20 @@ def test_epoch_runner_in_step_preparation_equals_pairs(dev, gs):
         assert int(eng.counters[0]) == 21 and int(eng.counters[8]) == 21
         results.append((eng.params.clone(), eng.stats.clone()))
     assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+
+
+def test_next_batch_feed_refuses_the_buffers_the_step_reads(dev):
+    from mvae_amd import synthetic
+    from mvae_amd._lib import MvaeHipError
+    from mvae_amd.engine import StepEngine
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev)
+    eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=1.5))
+    images = torch.randint(0, 256, (256, 784), dtype=torch.uint8).to(dev)
+    x = synthetic.binary_batches(1, 128, 784)[0].to(dev)
+    eps = synthetic.eps_batches(1, 128, 6)[0].to(dev)
+    eng.set_next_batch_feed(128, images, None, 1, 2, 1, x, torch.empty_like(eps))
+    with pytest.raises(MvaeHipError, match="buffers this step reads"):
+        eng.train_step(x, eps, 1.0, False)
+    eng.train_step(x, eps, 1.0, False)  # the refused arming is gone
+    torch.cuda.synchronize()
+    assert int(eng.counters[0]) == 1
