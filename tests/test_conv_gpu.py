@@ -655,6 +655,9 @@ def test_fused_conv_step_vs_the_generic_step(dev, monkeypatch, B, scalar):
     generic operator sequence (=0): forward outputs and statistics to 2e-5; gradients per entry to 2e-5 when no ReLU
     output changed sign between the two forward passes, else (see _relu_flips) by norm to 5e-3.  scalar: one logvar per
     component (component.py: scalar_parametrization)."""
+    # (mode 1: the step's forward pass runs on planes and has its own near-zero activations; the stand-alone _forward the flip
+    # count is taken from does not -- a flipped output would be mis-attributed.  tests/dev/mode1_fused_vs_generic.py)
+    _default_mode_only()
     from mvae_amd import synthetic
     from mvae_amd.conv import ConvEngine
     comps = _comps_of("h2,s2,e2")
@@ -1136,10 +1139,13 @@ def test_plane_backward_equals_in_kernel_split(dev, monkeypatch, B):
     k_gemm_b3): the same six piece products per f32 product, so the forward pass is bit-identical and every gradient agrees to
     accumulation-order rounding (the K slices of the two kernels differ)."""
     from mvae_amd import synthetic
+    from mvae_amd._lib import load
     from mvae_amd.conv import ConvEngine
     comps = _comps_of("h2,s2,e2")
     x = synthetic.uniform_batches(1, B, 3072)[0].to(dev)
     eps = synthetic.eps_batches(1, B, 6)[0].to(dev)
+    prev_mode = load().mvae_set_contraction_mode(-1)
+    monkeypatch.setenv("MVAE_CONV_SPLIT_BF16", "2")  # the statement is about mode 2, whatever the session runs in
 
     def run(planes):
         monkeypatch.setenv("MVAE_CONV_PLANES", planes)
@@ -1151,8 +1157,11 @@ def test_plane_backward_equals_in_kernel_split(dev, monkeypatch, B):
         torch.cuda.synchronize()
         return eng, out
 
-    e1, o1 = run("1")
-    e0, o0 = run("0")
+    try:
+        e1, o1 = run("1")
+        e0, o0 = run("0")
+    finally:
+        load().mvae_set_contraction_mode(prev_mode)
     for k in ("logits", "concat_z", "bce", "kl"):
         assert torch.equal(o1[k], o0[k]), k
     for (n, a), (_, b) in zip(e1.grad_views().items(), e0.grad_views().items()):
