@@ -436,7 +436,11 @@ int64_t mvae_conv3_k4s2p1_nchw_backward_colsum_floats(int B);
  * gradient of the last ConvTranspose2d, dbias[c] = sum_{b,y,x} g[b,c,y,x] (conv_vae.py:54; logits are NCHW rows of
  * D = C x HW, C <= 8, HW a multiple of 1024).  chan_part: [B, C] scratch; counter: 17 int32 that are 0 before the first
  * call and are left 0 by every call (arrival counters of the workgroups; the last one to finish performs the two
- * batch-wide sums in a fixed order, so results do not depend on the arrival order). */
+ * batch-wide sums in a fixed order, so results do not depend on the arrival order).  Between mvae_slice_sums_defer(1) and
+ * mvae_slice_sums_flush() those two batch-wide sums -- `dbias` and the update of `stats` -- are QUEUED like the slice sums and
+ * performed by the flush launch (same additions, same order; inside this launch they are five dependent memory round trips
+ * of one workgroup after all the others have finished); bce, kl and chan_part must then stay valid until the flush, and the
+ * counters are not touched.  MVAE_LOSS_TAIL_DEFER=0: always inside this launch. */
 int mvae_conv_bce_stats(const float* logits, const float* x, float* bce, float* g, const float* kl, float* stats,
                         float beta, int64_t B, int D, int HW, int ncomp, float* chan_part, float* dbias,
                         int32_t* counter, void* stream);

@@ -705,37 +705,14 @@ class ConvEngine:
         c = self._forward(x, eps, planes=use_p3, planes_forward=(p3 == 1), defer_logits=fuse_d3)
         c["p3"] = use_p3
         bce = x.new_empty(B)
-        if c["logits"] is None:
-            # the last transposed convolution, BCE + its gradient, the batch statistics and d3.bias in ONE launch
-            PV = self.param_views()
-            c["logits"], g, chan = x.new_empty(B, 3072), x.new_empty(B, 3072), x.new_empty(B, 3)
-            check(load().mvae_convt_to3_bce_stats(ptr(c["b2"]), ptr(PV["d3.weight"]), ptr(PV["d3.bias"]), ptr(x), ptr(c["logits"]),
-                                                  ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats), float(beta), B, 64, 16, 16, 3,
-                                                  lay.n, ptr(chan), ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
-                                                  stream_ptr(self.device)))
-            c["d3_bias_done"] = True
-        elif self.direct:
-            g = torch.empty_like(c["logits"])
-            # BCE + its gradient, the batch statistics and the bias gradient of d3 (sum of g per channel) in one launch
-            chan = x.new_empty(B, 3)
-            check(load().mvae_conv_bce_stats(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats),
-                                             float(beta), B, 3072, 1024, lay.n, ptr(chan),
-                                             ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
-                                             stream_ptr(self.device)))
-            c["d3_bias_done"] = True
-        else:
-            g = torch.empty_like(c["logits"])
-            check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
-                                                   stream_ptr(self.device)))
-            check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
-                                          stream_ptr(self.device)))
-        PV, GV = self.param_views(), self.grad_views()
-        # the final "add the slices" of every weight gradient / bias column sum below is queued and performed by ONE
-        # launch at the end of the backward pass (nobody reads those gradients before the optimizer)
+        # From here to the end of the backward pass the final "add the slices" of every weight gradient / bias column sum, and
+        # the tail of the loss end (d3.bias, batch statistics), are queued and performed by ONE launch at the end (nobody reads
+        # them before the optimizer).
         _DEFERRED_WS.clear()
         check(load().mvae_slice_sums_defer(1))
         try:
-            return self._backward(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay)
+            g = self._loss_end(x, c, bce, beta, B, lay)
+            return self._backward(x, eps, beta, want_outputs, c, g, bce, self.param_views(), self.grad_views(), B, lay)
         except BaseException:
             # an aborted pass may have left arrival counters of mvae_conv_bce_stats non-zero (the kernel re-arms them
             # itself only when it completes): without this no workgroup of the next step would ever see itself as the
@@ -747,6 +724,34 @@ class ConvEngine:
             raise
         finally:
             check(load().mvae_slice_sums_defer(0))
+
+    def _loss_end(self, x, c, bce, beta, B, lay):
+        """BCE, its gradient g, the batch statistics and d3.bias (the last two queued with the deferred sums)."""
+        if c["logits"] is None:
+            # the last transposed convolution, BCE + its gradient, the batch statistics and d3.bias in ONE launch
+            PV = self.param_views()
+            c["logits"], g, chan = x.new_empty(B, 3072), x.new_empty(B, 3072), _keep(x.new_empty(B, 3))  # (read at the flush)
+            check(load().mvae_convt_to3_bce_stats(ptr(c["b2"]), ptr(PV["d3.weight"]), ptr(PV["d3.bias"]), ptr(x), ptr(c["logits"]),
+                                                  ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats), float(beta), B, 64, 16, 16, 3,
+                                                  lay.n, ptr(chan), ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
+                                                  stream_ptr(self.device)))
+            c["d3_bias_done"] = True
+        elif self.direct:
+            g = torch.empty_like(c["logits"])
+            # BCE + its gradient, the batch statistics and the bias gradient of d3 (sum of g per channel) in one launch
+            chan = _keep(x.new_empty(B, 3))  # (read at the flush)
+            check(load().mvae_conv_bce_stats(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), ptr(c["kl"]), ptr(self.stats),
+                                             float(beta), B, 3072, 1024, lay.n, ptr(chan),
+                                             ptr(self.grad_views()["d3.bias"]), ptr(self._arrive),
+                                             stream_ptr(self.device)))
+            c["d3_bias_done"] = True
+        else:
+            g = torch.empty_like(c["logits"])
+            check(load().mvae_bce_forward_backward(ptr(c["logits"]), ptr(x), ptr(bce), ptr(g), B, 3072,
+                                                   stream_ptr(self.device)))
+            check(load().mvae_batch_stats(ptr(bce), ptr(c["kl"]), ptr(self.stats), float(beta), B, lay.n,
+                                          stream_ptr(self.device)))
+        return g
 
     def _backward(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
         side = self._branch

@@ -265,6 +265,22 @@ __device__ __forceinline__ void batch_stats_body(const float* bce, const float* 
     stats[last] = bs; stats[last + 1] = kt; stats[last + 2] = es; stats[last + 3] = 1.f;
   }
 }
+// The tail of the loss end: d(bias of the last layer) = per-channel sums of the images' partial sums (rows in order: lane = row
+// mod 64, then the DPP tree) and the batch statistics.  Run by the LAST workgroup of the loss-end launch (arrival counters), or
+// -- while slice sums are deferred -- by one workgroup of the flush launch (loss_tail_deferred below).
+__device__ __forceinline__ void loss_tail_body(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp,
+                                               const float* chan_part, float* dbias, int C) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    for (int c = 0; c < C; ++c) {
+      float a = 0.f;
+      for (int rr = tid; rr < B; rr += 64) a += chan_part[(size_t)rr * C + c];
+      a = wave_sum(a);
+      if (tid == 0) dbias[c] = a;
+    }
+  }
+  batch_stats_body(bce, kl, stats, beta, B, ncomp);
+}
 __global__ __launch_bounds__(256) void k_batch_stats(const float* bce, const float* kl, float* stats, float beta, int B,
                                                      int ncomp) {
   batch_stats_body(bce, kl, stats, beta, B, ncomp);
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256) void k_bce_stats(const float* logits, const fl
   // XCD's whole L2, dirty with 12 KB of g per row, once per workgroup: 28 us instead of 9.)
   if (tid == 0) store4_wt(bce, (size_t)r, (sm[0] + sm[1]) + (sm[2] + sm[3]));
   if (tid < C) store4_wt(chan_part, (size_t)r * C + tid, (chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid]));
+  if (!counter) return;  // the tail is queued with the deferred slice sums (loss_tail_deferred)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -333,15 +350,7 @@ __global__ __launch_bounds__(256) void k_bce_stats(const float* logits, const fl
   __syncthreads();
   if (!last_s) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (tid < 64) {  // wave 0: dbias, one channel at a time, rows in order (lane = row mod 64, then the DPP tree)
-    for (int c = 0; c < C; ++c) {
-      float a = 0.f;
-      for (int rr = tid; rr < B; rr += 64) a += chan_part[(size_t)rr * C + c];
-      a = wave_sum(a);
-      if (tid == 0) dbias[c] = a;
-    }
-  }
-  batch_stats_body(bce, kl, stats, beta, B, ncomp);
+  loss_tail_body(bce, kl, stats, beta, B, ncomp, chan_part, dbias, C);
 }
 
 static int grid_for(int64_t total) {
@@ -1164,6 +1173,14 @@ struct SumJobs {
   int slices[kMaxSumJobs];
   int blk0[kMaxSumJobs + 1];
   int njobs;
+  // the queued tail of the loss end (loss_tail_body), run by ONE extra workgroup of the flush launch; lt_stats == NULL: none
+  const float* lt_bce;
+  const float* lt_kl;
+  float* lt_stats;
+  const float* lt_chan;
+  float* lt_dbias;
+  float lt_beta;
+  int lt_B, lt_ncomp, lt_C;
 };
 static thread_local SumJobs g_sums;
 static thread_local bool g_defer = false;
@@ -1174,8 +1191,16 @@ static thread_local bool g_suspended = false;  // deferral paused (mvae_slice_su
 // the four partial sums meet in LDS and are added in wave order -- the same additions in the same order as k_sum_slices.
 __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
   __shared__ f32x4 sm[4][64];
+  // the extra workgroup of a queued loss tail is dispatched FIRST: a chain of ~6 us of dependent round trips that must not start
+  // when the last slice-sum workgroup does
+  const int bx = (int)blockIdx.x - (jobs.lt_stats ? 1 : 0);
+  if (bx < 0) {
+    loss_tail_body(jobs.lt_bce, jobs.lt_kl, jobs.lt_stats, jobs.lt_beta, jobs.lt_B, jobs.lt_ncomp, jobs.lt_chan, jobs.lt_dbias,
+                   jobs.lt_C);
+    return;
+  }
   int j = 0;
-  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
+  while (j + 1 < jobs.njobs && bx >= jobs.blk0[j + 1]) ++j;  // uniform
   const float* part = jobs.part[j];
   float* out = jobs.out[j];
   const long long n = jobs.n[j];
@@ -1186,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
   if (vec) {
     const long long n4 = n >> 2;
     const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
-    for (long long base = (long long)((int)blockIdx.x - jobs.blk0[j]) * 64; base < n4; base += (long long)nblk * 64) {
+    for (long long base = (long long)(bx - jobs.blk0[j]) * 64; base < n4; base += (long long)nblk * 64) {
       const long long i = base + lane;
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       if (i < n4) {
@@ -1209,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
     return;
   }
   float* sms = reinterpret_cast<float*>(&sm[0][0]);  // [4][64] floats
-  for (long long base = (long long)((int)blockIdx.x - jobs.blk0[j]) * 64; base < n; base += (long long)nblk * 64) {
+  for (long long base = (long long)(bx - jobs.blk0[j]) * 64; base < n; base += (long long)nblk * 64) {
     const long long i = base + lane;
     float s = 0.f;
     if (i < n) {
@@ -1285,9 +1310,26 @@ static void flush_sums(hipStream_t s) {
     hipLaunchKernelGGL(k_colsum_batched, dim3((unsigned)g_cols.blk0[g_cols.njobs]), dim3(256), 0, s, g_cols);
     g_cols.njobs = 0;
   }
-  if (g_sums.njobs == 0) return;
-  hipLaunchKernelGGL(k_sum_slices_batched, dim3((unsigned)g_sums.blk0[g_sums.njobs]), dim3(256), 0, s, g_sums);
+  if (g_sums.njobs == 0 && !g_sums.lt_stats) return;
+  if (g_sums.njobs == 0) g_sums.blk0[0] = 0;
+  hipLaunchKernelGGL(k_sum_slices_batched, dim3((unsigned)(g_sums.blk0[g_sums.njobs] + (g_sums.lt_stats ? 1 : 0))), dim3(256), 0, s,
+                     g_sums);
   g_sums.njobs = 0;
+  g_sums.lt_stats = nullptr;
+}
+
+// The loss end's tail while deferral is on: nobody reads the statistics or d(bias) before the optimizer, and inside the
+// loss-end launch the tail is five dependent memory round trips of ONE workgroup after all the others have finished (stores
+// drained, two arrival atomics, acquire, the partial sums, the statistics: 8.7 of that launch's 19 us at B = 256).  Queued, it
+// runs beside the slice sums.  Returns false when deferral is off (the caller keeps the arrival-counted tail).
+static bool loss_tail_deferred(const float* bce, const float* kl, float* stats, float beta, int B, int ncomp,
+                               const float* chan_part, float* dbias, int C, hipStream_t s) {
+  static const bool off = [] { const char* e = getenv("MVAE_LOSS_TAIL_DEFER"); return e && e[0] == '0'; }();
+  if (!g_defer || off) return false;
+  if (g_sums.lt_stats) flush_sums(s);  // (a second loss end before the flush: the first one's tail goes now)
+  g_sums.lt_bce = bce; g_sums.lt_kl = kl; g_sums.lt_stats = stats; g_sums.lt_chan = chan_part; g_sums.lt_dbias = dbias;
+  g_sums.lt_beta = beta; g_sums.lt_B = B; g_sums.lt_ncomp = ncomp; g_sums.lt_C = C;
+  return true;
 }
 
 // the final sum of `slices` partial results: now, or queued while deferral is on
@@ -1321,7 +1363,10 @@ void p3_sum_slices_now(const float* part, float* out, int64_t n, int slices, hip
 //         exception the queued outputs / workspaces may be gone, so the stale jobs must not run with the next pass).
 extern "C" int mvae_slice_sums_defer(int on) {
   if (on == 1) {
-    if (!g_defer && !g_suspended) g_sums.njobs = g_cols.njobs = 0;
+    if (!g_defer && !g_suspended) {
+      g_sums.njobs = g_cols.njobs = 0;
+      g_sums.lt_stats = nullptr;
+    }
     g_defer = true;
     g_suspended = false;
   } else if (on == 2) {
@@ -1331,6 +1376,7 @@ extern "C" int mvae_slice_sums_defer(int on) {
     g_defer = false;
     g_suspended = false;
     g_sums.njobs = g_cols.njobs = 0;
+    g_sums.lt_stats = nullptr;
   }
   return 0;
 }
@@ -1642,8 +1688,9 @@ extern "C" int mvae_conv_bce_stats(const float* logits, const float* x, float* b
     return fail(MVAE_E_UNSUPPORTED, "mvae_conv_bce_stats: D = C x HW with C <= 8 and HW a multiple of 1024%s", "");
   if (((((uintptr_t)logits) | ((uintptr_t)x) | ((uintptr_t)g)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "mvae_conv_bce_stats needs 16-byte aligned logits / x / g%s", "");
+  const bool queued = loss_tail_deferred(bce, kl, stats, beta, (int)B, ncomp, chan_part, dbias, D / HW, (hipStream_t)stream);
   hipLaunchKernelGGL(k_bce_stats, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, x, bce, g, kl, stats, beta,
-                     (int)B, D, HW, ncomp, chan_part, dbias, counter);
+                     (int)B, D, HW, ncomp, chan_part, dbias, queued ? nullptr : counter);
   LAUNCH_CHECK("bce + statistics launch");
   return 0;
 }
@@ -1838,6 +1885,7 @@ __global__ __launch_bounds__(512) void k_d3_bce_stats(const float* __restrict__ 
   if (tid < kBC)
     store4_wt(chan_part, (size_t)r * kBC + tid, ((chs[0][tid] + chs[1][tid]) + (chs[2][tid] + chs[3][tid])) +
                                                     ((chs[4][tid] + chs[5][tid]) + (chs[6][tid] + chs[7][tid])));
+  if (!counter) return;  // the tail is queued with the deferred slice sums (loss_tail_deferred)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -1856,15 +1904,7 @@ __global__ __launch_bounds__(512) void k_d3_bce_stats(const float* __restrict__ 
   __syncthreads();
   if (!last_s) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (tid < 64) {
-    for (int c = 0; c < kBC; ++c) {
-      float a = 0.f;
-      for (int rr = tid; rr < B; rr += 64) a += chan_part[(size_t)rr * kBC + c];
-      a = wave_sum(a);
-      if (tid == 0) dbias[c] = a;
-    }
-  }
-  batch_stats_body(bce, kl, stats, beta, B, ncomp);
+  loss_tail_body(bce, kl, stats, beta, B, ncomp, chan_part, dbias, kBC);
 }
 
 extern "C" int mvae_convt_to3_bce_stats(const float* src, const float* W, const float* bias, const float* x, float* logits,
@@ -1878,8 +1918,9 @@ extern "C" int mvae_convt_to3_bce_stats(const float* src, const float* W, const 
     return fail(MVAE_E_UNSUPPORTED, "fused last layer + loss end: 64 features to 3 x 32 x 32%s", "");
   if (((((uintptr_t)src) | ((uintptr_t)x) | ((uintptr_t)logits) | ((uintptr_t)g)) & 15) != 0)
     return fail(MVAE_E_ALIGN, "mvae_convt_to3_bce_stats needs 16-byte aligned src / x / logits / g%s", "");
+  const bool queued = loss_tail_deferred(bce, kl, stats, beta, (int)B, ncomp, chan_part, dbias, kBC, (hipStream_t)stream);
   hipLaunchKernelGGL(k_d3_bce_stats, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, src, W, bias, x, logits, bce, g, kl,
-                     stats, beta, (int)B, ncomp, chan_part, dbias, counter);
+                     stats, beta, (int)B, ncomp, chan_part, dbias, queued ? nullptr : counter);
   LAUNCH_CHECK("fused last layer + loss end launch");
   return 0;
 }

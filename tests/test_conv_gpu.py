@@ -1082,6 +1082,46 @@ def test_fused_last_layer_and_loss_end(dev, B):
     for a, b, nm in zip(got, want, ("logits", "bce", "g", "d3.bias", "stats")):
         assert_close(_cpu(a), _cpu(b), 2e-5, nm + " vs the two-launch route", atol_frac=1e-5)
 
+    # Between mvae_slice_sums_defer(1) and the flush the two batch-wide sums (d3.bias, the statistics) are queued and run by the
+    # flush launch: nothing of them before the flush, the SAME BITS after it, the arrival counters untouched -- both entry points,
+    # with and without other queued sums; dropping the queue (defer(0) without a flush) drops the tail as well.
+    def run_deferred(fused, other_jobs, flush=True):
+        logits = new(B, 3072) if fused else _convT_to3(b2, W, bias, B)
+        bce, g, chan, dbias = new(B), new(B, 3072), new(B, 3), torch.full((3,), -5.0, device=dev)
+        stats, arrive = torch.zeros(64, device=dev), torch.zeros(17, dtype=torch.int32, device=dev)
+        part, tot = torch.rand(2048, 1000, generator=gen).to(dev), new(1000)  # a tall column sum: sliced, its final sum deferrable
+        cws = new(int(load().mvae_colsum_workspace_floats(2048, 1000)))
+        check(load().mvae_slice_sums_defer(1))
+        try:
+            if fused:
+                check(load().mvae_convt_to3_bce_stats(ptr(b2), ptr(W), ptr(bias), ptr(x), ptr(logits), ptr(bce), ptr(g), ptr(kl),
+                                                      ptr(stats), 0.7, B, 64, 16, 16, 3, 3, ptr(chan), ptr(dbias), ptr(arrive),
+                                                      stream_ptr(dev)))
+            else:
+                check(load().mvae_conv_bce_stats(ptr(logits), ptr(x), ptr(bce), ptr(g), ptr(kl), ptr(stats), 0.7, B, 3072, 1024,
+                                                 3, ptr(chan), ptr(dbias), ptr(arrive), stream_ptr(dev)))
+            if other_jobs:
+                check(load().mvae_colsum(ptr(part), ptr(tot), 2048, 1000, ptr(cws), stream_ptr(dev)))
+            torch.cuda.synchronize()
+            assert float(dbias[0]) == -5.0 and float(stats.abs().sum()) == 0.0, "the tail ran before the flush"
+            if flush:
+                check(load().mvae_slice_sums_flush(stream_ptr(dev)))
+        finally:
+            check(load().mvae_slice_sums_defer(0))
+        torch.cuda.synchronize()
+        assert int(arrive.abs().sum()) == 0
+        if other_jobs and flush:
+            assert_close(_cpu(tot), part.double().sum(0).cpu().numpy(), 2e-5, "the other queued sum")
+        return logits, bce, g, dbias, stats
+
+    for fused, ref_run in ((True, got), (False, want)):
+        for other in (False, True):
+            d = run_deferred(fused, other)
+            for a, b, nm in zip(d, ref_run, ("logits", "bce", "g", "d3.bias", "stats")):
+                assert torch.equal(a, b), f"{nm}: deferred tail differs (fused={fused}, other jobs={other})"
+    d = run_deferred(True, False, flush=False)
+    assert float(d[3][0]) == -5.0 and float(d[4].abs().sum()) == 0.0
+
 
 @pytest.mark.parametrize("B", [8, 256, 300])
 def test_edge_layers_without_patch_matrix(dev, B):

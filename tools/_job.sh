@@ -1,11 +1,11 @@
 export TMPDIR=/tmp
-for m in warm cold; do
-rm -rf /tmp/p_$m; MODE=$m timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/p_$m -o r --output-format csv -- python tests/dev/conv_latent_repeat.py > /tmp/p_$m.log 2>&1
-f=$(find /tmp/p_$m -name '*kernel_stats.csv' | head -1)
-echo == $m
+python -m pytest tests/test_conv_gpu.py tests/test_input_pipeline_gpu.py -x -q -m gpu 2>&1 | tail -3
+rm -rf /tmp/p_b; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/p_b -o r --output-format csv -- python tools/bench_conv.py 256 30 > /tmp/p_b.log 2>&1
+f=$(find /tmp/p_b -name '*kernel_stats.csv' | head -1)
 python - $f <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'k_cl_' in r['Name']: print(r['Name'][:40], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
+    if 'k_d3_bce' in r['Name'] or 'k_sum_slices' in r['Name'] or 'k_optim' in r['Name']: print(r['Name'][:30], r['Calls'], r['AverageNs'])
 PY
-done
+GRAPH=1 python tools/bench_conv.py 256 100
+GRAPH=1 python tools/bench_conv.py 256 100
