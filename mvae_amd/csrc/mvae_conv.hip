@@ -1968,9 +1968,27 @@ __global__ __launch_bounds__(256) void k_cl_heads_part(const float* __restrict__
   __shared__ __attribute__((aligned(16))) float sW[NN][128];
   const int tid = threadIdx.x, l = tid & 31, g = tid >> 5;
   const int s = blockIdx.x, p = s >> 2, c0 = (s & 3) << 7, c = c0 + (l << 2);
-  for (int e = tid; e < NN * 128; e += 256) {
-    const int n = e >> 7, cc = e & 127;
-    sW[n][cc] = W[(size_t)(n < N ? n : 0) * kFlat + (c0 + cc) * kPix + p];
+  // the activation rows are requested BEFORE the weights are staged: behind the staging barrier they were a second memory round
+  // trip of a launch that is two round trips long
+  const int r0 = blockIdx.y * 64;
+  f32x4 xv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int r = r0 + g + 8 * u;
+    xv[u] = *reinterpret_cast<const f32x4*>(a2 + (size_t)(r < B ? r : B - 1) * kFlat + p * kEncC + c);
+  }
+  constexpr int kWPer = NN * 128 / 256;
+  float wst[kWPer];
+#pragma unroll
+  for (int q = 0; q < kWPer; ++q) {
+    const int e = tid + 256 * q, n = e >> 7, cc = e & 127;
+    wst[q] = W[(size_t)(n < N ? n : 0) * kFlat + (c0 + cc) * kPix + p];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < kWPer; ++q) {
+    const int e = tid + 256 * q;
+    sW[e >> 7][e & 127] = wst[q];
   }
   __syncthreads();
   float w[NN][4];
@@ -1979,13 +1997,6 @@ __global__ __launch_bounds__(256) void k_cl_heads_part(const float* __restrict__
     const f32x4 wv = *reinterpret_cast<const f32x4*>(&sW[n][l << 2]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[n][i] = wv[i];
-  }
-  const int r0 = blockIdx.y * 64;
-  f32x4 xv[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int r = r0 + g + 8 * u;
-    xv[u] = *reinterpret_cast<const f32x4*>(a2 + (size_t)(r < B ? r : B - 1) * kFlat + p * kEncC + c);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
