@@ -1165,7 +1165,6 @@ __global__ __launch_bounds__(256) void k_sum_slices(const float* part, float* ou
 // performs every queued sum in ONE launch.  In the conv step these sums are ~13 launches of ~5 us each whose outputs
 // nobody reads before the optimizer.  Host-side state, per calling thread; nothing here synchronises.
 constexpr int kMaxSumJobs = 24;
-constexpr int kColSlice = 512;  // rows per slice of the tall column sums (mvae_colsum)
 struct SumJobs {
   const float* part[kMaxSumJobs];
   float* out[kMaxSumJobs];
@@ -1260,49 +1259,17 @@ __global__ __launch_bounds__(256) void k_sum_slices_batched(SumJobs jobs) {
 // slice sums that add their slice totals.  Thread (row group g = tid >> 4, column quad c = tid & 15) adds rows g, g + 16,
 // ... of its 512-row slice, 8 requests of 16 bytes in flight; the 16 row groups meet in LDS and are added in group order:
 // per column the same additions in the same order as k_colsum_sliced.
-constexpr int kMaxColJobs = 12;
-struct ColJobs {
-  const float* G[kMaxColJobs];
-  float* part[kMaxColJobs];
-  int M[kMaxColJobs], N[kMaxColJobs], ncb[kMaxColJobs];
-  int blk0[kMaxColJobs + 1];
-  int njobs;
-};
-static thread_local ColJobs g_cols;
+static thread_local ColJobs g_cols;  // (ColJobs, kColSlice and colsum_batched_body: mvae_p3.hpp)
 
-__global__ __launch_bounds__(256) void k_colsum_batched(ColJobs jobs) {
-  __shared__ f32x4 sm[16][17];
-  int j = 0;
-  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
-  const int b = (int)blockIdx.x - jobs.blk0[j];
-  const int ncb = jobs.ncb[j], N = jobs.N[j], M = jobs.M[j];
-  const int slice = b / ncb, cb = b - slice * ncb;
-  const int m0 = slice * kColSlice;
-  const int rows = (M - m0) < kColSlice ? (M - m0) : kColSlice;
-  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int col = cb * 64 + c * 4;
-  const bool act = col < N;
-  const float* base = jobs.G[j] + (size_t)m0 * N + (act ? col : 0);
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int m = g; m < rows; m += 16 * 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int mm = m + 16 * u;
-      v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(mm < rows ? mm : 0) * N);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (m + 16 * u < rows) s += v[u];
-  }
-  sm[g][c] = s;
-  __syncthreads();
-  if (g == 0 && act) {
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < 16; ++q) t += sm[q][c];
-    *reinterpret_cast<f32x4*>(jobs.part[j] + (size_t)slice * N + col) = t;
-  }
+__global__ __launch_bounds__(256) void k_colsum_batched(ColJobs jobs) { colsum_batched_body(jobs, (int)blockIdx.x); }
+
+// The queued column sums handed to a launch that can carry them as extra workgroups (the boundary layer's weight gradient,
+// mvae_edge.hip: the last launch of the backward pass before the flush, independent of them) instead of a launch of their own.
+bool p3_take_coljobs(ColJobs* out) {
+  if (!g_defer || g_cols.njobs == 0) return false;
+  *out = g_cols;
+  g_cols.njobs = 0;
+  return true;
 }
 
 static void flush_sums(hipStream_t s) {

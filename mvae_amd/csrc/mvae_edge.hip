@@ -199,6 +199,13 @@ __global__ __launch_bounds__(512) void k_edge3_tn(const float* __restrict__ act,
                                                   float* __restrict__ part, const int B, const int img_per_wg) {
   edge3_tn_body((int)blockIdx.x, act, img, part, B, img_per_wg);
 }
+// the same launch carrying the queued column sums of the backward pass (bias gradients) as extra workgroups
+__global__ __launch_bounds__(512) void k_edge3_tn_cols(const float* __restrict__ act, const float* __restrict__ img,
+                                                       float* __restrict__ part, const int B, const int img_per_wg,
+                                                       const int n_tn, const ColJobs cols) {
+  if ((int)blockIdx.x < n_tn) edge3_tn_body((int)blockIdx.x, act, img, part, B, img_per_wg);
+  else colsum_batched_body(cols, (int)blockIdx.x - n_tn);
+}
 // both backward contractions of d3 in one launch (they read the same gradient image and not each other): workgroups
 // 0 .. n_tn - 1 the weight gradient, the rest the backward-data
 __global__ __launch_bounds__(512) void k_edge3_bwd(const float* __restrict__ act, const float* __restrict__ img,
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(512) void k_edge3_bwd(const float* __restrict__ act
 }
 
 void p3_sum_slices(const float* part, float* out, int64_t n, int slices, hipStream_t s);  // mvae_conv.hip (honours deferral)
+bool p3_take_coljobs(ColJobs* out);                                                          // mvae_conv.hip
 
 static bool edge_geometry(int C, int H, int Wd, int F) { return C == kEC && H == kEH && Wd == kEH && F == kEF; }
 
@@ -243,7 +251,16 @@ extern "C" int mvae_conv3_k4s2p1_nchw_wgrad(const float* act, const float* img, 
   if (!aligned16(act) || !aligned16(workspace) || !aligned16(dW))
     return fail(MVAE_E_ALIGN, "direct boundary weight gradient: 16-byte aligned operands%s", "");
   const int ipw = edge_img_per_wg(B), wgs = (B + ipw - 1) / ipw;
-  hipLaunchKernelGGL(k_edge3_tn, dim3((unsigned)wgs), dim3(512), 0, (hipStream_t)stream, act, img, workspace, B, ipw);
+  // While sums are deferred, the column sums queued so far (the bias gradients of the backward pass: nothing this launch reads
+  // or writes) ride along as extra workgroups instead of taking a launch of their own at the flush; their slice totals are
+  // still added by the flush.
+  ColJobs cols;
+  static const bool no_ride = [] { const char* e = getenv("MVAE_COLSUM_RIDE"); return e && e[0] == '0'; }();
+  if (!no_ride && p3_take_coljobs(&cols))
+    hipLaunchKernelGGL(k_edge3_tn_cols, dim3((unsigned)(wgs + cols.blk0[cols.njobs])), dim3(512), 0, (hipStream_t)stream, act, img,
+                       workspace, B, ipw, wgs, cols);
+  else
+    hipLaunchKernelGGL(k_edge3_tn, dim3((unsigned)wgs), dim3(512), 0, (hipStream_t)stream, act, img, workspace, B, ipw);
   p3_sum_slices(workspace, dW, (int64_t)kEF * kEK, wgs, (hipStream_t)stream);
   LAUNCH_CHECK("direct boundary weight gradient launch");
   return 0;

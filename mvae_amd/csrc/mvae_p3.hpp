@@ -45,3 +45,56 @@ __device__ __forceinline__ void store_planes4(bf16r* planes, long long plane_str
   *reinterpret_cast<p3_u32x2*>(planes + plane_stride + idx) = m;
   *reinterpret_cast<p3_u32x2*>(planes + 2 * plane_stride + idx) = l;
 }
+
+// ---- deferred column sums of tall matrices (bias gradients): job table and workgroup body, shared by the flush launch
+// (mvae_conv.hip) and the launches that carry the jobs as extra workgroups (mvae_edge.hip).  Thread (row group g = tid >> 4,
+// column quad c = tid & 15) of the first 256 threads adds rows g, g + 16, ... of its 512-row slice, 8 requests of 16 bytes in
+// flight; the 16 row groups meet in LDS and are added in group order: per column the same additions in the same order as
+// k_colsum_sliced.
+constexpr int kColSlice = 512;  // rows per slice of the tall column sums (mvae_colsum)
+constexpr int kMaxColJobs = 12;
+struct ColJobs {
+  const float* G[kMaxColJobs];
+  float* part[kMaxColJobs];
+  int M[kMaxColJobs], N[kMaxColJobs], ncb[kMaxColJobs];
+  int blk0[kMaxColJobs + 1];
+  int njobs;
+};
+typedef float p3_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void colsum_batched_body(const ColJobs& jobs, const int blk) {
+  __shared__ p3_f32x4 sm[16][17];
+  int j = 0;
+  while (j + 1 < jobs.njobs && blk >= jobs.blk0[j + 1]) ++j;  // uniform
+  const int b = blk - jobs.blk0[j];
+  const int ncb = jobs.ncb[j], N = jobs.N[j], M = jobs.M[j];
+  const int slice = b / ncb, cb = b - slice * ncb;
+  const int m0 = slice * kColSlice;
+  const int rows = (M - m0) < kColSlice ? (M - m0) : kColSlice;
+  const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 15;
+  const bool worker = threadIdx.x < 256;  // (callers may run wider workgroups)
+  const int col = cb * 64 + c * 4;
+  const bool act = col < N;
+  const float* base = jobs.G[j] + (size_t)m0 * N + (act ? col : 0);
+  p3_f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (worker) {
+    for (int m = g; m < rows; m += 16 * 8) {
+      p3_f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int mm = m + 16 * u;
+        v[u] = *reinterpret_cast<const p3_f32x4*>(base + (size_t)(mm < rows ? mm : 0) * N);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (m + 16 * u < rows) s += v[u];
+    }
+    sm[g][c] = s;
+  }
+  __syncthreads();
+  if (worker && g == 0 && act) {
+    p3_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 16; ++q) t += sm[q][c];
+    *reinterpret_cast<p3_f32x4*>(jobs.part[j] + (size_t)slice * N + col) = t;
+  }
+}
