@@ -57,6 +57,17 @@ __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __rest
       pf[gI][s] = ok ? img[(((size_t)b * kEC + c) * kEH + iy) * kEH + ix] : 0.f;
     }
   }
+  // the ReLU mask of the wave's rows travels with the gather (asked for in the epilogue it is a memory round trip of its own
+  // between the last MFMA and the first store)
+  f32x4 mkv[G][4];
+#pragma unroll
+  for (int gI = 0; gI < G; ++gI)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + gI, px = 4 * i + l4;
+      mkv[gI][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (mask && row < nrows) mkv[gI][i] = *reinterpret_cast<const f32x4*>(mask + ((size_t)row * 16 + px) * kEF + 4 * l15);
+    }
   __syncthreads();
   if (row0 >= nrows && !colpart) return;
   // weight fragments for the whole life of the wave: operand "a" of tile t, step s = W[16 t + l15][4 s + l4]
@@ -97,7 +108,7 @@ __device__ __forceinline__ void edge3_nt_body(const int blk, const float* __rest
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (mask) {
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + o);
+        const f32x4 mk = mkv[gI][i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
       }
