@@ -132,7 +132,8 @@ def conv_effective_peak_tf(mode):
     return CONV_FLOPS_B256 / t / 1e12
 
 
-def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=None, strong=False, force_dp=False):
+def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=None, strong=False, force_dp=False,
+             repeats=5):
     """BASELINE configs[4]: CIFAR shapes (3x32x32, soft targets), conv architecture, h_dim 8192, batch 256, model
     h2,s2,e2, learnable curvature.  One step = ConvEngine.train_step (forward, ELBO, backward, Adam + curvature SGD); the
     warm-up and the timed region are ONE HIP graph each.  MFMA-bound: the roofline is f32 MFMA flops.  N > 1 (or
@@ -197,14 +198,18 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
 
     run(warmup)
     sync_all()
-    t0 = time.perf_counter()
-    run(steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    times = []
+    for _ in range(repeats):  # every repeat: EXACTLY `steps` steps between barrier + synchronize, max over ranks
+        t0 = time.perf_counter()
+        run(steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    dt = sorted(times)[len(times) // 2]  # the median repeat
     st = eng.read_stats()["last"]
     assert st["elbo"] == st["elbo"], "non-finite ELBO"
     if rank != 0:
@@ -244,6 +249,9 @@ def conv_leg(steps, warmup, graph=True, world=1, rank=0, dist_on=False, backend=
                    "global_batch": Bc * world, "parallelism": f"dp{world}" + ("(forced exchange)" if force_dp else ""),
                    "exchange": (dp.exchange + (f" ({dp.exchange_note})" if dp.exchange_note else "")) if dp is not None else "none",
                    "graph_steps": steps if graphs else 0, "graph_replays": 1 if graphs else 0,
+                   "timed_repeats": repeats,
+                   "repeat_ms_per_step": {"median": step_s * 1e3, "first": times[0] / steps * 1e3,
+                                          "min": min(times) / steps * 1e3, "max": max(times) / steps * 1e3},
                    "final_elbo_per_sample": st["elbo"] / Bc},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": conv_effective_peak_tf(mode), "unit": "TFLOP/s",
                      "frac": tf / conv_effective_peak_tf(mode),
@@ -412,7 +420,7 @@ def mlp_roofline(eng, prof, step_s, fixed):
     return roof
 
 
-def mlp_leg(model, fixed, steps, warmup, dev):
+def mlp_leg(model, fixed, steps, warmup, dev, repeats=5):
     """A short single-GPU leg of another BASELINE MLP config (one graph for the warm-up, one for the timed region)."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
@@ -427,12 +435,17 @@ def mlp_leg(model, fixed, steps, warmup, dev):
     runner = StepRunner(eng, xs, eps, beta=1.0, do_curvature_step=not fixed, graph_steps=gs, graph_plan=plan)
     runner.run(warmup)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    runner.run(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(repeats):
+        if plan is not None and runner.gs > 0 and warmup > 0:
+            runner.cursor = warmup  # every repeat replays the timed graph
+        t0 = time.perf_counter()
+        runner.run(steps)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]  # the median repeat
     stats = eng.read_stats()
-    assert stats["sum"]["steps"] == warmup + steps, stats["sum"]["steps"]
+    assert stats["sum"]["steps"] == warmup + repeats * steps, stats["sum"]["steps"]
     assert stats["last"]["elbo"] == stats["last"]["elbo"], "non-finite ELBO"
     prof = eng.profile_step(xs[0], eps[0], 1.0, not fixed, iters=100)
     roof = mlp_roofline(eng, prof, dt / steps, fixed)
@@ -440,7 +453,9 @@ def mlp_leg(model, fixed, steps, warmup, dev):
             "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
             "workload": f"MNIST shapes (D=784), model {model}, {'fixed' if fixed else 'learnable'} curvature, "
                         "MLP h_dim=400, batch 128, epoch>=10 state",
-            "graph_replays": runner.replays,
+            "graph_replays": runner.replays, "timed_repeats": repeats,
+            "repeat_ms_per_step": {"median": dt / steps * 1e3, "first": times[0] / steps * 1e3,
+                                   "min": min(times) / steps * 1e3, "max": max(times) / steps * 1e3},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms",
                                               "step_hbm_frac", "step_mfma_frac")}}
 
@@ -479,6 +494,65 @@ def epoch_pipeline_leg(dev, epochs=3):
             "baseline_config": "configs[1] with the reference's DataLoader + ImageDynamicBinarization replaced (SURVEY 8 f-2)"}
 
 
+def loglik_leg(dev, n=500, iters=10):
+    """Scope row f-1 (ModelVAE.log_likelihood, vae.py:82-123) at the reference's evaluation setting: B = 128, n = 500
+    importance samples, model h2,s2,e2, MLP h_dim 400 -- 64 000 decoded rows per batch.  MFMA-bound: the decoder's two
+    layers are 2 * 64000 * (Z*H + H*D) flops."""
+    from mvae_amd import functional as Fn, utils
+    from mvae_amd.models import FeedForwardVAE
+
+    class _DS:
+        in_dim, img_dims = D, None
+
+        @staticmethod
+        def reconstruction_loss(x_, x):
+            return Fn.bce_rows(x_, x)
+
+    torch.manual_seed(0)
+    m = FeedForwardVAE(H, utils.parse_components(MODEL, False), _DS(), False).to(dev)
+    x = (torch.rand(B, D, device=dev) > 0.7).float()
+    for _ in range(3):
+        out = m.log_likelihood(x, n=n)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = m.log_likelihood(x, n=n)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / iters)
+    dt = sorted(times)[len(times) // 2]
+    assert bool(torch.isfinite(out[0]).all()), "non-finite log-likelihood"
+    Z = m.total_z_dim
+    flops = 2.0 * n * B * (Z * H + H * D) + 2.0 * B * (D * H + H * 2 * Z)
+    tf = flops / dt / 1e12
+    return {"metric": f"IWAE log-likelihood batches/sec (B={B}, n={n}) MNIST {MODEL}", "value": 1.0 / dt, "unit": "batches/sec",
+            "ms_per_batch": dt * 1e3, "n": n, "batch": B, "dtype": "f32", "timed_repeats": 5, "iters_per_repeat": iters,
+            "repeat_ms_per_batch": {"median": dt * 1e3, "first": times[0] * 1e3, "min": min(times) * 1e3, "max": max(times) * 1e3},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                         "flops_per_batch": flops},
+            "baseline_config": "scope row f-1: ModelVAE.log_likelihood (vae.py:82-123), the reference's test-time estimator"}
+
+
+def configs_summary(line):
+    """The last object of the JSON line: every BASELINE config of this run as [value, ms, roofline frac], short enough to
+    survive a 2000-character tail of stdout (the full legs are under `configs`)."""
+    def row(d, ms_key="ms_per_step"):
+        if not isinstance(d, dict) or "error" in d or "value" not in d:
+            return None
+        fr = (d.get("roofline") or {}).get("frac")
+        return [round(d["value"], 1), round(d[ms_key], 5), None if fr is None else round(fr, 4)]
+    c = line.get("configs", {})
+    out = {"fmt": "[value/s, ms, roofline frac]; median of timed_repeats repeats",
+           "h2s2e2": row(line), "e6": row(c.get("e6")), "prod36": row(c.get("prod36")), "conv": row(c.get("conv")),
+           "conv_f32_mfma": row(c.get("conv_f32_mfma")), "conv_split": row(c.get("conv_split_bf16_products")),
+           "epoch_pipeline": row(c.get("epoch_pipeline")), "loglik": row(c.get("loglik"), "ms_per_batch"),
+           "conv_mode": (c.get("conv") or {}).get("contraction_mode"),
+           "timed_repeats": line["config"]["timed_repeats"],
+           "first_repeat": round(line["config"]["first_repeat_value"], 1)}
+    return out
+
+
 def conv_short_leg(mode):
     """A 20-step leg of the conv config in contraction mode `mode` (None: the library's current one), reduced to the fields
     the `configs` block of the headline line carries."""
@@ -492,6 +566,8 @@ def conv_short_leg(mode):
         _load().mvae_set_contraction_mode(prev)
     out = {k: v for k, v in leg.items() if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")}
     out["contraction_mode"] = leg["config"]["contraction_mode"]
+    out["timed_repeats"] = leg["config"]["timed_repeats"]
+    out["repeat_ms_per_step"] = leg["config"]["repeat_ms_per_step"]
     return out
 
 
@@ -504,8 +580,9 @@ def main():
                     help="steps captured per HIP graph for timed regions longer than ONE_GRAPH_MAX steps (shorter "
                          "regions are ONE graph); 0 = eager launches")
     ap.add_argument("--repeats", type=int, default=0,
-                    help="timed repeats of --steps steps each (value = the median repeat, min / max reported); default: "
-                         "5 when --steps >= 1000 at N = 1 (SURVEY 8d protocol), else 1")
+                    help="timed repeats of EXACTLY --steps steps each, every one bracketed by barrier + synchronize "
+                         "(value = the median repeat; first / min / max reported beside it); default 5 (SURVEY 8d "
+                         "protocol: median of 5 repeats)")
     ap.add_argument("--reset-every", type=int, default=0,
                     help="restore the initial parameters / optimizer state every N steps (0 = never, the default: "
                          "40 000 consecutive learnable-curvature steps on the cycled synthetic batches stay finite); a "
@@ -550,7 +627,7 @@ def main():
             args.steps, args.warmup = 200, 20
         world, rank, local_rank, dist_on, backend = init_dist(args.force_dp)
         line = conv_leg(args.steps, args.warmup, graph=args.graph_steps > 0, world=world, rank=rank, dist_on=dist_on,
-                        backend=backend, strong=args.strong, force_dp=args.force_dp)
+                        backend=backend, strong=args.strong, force_dp=args.force_dp, repeats=args.repeats or 5)
         if rank == 0:
             emit(line)
         if dist_on:
@@ -606,7 +683,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    repeats = args.repeats if args.repeats > 0 else (5 if (args.steps >= 1000 and world == 1 and plan is None) else 1)
+    repeats = args.repeats if args.repeats > 0 else 5
     prewarm = 0
     if plan is not None and runner.gs > 0 and args.prewarm > 0:
         # Opt-in only (--prewarm N).  A short timed region (the driver's 20 steps = 0.65 ms) starts on a device that has
@@ -628,6 +705,8 @@ def main():
     times = []
     replays_before, gsteps_before = runner.replays, runner.graph_steps_replayed
     for _ in range(repeats):
+        if plan is not None and runner.gs > 0 and args.warmup > 0:
+            runner.cursor = args.warmup  # a one-graph timed region: every repeat replays THE timed graph (same batches)
         t0 = time.perf_counter()
         runner.run(args.steps)  # EXACTLY --steps steps per timed region
         sync_all()
@@ -697,8 +776,10 @@ def main():
                    "steps_in_graph_replays": graph_steps_replayed,
                    "timed_repeats": repeats,
                    "prewarm_replays": prewarm,  # of the timed graph, on a snapshot of the state that is restored
-                   "repeat_ms_per_step": {"median": dt / args.steps * 1e3, "min": min(times) / args.steps * 1e3,
-                                          "max": max(times) / args.steps * 1e3},
+                   "repeat_ms_per_step": {"median": dt / args.steps * 1e3, "first": times[0] / args.steps * 1e3,
+                                          "min": min(times) / args.steps * 1e3, "max": max(times) / args.steps * 1e3,
+                                          "all": [round(t / args.steps * 1e3, 6) for t in times]},
+                   "first_repeat_value": args.steps * (1 if strong else world) / times[0],
                    "inputs": "x and eps resident in HBM before the timed region (SURVEY 8d); the device-side gather + "
                              "binarisation + eps draw of mvae_prepare_batch is NOT in the timed step",
                    "state_reset_every": args.reset_every,
@@ -730,12 +811,17 @@ def main():
             extra["epoch_pipeline"] = epoch_pipeline_leg(dev)
         except Exception as e:  # noqa: BLE001
             extra["epoch_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            extra["loglik"] = loglik_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            extra["loglik"] = {"error": f"{type(e).__name__}: {e}"}
         extra["e6"].setdefault("baseline_config", "configs[0]: MNIST e6, fixed curvature")
         extra["prod36"].setdefault("baseline_config", "configs[3]: 6h2,6s2,6e2 (36-dim latent), learnable curvature")
         extra["conv"].setdefault("baseline_config", "configs[4] on ONE GPU: CIFAR conv h_dim=8192, batch 256")
         line["configs"] = extra
     if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
         line["cpu_baseline"] = cpu_baseline(model=args.model, fixed=args.fixed_curvature)
+    line["configs_summary"] = configs_summary(line)  # LAST: the tail of stdout carries every config's number
     emit(line)
     if dist_on:
         dist.barrier()

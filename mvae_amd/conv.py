@@ -11,8 +11,9 @@ kernel reads the activation directly (`mvae_conv_k4s2p1_nhwc`, `..._wgrad`), no 
 wrote and re-read 16x the activation for each of them: ~2 GB of HBM traffic per step at B = 256).  Where it SCATTERS
 (ConvTranspose2d forward, Conv2d backward-data) the contraction writes a patch matrix that `mvae_col2im_k4s2p1` folds
 (<= 4 terms per output, no atomics) or runs as four implicit contractions, one per output parity class, whichever measured
-faster for the layer.  The 3-channel NCHW boundary layers keep explicit patch matrices (48 wide) except the forward of d3, a
-direct kernel (`mvae_convt_to3_k4s2p1_forward`).  Between the last encoder and the first decoder convolution the latent
+faster for the layer.  The 3-channel NCHW boundary layers (e0, d3) have no patch matrix either: their kernels read the image
+straight into MFMA fragments (csrc/mvae_edge.hip), and the forward of d3 runs inside the loss-end launch
+(`mvae_convt_to3_bce_stats`).  Between the last encoder and the first decoder convolution the latent
 section (flatten -> heads -> components -> decoder fc) is two fused launches each way (`mvae_conv_latent_forward /
 _backward`), the loss end (BCE, statistics, d3.bias) one (`mvae_conv_bce_stats`).  Parameters, gradients and optimizer
 state live in flat buffers laid out like StepEngine's (first 64 floats = radii), so the optimizer is the same streaming

@@ -755,7 +755,8 @@ struct P3Post { const float* part; float* out; int64_t n; int slices; bool defer
 static thread_local bool g_p3_group = false;
 static thread_local int g_p3_nq = 0, g_p3_npost = 0;
 static thread_local P3Queued g_p3_q[2];
-static thread_local P3Post g_p3_post[2];
+constexpr int kP3PostMax = 4;  // a pair queues at most: the weight gradient's slice sum + the data gradient's slice sum + a column sum
+static thread_local P3Post g_p3_post[kP3PostMax];
 
 template <int BM, int BN, int WR, int AF, int BF, bool KALT>
 static void p3_single(const P3Args& a, dim3 grid, hipStream_t s) {
@@ -771,7 +772,7 @@ static void p3_submit(const P3Args& a, dim3 grid, hipStream_t s) {
 }
 // the immediate slice sum of a split-K backward-data result: after the (possibly queued) launch that writes the slices
 static void p3_sum_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
-  if (g_p3_group && g_p3_npost < 2) {
+  if (g_p3_group && g_p3_npost < kP3PostMax) {
     g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, false, nullptr};
     return;
   }
@@ -779,7 +780,7 @@ static void p3_sum_after(const float* part, float* out, int64_t n, int slices, h
 }
 // a deferrable slice sum (final gradients: bias column sums) of a result whose launch may still be queued
 static void p3_sum_deferrable_after(const float* part, float* out, int64_t n, int slices, hipStream_t s) {
-  if (g_p3_group && g_p3_npost < 2) {
+  if (g_p3_group && g_p3_npost < kP3PostMax) {
     g_p3_post[g_p3_npost++] = P3Post{part, out, n, slices, true, nullptr};
     return;
   }
@@ -795,7 +796,7 @@ static void p3_launch_pair(const P3Queued& w, const P3Queued& d, hipStream_t s) 
 void p3_colsum_deferrable(const float* G, float* out, int64_t M, int N, float* ws, hipStream_t s);  // mvae_conv.hip
 // the (deferrable) column sum of per-tile partial sums [rows, n] whose launch may still be queued
 static void p3_colsum_after(float* part, float* out, int64_t rows, int n, float* ws, hipStream_t s) {
-  if (g_p3_group && g_p3_npost < 2) {
+  if (g_p3_group && g_p3_npost < kP3PostMax) {
     g_p3_post[g_p3_npost++] = P3Post{part, out, n, (int)rows, true, ws};
     return;
   }
@@ -1066,7 +1067,9 @@ extern "C" int mvae_conv_k4s2p1_nhwc_wgrad_p3(const uint16_t* dy_planes, int64_t
   a.C = slices > 1 ? workspace : dWt; a.ldc = NQ; a.Cp = nullptr; a.mask = nullptr;
   a.M = OC; a.N = NQ; a.K = (int)M; a.k_per_slice = kps; a.slice_stride = n;
   launch_p3<128, 128, 2, A_KM, B_G2>(a, slices, (hipStream_t)stream);
-  if (slices > 1) p3_sum_slices(workspace, dWt, n, slices, (hipStream_t)stream);
+  // inside mvae_p3_group(1) the contraction above is only QUEUED: its slice sum joins the group's post queue (and runs, or is
+  // deferred, after group(0) has launched the contraction) -- summed right here it would read the workspace before it is written
+  if (slices > 1) p3_sum_deferrable_after(workspace, dWt, n, slices, (hipStream_t)stream);
   LAUNCH_CHECK("plane weight gradient launch");
   return 0;
 }

@@ -4,9 +4,11 @@ New functionality (the reference is single-device).  Sampl
 parameters and the loss is a batch SUM (stats.py:200-202), so:
   * batch rows are split contiguously across ranks (`shard_rows`), every rank draws / receives its own eps rows;
   * parameters, optimizer state and radii are replicated;
-  * ONE exchange per step, in two buckets: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2).
-    The fc_logits half of the buffer is final one launch before the rest, so its all-reduce is issued there and travels
-    while the last backward launch runs; then every rank applies the identical optimizer step;
+  * ONE exchange per step: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2) as ONE bucket
+    on the default route (librccl directly on the step's stream, mvae_amd/rccl.py), after the last backward launch;
+    then every rank applies the identical optimizer step.  (The torch.distributed route -- the agreed fall-back, and
+    MVAE_DP_EXCHANGE=allreduce -- splits it in two buckets by default (MVAE_DP_OVERLAP): the fc_logits half of the buffer is
+    final one launch before the rest, so its all-reduce is issued there and travels while the last backward launch runs);
   * the epoch >= 10 gate and the radius warm-up are functions of the epoch only: no communication;
   * statistics are summed across ranks only when somebody reads them (`reduce_stats`).
 `engine` is anything with `.grads` (flat tensor), `.stats`, `forward_backward(x, eps, beta)` and
@@ -154,6 +156,12 @@ class DataParallelStep:
         if self.world == 1:
             return self.group
         if dist.get_backend(self.group) == "nccl":
+            return self.group
+        # dist.new_group must be entered by EVERY rank of the default group: on a proper sub-group only its members are
+        # here, so a new group is not attempted (the members would hang in new_group) -- the sub-group itself is used
+        if self.group is not None and self.group is not dist.group.WORLD and \
+                dist.get_world_size(self.group) != dist.get_world_size():
+            self.exchange_note += "; all_reduce on the caller's sub-group (a new RCCL group needs every rank of the world)"
             return self.group
         ok, g = True, None
         try:

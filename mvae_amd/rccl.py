@@ -38,7 +38,7 @@ class RcclUnavailable(RuntimeError):
 
 
 def _fake_failure(stage: str, rank: int) -> bool:
-    """MVAE_FAKE_RCCL_INIT_FAILURE=<stage>[:<rank>] (stage: load | create | warmup; "1" = load; without a rank: every rank)
+    """MVAE_FAKE_RCCL_INIT_FAILURE=<stage>[:<rank>] (stage: load | id | create | warmup; "1" = load; without a rank: every rank)
     makes that stage fail here -- the test hook of the agreed fall-back."""
     v = os.environ.get("MVAE_FAKE_RCCL_INIT_FAILURE", "")
     if v in ("", "0"):
@@ -77,10 +77,14 @@ class FlatAllReduce:
 
         stage("load", lambda: check(load().mvae_rccl_load(_rccl_path())))
         ident = [None]
-        if self.rank == 0:
-            buf = (C.c_uint8 * ID_BYTES)()
-            check(load().mvae_rccl_unique_id(buf))
-            ident[0] = bytes(buf)
+
+        def draw_id():  # rank 0 only; a failure here is agreed like any other stage BEFORE anybody enters the broadcast
+            if self.rank == 0:
+                buf = (C.c_uint8 * ID_BYTES)()
+                check(load().mvae_rccl_unique_id(buf))
+                ident[0] = bytes(buf)
+
+        stage("id", draw_id)
         if self.world > 1:
             dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
 

@@ -98,6 +98,10 @@ def main(argv=None) -> None:
     if args.doubles:
         if world > 1 or args.architecture != "ff":
             raise SystemExit("--doubles=True (float64 latent chain) is built for the single-device ff architecture")
+        too_big = [f"{type(c).__name__}({c.true_dim})" for c in model.components if c.true_dim > 8]
+        if too_big:  # mvae_component_forward_f64 / _backward_f64 keep a component's vectors in registers: true dim <= 8
+            raise SystemExit("--doubles=True: the float64 latent chain is built for components of true dimension <= 8; "
+                             f"this model has {', '.join(too_big)} (run with --doubles=False)")
         model.float64_chain = True
     if world > 1:
         model.enable_data_parallel()

@@ -52,6 +52,19 @@ def test_bench_line_schema():
     ep = d["configs"]["epoch_pipeline"]
     assert "error" not in ep, ep
     assert ep["value"] > 1000 and ep["steps"] == ep["epochs"] * ep["steps_per_epoch"] and "in_step_preparation=True" in ep["workload"]
+    # median of 5 timed repeats of exactly --steps steps; the first repeat is reported beside it
+    assert d["config"]["timed_repeats"] == 5 and len(d["config"]["repeat_ms_per_step"]["all"]) == 5
+    rp = d["config"]["repeat_ms_per_step"]
+    assert rp["min"] <= rp["median"] <= rp["max"] and abs(rp["median"] - d["ms_per_step"]) < 1e-9
+    # scope row f-1 as a leg of its own, and the compact summary as the LAST key of the line (what a truncated tail keeps)
+    ll = d["configs"]["loglik"]
+    assert "error" not in ll and ll["ms_per_batch"] > 0 and 0 < ll["roofline"]["frac"] < 1, ll
+    assert list(d)[-1] == "configs_summary"
+    cs = d["configs_summary"]
+    assert len(json.dumps(cs)) <= 700, len(json.dumps(cs))
+    for key in ("h2s2e2", "e6", "prod36", "conv", "conv_f32_mfma", "conv_split", "epoch_pipeline", "loglik"):
+        assert cs[key] is not None and cs[key][0] > 0, (key, cs)
+    assert abs(cs["h2s2e2"][0] - d["value"]) < 0.06 and cs["timed_repeats"] == 5
 
 
 def test_bench_forced_exchange_route():

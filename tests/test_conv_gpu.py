@@ -1042,6 +1042,18 @@ def test_plane_contractions_vs_float64(dev, case):
         from mvae_amd._lib import load
         load().mvae_slice_sums_flush(torch.cuda.current_stream().cuda_stream)
         close(out, ref, case)
+        # the same weight gradient QUEUED inside mvae_p3_group(1) with slice-sum deferral OFF: its split-K slice sum must wait for
+        # group(0), which launches the contraction -- summed at submit time it would read the workspace before it is written
+        from mvae_amd._lib import check
+        from mvae_amd.conv import _p3_group
+        check(load().mvae_slice_sums_defer(0))
+        out2 = torch.full_like(out, float("nan"))
+        nws = int(load().mvae_conv_k4s2p1_nhwc_wgrad_p3_workspace_floats(B, Cc, IH, IH, OC))
+        assert nws > 0, "the case must exercise the split-K form"
+        with _p3_group(dev):
+            _conv_nhwc_wgrad_p3(_planes_of(dyl), _planes_of(src), out2, B, Cc, IH)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out), "a grouped weight gradient summed its slices before they were written"
 
 
 @pytest.mark.parametrize("B", [5, 256])
