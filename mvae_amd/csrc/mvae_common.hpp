@@ -440,6 +440,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the row's total): four DPP adds
+__device__ __forceinline__ float row16_sum(float v) {
+  int x = __float_as_int(v);
+#define MV_DPP_ADD(CTRL)                                                                                \
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true)));
+  MV_DPP_ADD(0xB1)   // quad_perm [1,0,3,2]
+  MV_DPP_ADD(0x4E)   // quad_perm [2,3,0,1]
+  MV_DPP_ADD(0x141)  // row_half_mirror
+  MV_DPP_ADD(0x140)  // row_mirror
+#undef MV_DPP_ADD
+  return __int_as_float(x);
+}
+
 // the value of the neighbouring lane (lane ^ 1): one DPP quad_perm [1,0,3,2], no LDS crossbar
 __device__ __forceinline__ float lane_swap1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -619,6 +632,296 @@ __device__ __forceinline__ void job_tn_wave(const float* P, int ldp, int NP, int
       }
   }
   MV_STAMP_B(18, MV_STAMP_BLK);
+}
+
+// ---- FRAGMENT-ORDER copies of the batch-contraction operands (g, hd, dh, x: the dW tiles of launches 5 and 6).
+// A row-major operand T[B][N] makes a wave-level request of the dW tile (4 rows x 16 columns of 4 bytes) touch four 64-byte
+// HALVES of 128-byte lines, 64 such requests per tile.  The fragment-order copy TF holds, for column tile nt and row block mb,
+// one contiguous 1 KB block in the order the MFMA wants it:
+//     TF[((nt * MB + mb) * 64 + q * 16 + i) * 4 + t] = T[16 mb + 4 q + t][16 nt + i]        (MB = B / 16)
+// so that lane (i, q) reads ONE 16-byte vector per row block -- four consecutive batch rows of its column, i.e. the A / B
+// values of four MFMA steps -- and a wave-level request is 1 KB of whole lines: 16 requests per tile instead of 64.  The
+// copies are written by the producers INSTEAD of the row-major tensor where every consumer can read fragment order (hd, dhd),
+// next to it where one cannot (h), or by spare workgroups (x: the padding workgroups of launch 1's grid).
+__host__ __device__ inline size_t frag_off(int m, int n, int MB) {
+  return ((size_t)((n >> 4) * MB + (m >> 4)) << 8) + (size_t)(((((m & 15) >> 2) << 4) + (n & 15)) << 2) + (size_t)(m & 3);
+}
+
+// dW tile per WAVE from fragment-order operands (+ optional Adam): out[p][q] = sum_m P[m][p] Q[m][q], the output mapping of
+// job_tn_wave (lane l: out[p0 + (l & 15)][q0 + 4 (l >> 4) + 0..3], one 16-byte access per lane for g / p / m / v).
+// Lanes whose output row is >= NP or whose columns reach past NQ load nothing of p / m / v and store nothing: a ragged last
+// tile (dW_heads: NP = heads_dim; dW_d0: NQ = z_dim) costs no branch in the contraction.  ldo % 4 != 0 (z_dim 6, 2): the
+// lane's outputs move as scalars.  PROW != NULL: P is read ROW-MAJOR (ld = ldp) in the fragment order's row sequence -- four
+// 4-byte requests per row block instead of one 16-byte one -- for an operand that has no fragment-order copy.
+// COLSUM: the wave also delivers cs_out[16 pt + i] = sum_m P[m][16 pt + i] (+ Adam on cs_aa) -- the bias gradient that goes
+// with the weight gradient's P operand -- from the fragments it holds anyway.
+template <bool ADAM, bool COLSUM = false>
+__device__ __forceinline__ void job_tn_frag_any(const float* PF, const float* PROW, int ldp, int pt, int NP, const float* QF,
+                                                int qt, int NQ, int MB, float* out, int ldo, const AdamArgs& aa,
+                                                float* cs_out = nullptr, const AdamArgs cs_aa = AdamArgs{}) {
+  if (qt * 16 >= NQ) return;
+  MV_STAMP_B(16, MV_STAMP_BLK);
+  const int lane = threadIdx.x & 63;
+  const int pr = pt * 16 + (lane & 15), qc0 = qt * 16 + ((lane >> 4) << 2);
+  const bool vec = (ldo & 3) == 0;  // uniform
+  const bool ok = pr < NP && (vec ? qc0 + 3 < NQ : qc0 < NQ);
+  const size_t idx = ok ? (size_t)pr * ldo + qc0 : 0;
+  const f32x4* qa = reinterpret_cast<const f32x4*>(QF) + ((size_t)qt * MB << 6) + lane;
+  const f32x4* pb = reinterpret_cast<const f32x4*>(PF) + ((size_t)pt * MB << 6) + lane;
+  const float* prow = PROW + (size_t)(4 * (lane >> 4)) * ldp + (pr < NP ? pr : 0);
+  f32x4 av[8], bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {  // (clamped: MB >= 1; blocks past MB are masked below)
+    const int cc = c < MB ? c : 0;
+    av[c] = qa[(size_t)cc << 6];
+    if (PROW) {
+      const float* r0 = prow + (size_t)(16 * cc) * ldp;
+      bv[c] = f32x4{r0[0], r0[(size_t)ldp], r0[2 * (size_t)ldp], r0[3 * (size_t)ldp]};
+    } else {
+      bv[c] = pb[(size_t)cc << 6];
+    }
+  }
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
+  float neg_step = 0.f, bc2s = 1.f;
+  if (ADAM) {
+    if (vec) {
+      p0 = *reinterpret_cast<const f32x4*>(aa.p + idx);
+      m0 = *reinterpret_cast<const f32x4*>(aa.m + idx);
+      v0 = *reinterpret_cast<const f32x4*>(aa.v + idx);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t ir = (ok && qc0 + r < NQ) ? idx + r : 0;
+        p0[r] = aa.p[ir];
+        m0[r] = aa.m[ir];
+        v0[r] = aa.v[ir];
+      }
+    }
+    neg_step = reinterpret_cast<const float*>(aa.counters)[2];  // {-lr/bc1, sqrt(bc2)} of this step (launch 1)
+    bc2s = reinterpret_cast<const float*>(aa.counters)[3];
+  }
+  float cp = 0.f, cm = 0.f, cv = 0.f;  // COLSUM: the bias entry of this lane's P column (lanes 0..15 finish it)
+  if (COLSUM && ADAM) {
+    const int col = pr < NP ? pr : 0;
+    cp = cs_aa.p[col];
+    cm = cs_aa.m[col];
+    cv = cs_aa.v[col];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, cs4 = acc;
+  for (int c0 = 0;;) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c0 + c < MB) {  // uniform
+        if (COLSUM) cs4 += bv[c];
+        acc = mfma16(av[c][0], bv[c][0], acc);
+        acc2 = mfma16(av[c][1], bv[c][1], acc2);
+        acc = mfma16(av[c][2], bv[c][2], acc);
+        acc2 = mfma16(av[c][3], bv[c][3], acc2);
+      }
+    }
+    c0 += 8;
+    if (c0 >= MB) break;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cc = c0 + c < MB ? c0 + c : 0;
+      av[c] = qa[(size_t)cc << 6];
+      if (PROW) {
+        const float* r0 = prow + (size_t)(16 * cc) * ldp;
+        bv[c] = f32x4{r0[0], r0[(size_t)ldp], r0[2 * (size_t)ldp], r0[3 * (size_t)ldp]};
+      } else {
+        bv[c] = pb[(size_t)cc << 6];
+      }
+    }
+  }
+  acc += acc2;
+  MV_STAMP_B(17, MV_STAMP_BLK);
+  if (COLSUM) {
+    float cs = (cs4[0] + cs4[1]) + (cs4[2] + cs4[3]);  // rows 4 q + t of every block; then the four row quads q
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 32);
+    if (lane < 16 && pr < NP) {
+      cs_out[pr] = cs;
+      if (ADAM) {
+        adam1(cp, cs, cm, cv, neg_step, bc2s);
+        cs_aa.p[pr] = cp;
+        cs_aa.m[pr] = cm;
+        cs_aa.v[pr] = cv;
+      }
+    }
+  }
+  if (ADAM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pp = p0[r], mm = m0[r], vv = v0[r];
+      adam1(pp, acc[r], mm, vv, neg_step, bc2s);
+      p0[r] = pp;
+      m0[r] = mm;
+      v0[r] = vv;
+    }
+  }
+  if (ok && vec) {
+    store16_wt(out, idx, acc);  // write-through, see job_tn_wave
+    if (ADAM) {
+      store16_wt(aa.p, idx, p0);
+      store16_wt(aa.m, idx, m0);
+      store16_wt(aa.v, idx, v0);
+    }
+  } else if (ok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (qc0 + r < NQ) {
+        out[idx + r] = acc[r];
+        if (ADAM) {
+          aa.p[idx + r] = p0[r];
+          aa.m[idx + r] = m0[r];
+          aa.v[idx + r] = v0[r];
+        }
+      }
+  }
+  MV_STAMP_B(18, MV_STAMP_BLK);
+}
+template <bool ADAM>
+__device__ __forceinline__ void job_tn_frag(const float* PF, int pt, int NP, const float* QF, int qt, int NQ, int MB,
+                                            float* out, int ldo, const AdamArgs& aa) {
+  job_tn_frag_any<ADAM>(PF, nullptr, 0, pt, NP, QF, qt, NQ, MB, out, ldo, aa);
+}
+template <bool ADAM>
+__device__ __forceinline__ void job_tn_halffrag(const float* Prow, int ldp, int pt, int NP, const float* QF, int qt, int NQ,
+                                                int MB, float* out, int ldo, const AdamArgs& aa) {
+  job_tn_frag_any<ADAM>(Prow, Prow, ldp, pt, NP, QF, qt, NQ, MB, out, ldo, aa);
+}
+
+// The same tile job in two phases, for a wave that runs TWO independent tiles (the small weight gradients of launch 6):
+// request() issues every load of a tile, finish() multiplies and stores; with both tiles requested first the second one's
+// memory round trip hides behind the first instead of following it.  Whole fragments only (MB <= 8).
+template <bool ADAM, bool COLSUM>
+struct FragJob {
+  f32x4 av[8], bv[8], p0, m0, v0;
+  float cp, cm, cv, neg_step, bc2s;
+  size_t idx;
+  int pr, qc0;
+  bool ok, vec, live;
+  __device__ __forceinline__ void request(const float* PF, int pt, int NP, const float* QF, int qt, int NQ, int MB, int ldo,
+                                          const AdamArgs& aa, const AdamArgs& cs_aa) {
+    const int lane = threadIdx.x & 63;
+    live = qt * 16 < NQ && pt * 16 < NP;  // uniform
+    pr = pt * 16 + (lane & 15);
+    qc0 = qt * 16 + ((lane >> 4) << 2);
+    vec = (ldo & 3) == 0;
+    ok = live && pr < NP && (vec ? qc0 + 3 < NQ : qc0 < NQ);
+    idx = ok ? (size_t)pr * ldo + qc0 : 0;
+    const f32x4* qa = reinterpret_cast<const f32x4*>(QF) + ((size_t)(live ? qt : 0) * MB << 6) + lane;
+    const f32x4* pb = reinterpret_cast<const f32x4*>(PF) + ((size_t)(live ? pt : 0) * MB << 6) + lane;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cc = c < MB ? c : 0;
+      av[c] = qa[(size_t)cc << 6];
+      bv[c] = pb[(size_t)cc << 6];
+    }
+    p0 = m0 = v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    neg_step = 0.f;
+    bc2s = 1.f;
+    cp = cm = cv = 0.f;
+    if (ADAM) {
+      if (vec) {
+        p0 = *reinterpret_cast<const f32x4*>(aa.p + idx);
+        m0 = *reinterpret_cast<const f32x4*>(aa.m + idx);
+        v0 = *reinterpret_cast<const f32x4*>(aa.v + idx);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t ir = (ok && qc0 + r < NQ) ? idx + r : 0;
+          p0[r] = aa.p[ir];
+          m0[r] = aa.m[ir];
+          v0[r] = aa.v[ir];
+        }
+      }
+      neg_step = reinterpret_cast<const float*>(aa.counters)[2];
+      bc2s = reinterpret_cast<const float*>(aa.counters)[3];
+      if (COLSUM) {
+        const int col = (live && pr < NP) ? pr : 0;
+        cp = cs_aa.p[col];
+        cm = cs_aa.m[col];
+        cv = cs_aa.v[col];
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(int NP, int NQ, int MB, float* out, const AdamArgs& aa, float* cs_out,
+                                         const AdamArgs& cs_aa) {
+    if (!live) return;
+    const int lane = threadIdx.x & 63;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, cs4 = acc;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < MB) {  // uniform
+        if (COLSUM) cs4 += bv[c];
+        acc = mfma16(av[c][0], bv[c][0], acc);
+        acc2 = mfma16(av[c][1], bv[c][1], acc2);
+        acc = mfma16(av[c][2], bv[c][2], acc);
+        acc2 = mfma16(av[c][3], bv[c][3], acc2);
+      }
+    }
+    acc += acc2;
+    if (COLSUM) {
+      float cs = (cs4[0] + cs4[1]) + (cs4[2] + cs4[3]);
+      cs += __shfl_xor(cs, 16);
+      cs += __shfl_xor(cs, 32);
+      if (lane < 16 && pr < NP) {
+        cs_out[pr] = cs;
+        if (ADAM) {
+          adam1(cp, cs, cm, cv, neg_step, bc2s);
+          cs_aa.p[pr] = cp;
+          cs_aa.m[pr] = cm;
+          cs_aa.v[pr] = cv;
+        }
+      }
+    }
+    if (ADAM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pp = p0[r], mm = m0[r], vv = v0[r];
+        adam1(pp, acc[r], mm, vv, neg_step, bc2s);
+        p0[r] = pp;
+        m0[r] = mm;
+        v0[r] = vv;
+      }
+    }
+    if (ok && vec) {
+      store16_wt(out, idx, acc);
+      if (ADAM) {
+        store16_wt(aa.p, idx, p0);
+        store16_wt(aa.m, idx, m0);
+        store16_wt(aa.v, idx, v0);
+      }
+    } else if (ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (qc0 + r < NQ) {
+          out[idx + r] = acc[r];
+          if (ADAM) {
+            aa.p[idx + r] = p0[r];
+            aa.m[idx + r] = m0[r];
+            aa.v[idx + r] = v0[r];
+          }
+        }
+    }
+  }
+};
+
+// x [B][N] -> its fragment-order copy, one column tile per workgroup (any block size that is a multiple of 64): thread
+// (block c, lane (i, q)) gathers its four batch rows and stores one 16-byte vector.
+__device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, int MB, float* TF) {
+  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  for (int c = threadIdx.x >> 6; c < MB; c += (int)(blockDim.x >> 6)) {
+    const float* src = T + (size_t)(16 * c + 4 * q) * ld + 16 * nt + i;
+    f32x4 v;
+    v[0] = src[0];
+    v[1] = src[(size_t)ld];
+    v[2] = src[2 * (size_t)ld];
+    v[3] = src[3 * (size_t)ld];
+    store16_wt(TF, (((size_t)(nt * MB + c) << 6) + lane) << 2, v);  // read by a later launch only
+  }
 }
 
 // bias gradient (+ optional Adam): out[c] = sum_m Gm[m][c] for 16 columns; any block size that is a multiple of 16

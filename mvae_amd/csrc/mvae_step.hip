@@ -34,6 +34,9 @@ struct mvae_ctx {
   int ldz;    // z row stride
   // workspace carve (floats)
   int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_dirtab, o_total;
+  int64_t o_hdF, o_xF, o_hF, o_dhdF, o_zF, o_dheadsF;  // fragment-order operands of the lite backward (mvae_common.hpp: frag_off)
+  int64_t o_dzp, o_dheads16, o_whF;  // [B][H/16][8] partial dz products of launch 4's tiles; dheads as [B][16] (zero-padded); W_heads snapshot
+  bool no_lite;                      // MVAE_NO_LITE=1: the fused-forward shapes keep the round-4 backward launches (A/B measurements)
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
   bool no_fwd23;         // MVAE_NO_FWD23=1: keep launches 2 and 3 separate (A/B measurements)
   GroupTable gt;         // component groups of the 16-row block kernels (mvae_step_blk.hpp)
@@ -80,6 +83,15 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   // whether or not they are trainable right now)
   c->o_duals = take(B * ((int64_t)d.heads_dim + d.ncomp) * dual_stride(dmax_bucket));
   c->o_dirtab = take(4 * (int64_t)kBlkDirs);  // int4 per active input direction (k_latent_bwd_blk)
+  c->o_hdF = take(B * H);
+  c->o_xF = take(B * D);
+  c->o_hF = take(B * H);
+  c->o_dhdF = take(B * H);
+  c->o_zF = take(B * 16);
+  c->o_dheadsF = take(B * 16);  // one 16-column tile each
+  c->o_dzp = take(B * (int64_t)c->nt_h * 8);
+  c->o_dheads16 = take(B * 16);
+  c->o_whF = take((int64_t)c->nt_h * 256);
   c->o_total = o;
 }
 
@@ -156,6 +168,8 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->blk_small = bs && bs[0] && bs[0] != '0';
   const char* bf = getenv("MVAE_BLK_FWD");
   c->blk_fwd = !(bf && bf[0] == '0');
+  const char* nl = getenv("MVAE_NO_LITE");
+  c->no_lite = nl && nl[0] && nl[0] != '0';
   c->groups_ok = build_groups(c->t, &c->gt);
   const char* nc = getenv("MVAE_NO_COOP");
   c->coop = bucket_of(c->dmax) > 8 && coop_eligible(c->t) && !(nc && nc[0] && nc[0] != '0');
@@ -193,7 +207,7 @@ extern "C" int mvae_debug_read_spans(unsigned long long* out /* [6][3][2048] */)
 // ---- 1: encoder layer (512 threads).  In the fused single-GPU step, workgroup (0,0) also advances the step counter.
 template <bool FULL>
 __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W, const float* b, float* h, int B, int H,
-                                                 int D, int* counters, int bump_step, double lr) {
+                                                 int D, int* counters, int bump_step, double lr, float* xF, float* hF) {
   __shared__ float red[kW8][16][17];
   const int wave = threadIdx.x >> 6;
   int mt, nt;
@@ -214,7 +228,16 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
       reinterpret_cast<float*>(counters)[3] = (float)sqrt(bc2);
     }
   }
-  if (!real) return;
+  if (!real) {
+    // The padding workgroups of the XCD-aware grid have a CU each and nothing to do: they write the fragment-order copy of x
+    // that launch 6's dW_e0 tiles contract with (xF != NULL only when the grid has padding workgroups).
+    if (xF) {
+      const int NT = (H + 15) / 16, MT = (B + 15) / 16;
+      const int npad = (8 * ((NT + 7) / 8) - NT) * MT;
+      for (int j = (nt - NT) * MT + mt; j < (D >> 4); j += npad) job_frag_copy(x, D, j, B >> 4, xF);
+    }
+    return;
+  }
   const bool vx = aligned16(x) && (D & 3) == 0, vw = aligned16(W) && (D & 3) == 0;
   // the epilogue's operand is requested with the tile operands (clamped address, no branch): asked for after the
   // contraction it costs the epilogue a memory round trip of its own
@@ -228,6 +251,7 @@ __global__ __launch_bounds__(512) void k_enc_fwd(const float* x, const float* W,
     if (FULL || (m < B && n < H)) {
       const float v = s + bias;
       h[(size_t)m * H + n] = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+      if (hF) hF[frag_off(m, n, B >> 4)] = v < 0.f ? 0.f : v;  // fragment order: launch 6 (dh's ReLU mask, dW_heads tiles)
     }
   }
   MV_SPAN_END(0, 1);
@@ -593,7 +617,8 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
                                                const float* bd0, const float* Wl, const float* bl, const float* x,
                                                float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
                                                float* kl_user, float* hd, float* g, float* bce_part,
-                                               float* logits_user, int B, int H, int D, int NH, int Z, float* duals) {
+                                               float* logits_user, int B, int H, int D, int NH, int Z, float* duals, float* zF,
+                                               float* hdF) {
   // dynamic LDS: hd_s[16][ld] | wl_s[32][ld] | wd_s[H][8] | bd_s[H]     (ld = H + 4: conflict-free ds_read_b128 of the
   // 16 rows an MFMA operand fetch touches)
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -897,6 +922,11 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   lds_barrier();
   MV_T(4);
   if (lead && z_user && tid < 16 * Z) z_user[((size_t)mt * 16 + tid / Z) * Z + tid % Z] = z_s[tid / Z][tid % Z];
+  if (lead && zF && tid < 64) {  // z in fragment order (one 16-column tile, zero past Z): launch 6's dW_d0 tiles
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < 8) v = f32x4{z_s[4 * q][i], z_s[4 * q + 1][i], z_s[4 * q + 2][i], z_s[4 * q + 3][i]};  // z_s is zero past Z
+    store16_wt(zF, ((size_t)mt * 64 + tid) << 2, v);
+  }
 
   // ---- hd = relu(z W_d0^T + b) as MFMA tiles (K = 8: two 16x16x4 steps per 16 columns), kept in LDS as the A operand
   // of the output layer.  A[i][k] = z[i][k] (zero past Z): lane (i, q) supplies k = q and q + 4.
@@ -923,7 +953,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   }
   lds_barrier();
   MV_T(5);
-  if (lead) {  // launches 4 and 5 read hd (ReLU mask, operand of dW_logits): coalesced 16-byte rows
+  if (lead && !hdF) {  // launches 4 and 5 read hd (ReLU mask, operand of dW_logits): coalesced 16-byte rows
     for (int e4 = tid; e4 < 4 * H; e4 += 512) {
       const int r = e4 / (H >> 2), c4 = e4 - r * (H >> 2);
       *reinterpret_cast<float4*>(hd + ((size_t)mt * 16 + r) * H + 4 * c4) =
@@ -952,6 +982,17 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     }
   }
   MV_T(6);
+  if (lead && hdF) {
+    // hd leaves in FRAGMENT ORDER only (launch 4 reads its ReLU mask element-wise, launch 5's dW_logits tiles read whole
+    // fragments): position (q', i') of the block of (column tile, this row block) = rows 4 q' .. 4 q' + 3 of column i'
+    const int MB = B >> 4;
+    for (int e = tid; e < (H >> 4) * 64; e += 512) {
+      const int tile = e >> 6, pos = e & 63, ii = pos & 15, qq = pos >> 4;
+      const float* src = hd_s + (4 * qq) * ld + tile * 16 + ii;
+      const f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
+      reinterpret_cast<f32x4*>(hdF)[((size_t)(tile * MB + mt) << 6) + pos] = v;
+    }
+  }
   // both partial tiles go to LDS under one barrier; threads 0..255 add up the first tile, 256..511 the second
   float sv;
   {
@@ -1067,6 +1108,19 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
 constexpr int kDhdGroup = MV_DHD_GROUP;  // adjacent 16-column tiles of W_logits owned by one XCD (see xcd_tile_g)
 // DUAL > 0 (fused step): the first n_dual workgroups compute the forward-mode dual records of the latent components
 // (job_duals<DUAL>), one thread per (row, input direction).
+// fragment-order copies produced inside launch 4: hd (by the dhd tile that reads it as its ReLU mask) and x (n_xf short jobs)
+struct FragArgs {
+  float* hdF;
+  float* dhdF;
+  const float* x;
+  float* xF;
+  int n_xf;  // > 0 only when launch 1's grid has no padding workgroups to do it
+  // the "lite" backward of the fused-forward shapes (dzp != NULL): hd arrives in fragment order (hdF is an INPUT), dhd leaves
+  // in fragment order only, and every dhd tile adds its share of dz = dhd W_d0 as a partial product dzp[row][tile][0..7]
+  float* dzp;
+  const float* Wd0;
+  int Z;
+};
 struct DualArgs {
   const float* heads;
   const float* eps;
@@ -1074,11 +1128,11 @@ struct DualArgs {
   float* duals;
   int ldh, eps_ld, NH, n_dual;
 };
-template <bool ADAM, bool FULL, int DUAL>
+template <bool ADAM, bool FULL, int DUAL, bool LITE = false>
 __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
-                                                  int n_db, AdamArgs ab, DualArgs da, FeedArgs fd) {
+                                                  int n_db, AdamArgs ab, DualArgs da, FeedArgs fd, FragArgs fr) {
   __shared__ float red[kW8][16][17];
   // Workgroup order: the short jobs first (statistics, bias column sums, padded to a multiple of 8 so that the tile
   // workgroups keep L % 8 == XCD), then the dhd tiles.  The grid is larger than the chip: workgroups dispatched last
@@ -1087,7 +1141,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
   const int n_dual = DUAL > 0 ? da.n_dual : 0;
-  const int n_short = (n_dual + 1 + n_db + fd.n_wg + 7) & ~7;
+  const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + 7) & ~7;
   MV_SPAN_BEGIN(3);
   if (DUAL > 0 && b < n_dual) {  // the longest chains of the launch: dispatched first, ONE wave per workgroup (= per CU)
     if (threadIdx.x < 64)
@@ -1104,12 +1158,51 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     const int wave = threadIdx.x >> 6;
     const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
     const bool ok = threadIdx.x < 256 && m < B && n < H;
-    const float mask = hd[(size_t)(m < B ? m : 0) * H + (n < H ? n : 0)];  // branch-free request, used in the epilogue
+    constexpr bool lite = LITE;  // FULL shapes only
+    // branch-free request, used in the epilogue
+    const float mask = *(lite ? fr.hdF + frag_off(m, n, B >> 4) : hd + (size_t)(m < B ? m : 0) * H + (n < H ? n : 0));
+    f32x4 wz0 = {0.f, 0.f, 0.f, 0.f}, wz1 = wz0;  // lite: W_d0[n][0..7] (zero past Z), the thread's share of dz
+    if (lite) {
+      const float* wr = fr.Wd0 + (size_t)n * fr.Z;
+      if (fr.Z == 8) {
+        wz0 = *reinterpret_cast<const f32x4*>(wr);
+        wz1 = *reinterpret_cast<const f32x4*>(wr + 4);
+      } else if (fr.Z == 4) {
+        wz0 = *reinterpret_cast<const f32x4*>(wr);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = wr[j < fr.Z ? j : 0], b2 = wr[j + 4 < fr.Z ? j + 4 : 0];
+          wz0[j] = j < fr.Z ? a : 0.f;
+          wz1[j] = j + 4 < fr.Z ? b2 : 0.f;
+        }
+      }
+    }
     const bool vg = aligned16(g) && (D & 3) == 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = tile_nn<7, FULL>(g, D, B, mt * 16, W, H, H, nt * 16, D, wave, kW8, vg, acc);
     const float s = reduce_tiles8(red, acc);
-    if (ok) dhd[(size_t)m * H + n] = (mask > 0.f) ? s : 0.f;
+    const float dv = (mask > 0.f) ? s : 0.f;
+    if (lite) {
+      if (threadIdx.x < 256) {
+        fr.dhdF[frag_off(m, n, B >> 4)] = dv;  // launch 6: dW_d0 tiles and the b_d0 column sums
+        // this tile's share of dz[m][j] = sum_n dhd[m][n] W_d0[n][j]: the 16 lanes of a row add up over n (DPP row sums)
+        f32x4 p0 = dv * wz0, p1 = dv * wz1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          p0[j] = row16_sum(p0[j]);
+          p1[j] = row16_sum(p1[j]);
+        }
+        if ((threadIdx.x & 15) == 0) {
+          f32x4* dst = reinterpret_cast<f32x4*>(fr.dzp + ((size_t)m * ntH + nt) * 8);
+          dst[0] = p0;
+          dst[1] = p1;
+        }
+      }
+      MV_SPAN_END(3, 1);
+      return;
+    }
+    if (ok) dhd[(size_t)m * H + n] = dv;
     MV_SPAN_END(3, 1);
     return;
   }
@@ -1122,6 +1215,8 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       const unsigned cursor = (unsigned)fd.counters[8];
       const int n = feed_items(fd);
       for (int i = fb * (int)blockDim.x + (int)threadIdx.x; i < n; i += fd.n_wg * (int)blockDim.x) feed_item(fd, cursor, i);
+    } else if (fb - fd.n_wg < fr.n_xf) {
+      job_frag_copy(fr.x, D, fb - fd.n_wg, B >> 4, fr.xF);  // x in fragment order for launch 6's dW_e0 tiles
     }
     return;  // (the rest: padding)
   }
@@ -1724,6 +1819,359 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
   }
 }
 
+
+// ================================================================== the "lite" backward of the fused-forward shapes
+// Launches 5 and 6 for models on the fused forward (NH <= 16, Z <= 8, B <= 256).  What the row path of k_latent_bwd did per
+// batch row -- load a row of dhd and W_d0 for dz, load W_heads and the row of h for dh = (dheads W_heads)[h > 0] -- was ~4.5
+// us of memory round trips behind ~130 wave-level requests per workgroup.  Here:
+//   * dz arrives as 25 partial products per row from launch 4's tiles (k_dec1_bwd, FragArgs::dzp) and is a fixed-order sum;
+//   * dh is never written: each dW_e0 workgroup of launch 6 rebuilds the fragments of dh it contracts with -- the MFMA
+//     D = dheads[16 rows][16] W_heads[16][16 columns], whose output lane layout IS the B-operand fragment of the weight-gradient
+//     MFMA -- masks them with h's fragment-order copy and shares them through LDS (their column sums are b_e0's gradient);
+//   * every batch contraction reads fragment-order operands (mvae_common.hpp: frag_off).
+// ---- 5': one WAVE per batch row: dz (sum of the partials) -> contraction with the dual records -> dheads; dW_logits tiles
+template <int DMAX, bool ADAM>
+__global__ __launch_bounds__(64 * kTileWaves) void k_latent_bwd2(CompTable t, const float* dzp, int ntH, int ldh, float* dheads,
+                                                     float* dheads16, float* dheadsF, float* drpart, const float* g,
+                                                     const float* hdF, float* dWl, float beta, int B, int H,
+                                                     int D, int NH, int Z, int n_rowwg, AdamArgs awl, const float* duals,
+                                                     const float* Wh, float* whF, int n_snap) {
+  __shared__ mvae_component_desc desc_s[kMaxComp];
+  __shared__ int doff_s[kMaxComp + 1];
+  __shared__ int first_s[kMaxComp + 1];
+  __shared__ float dz_s[kTileWaves][8];
+  __shared__ float dh_s[kTileWaves][16];
+  int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  MV_SPAN_BEGIN(4);
+  if (b < n_snap) {  // (dispatched FIRST: at the end of the grid their requests queued behind everybody's, launch 5 +1 us)
+    // Launch 6 rebuilds dh = dheads W_heads while its dW_heads tiles update W_heads in place: it reads THIS launch's snapshot,
+    // laid out as the B fragments of that product: whF[(pt * 64 + q * 16 + i) * 4 + t] = W_heads[4 q + t][16 pt + i] (0 past NH)
+    for (int e = b * 64 * kTileWaves + tid; e < (H >> 4) * 256; e += n_snap * 64 * kTileWaves) {
+      const int pt = e >> 8, ln = (e & 255) >> 2, n = 4 * (ln >> 4) + (e & 3);
+      const float v = Wh[(size_t)(n < NH ? n : 0) * H + pt * 16 + (ln & 15)];
+      whF[e] = n < NH ? v : 0.f;
+    }
+    return;
+  }
+  b -= n_snap;
+  if (b >= n_rowwg) {  // dW_logits[D, H] tiles, one per wave
+    b -= n_rowwg;
+    // five-wave workgroups: 49 x 5 = 245 of them for the BASELINE shapes, which with the row workgroups is about one per CU
+    // (a tile workgroup that shares its CU with another one finishes ~1 us late: 343 four-wave ones ended at 3.4 / 4.6 us)
+    const int ntHg = ((H >> 4) + kTileWaves - 1) / kTileWaves;
+    const int pt = fast_div(b, ntHg), qg = b - pt * ntHg;
+    // P = g read row-major in the fragments' row order (a second, fragment-order copy of g cost the forward launch more than
+    // these tiles gained), Q = hd in fragment order: 40 wave-level requests per tile instead of 64
+    job_tn_halffrag<ADAM>(g, D, pt, D, hdF, qg * kTileWaves + wave, H, B >> 4, dWl, H, awl);
+    MV_SPAN_END(4, 2);
+    return;
+  }
+  const int row = b * kTileWaves + wave;
+  MV_STAMP(8);
+  // requests first: the row's 25 x 8 partials (lanes 0..ntH-1: two 16-byte vectors each), then the tables
+  f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(dzp + ((size_t)(row < B ? row : 0) * ntH + (lane < ntH ? lane : 0)) * 8);
+    const f32x4 a = src[0], c2 = src[1];
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane < ntH) {
+      pa = a;
+      pb = c2;
+    }
+  }
+  // this lane's dual record (written by the forward launch): lane k owns the k-th active direction of the row.  Its
+  // component is found with a UNIFORM loop over the kernarg table (scalar loads, per-lane selects), so that the request
+  // travels with the partials above instead of behind the LDS tables.  (Measured: taking the whole descriptor through that
+  // loop -- no LDS tables, no barriers -- made the launch 1 us SLOWER: the scalar loads of the kernarg table are a dependent
+  // chain in front of everything else.)
+  constexpr int DS = DMAX + 2;
+  const int total = t.dir_off[t.n];
+  float du[DS];
+  int my_ci = 0, my_dir = 0;
+  {
+    const int gi = lane < total ? lane : 0;
+    int first = 0;
+    for (int ci = 0; ci < t.n; ++ci) {
+      const int lo = t.dir_off[ci], hi = t.dir_off[ci + 1];
+      const bool in = gi >= lo && gi < hi;
+      my_ci = in ? ci : my_ci;
+      my_dir = in ? gi - lo : my_dir;
+      first = in ? (int)t.first_dir[ci] : first;
+    }
+    const float* rec = duals + ((size_t)(row < B ? row : 0) * (NH + t.n) + first + my_dir) * DS;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) du[i] = rec[i];
+  }
+  if (tid <= t.n) {
+    if (tid < t.n) desc_s[tid] = t.c[tid];
+    doff_s[tid] = t.dir_off[tid];
+    first_s[tid] = t.first_dir[tid < t.n ? tid : 0];
+  }
+  if (lane < 16) dh_s[wave][lane] = 0.f;
+  lds_barrier();
+  MV_STAMP(9);
+  // dz[j] = sum over the column tiles, in DPP-tree order (the same tree every step: deterministic)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pa[j] = wave_sum(pa[j]);
+    pb[j] = wave_sum(pb[j]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dz_s[wave][j] = pa[j];
+      dz_s[wave][4 + j] = pb[j];
+    }
+  }
+  lds_barrier();
+  MV_STAMP(10);
+  // d(loss)/d(direction) = beta * d kl + <dz, d z>
+  for (int gi = lane; gi < total && row < B; gi += 64) {
+    if (gi >= 64) {
+      my_ci = 0;
+      while (gi >= doff_s[my_ci + 1]) ++my_ci;
+      my_dir = gi - doff_s[my_ci];
+      const float* rec = duals + ((size_t)row * (NH + t.n) + first_s[my_ci] + my_dir) * DS;
+#pragma unroll
+      for (int i = 0; i < DS; ++i) du[i] = rec[i];
+    }
+    const mvae_component_desc& c = desc_s[my_ci];
+    const int A = ambient_dim(c.kind, c.true_dim);
+    float gv = beta * du[0];
+#pragma unroll
+    for (int i = 0; i < DMAX + 1; ++i)
+      if (i < A) gv += dz_s[wave][c.z_col + i] * du[1 + i];
+    if (my_dir < c.true_dim) dh_s[wave][c.mean_col + my_dir] = gv;
+    else if (my_dir < c.true_dim + c.logvar_dim) dh_s[wave][c.logvar_col + (my_dir - c.true_dim)] = gv;
+    else drpart[(size_t)my_ci * B + row] = gv;
+  }
+  lds_barrier();
+  MV_STAMP(11);
+  if (lane < 16 && row < B) {
+    const float v = dh_s[wave][lane];  // zero past NH
+    if (lane < NH) dheads[(size_t)row * ldh + lane] = v;
+    dheads16[(size_t)row * 16 + lane] = v;          // A operand of launch 6's dh fragments
+    dheadsF[frag_off(row, lane, B >> 4)] = v;       // P operand of launch 6's dW_heads tiles
+  }
+  MV_STAMP(12);
+  MV_SPAN_END(4, 1);
+}
+
+// ---- 6': dW_e0 (+ b_e0) from rebuilt dh fragments, dW_heads, dW_d0, b_heads, b_d0 (+Adam) ; radius gradients (+SGD)
+// MBT = 8 (B <= 128) or 16 (B <= 256): row blocks held per lane
+template <bool ADAM, int MBT>
+__global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd2(CompTable t, const float* xF, const float* hF,
+                                                  const float* dheads16, const float* dheadsF, const float* dheads, int ldh,
+                                                  const float* whF, const float* dhdF, const float* zF, const float* drpart,
+                                                  float* G, float* P, int B, int H, int D, int NH, int Z, int n_small,
+                                                  int heads_on_idle, int64_t off_w_e0, int64_t off_b_e0, int64_t off_w_heads,
+                                                  int64_t off_b_heads, int64_t off_w_d0, int64_t off_b_d0, AdamArgs base,
+                                                  double curv_lr, int do_curv) {
+  __shared__ float red[4][16][17];
+  __shared__ f32x4 frag_s[MBT][64];  // the masked dh fragments of this workgroup's 16 columns, all row blocks
+  int b = blockIdx.x;
+  const int MB = B >> 4;
+  MV_SPAN_BEGIN(5);
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
+  // Grid: 1 + n_small + tiles workgroups = 1 + 5 + 250 for the BASELINE shapes: exactly one per CU.
+  if (b == 0) {  // radius gradients (+ SGD) as in k_enc_bwd, then b_heads
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* gsh = &red[0][0][0];
+    if (tid < kRadiiRegion) {
+      G[tid] = 0.f;
+      gsh[tid] = 0.f;
+    }
+    __syncthreads();
+    for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
+      if (!t.trainable[ci]) continue;
+      float s = 0.f;
+      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
+      s = wave_sum(s);
+      if (lane == 0) gsh[ci] = s;
+    }
+    __syncthreads();
+    if (tid < t.n && t.trainable[tid]) {
+      float s = gsh[tid];
+      if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
+      G[tid] = s;
+      if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
+    }
+    __syncthreads();
+    job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, 0, G + off_b_heads, at(off_b_heads));  // NH <= 16: one block
+    MV_SPAN_END(5, 7);
+    return;
+  }
+  b -= 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (b < n_small) {
+    // wave w, column tile tl = 5 b + w of H: the dW_d0 tile [16 rows tl, Z] = dhd^T z with b_d0's 16 entries (the column sums
+    // of its dhd fragments) and the dW_heads tile [NH, 16 columns tl] = dheads^T h; fragment-order operands.  (As two jobs
+    // one after the other these waves were the tail of the launch, 5.6 us; as ten workgroups the grid no longer fit one
+    // workgroup per CU and the last tile workgroups dispatched ended at 5.2 us.)
+    const int tl = b * kTileWaves + wave;
+    if (tl * 16 < H) {
+      if (heads_on_idle) {  // (dW_heads rides on the idle waves of the tile workgroups)
+        job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
+                                    at(off_b_d0));
+      } else if (MBT == 8) {  // both tiles requested before either is multiplied: the second round trip hides behind the first
+        FragJob<ADAM, true> j0;
+        FragJob<ADAM, false> j1;
+        const AdamArgs a0 = at(off_w_d0), b0 = at(off_b_d0), a1 = at(off_w_heads);
+        j0.request(dhdF, tl, H, zF, 0, Z, MB, Z, a0, b0);
+        j1.request(dheadsF, 0, NH, hF, tl, H, MB, H, a1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        j0.finish(H, Z, MB, G + off_w_d0, a0, G + off_b_d0, b0);
+        j1.finish(NH, H, MB, G + off_w_heads, a1, nullptr, a1);
+      } else {
+        job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
+                                    at(off_b_d0));
+        job_tn_frag<ADAM>(dheadsF, 0, NH, hF, tl, H, MB, G + off_w_heads, H, at(off_w_heads));
+      }
+    }
+    MV_SPAN_END(5, 3);
+    return;
+  }
+  b -= n_small;
+  {  // dW_e0[H, D] = dh^T x ; b_e0 = column sums of dh ; on the idle wave of a tile row: its dW_heads tile
+    const int ntDg = ((D >> 4) + kTileWaves - 1) / kTileWaves;
+    const int pt = fast_div(b, ntDg), qg = b - pt * ntDg;
+    const int qt = qg * kTileWaves + wave;
+    const bool have = qt * 16 < D;  // wave-uniform
+    const int i = lane & 15, q = lane >> 4;
+    // (uniform) the last tile group of a row of tiles has idle waves when D / 16 is not a multiple of 5.  The first of them
+    // adds up b_e0 for the workgroup's 16 columns and multiplies the dW_heads tile of those columns, dheads^T h: its Q
+    // operand is h's fragment (the same requests as a tile wave's x fragments, another base), its P operand dheads' one.
+    const bool idle_wave = heads_on_idle && !have && qt == (D >> 4);
+    // (on the idle wave, next to its dW_heads tile, the launch took 5.7 us against 5.2)
+    const bool bias_wave = qg == 0 && wave == 0;
+    // ---- requests.  First this wave's share of the dh fragments' operands (the workgroup meets on them): A = dheads16 rows
+    // of row blocks c = wave, wave + 5, ... (16 bytes per lane), B = W_heads[4 q + t][p0 + i] from launch 5's snapshot (this
+    // launch's dW_heads tiles update W_heads in place), mask = h's fragment.
+    constexpr int kPer = (MBT + kTileWaves - 1) / kTileWaves;
+    f32x4 da[kPer], hm[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      const int cc = c < MB ? c : 0;
+      da[u] = *reinterpret_cast<const f32x4*>(dheads16 + ((size_t)(16 * cc + i) << 4) + (q << 2));
+      hm[u] = reinterpret_cast<const f32x4*>(hF)[((size_t)(pt * MB + cc) << 6) + lane];
+    }
+    const f32x4 wb = reinterpret_cast<const f32x4*>(whF)[((size_t)pt << 6) + lane];  // launch 5's snapshot of W_heads
+    // the idle wave's P operand (the only requests behind a branch: the block ends with a wait for everything requested so
+    // far, which is exactly what the fragment phase below needs anyway)
+    f32x4 dv[MBT];
+#pragma unroll
+    for (int c = 0; c < MBT; ++c) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idle_wave) {
+#pragma unroll
+      for (int c = 0; c < MBT; ++c) dv[c] = reinterpret_cast<const f32x4*>(dheadsF)[((size_t)(c < MB ? c : 0) << 6) + lane];
+    }
+    // Q operand and optimizer state, branch-free: tile wave = x's fragments of column tile qt and W_e0's tile (pt, qt);
+    // idle wave = h's fragments of column tile pt and W_heads' tile (0, pt)
+    const bool ok = idle_wave ? i < NH : have;
+    const size_t idx = idle_wave ? (size_t)(i < NH ? i : 0) * H + pt * 16 + (q << 2)
+                                 : (size_t)(pt * 16 + i) * D + (have ? qt : 0) * 16 + (q << 2);
+    const int64_t woff = idle_wave ? off_w_heads : off_w_e0;
+    const f32x4* qa = reinterpret_cast<const f32x4*>(idle_wave ? hF : xF) + ((size_t)(idle_wave ? pt : (have ? qt : 0)) * MB << 6) + lane;
+    f32x4 av[MBT];
+#pragma unroll
+    for (int c = 0; c < MBT; ++c) av[c] = qa[(size_t)(c < MB ? c : 0) << 6];
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
+    float neg_step = 0.f, bc2s = 1.f;
+    const int bcol = pt * 16 + i;
+    float bp = 0.f, bm = 0.f, bvv = 0.f;
+    if (ADAM) {
+      p0 = *reinterpret_cast<const f32x4*>(base.p + woff + idx);
+      m0 = *reinterpret_cast<const f32x4*>(base.m + woff + idx);
+      v0 = *reinterpret_cast<const f32x4*>(base.v + woff + idx);
+      neg_step = reinterpret_cast<const float*>(base.counters)[2];
+      bc2s = reinterpret_cast<const float*>(base.counters)[3];
+      // (every wave requests the bias column: under `if (bias_wave)` the compiler ends the block with a wait for ALL
+      // outstanding requests -- a full memory round trip in front of the fragment phase the five waves meet on)
+      bp = base.p[off_b_e0 + bcol];
+      bm = base.m[off_b_e0 + bcol];
+      bvv = base.v[off_b_e0 + bcol];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      if (c < MB) {  // uniform
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = mfma16(da[u][0], wb[0], d);
+        d = mfma16(da[u][1], wb[1], d);
+        d = mfma16(da[u][2], wb[2], d);
+        d = mfma16(da[u][3], wb[3], d);
+        // lane (column i, rows 4 q + r of block c): exactly the fragment position (q, i); ReLU mask from h
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = hm[u][r] > 0.f ? d[r] : 0.f;
+        frag_s[c][lane] = d;
+      }
+    }
+    lds_barrier();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, csum = acc;
+#pragma unroll
+    for (int c = 0; c < MBT; ++c) {
+      if (c < MB) {  // uniform
+        f32x4 bv = frag_s[c][lane];
+        if (bias_wave) csum += bv;
+        if (idle_wave) bv = dv[c];  // dheads' fragment instead of dh's
+        if (have || idle_wave) {
+          acc = mfma16(av[c][0], bv[0], acc);
+          acc2 = mfma16(av[c][1], bv[1], acc2);
+          acc = mfma16(av[c][2], bv[2], acc);
+          acc2 = mfma16(av[c][3], bv[3], acc2);
+        }
+      }
+    }
+    acc += acc2;
+    if (bias_wave) {
+      // b_e0[p0 + i] = sum over all rows of dh[:, p0 + i]: the lane's 4 MB values, then the four row quads q
+      float tsum = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+      tsum += __shfl_xor(tsum, 16);
+      tsum += __shfl_xor(tsum, 32);
+      if (lane < 16) {
+        const int col = pt * 16 + lane;
+        G[off_b_e0 + col] = tsum;
+        if (ADAM) {  // (lanes 0..15: q == 0, so col == bcol)
+          adam1(bp, tsum, bm, bvv, neg_step, bc2s);
+          base.p[off_b_e0 + col] = bp;
+          base.m[off_b_e0 + col] = bm;
+          base.v[off_b_e0 + col] = bvv;
+        }
+      }
+    }
+    if (have || idle_wave) {
+      if (ADAM) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pp = p0[r], mm = m0[r], vv = v0[r];
+          adam1(pp, acc[r], mm, vv, neg_step, bc2s);
+          p0[r] = pp;
+          m0[r] = mm;
+          v0[r] = vv;
+        }
+      }
+      if (ok) {
+        store16_wt(G + woff, idx, acc);
+        if (ADAM) {
+          store16_wt(base.p + woff, idx, p0);
+          store16_wt(base.m + woff, idx, m0);
+          store16_wt(base.v + woff, idx, v0);
+        }
+      }
+    }
+    MV_SPAN_END(5, 1);
+  }
+}
+
 // ---- 7 (data-parallel / two-call path only): fused optimizer over the flat buffer after the gradient all-reduce
 // PEER: the gradient is the sum of the ranks' published slots (mvae_peer.hip), added in rank order -- the same
 // floating-point sum on every rank -- and written to g like an all-reduced .grad.
@@ -1902,14 +2350,24 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
   const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
                     aligned16(P + d.off_w_logits) && aligned16(ws);
+  // The "lite" backward (k_latent_bwd2 / k_enc_bwd2, fragment-order operands): fused-forward shapes with B <= 256.
+  // MVAE_NO_LITE=1: the round-4 launches (A/B measurements).
+  const bool lite = full && !c->no_lite && latent_path(c, aligned16(x)) == MVAE_PATH_FUSED && !uses_blk_bwd(c, aligned16(x)) &&
+                    fast_b && NH <= 16 && Z <= 8 && B <= 256;
+  float *hdF = lite ? ws + c->o_hdF : nullptr, *xF = lite ? ws + c->o_xF : nullptr, *hF = lite ? ws + c->o_hF : nullptr,
+        *dhdF = lite ? ws + c->o_dhdF : nullptr, *zF = lite ? ws + c->o_zF : nullptr,
+        *dheadsF = lite ? ws + c->o_dheadsF : nullptr;
+  // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
+  const bool xf_in_l1 = lite && (c->nt_h & 7) != 0;
+  float *dzp = ws + c->o_dzp, *dheads16 = ws + c->o_dheads16, *whF = ws + c->o_whF;
   if (parts & MVAE_STEP_HEAD) {  // launches 1-5
   ki = 0;
   if (full)
     STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
-                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr, xf_in_l1 ? xF : nullptr, hF);
   else
     STEP_LAUNCH(k_enc_fwd<false>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
-                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr);
+                P + d.off_b_e0, h, B, H, D, d.step_count, fused ? 1 : 0, (double)d.lr, nullptr, nullptr);
   // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
   const int path = latent_path(c, aligned16(x));
   const bool fwd23 = path == MVAE_PATH_FUSED, blk = path == MVAE_PATH_BLOCK;
@@ -1931,7 +2389,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b + MV_PREFETCH_WGS), dim3(512), lds, c->t, h, P + d.off_w_heads,  \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
-              NH, Z, duals)
+              NH, Z, duals, zF, hdF)
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
@@ -2001,11 +2459,16 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
-    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + 7) & ~7;
-#define DB(AD, FU, DU)                                                                                         \
-  STEP_LAUNCH((k_dec1_bwd<AD, FU, DU>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits,     \
+    const FragArgs fr = {hdF, dhdF, x, xF, (lite && !xf_in_l1) ? c->nt_d : 0, lite ? dzp : nullptr, P + d.off_w_d0, Z};
+    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + 7) & ~7;
+#define DBX(AD, FU, DU, LI)                                                                                    \
+  STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
-              at(d.off_b_logits), da, fd)
+              at(d.off_b_logits), da, fd, fr)
+#define DB(AD, FU, DU) DBX(AD, FU, DU, false)
+    if (lite) {
+      if (fused) DBX(true, true, 0, true); else DBX(false, true, 0, true);
+    } else
     if (fwd23 && duals_in_l4) {  // full && dmax bucket in {2, 4, 8}
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) DB(true, true, 2); else if (bk == 4) DB(true, true, 4); else DB(true, true, 8); }
@@ -2013,6 +2476,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     } else if (fused) { if (full) DB(true, true, 0); else DB(true, false, 0); }
     else { if (full) DB(false, true, 0); else DB(false, false, 0); }
 #undef DB
+#undef DBX
   }
   {
     ki = 4;
@@ -2023,7 +2487,18 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
-    if (uses_blk_bwd(c, aligned16(x))) {
+    if (lite) {
+      const int n_snap = 4;  // W_heads snapshot workgroups (1600 floats each for H = 400)
+      const int n_rowwg = (B + kTileWaves - 1) / kTileWaves, n_tiles = c->nt_d * ((c->nt_h + kTileWaves - 1) / kTileWaves);
+#define LB2(DM, AD)                                                                                                  \
+  STEP_LAUNCH((k_latent_bwd2<DM, AD>), dim3(n_snap + n_rowwg + n_tiles), dim3(64 * kTileWaves), 0, c->t, dzp, c->nt_h, c->ldh, dheads,     \
+              dheads16, dheadsF, drpart, g, hdF, G + d.off_w_logits, beta, B, H, D, NH, Z, n_rowwg,               \
+              at(d.off_w_logits), duals, P + d.off_w_heads, whF, n_snap)
+      const int bk = bucket_of(c->dmax);
+      if (fused) { if (bk == 2) LB2(2, true); else if (bk == 4) LB2(4, true); else LB2(8, true); }
+      else { if (bk == 2) LB2(2, false); else if (bk == 4) LB2(4, false); else LB2(8, false); }
+#undef LB2
+    } else if (uses_blk_bwd(c, aligned16(x))) {
       const int n_blk = c->nt_b * ((H + 63) / 64);
       const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
       const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
@@ -2053,12 +2528,25 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
+    if (lite) {
+      const int n_small = (c->nt_h + tw - 1) / tw;
+      const int grid2 = 1 + n_small + n_we0;
+#define EB2(AD, MBT)                                                                                                 \
+  STEP_LAUNCH((k_enc_bwd2<AD, MBT>), dim3(grid2), dim3(64 * kTileWaves), 0, c->t, xF, hF, dheads16, dheadsF, dheads,  \
+              c->ldh, whF, dhdF, zF, drpart, G, P, B, H, D, NH, Z, n_small, (c->nt_d % tw) != 0 ? 1 : 0, d.off_w_e0, d.off_b_e0, d.off_w_heads,    \
+              d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+      if (fused) { if (B <= 128) EB2(true, 8); else EB2(true, 16); }
+      else { if (B <= 128) EB2(false, 8); else EB2(false, 16); }
+#undef EB2
+    } else
 #define EB(AD, FU)                                                                                                   \
   STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(64 * kTileWaves), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz, \
                      drpart, G, P, B, H, D, NH, Z, n_we0, n_wh, n_wd0, n_be0, n_bh, n_bd0, d.off_w_e0, d.off_b_e0,   \
                      d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+    {
     if (fused) { if (full) EB(true, true); else EB(true, false); }
     else { if (full) EB(false, true); else EB(false, false); }
+    }
 #undef EB
   }
 #undef STEP_LAUNCH

@@ -479,6 +479,54 @@ def test_fused_step_matches_oracle_other_batch_sizes(dev):
             assert_close(_cpu(t), orc.P[n].detach().numpy(), RTOL, f"param {n} B={B}")
 
 
+@pytest.mark.parametrize("model,B,H,D", [("h2,s2,e2", 128, 400, 784), ("h2,s2,e2", 256, 400, 784), ("e6", 128, 400, 784),
+                                         ("e2", 128, 400, 784), ("p2,u2", 128, 400, 784), ("h2,s2,e2", 128, 512, 784),
+                                         ("h2,s2,e2", 128, 400, 800), ("s2,h2", 256, 128, 96)])
+def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkeypatch):
+    """The "lite" backward of the fused-forward shapes (csrc/mvae_step.hip: k_latent_bwd2 / k_enc_bwd2 -- dz from the partial
+    products of launch 4's tiles, dh rebuilt per weight-gradient workgroup from a snapshot of W_heads, every batch contraction
+    on fragment-order operands) against the oracle (1e-4) and against the round-4 launches (MVAE_NO_LITE=1: same sums in another
+    order, 2e-5 of each tensor's scale), for: the BASELINE shapes, B = 256 (two fragment batches), z_dim 6 / 2 (scalar
+    epilogues), z_dim 4, H = 512 (launch 1's grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle
+    wave in a row of tiles: the small weight gradients share their waves), a small model; fused single-call step and the
+    gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False)
+    ncomp = len(spec.components)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    xs = synthetic.binary_batches(3, B, D)
+    eps = synthetic.eps_batches(3, B, spec.total_true_dim)
+    orc = M.StepOracle(spec, state0)
+    for k in range(3):
+        ref = orc.train_step(xs[k], eps[k], beta=0.7, epoch=12)
+    res = {}
+    for mode in ("lite", "round4"):
+        if mode == "round4":
+            monkeypatch.setenv("MVAE_NO_LITE", "1")
+        eng = StepEngine([(c.letter, c.true_dim) for c in spec.components], D, H, dev, radius_trainable=[True] * ncomp)
+        eng.load_state(state0)
+        for k in range(3):
+            eng.train_step(xs[k].to(dev), eps[k].to(dev), 0.7, True)
+        torch.cuda.synchronize()
+        res[mode] = ({n: _cpu(t).copy() for n, t in eng.param_views().items()}, _cpu(eng.grads).copy(),
+                     eng.read_stats()["last"]["elbo"])
+        # gradients-only call (the data-parallel route) from the same state
+        eng2 = StepEngine([(c.letter, c.true_dim) for c in spec.components], D, H, dev, radius_trainable=[True] * ncomp)
+        eng2.load_state(state0)
+        eng2.forward_backward(xs[0].to(dev), eps[0].to(dev), 0.7)
+        res[mode] += (_cpu(eng2.grads).copy(),)
+    assert_close(res["lite"][2], float(ref.elbo), 2e-4, "elbo after 3 steps")
+    for n, v in res["lite"][0].items():
+        if n.endswith("radius") or n.endswith("curvature"):  # SGD on a batch-summed gradient: plain relative bar
+            assert_close(v, orc.P[n].detach().numpy(), 2e-4, f"param {n} after 3 lite steps vs oracle")
+            continue
+        assert_close_after_adam(v, orc.P[n].detach().numpy(), 1e-3, 3, f"param {n} after 3 lite steps vs oracle")
+        assert_close_after_adam(v, res["round4"][0][n], 1e-3, 3, f"param {n}: lite vs round-4 launches")
+    assert_close(res["lite"][3], res["round4"][3], 2e-5, "gradients-only call: lite vs round-4 launches", atol_frac=2e-5)
+
+
 @pytest.mark.parametrize("model,H,D,B", [("3h2,s3,e2,p3,d2,u2,e2", 128, 96, 32), ("5e3,h4,2s2,e6", 64, 48, 16),
                                          ("4e2,h3", 64, 48, 16),
                                          ("6h2,6s2,6e2", 400, 784, 128)])

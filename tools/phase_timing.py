@@ -43,6 +43,13 @@ for i in range(N):
             continue
         t0 = min(st[i] for i in used)
         bounds.append((t0, max(en[i] for i in used)))
+        if L == 5 and i == N - 1:  # the latest tile workgroups of launch 6 (which ones are the tail?)
+            tiles = [j for j in used if kd[j] == 1]
+            if tiles:
+                j0 = min(tiles)
+                late = sorted(tiles, key=lambda j: -en[j])[:12]
+                print("launch 6: latest tile workgroups (index - first tile index, end ns):",
+                      [(j - j0, (en[j] - t0) * 10) for j in late])
         for kind in sorted(set(kd[i] for i in used)):
             ends = sorted((en[i] - t0) * 10 for i in used if kd[i] == kind)
             starts = sorted((st[i] - t0) * 10 for i in used if kd[i] == kind)
