@@ -523,7 +523,9 @@ def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkey
             assert_close(v, orc.P[n].detach().numpy(), 2e-4, f"param {n} after 3 lite steps vs oracle")
             continue
         assert_close_after_adam(v, orc.P[n].detach().numpy(), 1e-3, 3, f"param {n} after 3 lite steps vs oracle")
-        assert_close_after_adam(v, res["round4"][0][n], 1e-3, 3, f"param {n}: lite vs round-4 launches")
+        # (two float32 evaluations with different summation orders, three Adam steps apart: where a gradient entry is rounding
+        # noise the update's sign follows the noise -- a few 1e-4 of the entries may sit a step apart)
+        assert_close_after_adam(v, res["round4"][0][n], 1e-3, 3, f"param {n}: lite vs round-4 launches", bad_frac=2e-3)
     assert_close(res["lite"][3], res["round4"][3], 2e-5, "gradients-only call: lite vs round-4 launches", atol_frac=2e-5)
 
 
