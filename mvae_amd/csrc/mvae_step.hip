@@ -89,7 +89,7 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   c->o_dhdF = take(B * H);
   c->o_zF = take(B * 16);
   c->o_dheadsF = take(B * 16);  // one 16-column tile each
-  c->o_dzp = take(B * (int64_t)c->nt_h * 8);
+  c->o_dzp = take(B * (int64_t)c->nt_h * 64);  // [B][H/16][8] (lite) | [B/16][H/16][z tiles <= 4][64][4] (block backward)
   c->o_dheads16 = take(B * 16);
   c->o_whF = take((int64_t)c->nt_h * 256);
   c->o_total = o;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) void k_duals_coop(CompTable t, const float* he
 // row block (nt == mt mod ntD: spread over the XCDs) writes what later launches need: heads, z, kl, hd.
 // Forward-mode dual records for launch 5 are produced by extra workgroups of launch 4 (job_duals).
 // Preconditions (checked on the host): NH <= 16, Z <= 8, eps_dim <= 8, ncomp <= 8 with at most 4 components per wave,
-// H <= 512, B, H, D multiples of 16, 16-byte aligned operands.
+// H <= 416 (the staging of W_logits: kWl), B, H, D multiples of 16, 16-byte aligned operands.
 template <int DMAX>
 __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, const float* Wh, const float* bh,
                                                const float* eps, int eps_ld, const float* radii, const float* Wd0,
@@ -1128,7 +1128,10 @@ struct DualArgs {
   float* duals;
   int ldh, eps_ld, NH, n_dual;
 };
-template <bool ADAM, bool FULL, int DUAL, bool LITE = false>
+// LITE: 0 the round-4 launch; 1 the lite backward (z_dim <= 8: hd read / dhd written in fragment order, dz partials as
+// [row][tile][8] from per-thread products and DPP row sums); 2 the round-4 launch PLUS dz partials for the block backward
+// (z_dim <= 64): the partial of a tile is itself an MFMA product, stored in the MFMA's output order
+template <bool ADAM, bool FULL, int DUAL, int LITE = 0>
 __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
                                                   float* stats, float beta, int B, int H, int D, int ncomp, int n_dhd,
@@ -1158,10 +1161,20 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     const int wave = threadIdx.x >> 6;
     const int m = mt * 16 + ((threadIdx.x & 255) >> 4), n = nt * 16 + (threadIdx.x & 15);
     const bool ok = threadIdx.x < 256 && m < B && n < H;
-    constexpr bool lite = LITE;  // FULL shapes only
+    constexpr bool lite = LITE == 1;  // FULL shapes only
     // branch-free request, used in the epilogue
     const float mask = *(lite ? fr.hdF + frag_off(m, n, B >> 4) : hd + (size_t)(m < B ? m : 0) * H + (n < H ? n : 0));
     f32x4 wz0 = {0.f, 0.f, 0.f, 0.f}, wz1 = wz0;  // lite: W_d0[n][0..7] (zero past Z), the thread's share of dz
+    // LITE 2: wave w < ZT multiplies the masked dhd tile by W_d0[16 tile rows][16 z columns w]: B[k = 4 q + t][j = i]
+    float wzt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (LITE == 2) {
+      const int lane = threadIdx.x & 63, zc = 16 * wave + (lane & 15);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const float v = fr.Wd0[(size_t)(nt * 16 + 4 * (lane >> 4) + t4) * fr.Z + (zc < fr.Z ? zc : 0)];
+        wzt[t4] = zc < fr.Z ? v : 0.f;
+      }
+    }
     if (lite) {
       const float* wr = fr.Wd0 + (size_t)n * fr.Z;
       if (fr.Z == 8) {
@@ -1203,6 +1216,22 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       return;
     }
     if (ok) dhd[(size_t)m * H + n] = dv;
+    if (LITE == 2) {
+      __shared__ float dvs[16][17];
+      if (threadIdx.x < 256) dvs[threadIdx.x >> 4][threadIdx.x & 15] = dv;
+      lds_barrier();
+      const int ZT = (fr.Z + 15) >> 4;
+      if (wave < ZT) {  // uniform
+        const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, d2 = d;
+        d = mfma16(dvs[i][4 * q + 0], wzt[0], d);
+        d2 = mfma16(dvs[i][4 * q + 1], wzt[1], d2);
+        d = mfma16(dvs[i][4 * q + 2], wzt[2], d);
+        d2 = mfma16(dvs[i][4 * q + 3], wzt[3], d2);
+        // lane (z column j = i of tile w, rows 4 q + r): one 16-byte store per lane, [row block][tile][z tile][64][4]
+        reinterpret_cast<f32x4*>(fr.dzp)[((size_t)((mt * ntH + nt) * ZT + wave) << 6) + lane] = d + d2;
+      }
+    }
     MV_SPAN_END(3, 1);
     return;
   }
@@ -2282,8 +2311,10 @@ static int latent_path(const mvae_ctx* c, bool x_aligned) {
                     aligned16(P + d.off_w_logits) && aligned16(d.workspace);
   int max_slot = 0;
   for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
-  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for
-  if (fast && full && (B % 128 == 0) && (Z == 8 || Z == 4 || Z == 6 || Z == 2) && d.eps_dim <= 8 && d.ncomp <= 8 &&
+  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for.  H <= 416: its staging of the two
+  // W_logits row blocks is sized for 32 x 416 floats (kWl = 13 vectors per thread) -- up to round 4 wider layers (H <= 512)
+  // were let through and read LDS rows nobody had written
+  if (fast && full && H <= 416 && (B % 128 == 0) && (Z == 8 || Z == 4 || Z == 6 || Z == 2) && d.eps_dim <= 8 && d.ncomp <= 8 &&
       max_slot < 4 && aligned16(P + d.off_w_d0) &&
       bucket_of(c->dmax) <= 8 && !c->no_fwd23)
     return MVAE_PATH_FUSED;
@@ -2359,6 +2390,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
         *dheadsF = lite ? ws + c->o_dheadsF : nullptr;
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = lite && (c->nt_h & 7) != 0;
+  // the block backward (many small components) takes dz from partial products of launch 4's tiles too (z_dim 17 .. 64)
+  const bool dzp_blk = full && !c->no_lite && uses_blk_bwd(c, aligned16(x)) && Z > 16 && Z <= 64;
   float *dzp = ws + c->o_dzp, *dheads16 = ws + c->o_dheads16, *whF = ws + c->o_whF;
   if (parts & MVAE_STEP_HEAD) {  // launches 1-5
   ki = 0;
@@ -2459,15 +2492,17 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
-    const FragArgs fr = {hdF, dhdF, x, xF, (lite && !xf_in_l1) ? c->nt_d : 0, lite ? dzp : nullptr, P + d.off_w_d0, Z};
+    const FragArgs fr = {hdF, dhdF, x, xF, (lite && !xf_in_l1) ? c->nt_d : 0, (lite || dzp_blk) ? dzp : nullptr, P + d.off_w_d0, Z};
     const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
               at(d.off_b_logits), da, fd, fr)
-#define DB(AD, FU, DU) DBX(AD, FU, DU, false)
+#define DB(AD, FU, DU) DBX(AD, FU, DU, 0)
     if (lite) {
-      if (fused) DBX(true, true, 0, true); else DBX(false, true, 0, true);
+      if (fused) DBX(true, true, 0, 1); else DBX(false, true, 0, 1);
+    } else if (dzp_blk) {
+      if (fused) DBX(true, true, 0, 2); else DBX(false, true, 0, 2);
     } else
     if (fwd23 && duals_in_l4) {  // full && dmax bucket in {2, 4, 8}
       const int bk = bucket_of(c->dmax);
@@ -2505,7 +2540,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LBB(DM, AD, TT)                                                                                               \
   STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + c->nt_d * ntHg5), dim3(256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
               c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g, hd, G + d.off_w_logits, beta, B, H, D, NH, Z,       \
-              n_blk, at(d.off_w_logits), duals)
+              n_blk, at(d.off_w_logits), duals, dzp_blk ? dzp : nullptr)
 #define LBB2(DM, AD) do { if (Z <= 16) LBB(DM, AD, 1); else if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) LBB2(2, true); else if (bk == 4) LBB2(4, true); else LBB2(8, true); }

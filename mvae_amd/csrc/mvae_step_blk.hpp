@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
                                                         const float* Wd0, int ldh, const float* h, const float* Wh,
                                                         float* dheads, float* dh, float* drpart, const float* g,
                                                         const float* hd, float* dWl, float beta, int B, int H, int D,
-                                                        int NH, int Z, int n_blk, AdamArgs awl, const float* duals) {
+                                                        int NH, int Z, int n_blk, AdamArgs awl, const float* duals,
+                                                        const float* dzp) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // TT == 1: W_d0 [H][Z]
   __shared__ float red[4][4][16][17];  // [wave][interleaved tile][row][col]
   __shared__ __attribute__((aligned(16))) float dz_s[16][68];
@@ -481,6 +482,34 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
       }
     }
     acc[0] += acc[1];
+  } else if (dzp) {
+    // (uniform) dz arrives as H / 16 partial products per row block from launch 4's tiles (k_dec1_bwd, LITE 2), each a
+    // [16 rows][16 z columns] tile in the MFMA's output order: wave w adds the tiles nt = w, w + 4, ... of every z tile
+    // (fixed order), the four waves meet in `red` like the contraction they replace -- no K = H product over dhd and W_d0,
+    // whose operand requests alone took ~3 us to issue.
+    const int ZT = (Z + 15) >> 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(dzp) + ((size_t)(mt * nchunks) * ZT << 6) + lane;
+    for (int e = tid; e < 16 * (KC * 16 - NH); e += 256) {  // zero padding of the last chunk
+      const int w = KC * 16 - NH;
+      dheads_s[e / w][NH + e % w] = 0.f;
+    }
+    f32x4 pv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int nt = wave + 4 * u;
+#pragma unroll
+      for (int zt = 0; zt < 4; ++zt)
+        if (zt < TT) pv[u][zt] = src[(size_t)((nt < nchunks ? nt : 0) * ZT + (zt < ZT ? zt : 0)) << 6];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    MV_T(1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (wave + 4 * u < nchunks) {  // uniform
+#pragma unroll
+        for (int zt = 0; zt < 4; ++zt)
+          if (zt < TT) acc[zt] += pv[u][zt];
+      }
   } else {
   // a lane whose first column exists reads its TT columns even if the last ones lie past the row (they belong to the
   // next row / the padding after the matrix: finite or not, they only reach output columns >= Z, which nobody reads);
@@ -546,8 +575,9 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
   {
     const int r = tid >> 4, cj = tid & 15;
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)  // z column TT cj + tt
-      dz_s[r][TT * cj + tt] = (red[0][tt][r][cj] + red[1][tt][r][cj]) + (red[2][tt][r][cj] + red[3][tt][r][cj]);
+    for (int tt = 0; tt < TT; ++tt)  // z column TT cj + tt (the contraction's interleaved tiles) | 16 tt + cj (partial tiles)
+      dz_s[r][(TT > 1 && dzp) ? 16 * tt + cj : TT * cj + tt] =
+          (red[0][tt][r][cj] + red[1][tt][r][cj]) + (red[2][tt][r][cj] + red[3][tt][r][cj]);
   }
   lds_barrier();
   MV_T(3);

@@ -479,16 +479,44 @@ def test_fused_step_matches_oracle_other_batch_sizes(dev):
             assert_close(_cpu(t), orc.P[n].detach().numpy(), RTOL, f"param {n} B={B}")
 
 
+@pytest.mark.parametrize("H", [416, 448, 512])
+def test_wide_hidden_layer_vs_oracle(dev, H):
+    """h_dim above the reference's default: 416 is the widest layer the fused forward stages (k_fwd23: kWl), 448 / 512 take the
+    one-row-per-workgroup forward (up to round 4 they were let into the fused forward, which read LDS rows nobody had written:
+    ELBO and gradients were off by percents and differed from run to run)."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    B, D = 128, 784
+    spec = M.Spec("h2,s2,e2", in_dim=D, h_dim=H, fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, D)[0]
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+    eng = StepEngine([(c.letter, c.true_dim) for c in spec.components], D, H, dev, radius_trainable=[True] * 3)
+    eng.load_state(state0)
+    out = eng.forward_backward(x.to(dev), eps.to(dev), 0.7, want_outputs=True)
+    eng.optimizer_step(True)
+    assert_close(_cpu(out["bce"]), ref.bce.detach().numpy(), RTOL, f"bce H={H}")
+    assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, f"elbo H={H}")
+    for n, t in eng.param_views().items():
+        assert_close_after_adam(_cpu(t), orc.P[n].detach().numpy(), 1e-3, 1, f"param {n} H={H}")
+
+
 @pytest.mark.parametrize("model,B,H,D", [("h2,s2,e2", 128, 400, 784), ("h2,s2,e2", 256, 400, 784), ("e6", 128, 400, 784),
-                                         ("e2", 128, 400, 784), ("p2,u2", 128, 400, 784), ("h2,s2,e2", 128, 512, 784),
-                                         ("h2,s2,e2", 128, 400, 800), ("s2,h2", 256, 128, 96)])
+                                         ("e2", 128, 400, 784), ("p2,u2", 128, 400, 784), ("h2,s2,e2", 128, 384, 784),
+                                         ("h2,s2,e2", 128, 400, 800), ("s2,h2", 256, 128, 96),
+                                         ("6h2,6s2,6e2", 128, 400, 784), ("6h2,6s2,6e2", 256, 400, 784),
+                                         ("3h2,s3,e2,p3,d2,u2,e2", 32, 128, 96), ("5e3,h4,2s2,e6", 16, 64, 48)])
 def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkeypatch):
     """The "lite" backward of the fused-forward shapes (csrc/mvae_step.hip: k_latent_bwd2 / k_enc_bwd2 -- dz from the partial
     products of launch 4's tiles, dh rebuilt per weight-gradient workgroup from a snapshot of W_heads, every batch contraction
     on fragment-order operands) against the oracle (1e-4) and against the round-4 launches (MVAE_NO_LITE=1: same sums in another
     order, 2e-5 of each tensor's scale), for: the BASELINE shapes, B = 256 (two fragment batches), z_dim 6 / 2 (scalar
-    epilogues), z_dim 4, H = 512 (launch 1's grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle
-    wave in a row of tiles: the small weight gradients share their waves), a small model; fused single-call step and the
+    epilogues), z_dim 4, H = 384 (launch 1's grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle
+    wave in a row of tiles: the small weight gradients share their waves), a small model, and the block-forward shapes (many
+    small components, BASELINE config [3]: the round-4 launches with dz from partial MFMA tiles of launch 4); fused step and the
     gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
@@ -522,7 +550,10 @@ def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkey
         if n.endswith("radius") or n.endswith("curvature"):  # SGD on a batch-summed gradient: plain relative bar
             assert_close(v, orc.P[n].detach().numpy(), 2e-4, f"param {n} after 3 lite steps vs oracle")
             continue
-        assert_close_after_adam(v, orc.P[n].detach().numpy(), 1e-3, 3, f"param {n} after 3 lite steps vs oracle")
+        # (the projected components' steps are ill-conditioned: the round-4 launches sit as far from the oracle after three
+        # Adam steps -- 4.9 % of fc_e0.weight's entries beyond the bar for p2,u2 against 4.8 % here -- the two paths agree)
+        assert_close_after_adam(v, orc.P[n].detach().numpy(), 1e-3, 3, f"param {n} after 3 lite steps vs oracle",
+                                bad_frac=0.06 if ("p" in model or "u" in model or "d" in model) else 2e-3)
         # (two float32 evaluations with different summation orders, three Adam steps apart: where a gradient entry is rounding
         # noise the update's sign follows the noise -- a few 1e-4 of the entries may sit a step apart)
         assert_close_after_adam(v, res["round4"][0][n], 1e-3, 3, f"param {n}: lite vs round-4 launches", bad_frac=2e-3)
