@@ -306,10 +306,13 @@ def _gemm_tn(P: Tensor, Q: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+_EDGE_DIRECT = os.environ.get("MVAE_CONV_EDGE_DIRECT", "1") != "0"  # (read once, at import)
+
+
 def _edge_direct() -> bool:
     """The 3-channel boundary layers straight from the image (csrc/mvae_edge.hip, the default) or through the patch matrix
     (MVAE_CONV_EDGE_DIRECT=0: mvae_im2col_k4s2p1 + generic contractions; same bits on the activation side)."""
-    return os.environ.get("MVAE_CONV_EDGE_DIRECT", "1") != "0"
+    return _EDGE_DIRECT
 
 
 def _edge_conv(img: Tensor, W: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], relu: bool, B: int,
@@ -406,10 +409,8 @@ def _convT_to3(src: Tensor, W48: Tensor, bias: Tensor, R: int) -> Tensor:
 
 def _conv_e2(a1: Tensor, We2: Tensor, bias: Tensor, B: int) -> Tensor:
     """The e2 layer forward (128 -> 512 channels on 8 x 8): the implicit contraction (operand gather in the LDS-DMA requests
-    of k_gemm_f32pp).  Until round 4 the patch matrix + plain contraction was faster on the register-staged kernel (12 + 83 us
-    against 105 us); MVAE_CONV_E2_IMPLICIT=0 restores that form (same bits: the same order of MFMA steps)."""
-    if B * 16 >= 512 and os.environ.get("MVAE_CONV_E2_IMPLICIT", "1") == "0":
-        return Fn.linear_forward(_im2col(a1, None, B, 128, 8, _nhwc(8, 128), True), We2, bias, relu=True)
+    of k_gemm_f32pp).  (Until round 4 the patch matrix + plain contraction was faster on the register-staged kernel, 12 + 83 us
+    against 105 us, and stayed selectable; that form is gone.)"""
     return _conv_nhwc(a1, We2, bias, None, B, 128, 8, True)
 
 
@@ -489,12 +490,17 @@ class ConvEngine:
         #   the forward epilogues write the bf16 planes of the activations next to them, the backward contractions stage the
         #   planes by LDS-DMA; 0: the split happens inside the backward kernels (k_gemm_b3).  Same arithmetic either way.
         self.planes = os.environ.get("MVAE_CONV_PLANES", "1") != "0"
-        # MVAE_CONV_STREAMS (default 0): backward pass on three HIP streams -- the backward-data chain stays on the caller's
-        #   stream, the weight gradients go to side stream 0, the bias sums / re-orderings to side stream 1, forked and joined
-        #   through events (parallel branches in a captured graph).  Same bits, measured SLOWER (1.08 -> 1.21 ms): off.
-        self.overlap = os.environ.get("MVAE_CONV_STREAMS", "0") == "1"
-        self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if self.overlap else []
-        self._forked: List[int] = []
+        # A/B switches of the plane backward pass, read ONCE here (INTEGRATION.md lists every surviving switch):
+        # MVAE_CONV_D3_FUSED (1): the last transposed convolution inside the loss-end launch; MVAE_CONV_EPI_COLSUM (1; "2": db1
+        # only): bias gradients from the producing launch's epilogue; MVAE_CONV_DT0_SLICES (1): dt0's K slices added by the
+        # latent backward; MVAE_CONV_DA1_IMPLICIT (1): da1 as four implicit parity-class contractions
+        self._sw_d3_fused = os.environ.get("MVAE_CONV_D3_FUSED", "1") != "0"
+        self._sw_epi_colsum = os.environ.get("MVAE_CONV_EPI_COLSUM", "1")
+        self._sw_dt0_slices = os.environ.get("MVAE_CONV_DT0_SLICES", "1") != "0"
+        self._sw_da1_implicit = os.environ.get("MVAE_CONV_DA1_IMPLICIT", "1") != "0"
+        # (Rounds 3-4 also carried a backward pass on three HIP streams -- weight gradients and bias sums forked onto side
+        # streams --: same bits, measured slower in every form (1.08 -> 1.21 ms eager, no overlap inside a captured graph);
+        # removed in round 5.)
 
     def set_radius_trainable(self, radius_trainable: Sequence[bool]) -> None:
         """0 fixed / 1 trainable radius / 3 trainable universal curvature (clip group), see mvae_optimizer_step_flat."""
@@ -527,38 +533,12 @@ class ConvEngine:
     def _w(self, name: str) -> Tensor:
         return self.param_views()[name]
 
-    # ---- side streams
-    def _branch(self, k: int, fn) -> None:
-        """Run `fn` (launches only) on side stream k, ordered after everything issued so far on the current stream.
-        Tensors the branch reads must stay referenced until `_join` (the caching allocator reuses a freed block on the
-        stream that allocated it without waiting for other streams)."""
-        if not self.overlap:
-            fn()
-            return
-        main = torch.cuda.current_stream(self.device)
-        side = self._side[k]
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            fn()
-        if k not in self._forked:
-            self._forked.append(k)
-
-    def _join(self) -> None:
-        main = torch.cuda.current_stream(self.device)
-        for k in self._forked:
-            ev = torch.cuda.Event()
-            ev.record(self._side[k])
-            main.wait_event(ev)
-        self._forked = []
-
     def _use_p3(self, B: int) -> int:
         """Which passes of a B-row step run on pre-split operands: 0 none, 2 the backward pass (contraction mode 2), 1 both
-        passes (contraction mode 1: split products everywhere).  Needs the switch on, no side streams, and every plane
+        passes (contraction mode 1: split products everywhere).  Needs the switch on and every plane
         contraction's shape made of whole tiles."""
         mode = load().mvae_set_contraction_mode(-1)
-        if not self.planes or self.overlap or mode not in (1, 2):
+        if not self.planes or mode not in (1, 2):
             return 0
         sup = load().mvae_p3_supported
         ok = bool(sup(0, B * 64, 256, 1024, 64) and sup(0, B * 16, 128, 4096, 256) and sup(1, B * 16, 2048, 512, 0) and
@@ -656,11 +636,8 @@ class ConvEngine:
     def _d2_forward(b1: Tensor, Wd2: Tensor, bias: Tensor, R: int) -> Tensor:
         """ConvTranspose2d(256 -> 64) + ReLU (conv_vae.py:53,73): [R * 64, 256] -> [R * 256, 64].  Four implicit contractions,
         one per output parity class (no [R * 64, 1024] product, no col2im): 0.86 -> 0.84 ms per step once the ping-pong
-        kernel took the gathers; MVAE_CONV_D2_IMPLICIT=0: product + col2im (rounding differs: that form adds the four taps of a
-        pixel after the contraction)."""
-        if os.environ.get("MVAE_CONV_D2_IMPLICIT", "1") != "0":
-            return _convT_nhwc(b1, Wd2, bias, None, R, 256, 8, 64, True)
-        return _col2im(_gemm_nn(b1, Wd2), bias, None, R, 64, 16, _nhwc(16, 64), True, (R * 256, 64), True)
+        kernel took the gathers (the product + col2im form it replaced is gone)."""
+        return _convT_nhwc(b1, Wd2, bias, None, R, 256, 8, 64, True)
 
     def _heads_channel_last(self):
         """(W_heads with its 8192 columns re-ordered from the reference's (c, y, x) to channel-last (y, x, c), b_heads)."""
@@ -702,7 +679,7 @@ class ConvEngine:
         lay = self.layout
         p3 = self._use_p3(B) if eps.dim() == 2 else 0
         use_p3 = p3 != 0
-        fuse_d3 = self.direct and os.environ.get("MVAE_CONV_D3_FUSED", "1") != "0"
+        fuse_d3 = self.direct and self._sw_d3_fused
         c = self._forward(x, eps, planes=use_p3, planes_forward=(p3 == 1), defer_logits=fuse_d3)
         c["p3"] = use_p3
         bce = x.new_empty(B)
@@ -755,15 +732,10 @@ class ConvEngine:
         return g
 
     def _backward(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
-        side = self._branch
-        try:
-            body = self._backward_body_p3 if c.get("p3") else self._backward_body
-            return body(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side)
-        finally:
-            self._join()  # (also after an exception: a captured side stream must rejoin before the capture ends)
+        body = self._backward_body_p3 if c.get("p3") else self._backward_body
+        return body(x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay)
 
-    def _backward_body(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side):
-        # Every activation gradient below stays referenced by a local until the join at the end (see _branch).
+    def _backward_body(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
         # ---- decoder backward
         def d3_bias():
             # d3.bias gradient = sum over (b, y, x) of g[b, c, y, x]: column sums over the batch first ([B, 3072] ->
@@ -776,20 +748,20 @@ class ConvEngine:
             _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
 
         if not c.get("d3_bias_done"):
-            side(1, d3_bias)
+            d3_bias()
         if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
-            side(0, lambda: _edge_wgrad(c["b2"], g, GV["d3.weight"].view(64, 48), B))
+            _edge_wgrad(c["b2"], g, GV["d3.weight"].view(64, 48), B)
             db2 = _edge_conv(g, PV["d3.weight"].view(64, 48), None, c["b2"], False, B)
         else:
             dcol3 = _im2col(g, None, B, 3, 32, _nchw(32, 3))  # ConvT backward = im2col of the incoming gradient
-            side(0, lambda: _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48)))
+            _gemm_tn(c["b2"], dcol3, out=GV["d3.weight"].view(64, 48))
             db2 = _linear_masked(dcol3, PV["d3.weight"].view(64, 48), c["b2"])  # ReLU mask in the contraction's epilogue
         # ConvTranspose2d backward = a Conv2d of the incoming gradient: implicit contractions, no patch matrices
-        side(0, lambda: _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16))
-        side(1, lambda: _colsum(db2, out=GV["d2.bias"]))
+        _conv_nhwc_wgrad(c["b1"], db2, self.flat.matrix(self.grads, "d2"), B, 64, 16)
+        _colsum(db2, out=GV["d2.bias"])
         db1 = _conv_nhwc(db2, c["Wd2"], None, c["b1"], B, 64, 16, False, BACKWARD)  # [B*64, 256], ReLU mask in the epilogue
-        side(0, lambda: _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8))
-        side(1, lambda: _colsum(db1, out=GV["d1.bias"]))
+        _conv_nhwc_wgrad(c["t0"], db1, self.flat.matrix(self.grads, "d1"), B, 256, 8)
+        _colsum(db1, out=GV["d1.bias"])
         dt0 = _conv_nhwc(db1, c["Wd1"], None, None, B, 256, 8, False, BACKWARD)  # [B*16, 128]
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
@@ -806,29 +778,28 @@ class ConvEngine:
                 ptr(GV["d0.weight"]), ptr(GV["d0.bias"]), ptr(self.grads[:lay.n]), ptr(dheads), ptr(ws), B,
                 stream_ptr(self.device)))
         else:
-            dhflat = self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay, side)
+            dhflat = self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay)
         # ---- encoder backward (Conv2d backward-data = col2im)
         da2 = dhflat.view(B * 16, 512)
-        side(0, lambda: _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8))
-        side(1, lambda: _colsum(da2, out=GV["e2.bias"]))
+        _conv_nhwc_wgrad(da2, c["a1"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
+        _colsum(da2, out=GV["e2.bias"])
         da1 = _col2im(_gemm_nn(da2, c["We2"], BACKWARD), None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128),
                       True)
-        side(0, lambda: _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16))
-        side(1, lambda: _colsum(da1, out=GV["e1.bias"]))
+        _conv_nhwc_wgrad(da1, c["a0"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
+        _colsum(da1, out=GV["e1.bias"])
         da0 = _convT_nhwc(da1, c["We1"], None, c["a0"], B, 128, 8, 64, False, BACKWARD)    # [B*256, 64], ReLU mask of a0
         if c["col0"] is None:
-            side(0, lambda: _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B))
+            _edge_wgrad(da0, c["x"], GV["e0.weight"].view(64, 48), B)
         else:
-            side(0, lambda: _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48)))
+            _gemm_tn(da0, c["col0"], out=GV["e0.weight"].view(64, 48))
         _colsum(da0, out=GV["e0.bias"])
-        self._join()
         check(load().mvae_slice_sums_flush(stream_ptr(self.device)))
         _DEFERRED_WS.clear()
         if want_outputs:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None
 
-    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, side, planes=None, chansum_out=None):
+    def _latent_backward(self, c, dt0, eps, beta, PV, GV, B, lay, planes=None, chansum_out=None):
         """Decoder fc backward, the components, the heads' backward: -> dhflat = the gradient of the channel-last a2 (+ its
         bf16 planes into `planes` [3, B*16, 512], fused latent section only).  chansum_out [512] (with planes): the sum of that
         gradient over rows and pixels per channel (e2.bias) from the same launch; the f32 gradient is then not written and None
@@ -836,7 +807,7 @@ class ConvEngine:
         NH = lay.heads_dim
         ow, ob = self.flat.off["w_heads"], self.flat.off["b_heads"]
         if not c.get("fused"):
-            return self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay, side)
+            return self._latent_backward_generic(c, dt0, eps, beta, PV, GV, B, lay)
         skip = planes is not None and chansum_out is not None
         dhflat = None if skip else torch.empty_like(c["hflat"])
         cws = _keep(dt0.new_empty(H_DIM)) if skip else None
@@ -852,7 +823,7 @@ class ConvEngine:
             ptr(dheads), ptr(ws), B, stream_ptr(self.device)))
         return dhflat
 
-    def _backward_body_p3(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay, side):
+    def _backward_body_p3(self, x, eps, beta, want_outputs, c, g, bce, PV, GV, B, lay):
         """The backward pass on pre-split operands (contraction mode 2, csrc/mvae_p3.hip): the same sequence of contractions
         as _backward_body -- autograd of conv_vae.py:57-79 -- with every large one reading bf16 planes: of the forward
         activations (written by the forward epilogues), of the activation gradients (written by the epilogue that produces
@@ -873,7 +844,7 @@ class ConvEngine:
             _colsum(_permute_rc(gpix, 1, 3, 1024).view(1024, 3), out=GV["d3.bias"])
         db2_p = _new_planes(B * 256, 64, dev)
         if c["col0"] is None:  # the boundary layers straight from the images (csrc/mvae_edge.hip)
-            epi2 = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") == "1"  # d2.bias from the same launch, no f32 db2 ("2": db1 only)
+            epi2 = self._sw_epi_colsum == "1"  # d2.bias from the same launch, no f32 db2 ("2": db1 only)
             db2 = _edge_backward(c["b2"], g, PV["d3.weight"].view(64, 48), GV["d3.weight"].view(64, 48), B, db2_p,
                                  colsum_out=GV["d2.bias"] if epi2 else None)
         else:
@@ -885,7 +856,7 @@ class ConvEngine:
             _conv_nhwc_wgrad_p3(c["b1_p"], db2_p, self.flat.matrix(self.grads, "d2"), B, 64, 16)
             # [B*64, 256], ReLU mask of b1; only its planes and its column sums (d1.bias) are ever read: the epilogue delivers
             # both and the f32 tensor is not written (MVAE_CONV_EPI_COLSUM=0: f32 result + the batched column sum)
-            epi = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"
+            epi = self._sw_epi_colsum != "0"
             db1, db1_p = _conv_nhwc_p3(db2_p, Wd2_p, c["b1"], B, 64, 16, want_planes=True,
                                        colsum_out=GV["d1.bias"] if epi else None)
         if db2 is not None:
@@ -893,13 +864,13 @@ class ConvEngine:
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(t0_p, db1_p, self.flat.matrix(self.grads, "d1"), B, 256, 8)
             # [B*16, 128]; with the fused latent section its K slices stay un-added (the latent backward adds them as it reads)
-            dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8, keep_slices=bool(c.get("fused")) and os.environ.get("MVAE_CONV_DT0_SLICES", "1") != "0")
+            dt0, _ = _conv_nhwc_p3(db1_p, Wd1_p, None, B, 256, 8, keep_slices=bool(c.get("fused")) and self._sw_dt0_slices)
         if db1 is not None:
             _colsum(db1, out=GV["d1.bias"])
         # ---- latent section
         da2_p = _new_planes(B * 16, 512, dev) if c.get("fused") else None
-        epi_l = da2_p is not None and os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e2.bias from the latent launch
-        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, side, planes=da2_p,
+        epi_l = da2_p is not None and self._sw_epi_colsum != "0"  # e2.bias from the latent launch
+        dhflat = self._latent_backward(c, dt0, eps, beta, PV, GV, B, lay, planes=da2_p,
                                        chansum_out=GV["e2.bias"] if epi_l else None)
         # ---- encoder backward
         if dhflat is not None:
@@ -907,14 +878,14 @@ class ConvEngine:
             if da2_p is None:
                 da2_p = _split_planes([da2])[0]
             _colsum(da2, out=GV["e2.bias"])
-        if os.environ.get("MVAE_CONV_DA1_IMPLICIT", "1") != "0" and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
+        if self._sw_da1_implicit and load().mvae_p3_supported(2, B * 16, 128, 2048, 512):
             # backward-data of e2 as four implicit contractions per output parity class (no [B * 16, 2048] product, no col2im:
             # 256 workgroups with 64 K steps each instead of two rounds of 16-step ones).  Equal to the product form until the
             # transposed-convolution kernels took alternate K steps; now 0.744 -> 0.717 ms (mode 2), 0.631 -> 0.609 (mode 1).
             # MVAE_CONV_DA1_IMPLICIT=0: product + col2im.
             with _p3_group(dev):
                 _conv_nhwc_wgrad_p3(da2_p, c["a1_p"], self.flat.matrix(self.grads, "e2"), B, 128, 8)
-                epi = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e1.bias from the epilogue, no f32 da1
+                epi = self._sw_epi_colsum != "0"  # e1.bias from the epilogue, no f32 da1
                 da1, da1_p = _convT_nhwc_p3(da2_p, We2_p, c["a1"], B, 512, 4, 128, want_planes=True,
                                             colsum_out=GV["e1.bias"] if epi else None, want_y=not epi)
         else:
@@ -925,7 +896,7 @@ class ConvEngine:
             da1 = _col2im(prod, None, c["a1"], B, 128, 8, _nhwc(8, 128), False, (B * 64, 128), True, planes=da1_p)
         with _p3_group(dev):
             _conv_nhwc_wgrad_p3(da1_p, c["a0_p"], self.flat.matrix(self.grads, "e1"), B, 64, 16)
-            epi0 = os.environ.get("MVAE_CONV_EPI_COLSUM", "1") != "0"  # e0.bias from the epilogue (da0 itself is still read)
+            epi0 = self._sw_epi_colsum != "0"  # e0.bias from the epilogue (da0 itself is still read)
             da0, _ = _convT_nhwc_p3(da1_p, We1_p, c["a0"], B, 128, 8, 64,
                                     colsum_out=GV["e0.bias"] if epi0 else None)  # [B*256, 64], ReLU mask of a0
         if da1 is not None:
@@ -942,7 +913,7 @@ class ConvEngine:
             return {"logits": c["logits"], "concat_z": c["z"], "bce": bce, "kl": c["kl"]}
         return None
 
-    def _latent_backward_generic(self, c, dt0, eps, beta, PV, GV, B, lay, side):
+    def _latent_backward_generic(self, c, dt0, eps, beta, PV, GV, B, lay):
         dd0 = _relu_mask_(_permute_rc(dt0, B, 16, 128).view(B, 2048), c["d0o"])
         _, _, dz = Fn.linear_backward(c["z"], PV["d0.weight"], dd0, relu_in=False, need_dx=True,
                                       out_dW=GV["d0.weight"], out_db=GV["d0.bias"])
@@ -958,8 +929,7 @@ class ConvEngine:
         dW_cl = dheads.new_empty(NH, H_DIM)
         _, _, dhflat = Fn.linear_backward(c["hflat"], c["w_heads_cl"], dheads, relu_in=True, need_dx=True,
                                           out_dW=dW_cl, out_db=self.grads[ob:ob + NH])
-        c["dW_cl"] = dW_cl  # (read on a side stream: alive until the join)
-        side(1, lambda: _permute_rc(dW_cl.view(NH, 16, 512), NH, 16, 512, out=self.grads[ow:ow + NH * H_DIM]))
+        _permute_rc(dW_cl.view(NH, 16, 512), NH, 16, 512, out=self.grads[ow:ow + NH * H_DIM])
         return dhflat
 
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:

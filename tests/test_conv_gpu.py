@@ -524,51 +524,6 @@ def test_linear_splitk_vs_float64(dev):
                      atol_frac=5e-6)
 
 
-def test_conv_backward_on_side_streams_is_the_same_step(dev, monkeypatch):
-    """The backward pass forks its weight gradients and bias sums onto side streams (ConvEngine._branch / _join): the
-    same kernels on the same operands, so gradients and post-step parameters are the SAME BITS as on one stream --
-    launched eagerly and replayed as a HIP graph with parallel branches (three steps, so a stale read across a
-    fork/join would show)."""
-    from mvae_amd import synthetic
-    from mvae_amd.conv import ConvEngine
-    B = 64
-    xs = synthetic.uniform_batches(3, B, 3072).to(dev)
-    eps = synthetic.eps_batches(3, B, 6).to(dev)
-
-    # (the side-stream form keeps the in-kernel split of the backward pass; bit-identity is claimed between the two STREAM forms)
-    monkeypatch.setenv("MVAE_CONV_PLANES", "0")
-
-    def engine(streams):
-        monkeypatch.setenv("MVAE_CONV_STREAMS", streams)
-        eng = ConvEngine([("h", 2), ("s", 2), ("e", 2)], dev, radius_trainable=[True, True, False])
-        shapes = [(name, tuple(v.shape)) for name, v in eng.param_views().items()]
-        eng.load_state(synthetic.synthetic_state(shapes, radius=2.0, transposed_conv=("d1", "d2", "d3")))
-        return eng
-
-    one, three = engine("0"), engine("1")
-    assert not one.overlap and three.overlap and len(three._side) == 2
-    for i in range(3):
-        one.train_step(xs[i], eps[i], 1.0, True)
-        three.train_step(xs[i], eps[i], 1.0, True)
-    torch.cuda.synchronize()
-    assert torch.equal(one.grads, three.grads) and torch.equal(one.params, three.params)
-    assert one.read_stats()["sum"] == three.read_stats()["sum"]
-    # graph replay of the forked step
-    graphed = engine("1")
-    graphed.train_step(xs[0], eps[0], 1.0, True)  # allocator warm-up outside the capture
-    graphed.load_state({k: v.clone() for k, v in engine("0").param_views().items()})
-    for t in (graphed.adam_m, graphed.adam_v, graphed.counters, graphed.stats):
-        t.zero_()
-    torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        for i in range(3):
-            graphed.train_step(xs[i], eps[i], 1.0, True)
-    gr.replay()  # (a capture executes nothing: the state is still the initial one)
-    torch.cuda.synchronize()
-    assert torch.equal(one.grads, graphed.grads) and torch.equal(one.params, graphed.params)
-
-
 @pytest.mark.parametrize("model,B", [("h2,s2,e2", 256), ("h2,s2,e2", 77), ("p2,d2,u2", 40), ("s8", 300), ("e3,h2", 640),
                                      ("h2,h2,s3", 96), ("e2,e1,e2,h2", 64)])
 def test_fused_conv_latent_kernels_vs_generic_operators(dev, model, B):
