@@ -345,7 +345,7 @@ def make_plan(steps, warmup, graph_steps):
     return graph_steps, None
 
 
-def mlp_roofline(eng, prof, step_s, fixed):
+def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
     """Whole-step roofline + per-launch table."""
     alg = algorithmic_per_launch(eng.flat.n_logical_params(), eng.layout.heads_dim, eng.layout.z_dim,
                                  eng.layout.eps_dim)
@@ -391,11 +391,24 @@ def mlp_roofline(eng, prof, step_s, fixed):
             if doc.get("source_hash") != cur:
                 stale = stale or name
                 continue
-            kern = doc["kernels"]
-            names = {"latent_dec1_fwd": "k_fwd23"}
-            traffic = kern[names.get(dom, "k_" + dom)]["traffic_bytes"]
-            traffic_step = sum(kern[names.get(k, "k_" + k)]["traffic_bytes"] for k in prof)
-            traffic_src = "profiles/" + name
+            kern = doc.get("configs", {}).get(pmc_config) if pmc_config else doc["kernels"]
+            if kern is None:
+                continue
+            # a profile slot -> the kernels that can fill it (the fused / block / per-row / wave-cooperative paths)
+            cands = {"enc_fwd": [["k_enc_fwd"]], "latent_dec1_fwd": [["k_fwd23"]],
+                     "latent_fwd": [["k_heads_comp"], ["k_latent_fwd", "k_duals_coop"], ["k_latent_fwd"]],
+                     "dec1_fwd": [["k_fwd3m"], ["k_dec1_fwd"]], "dec1_bwd": [["k_dec1_bwd"]],
+                     "latent_bwd": [["k_latent_bwd2"], ["k_latent_bwd_blk"], ["k_latent_bwd"]],
+                     "enc_bwd": [["k_enc_bwd2"], ["k_enc_bwd"]]}
+
+            def slot_bytes(slot):
+                for group in cands[slot]:
+                    if all(g in kern for g in group):
+                        return sum(kern[g]["traffic_bytes"] for g in group)
+                raise KeyError(slot)
+            traffic = slot_bytes(dom)
+            traffic_step = sum(slot_bytes(k) for k in prof)
+            traffic_src = "profiles/" + name + (f" [configs.{pmc_config}]" if pmc_config else "")
             break
         except (OSError, KeyError, ValueError):
             continue
@@ -448,7 +461,7 @@ def mlp_leg(model, fixed, steps, warmup, dev, repeats=5):
     assert stats["sum"]["steps"] == warmup + repeats * steps, stats["sum"]["steps"]
     assert stats["last"]["elbo"] == stats["last"]["elbo"], "non-finite ELBO"
     prof = eng.profile_step(xs[0], eps[0], 1.0, not fixed, iters=100)
-    roof = mlp_roofline(eng, prof, dt / steps, fixed)
+    roof = mlp_roofline(eng, prof, dt / steps, fixed, pmc_config={"e6": "e6", "6h2,6s2,6e2": "prod36", "h40": "h40"}.get(model))
     return {"metric": f"ELBO-steps/sec (batch 128) MNIST {model}", "value": steps / dt, "unit": "ELBO-steps/sec",
             "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
             "workload": f"MNIST shapes (D=784), model {model}, {'fixed' if fixed else 'learnable'} curvature, "
@@ -457,7 +470,7 @@ def mlp_leg(model, fixed, steps, warmup, dev, repeats=5):
             "repeat_ms_per_step": {"median": dt / steps * 1e3, "first": times[0] / steps * 1e3,
                                    "min": min(times) / steps * 1e3, "max": max(times) / steps * 1e3},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms",
-                                              "step_hbm_frac", "step_mfma_frac")}}
+                                              "step_hbm_frac", "step_mfma_frac", "traffic", "traffic_step", "traffic_source")}}
 
 
 def epoch_pipeline_leg(dev, epochs=3):
@@ -747,7 +760,8 @@ def main():
 
     # per-launch durations measured live with HIP events on the launch stream (mvae_step_profile)
     prof = eng.profile_step(xs[0], eps[0], 1.0, not args.fixed_curvature, iters=200)
-    roof = mlp_roofline(eng, prof, dt / args.steps, args.fixed_curvature)
+    roof = mlp_roofline(eng, prof, dt / args.steps, args.fixed_curvature,
+                        pmc_config={"e6": "e6", "6h2,6s2,6e2": "prod36", "h40": "h40"}.get(args.model))
 
     line = {
         "metric": f"ELBO-steps/sec (batch 128) MNIST {args.model}",

@@ -982,16 +982,19 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
     }
   }
   MV_T(6);
-  if (lead && hdF) {
+  if (hdF) {
     // hd leaves in FRAGMENT ORDER only (launch 4 reads its ReLU mask element-wise, launch 5's dW_logits tiles read whole
-    // fragments): position (q', i') of the block of (column tile, this row block) = rows 4 q' .. 4 q' + 3 of column i'
+    // fragments): position (q', i') of the block of (column tile, this row block) = rows 4 q' .. 4 q' + 3 of column i'.
+    // EVERY pair workgroup of the row block holds all of hd in LDS: each stores the column tiles t = pt, pt + ntP, ... (one
+    // 1 KB block for the BASELINE shapes) instead of the lead storing all H / 16 of them on the launch's critical path.
     const int MB = B >> 4;
-    for (int e = tid; e < (H >> 4) * 64; e += 512) {
-      const int tile = e >> 6, pos = e & 63, ii = pos & 15, qq = pos >> 4;
-      const float* src = hd_s + (4 * qq) * ld + tile * 16 + ii;
-      const f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
-      reinterpret_cast<f32x4*>(hdF)[((size_t)(tile * MB + mt) << 6) + pos] = v;
-    }
+    if (wave == 0)
+      for (int tile = pt; tile < (H >> 4); tile += ntP) {
+        const int ii = lane & 15, qq = lane >> 4;
+        const float* src = hd_s + (4 * qq) * ld + tile * 16 + ii;
+        const f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
+        reinterpret_cast<f32x4*>(hdF)[((size_t)(tile * MB + mt) << 6) + lane] = v;
+      }
   }
   // both partial tiles go to LDS under one barrier; threads 0..255 add up the first tile, 256..511 the second
   float sv;

@@ -28,6 +28,10 @@ class PeerExchange:
         """two_shot: every rank first reduces its own 1/world slice of all slots, the optimizer launch then reads each
         slice from its owner (2 n / world floats per link and step instead of n; one more flag round per step)."""
         self.engine = engine
+        # MVAE_PEER_TIMEOUT=<seconds>: the bound of a wait for a peer's flag.  Ranks that SHARE a device (the one-device
+        # rehearsals of the node layout) are time-sliced: a spinning wait holds the GPU while its peer cannot run, and the
+        # 2 s default was occasionally not enough for eight processes on a loaded box.
+        timeout_seconds = float(os.environ.get("MVAE_PEER_TIMEOUT", timeout_seconds))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC

@@ -264,7 +264,7 @@ def test_peer_exchange_eight_processes_one_device(exchange):
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
     steps, world = 6, 8
-    res = _run_ranks(steps, world, exchange=exchange, graph_steps=3)
+    res = _run_ranks(steps, world, exchange=exchange, graph_steps=3, env={"MVAE_PEER_TIMEOUT": "20"})  # (8 ranks share the GPU)
     assert all(r[3] == 0 for r in res), "a rank gave up waiting for a peer"
     for r in res[1:]:
         assert np.array_equal(res[0][1], r[1]), f"rank {r[0]} diverged from rank 0"
@@ -290,7 +290,8 @@ def test_bench_flow_eight_ranks_one_device():
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MVAE_BENCH_BACKEND="gloo", MVAE_BENCH_ONE_DEVICE="1", MVAE_DP_EXCHANGE="peer2")
+    env = dict(os.environ, MVAE_BENCH_BACKEND="gloo", MVAE_BENCH_ONE_DEVICE="1", MVAE_DP_EXCHANGE="peer2",
+               MVAE_PEER_TIMEOUT="20")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20",
            "--warmup", "5"]

@@ -16,6 +16,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace 
 # 2./3. PMC passes, one counter each, kernel trace only
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- $PMCB > $OUT/pmc_write.log 2>&1
+# 3b. the same two passes for the other MLP kernel paths (block kernels: configs[3]; wave-cooperative components: h40; e6 =
+#     configs[0]), so that their bench legs can quote counter traffic of THEIR kernels
+for cfg in "prod36 --model 6h2,6s2,6e2" "h40 --model h40" "e6 --model e6 --fixed-curvature"; do
+  set -- $cfg; key=$1; shift
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${key}_$ctr -o bench -- $PMCB "$@" > $OUT/pmc_${key}_$ctr.log 2>&1
+  done
+done
 # 4. conv architecture (BASELINE configs[4]) kernel stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/conv -o conv -- python $ROOT/tools/bench_conv.py 256 20 > $OUT/conv.log 2>&1
 # 4b. MFMA-pipe busy cycles (own PMC pass, kernel trace only): the MLP step and the conv step

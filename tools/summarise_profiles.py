@@ -88,6 +88,17 @@ if fetch and write:
                       "this is an upper bound on HBM bytes (the whole working set is ~12 MB and MALL-resident).",
         "source_hash": source_hash(),  # bench.py refuses this summary once the kernels' sources change
         "kernels": kernels}
+    # the other kernel paths (tools/collect_profiles.sh step 3b): per-config kernel tables under "configs"
+    rec["configs"] = {}
+    for key in ("prod36", "h40", "e6"):
+        f2, w2 = first(f"pmc_{key}_FETCH_SIZE/**/*counter_collection.csv"), first(f"pmc_{key}_WRITE_SIZE/**/*counter_collection.csv")
+        if not (f2 and w2):
+            continue
+        F2, W2 = pmc_average(f2, "FETCH_SIZE"), pmc_average(w2, "WRITE_SIZE")
+        rec["configs"][key] = {k: {"FETCH_SIZE_KB": round(F2[k][0], 1), "WRITE_SIZE_KB": round(W2.get(k, (0.0, 0))[0], 1),
+                                   "dispatches": F2[k][1],
+                                   "traffic_bytes": int(round((2.0 * F2[k][0] + W2.get(k, (0.0, 0))[0]) * 1024))}
+                               for k in F2 if k.startswith("k_")}
     with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     print(json.dumps(kernels, indent=1))
