@@ -911,10 +911,12 @@ struct FragJob {
 
 // x [B][N] -> its fragment-order copy, one column tile per workgroup (any block size that is a multiple of 64): thread
 // (block c, lane (i, q)) gathers its four batch rows and stores one 16-byte vector.
-__device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, int MB, float* TF) {
+// ncols > 0: columns past ncols (a ragged last tile) repeat the last column; they only reach outputs nobody stores.
+__device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, int MB, float* TF, int ncols = 0) {
   const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  const int col = (ncols > 0 && 16 * nt + i >= ncols) ? ncols - 1 : 16 * nt + i;
   for (int c = threadIdx.x >> 6; c < MB; c += (int)(blockDim.x >> 6)) {
-    const float* src = T + (size_t)(16 * c + 4 * q) * ld + 16 * nt + i;
+    const float* src = T + (size_t)(16 * c + 4 * q) * ld + col;
     f32x4 v;
     v[0] = src[0];
     v[1] = src[(size_t)ld];

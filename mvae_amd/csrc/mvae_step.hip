@@ -34,7 +34,7 @@ struct mvae_ctx {
   int ldz;    // z row stride
   // workspace carve (floats)
   int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_dirtab, o_total;
-  int64_t o_hdF, o_xF, o_hF, o_dhdF, o_zF, o_dheadsF;  // fragment-order operands of the lite backward (mvae_common.hpp: frag_off)
+  int64_t o_hdF, o_xF, o_hF, o_dhdF, o_zF, o_dheadsF, o_dhF;  // fragment-order operands of the lite backward (mvae_common.hpp: frag_off)
   int64_t o_dzp, o_dheads16, o_whF;  // [B][H/16][8] partial dz products of launch 4's tiles; dheads as [B][16] (zero-padded); W_heads snapshot
   bool no_lite;                      // MVAE_NO_LITE=1: the fused-forward shapes keep the round-4 backward launches (A/B measurements)
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
@@ -87,8 +87,9 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   c->o_xF = take(B * D);
   c->o_hF = take(B * H);
   c->o_dhdF = take(B * H);
-  c->o_zF = take(B * 16);
-  c->o_dheadsF = take(B * 16);  // one 16-column tile each
+  c->o_dhF = take(B * H);
+  c->o_zF = take(B * 16 * (((int64_t)d.z_dim + 15) / 16));  // whole 16-column tiles
+  c->o_dheadsF = take(B * 16 * (((int64_t)d.heads_dim + 15) / 16));  // whole 16-column tiles (zero past heads_dim)
   c->o_dzp = take(B * (int64_t)c->nt_h * 64);  // [B][H/16][8] (lite) | [B/16][H/16][z tiles <= 4][64][4] (block backward)
   c->o_dheads16 = take(B * 16);
   c->o_whF = take((int64_t)c->nt_h * 256);
@@ -1123,6 +1124,10 @@ struct FragArgs {
   float* dzp;
   const float* Wd0;
   int Z;
+  // block backward: z's fragment-order copy for launch 6'' (n_zf = z tiles, one spare workgroup each)
+  const float* z;
+  float* zF;
+  int ldz, n_zf;
 };
 struct DualArgs {
   const float* heads;
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
   const int n_dual = DUAL > 0 ? da.n_dual : 0;
-  const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + 7) & ~7;
+  const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + 7) & ~7;
   MV_SPAN_BEGIN(3);
   if (DUAL > 0 && b < n_dual) {  // the longest chains of the launch: dispatched first, ONE wave per workgroup (= per CU)
     if (threadIdx.x < 64)
@@ -1166,7 +1171,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     const bool ok = threadIdx.x < 256 && m < B && n < H;
     constexpr bool lite = LITE == 1;  // FULL shapes only
     // branch-free request, used in the epilogue
-    const float mask = *(lite ? fr.hdF + frag_off(m, n, B >> 4) : hd + (size_t)(m < B ? m : 0) * H + (n < H ? n : 0));
+    const float mask = *((LITE && fr.hdF) ? fr.hdF + frag_off(m, n, B >> 4) : hd + (size_t)(m < B ? m : 0) * H + (n < H ? n : 0));
     f32x4 wz0 = {0.f, 0.f, 0.f, 0.f}, wz1 = wz0;  // lite: W_d0[n][0..7] (zero past Z), the thread's share of dz
     // LITE 2: wave w < ZT multiplies the masked dhd tile by W_d0[16 tile rows][16 z columns w]: B[k = 4 q + t][j = i]
     float wzt[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1218,7 +1223,11 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       MV_SPAN_END(3, 1);
       return;
     }
-    if (ok) dhd[(size_t)m * H + n] = dv;
+    if (LITE == 2 && fr.dhdF) {  // fragment order only: launch 5 takes dz from the partial tiles, launch 6'' contracts fragments
+      if (threadIdx.x < 256) fr.dhdF[frag_off(m, n, B >> 4)] = dv;
+    } else if (ok) {
+      dhd[(size_t)m * H + n] = dv;
+    }
     if (LITE == 2) {
       __shared__ float dvs[16][17];
       if (threadIdx.x < 256) dvs[threadIdx.x >> 4][threadIdx.x & 15] = dv;
@@ -1249,6 +1258,8 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       for (int i = fb * (int)blockDim.x + (int)threadIdx.x; i < n; i += fd.n_wg * (int)blockDim.x) feed_item(fd, cursor, i);
     } else if (fb - fd.n_wg < fr.n_xf) {
       job_frag_copy(fr.x, D, fb - fd.n_wg, B >> 4, fr.xF);  // x in fragment order for launch 6's dW_e0 tiles
+    } else if (fb - fd.n_wg - fr.n_xf < fr.n_zf) {
+      job_frag_copy(fr.z, fr.ldz, fb - fd.n_wg - fr.n_xf, B >> 4, fr.zF, fr.Z);
     }
     return;  // (the rest: padding)
   }
@@ -1754,6 +1765,57 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   MV_SPAN_END(4, 1);
 }
 
+// radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in the
+// fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr).  One workgroup; gsh: LDS,
+// kRadiiRegion floats.
+template <bool ADAM>
+__device__ __forceinline__ void job_radii(const CompTable& t, float* gsh, const float* drpart, float* G, float* P, int B,
+                                          double curv_lr, int do_curv) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < kRadiiRegion) {
+    G[tid] = 0.f;
+    gsh[tid] = 0.f;
+  }
+  __syncthreads();
+  const int nw = (int)(blockDim.x >> 6);
+  if (B <= 256) {  // four components per wave and round, every request of the round in flight at once (rows in the same order)
+    for (int c0 = wave; c0 < t.n; c0 += 4 * nw) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ci = c0 + u * nw;
+        const bool on = ci < t.n && t.trainable[ci];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = lane + 64 * k;
+          v[u][k] = on && r < B ? drpart[(size_t)ci * B + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ci = c0 + u * nw;
+        const float s = wave_sum(((v[u][0] + v[u][1]) + v[u][2]) + v[u][3]);
+        if (lane == 0 && ci < t.n && t.trainable[ci]) gsh[ci] = s;
+      }
+    }
+  } else {
+    for (int ci = wave; ci < t.n; ci += nw) {
+      if (!t.trainable[ci]) continue;
+      float s = 0.f;
+      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
+      s = wave_sum(s);
+      if (lane == 0) gsh[ci] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < t.n && t.trainable[tid]) {
+    float s = gsh[tid];
+    if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
+    G[tid] = s;
+    if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
+  }
+}
+
 // ---- 6: dW_e0, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
 template <bool ADAM, bool FULL>
 __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const float* dh, const float* x, const float* dheads,
@@ -1780,27 +1842,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
   if (b == 0) {
     // radius gradients: sum over the batch rows of the per-row terms of launch 5 (fixed order: deterministic), and in
     // the fused step torch.optim.SGD(lr=curv_lr) on the trainable radii: param.add_(grad, alpha=-lr)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float* gsh = &red[0][0][0];  // per-component batch sums
-    if (tid < kRadiiRegion) {
-      G[tid] = 0.f;
-      gsh[tid] = 0.f;
-    }
-    __syncthreads();
-    for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
-      if (!t.trainable[ci]) continue;
-      float s = 0.f;
-      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
-      s = wave_sum(s);
-      if (lane == 0) gsh[ci] = s;
-    }
-    __syncthreads();
-    if (tid < t.n && t.trainable[tid]) {
-      float s = gsh[tid];
-      if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
-      G[tid] = s;
-      if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
-    }
+    job_radii<ADAM>(t, &red[0][0][0], drpart, G, P, B, curv_lr, do_curv);
     MV_SPAN_END(5, 7);
     return;
   }
@@ -2014,27 +2056,7 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd2(CompTable t, const
   };
   // Grid: 1 + n_small + tiles workgroups = 1 + 5 + 250 for the BASELINE shapes: exactly one per CU.
   if (b == 0) {  // radius gradients (+ SGD) as in k_enc_bwd, then b_heads
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float* gsh = &red[0][0][0];
-    if (tid < kRadiiRegion) {
-      G[tid] = 0.f;
-      gsh[tid] = 0.f;
-    }
-    __syncthreads();
-    for (int ci = wave; ci < t.n; ci += (int)(blockDim.x >> 6)) {
-      if (!t.trainable[ci]) continue;
-      float s = 0.f;
-      for (int r = lane; r < B; r += 64) s += drpart[(size_t)ci * B + r];
-      s = wave_sum(s);
-      if (lane == 0) gsh[ci] = s;
-    }
-    __syncthreads();
-    if (tid < t.n && t.trainable[tid]) {
-      float s = gsh[tid];
-      if (ADAM && (t.trainable[tid] & 2)) s *= clip_coef(t, gsh);  // vae.py:161-163 (fused step; else k_optim clips)
-      G[tid] = s;
-      if (ADAM && do_curv) P[tid] = P[tid] + (float)(-curv_lr) * s;
-    }
+    job_radii<ADAM>(t, &red[0][0][0], drpart, G, P, B, curv_lr, do_curv);
     __syncthreads();
     job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, 0, G + off_b_heads, at(off_b_heads));  // NH <= 16: one block
     MV_SPAN_END(5, 7);
@@ -2200,6 +2222,76 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd2(CompTable t, const
         }
       }
     }
+    MV_SPAN_END(5, 1);
+  }
+}
+
+// ---- 6'' (block backward, z_dim 17 .. 64): every weight gradient from fragment-order operands -- dh and dhd arrive in
+// fragment order from launches 5 / 4 (never row-major), dheads from launch 5 too, x and h as the copies launch 1 writes, z as the
+// copy spare workgroups of launch 4 write.  One tile per wave; the wave whose tile is the first of its P column block
+// also delivers that block's bias gradient (the column sums of the P fragments it holds): no column-sum workgroups.
+// Grid: 1 (radii) + n_wd0 + n_wh + nt_h * ceil(nt_d / 5) workgroups, short jobs first.
+template <bool ADAM, int W>
+__global__ __launch_bounds__(64 * W) void k_enc_bwd3(CompTable t, const float* xF, const float* hF, const float* dhF,
+                                                  const float* dheadsF, const float* dhdF, const float* zF,
+                                                  const float* drpart, float* G, float* P, int B, int H, int D, int NH,
+                                                  int Z, int n_wd0, int n_wh, int64_t off_w_e0, int64_t off_b_e0,
+                                                  int64_t off_w_heads, int64_t off_b_heads, int64_t off_w_d0,
+                                                  int64_t off_b_d0, AdamArgs base, double curv_lr, int do_curv) {
+  __shared__ float gsh[kRadiiRegion];
+  int b = blockIdx.x;
+  const int MB = B >> 4, ntH = H >> 4;
+  MV_SPAN_BEGIN(5);
+  auto at = [&](int64_t off) {
+    AdamArgs a = base;
+    a.p += off;
+    a.m += off;
+    a.v += off;
+    return a;
+  };
+  if (b == 0) {
+    job_radii<ADAM>(t, gsh, drpart, G, P, B, curv_lr, do_curv);
+    MV_SPAN_END(5, 7);
+    return;
+  }
+  b -= 1;
+  const int wave = threadIdx.x >> 6;
+  if (b < n_wd0) {  // dW_d0[H, Z] = dhd^T z (+ b_d0 on the z tile 0 of a row tile)
+    const int ZT = (Z + 15) >> 4;
+    const int tw = b * W + wave, pt = tw / ZT, zt = tw - pt * ZT;
+    if (pt < ntH) {
+      if (zt == 0)
+        job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, pt, H, zF, zt, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
+                                    at(off_b_d0));
+      else
+        job_tn_frag_any<ADAM, false>(dhdF, nullptr, 0, pt, H, zF, zt, Z, MB, G + off_w_d0, Z, at(off_w_d0));
+    }
+    MV_SPAN_END(5, 3);
+    return;
+  }
+  b -= n_wd0;
+  if (b < n_wh) {  // dW_heads[NH, H] = dheads^T h (+ b_heads on the h tile 0 of a heads tile)
+    const int NT = (NH + 15) >> 4;
+    const int tw = b * W + wave, qt = tw / NT, pt = tw - qt * NT;
+    if (qt < ntH) {
+      if (qt == 0)
+        job_tn_frag_any<ADAM, true>(dheadsF, nullptr, 0, pt, NH, hF, qt, H, MB, G + off_w_heads, H, at(off_w_heads),
+                                    G + off_b_heads, at(off_b_heads));
+      else
+        job_tn_frag_any<ADAM, false>(dheadsF, nullptr, 0, pt, NH, hF, qt, H, MB, G + off_w_heads, H, at(off_w_heads));
+    }
+    MV_SPAN_END(5, 2);
+    return;
+  }
+  b -= n_wh;
+  {  // dW_e0[H, D] = dh^T x (+ b_e0 on the x tile 0 of a row tile)
+    const int ntDg = ((D >> 4) + W - 1) / W;
+    const int pt = fast_div(b, ntDg), qt = (b - pt * ntDg) * W + wave;
+    if (qt == 0)
+      job_tn_frag_any<ADAM, true>(dhF, nullptr, 0, pt, H, xF, qt, D, MB, G + off_w_e0, D, at(off_w_e0), G + off_b_e0,
+                                  at(off_b_e0));
+    else
+      job_tn_frag_any<ADAM, false>(dhF, nullptr, 0, pt, H, xF, qt, D, MB, G + off_w_e0, D, at(off_w_e0));
     MV_SPAN_END(5, 1);
   }
 }
@@ -2388,13 +2480,17 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // MVAE_NO_LITE=1: the round-4 launches (A/B measurements).
   const bool lite = full && !c->no_lite && latent_path(c, aligned16(x)) == MVAE_PATH_FUSED && !uses_blk_bwd(c, aligned16(x)) &&
                     fast_b && NH <= 16 && Z <= 8 && B <= 256;
-  float *hdF = lite ? ws + c->o_hdF : nullptr, *xF = lite ? ws + c->o_xF : nullptr, *hF = lite ? ws + c->o_hF : nullptr,
-        *dhdF = lite ? ws + c->o_dhdF : nullptr, *zF = lite ? ws + c->o_zF : nullptr,
-        *dheadsF = lite ? ws + c->o_dheadsF : nullptr;
-  // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
-  const bool xf_in_l1 = lite && (c->nt_h & 7) != 0;
-  // the block backward (many small components) takes dz from partial products of launch 4's tiles too (z_dim 17 .. 64)
+  // the block backward (many small components) takes dz from partial products of launch 4's tiles too (z_dim 17 .. 64),
+  // and its weight gradients from fragment-order operands (k_enc_bwd3)
   const bool dzp_blk = full && !c->no_lite && uses_blk_bwd(c, aligned16(x)) && Z > 16 && Z <= 64;
+  const bool fr6 = lite || dzp_blk;  // launch 6 reads fragment order
+  // ... and with the block FORWARD (k_fwd3m) hd exists in fragment order only
+  const bool hdf_blk = dzp_blk && latent_path(c, aligned16(x)) == MVAE_PATH_BLOCK && c->blk_fwd;
+  float *hdF = (lite || hdf_blk) ? ws + c->o_hdF : nullptr, *xF = fr6 ? ws + c->o_xF : nullptr, *hF = fr6 ? ws + c->o_hF : nullptr,
+        *dhdF = fr6 ? ws + c->o_dhdF : nullptr, *zF = fr6 ? ws + c->o_zF : nullptr,
+        *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = dzp_blk ? ws + c->o_dhF : nullptr;
+  // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
+  const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
   float *dzp = ws + c->o_dzp, *dheads16 = ws + c->o_dheads16, *whF = ws + c->o_whF;
   if (parts & MVAE_STEP_HEAD) {  // launches 1-5
   ki = 0;
@@ -2444,7 +2540,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LF3(DM)                                                                                                      \
   STEP_LAUNCH((k_fwd3m<DM>), dim3(n_dual3 + ((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, c->t, c->gt, heads,       \
               c->ldh, eps, d.eps_dim, P + d.off_radii, NH, duals, n_dual3, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0, \
-              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z)
+              P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z,  \
+              hdF)
     if (bk == 2) { LF3(2); } else if (bk == 4) { LF3(4); } else { LF3(8); }
 #undef LF3
   } else {
@@ -2495,8 +2592,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
-    const FragArgs fr = {hdF, dhdF, x, xF, (lite && !xf_in_l1) ? c->nt_d : 0, (lite || dzp_blk) ? dzp : nullptr, P + d.off_w_d0, Z};
-    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + 7) & ~7;
+    const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, fr6 ? dzp : nullptr, P + d.off_w_d0, Z,
+                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0};
+    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
@@ -2540,10 +2638,11 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       const int n_blk = c->nt_b * ((H + 63) / 64);
       const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
       const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
+      const int n_tile_wg = hdf_blk ? (c->nt_d * c->nt_h + 7) / 8 : c->nt_d * ntHg5;
 #define LBB(DM, AD, TT)                                                                                               \
-  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + c->nt_d * ntHg5), dim3(256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
+  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_tile_wg), dim3(hdf_blk ? 512 : 256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
               c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g, hd, G + d.off_w_logits, beta, B, H, D, NH, Z,       \
-              n_blk, at(d.off_w_logits), duals, dzp_blk ? dzp : nullptr)
+              n_blk, at(d.off_w_logits), duals, dzp_blk ? dzp : nullptr, dhF, hF, dzp_blk ? dheadsF : nullptr, hdf_blk ? hdF : nullptr)
 #define LBB2(DM, AD) do { if (Z <= 16) LBB(DM, AD, 1); else if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) LBB2(2, true); else if (bk == 4) LBB2(4, true); else LBB2(8, true); }
@@ -2576,6 +2675,20 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       if (fused) { if (B <= 128) EB2(true, 8); else EB2(true, 16); }
       else { if (B <= 128) EB2(false, 8); else EB2(false, 16); }
 #undef EB2
+    } else if (dzp_blk) {
+      // seven waves per workgroup: 49 x tiles of a dh column block = 7 x 7, and 1 + 11 + 18 + 175 workgroups for config [3] fit
+      // one per CU (five-wave workgroups, 291 of them: 39.0 us per step against 37.8)
+      constexpr int w3 = 7;
+      const int n_wd0f = (c->nt_h * ((Z + 15) / 16) + w3 - 1) / w3, n_whf = (((NH + 15) / 16) * c->nt_h + w3 - 1) / w3;
+      const int n_we0f = c->nt_h * ((c->nt_d + w3 - 1) / w3);
+#define EB3(AD) EB3W(AD, w3)
+#define EB3W(AD, WV)                                                                                                      \
+  STEP_LAUNCH((k_enc_bwd3<AD, WV>), dim3(1 + n_wd0f + n_whf + n_we0f), dim3(64 * WV), 0, c->t, xF, hF, dhF, dheadsF, \
+              dhdF, zF, drpart, G, P, B, H, D, NH, Z, n_wd0f, n_whf, d.off_w_e0, d.off_b_e0,           \
+              d.off_w_heads, d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+      if (fused) EB3(true); else EB3(false);
+#undef EB3
+#undef EB3W
     } else
 #define EB(AD, FU)                                                                                                   \
   STEP_LAUNCH((k_enc_bwd<AD, FU>), dim3(grid), dim3(64 * kTileWaves), 0, c->t, dh, x, dheads, c->ldh, h, dhd, z, c->ldz, \

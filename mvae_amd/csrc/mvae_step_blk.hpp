@@ -159,7 +159,8 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
                                                const float* eps, int eps_ld, const float* radii, int NH, float* duals,
                                                int n_dual, const float* z, int ldz, const float* Wd0, const float* bd0,
                                                const float* Wl, const float* bl, const float* x, float* hd, float* g,
-                                               float* bce_part, float* logits_user, int B, int H, int D, int Z) {
+                                               float* bce_part, float* logits_user, int B, int H, int D, int Z,
+                                               float* hdF) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // hd_s[16][H + 4]
   __shared__ float red[kW8][16][17];
   __shared__ float red2[kW8][16][17];
@@ -300,10 +301,18 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
   }
   lds_barrier();
   if (lead) {
-    for (int e4 = tid; e4 < 4 * H; e4 += 512) {
-      const int r = e4 / (H >> 2), c4 = e4 - r * (H >> 2);
-      *reinterpret_cast<float4*>(hd + ((size_t)mt * 16 + r) * H + 4 * c4) =
-          *reinterpret_cast<const float4*>(hd_s + r * ld + 4 * c4);
+    if (hdF) {  // (uniform) fragment order only: every later reader (launches 4 and 5) takes fragments
+      for (int e = tid; e < nchunks * 64; e += 512) {
+        const int c = e >> 6, l = e & 63;
+        const float* src = hd_s + (4 * (l >> 4)) * ld + 16 * c + (l & 15);
+        reinterpret_cast<f32x4*>(hdF)[((size_t)(c * MT + mt) << 6) + l] = f32x4{src[0], src[ld], src[2 * ld], src[3 * ld]};
+      }
+    } else {
+      for (int e4 = tid; e4 < 4 * H; e4 += 512) {
+        const int r = e4 / (H >> 2), c4 = e4 - r * (H >> 2);
+        *reinterpret_cast<float4*>(hd + ((size_t)mt * 16 + r) * H + 4 * c4) =
+            *reinterpret_cast<const float4*>(hd_s + r * ld + 4 * c4);
+      }
     }
   }
   // ---- the two logits tiles
@@ -382,13 +391,17 @@ inline int fill_dirtab(const CompTable& t, int4* tab) {
 
 // TT = interleaved column tiles of dz: lane (i, q) loads W_d0[k][TT i .. TT i + TT - 1] (one 4 TT-byte request) and
 // tile tt's column j stands for z column TT j + tt; TT = 3 covers z_dim <= 48 (config [3]: exactly), TT = 4 up to 64.
+// hdF != NULL (with dzp, dhF, dheadsF: the fragment-order form): the launch has 512-thread workgroups -- the dW_logits tiles
+// eight per workgroup from g (row-major, fragment row sequence) and hd's fragment-order copy, so that tiles + row workgroups
+// are fewer than the chip has CUs (a row workgroup that shares its CU with a tile workgroup ends ~0.8 us late); the row
+// workgroups keep their four waves, the other four leave at once.
 template <int DMAX, bool ADAM, int TT>
-__global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4* dirtab, const float* dhd,
+__global__ __launch_bounds__(512) void k_latent_bwd_blk(CompTable t, const int4* dirtab, const float* dhd,
                                                         const float* Wd0, int ldh, const float* h, const float* Wh,
                                                         float* dheads, float* dh, float* drpart, const float* g,
                                                         const float* hd, float* dWl, float beta, int B, int H, int D,
                                                         int NH, int Z, int n_blk, AdamArgs awl, const float* duals,
-                                                        const float* dzp) {
+                                                        const float* dzp, float* dhF, const float* hF, float* dheadsF, const float* hdF) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // TT == 1: W_d0 [H][Z]
   __shared__ float red[4][4][16][17];  // [wave][interleaved tile][row][col]
   __shared__ __attribute__((aligned(16))) float dz_s[16][68];
@@ -398,11 +411,18 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
   MV_SPAN_BEGIN(4);
   if (b >= n_blk) {
     b -= n_blk;
+    if (hdF) {  // (uniform) tile index -> (H tile fastest, D tile): the 8 waves of a workgroup share g's column block mostly
+      const int ntH = H >> 4, tw = b * 8 + wave, pt = tw / ntH, qt = tw - pt * ntH;
+      if (pt * 16 < D) job_tn_halffrag<ADAM>(g, D, pt, D, hdF, qt, H, B >> 4, dWl, H, awl);
+      MV_SPAN_END(4, 2);
+      return;
+    }
     const int ntHg = ((H >> 4) + kTileWaves5 - 1) / kTileWaves5;
     job_tn_wave<ADAM, true>(g, D, D, b / ntHg, hd, H, H, (b % ntHg) * kTileWaves5 + wave, B, dWl, H, awl);
     MV_SPAN_END(4, 2);
     return;
   }
+  if (tid >= 256) return;  // (fragment-order form: 512-thread workgroups; the row part is written for four waves)
   const int MT = B >> 4;
   const int mt = b % MT, s = b / MT;  // s: the 64-column group of dh this workgroup produces
   MV_TDECL;
@@ -431,8 +451,11 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
       for (int e = 0; e < DS / 2; ++e) du[rd][rr][e] = rec[e];
     }
   }
+  // the ReLU mask of this workgroup's dh block: row-major h, or (dhF: dh leaves in fragment order, wave w = the 16-column
+  // tile 4 s + w) the fragment-order copy launch 1 wrote
   const float4 hm = *reinterpret_cast<const float4*>(
-      h + ((size_t)mt * 16 + (tid >> 4)) * H + ((s * 64 + 4 * (tid & 15) < H) ? s * 64 + 4 * (tid & 15) : 0));
+      dhF ? hF + ((((size_t)((4 * s + wave) * 16 < H ? 4 * s + wave : 0) * (B >> 4) + mt) << 6) + lane) * 4
+          : h + ((size_t)mt * 16 + (tid >> 4)) * H + ((s * 64 + 4 * (tid & 15) < H) ? s * 64 + 4 * (tid & 15) : 0));
   const int nchunks = H >> 4;
   const float* arow = dhd + (size_t)(mt * 16 + i) * H;
   const int KC = (NH + 15) >> 4;  // 16-wide k chunks of the dh contraction
@@ -620,11 +643,21 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
   }
   lds_barrier();
   MV_T(4);
-  if (s == 0)
-    for (int e = tid; e < 16 * NH; e += 256) {
-      const int r = e / NH, n = e - r * NH;
-      dheads[((size_t)mt * 16 + r) * ldh + n] = dheads_s[r][n];
+  if (s == 0) {
+    if (dheadsF) {  // (uniform) fragment order, whole tiles (dheads_s is zero past NH): launch 6'' contracts fragments
+      for (int e = tid; e < KC * 64; e += 256) {
+        const int pt = e >> 6, l = e & 63, li = l & 15, lq = l >> 4;
+        reinterpret_cast<f32x4*>(dheadsF)[((size_t)(pt * (B >> 4) + mt) << 6) + l] =
+            f32x4{dheads_s[4 * lq][16 * pt + li], dheads_s[4 * lq + 1][16 * pt + li], dheads_s[4 * lq + 2][16 * pt + li],
+                  dheads_s[4 * lq + 3][16 * pt + li]};
+      }
+    } else {
+      for (int e = tid; e < 16 * NH; e += 256) {
+        const int r = e / NH, n = e - r * NH;
+        dheads[((size_t)mt * 16 + r) * ldh + n] = dheads_s[r][n];
+      }
     }
+  }
 
   // ---- dh columns [64 s, 64 s + 64) = (dheads W_heads) [h > 0]: K = NH in 16-wide chunks over the 4 waves
   {
@@ -647,6 +680,26 @@ __global__ __launch_bounds__(256) void k_latent_bwd_blk(CompTable t, const int4*
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) red[wave][tt][q * 4 + r4][i] = acc[tt][r4];
     lds_barrier();
+    if (dhF) {  // (uniform) fragment order for launch 6 (k_enc_bwd3): lane (i, q) of wave w holds dh[16 mt + 4 q + t][n0 + 16 w + i]
+      const int c = 16 * wave + i, cq = c >> 2, tt = c & 3;
+      if (n0 + 16 * wave < H) {
+        f32x4 v;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int r = 4 * q + t4;
+          v[t4] = (red[0][tt][r][cq] + red[1][tt][r][cq]) + (red[2][tt][r][cq] + red[3][tt][r][cq]);
+        }
+        v[0] = hm.x > 0.f ? v[0] : 0.f;
+        v[1] = hm.y > 0.f ? v[1] : 0.f;
+        v[2] = hm.z > 0.f ? v[2] : 0.f;
+        v[3] = hm.w > 0.f ? v[3] : 0.f;
+        reinterpret_cast<f32x4*>(dhF)[((size_t)((4 * s + wave) * (B >> 4) + mt) << 6) + lane] = v;
+      }
+      MV_T(5);
+      MV_TFLUSH(24, 6, 9);
+      MV_SPAN_END(4, 1);
+      return;
+    }
     const int r = tid >> 4, cq = tid & 15;
     const int n = n0 + 4 * cq;
     if (n < H) {
