@@ -23,6 +23,15 @@
 #endif
 #include "mvae_common.hpp"
 #include "mvae_coop.hpp"
+struct StatsArgs {  // job_step_stats outside launch 4; bce_part == NULL: not here
+  const float* bce_part;
+  const float* kl;
+  float* bce_user;
+  float* stats;
+  int ncomp;
+};
+__device__ __forceinline__ void job_step_stats(float* sm, const float* bce_part, const float* kl, float* bce_user, float* stats,
+                                               float beta, int B, int ntD, int ncomp);
 #include "mvae_step_blk.hpp"
 
 // ================================================================================================ the fused step
@@ -1128,6 +1137,7 @@ struct FragArgs {
   const float* z;
   float* zF;
   int ldz, n_zf;
+  int stats_later;  // the statistics job runs in launch 5 (k_latent_bwd_blk, StatsArgs)
 };
 struct DualArgs {
   const float* heads;
@@ -1139,6 +1149,144 @@ struct DualArgs {
 // LITE: 0 the round-4 launch; 1 the lite backward (z_dim <= 8: hd read / dhd written in fragment order, dz partials as
 // [row][tile][8] from per-thread products and DPP row sums); 2 the round-4 launch PLUS dz partials for the block backward
 // (z_dim <= 64): the partial of a tile is itself an MFMA product, stored in the MFMA's output order
+// statistics job of the step (one workgroup; launch 4, or launch 5 of the fragment-order block backward where launch 4's
+// tiles end before it would).  sm: kW8 * 16 * 17 = 2176 floats of LDS: [0, 64) block sums / component sums, [64, ...) part sums
+__device__ __forceinline__ void job_step_stats(float* sm, const float* bce_part, const float* kl, float* bce_user, float* stats,
+                                               float beta, int B, int ntD, int ncomp) {
+  // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo.
+  // Thread (row r, part p) adds its quarter of the column tiles of the row's BCE partials with every load in flight at
+  // once (one memory round trip instead of one per 8 tiles: this workgroup used to be the tail of the launch); the P
+  // part sums of a row meet in LDS and are added in part order, so the result is deterministic.
+  __shared__ float kl_s[4096];   // kl[i][r] of this step when ncomp * B fits: the per-component sums then read LDS
+  __shared__ float old_s[8 + kMaxComp];  // the running sums this step is added to, requested with the first loads
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool kl_in_lds = (size_t)ncomp * B <= 4096;
+  __shared__ float old_c[8 + kMaxComp];  // their Kahan compensation terms (third block of `stats`)
+  if (tid < 4 + ncomp) {
+    old_s[tid] = stats[tid];
+    old_c[tid] = stats[2 * (4 + ncomp) + tid];
+  }
+  const int P = (4 * B <= nthr) ? 4 : ((2 * B <= nthr) ? 2 : 1);
+  const int rows_pass = nthr / P;  // rows handled per pass
+  const int chunk = (ntD + P - 1) / P;
+  float bce_acc = 0.f, elbo_acc = 0.f;
+  __shared__ float cs_s[kMaxComp];  // per-component batch sums of this step
+  // (tried: 16-byte loads of four rows' partials per thread, 3 requests instead of 13, the group sums added from LDS:
+  // 4.5 us against 4.2 us for this form)
+  for (int r0 = 0; r0 < B; r0 += rows_pass) {
+    const int rl = tid % rows_pass, p = tid / rows_pass;
+    const int r = r0 + rl;
+    const bool act = p < P && r < B;
+    const int rr = act ? r : 0;
+    float part = 0.f;
+    for (int nt0 = p * chunk; nt0 < (p + 1) * chunk && nt0 < ntD; nt0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {  // pure requests (clamped); the masks come after the batch
+        const int nt = nt0 + u;
+        const bool ok = nt < (p + 1) * chunk && nt < ntD;
+        v[u] = bce_part[(size_t)(ok ? nt : 0) * B + rr];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int nt = nt0 + u;
+        part += (nt < (p + 1) * chunk && nt < ntD) ? v[u] : 0.f;
+      }
+    }
+    // the row's KL terms: part p takes the components p, p + P, ... (one batch of requests instead of one round trip per
+    // 8 components on a quarter of the threads); the P partial sums meet in LDS next to the BCE partials
+    float klp = 0.f;
+    if (act) {
+      for (int i0 = p; i0 < ncomp; i0 += 8 * P) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * P;
+          v[u] = kl[(size_t)(i < ncomp ? i : 0) * B + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * P;
+          if (i < ncomp) {
+            klp += v[u];
+            if (kl_in_lds) kl_s[(size_t)i * B + r] = v[u];
+          }
+        }
+      }
+    }
+    if (P > 1) {
+      if (p < P) {
+        sm[64 + p * rows_pass + rl] = part;
+        sm[64 + 1024 + p * rows_pass + rl] = klp;
+      }
+      __syncthreads();
+    }
+    if (p == 0 && act) {
+      float bce = part, klr = klp;
+      if (P == 2) {
+        bce = sm[64 + rl] + sm[64 + rows_pass + rl];
+        klr = sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl];
+      }
+      if (P == 4) {
+        bce = (sm[64 + rl] + sm[64 + rows_pass + rl]) + (sm[64 + 2 * rows_pass + rl] + sm[64 + 3 * rows_pass + rl]);
+        klr = (sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl]) +
+              (sm[64 + 1024 + 2 * rows_pass + rl] + sm[64 + 1024 + 3 * rows_pass + rl]);
+      }
+      if (bce_user) bce_user[r] = bce;
+      bce_acc += bce;
+      elbo_acc += (-bce - beta * klr);
+    }
+    if (P > 1) __syncthreads();
+  }
+  // One phase, one barrier: every wave leaves its partial sums of bce / elbo in LDS and, round-robin, the batch sum of a
+  // component's KL (rows in lane order); thread 0 then adds the wave partials in wave order (fixed order: deterministic).
+  // (As two block-wide reductions followed by the component sums this tail cost six barriers, and the statistics
+  // workgroup -- 4.6 us -- outlasted the dhd tiles of the launch.)
+  const int last = 4 + ncomp;
+  if (P == 1) __syncthreads();  // kl_s complete (the loop's own barriers cover P > 1)
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    const float wb = wave_sum(bce_acc), we = wave_sum(elbo_acc);
+    if (lane == 0) {
+      sm[wave] = wb;
+      sm[8 + wave] = we;
+    }
+    for (int i = wave; i < ncomp; i += nw) {
+      float a = 0.f;
+      if (kl_in_lds) {
+        for (int r = lane; r < B; r += 64) a += kl_s[(size_t)i * B + r];
+      } else {
+        for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
+      }
+      a = wave_sum(a);
+      if (lane == 0) {
+        kahan_add(stats, 4 + i, 2 * last, old_s[4 + i], old_c[4 + i], a);
+        stats[last + 4 + i] = a;
+        cs_s[i] = a;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float bce_sum = 0.f, elbo_sum = 0.f, kl_total = 0.f;
+    for (int w = 0; w < (nthr >> 6); ++w) {
+      bce_sum += sm[w];
+      elbo_sum += sm[8 + w];
+    }
+    for (int i = 0; i < ncomp; ++i) kl_total += cs_s[i];
+    kahan_add(stats, 0, 2 * last, old_s[0], old_c[0], bce_sum);
+    kahan_add(stats, 1, 2 * last, old_s[1], old_c[1], kl_total);
+    kahan_add(stats, 2, 2 * last, old_s[2], old_c[2], elbo_sum);
+    stats[3] = old_s[3] + 1.f;
+    stats[last + 0] = bce_sum;
+    stats[last + 1] = kl_total;
+    stats[last + 2] = elbo_sum;
+    stats[last + 3] = 1.f;
+  }
+}
+
 template <bool ADAM, bool FULL, int DUAL, int LITE = 0>
 __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, const float* hd, const float* W, float* db,
                                                   float* dhd, const float* bce_part, const float* kl, float* bce_user,
@@ -1269,139 +1417,8 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     MV_SPAN_END(3, 2);
     return;
   }
-  // statistics block (BatchStats, stats.py:144-212): sums over the batch of bce, kl_i, elbo.
-  // Thread (row r, part p) adds its quarter of the column tiles of the row's BCE partials with every load in flight at
-  // once (one memory round trip instead of one per 8 tiles: this workgroup used to be the tail of the launch); the P
-  // part sums of a row meet in LDS and are added in part order, so the result is deterministic.
-  float* sm = &red[0][0][0];  // kW8 * 16 * 17 = 2176 floats: [0, 64) block sums / component sums, [64, ...) part sums
-  __shared__ float kl_s[4096];   // kl[i][r] of this step when ncomp * B fits: the per-component sums then read LDS
-  __shared__ float old_s[8 + kMaxComp];  // the running sums this step is added to, requested with the first loads
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const bool kl_in_lds = (size_t)ncomp * B <= 4096;
-  __shared__ float old_c[8 + kMaxComp];  // their Kahan compensation terms (third block of `stats`)
-  if (tid < 4 + ncomp) {
-    old_s[tid] = stats[tid];
-    old_c[tid] = stats[2 * (4 + ncomp) + tid];
-  }
-  const int P = (4 * B <= nthr) ? 4 : ((2 * B <= nthr) ? 2 : 1);
-  const int rows_pass = nthr / P;  // rows handled per pass
-  const int chunk = (ntD + P - 1) / P;
-  float bce_acc = 0.f, elbo_acc = 0.f;
-  __shared__ float cs_s[kMaxComp];  // per-component batch sums of this step
-  // (tried: 16-byte loads of four rows' partials per thread, 3 requests instead of 13, the group sums added from LDS:
-  // 4.5 us against 4.2 us for this form)
-  for (int r0 = 0; r0 < B; r0 += rows_pass) {
-    const int rl = tid % rows_pass, p = tid / rows_pass;
-    const int r = r0 + rl;
-    const bool act = p < P && r < B;
-    const int rr = act ? r : 0;
-    float part = 0.f;
-    for (int nt0 = p * chunk; nt0 < (p + 1) * chunk && nt0 < ntD; nt0 += 16) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {  // pure requests (clamped); the masks come after the batch
-        const int nt = nt0 + u;
-        const bool ok = nt < (p + 1) * chunk && nt < ntD;
-        v[u] = bce_part[(size_t)(ok ? nt : 0) * B + rr];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int nt = nt0 + u;
-        part += (nt < (p + 1) * chunk && nt < ntD) ? v[u] : 0.f;
-      }
-    }
-    // the row's KL terms: part p takes the components p, p + P, ... (one batch of requests instead of one round trip per
-    // 8 components on a quarter of the threads); the P partial sums meet in LDS next to the BCE partials
-    float klp = 0.f;
-    if (act) {
-      for (int i0 = p; i0 < ncomp; i0 += 8 * P) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * P;
-          v[u] = kl[(size_t)(i < ncomp ? i : 0) * B + r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * P;
-          if (i < ncomp) {
-            klp += v[u];
-            if (kl_in_lds) kl_s[(size_t)i * B + r] = v[u];
-          }
-        }
-      }
-    }
-    if (P > 1) {
-      if (p < P) {
-        sm[64 + p * rows_pass + rl] = part;
-        sm[64 + 1024 + p * rows_pass + rl] = klp;
-      }
-      __syncthreads();
-    }
-    if (p == 0 && act) {
-      float bce = part, klr = klp;
-      if (P == 2) {
-        bce = sm[64 + rl] + sm[64 + rows_pass + rl];
-        klr = sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl];
-      }
-      if (P == 4) {
-        bce = (sm[64 + rl] + sm[64 + rows_pass + rl]) + (sm[64 + 2 * rows_pass + rl] + sm[64 + 3 * rows_pass + rl]);
-        klr = (sm[64 + 1024 + rl] + sm[64 + 1024 + rows_pass + rl]) +
-              (sm[64 + 1024 + 2 * rows_pass + rl] + sm[64 + 1024 + 3 * rows_pass + rl]);
-      }
-      if (bce_user) bce_user[r] = bce;
-      bce_acc += bce;
-      elbo_acc += (-bce - beta * klr);
-    }
-    if (P > 1) __syncthreads();
-  }
-  // One phase, one barrier: every wave leaves its partial sums of bce / elbo in LDS and, round-robin, the batch sum of a
-  // component's KL (rows in lane order); thread 0 then adds the wave partials in wave order (fixed order: deterministic).
-  // (As two block-wide reductions followed by the component sums this tail cost six barriers, and the statistics
-  // workgroup -- 4.6 us -- outlasted the dhd tiles of the launch.)
-  const int last = 4 + ncomp;
-  if (P == 1) __syncthreads();  // kl_s complete (the loop's own barriers cover P > 1)
-  {
-    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-    const float wb = wave_sum(bce_acc), we = wave_sum(elbo_acc);
-    if (lane == 0) {
-      sm[wave] = wb;
-      sm[8 + wave] = we;
-    }
-    for (int i = wave; i < ncomp; i += nw) {
-      float a = 0.f;
-      if (kl_in_lds) {
-        for (int r = lane; r < B; r += 64) a += kl_s[(size_t)i * B + r];
-      } else {
-        for (int r = lane; r < B; r += 64) a += kl[(size_t)i * B + r];
-      }
-      a = wave_sum(a);
-      if (lane == 0) {
-        kahan_add(stats, 4 + i, 2 * last, old_s[4 + i], old_c[4 + i], a);
-        stats[last + 4 + i] = a;
-        cs_s[i] = a;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float bce_sum = 0.f, elbo_sum = 0.f, kl_total = 0.f;
-    for (int w = 0; w < (nthr >> 6); ++w) {
-      bce_sum += sm[w];
-      elbo_sum += sm[8 + w];
-    }
-    for (int i = 0; i < ncomp; ++i) kl_total += cs_s[i];
-    kahan_add(stats, 0, 2 * last, old_s[0], old_c[0], bce_sum);
-    kahan_add(stats, 1, 2 * last, old_s[1], old_c[1], kl_total);
-    kahan_add(stats, 2, 2 * last, old_s[2], old_c[2], elbo_sum);
-    stats[3] = old_s[3] + 1.f;
-    stats[last + 0] = bce_sum;
-    stats[last + 1] = kl_total;
-    stats[last + 2] = elbo_sum;
-    stats[last + 3] = 1.f;
-  }
+  if (fr.stats_later) return;  // (block backward, fragment-order form: the job runs in launch 5)
+  job_step_stats(&red[0][0][0], bce_part, kl, bce_user, stats, beta, B, ntD, ncomp);
   MV_SPAN_END(3, 3);
 }
 
@@ -1904,8 +1921,8 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
 //     MFMA -- masks them with h's fragment-order copy and shares them through LDS (their column sums are b_e0's gradient);
 //   * every batch contraction reads fragment-order operands (mvae_common.hpp: frag_off).
 // ---- 5': one WAVE per batch row: dz (sum of the partials) -> contraction with the dual records -> dheads; dW_logits tiles
-template <int DMAX, bool ADAM>
-__global__ __launch_bounds__(64 * kTileWaves) void k_latent_bwd2(CompTable t, const float* dzp, int ntH, int ldh, float* dheads,
+template <int DMAX, bool ADAM, int TW>
+__global__ __launch_bounds__(64 * TW) void k_latent_bwd2(CompTable t, const float* dzp, int ntH, int ldh, float* dheads,
                                                      float* dheads16, float* dheadsF, float* drpart, const float* g,
                                                      const float* hdF, float* dWl, float beta, int B, int H,
                                                      int D, int NH, int Z, int n_rowwg, AdamArgs awl, const float* duals,
@@ -1913,15 +1930,15 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_latent_bwd2(CompTable t, co
   __shared__ mvae_component_desc desc_s[kMaxComp];
   __shared__ int doff_s[kMaxComp + 1];
   __shared__ int first_s[kMaxComp + 1];
-  __shared__ float dz_s[kTileWaves][8];
-  __shared__ float dh_s[kTileWaves][16];
+  __shared__ float dz_s[TW][8];
+  __shared__ float dh_s[TW][16];
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   MV_SPAN_BEGIN(4);
   if (b < n_snap) {  // (dispatched FIRST: at the end of the grid their requests queued behind everybody's, launch 5 +1 us)
     // Launch 6 rebuilds dh = dheads W_heads while its dW_heads tiles update W_heads in place: it reads THIS launch's snapshot,
     // laid out as the B fragments of that product: whF[(pt * 64 + q * 16 + i) * 4 + t] = W_heads[4 q + t][16 pt + i] (0 past NH)
-    for (int e = b * 64 * kTileWaves + tid; e < (H >> 4) * 256; e += n_snap * 64 * kTileWaves) {
+    for (int e = b * 64 * TW + tid; e < (H >> 4) * 256; e += n_snap * 64 * TW) {
       const int pt = e >> 8, ln = (e & 255) >> 2, n = 4 * (ln >> 4) + (e & 3);
       const float v = Wh[(size_t)(n < NH ? n : 0) * H + pt * 16 + (ln & 15)];
       whF[e] = n < NH ? v : 0.f;
@@ -1931,17 +1948,16 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_latent_bwd2(CompTable t, co
   b -= n_snap;
   if (b >= n_rowwg) {  // dW_logits[D, H] tiles, one per wave
     b -= n_rowwg;
-    // five-wave workgroups: 49 x 5 = 245 of them for the BASELINE shapes, which with the row workgroups is about one per CU
-    // (a tile workgroup that shares its CU with another one finishes ~1 us late: 343 four-wave ones ended at 3.4 / 4.6 us)
-    const int ntHg = ((H >> 4) + kTileWaves - 1) / kTileWaves;
-    const int pt = fast_div(b, ntHg), qg = b - pt * ntHg;
+    // TW-wave workgroups over the linear tile index, so that tiles + row workgroups are about one per CU (a tile workgroup
+    // that shares its CU with another one finishes ~1 us late: 343 four-wave ones ended at 3.4 / 4.6 us)
+    const int tw = b * TW + wave, pt = fast_div(tw, ntH), qt = tw - pt * ntH;
     // P = g read row-major in the fragments' row order (a second, fragment-order copy of g cost the forward launch more than
     // these tiles gained), Q = hd in fragment order: 40 wave-level requests per tile instead of 64
-    job_tn_halffrag<ADAM>(g, D, pt, D, hdF, qg * kTileWaves + wave, H, B >> 4, dWl, H, awl);
+    if (pt * 16 < D) job_tn_halffrag<ADAM>(g, D, pt, D, hdF, qt, H, B >> 4, dWl, H, awl);
     MV_SPAN_END(4, 2);
     return;
   }
-  const int row = b * kTileWaves + wave;
+  const int row = b * TW + wave;
   MV_STAMP(8);
   // requests first: the row's 25 x 8 partials (lanes 0..ntH-1: two 16-byte vectors each), then the tables
   f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
@@ -2593,7 +2609,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
     const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, fr6 ? dzp : nullptr, P + d.off_w_d0, Z,
-                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0};
+                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0};
     const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
@@ -2625,24 +2641,30 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
     if (lite) {
       const int n_snap = 4;  // W_heads snapshot workgroups (1600 floats each for H = 400)
-      const int n_rowwg = (B + kTileWaves - 1) / kTileWaves, n_tiles = c->nt_d * ((c->nt_h + kTileWaves - 1) / kTileWaves);
-#define LB2(DM, AD)                                                                                                  \
-  STEP_LAUNCH((k_latent_bwd2<DM, AD>), dim3(n_snap + n_rowwg + n_tiles), dim3(64 * kTileWaves), 0, c->t, dzp, c->nt_h, c->ldh, dheads,     \
+      // seven waves per workgroup: 4 + 19 + 175 workgroups, one per CU (five: 275 workgroups, rows end 4.3 us / tiles 3.9; seven:
+      // 3.9 / 4.0 -- the step 30.79 -> 30.77 us, within the noise)
+      constexpr int tw5 = 7;
+      const int n_rowwg = (B + tw5 - 1) / tw5, n_tiles = (c->nt_d * c->nt_h + tw5 - 1) / tw5;
+#define LB2(DM, AD) LB2W(DM, AD, tw5)
+#define LB2W(DM, AD, TWV)                                                                                                  \
+  STEP_LAUNCH((k_latent_bwd2<DM, AD, TWV>), dim3(n_snap + n_rowwg + n_tiles), dim3(64 * TWV), 0, c->t, dzp, c->nt_h, c->ldh, dheads,     \
               dheads16, dheadsF, drpart, g, hdF, G + d.off_w_logits, beta, B, H, D, NH, Z, n_rowwg,               \
               at(d.off_w_logits), duals, P + d.off_w_heads, whF, n_snap)
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) LB2(2, true); else if (bk == 4) LB2(4, true); else LB2(8, true); }
       else { if (bk == 2) LB2(2, false); else if (bk == 4) LB2(4, false); else LB2(8, false); }
 #undef LB2
+#undef LB2W
     } else if (uses_blk_bwd(c, aligned16(x))) {
       const int n_blk = c->nt_b * ((H + 63) / 64);
       const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
       const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
+      const StatsArgs sa = {hdf_blk ? bce_part : nullptr, klw, bce, d.stats, d.ncomp};  // (launch 4 skipped it: FragArgs::stats_later)
       const int n_tile_wg = hdf_blk ? (c->nt_d * c->nt_h + 7) / 8 : c->nt_d * ntHg5;
 #define LBB(DM, AD, TT)                                                                                               \
-  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_tile_wg), dim3(hdf_blk ? 512 : 256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
+  STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_tile_wg + (hdf_blk ? 1 : 0)), dim3(hdf_blk ? 512 : 256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \
               c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g, hd, G + d.off_w_logits, beta, B, H, D, NH, Z,       \
-              n_blk, at(d.off_w_logits), duals, dzp_blk ? dzp : nullptr, dhF, hF, dzp_blk ? dheadsF : nullptr, hdf_blk ? hdF : nullptr)
+              n_blk, at(d.off_w_logits), duals, dzp_blk ? dzp : nullptr, dhF, hF, dzp_blk ? dheadsF : nullptr, hdf_blk ? hdF : nullptr, sa)
 #define LBB2(DM, AD) do { if (Z <= 16) LBB(DM, AD, 1); else if (Z <= 48) LBB(DM, AD, 3); else LBB(DM, AD, 4); } while (0)
       const int bk = bucket_of(c->dmax);
       if (fused) { if (bk == 2) LBB2(2, true); else if (bk == 4) LBB2(4, true); else LBB2(8, true); }

@@ -401,7 +401,8 @@ __global__ __launch_bounds__(512) void k_latent_bwd_blk(CompTable t, const int4*
                                                         float* dheads, float* dh, float* drpart, const float* g,
                                                         const float* hd, float* dWl, float beta, int B, int H, int D,
                                                         int NH, int Z, int n_blk, AdamArgs awl, const float* duals,
-                                                        const float* dzp, float* dhF, const float* hF, float* dheadsF, const float* hdF) {
+                                                        const float* dzp, float* dhF, const float* hF, float* dheadsF, const float* hdF,
+                                                        StatsArgs sa) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // TT == 1: W_d0 [H][Z]
   __shared__ float red[4][4][16][17];  // [wave][interleaved tile][row][col]
   __shared__ __attribute__((aligned(16))) float dz_s[16][68];
@@ -409,6 +410,14 @@ __global__ __launch_bounds__(512) void k_latent_bwd_blk(CompTable t, const int4*
   int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   MV_SPAN_BEGIN(4);
+  if (sa.bce_part) {  // (uniform) the step's statistics job, dispatched first: launch 4's tiles end before it would there
+    if (b == 0) {
+      job_step_stats(&red[0][0][0][0], sa.bce_part, sa.kl, sa.bce_user, sa.stats, beta, B, D >> 4, sa.ncomp);
+      MV_SPAN_END(4, 3);
+      return;
+    }
+    b -= 1;
+  }
   if (b >= n_blk) {
     b -= n_blk;
     if (hdF) {  // (uniform) tile index -> (H tile fastest, D tile): the 8 waves of a workgroup share g's column block mostly

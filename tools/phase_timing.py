@@ -70,7 +70,7 @@ for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
 print("fwd23 per-wave time to the end of the heads MFMA (ns):", [round(a / N * 10) for a in wacc])
 KERNELS = ["enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd"]
 KINDS = {(0, 1): "tiles", (1, 1): "main waves", (1, 2): "dual waves", (2, 1): "tiles", (2, 2): "dual workgroups", (3, 1): "dhd tiles",
-         (3, 2): "db_logits", (3, 3): "statistics", (3, 4): "dual records", (4, 1): "rows", (4, 2): "dW_logits tiles", (5, 1): "dW_e0 tiles",
+         (3, 2): "db_logits", (3, 3): "statistics", (3, 4): "dual records", (4, 1): "rows", (4, 2): "dW_logits tiles", (4, 3): "statistics", (5, 1): "dW_e0 tiles",
          (5, 2): "dW_heads", (5, 3): "dW_d0", (5, 4): "b_e0", (5, 5): "b_heads", (5, 6): "b_d0", (5, 7): "radii"}
 import numpy as np
 print("per launch: workgroup END time after the first workgroup's start, ns (median / latest over workgroups)")
