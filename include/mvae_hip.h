@@ -495,6 +495,13 @@ int mvae_optimizer_step_flat(float* params, float* grads, float* adam_m, float* 
 /* out[r] = sum_j binary_cross_entropy_with_logits(logits[r][j], x[r % x_rows][j])   (vae.py:108-109 without
  * materialising x.repeat((n,1,1))).  logits[rows, D], x[x_rows, D]. */
 int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows, int64_t x_rows, int D, void* stream);
+/* The MLP decoder and the per-row BCE in one launch (vae.py:98-109 with ffnn_vae.py:52-60 as `decode`):
+ *   out[r] = sum_j binary_cross_entropy_with_logits((relu(z[r] W_d0^T + b_d0) W_l^T + b_l)[j], x[r % x_rows][j])
+ * z[rows, Z] (the n * B sampled latents), W_d0[H, Z], W_l[D, H], x[x_rows, D].  Neither the hidden layer nor the logits
+ * are written to memory.  H in {16, 64, 128, 256, 400, 512}, D % 16 == 0, Z <= 16, W_l 16-byte aligned; anything else returns
+ * MVAE_E_UNSUPPORTED without touching `out` (no error message: the caller composes mvae_linear_forward x 2 + mvae_bce_rows). */
+int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, const float* bd0, const float* Wl,
+                         const float* bl, const float* x, int64_t x_rows, int H, int D, float* out, void* stream);
 /* log_px[b] = logsumexp_n(-bce + log_p - log_q) - log n ; mi[b] = logsumexp_n(log_q - log_p) - log n   (vae.py:113-117)
  * bce, log_p, log_q: [n, B]. */
 int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi, int n,

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "mvae_optimizer_step_flat": (C.c_int, [_P, _P, _P, _P, _L, _P, _I, C.POINTER(C.c_uint8), C.c_double, C.c_double,
                                            _I, _I, _P]),
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),
+    "mvae_decode_bce_rows": (C.c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "mvae_loglik_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),
     "mvae_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),

@@ -974,6 +974,198 @@ extern "C" int mvae_bce_rows(const float* logits, const float* x, float* out, in
   return 0;
 }
 
+// ---- decoder + per-row BCE of the log-likelihood estimator in ONE launch (vae.py:98-109 for the MLP decoder, ffnn_vae.py:52-60):
+//   out[r] = sum_j BCE-with-logits( (relu(z[r] W_d0^T + b_d0) W_l^T + b_l)[j], x[r % x_rows][j] ).
+// n * B = 64 000 rows for the reference's n = 500: as three launches the hidden layer (102 MB) and the logits (200 MB) went
+// to HBM and back, and the logits contraction ran on the generic LDS-tiled kernel.  Here neither exists in memory:
+//   * workgroup = 64 rows, wave = 16 rows; the wave's hidden-layer block [16][H] is computed ONCE (K = z_dim: VALU FMAs from
+//     LDS copies of W_d0 / b_d0) straight into the A fragments of the f32-input MFMA and stays in registers (H / 4 per lane);
+//   * the logits are produced 16 columns at a time: W_l's row block [16][H] -- 16 H contiguous floats -- goes to LDS by LDS-DMA
+//     (double buffered, requested one column tile ahead, one barrier per tile) and is shared by the four waves; H / 4 MFMAs
+//     per wave and tile on four independent accumulators; the epilogue adds the bias, takes the targets from x
+//     (L2-resident) and adds the BCE terms to four per-lane row sums; a DPP row sum at the very end.
+// Next to the 8-pass f32 MFMA the VALU instructions of BOTH waves of a SIMD are step time (mvae_f32pp.hip), so the loop is
+// written for few of them: LDS-DMA instead of load + ds_write, scalar bases + 32-bit byte offsets, bare v_exp_f32 / v_log_f32.
+// First version (register-staged tiles, expf / log1p, 125 VALU per 100 MFMAs): 414 us = 62 % of the f32 MFMA peak for the
+// reference's shape; this one (~45 VALU): 352-356 us = 72-73 % (MFMA busy cycles / SIMD cycles by the counters: 0.73 -> see
+// DESIGN.md).  -DMV_DBR_NOEPI (tools/build_variant.py): the loop without the BCE terms, for A/B timing.
+#ifndef MV_DBR_PF
+#define MV_DBR_PF 1
+#endif
+template <int NCH, int ZP>  // H = 16 NCH ; z_dim <= ZP
+__global__ __launch_bounds__(256, 2) void k_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0,
+                                                            const float* bd0, const float* Wl, const float* bl,
+                                                            const float* x, int64_t x_rows, int D, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  constexpr int H = 16 * NCH;
+  float* bt = dyn;                 // [2][16][H]: W_l row blocks (contiguous in memory and here: NCH pieces of 1 KB)
+  float* wd_s = dyn + 2 * 16 * H;  // [H][ZP] (zero past z_dim)
+  float* bd_s = wd_s + H * ZP;     // [H]
+  // (two workgroups per CU.  Three -- the W_d0 copy overlaid on the second buffer, 51 KB each -- measured 357.7 us against 352:
+  // 1000 workgroups are 1.95 rounds of 512 slots but 1.3 rounds of 768)
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (in an SGPR: piece addresses and their guards are scalar)
+  const int64_t r0 = (int64_t)blockIdx.x * 64 + wave * 16;
+  const int ntD = D >> 4;
+  // W_l's row block nt -> LDS buffer `buf` by LDS-DMA: wave w moves the 1 KB pieces w, w + 4, ... -- no staging registers, no
+  // ds_write, and no VALU: scalar base + the lane's fixed byte offset (next to the 8-pass f32 MFMA every VALU instruction of
+  // either wave of the SIMD is step time: the counters of the first version showed 125 of them per 100 MFMAs)
+  // (addresses as scalar base + zero-extended 32-bit BYTE offset: the form the global instructions take an SGPR base for)
+  const unsigned lane16 = lane * 16;
+  auto request = [&](int nt, int buf) __attribute__((always_inline)) {
+    const char* src = reinterpret_cast<const char*>(Wl + (size_t)nt * (16 * H) + wave * 256);  // (scalar)
+#pragma unroll
+    for (int u = 0; u < (NCH + 3) / 4; ++u)
+      if (wave + 4 * u < NCH)  // (scalar branch)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + u * 4096 + lane16),
+                                         (__attribute__((address_space(3))) void*)(bt + buf * (16 * H) + (wave + 4 * u) * 256), 16, 0, 0);
+  };
+  request(0, 0);
+  float zr[ZP];
+  {
+    const int64_t r = r0 + i < rows ? r0 + i : rows - 1;
+#pragma unroll
+    for (int j = 0; j < ZP; ++j) {
+      const float v = z[r * Z + (j < Z ? j : 0)];
+      zr[j] = j < Z ? v : 0.f;
+    }
+  }
+  for (int e = tid; e < H * ZP; e += 256) {
+    const int k = e / ZP, j = e - k * ZP;
+    const float v = Wd0[(size_t)k * Z + (j < Z ? j : 0)];
+    wd_s[e] = j < Z ? v : 0.f;
+  }
+  for (int e = tid; e < H; e += 256) bd_s[e] = bd0[e];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA is invisible to the compiler's LDS dependence tracking)
+  __syncthreads();
+  // hidden layer of this wave's 16 rows, as A fragments: a[c][t] = relu(b_d0[k] + <z[row i], W_d0[k]>), k = 16 c + 4 q + t
+  f32x4 a[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 16 * c + 4 * q + t;
+      float v = bd_s[k];
+#pragma unroll
+      for (int j4 = 0; j4 < ZP; j4 += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wd_s + k * ZP + j4);
+        v = fmaf(zr[j4], w[0], v);
+        v = fmaf(zr[j4 + 1], w[1], v);
+        v = fmaf(zr[j4 + 2], w[2], v);
+        v = fmaf(zr[j4 + 3], w[3], v);
+      }
+      v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+      // (opaque to the SLP vectorizer: left alone it packs this phase into wide vectors whose shuffles spill ~700 registers,
+      // and the loop's pointers come back from scratch INSIDE the loop, behind the piece requests: 367 -> 616 us)
+      asm volatile("" : "+v"(v));
+      a[c][t] = v;
+    }
+  }
+  // targets' rows (x broadcast over the samples) of this lane's four output rows
+  unsigned xo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t rr = r0 + 4 * q + r < rows ? r0 + 4 * q + r : rows - 1;
+    xo[r] = (unsigned)((rr % x_rows) * D + i) * 4u;  // bytes
+  }
+  const unsigned i4 = i * 4;
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < ntD; ++nt) {
+    const int buf = nt & 1;
+    // (the tile index through readfirstlane -- opaque and uniform: otherwise loop strength reduction turns every address below into a loop-carried 64-bit
+    // VGPR pointer with its own VALU increment per tile -- 12 of the loop's 51 VALU instructions)
+    const int nts = __builtin_amdgcn_readfirstlane(nt);
+    if (nt + 1 < ntD) request(nts + 1, buf ^ 1);  // (uniform)
+    const char* blt = reinterpret_cast<const char*>(bl + nts * 16);  // (scalar bases)
+    const char* xt = reinterpret_cast<const char*>(x + nts * 16);
+    const float bias = *reinterpret_cast<const float*>(blt + i4);
+    float tv[4];  // targets: requested here, first USED in the epilogue (a use up here would wait for the piece requests too)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[r] = *reinterpret_cast<const float*>(xt + xo[r]);
+    // four independent chains (two -- a dependent MFMA 64 cycles after its predecessor -- measured slower: 337 -> 356 us)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const float* brow = bt + buf * (16 * H) + i * H + 4 * q;
+    // B fragments PF chunks ahead of the MFMAs that use them
+    constexpr int PF = MV_DBR_PF;
+    f32x4 bq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) bq[u] = *reinterpret_cast<const f32x4*>(brow + 16 * (u < NCH ? u : 0));
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += PF) {
+      f32x4 bn[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) bn[u] = *reinterpret_cast<const f32x4*>(brow + 16 * (c0 + PF + u < NCH ? c0 + PF + u : 0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (c0 + u < NCH) {
+          acc0 = mfma16(a[c0 + u][0], bq[u][0], acc0);
+          acc1 = mfma16(a[c0 + u][1], bq[u][1], acc1);
+          acc2 = mfma16(a[c0 + u][2], bq[u][2], acc2);
+          acc3 = mfma16(a[c0 + u][3], bq[u][3], acc3);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) bq[u] = bn[u];
+    }
+    const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // F.binary_cross_entropy_with_logits: (1 - t) y + softplus(-y) = (1 - t) y - min(y, 0) + log(1 + exp(-|y|)), the
+      // two transcendentals as bare v_exp_f32 / v_log_f32 (their arguments need no range handling here; |error| per term
+      // ~1e-7 against a row sum of several hundred)
+      const float y = acc[r] + bias;
+#ifdef MV_DBR_NOEPI
+      rs[r] += (1.f - tv[r]) * y;
+#else
+      const float e = __builtin_amdgcn_exp2f(fabsf(y) * -1.4426950408889634f);      // exp(-|y|) in (0, 1]
+      const float l2 = __builtin_amdgcn_logf(1.f + e);                              // log2(1 + e): argument in [1, 2]
+      rs[r] += fmaf(l2, 0.6931471805599453f, fmaf(1.f - tv[r], y, -fminf(y, 0.f)));
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next row block has landed (requested ~100 MFMAs ago)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float tot = row16_sum(rs[r]);
+    if (i == 0 && r0 + 4 * q + r < rows) out[r0 + 4 * q + r] = tot;
+  }
+}
+
+extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, const float* bd0, const float* Wl,
+                                    const float* bl, const float* x, int64_t x_rows, int H, int D, float* out,
+                                    void* stream) {
+  if (!z || !Wd0 || !bd0 || !Wl || !bl || !x || !out || rows < 0 || Z < 1 || x_rows < 1 || H < 1 || D < 1)
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  if (rows == 0) return 0;
+  const int nch = H >> 4;
+  if ((H & 15) || (D & 15) || Z > 16 || !aligned16(Wl) || !(nch == 1 || nch == 4 || nch == 8 || nch == 16 || nch == 25 || nch == 32))
+    return MVAE_E_UNSUPPORTED;  // (quietly: the caller takes the three-launch route, mvae_linear_forward x 2 + mvae_bce_rows)
+  const int zp = Z <= 8 ? 8 : 16;
+  const size_t lds = ((size_t)2 * 16 * H + (size_t)H * zp + H) * sizeof(float);
+  const dim3 grid((unsigned)((rows + 63) / 64));
+#define MV_DBR(NCH_, ZP_)                                                                                            \
+  do {                                                                                                               \
+    static bool set_ = false;                                                                                        \
+    if (!set_ && lds > 64 * 1024) {                                                                                  \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_bce_rows<NCH_, ZP_>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e_ != hipSuccess) return hip_fail(e_, "hipFuncSetAttribute(k_decode_bce_rows)");                           \
+      set_ = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((k_decode_bce_rows<NCH_, ZP_>), grid, dim3(256), lds, (hipStream_t)stream, z, rows, Z, Wd0,    \
+                       bd0, Wl, bl, x, x_rows, D, out);                                                              \
+  } while (0)
+#define MV_DBR_Z(NCH_) do { if (zp == 8) MV_DBR(NCH_, 8); else MV_DBR(NCH_, 16); } while (0)
+  if (nch == 1) MV_DBR_Z(1); else if (nch == 4) MV_DBR_Z(4); else if (nch == 8) MV_DBR_Z(8); else if (nch == 16) MV_DBR_Z(16); else if (nch == 25) MV_DBR_Z(25); else MV_DBR_Z(32);
+#undef MV_DBR_Z
+#undef MV_DBR
+  LAUNCH_CHECK("decode + bce rows launch");
+  return 0;
+}
+
 extern "C" int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi,
                                   int n, int B, void* stream) {
   if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1)

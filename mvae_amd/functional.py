@@ -552,6 +552,23 @@ def bce_rows(logits: Tensor, x: Tensor) -> Tensor:
     return out
 
 
+def decode_bce_rows(z: Tensor, w_d0: Tensor, b_d0: Tensor, w_l: Tensor, b_l: Tensor, x: Tensor) -> Optional[Tensor]:
+    """bce_rows(linear(relu(linear(z, w_d0, b_d0)), w_l, b_l), x) in one launch (mvae_decode_bce_rows: the hidden layer and the
+    logits never reach memory).  z [..., Z], x [x_rows, D] broadcast over z's leading sample dims.  None if the shape is outside
+    what that kernel covers -- the caller then composes the three operators."""
+    z, x = _f32c(z), _f32c(x)
+    w_d0, b_d0, w_l, b_l = _f32c(w_d0.detach()), _f32c(b_d0.detach()), _f32c(w_l.detach()), _f32c(b_l.detach())
+    Z, H, D = z.shape[-1], w_d0.shape[0], w_l.shape[0]
+    rows, x_rows = z.numel() // Z, x.numel() // D
+    out = z.new_empty(z.shape[:-1])
+    rc = load().mvae_decode_bce_rows(ptr(z), rows, Z, ptr(w_d0), ptr(b_d0), ptr(w_l), ptr(b_l), ptr(x), x_rows, H, D, ptr(out),
+                                     stream_ptr(z.device))
+    if rc == -2:  # MVAE_E_UNSUPPORTED
+        return None
+    check(rc)
+    return out
+
+
 def scale_rows(g: Tensor, sc: Tensor) -> Tensor:
     g, sc = _f32c(g), _f32c(sc)
     out = torch.empty_like(g)

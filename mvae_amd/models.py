@@ -170,6 +170,10 @@ class ModelVAE(nn.Module):
     def decode(self, concat_z: Tensor) -> Tensor:
         raise NotImplementedError
 
+    def _decode_bce_rows(self, concat_z: Tensor, x: Tensor) -> Tensor:
+        """sum_j BCE(decode(z)[..., j], x[..., j]) of log_likelihood (vae.py:98-109)."""
+        return Fn.bce_rows(self.decode(concat_z), x)
+
     def _wrap_outputs(self, out, heads: Optional[Tensor] = None) -> Outputs:
         eng = self._need_engine()
         reps = []
@@ -246,12 +250,12 @@ class ModelVAE(nn.Module):
         heads = Fn.linear_forward(h, P["w_heads"], P["b_heads"])
         co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=False, want_log_probs=True)
         concat_z = co["z"]  # [n, B, Z]
-        logits = self.decode(concat_z)  # [n, B, D]
-        bce = Fn.bce_rows(logits, x)  # [n, B] without materialising x.repeat
+        bce = self._decode_bce_rows(concat_z, x)  # [n, B] without materialising x.repeat
         log_p_z, log_q_z_x = co["log_p"].sum(dim=0), co["log_q"].sum(dim=0)
         log_p_x, mi = Fn.loglik_reduce(bce, log_p_z, log_q_z_x)
         # cov_norm (vae.py:119-121): mean_n[(x - mean_x)^T (z_n - mean_z_n)] = (x - mean_x)^T mean_n(z_n - mean_z_n)
-        zc = (concat_z - concat_z.mean(dim=1, keepdim=True)).mean(dim=0)
+        zn = concat_z.mean(dim=0)  # mean_n(z_n - mean_b z_n) = mean_n z_n - mean_b mean_n z_n: one pass over the samples
+        zc = zn - zn.mean(dim=0, keepdim=True)
         xc = x - x.mean(dim=0, keepdim=True)
         cov, _, _ = Fn.linear_backward(xc, torch.zeros(zc.shape[1], xc.shape[1], device=self.device), zc,
                                        need_dx=False)
@@ -346,6 +350,13 @@ class FeedForwardVAE(ModelVAE):
         h = Fn.linear(concat_z, self.fc_d0.weight, self.fc_d0.bias, relu=True)
         return Fn.linear(h, self.fc_logits.weight, self.fc_logits.bias)
 
+    def _decode_bce_rows(self, concat_z: Tensor, x: Tensor) -> Tensor:
+        # the fused launch (hidden layer and logits stay on chip) for the shapes it covers, else the three operators
+        out = None
+        if not Fn._FLOAT64_CHAIN and concat_z.shape[-1] <= 16:
+            out = Fn.decode_bce_rows(concat_z, self.fc_d0.weight, self.fc_d0.bias, self.fc_logits.weight, self.fc_logits.bias, x)
+        return super()._decode_bce_rows(concat_z, x) if out is None else out
+
 
 class ConvolutionalVAE(ModelVAE):
     """conv_vae.py:28-79 (BASELINE config [4], CIFAR shapes): 3 x Conv(k4,s2,p1) encoder, Linear + 3 x ConvTranspose
@@ -399,7 +410,8 @@ class ConvolutionalVAE(ModelVAE):
         step = max(1, max_rows // B)
         bce = torch.cat([Fn.bce_rows(eng.decode(concat_z[i:i + step]), x) for i in range(0, n, step)], dim=0)  # [n, B]
         log_p_x, mi = Fn.loglik_reduce(bce, co["log_p"].sum(dim=0), co["log_q"].sum(dim=0))
-        zc = (concat_z - concat_z.mean(dim=1, keepdim=True)).mean(dim=0)
+        zn = concat_z.mean(dim=0)  # mean_n(z_n - mean_b z_n) = mean_n z_n - mean_b mean_n z_n: one pass over the samples
+        zc = zn - zn.mean(dim=0, keepdim=True)
         xc = x - x.mean(dim=0, keepdim=True)
         cov, _, _ = Fn.linear_backward(xc, torch.zeros(zc.shape[1], xc.shape[1], device=self.device), zc,
                                        need_dx=False)

@@ -340,3 +340,34 @@ def test_export_representations(dev, tmp_path):
     assert h.shape == (10, 3) and torch.load(os.path.join(rep, "eval_total_0.pt")).shape == (10, 6)
     R = float(m.components[0].manifold.radius)
     assert torch.allclose(-h[:, 0]**2 + (h[:, 1:]**2).sum(-1), torch.full((10,), -R * R), rtol=1e-4)  # on the hyperboloid
+
+
+@pytest.mark.parametrize("rows,xr,Z,H,D", [(3 * 128, 128, 6, 400, 784), (70, 7, 10, 128, 96), (64, 64, 3, 16, 32),
+                                           (500, 25, 16, 64, 48), (129, 3, 8, 256, 160), (40, 40, 2, 512, 64)])
+def test_fused_decoder_bce_rows_equals_the_three_operators(dev, rows, xr, Z, H, D):
+    """mvae_decode_bce_rows (the log-likelihood estimator's decoder + BCE in one launch, vae.py:98-109) against the composed
+    operators it replaces (themselves pinned to the reference's vectors above) and against float64."""
+    from mvae_amd import functional as Fn
+    gen = torch.Generator().manual_seed(rows + H)
+    z = torch.randn(rows // xr, xr, Z, generator=gen)
+    w0, b0 = torch.randn(H, Z, generator=gen) * 0.7, torch.randn(H, generator=gen) * 0.3
+    wl, bl = torch.randn(D, H, generator=gen) * 0.2, torch.randn(D, generator=gen) * 0.3
+    x = (torch.rand(xr, D, generator=gen) < 0.4).float()
+    zd, xd = z.to(dev), x.to(dev)
+    fused = Fn.decode_bce_rows(zd, w0.to(dev), b0.to(dev), wl.to(dev), bl.to(dev), xd)
+    assert fused is not None, "shape inside the fused kernel's coverage"
+    hd = Fn.linear_forward(zd.reshape(-1, Z), w0.to(dev), b0.to(dev), relu=True)
+    composed = Fn.bce_rows(Fn.linear_forward(hd, wl.to(dev), bl.to(dev)).view(rows // xr, xr, D), xd)
+    y = torch.relu(z.double() @ w0.double().T + b0.double()) @ wl.double().T + bl.double()
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(y, x.double().expand_as(y), reduction="none").sum(-1)
+    assert_close(_cpu(fused), ref.numpy(), 1e-5, "fused vs float64")
+    assert_close(_cpu(fused), _cpu(composed), 1e-5, "fused vs composed")
+
+
+def test_fused_decoder_bce_rows_declines_other_shapes(dev):
+    from mvae_amd import functional as Fn
+    z = torch.randn(4, 8, 6).to(dev)
+    assert Fn.decode_bce_rows(z, torch.randn(48, 6).to(dev), torch.randn(48).to(dev), torch.randn(32, 48).to(dev),
+                              torch.randn(32).to(dev), torch.rand(8, 32).to(dev)) is None      # H = 48
+    assert Fn.decode_bce_rows(z, torch.randn(64, 6).to(dev), torch.randn(64).to(dev), torch.randn(30, 64).to(dev),
+                              torch.randn(30).to(dev), torch.rand(8, 30).to(dev)) is None      # D % 16 != 0
