@@ -43,6 +43,11 @@ timeout 600 python bench.py --no-cpu-baseline --config conv --gpus 1 --steps 20 
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model e6 --fixed-curvature > $OUT/bench_e6.json 2>&1
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --force-dp > $OUT/bench_forced_dp.json 2>&1   # world 1, exchange forced (librccl)
 timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --model h40 --steps 500 --warmup 50 > $OUT/bench_h40.json 2>&1
+# 6. the log-likelihood estimator (scope row f-1): kernel stats of one call sequence, the counters of its fused decoder launch
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loglik -o ll -- python $ROOT/tools/bench_ll.py > $OUT/loglik.log 2>&1)
+bash $ROOT/tools/pmc_decode_bce.sh ${TAG}_loglik > $OUT/loglik_pmc.log 2>&1
+cp $ROOT/gpurun_out/prof_${TAG}_loglik/pmc.txt $OUT/loglik_pmc.txt 2>/dev/null
+timeout 120 python tools/bench_decode_bce.py > $OUT/loglik_decoder.txt 2>&1
 # keep only the small summaries (the traces are large)
 (cd /tmp && rm -rf $OUT/epoch && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/epoch -o epoch -- python $ROOT/tools/bench_epoch.py > $OUT/epoch.log 2>&1)   # launch list of an epoch: no prepare launch per step
 timeout 300 python tools/bench_epoch.py > $OUT/bench_epoch.txt 2>&1   # a 60000-image MNIST epoch through the device-side input pipeline
