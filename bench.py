@@ -539,11 +539,32 @@ def loglik_leg(dev, n=500, iters=10):
     Z = m.total_z_dim
     flops = 2.0 * n * B * (Z * H + H * D) + 2.0 * B * (D * H + H * 2 * Z)
     tf = flops / dt / 1e12
+    # the dominant launch alone (the decoder + per-row BCE of the n * B sampled rows: mvae_decode_bce_rows), HIP events on
+    # the stream it is launched on; None if the shape fell back to the three generic operators
+    kern = None
+    zs = torch.randn(n, B, Z, device=dev)
+    if Fn.decode_bce_rows(zs, m.fc_d0.weight, m.fc_d0.bias, m.fc_logits.weight, m.fc_logits.bias, x) is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ks = []
+        for _ in range(5):
+            e0.record()
+            for _ in range(iters):
+                Fn.decode_bce_rows(zs, m.fc_d0.weight, m.fc_d0.bias, m.fc_logits.weight, m.fc_logits.bias, x)
+            e1.record()
+            torch.cuda.synchronize()
+            ks.append(e0.elapsed_time(e1) / iters)
+        kms = sorted(ks)[len(ks) // 2]
+        kfl = 2.0 * n * B * (Z * H + H * D)
+        kern = {"kernel": "k_decode_bce_rows: relu(z W_d0^T + b) W_logits^T + b -> BCE row sums, hidden layer and logits on chip",
+                "kernel_ms": kms, "kernel_flops": kfl, "kernel_achieved_TFLOPs": kfl / kms / 1e9,
+                "kernel_mfma_frac": kfl / kms / 1e9 / F32_MFMA_PEAK_TF,
+                "kernel_algorithmic_bytes": 4.0 * (n * B * (Z + 1) + H * (Z + 1) + D * (H + 1) + B * D),
+                "counters": "profiles/r05_loglik_decoder_pmc.txt"}
     return {"metric": f"IWAE log-likelihood batches/sec (B={B}, n={n}) MNIST {MODEL}", "value": 1.0 / dt, "unit": "batches/sec",
             "ms_per_batch": dt * 1e3, "n": n, "batch": B, "dtype": "f32", "timed_repeats": 5, "iters_per_repeat": iters,
             "repeat_ms_per_batch": {"median": dt * 1e3, "first": times[0] * 1e3, "min": min(times) * 1e3, "max": max(times) * 1e3},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
-                         "flops_per_batch": flops},
+            "roofline": dict({"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                              "flops_per_batch": flops, "scope": "the whole log_likelihood call"}, **(kern or {})),
             "baseline_config": "scope row f-1: ModelVAE.log_likelihood (vae.py:82-123), the reference's test-time estimator"}
 
 

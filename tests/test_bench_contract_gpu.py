@@ -59,6 +59,8 @@ def test_bench_line_schema():
     # scope row f-1 as a leg of its own, and the compact summary as the LAST key of the line (what a truncated tail keeps)
     ll = d["configs"]["loglik"]
     assert "error" not in ll and ll["ms_per_batch"] > 0 and 0 < ll["roofline"]["frac"] < 1, ll
+    # its dominant launch (the fused decoder + BCE) timed alone: below the whole call, above half of the f32 MFMA peak
+    assert 0 < ll["roofline"]["kernel_ms"] < ll["ms_per_batch"] and 0.5 < ll["roofline"]["kernel_mfma_frac"] < 1, ll["roofline"]
     assert list(d)[-1] == "configs_summary"
     cs = d["configs_summary"]
     assert len(json.dumps(cs)) <= 700, len(json.dumps(cs))
