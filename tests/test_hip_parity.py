@@ -516,8 +516,9 @@ def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkey
     order, 2e-5 of each tensor's scale), for: the BASELINE shapes, B = 256 (two fragment batches), z_dim 6 / 2 (scalar
     epilogues), z_dim 4, H = 384 (launch 1's grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle
     wave in a row of tiles: the small weight gradients share their waves), a small model, and the block-forward shapes (many
-    small components, BASELINE config [3]: the round-4 launches with dz from partial MFMA tiles of launch 4); fused step and the
-    gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
+    small components, BASELINE config [3]: dz from partial MFMA tiles of launch 4, dh / dhd / dheads / hd in fragment order only,
+    launch 6 = k_enc_bwd3 with the bias gradients as column sums of its fragments, the statistics job in launch 5; MVAE_NO_LITE=1
+    switches all of that off too); fused step and the gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
     from oracle import model as M
