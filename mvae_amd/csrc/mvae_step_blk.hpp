@@ -241,10 +241,13 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
   const float* zrow = z + (size_t)(mt * 16 + i) * ldz;
   float4 za[4], wb[4][4];
   float bdv[4];
+  // (16-wide K chunks past z_dim are not requested at all -- uniform guards: at ~36 cycles per wave-level request the 30
+  // requests per wave of this phase are the kernel's first ~3.5 us, and for z_dim 48 a quarter of them fetched nothing used)
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
     const int k = kc * 16 + q * 4;
-    za[kc] = *reinterpret_cast<const float4*>(zrow + (k < Z ? k : 0));
+    za[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kc * 16 < Z) za[kc] = *reinterpret_cast<const float4*>(zrow + (k < Z ? k : 0));
   }
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       const int k = kc * 16 + q * 4;
-      wb[gq][kc] = *reinterpret_cast<const float4*>(wrow + (k < Z ? k : 0));
+      wb[gq][kc] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kc * 16 < Z) wb[gq][kc] = *reinterpret_cast<const float4*>(wrow + (k < Z ? k : 0));
     }
     bdv[gq] = bd0[cc * 16 + i];
   }
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
   lds_barrier();
   if (lead) {
     if (hdF) {  // (uniform) fragment order only: every later reader (launches 4 and 5) takes fragments
+      // (every pair workgroup storing one tile instead of the lead workgroup all 25: no faster, 36.65 vs 36.74 us per step)
       for (int e = tid; e < nchunks * 64; e += 512) {
         const int c = e >> 6, l = e & 63;
         const float* src = hd_s + (4 * (l >> 4)) * ld + 16 * c + (l & 15);
