@@ -249,6 +249,7 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
     za[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kc * 16 < Z) za[kc] = *reinterpret_cast<const float4*>(zrow + (k < Z ? k : 0));
   }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // (scalar guards below: chunks this wave does not have)
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int c = wave + 8 * gq;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
     for (int kc = 0; kc < 4; ++kc) {
       const int k = kc * 16 + q * 4;
       wb[gq][kc] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kc * 16 < Z) wb[gq][kc] = *reinterpret_cast<const float4*>(wrow + (k < Z ? k : 0));
+      if (kc * 16 < Z && wave_s + 8 * gq < nchunks) wb[gq][kc] = *reinterpret_cast<const float4*>(wrow + (k < Z ? k : 0));
     }
     bdv[gq] = bd0[cc * 16 + i];
   }
@@ -267,8 +268,11 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
   for (int gq = 0; gq < 4; ++gq) {
     const int c = wave + 8 * gq;
     const int k = ((c < nchunks ? c : 0) << 4) + (q << 2);
-    w1[gq] = *reinterpret_cast<const float4*>(Wl + (size_t)(nt * 16 + i) * H + k);
-    w2[gq] = *reinterpret_cast<const float4*>(Wl + (size_t)((two ? nt + 1 : nt) * 16 + i) * H + k);
+    w1[gq] = w2[gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave_s + 8 * gq < nchunks) {
+      w1[gq] = *reinterpret_cast<const float4*>(Wl + (size_t)(nt * 16 + i) * H + k);
+      w2[gq] = *reinterpret_cast<const float4*>(Wl + (size_t)((two ? nt + 1 : nt) * 16 + i) * H + k);
+    }
   }
   const int nt_ep = (tid < 256 || !two) ? nt : nt + 1;
   const int m_ep = mt * 16 + ((tid & 255) >> 4), n_ep = nt_ep * 16 + (tid & 15);
