@@ -506,6 +506,16 @@ int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, 
  * bce, log_p, log_q: [n, B]. */
 int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi, int n,
                        int B, void* stream);
+/* The same with the per-component terms added up inside -- log_p / log_q [ncomp][n][B] as mvae_component_forward writes
+ * them -- and, from the same pass, zmean[b][j] = mean_n z[n][b][j] (z [n][B][Z], Z <= 16; zmean NULL: skipped). */
+int mvae_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q, int ncomp, const float* z, int Z,
+                             float* log_px, float* mi, float* zmean, int n, int B, void* stream);
+/* out[0] = || (x - mean_b x)^T (zmean - mean_b zmean) ||_F : the covariance norm of vae.py:119-121 with the mean over the
+ * samples taken first (zmean from mvae_loglik_reduce_comps).  x [B][D], zmean [B][Z].  workspace: mvae_cov_norm_workspace_floats(D)
+ * floats, ZEROED ONCE by the caller (the last float is an arrival counter the launch re-arms).  Z > 16 or B (16 + Z) floats
+ * beyond 48 KB: MVAE_E_UNSUPPORTED without an error message. */
+int64_t mvae_cov_norm_workspace_floats(int D);
+int mvae_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* workspace, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The whole step.  ModelVAE.train_step, vae.py:149-166; BatchStats, stats.py:144-212; CurvatureOptimizer.step,

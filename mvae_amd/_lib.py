@@ -125,6 +125,9 @@ PROTOTYPES = {
     "mvae_bce_rows": (C.c_int, [_P, _P, _P, _L, _L, _I, _P]),
     "mvae_decode_bce_rows": (C.c_int, [_P, _L, _I, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "mvae_loglik_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "mvae_loglik_reduce_comps": (C.c_int, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "mvae_cov_norm_workspace_floats": (_L, [_I]),
+    "mvae_cov_norm": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "mvae_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc)]),
     "mvae_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "mvae_destroy": (None, [C.c_void_p]),

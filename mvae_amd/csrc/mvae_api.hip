@@ -1166,6 +1166,191 @@ extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const f
   return 0;
 }
 
+// The tail of the estimator in two launches (instead of ~10 small ones of the host framework):
+//  * k_loglik_reduce_comps = k_loglik_reduce with the per-component terms added up inside (log_p / log_q as the component
+//    kernels write them: [ncomp][n][B], components in index order) and, from the same pass over the samples, zmean[b][j] =
+//    mean_n z[n][b][j] (thread sums in sample order, wave sums by DPP, wave totals in wave order: deterministic);
+//  * k_cov_norm: || (x - mean_b x)^T (zmean - mean_b zmean) ||_F  (vae.py:119-121 with the mean over the samples taken first:
+//    mean_n[(x - mean_x)^T (z_n - mean_b z_n)] = (x - mean_x)^T (mean_n z_n - mean_b mean_n z_n)); workgroup = 16 columns of x,
+//    two passes over its [B][16] block held in LDS; the per-workgroup sums of squares are added by the last workgroup to
+//    arrive, in workgroup order.
+__global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q,
+                                                             int ncomp, const float* z, int Z, float* log_px, float* mi,
+                                                             float* zmean, int n, int B) {
+  __shared__ float sm[2][4];
+  __shared__ float zs[4][16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t nB = (size_t)n * B;
+  auto terms = [&](int i, float* a1, float* a2) {
+    const size_t o = (size_t)i * B + b;
+    float lp = 0.f, lq = 0.f;
+    for (int c = 0; c < ncomp; ++c) {
+      lp += log_p[c * nB + o];
+      lq += log_q[c * nB + o];
+    }
+    *a1 = -bce[o] + lp - lq;
+    *a2 = lq - lp;
+  };
+  float m1 = -INFINITY, m2 = -INFINITY;
+  float za[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) za[j] = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    float a1, a2;
+    terms(i, &a1, &a2);
+    m1 = fmaxf(m1, a1);
+    m2 = fmaxf(m2, a2);
+    if (zmean) {
+      const float* zr = z + ((size_t)i * B + b) * Z;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < Z) za[j] += zr[j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    m1 = fmaxf(m1, __shfl_xor(m1, off));
+    m2 = fmaxf(m2, __shfl_xor(m2, off));
+  }
+  if (zmean) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < Z) {  // uniform
+        const float w = wave_sum(za[j]);
+        if ((tid & 63) == 0) zs[tid >> 6][j] = w;
+      }
+  }
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = m1;
+    sm[1][tid >> 6] = m2;
+  }
+  __syncthreads();
+  if (zmean && tid < Z) zmean[(size_t)b * Z + tid] = ((zs[0][tid] + zs[1][tid]) + (zs[2][tid] + zs[3][tid])) / (float)n;
+  m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+  m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    float a1, a2;
+    terms(i, &a1, &a2);
+    s1 += expf(a1 - m1);
+    s2 += expf(a2 - m2);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) {
+    sm[0][tid >> 6] = s1;
+    sm[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float ln = logf((float)n);
+    log_px[b] = m1 + logf((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) - ln;
+    mi[b] = m2 + logf((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) - ln;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* part,
+                                                  unsigned* counter, float* out) {
+  extern __shared__ float dyn[];  // x block [B][16] | zc [B][Z] | column scratch [16][17]
+  __shared__ float zbar[16];
+  __shared__ float red[16][17];
+  __shared__ float wsum[4];
+  __shared__ bool last;
+  float* xs = dyn;
+  float* zc = dyn + (size_t)B * 16;
+  const int tid = threadIdx.x, c = tid & 15, r = tid >> 4;
+  const int d = blockIdx.x * 16 + c;
+  // this workgroup's 16 columns of x, and zmean
+  for (int b = r; b < B; b += 16) xs[b * 16 + c] = d < D ? x[(size_t)b * D + d] : 0.f;
+  for (int e = tid; e < B * Z; e += 256) zc[e] = zmean[e];
+  __syncthreads();
+  // column means (16 partial sums per column in row-group order, then in that order), zbar likewise
+  {
+    float sx = 0.f;
+    for (int b = r; b < B; b += 16) sx += xs[b * 16 + c];
+    red[r][c] = sx;
+    if (tid < Z) {
+      float sz = 0.f;
+      for (int b = 0; b < B; ++b) sz += zc[b * Z + tid];
+      zbar[tid] = sz / (float)B;
+    }
+  }
+  __syncthreads();
+  float xbar = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) xbar += red[k][c];
+  xbar /= (float)B;
+  __syncthreads();
+  // cov[j][c] = sum_b (zmean[b][j] - zbar[j]) (x[b][c] - xbar[c]); thread (r, c) takes the rows b = r, r + 16, ...
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int b = r; b < B; b += 16) {
+    const float xv = xs[b * 16 + c] - xbar;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < Z) acc[j] = fmaf(zc[b * Z + j] - zbar[j], xv, acc[j]);
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < Z) {  // uniform
+      red[r][c] = acc[j];
+      __syncthreads();
+      if (r == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][c];
+        if (d < D) sq = fmaf(v, v, sq);
+      }
+      __syncthreads();
+    }
+  }
+  // (r == 0 lanes = lanes 0..15 of wave 0 hold the columns' sums of squares)
+  if (tid < 64) {
+    const float w = wave_sum(tid < 16 ? sq : 0.f);
+    if (tid == 0) {
+      // (write-through store waited for before the arrival is counted; the last workgroup acquires before it reads the others')
+      store4_wt(part, (size_t)blockIdx.x, w);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+  }
+  __syncthreads();
+  if (last && tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float tot = 0.f;
+    for (unsigned k = 0; k < gridDim.x; ++k) tot += part[k];
+    out[0] = sqrtf(tot);
+    *counter = 0u;  // re-armed for the next call
+  }
+}
+
+extern "C" int mvae_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q, int ncomp, const float* z,
+                                        int Z, float* log_px, float* mi, float* zmean, int n, int B, void* stream) {
+  if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1 || ncomp < 1 || (zmean && (!z || Z < 1 || Z > 16)))
+    return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  hipLaunchKernelGGL(k_loglik_reduce_comps, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q, ncomp, z, Z,
+                     log_px, mi, zmean, n, B);
+  LAUNCH_CHECK("loglik reduce (components) launch");
+  return 0;
+}
+
+extern "C" int64_t mvae_cov_norm_workspace_floats(int D) { return (D + 15) / 16 + 1; }
+
+extern "C" int mvae_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* workspace, float* out,
+                             void* stream) {
+  if (!x || !zmean || !workspace || !out || B < 1 || D < 1 || Z < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
+  const size_t lds = ((size_t)B * 16 + (size_t)B * Z) * sizeof(float);
+  if (Z > 16 || lds > 48 * 1024) return MVAE_E_UNSUPPORTED;  // (quietly: the caller composes the generic operators)
+  const int nwg = (D + 15) / 16;
+  hipLaunchKernelGGL(k_cov_norm, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, zmean, B, D, Z, workspace,
+                     reinterpret_cast<unsigned*>(workspace + nwg), out);
+  LAUNCH_CHECK("cov norm launch");
+  return 0;
+}
+
 extern "C" int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi,
                                   int n, int B, void* stream) {
   if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1)

@@ -607,6 +607,31 @@ def bce_with_logits_rows(logits: Tensor, x: Tensor) -> Tensor:
     return bce_rows(logits.detach(), x)
 
 
+_COV_WS = {}
+
+
+def loglik_tail(bce: Tensor, log_p: Tensor, log_q: Tensor, z: Tensor, x: Tensor):
+    """The tail of ModelVAE.log_likelihood (vae.py:110-121) in two launches: (log p(x) [B], mi [B], cov_norm []) from
+    bce [n, B], the per-component log_p / log_q [ncomp, n, B] (component_forward's outputs, summed inside), the samples
+    z [n, B, Z] and the targets x [B, D].  None if the shape is outside the covariance kernel's coverage."""
+    bce, log_p, log_q, z, x = _f32c(bce), _f32c(log_p), _f32c(log_q), _f32c(z), _f32c(x)
+    n, B = bce.shape
+    Z, D = z.shape[-1], x.shape[-1]
+    if Z > 16 or B * (16 + Z) * 4 > 48 * 1024 or x.shape[0] != B:
+        return None
+    lib = load()
+    key = (bce.device, D)
+    ws = _COV_WS.get(key)
+    if ws is None:  # zeroed once: the launch re-arms its arrival counter
+        ws = _COV_WS[key] = torch.zeros(int(lib.mvae_cov_norm_workspace_floats(D)), device=bce.device)
+    log_px, mi, zmean, cn = bce.new_empty(B), bce.new_empty(B), bce.new_empty(B, Z), bce.new_empty(())
+    st = stream_ptr(bce.device)
+    check(lib.mvae_loglik_reduce_comps(ptr(bce), ptr(log_p), ptr(log_q), log_p.shape[0], ptr(z), Z, ptr(log_px), ptr(mi),
+                                       ptr(zmean), n, B, st))
+    check(lib.mvae_cov_norm(ptr(x), ptr(zmean), B, D, Z, ptr(ws), ptr(cn), st))
+    return log_px, mi, cn
+
+
 def loglik_reduce(bce: Tensor, log_p: Tensor, log_q: Tensor):
     bce, log_p, log_q = _f32c(bce), _f32c(log_p), _f32c(log_q)
     n, B = bce.shape

@@ -251,6 +251,9 @@ class ModelVAE(nn.Module):
         co = Fn.component_forward(eng.layout, heads, eps, eng.params[:eng.layout.n], want_kl=False, want_log_probs=True)
         concat_z = co["z"]  # [n, B, Z]
         bce = self._decode_bce_rows(concat_z, x)  # [n, B] without materialising x.repeat
+        tail = None if Fn._FLOAT64_CHAIN else Fn.loglik_tail(bce, co["log_p"], co["log_q"], concat_z, x)
+        if tail is not None:  # logsumexp rows, mutual information and the covariance norm in two launches
+            return tail
         log_p_z, log_q_z_x = co["log_p"].sum(dim=0), co["log_q"].sum(dim=0)
         log_p_x, mi = Fn.loglik_reduce(bce, log_p_z, log_q_z_x)
         # cov_norm (vae.py:119-121): mean_n[(x - mean_x)^T (z_n - mean_z_n)] = (x - mean_x)^T mean_n(z_n - mean_z_n)
@@ -409,6 +412,9 @@ class ConvolutionalVAE(ModelVAE):
         concat_z = co["z"]  # [n, B, Z]
         step = max(1, max_rows // B)
         bce = torch.cat([Fn.bce_rows(eng.decode(concat_z[i:i + step]), x) for i in range(0, n, step)], dim=0)  # [n, B]
+        tail = Fn.loglik_tail(bce, co["log_p"], co["log_q"], concat_z, x.view(B, -1))
+        if tail is not None:
+            return tail
         log_p_x, mi = Fn.loglik_reduce(bce, co["log_p"].sum(dim=0), co["log_q"].sum(dim=0))
         zn = concat_z.mean(dim=0)  # mean_n(z_n - mean_b z_n) = mean_n z_n - mean_b mean_n z_n: one pass over the samples
         zc = zn - zn.mean(dim=0, keepdim=True)

@@ -371,3 +371,32 @@ def test_fused_decoder_bce_rows_declines_other_shapes(dev):
                               torch.randn(32).to(dev), torch.rand(8, 32).to(dev)) is None      # H = 48
     assert Fn.decode_bce_rows(z, torch.randn(64, 6).to(dev), torch.randn(64).to(dev), torch.randn(30, 64).to(dev),
                               torch.randn(30).to(dev), torch.rand(8, 30).to(dev)) is None      # D % 16 != 0
+
+
+@pytest.mark.parametrize("n,B,Z,D,C", [(500, 128, 6, 784, 3), (8, 32, 6, 32, 3), (37, 100, 12, 200, 5), (5, 4, 6, 3072, 3),
+                                       (300, 1, 3, 17, 1)])
+def test_loglik_tail_equals_the_composed_operators(dev, n, B, Z, D, C):
+    """mvae_loglik_reduce_comps + mvae_cov_norm (the estimator's tail, vae.py:110-121, in two launches) against float64 and
+    against the composition they replace (mvae_loglik_reduce on torch sums, torch means + mvae_linear_backward + norm);
+    twice in a row: the arrival counter of the covariance launch re-arms itself."""
+    from mvae_amd import functional as Fn
+    gen = torch.Generator().manual_seed(n * 7 + B)
+    bce = torch.rand(n, B, generator=gen) * 40 + 500
+    lp, lq = torch.randn(C, n, B, generator=gen) * 2 - 3, torch.randn(C, n, B, generator=gen) * 2 + 1
+    z = torch.randn(n, B, Z, generator=gen)
+    x = (torch.rand(B, D, generator=gen) < 0.3).float()
+    for _ in range(2):
+        out = Fn.loglik_tail(bce.to(dev), lp.to(dev), lq.to(dev), z.to(dev), x.to(dev))
+        assert out is not None
+        torch.cuda.synchronize()
+    a = -bce.double() + lp.double().sum(0) - lq.double().sum(0)
+    ref_lp = torch.logsumexp(a, dim=0) - np.log(n)
+    ref_mi = torch.logsumexp(lq.double().sum(0) - lp.double().sum(0), dim=0) - np.log(n)
+    zn = z.double().mean(0)
+    ref_cn = ((x.double() - x.double().mean(0, keepdim=True)).T @ (zn - zn.mean(0, keepdim=True))).norm()
+    assert_close(_cpu(out[0]), ref_lp.numpy(), 1e-5, "log p(x)")
+    assert_close(_cpu(out[1]), ref_mi.numpy(), 1e-5, "mi", atol_frac=1e-5)
+    assert_close(float(out[2]), float(ref_cn), 1e-4, "cov norm", atol_frac=1e-5)
+    lp2, mi2 = Fn.loglik_reduce(bce.to(dev), lp.to(dev).sum(dim=0), lq.to(dev).sum(dim=0))
+    assert_close(_cpu(out[0]), _cpu(lp2), 1e-5, "log p(x) vs mvae_loglik_reduce")
+    assert_close(_cpu(out[1]), _cpu(mi2), 1e-5, "mi vs mvae_loglik_reduce", atol_frac=1e-5)
