@@ -1195,12 +1195,28 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
   float za[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) za[j] = 0.f;
-  for (int i = tid; i < n; i += 256) {
+  // the terms of this thread's first four samples stay in registers (n <= 1024: all of them -- one pass over memory, the
+  // four samples' requests in flight together)
+  float k1[4], k2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid + 256 * u;
+    k1[u] = k2[u] = -INFINITY;
+    if (i < n) terms(i, &k1[u], &k2[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    m1 = fmaxf(m1, k1[u]);
+    m2 = fmaxf(m2, k2[u]);
+  }
+  for (int i = tid + 1024; i < n; i += 256) {
     float a1, a2;
     terms(i, &a1, &a2);
     m1 = fmaxf(m1, a1);
     m2 = fmaxf(m2, a2);
-    if (zmean) {
+  }
+  if (zmean) {
+    for (int i = tid; i < n; i += 256) {  // (sample order per thread as before)
       const float* zr = z + ((size_t)i * B + b) * Z;
 #pragma unroll
       for (int j = 0; j < 16; ++j)
@@ -1230,7 +1246,13 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
   m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
-  for (int i = tid; i < n; i += 256) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (tid + 256 * u < n) {  // (k = -inf past n would add exp(-inf) = 0 as well; the guard keeps NaN maxima out)
+      s1 += expf(k1[u] - m1);
+      s2 += expf(k2[u] - m2);
+    }
+  for (int i = tid + 1024; i < n; i += 256) {
     float a1, a2;
     terms(i, &a1, &a2);
     s1 += expf(a1 - m1);
@@ -1262,25 +1284,50 @@ __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* z
   const int tid = threadIdx.x, c = tid & 15, r = tid >> 4;
   const int d = blockIdx.x * 16 + c;
   // this workgroup's 16 columns of x, and zmean
-  for (int b = r; b < B; b += 16) xs[b * 16 + c] = d < D ? x[(size_t)b * D + d] : 0.f;
-  for (int e = tid; e < B * Z; e += 256) zc[e] = zmean[e];
+  // (eight rows' requests in flight per thread: as a plain loop every LDS store waited for its own load's round trip)
+  for (int b0 = r; b0 < B; b0 += 128) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      v[u] = x[(size_t)(b < B ? b : 0) * D + (d < D ? d : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      if (b < B) xs[b * 16 + c] = d < D ? v[u] : 0.f;
+    }
+  }
+  for (int e0 = tid; e0 < B * Z; e0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = zmean[e0 + 256 * u < B * Z ? e0 + 256 * u : 0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < B * Z) zc[e0 + 256 * u] = v[u];
+  }
   __syncthreads();
-  // column means (16 partial sums per column in row-group order, then in that order), zbar likewise
+  // column means: thread (r, c) adds the rows b = r, r + 16, ...; the four row groups of a wave meet by lane exchange, the
+  // four waves in LDS (wave order: deterministic); zbar[j]: every thread adds the rows tid, tid + 256, ..., waves likewise
+  const int wave = tid >> 6;
   {
     float sx = 0.f;
     for (int b = r; b < B; b += 16) sx += xs[b * 16 + c];
-    red[r][c] = sx;
-    if (tid < Z) {
-      float sz = 0.f;
-      for (int b = 0; b < B; ++b) sz += zc[b * Z + tid];
-      zbar[tid] = sz / (float)B;
-    }
+    sx += __shfl_xor(sx, 16);
+    sx += __shfl_xor(sx, 32);
+    if ((tid & 63) < 16) red[wave][c] = sx;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < Z) {  // uniform
+        float sz = 0.f;
+        for (int b = tid; b < B; b += 256) sz += zc[b * Z + j];
+        sz = wave_sum(sz);
+        if ((tid & 63) == 0) red[4 + wave][j] = sz;
+      }
   }
   __syncthreads();
-  float xbar = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) xbar += red[k][c];
-  xbar /= (float)B;
+  const float xbar = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / (float)B;
+  if (tid < Z) zbar[tid] = ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])) / (float)B;
   __syncthreads();
   // cov[j][c] = sum_b (zmean[b][j] - zbar[j]) (x[b][c] - xbar[c]); thread (r, c) takes the rows b = r, r + 16, ...
   float acc[16];
@@ -1292,22 +1339,28 @@ __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* z
     for (int j = 0; j < 16; ++j)
       if (j < Z) acc[j] = fmaf(zc[b * Z + j] - zbar[j], xv, acc[j]);
   }
-  float sq = 0.f;
+  // the 16 row groups of a column: 4 per wave by lane exchange, the 4 waves through LDS (one barrier for all j)
+  float* cv = dyn;  // [4][16][16] over the x block (read for the last time above)
+  __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < Z) {  // uniform
-      red[r][c] = acc[j];
-      __syncthreads();
-      if (r == 0) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][c];
-        if (d < D) sq = fmaf(v, v, sq);
-      }
-      __syncthreads();
+  for (int j = 0; j < 16; ++j)
+    if (j < Z) {
+      float v = acc[j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if ((tid & 63) < 16) cv[(wave * 16 + j) * 16 + c] = v;
     }
+  __syncthreads();
+  float sq = 0.f;
+  if (tid < 16 && d < D) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < Z) {
+        const float v = (cv[(0 * 16 + j) * 16 + c] + cv[(1 * 16 + j) * 16 + c]) + (cv[(2 * 16 + j) * 16 + c] + cv[(3 * 16 + j) * 16 + c]);
+        sq = fmaf(v, v, sq);
+      }
   }
-  // (r == 0 lanes = lanes 0..15 of wave 0 hold the columns' sums of squares)
+  // (lanes 0..15 of wave 0 hold the columns' sums of squares)
   if (tid < 64) {
     const float w = wave_sum(tid < 16 ? sq : 0.f);
     if (tid == 0) {
@@ -1318,12 +1371,18 @@ __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* z
     }
   }
   __syncthreads();
-  if (last && tid == 0) {
+  if (last) {  // (uniform) every thread fetches its share of the partials at once -- one thread adding them in a loop paid one
+               // fabric round trip per workgroup, ~10 us for 49 -- then a fixed tree: wave sums, the four waves in order
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    float tot = 0.f;
-    for (unsigned k = 0; k < gridDim.x; ++k) tot += part[k];
-    out[0] = sqrtf(tot);
-    *counter = 0u;  // re-armed for the next call
+    float v = 0.f;
+    for (unsigned k = tid; k < gridDim.x; k += 256) v += part[k];
+    v = wave_sum(v);
+    if ((tid & 63) == 0) wsum[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+      out[0] = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+      *counter = 0u;  // re-armed for the next call
+    }
   }
 }
 
@@ -1342,8 +1401,9 @@ extern "C" int64_t mvae_cov_norm_workspace_floats(int D) { return (D + 15) / 16 
 extern "C" int mvae_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* workspace, float* out,
                              void* stream) {
   if (!x || !zmean || !workspace || !out || B < 1 || D < 1 || Z < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
-  const size_t lds = ((size_t)B * 16 + (size_t)B * Z) * sizeof(float);
-  if (Z > 16 || lds > 48 * 1024) return MVAE_E_UNSUPPORTED;  // (quietly: the caller composes the generic operators)
+  size_t lds = ((size_t)B * 16 + (size_t)B * Z) * sizeof(float);
+  if (Z > 16 || lds > 48 * 1024) return MVAE_E_UNSUPPORTED;
+  if (lds < 4 * 16 * 16 * sizeof(float)) lds = 4 * 16 * 16 * sizeof(float);  // the column sums of the four waves reuse the block  // (quietly: the caller composes the generic operators)
   const int nwg = (D + 15) / 16;
   hipLaunchKernelGGL(k_cov_norm, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, zmean, B, D, Z, workspace,
                      reinterpret_cast<unsigned*>(workspace + nwg), out);
