@@ -498,7 +498,7 @@ int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows,
 /* The MLP decoder and the per-row BCE in one launch (vae.py:98-109 with ffnn_vae.py:52-60 as `decode`):
  *   out[r] = sum_j binary_cross_entropy_with_logits((relu(z[r] W_d0^T + b_d0) W_l^T + b_l)[j], x[r % x_rows][j])
  * z[rows, Z] (the n * B sampled latents), W_d0[H, Z], W_l[D, H], x[x_rows, D].  Neither the hidden layer nor the logits
- * are written to memory.  H in {16, 64, 128, 256, 400, 512}, D % 16 == 0, Z <= 16, W_l 16-byte aligned; anything else returns
+ * are written to memory.  H in {16, 64, 128, 256, 400, 512}, D % 16 == 0, Z <= 64, W_l 16-byte aligned; anything else returns
  * MVAE_E_UNSUPPORTED without touching `out` (no error message: the caller composes mvae_linear_forward x 2 + mvae_bce_rows). */
 int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, const float* bd0, const float* Wl,
                          const float* bl, const float* x, int64_t x_rows, int H, int D, float* out, void* stream);
@@ -507,12 +507,12 @@ int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, 
 int mvae_loglik_reduce(const float* bce, const float* log_p, const float* log_q, float* log_px, float* mi, int n,
                        int B, void* stream);
 /* The same with the per-component terms added up inside -- log_p / log_q [ncomp][n][B] as mvae_component_forward writes
- * them -- and, from the same pass, zmean[b][j] = mean_n z[n][b][j] (z [n][B][Z], Z <= 16; zmean NULL: skipped). */
+ * them -- and, from the same pass, zmean[b][j] = mean_n z[n][b][j] (z [n][B][Z], Z <= 64; zmean NULL: skipped). */
 int mvae_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q, int ncomp, const float* z, int Z,
                              float* log_px, float* mi, float* zmean, int n, int B, void* stream);
 /* out[0] = || (x - mean_b x)^T (zmean - mean_b zmean) ||_F : the covariance norm of vae.py:119-121 with the mean over the
  * samples taken first (zmean from mvae_loglik_reduce_comps).  x [B][D], zmean [B][Z].  workspace: mvae_cov_norm_workspace_floats(D)
- * floats, ZEROED ONCE by the caller (the last float is an arrival counter the launch re-arms).  Z > 16 or B (16 + Z) floats
+ * floats, ZEROED ONCE by the caller (the last float is an arrival counter the launch re-arms).  Z > 64 or B (16 + Z) floats
  * beyond 48 KB: MVAE_E_UNSUPPORTED without an error message. */
 int64_t mvae_cov_norm_workspace_floats(int D);
 int mvae_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* workspace, float* out, void* stream);

@@ -992,7 +992,7 @@ extern "C" int mvae_bce_rows(const float* logits, const float* x, float* out, in
 #ifndef MV_DBR_PF
 #define MV_DBR_PF 1
 #endif
-template <int NCH, int ZP>  // H = 16 NCH ; z_dim <= ZP
+template <int NCH, int ZP>  // H = 16 NCH ; z_dim in slices of ZP columns
 __global__ __launch_bounds__(256, 2) void k_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0,
                                                             const float* bd0, const float* Wl, const float* bl,
                                                             const float* x, int64_t x_rows, int D, float* out) {
@@ -1021,46 +1021,77 @@ __global__ __launch_bounds__(256, 2) void k_decode_bce_rows(const float* z, int6
                                          (__attribute__((address_space(3))) void*)(bt + buf * (16 * H) + (wave + 4 * u) * 256), 16, 0, 0);
   };
   request(0, 0);
-  float zr[ZP];
-  {
-    const int64_t r = r0 + i < rows ? r0 + i : rows - 1;
-#pragma unroll
-    for (int j = 0; j < ZP; ++j) {
-      const float v = z[r * Z + (j < Z ? j : 0)];
-      zr[j] = j < Z ? v : 0.f;
-    }
-  }
-  for (int e = tid; e < H * ZP; e += 256) {
-    const int k = e / ZP, j = e - k * ZP;
-    const float v = Wd0[(size_t)k * Z + (j < Z ? j : 0)];
-    wd_s[e] = j < Z ? v : 0.f;
-  }
   for (int e = tid; e < H; e += 256) bd_s[e] = bd0[e];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA is invisible to the compiler's LDS dependence tracking)
-  __syncthreads();
-  // hidden layer of this wave's 16 rows, as A fragments: a[c][t] = relu(b_d0[k] + <z[row i], W_d0[k]>), k = 16 c + 4 q + t
+  // hidden layer of this wave's 16 rows, as A fragments: a[c][t] = relu(b_d0[k] + <z[row i], W_d0[k]>), k = 16 c + 4 q + t.
+  // K = z_dim in slices of ZP columns (one slice for z_dim <= ZP; up to four of 16 for the many-component models): per slice
+  // the ZP columns of W_d0 are staged in LDS (zero past z_dim) and this lane's ZP z values sit in registers.
   f32x4 a[NCH];
+  const int64_t zrow = (r0 + i < rows ? r0 + i : rows - 1) * Z;
+  __syncthreads();
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int k = 16 * c + 4 * q + t;
-      float v = bd_s[k];
-#pragma unroll
-      for (int j4 = 0; j4 < ZP; j4 += 4) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wd_s + k * ZP + j4);
-        v = fmaf(zr[j4], w[0], v);
-        v = fmaf(zr[j4 + 1], w[1], v);
-        v = fmaf(zr[j4 + 2], w[2], v);
-        v = fmaf(zr[j4 + 3], w[3], v);
-      }
-      v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
-      // (opaque to the SLP vectorizer: left alone it packs this phase into wide vectors whose shuffles spill ~700 registers,
-      // and the loop's pointers come back from scratch INSIDE the loop, behind the piece requests: 367 -> 616 us)
+      float v = bd_s[16 * c + 4 * q + t];
       asm volatile("" : "+v"(v));
       a[c][t] = v;
     }
+  for (int s0 = 0; s0 < Z; s0 += ZP) {
+    if (s0 > 0) __syncthreads();  // the previous slice has been consumed
+    float zr[ZP];
+#pragma unroll
+    for (int j = 0; j < ZP; ++j) {
+      const float v = z[zrow + (s0 + j < Z ? s0 + j : 0)];
+      zr[j] = s0 + j < Z ? v : 0.f;
+    }
+    // (eight requests in flight per thread: as a plain loop every LDS store waited for its own load's round trip -- 13 to 25
+    // of them per slice)
+    for (int e0 = tid; e0 < H * ZP; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u < H * ZP ? e0 + 256 * u : 0;
+        const int k = e / ZP, j = e - k * ZP;
+        v[u] = Wd0[(size_t)k * Z + (s0 + j < Z ? s0 + j : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < H * ZP) wd_s[e] = s0 + (e % ZP) < Z ? v[u] : 0.f;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (first slice: the DMA is invisible to the compiler's LDS dependence tracking)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 16 * c + 4 * q + t;
+        float v = a[c][t];
+#pragma unroll
+        for (int j4 = 0; j4 < ZP; j4 += 4) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wd_s + k * ZP + j4);
+          v = fmaf(zr[j4], w[0], v);
+          v = fmaf(zr[j4 + 1], w[1], v);
+          v = fmaf(zr[j4 + 2], w[2], v);
+          v = fmaf(zr[j4 + 3], w[3], v);
+        }
+        // (opaque to the SLP vectorizer: left alone it packs this phase into wide vectors whose shuffles spill ~700 registers,
+        // and the loop's pointers come back from scratch INSIDE the loop, behind the piece requests: 367 -> 616 us)
+        asm volatile("" : "+v"(v));
+        a[c][t] = v;
+      }
+    }
   }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = a[c][t];
+      v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+      asm volatile("" : "+v"(v));
+      a[c][t] = v;
+    }
   // targets' rows (x broadcast over the samples) of this lane's four output rows
   unsigned xo[4];
 #pragma unroll
@@ -1141,7 +1172,7 @@ extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const f
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (rows == 0) return 0;
   const int nch = H >> 4;
-  if ((H & 15) || (D & 15) || Z > 16 || !aligned16(Wl) || !(nch == 1 || nch == 4 || nch == 8 || nch == 16 || nch == 25 || nch == 32))
+  if ((H & 15) || (D & 15) || Z > 64 || !aligned16(Wl) || !(nch == 1 || nch == 4 || nch == 8 || nch == 16 || nch == 25 || nch == 32))
     return MVAE_E_UNSUPPORTED;  // (quietly: the caller takes the three-launch route, mvae_linear_forward x 2 + mvae_bce_rows)
   const int zp = Z <= 8 ? 8 : 16;
   const size_t lds = ((size_t)2 * 16 * H + (size_t)H * zp + H) * sizeof(float);
@@ -1174,11 +1205,12 @@ extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const f
 //    mean_n[(x - mean_x)^T (z_n - mean_b z_n)] = (x - mean_x)^T (mean_n z_n - mean_b mean_n z_n)); workgroup = 16 columns of x,
 //    two passes over its [B][16] block held in LDS; the per-workgroup sums of squares are added by the last workgroup to
 //    arrive, in workgroup order.
+template <int ZM>  // z_dim <= ZM
 __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q,
                                                              int ncomp, const float* z, int Z, float* log_px, float* mi,
                                                              float* zmean, int n, int B) {
   __shared__ float sm[2][4];
-  __shared__ float zs[4][16];
+  __shared__ float zs[4][ZM];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t nB = (size_t)n * B;
   auto terms = [&](int i, float* a1, float* a2) {
@@ -1192,9 +1224,9 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
     *a2 = lq - lp;
   };
   float m1 = -INFINITY, m2 = -INFINITY;
-  float za[16];
+  float za[ZM];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) za[j] = 0.f;
+  for (int j = 0; j < ZM; ++j) za[j] = 0.f;
   // the terms of this thread's first four samples stay in registers (n <= 1024: all of them -- one pass over memory, the
   // four samples' requests in flight together)
   float k1[4], k2[4];
@@ -1219,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
     for (int i = tid; i < n; i += 256) {  // (sample order per thread as before)
       const float* zr = z + ((size_t)i * B + b) * Z;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
+      for (int j = 0; j < ZM; ++j)
         if (j < Z) za[j] += zr[j];
     }
   }
@@ -1230,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
   }
   if (zmean) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < ZM; ++j)
       if (j < Z) {  // uniform
         const float w = wave_sum(za[j]);
         if ((tid & 63) == 0) zs[tid >> 6][j] = w;
@@ -1272,10 +1304,12 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
   }
 }
 
+template <int ZM>  // z_dim <= ZM
 __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* zmean, int B, int D, int Z, float* part,
                                                   unsigned* counter, float* out) {
   extern __shared__ float dyn[];  // x block [B][16] | zc [B][Z] | column scratch [16][17]
-  __shared__ float zbar[16];
+  __shared__ float zbar[ZM];
+  __shared__ float zred[4][ZM];
   __shared__ float red[16][17];
   __shared__ float wsum[4];
   __shared__ bool last;
@@ -1317,46 +1351,46 @@ __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* z
     sx += __shfl_xor(sx, 32);
     if ((tid & 63) < 16) red[wave][c] = sx;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < ZM; ++j)
       if (j < Z) {  // uniform
         float sz = 0.f;
         for (int b = tid; b < B; b += 256) sz += zc[b * Z + j];
         sz = wave_sum(sz);
-        if ((tid & 63) == 0) red[4 + wave][j] = sz;
+        if ((tid & 63) == 0) zred[wave][j] = sz;
       }
   }
   __syncthreads();
   const float xbar = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / (float)B;
-  if (tid < Z) zbar[tid] = ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])) / (float)B;
+  if (tid < Z) zbar[tid] = ((zred[0][tid] + zred[1][tid]) + (zred[2][tid] + zred[3][tid])) / (float)B;
   __syncthreads();
   // cov[j][c] = sum_b (zmean[b][j] - zbar[j]) (x[b][c] - xbar[c]); thread (r, c) takes the rows b = r, r + 16, ...
-  float acc[16];
+  float acc[ZM];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int j = 0; j < ZM; ++j) acc[j] = 0.f;
   for (int b = r; b < B; b += 16) {
     const float xv = xs[b * 16 + c] - xbar;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < ZM; ++j)
       if (j < Z) acc[j] = fmaf(zc[b * Z + j] - zbar[j], xv, acc[j]);
   }
   // the 16 row groups of a column: 4 per wave by lane exchange, the 4 waves through LDS (one barrier for all j)
-  float* cv = dyn;  // [4][16][16] over the x block (read for the last time above)
+  float* cv = dyn;  // [4][ZM][16] over the x block (read for the last time above)
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
+  for (int j = 0; j < ZM; ++j)
     if (j < Z) {
       float v = acc[j];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if ((tid & 63) < 16) cv[(wave * 16 + j) * 16 + c] = v;
+      if ((tid & 63) < 16) cv[(wave * ZM + j) * 16 + c] = v;
     }
   __syncthreads();
   float sq = 0.f;
   if (tid < 16 && d < D) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < ZM; ++j)
       if (j < Z) {
-        const float v = (cv[(0 * 16 + j) * 16 + c] + cv[(1 * 16 + j) * 16 + c]) + (cv[(2 * 16 + j) * 16 + c] + cv[(3 * 16 + j) * 16 + c]);
+        const float v = (cv[(0 * ZM + j) * 16 + c] + cv[(1 * ZM + j) * 16 + c]) + (cv[(2 * ZM + j) * 16 + c] + cv[(3 * ZM + j) * 16 + c]);
         sq = fmaf(v, v, sq);
       }
   }
@@ -1388,10 +1422,14 @@ __global__ __launch_bounds__(256) void k_cov_norm(const float* x, const float* z
 
 extern "C" int mvae_loglik_reduce_comps(const float* bce, const float* log_p, const float* log_q, int ncomp, const float* z,
                                         int Z, float* log_px, float* mi, float* zmean, int n, int B, void* stream) {
-  if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1 || ncomp < 1 || (zmean && (!z || Z < 1 || Z > 16)))
+  if (!bce || !log_p || !log_q || !log_px || !mi || n < 1 || B < 1 || ncomp < 1 || (zmean && (!z || Z < 1 || Z > 64)))
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
-  hipLaunchKernelGGL(k_loglik_reduce_comps, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q, ncomp, z, Z,
-                     log_px, mi, zmean, n, B);
+  if (zmean && Z > 16)
+    hipLaunchKernelGGL(k_loglik_reduce_comps<64>, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q, ncomp, z, Z,
+                       log_px, mi, zmean, n, B);
+  else
+    hipLaunchKernelGGL(k_loglik_reduce_comps<16>, dim3(B), dim3(256), 0, (hipStream_t)stream, bce, log_p, log_q, ncomp, z, Z,
+                       log_px, mi, zmean, n, B);
   LAUNCH_CHECK("loglik reduce (components) launch");
   return 0;
 }
@@ -1402,11 +1440,16 @@ extern "C" int mvae_cov_norm(const float* x, const float* zmean, int B, int D, i
                              void* stream) {
   if (!x || !zmean || !workspace || !out || B < 1 || D < 1 || Z < 1) return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   size_t lds = ((size_t)B * 16 + (size_t)B * Z) * sizeof(float);
-  if (Z > 16 || lds > 48 * 1024) return MVAE_E_UNSUPPORTED;
-  if (lds < 4 * 16 * 16 * sizeof(float)) lds = 4 * 16 * 16 * sizeof(float);  // the column sums of the four waves reuse the block  // (quietly: the caller composes the generic operators)
+  if (Z > 64 || lds > 48 * 1024) return MVAE_E_UNSUPPORTED;  // (quietly: the caller composes the generic operators)
+  const size_t zm = Z > 16 ? 64 : 16;
+  if (lds < 4 * zm * 16 * sizeof(float)) lds = 4 * zm * 16 * sizeof(float);  // the column sums of the four waves reuse the block
   const int nwg = (D + 15) / 16;
-  hipLaunchKernelGGL(k_cov_norm, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, zmean, B, D, Z, workspace,
-                     reinterpret_cast<unsigned*>(workspace + nwg), out);
+  if (Z > 16)
+    hipLaunchKernelGGL(k_cov_norm<64>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, zmean, B, D, Z, workspace,
+                       reinterpret_cast<unsigned*>(workspace + nwg), out);
+  else
+    hipLaunchKernelGGL(k_cov_norm<16>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, x, zmean, B, D, Z, workspace,
+                       reinterpret_cast<unsigned*>(workspace + nwg), out);
   LAUNCH_CHECK("cov norm launch");
   return 0;
 }

@@ -617,7 +617,7 @@ def loglik_tail(bce: Tensor, log_p: Tensor, log_q: Tensor, z: Tensor, x: Tensor)
     bce, log_p, log_q, z, x = _f32c(bce), _f32c(log_p), _f32c(log_q), _f32c(z), _f32c(x)
     n, B = bce.shape
     Z, D = z.shape[-1], x.shape[-1]
-    if Z > 16 or B * (16 + Z) * 4 > 48 * 1024 or x.shape[0] != B:
+    if Z > 64 or B * (16 + Z) * 4 > 48 * 1024 or x.shape[0] != B:
         return None
     lib = load()
     key = (bce.device, D)

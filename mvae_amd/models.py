@@ -356,7 +356,7 @@ class FeedForwardVAE(ModelVAE):
     def _decode_bce_rows(self, concat_z: Tensor, x: Tensor) -> Tensor:
         # the fused launch (hidden layer and logits stay on chip) for the shapes it covers, else the three operators
         out = None
-        if not Fn._FLOAT64_CHAIN and concat_z.shape[-1] <= 16:
+        if not Fn._FLOAT64_CHAIN and concat_z.shape[-1] <= 64:
             out = Fn.decode_bce_rows(concat_z, self.fc_d0.weight, self.fc_d0.bias, self.fc_logits.weight, self.fc_logits.bias, x)
         return super()._decode_bce_rows(concat_z, x) if out is None else out
 

@@ -343,7 +343,8 @@ def test_export_representations(dev, tmp_path):
 
 
 @pytest.mark.parametrize("rows,xr,Z,H,D", [(3 * 128, 128, 6, 400, 784), (70, 7, 10, 128, 96), (64, 64, 3, 16, 32),
-                                           (500, 25, 16, 64, 48), (129, 3, 8, 256, 160), (40, 40, 2, 512, 64)])
+                                           (500, 25, 16, 64, 48), (129, 3, 8, 256, 160), (40, 40, 2, 512, 64),
+                                           (256, 128, 48, 400, 784), (70, 7, 20, 128, 96), (64, 64, 64, 64, 32)])
 def test_fused_decoder_bce_rows_equals_the_three_operators(dev, rows, xr, Z, H, D):
     """mvae_decode_bce_rows (the log-likelihood estimator's decoder + BCE in one launch, vae.py:98-109) against the composed
     operators it replaces (themselves pinned to the reference's vectors above) and against float64."""
@@ -374,7 +375,7 @@ def test_fused_decoder_bce_rows_declines_other_shapes(dev):
 
 
 @pytest.mark.parametrize("n,B,Z,D,C", [(500, 128, 6, 784, 3), (8, 32, 6, 32, 3), (37, 100, 12, 200, 5), (5, 4, 6, 3072, 3),
-                                       (300, 1, 3, 17, 1)])
+                                       (300, 1, 3, 17, 1), (50, 128, 48, 784, 18), (9, 16, 33, 48, 4)])
 def test_loglik_tail_equals_the_composed_operators(dev, n, B, Z, D, C):
     """mvae_loglik_reduce_comps + mvae_cov_norm (the estimator's tail, vae.py:110-121, in two launches) against float64 and
     against the composition they replace (mvae_loglik_reduce on torch sums, torch means + mvae_linear_backward + norm);
