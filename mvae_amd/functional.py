@@ -560,6 +560,8 @@ def decode_bce_rows(z: Tensor, w_d0: Tensor, b_d0: Tensor, w_l: Tensor, b_l: Ten
     w_d0, b_d0, w_l, b_l = _f32c(w_d0.detach()), _f32c(b_d0.detach()), _f32c(w_l.detach()), _f32c(b_l.detach())
     Z, H, D = z.shape[-1], w_d0.shape[0], w_l.shape[0]
     rows, x_rows = z.numel() // Z, x.numel() // D
+    if x.numel() * 4 >= 2 ** 32:  # the kernel addresses the targets with 32-bit byte offsets
+        return None
     out = z.new_empty(z.shape[:-1])
     rc = load().mvae_decode_bce_rows(ptr(z), rows, Z, ptr(w_d0), ptr(b_d0), ptr(w_l), ptr(b_l), ptr(x), x_rows, H, D, ptr(out),
                                      stream_ptr(z.device))
