@@ -358,6 +358,11 @@ def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
         prof["latent_dec1_fwd"] = prof.pop("dec1_fwd")
         del prof["latent_fwd"], alg["latent_fwd"], alg["dec1_fwd"]
         prof = {k: prof[k] for k in ("enc_fwd", "latent_dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd")}
+    if prof.get("latent_bwd", 1.0) == 0.0:  # the four-launch step: launches 5 + 6 are ONE launch (k_bwd56)
+        alg["latent_enc_bwd"] = dict(flops=alg["latent_bwd"]["flops"] + alg["enc_bwd"]["flops"],
+                                     bytes=alg["latent_bwd"]["bytes"] + alg["enc_bwd"]["bytes"])
+        prof["latent_enc_bwd"] = prof.pop("enc_bwd")
+        del prof["latent_bwd"], alg["latent_bwd"], alg["enc_bwd"]
     # The headline fraction is the WHOLE STEP against the roofline: SURVEY section 8(d)'s algorithmic bytes / flops of one
     # step (each tensor once: x, eps, and p, m, v, g read + written) over the measured ms_per_step.  `kernel` names the
     # longest launch -- whatever it is -- with its own numbers; every launch is listed in `per_kernel`.
@@ -399,7 +404,8 @@ def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
                      "latent_fwd": [["k_heads_comp"], ["k_latent_fwd", "k_duals_coop"], ["k_latent_fwd"]],
                      "dec1_fwd": [["k_fwd3m"], ["k_dec1_fwd"]], "dec1_bwd": [["k_dec1_bwd"]],
                      "latent_bwd": [["k_latent_bwd2"], ["k_latent_bwd_blk"], ["k_latent_bwd"]],
-                     "enc_bwd": [["k_enc_bwd2"], ["k_enc_bwd3"], ["k_enc_bwd"]]}
+                     "enc_bwd": [["k_enc_bwd2"], ["k_enc_bwd3"], ["k_enc_bwd"]],
+                     "latent_enc_bwd": [["k_bwd56"]]}
 
             def slot_bytes(slot):
                 for group in cands[slot]:

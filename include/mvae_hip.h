@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 10
+#define MVAE_ABI_VERSION 11
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -498,8 +498,9 @@ int mvae_bce_rows(const float* logits, const float* x, float* out, int64_t rows,
 /* The MLP decoder and the per-row BCE in one launch (vae.py:98-109 with ffnn_vae.py:52-60 as `decode`):
  *   out[r] = sum_j binary_cross_entropy_with_logits((relu(z[r] W_d0^T + b_d0) W_l^T + b_l)[j], x[r % x_rows][j])
  * z[rows, Z] (the n * B sampled latents), W_d0[H, Z], W_l[D, H], x[x_rows, D].  Neither the hidden layer nor the logits
- * are written to memory.  H in {16, 64, 128, 256, 400, 512}, D % 16 == 0, Z <= 64, W_l 16-byte aligned; anything else returns
- * MVAE_E_UNSUPPORTED without touching `out` (no error message: the caller composes mvae_linear_forward x 2 + mvae_bce_rows). */
+ * are written to memory.  H in {16, 64, 128, 256, 400, 512}, D % 16 == 0, Z <= 64, W_l 16-byte aligned, targets below 4 GB
+ * (x_rows * D * 4 < 2^32: the kernel addresses them with 32-bit byte offsets); anything else -- and a device that refuses the
+ * kernel's dynamic LDS size -- returns MVAE_E_UNSUPPORTED without touching `out` (no error message: the caller composes mvae_linear_forward x 2 + mvae_bce_rows). */
 int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, const float* bd0, const float* Wl,
                          const float* bl, const float* x, int64_t x_rows, int H, int D, float* out, void* stream);
 /* log_px[b] = logsumexp_n(-bce + log_p - log_q) - log n ; mi[b] = logsumexp_n(log_q - log_p) - log n   (vae.py:113-117)

@@ -2,6 +2,8 @@
 // the reference's guarded scalar functions, the per-component operators, generic dense layers, log-likelihood helpers.
 #include "mvae_common.hpp"
 #include "mvae_coop.hpp"
+#include <atomic>
+constexpr int kMaxDevices = 64;  // per-device "attribute set" flags of the kernels that need more than 64 KB of dynamic LDS
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -942,6 +944,9 @@ __global__ __launch_bounds__(256) void k_loglik_reduce(const float* bce, const f
   __syncthreads();
   m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
   m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+  // torch.logsumexp subtracts 0 instead of an infinite maximum: a column of -inf terms gives -inf, not exp(-inf + inf) = NaN
+  m1 = isinf(m1) ? 0.f : m1;
+  m2 = isinf(m2) ? 0.f : m2;
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
   for (int i = tid; i < n; i += 256) {
@@ -1172,19 +1177,30 @@ extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const f
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   if (rows == 0) return 0;
   const int nch = H >> 4;
+  // (quietly: the caller takes the three-launch route, mvae_linear_forward x 2 + mvae_bce_rows)
   if ((H & 15) || (D & 15) || Z > 64 || !aligned16(Wl) || !(nch == 1 || nch == 4 || nch == 8 || nch == 16 || nch == 25 || nch == 32))
-    return MVAE_E_UNSUPPORTED;  // (quietly: the caller takes the three-launch route, mvae_linear_forward x 2 + mvae_bce_rows)
+    return MVAE_E_UNSUPPORTED;
+  // the kernel addresses the targets with 32-bit BYTE offsets (xo[r]): 4 GB of targets and more are declined here
+  if ((uint64_t)x_rows * (uint64_t)D * 4ull >= (1ull << 32)) return MVAE_E_UNSUPPORTED;
   const int zp = Z <= 8 ? 8 : 16;
   const size_t lds = ((size_t)2 * 16 * H + (size_t)H * zp + H) * sizeof(float);
   const dim3 grid((unsigned)((rows + 63) / 64));
 #define MV_DBR(NCH_, ZP_)                                                                                            \
   do {                                                                                                               \
-    static bool set_ = false;                                                                                        \
-    if (!set_ && lds > 64 * 1024) {                                                                                  \
+    /* the attribute is per DEVICE on ROCm: one flag per device ordinal (a failure declines the call: the caller then \
+       composes the generic operators) */                                                                            \
+    static std::atomic<bool> set_[kMaxDevices];                                                                      \
+    int dev_ = 0;                                                                                                    \
+    (void)hipGetDevice(&dev_);                                                                                       \
+    const bool tracked_ = dev_ >= 0 && dev_ < kMaxDevices;                                                           \
+    if (lds > 64 * 1024 && !(tracked_ && set_[dev_].load(std::memory_order_acquire))) {                              \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_bce_rows<NCH_, ZP_>),              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-      if (e_ != hipSuccess) return hip_fail(e_, "hipFuncSetAttribute(k_decode_bce_rows)");                           \
-      set_ = true;                                                                                                   \
+      if (e_ != hipSuccess) {                                                                                        \
+        (void)hipGetLastError();                                                                                     \
+        return MVAE_E_UNSUPPORTED;                                                                                   \
+      }                                                                                                              \
+      if (tracked_) set_[dev_].store(true, std::memory_order_release);                                               \
     }                                                                                                                \
     hipLaunchKernelGGL((k_decode_bce_rows<NCH_, ZP_>), grid, dim3(256), lds, (hipStream_t)stream, z, rows, Z, Wd0,    \
                        bd0, Wl, bl, x, x_rows, D, out);                                                              \
@@ -1276,6 +1292,9 @@ __global__ __launch_bounds__(256) void k_loglik_reduce_comps(const float* bce, c
   if (zmean && tid < Z) zmean[(size_t)b * Z + tid] = ((zs[0][tid] + zs[1][tid]) + (zs[2][tid] + zs[3][tid])) / (float)n;
   m1 = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
   m2 = fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]));
+  // torch.logsumexp subtracts 0 instead of an infinite maximum: a column of -inf terms gives -inf, not exp(-inf + inf) = NaN
+  m1 = isinf(m1) ? 0.f : m1;
+  m2 = isinf(m2) ? 0.f : m2;
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll

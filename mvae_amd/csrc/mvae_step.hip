@@ -34,6 +34,19 @@ __device__ __forceinline__ void job_step_stats(float* sm, const float* bce_part,
                                                float beta, int B, int ntD, int ncomp);
 #include "mvae_step_blk.hpp"
 
+// ---- the four-launch step (k_bwd56 below): what the forward launch and launch 4 hand to it
+constexpr int kRecVecMax = 3;   // 16-byte vectors per dual record: {d kl, d z_0 .. d z_{A-1}}, A <= 9 on the fused-forward path
+constexpr int kRecRad = 8;      // radius-direction records per row (ncomp <= 8 on that path)
+constexpr double kDzScale = 274877906944.0;  // 2^38: dz partial sums as 64-bit fixed point (|partial| < 2^19, 25 .. 32 of them)
+constexpr float kDzLimit = 524288.f;         // 2^19
+struct Rec4Args {
+  float* recH;        // head-direction records in the consumer's lane order (NULL: the records go to `duals`)
+  float* recR;        // radius-direction records [B][kRecRad][NV] vectors
+  long long* dzfix;   // [B][8] fixed-point sums of dz, then one unsigned: the overflow / non-finite mark
+  float* gF;          // g in fragment order (NULL: the dW_logits tiles read it row-major)
+  int NV;             // vectors per record, (max ambient dim + 1 + 3) / 4
+};
+
 // ================================================================================================ the fused step
 struct mvae_ctx {
   mvae_model_desc d;
@@ -45,6 +58,10 @@ struct mvae_ctx {
   int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_dirtab, o_total;
   int64_t o_hdF, o_xF, o_hF, o_dhdF, o_zF, o_dheadsF, o_dhF;  // fragment-order operands of the lite backward (mvae_common.hpp: frag_off)
   int64_t o_dzp, o_dheads16, o_whF;  // [B][H/16][8] partial dz products of launch 4's tiles; dheads as [B][16] (zero-padded); W_heads snapshot
+  int64_t o_recH, o_recR, o_dzfix, o_gF;  // the four-launch step: dual records per head column / radius, fixed-point dz sums, g in fragment order
+  int rec_nv;                        // 16-byte vectors per dual record there: (max ambient dimension + 1 + 3) / 4
+  bool five_launch;                  // MVAE_STEP5=1: the lite backward as launches 5' + 6' (k_latent_bwd2, k_enc_bwd2) instead of k_bwd56
+  bool gf;                           // MVAE_GF=1: k_fwd23 also writes g in fragment order for k_bwd56's dW_logits tiles
   bool no_lite;                      // MVAE_NO_LITE=1: the fused-forward shapes keep the round-4 backward launches (A/B measurements)
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
   bool no_fwd23;         // MVAE_NO_FWD23=1: keep launches 2 and 3 separate (A/B measurements)
@@ -102,6 +119,10 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   c->o_dzp = take(B * (int64_t)c->nt_h * 64);  // [B][H/16][8] (lite) | [B/16][H/16][z tiles <= 4][64][4] (block backward)
   c->o_dheads16 = take(B * 16);
   c->o_whF = take((int64_t)c->nt_h * 256);
+  c->o_recH = take(B * 64 * kRecVecMax);
+  c->o_recR = take(B * kRecRad * 4 * kRecVecMax);
+  c->o_dzfix = take(B * 16 + 64);  // [B][8] 64-bit sums + the overflow mark
+  c->o_gF = take(B * D);
   c->o_total = o;
 }
 
@@ -180,6 +201,18 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->blk_fwd = !(bf && bf[0] == '0');
   const char* nl = getenv("MVAE_NO_LITE");
   c->no_lite = nl && nl[0] && nl[0] != '0';
+  const char* s5 = getenv("MVAE_STEP5");
+  c->five_launch = s5 && s5[0] && s5[0] != '0';
+  const char* gfe = getenv("MVAE_GF");
+  c->gf = gfe && gfe[0] && gfe[0] != '0';
+  {
+    int amax = 1;
+    for (int i = 0; i < desc->ncomp; ++i) {
+      const int A = ambient_dim(desc->comps[i].kind, desc->comps[i].true_dim);
+      amax = A > amax ? A : amax;
+    }
+    c->rec_nv = (amax + 1 + 3) / 4;
+  }
   c->groups_ok = build_groups(c->t, &c->gt);
   const char* nc = getenv("MVAE_NO_COOP");
   c->coop = bucket_of(c->dmax) > 8 && coop_eligible(c->t) && !(nc && nc[0] && nc[0] != '0');
@@ -628,7 +661,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
                                                float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
                                                float* kl_user, float* hd, float* g, float* bce_part,
                                                float* logits_user, int B, int H, int D, int NH, int Z, float* duals, float* zF,
-                                               float* hdF) {
+                                               float* hdF, Rec4Args r4) {
   // dynamic LDS: hd_s[16][ld] | wl_s[32][ld] | wd_s[H][8] | bd_s[H]     (ld = H + 4: conflict-free ds_read_b128 of the
   // 16 rows an MFMA operand fetch touches)
   extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -849,12 +882,39 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       const mvae_component_desc c = t.c[mine];
       float zd[AM];
       const float kld = comp_dual_dir<DMAX>(c, heads_s[r], eps_s[r], rad_s, mydir, zd);
-      float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + t.first_dir[mine] + mydir) * DS;
       const int A = ambient_dim(c.kind, c.true_dim);
-      rec[0] = kld;
+      if (r4.recH) {
+        // the four-launch step (k_bwd56): a record = NV 16-byte vectors {d kl, d z_0 .. d z_{A-1}, 0 ...}.  Head directions
+        // are indexed by the HEAD COLUMN hc that receives the derivative and stored in the order the consumer's lanes read
+        // them -- lane (i = row & 15, q = hc >> 2) of row block mt takes vector v of column 4 q + tt at
+        // ((mt * 4 + tt) * NV + v) * 64 + q * 16 + i: one 1 KB wave-level request per (tt, v); radius directions: recR[row][ci]
+        float rv[4 * kRecVecMax];
+        rv[0] = kld;
 #pragma unroll
-      for (int q2 = 0; q2 < AM; ++q2)
-        if (q2 < A) rec[1 + q2] = zd[q2];
+        for (int q2 = 0; q2 < 4 * kRecVecMax - 1; ++q2) rv[1 + q2] = (q2 < AM && q2 < A) ? zd[q2 < AM ? q2 : 0] : 0.f;
+        const bool head_dir = mydir < c.true_dim + c.logvar_dim;
+        const int hc = mydir < c.true_dim ? c.mean_col + mydir : c.logvar_col + (mydir - c.true_dim);
+        f32x4* dst = head_dir
+                         ? reinterpret_cast<f32x4*>(r4.recH) + ((size_t)(mt * 4 + (hc & 3)) * r4.NV << 6) + ((hc >> 2) << 4) + r
+                         : reinterpret_cast<f32x4*>(r4.recR) + ((size_t)(mt * 16 + r) * kRecRad + mine) * r4.NV;
+        const int vstride = head_dir ? 64 : 1;
+#pragma unroll
+        for (int v = 0; v < kRecVecMax; ++v)
+          if (v < r4.NV) dst[(size_t)v * vstride] = f32x4{rv[4 * v], rv[4 * v + 1], rv[4 * v + 2], rv[4 * v + 3]};
+      } else {
+        float* rec = duals + (((size_t)mt * 16 + r) * (NH + t.n) + t.first_dir[mine] + mydir) * DS;
+        rec[0] = kld;
+#pragma unroll
+        for (int q2 = 0; q2 < AM; ++q2)
+          if (q2 < A) rec[1 + q2] = zd[q2];
+      }
+    }
+    if (r4.dzfix && tid < 64) {
+      // launch 4's tiles ADD their shares of dz to these fixed-point sums (k_dec1_bwd, LITE 1): zeroed here, one launch after
+      // the previous step's last reader (k_bwd56) and one before the adds; this row block's 16 rows x 8 sums = 64 x 16 bytes
+      typedef long long i64x2 __attribute__((ext_vector_type(2)));
+      reinterpret_cast<i64x2*>(r4.dzfix + (size_t)mt * 128)[tid] = i64x2{0, 0};
+      if (mt == 0 && tid == 0) *reinterpret_cast<unsigned*>(r4.dzfix + (size_t)B * 8) = 0u;  // the overflow / NaN mark
     }
     MV_SPAN_END(2, 2);
     return;
@@ -1035,6 +1095,7 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
   g[(size_t)m_ep * D + n_ep] = sig - tv;  // d(sum bce)/d(logit)
+  if (r4.gF) store4_wt(r4.gF, frag_off(m_ep, n_ep, B >> 4), sig - tv);  // P operand of the dW_logits tiles (k_bwd56)
   if (logits_user) logits_user[(size_t)m_ep * D + n_ep] = y;
   if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = loss;
   MV_TFLUSH(24, 8, 96);
@@ -1138,6 +1199,12 @@ struct FragArgs {
   float* zF;
   int ldz, n_zf;
   int stats_later;  // the statistics job runs in launch 5 (k_latent_bwd_blk, StatsArgs)
+  // the four-launch step: dz = sum over the tiles as 64-bit fixed-point ATOMIC adds (order-independent, hence deterministic),
+  // and the snapshot of W_heads for k_bwd56's dh product by n_snap short jobs of this launch (W_heads changes in k_bwd56)
+  long long* dzfix;
+  const float* Wh;
+  float* whF;
+  int n_snap, NH;
 };
 struct DualArgs {
   const float* heads;
@@ -1300,7 +1367,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   int b = blockIdx.x;
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
   const int n_dual = DUAL > 0 ? da.n_dual : 0;
-  const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + 7) & ~7;
+  const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
   MV_SPAN_BEGIN(3);
   if (DUAL > 0 && b < n_dual) {  // the longest chains of the launch: dispatched first, ONE wave per workgroup (= per CU)
     if (threadIdx.x < 64)
@@ -1362,7 +1429,27 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
           p0[j] = row16_sum(p0[j]);
           p1[j] = row16_sum(p1[j]);
         }
-        if ((threadIdx.x & 15) == 0) {
+        if (fr.dzfix) {
+          // lane j < Z of the row adds entry j to the row's fixed-point sum (integer adds commute: any arrival order gives the
+          // same bits); a partial that is not finite or too large for the format marks the step instead (k_bwd56: dz = NaN)
+          const int j = threadIdx.x & 15;
+          float pv = p0[0];
+          pv = j == 1 ? p0[1] : pv;
+          pv = j == 2 ? p0[2] : pv;
+          pv = j == 3 ? p0[3] : pv;
+          pv = j == 4 ? p1[0] : pv;
+          pv = j == 5 ? p1[1] : pv;
+          pv = j == 6 ? p1[2] : pv;
+          pv = j == 7 ? p1[3] : pv;
+          if (j < fr.Z) {
+            if (fabsf(pv) < kDzLimit) {
+              const long long fx = (long long)rint((double)pv * kDzScale);
+              atomicAdd(reinterpret_cast<unsigned long long*>(fr.dzfix) + (size_t)m * 8 + j, (unsigned long long)fx);
+            } else {
+              atomicOr(reinterpret_cast<unsigned*>(fr.dzfix + (size_t)B * 8), 1u);
+            }
+          }
+        } else if ((threadIdx.x & 15) == 0) {
           f32x4* dst = reinterpret_cast<f32x4*>(fr.dzp + ((size_t)m * ntH + nt) * 8);
           dst[0] = p0;
           dst[1] = p1;
@@ -1408,6 +1495,14 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
       job_frag_copy(fr.x, D, fb - fd.n_wg, B >> 4, fr.xF);  // x in fragment order for launch 6's dW_e0 tiles
     } else if (fb - fd.n_wg - fr.n_xf < fr.n_zf) {
       job_frag_copy(fr.z, fr.ldz, fb - fd.n_wg - fr.n_xf, B >> 4, fr.zF, fr.Z);
+    } else if (fb - fd.n_wg - fr.n_xf - fr.n_zf < fr.n_snap) {
+      // whF[(pt * 64 + q * 16 + i) * 4 + t] = W_heads[4 q + t][16 pt + i] (0 past NH): the B fragments of k_bwd56's dh product
+      const int sb = fb - fd.n_wg - fr.n_xf - fr.n_zf;
+      for (int e = sb * (int)blockDim.x + (int)threadIdx.x; e < (H >> 4) * 256; e += fr.n_snap * (int)blockDim.x) {
+        const int pt = e >> 8, ln = (e & 255) >> 2, n = 4 * (ln >> 4) + (e & 3);
+        const float v = fr.Wh[(size_t)(n < fr.NH ? n : 0) * H + pt * 16 + (ln & 15)];
+        fr.whF[e] = n < fr.NH ? v : 0.f;
+      }
     }
     return;  // (the rest: padding)
   }
@@ -2242,6 +2337,431 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd2(CompTable t, const
   }
 }
 
+// =============================================================== the FOUR-launch step: launches 5' and 6' in one (k_bwd56)
+// What launch 5' did between launch 4 and launch 6' was small: add 25 partial products per row (dz), contract them with the
+// row's dual records (dheads), and -- independent of launch 4 -- the dW_logits tiles.  A launch costs ~4 us whatever it does
+// (DESIGN section 5), so:
+//   * dz arrives SUMMED: launch 4's tiles add their shares into 64-bit fixed-point accumulators with atomic adds (integer
+//     adds commute: the sum has the same bits in any arrival order; the forward launch zeroes them);
+//   * every workgroup of this launch rebuilds the dheads rows it needs from dz and the dual records -- which the forward
+//     launch now stores per HEAD COLUMN in the order these lanes read them (Rec4Args): lane (i, q) of the wave that owns row
+//     block c computes dheads[16 c + i][4 q .. 4 q + 3], which IS the A fragment of the dh product -- 4 NV + 1 wave-level
+//     requests per row block, no cross-wave dependency in front of the dh MFMAs;
+//   * the dW_logits tiles (+ Adam) ride on FIVE MORE WAVES of the same workgroups (W_logits was last read by launch 4); the
+//     five waves of the weight-gradient phase meet on an LDS counter, not on s_barrier, which would also wait for those.
+// Workgroup 0: radii (+ SGD, clip) and b_heads; workgroups 1 .. n_small: dW_d0 (+ b_d0) tiles; the rest: dW_e0 tiles as in
+// k_enc_bwd2.  1 + 5 + 250 workgroups of ten waves for the BASELINE shapes: one per CU.
+constexpr int kW56 = 2 * kTileWaves;
+struct L56Args {
+  const long long* dzfix;  // [B][8] fixed-point dz, then the overflow mark
+  const float* recH;       // head-direction records (Rec4Args)
+  const float* recR;       // radius-direction records
+  const float* g;          // [B][D] row-major
+  const float* gF;         // g in fragment order, or NULL
+  const float* hdF;        // hd in fragment order
+  float* dheads;           // [B][ldh] (for observers; written by workgroup 0)
+  float* drpart;           // [ncomp][B]     "
+  int ldh;
+  float beta;
+  int64_t off_w_logits;
+};
+
+// the five main waves of a k_bwd56 workgroup meet here (s_barrier would wait for the tile waves as well)
+__device__ __forceinline__ void group_sync(int* ctr, int target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// dheads of the row blocks c = wave, wave + 5, ... of this wave (waves 0 .. 4): da[u] = dheads[16 c + i][4 q .. 4 q + 3] of lane
+// (i, q); also left in dh_s (every row of the batch once the five waves have met) and dz_s (dz as floats).
+template <int NV, int MBT>
+struct DheadsJob {
+  static constexpr int kPer = (MBT + kTileWaves - 1) / kTileWaves;
+  static constexpr int AM = 4 * NV - 1;
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  i64x2 zq[kPer];
+  f32x4 rv[kPer][4][NV];
+  unsigned mark;
+  __device__ __forceinline__ void request(const L56Args& a, int MB, int B, int wave, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      const int cc = c < MB ? c : 0;
+      zq[u] = *reinterpret_cast<const i64x2*>(a.dzfix + ((size_t)(16 * cc + i) << 3) + (q << 1));
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          rv[u][tt][v] = reinterpret_cast<const f32x4*>(a.recH)[((size_t)((cc * 4 + tt) * NV + v) << 6) + lane];
+    }
+    mark = *reinterpret_cast<const unsigned*>(a.dzfix + (size_t)B * 8);
+  }
+  __device__ __forceinline__ void finish(const CompTable& t, const L56Args& a, int MB, int NH, int wave, int lane,
+                                         f32x4 (&da)[kPer], float (*dh_s)[16], float (*dz_s)[8]) {
+    const int i = lane & 15, q = lane >> 4;
+    // this lane's four head columns 4 q + tt: z column and ambient dimension of the component that owns each (A = 0: none)
+    int zc[4] = {0, 0, 0, 0}, Aa[4] = {0, 0, 0, 0};
+    for (int ci = 0; ci < t.n; ++ci) {  // uniform loop, per-lane selects
+      const mvae_component_desc c = t.c[ci];
+      const int A = ambient_dim(c.kind, c.true_dim);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int col = 4 * q + tt;
+        const bool in = (col >= c.mean_col && col < c.mean_col + c.true_dim) ||
+                        (col >= c.logvar_col && col < c.logvar_col + c.logvar_dim);
+        zc[tt] = in ? c.z_col : zc[tt];
+        Aa[tt] = in ? A : Aa[tt];
+      }
+    }
+    const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      if (c < MB) {  // uniform
+        const int row = 16 * c + i;
+        float d0 = (float)((double)zq[u][0] * (1.0 / kDzScale)), d1 = (float)((double)zq[u][1] * (1.0 / kDzScale));
+        d0 = mark ? nanv : d0;
+        d1 = mark ? nanv : d1;
+        typedef float f32x2l __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2l*>(&dz_s[row][2 * q]) = f32x2l{d0, d1};
+        // the four q lanes of a row exchange through LDS: one wave, program order, no barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 gv;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float acc = a.beta * rv[u][tt][0][0];
+#pragma unroll
+          for (int k = 0; k < AM; ++k) {
+            const int zi = zc[tt] + k;
+            const float dzv = dz_s[row][zi < 8 ? zi : 7];
+            const float rk = rv[u][tt][(1 + k) >> 2][(1 + k) & 3];
+            acc += k < Aa[tt] ? dzv * rk : 0.f;
+          }
+          gv[tt] = (Aa[tt] > 0 && 4 * q + tt < NH) ? acc : 0.f;
+        }
+        da[u] = gv;
+        *reinterpret_cast<f32x4*>(&dh_s[row][4 * q]) = gv;
+      } else {
+        da[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+};
+
+template <int NV, bool ADAM, int MBT>
+__global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, const float* xF, const float* hF, const float* whF,
+                                                     const float* dhdF, const float* zF, float* G, float* P, int B, int H,
+                                                     int D, int NH, int Z, int n_small, int heads_on_idle, int64_t off_w_e0,
+                                                     int64_t off_b_e0, int64_t off_w_heads, int64_t off_b_heads,
+                                                     int64_t off_w_d0, int64_t off_b_d0, AdamArgs base, double curv_lr,
+                                                     int do_curv) {
+  __shared__ float red[4][16][17];
+  __shared__ f32x4 frag_s[MBT][64];  // the masked dh fragments of this workgroup's 16 columns, all row blocks
+  __shared__ __attribute__((aligned(16))) float dh_s[MBT * 16][16];  // dheads of every batch row (zero past NH)
+  __shared__ __attribute__((aligned(16))) float dz_s[MBT * 16][8];   // dz of every batch row
+  __shared__ int meet_s;
+  const int b = blockIdx.x;
+  const int MB = B >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, q = lane >> 4;
+  MV_SPAN_BEGIN(5);
+  auto at = [&](int64_t off) {
+    AdamArgs r = base;
+    r.p += off;
+    r.m += off;
+    r.v += off;
+    return r;
+  };
+  constexpr int kPer = DheadsJob<NV, MBT>::kPer;
+  if (b == 0) {
+    // ---- radii (+ SGD, clip) and b_heads: all ten waves.  Waves 0 .. 4 rebuild dheads / dz for every row; meanwhile every
+    // thread requests its radius-direction records, item = ci * B + row
+    __shared__ float drp_s[kRecRad * MBT * 16];
+    constexpr int kRI = (kRecRad * MBT * 16 + 64 * kW56 - 1) / (64 * kW56);
+    DheadsJob<NV, MBT> dj;
+    f32x4 da[kPer];
+    if (wave < kTileWaves) dj.request(a, MB, B, wave, lane);
+    f32x4 rr[kRI][NV];
+    const int n_items = t.n * B;
+#pragma unroll
+    for (int k = 0; k < kRI; ++k) {
+      const int it = (int)threadIdx.x + 64 * kW56 * k;
+      const int itc = it < n_items ? it : 0;
+      const int ci = itc / B, row = itc - ci * B;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        rr[k][v] = reinterpret_cast<const f32x4*>(a.recR)[((size_t)row * kRecRad + ci) * NV + v];
+    }
+    float bp = 0.f, bm = 0.f, bv2 = 0.f, neg_step = 0.f, bc2s = 1.f;
+    if (ADAM) {
+      const int col = (int)threadIdx.x < NH ? (int)threadIdx.x : 0;
+      bp = base.p[off_b_heads + col];
+      bm = base.m[off_b_heads + col];
+      bv2 = base.v[off_b_heads + col];
+      neg_step = reinterpret_cast<const float*>(base.counters)[2];
+      bc2s = reinterpret_cast<const float*>(base.counters)[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < kTileWaves) dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRI; ++k) {
+      const int it = (int)threadIdx.x + 64 * kW56 * k;
+      if (it < n_items) {
+        const int ci = it / B, row = it - ci * B;
+        int zc = 0, A = 0, on = 0;
+        for (int cj = 0; cj < t.n; ++cj) {  // uniform loop, per-lane selects
+          const mvae_component_desc c = t.c[cj];
+          const bool me = cj == ci;
+          zc = me ? c.z_col : zc;
+          A = me ? ambient_dim(c.kind, c.true_dim) : A;
+          on = me ? (int)t.trainable[cj] : on;
+        }
+        float acc = a.beta * rr[k][0][0];
+#pragma unroll
+        for (int kk = 0; kk < 4 * NV - 1; ++kk) {
+          const int zi = zc + kk;
+          const float dzv = dz_s[row][zi < 8 ? zi : 7];
+          acc += kk < A ? dzv * rr[k][(1 + kk) >> 2][(1 + kk) & 3] : 0.f;
+        }
+        acc = on ? acc : 0.f;  // (the record of a fixed radius is not written)
+        drp_s[it] = acc;
+        a.drpart[it] = acc;
+      }
+    }
+    for (int e = threadIdx.x; e < B * 16; e += 64 * kW56)
+      if ((e & 15) < NH) a.dheads[(size_t)(e >> 4) * a.ldh + (e & 15)] = dh_s[e >> 4][e & 15];
+    __syncthreads();
+    job_radii<ADAM>(t, &red[0][0][0], drp_s, G, P, B, curv_lr, do_curv);
+    __syncthreads();
+    // b_heads[col] = sum over the rows of dheads[:, col]: 16 row groups, then the groups in index order
+    if (threadIdx.x < 256) {
+      const int c = threadIdx.x & 15, gq = threadIdx.x >> 4;
+      float s = 0.f;
+      for (int m = gq; m < B; m += 16) s += dh_s[m][c];
+      red[0][gq][c] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NH) {
+      float tsum = 0.f;
+      for (int gq = 0; gq < 16; ++gq) tsum += red[0][gq][threadIdx.x];
+      G[off_b_heads + threadIdx.x] = tsum;
+      if (ADAM) {
+        adam1(bp, tsum, bm, bv2, neg_step, bc2s);
+        base.p[off_b_heads + threadIdx.x] = bp;
+        base.m[off_b_heads + threadIdx.x] = bm;
+        base.v[off_b_heads + threadIdx.x] = bv2;
+      }
+    }
+    MV_SPAN_END(5, 7);
+    return;
+  }
+  if (threadIdx.x == 0) meet_s = 0;
+  __syncthreads();  // (the only hardware barrier of these workgroups: all ten waves are at their first instructions)
+  if (wave >= kTileWaves) {
+    // ---- dW_logits[D, H] tiles (+ Adam), one per wave: tile index over (workgroup - 1, wave - 5)
+    const int ntH = H >> 4;
+    const int tw = (b - 1) * kTileWaves + (wave - kTileWaves), pt = fast_div(tw, ntH), qt = tw - pt * ntH;
+    if (pt * 16 < D) {
+      const AdamArgs awl = at(a.off_w_logits);
+      if (a.gF) job_tn_frag<ADAM>(a.gF, pt, D, a.hdF, qt, H, MB, G + a.off_w_logits, H, awl);
+      else job_tn_halffrag<ADAM>(a.g, D, pt, D, a.hdF, qt, H, MB, G + a.off_w_logits, H, awl);
+    }
+    return;
+  }
+  const int bs = b - 1;
+  if (bs < n_small) {
+    // wave w, column tile tl = 5 bs + w of H: the dW_d0 tile [16 rows tl, Z] = dhd^T z with b_d0's 16 entries (the column sums
+    // of its dhd fragments); without idle tile waves (D / 16 a multiple of 5) also the dW_heads tile [NH, 16 columns tl]
+    const int tl = bs * kTileWaves + wave;
+    const bool live = tl * 16 < H;  // uniform
+    if (live)
+      job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
+                                  at(off_b_d0));
+    if (!heads_on_idle) {  // (uniform; one job after the other: a rare shape, and both at once do not fit the registers)
+      DheadsJob<NV, MBT> dj;
+      f32x4 da[kPer];
+      f32x4 hv[MBT];
+      f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
+      float neg_step = 0.f, bc2s = 1.f;
+      const bool okh = i < NH && live;
+      const size_t idxh = (size_t)(i < NH ? i : 0) * H + (live ? tl : 0) * 16 + (q << 2);
+      dj.request(a, MB, B, wave, lane);
+#pragma unroll
+      for (int c = 0; c < MBT; ++c) hv[c] = reinterpret_cast<const f32x4*>(hF)[((size_t)((live ? tl : 0) * MB + (c < MB ? c : 0)) << 6) + lane];
+      if (ADAM) {
+        p0 = *reinterpret_cast<const f32x4*>(base.p + off_w_heads + idxh);
+        m0 = *reinterpret_cast<const f32x4*>(base.m + off_w_heads + idxh);
+        v0 = *reinterpret_cast<const f32x4*>(base.v + off_w_heads + idxh);
+        neg_step = reinterpret_cast<const float*>(base.counters)[2];
+        bc2s = reinterpret_cast<const float*>(base.counters)[3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
+      group_sync(&meet_s, kTileWaves);
+      if (live) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+        for (int c = 0; c < MBT; ++c)
+          if (c < MB) {  // uniform
+            const int r0 = 16 * c + 4 * q;
+            acc = mfma16(hv[c][0], dh_s[r0 + 0][i], acc);
+            acc2 = mfma16(hv[c][1], dh_s[r0 + 1][i], acc2);
+            acc = mfma16(hv[c][2], dh_s[r0 + 2][i], acc);
+            acc2 = mfma16(hv[c][3], dh_s[r0 + 3][i], acc2);
+          }
+        acc += acc2;
+        if (ADAM) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pp = p0[r], mm = m0[r], vv = v0[r];
+            adam1(pp, acc[r], mm, vv, neg_step, bc2s);
+            p0[r] = pp;
+            m0[r] = mm;
+            v0[r] = vv;
+          }
+        }
+        if (okh) {
+          store16_wt(G + off_w_heads, idxh, acc);
+          if (ADAM) {
+            store16_wt(base.p + off_w_heads, idxh, p0);
+            store16_wt(base.m + off_w_heads, idxh, m0);
+            store16_wt(base.v + off_w_heads, idxh, v0);
+          }
+        }
+      }
+    }
+    MV_SPAN_END(5, 3);
+    return;
+  }
+  {  // dW_e0[H, D] = dh^T x ; b_e0 = column sums of dh ; on the idle wave of a tile row: its dW_heads tile
+    const int bt = bs - n_small;
+    const int ntDg = ((D >> 4) + kTileWaves - 1) / kTileWaves;
+    const int pt = fast_div(bt, ntDg), qg = bt - pt * ntDg;
+    const int qt = qg * kTileWaves + wave;
+    const bool have = qt * 16 < D;  // wave-uniform
+    const bool idle_wave = heads_on_idle && !have && qt == (D >> 4);
+    const bool bias_wave = qg == 0 && wave == 0;
+    // ---- requests.  First what the dheads rows of this wave's row blocks are made of (the head of the dependent chain), then
+    // the operands of the dh product (B = W_heads[4 q + t][p0 + i] from launch 4's snapshot: this launch's dW_heads tiles
+    // update W_heads in place; mask = h's fragment), then the tile's own
+    DheadsJob<NV, MBT> dj;
+    dj.request(a, MB, B, wave, lane);
+    f32x4 da[kPer], hm[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      const int cc = c < MB ? c : 0;
+      hm[u] = reinterpret_cast<const f32x4*>(hF)[((size_t)(pt * MB + cc) << 6) + lane];
+    }
+    const f32x4 wb = reinterpret_cast<const f32x4*>(whF)[((size_t)pt << 6) + lane];
+    // Q operand and optimizer state, branch-free: tile wave = x's fragments of column tile qt and W_e0's tile (pt, qt);
+    // idle wave = h's fragments of column tile pt and W_heads' tile (0, pt)
+    const bool ok = idle_wave ? i < NH : have;
+    const size_t idx = idle_wave ? (size_t)(i < NH ? i : 0) * H + pt * 16 + (q << 2)
+                                 : (size_t)(pt * 16 + i) * D + (have ? qt : 0) * 16 + (q << 2);
+    const int64_t woff = idle_wave ? off_w_heads : off_w_e0;
+    const f32x4* qa = reinterpret_cast<const f32x4*>(idle_wave ? hF : xF) + ((size_t)(idle_wave ? pt : (have ? qt : 0)) * MB << 6) + lane;
+    f32x4 av[MBT];
+#pragma unroll
+    for (int c = 0; c < MBT; ++c) av[c] = qa[(size_t)(c < MB ? c : 0) << 6];
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
+    float neg_step = 0.f, bc2s = 1.f;
+    const int bcol = pt * 16 + i;
+    float bp = 0.f, bm = 0.f, bvv = 0.f;
+    if (ADAM) {
+      p0 = *reinterpret_cast<const f32x4*>(base.p + woff + idx);
+      m0 = *reinterpret_cast<const f32x4*>(base.m + woff + idx);
+      v0 = *reinterpret_cast<const f32x4*>(base.v + woff + idx);
+      neg_step = reinterpret_cast<const float*>(base.counters)[2];
+      bc2s = reinterpret_cast<const float*>(base.counters)[3];
+      // (every wave requests the bias column: under `if (bias_wave)` the compiler ends the block with a wait for ALL
+      // outstanding requests -- a full memory round trip in front of the fragment phase the five waves meet on)
+      bp = base.p[off_b_e0 + bcol];
+      bm = base.m[off_b_e0 + bcol];
+      bvv = base.v[off_b_e0 + bcol];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int c = wave + kTileWaves * u;
+      if (c < MB) {  // uniform
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = mfma16(da[u][0], wb[0], d);
+        d = mfma16(da[u][1], wb[1], d);
+        d = mfma16(da[u][2], wb[2], d);
+        d = mfma16(da[u][3], wb[3], d);
+        // lane (column i, rows 4 q + r of block c): exactly the fragment position (q, i); ReLU mask from h
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = hm[u][r] > 0.f ? d[r] : 0.f;
+        frag_s[c][lane] = d;
+      }
+    }
+    group_sync(&meet_s, kTileWaves);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, csum = acc;
+#pragma unroll
+    for (int c = 0; c < MBT; ++c) {
+      if (c < MB) {  // uniform
+        f32x4 bv = frag_s[c][lane];
+        if (bias_wave) csum += bv;
+        if (idle_wave) {  // dheads' fragment instead of dh's: rows 4 q + t of block c, head column i
+          const int r0 = 16 * c + 4 * q;
+          bv = f32x4{dh_s[r0][i], dh_s[r0 + 1][i], dh_s[r0 + 2][i], dh_s[r0 + 3][i]};
+        }
+        if (have || idle_wave) {
+          acc = mfma16(av[c][0], bv[0], acc);
+          acc2 = mfma16(av[c][1], bv[1], acc2);
+          acc = mfma16(av[c][2], bv[2], acc);
+          acc2 = mfma16(av[c][3], bv[3], acc2);
+        }
+      }
+    }
+    acc += acc2;
+    if (bias_wave) {
+      // b_e0[p0 + i] = sum over all rows of dh[:, p0 + i]: the lane's 4 MB values, then the four row quads q
+      float tsum = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+      tsum += __shfl_xor(tsum, 16);
+      tsum += __shfl_xor(tsum, 32);
+      if (lane < 16) {
+        const int col = pt * 16 + lane;
+        G[off_b_e0 + col] = tsum;
+        if (ADAM) {  // (lanes 0..15: q == 0, so col == bcol)
+          adam1(bp, tsum, bm, bvv, neg_step, bc2s);
+          base.p[off_b_e0 + col] = bp;
+          base.m[off_b_e0 + col] = bm;
+          base.v[off_b_e0 + col] = bvv;
+        }
+      }
+    }
+    if (have || idle_wave) {
+      if (ADAM) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pp = p0[r], mm = m0[r], vv = v0[r];
+          adam1(pp, acc[r], mm, vv, neg_step, bc2s);
+          p0[r] = pp;
+          m0[r] = mm;
+          v0[r] = vv;
+        }
+      }
+      if (ok) {
+        store16_wt(G + woff, idx, acc);
+        if (ADAM) {
+          store16_wt(base.p + woff, idx, p0);
+          store16_wt(base.m + woff, idx, m0);
+          store16_wt(base.v + woff, idx, v0);
+        }
+      }
+    }
+    MV_SPAN_END(5, 1);
+  }
+}
+
 // ---- 6'' (block backward, z_dim 17 .. 64): every weight gradient from fragment-order operands -- dh and dhd arrive in
 // fragment order from launches 5 / 4 (never row-major), dheads from launch 5 too, x and h as the copies launch 1 writes, z as the
 // copy spare workgroups of launch 4 write.  One tile per wave; the wave whose tile is the first of its P column block
@@ -2508,6 +3028,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
   float *dzp = ws + c->o_dzp, *dheads16 = ws + c->o_dheads16, *whF = ws + c->o_whF;
+  // the four-launch step (k_bwd56 = launches 5' and 6' in one): MVAE_STEP5=1 keeps the two launches (A/B measurements)
+  const bool four = lite && !c->five_launch && d.ncomp <= kRecRad && c->rec_nv <= kRecVecMax;
+  float *recH = ws + c->o_recH, *recR = ws + c->o_recR, *gF = ws + c->o_gF;
+  long long* dzfix = reinterpret_cast<long long*>(ws + c->o_dzfix);
   if (parts & MVAE_STEP_HEAD) {  // launches 1-5
   ki = 0;
   if (full)
@@ -2537,7 +3061,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b + MV_PREFETCH_WGS), dim3(512), lds, c->t, h, P + d.off_w_heads,  \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
-              NH, Z, duals, zF, hdF)
+              NH, Z, duals, zF, hdF, r4)
+    const Rec4Args r4 = {four ? recH : nullptr, recR, four ? dzfix : nullptr, (four && c->gf) ? gF : nullptr, c->rec_nv};
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
@@ -2609,8 +3134,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
     const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, fr6 ? dzp : nullptr, P + d.off_w_d0, Z,
-                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0};
-    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + 7) & ~7;
+                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0,
+                         four ? dzfix : nullptr, P + d.off_w_heads, whF, four ? 4 : 0, NH};
+    const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
               G + d.off_b_logits, dhd, bce_part, klw, bce, d.stats, beta, B, H, D, d.ncomp, n_dhd, n_db,          \
@@ -2639,7 +3165,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
-    if (lite) {
+    if (four) {
+      // (no launch 5: k_bwd56, the TAIL part, does its work)
+    } else if (lite) {
       const int n_snap = 4;  // W_heads snapshot workgroups (1600 floats each for H = 400)
       // seven waves per workgroup: 4 + 19 + 175 workgroups, one per CU (five: 275 workgroups, rows end 4.3 us / tiles 3.9; seven:
       // 3.9 / 4.0 -- the step 30.79 -> 30.77 us, within the noise)
@@ -2687,7 +3215,20 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
-    if (lite) {
+    if (four) {
+      const int n_small = (c->nt_h + tw - 1) / tw;
+      const int grid2 = 1 + n_small + n_we0;
+      const L56Args la = {dzfix, recH, recR, g, c->gf ? gF : nullptr, hdF, dheads, drpart, c->ldh, beta, d.off_w_logits};
+#define B56(NVV, AD, MBT)                                                                                            \
+  STEP_LAUNCH((k_bwd56<NVV, AD, MBT>), dim3(grid2), dim3(64 * kW56), 0, c->t, la, xF, hF, whF, dhdF, zF, G, P, B, H, D, \
+              NH, Z, n_small, (c->nt_d % tw) != 0 ? 1 : 0, d.off_w_e0, d.off_b_e0, d.off_w_heads, d.off_b_heads,      \
+              d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
+#define B56N(AD, MBT) do { if (c->rec_nv == 1) B56(1, AD, MBT); else if (c->rec_nv == 2) B56(2, AD, MBT); else B56(3, AD, MBT); } while (0)
+      if (fused) { if (B <= 128) B56N(true, 8); else B56N(true, 16); }
+      else { if (B <= 128) B56N(false, 8); else B56N(false, 16); }
+#undef B56N
+#undef B56
+    } else if (lite) {
       const int n_small = (c->nt_h + tw - 1) / tw;
       const int grid2 = 1 + n_small + n_we0;
 #define EB2(AD, MBT)                                                                                                 \

@@ -622,12 +622,17 @@ def loglik_tail(bce: Tensor, log_p: Tensor, log_q: Tensor, z: Tensor, x: Tensor)
     if Z > 64 or B * (16 + Z) * 4 > 48 * 1024 or x.shape[0] != B:
         return None
     lib = load()
-    key = (bce.device, D)
+    st = stream_ptr(bce.device)
+    # one workspace (partial sums + arrival counter) per (device, STREAM, D): two calls in flight on different streams must
+    # not share a counter.  Zeroed once -- the launch re-arms its counter; a first call inside a graph capture would put the
+    # allocation and the fill into the capture, so it is refused there
+    key = (bce.device, int(st or 0), D)
     ws = _COV_WS.get(key)
-    if ws is None:  # zeroed once: the launch re-arms its arrival counter
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
         ws = _COV_WS[key] = torch.zeros(int(lib.mvae_cov_norm_workspace_floats(D)), device=bce.device)
     log_px, mi, zmean, cn = bce.new_empty(B), bce.new_empty(B), bce.new_empty(B, Z), bce.new_empty(())
-    st = stream_ptr(bce.device)
     check(lib.mvae_loglik_reduce_comps(ptr(bce), ptr(log_p), ptr(log_q), log_p.shape[0], ptr(z), Z, ptr(log_px), ptr(mi),
                                        ptr(zmean), n, B, st))
     check(lib.mvae_cov_norm(ptr(x), ptr(zmean), B, D, Z, ptr(ws), ptr(cn), st))

@@ -83,6 +83,13 @@ def main(argv=None) -> None:
     print(f"VAE Model: {model_name}; Epochs: {args.epochs}; Time: {cur_time}; Fixed curvature: {args.fixed_curvature}; "
           f"Dataset: {args.dataset}")
     print("#####", flush=True)
+    if args.doubles:  # refused before anything is created (checkpoint directory, model)
+        if world > 1 or args.architecture != "ff":
+            raise SystemExit("--doubles=True (float64 latent chain) is built for the single-device ff architecture")
+        too_big = [f"{type(c).__name__}({c.true_dim})" for c in components if c.true_dim > 8]
+        if too_big:  # mvae_component_forward_f64 / _backward_f64 keep a component's vectors in registers: true dim <= 8
+            raise SystemExit("--doubles=True: the float64 latent chain is built for components of true dimension <= 8; "
+                             f"this model has {', '.join(too_big)} (run with --doubles=False)")
     chkpt_dir = f"./chkpt/vae-{args.dataset}-{model_name}-{cur_time}" + (f"-rank{rank}" if rank else "")
     os.makedirs(chkpt_dir)
     if args.architecture == "ff":
@@ -96,12 +103,6 @@ def main(argv=None) -> None:
     if args.seed:
         model.seed_sampler(args.seed + rank)
     if args.doubles:
-        if world > 1 or args.architecture != "ff":
-            raise SystemExit("--doubles=True (float64 latent chain) is built for the single-device ff architecture")
-        too_big = [f"{type(c).__name__}({c.true_dim})" for c in model.components if c.true_dim > 8]
-        if too_big:  # mvae_component_forward_f64 / _backward_f64 keep a component's vectors in registers: true dim <= 8
-            raise SystemExit("--doubles=True: the float64 latent chain is built for components of true dimension <= 8; "
-                             f"this model has {', '.join(too_big)} (run with --doubles=False)")
         model.float64_chain = True
     if world > 1:
         model.enable_data_parallel()
