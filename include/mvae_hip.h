@@ -580,14 +580,6 @@ int mvae_set_radius_trainable(mvae_ctx* ctx, const uint8_t* trainable);
 int mvae_step_forward_backward(mvae_ctx* ctx, const float* x, const float* eps, float beta, int want_outputs,
                                float* logits, float* concat_z, float* bce, float* kl, void* stream);
 
-/* mvae_step_forward_backward in two calls, for data-parallel runs that overlap the gradient exchange with the last
- * launch: MVAE_STEP_HEAD runs launches 1-5, after which the gradients of fc_logits -- the LAST segment of the flat
- * buffer, [off_w_logits, n_params), half of it -- are final and can be all-reduced on another stream; MVAE_STEP_TAIL runs
- * launch 6 (every other gradient).  HEAD | TAIL in one call == mvae_step_forward_backward without outputs. */
-enum { MVAE_STEP_HEAD = 1, MVAE_STEP_TAIL = 2 };
-int mvae_step_forward_backward_parts(mvae_ctx* ctx, const float* x, const float* eps, float beta, int parts,
-                                     void* stream);
-
 /* optimizer: fused Adam over the flat buffer (radii excluded) + SGD(lr=curvature_lr) on trainable radii iff
  * do_curvature_step (the reference's `not fixed_curvature and epoch >= 10`, train.py:357-358); the gradients of
  * universal curvatures are first clipped to joint L2 norm 1, in place (vae.py:161-163).  In data-parallel runs the

@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so"
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 11
+# return codes of the C ABI (include/mvae_hip.h)
+MVAE_OK, MVAE_E_BADARG, MVAE_E_UNSUPPORTED, MVAE_E_ALIGN, MVAE_E_SYSTEM = 0, -1, -2, -3, -4
 MAX_TRUE_DIM = 64
 MAX_COMPONENTS = 64
 RADII_REGION = 64
@@ -133,7 +135,6 @@ PROTOTYPES = {
     "mvae_destroy": (None, [C.c_void_p]),
     "mvae_set_radius_trainable": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "mvae_step_forward_backward": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
-    "mvae_step_forward_backward_parts": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),

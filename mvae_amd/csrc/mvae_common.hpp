@@ -658,7 +658,8 @@ __host__ __device__ inline size_t frag_off(int m, int n, int MB) {
 template <bool ADAM, bool COLSUM = false>
 __device__ __forceinline__ void job_tn_frag_any(const float* PF, const float* PROW, int ldp, int pt, int NP, const float* QF,
                                                 int qt, int NQ, int MB, float* out, int ldo, const AdamArgs& aa,
-                                                float* cs_out = nullptr, const AdamArgs cs_aa = AdamArgs{}) {
+                                                float* cs_out = nullptr, const AdamArgs cs_aa = AdamArgs{},
+                                                const float* scal = nullptr /* {-lr/bc1, sqrt(bc2)} already in registers */) {
   if (qt * 16 >= NQ) return;
   MV_STAMP_B(16, MV_STAMP_BLK);
   const int lane = threadIdx.x & 63;
@@ -697,8 +698,13 @@ __device__ __forceinline__ void job_tn_frag_any(const float* PF, const float* PR
         v0[r] = aa.v[ir];
       }
     }
-    neg_step = reinterpret_cast<const float*>(aa.counters)[2];  // {-lr/bc1, sqrt(bc2)} of this step (launch 1)
-    bc2s = reinterpret_cast<const float*>(aa.counters)[3];
+    if (scal) {
+      neg_step = scal[0];
+      bc2s = scal[1];
+    } else {
+      neg_step = reinterpret_cast<const float*>(aa.counters)[2];  // {-lr/bc1, sqrt(bc2)} of this step (launch 1)
+      bc2s = reinterpret_cast<const float*>(aa.counters)[3];
+    }
   }
   float cp = 0.f, cm = 0.f, cv = 0.f;  // COLSUM: the bias entry of this lane's P column (lanes 0..15 finish it)
   if (COLSUM && ADAM) {
@@ -783,131 +789,14 @@ __device__ __forceinline__ void job_tn_frag_any(const float* PF, const float* PR
 }
 template <bool ADAM>
 __device__ __forceinline__ void job_tn_frag(const float* PF, int pt, int NP, const float* QF, int qt, int NQ, int MB,
-                                            float* out, int ldo, const AdamArgs& aa) {
-  job_tn_frag_any<ADAM>(PF, nullptr, 0, pt, NP, QF, qt, NQ, MB, out, ldo, aa);
+                                            float* out, int ldo, const AdamArgs& aa, const float* scal = nullptr) {
+  job_tn_frag_any<ADAM>(PF, nullptr, 0, pt, NP, QF, qt, NQ, MB, out, ldo, aa, nullptr, AdamArgs{}, scal);
 }
 template <bool ADAM>
 __device__ __forceinline__ void job_tn_halffrag(const float* Prow, int ldp, int pt, int NP, const float* QF, int qt, int NQ,
-                                                int MB, float* out, int ldo, const AdamArgs& aa) {
-  job_tn_frag_any<ADAM>(Prow, Prow, ldp, pt, NP, QF, qt, NQ, MB, out, ldo, aa);
+                                                int MB, float* out, int ldo, const AdamArgs& aa, const float* scal = nullptr) {
+  job_tn_frag_any<ADAM>(Prow, Prow, ldp, pt, NP, QF, qt, NQ, MB, out, ldo, aa, nullptr, AdamArgs{}, scal);
 }
-
-// The same tile job in two phases, for a wave that runs TWO independent tiles (the small weight gradients of launch 6):
-// request() issues every load of a tile, finish() multiplies and stores; with both tiles requested first the second one's
-// memory round trip hides behind the first instead of following it.  Whole fragments only (MB <= 8).
-template <bool ADAM, bool COLSUM>
-struct FragJob {
-  f32x4 av[8], bv[8], p0, m0, v0;
-  float cp, cm, cv, neg_step, bc2s;
-  size_t idx;
-  int pr, qc0;
-  bool ok, vec, live;
-  __device__ __forceinline__ void request(const float* PF, int pt, int NP, const float* QF, int qt, int NQ, int MB, int ldo,
-                                          const AdamArgs& aa, const AdamArgs& cs_aa) {
-    const int lane = threadIdx.x & 63;
-    live = qt * 16 < NQ && pt * 16 < NP;  // uniform
-    pr = pt * 16 + (lane & 15);
-    qc0 = qt * 16 + ((lane >> 4) << 2);
-    vec = (ldo & 3) == 0;
-    ok = live && pr < NP && (vec ? qc0 + 3 < NQ : qc0 < NQ);
-    idx = ok ? (size_t)pr * ldo + qc0 : 0;
-    const f32x4* qa = reinterpret_cast<const f32x4*>(QF) + ((size_t)(live ? qt : 0) * MB << 6) + lane;
-    const f32x4* pb = reinterpret_cast<const f32x4*>(PF) + ((size_t)(live ? pt : 0) * MB << 6) + lane;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int cc = c < MB ? c : 0;
-      av[c] = qa[(size_t)cc << 6];
-      bv[c] = pb[(size_t)cc << 6];
-    }
-    p0 = m0 = v0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    neg_step = 0.f;
-    bc2s = 1.f;
-    cp = cm = cv = 0.f;
-    if (ADAM) {
-      if (vec) {
-        p0 = *reinterpret_cast<const f32x4*>(aa.p + idx);
-        m0 = *reinterpret_cast<const f32x4*>(aa.m + idx);
-        v0 = *reinterpret_cast<const f32x4*>(aa.v + idx);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const size_t ir = (ok && qc0 + r < NQ) ? idx + r : 0;
-          p0[r] = aa.p[ir];
-          m0[r] = aa.m[ir];
-          v0[r] = aa.v[ir];
-        }
-      }
-      neg_step = reinterpret_cast<const float*>(aa.counters)[2];
-      bc2s = reinterpret_cast<const float*>(aa.counters)[3];
-      if (COLSUM) {
-        const int col = (live && pr < NP) ? pr : 0;
-        cp = cs_aa.p[col];
-        cm = cs_aa.m[col];
-        cv = cs_aa.v[col];
-      }
-    }
-  }
-  __device__ __forceinline__ void finish(int NP, int NQ, int MB, float* out, const AdamArgs& aa, float* cs_out,
-                                         const AdamArgs& cs_aa) {
-    if (!live) return;
-    const int lane = threadIdx.x & 63;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, cs4 = acc;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      if (c < MB) {  // uniform
-        if (COLSUM) cs4 += bv[c];
-        acc = mfma16(av[c][0], bv[c][0], acc);
-        acc2 = mfma16(av[c][1], bv[c][1], acc2);
-        acc = mfma16(av[c][2], bv[c][2], acc);
-        acc2 = mfma16(av[c][3], bv[c][3], acc2);
-      }
-    }
-    acc += acc2;
-    if (COLSUM) {
-      float cs = (cs4[0] + cs4[1]) + (cs4[2] + cs4[3]);
-      cs += __shfl_xor(cs, 16);
-      cs += __shfl_xor(cs, 32);
-      if (lane < 16 && pr < NP) {
-        cs_out[pr] = cs;
-        if (ADAM) {
-          adam1(cp, cs, cm, cv, neg_step, bc2s);
-          cs_aa.p[pr] = cp;
-          cs_aa.m[pr] = cm;
-          cs_aa.v[pr] = cv;
-        }
-      }
-    }
-    if (ADAM) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pp = p0[r], mm = m0[r], vv = v0[r];
-        adam1(pp, acc[r], mm, vv, neg_step, bc2s);
-        p0[r] = pp;
-        m0[r] = mm;
-        v0[r] = vv;
-      }
-    }
-    if (ok && vec) {
-      store16_wt(out, idx, acc);
-      if (ADAM) {
-        store16_wt(aa.p, idx, p0);
-        store16_wt(aa.m, idx, m0);
-        store16_wt(aa.v, idx, v0);
-      }
-    } else if (ok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (qc0 + r < NQ) {
-          out[idx + r] = acc[r];
-          if (ADAM) {
-            aa.p[idx + r] = p0[r];
-            aa.m[idx + r] = m0[r];
-            aa.v[idx + r] = v0[r];
-          }
-        }
-    }
-  }
-};
 
 // x [B][N] -> its fragment-order copy, one column tile per workgroup (any block size that is a multiple of 64): thread
 // (block c, lane (i, q)) gathers its four batch rows and stores one 16-byte vector.

@@ -13,6 +13,8 @@
 //                   dh = (dheads W_heads) * [h>0]                  tiles: dW_logits = g^T hd (+Adam)
 //   6 k_enc_bwd     dW_e0 = dh^T x, dW_heads, dW_d0, their biases (+Adam) ; radius gradients (+SGD)
 //
+// The BASELINE MLP shapes (heads_dim <= 16, z_dim <= 8, B a multiple of 128, B <= 256) take FOUR launches instead:
+// 1, k_fwd23 (2 + 3 in one), 4 (which also sums dz), and k_bwd56 (5 + 6 in one) -- see those kernels.
 // In the single-GPU step the optimizer runs in the gradient epilogues, each weight one launch after its last read;
 // the two-call path (mvae_step_forward_backward -> all-reduce -> mvae_step_optimizer) uses k_optim instead.
 // Nothing here synchronises or allocates, so the host layer can capture any number of steps into one HIP graph.
@@ -43,7 +45,6 @@ struct Rec4Args {
   float* recH;        // head-direction records in the consumer's lane order (NULL: the records go to `duals`)
   float* recR;        // radius-direction records [B][kRecRad][NV] vectors
   long long* dzfix;   // [B][8] fixed-point sums of dz, then one unsigned: the overflow / non-finite mark
-  float* gF;          // g in fragment order (NULL: the dW_logits tiles read it row-major)
   int NV;             // vectors per record, (max ambient dim + 1 + 3) / 4
 };
 
@@ -57,11 +58,9 @@ struct mvae_ctx {
   // workspace carve (floats)
   int64_t o_h, o_heads, o_z, o_hd, o_g, o_bce_part, o_kl, o_dhd, o_dz, o_dheads, o_dh, o_drpart, o_duals, o_dirtab, o_total;
   int64_t o_hdF, o_xF, o_hF, o_dhdF, o_zF, o_dheadsF, o_dhF;  // fragment-order operands of the lite backward (mvae_common.hpp: frag_off)
-  int64_t o_dzp, o_dheads16, o_whF;  // [B][H/16][8] partial dz products of launch 4's tiles; dheads as [B][16] (zero-padded); W_heads snapshot
-  int64_t o_recH, o_recR, o_dzfix, o_gF;  // the four-launch step: dual records per head column / radius, fixed-point dz sums, g in fragment order
+  int64_t o_dzp, o_whF;  // partial dz products of launch 4's tiles (block backward: [B/16][H/16][z tiles <= 4][64][4]); W_heads snapshot
+  int64_t o_recH, o_recR, o_dzfix;   // the four-launch step: dual records per head column / radius, fixed-point dz sums
   int rec_nv;                        // 16-byte vectors per dual record there: (max ambient dimension + 1 + 3) / 4
-  bool five_launch;                  // MVAE_STEP5=1: the lite backward as launches 5' + 6' (k_latent_bwd2, k_enc_bwd2) instead of k_bwd56
-  bool gf;                           // MVAE_GF=1: k_fwd23 also writes g in fragment order for k_bwd56's dW_logits tiles
   bool no_lite;                      // MVAE_NO_LITE=1: the fused-forward shapes keep the round-4 backward launches (A/B measurements)
   int nt_d, nt_h, nt_b;  // 16-wide tile counts of D, H, B
   bool no_fwd23;         // MVAE_NO_FWD23=1: keep launches 2 and 3 separate (A/B measurements)
@@ -116,13 +115,11 @@ static void carve(mvae_ctx* c, int dmax_bucket) {
   c->o_dhF = take(B * H);
   c->o_zF = take(B * 16 * (((int64_t)d.z_dim + 15) / 16));  // whole 16-column tiles
   c->o_dheadsF = take(B * 16 * (((int64_t)d.heads_dim + 15) / 16));  // whole 16-column tiles (zero past heads_dim)
-  c->o_dzp = take(B * (int64_t)c->nt_h * 64);  // [B][H/16][8] (lite) | [B/16][H/16][z tiles <= 4][64][4] (block backward)
-  c->o_dheads16 = take(B * 16);
+  c->o_dzp = take(B * (int64_t)c->nt_h * 64);  // [B/16][H/16][z tiles <= 4][64][4] (block backward)
   c->o_whF = take((int64_t)c->nt_h * 256);
   c->o_recH = take(B * 64 * kRecVecMax);
   c->o_recR = take(B * kRecRad * 4 * kRecVecMax);
   c->o_dzfix = take(B * 16 + 64);  // [B][8] 64-bit sums + the overflow mark
-  c->o_gF = take(B * D);
   c->o_total = o;
 }
 
@@ -201,10 +198,6 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   c->blk_fwd = !(bf && bf[0] == '0');
   const char* nl = getenv("MVAE_NO_LITE");
   c->no_lite = nl && nl[0] && nl[0] != '0';
-  const char* s5 = getenv("MVAE_STEP5");
-  c->five_launch = s5 && s5[0] && s5[0] != '0';
-  const char* gfe = getenv("MVAE_GF");
-  c->gf = gfe && gfe[0] && gfe[0] != '0';
   {
     int amax = 1;
     for (int i = 0; i < desc->ncomp; ++i) {
@@ -1095,7 +1088,6 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
   g[(size_t)m_ep * D + n_ep] = sig - tv;  // d(sum bce)/d(logit)
-  if (r4.gF) store4_wt(r4.gF, frag_off(m_ep, n_ep, B >> 4), sig - tv);  // P operand of the dW_logits tiles (k_bwd56)
   if (logits_user) logits_user[(size_t)m_ep * D + n_ep] = y;
   if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = loss;
   MV_TFLUSH(24, 8, 96);
@@ -1189,8 +1181,8 @@ struct FragArgs {
   const float* x;
   float* xF;
   int n_xf;  // > 0 only when launch 1's grid has no padding workgroups to do it
-  // the "lite" backward of the fused-forward shapes (dzp != NULL): hd arrives in fragment order (hdF is an INPUT), dhd leaves
-  // in fragment order only, and every dhd tile adds its share of dz = dhd W_d0 as a partial product dzp[row][tile][0..7]
+  // LITE 1 (the four-launch step): hd arrives in fragment order (hdF is an INPUT), dhd leaves in fragment order only, and every
+  // dhd tile adds its share of dz = dhd W_d0 to the fixed-point sums `dzfix`.  LITE 2 (block backward): partial tiles in dzp
   float* dzp;
   const float* Wd0;
   int Z;
@@ -1213,8 +1205,8 @@ struct DualArgs {
   float* duals;
   int ldh, eps_ld, NH, n_dual;
 };
-// LITE: 0 the round-4 launch; 1 the lite backward (z_dim <= 8: hd read / dhd written in fragment order, dz partials as
-// [row][tile][8] from per-thread products and DPP row sums); 2 the round-4 launch PLUS dz partials for the block backward
+// LITE: 0 the generic launch; 1 the four-launch step (z_dim <= 8: hd read / dhd written in fragment order, the tile's share of
+// dz from per-thread products and DPP row sums, added to dzfix); 2 the generic launch PLUS dz partials for the block backward
 // (z_dim <= 64): the partial of a tile is itself an MFMA product, stored in the MFMA's output order
 // statistics job of the step (one workgroup; launch 4, or launch 5 of the fragment-order block backward where launch 4's
 // tiles end before it would).  sm: kW8 * 16 * 17 = 2176 floats of LDS: [0, 64) block sums / component sums, [64, ...) part sums
@@ -1429,7 +1421,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
           p0[j] = row16_sum(p0[j]);
           p1[j] = row16_sum(p1[j]);
         }
-        if (fr.dzfix) {
+        {
           // lane j < Z of the row adds entry j to the row's fixed-point sum (integer adds commute: any arrival order gives the
           // same bits); a partial that is not finite or too large for the format marks the step instead (k_bwd56: dz = NaN)
           const int j = threadIdx.x & 15;
@@ -1449,10 +1441,6 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
               atomicOr(reinterpret_cast<unsigned*>(fr.dzfix + (size_t)B * 8), 1u);
             }
           }
-        } else if ((threadIdx.x & 15) == 0) {
-          f32x4* dst = reinterpret_cast<f32x4*>(fr.dzp + ((size_t)m * ntH + nt) * 8);
-          dst[0] = p0;
-          dst[1] = p1;
         }
       }
       MV_SPAN_END(3, 1);
@@ -2006,358 +1994,38 @@ __global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd(CompTable t, const 
 }
 
 
-// ================================================================== the "lite" backward of the fused-forward shapes
-// Launches 5 and 6 for models on the fused forward (NH <= 16, Z <= 8, B <= 256).  What the row path of k_latent_bwd did per
-// batch row -- load a row of dhd and W_d0 for dz, load W_heads and the row of h for dh = (dheads W_heads)[h > 0] -- was ~4.5
-// us of memory round trips behind ~130 wave-level requests per workgroup.  Here:
-//   * dz arrives as 25 partial products per row from launch 4's tiles (k_dec1_bwd, FragArgs::dzp) and is a fixed-order sum;
-//   * dh is never written: each dW_e0 workgroup of launch 6 rebuilds the fragments of dh it contracts with -- the MFMA
-//     D = dheads[16 rows][16] W_heads[16][16 columns], whose output lane layout IS the B-operand fragment of the weight-gradient
-//     MFMA -- masks them with h's fragment-order copy and shares them through LDS (their column sums are b_e0's gradient);
-//   * every batch contraction reads fragment-order operands (mvae_common.hpp: frag_off).
-// ---- 5': one WAVE per batch row: dz (sum of the partials) -> contraction with the dual records -> dheads; dW_logits tiles
-template <int DMAX, bool ADAM, int TW>
-__global__ __launch_bounds__(64 * TW) void k_latent_bwd2(CompTable t, const float* dzp, int ntH, int ldh, float* dheads,
-                                                     float* dheads16, float* dheadsF, float* drpart, const float* g,
-                                                     const float* hdF, float* dWl, float beta, int B, int H,
-                                                     int D, int NH, int Z, int n_rowwg, AdamArgs awl, const float* duals,
-                                                     const float* Wh, float* whF, int n_snap) {
-  __shared__ mvae_component_desc desc_s[kMaxComp];
-  __shared__ int doff_s[kMaxComp + 1];
-  __shared__ int first_s[kMaxComp + 1];
-  __shared__ float dz_s[TW][8];
-  __shared__ float dh_s[TW][16];
-  int b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  MV_SPAN_BEGIN(4);
-  if (b < n_snap) {  // (dispatched FIRST: at the end of the grid their requests queued behind everybody's, launch 5 +1 us)
-    // Launch 6 rebuilds dh = dheads W_heads while its dW_heads tiles update W_heads in place: it reads THIS launch's snapshot,
-    // laid out as the B fragments of that product: whF[(pt * 64 + q * 16 + i) * 4 + t] = W_heads[4 q + t][16 pt + i] (0 past NH)
-    for (int e = b * 64 * TW + tid; e < (H >> 4) * 256; e += n_snap * 64 * TW) {
-      const int pt = e >> 8, ln = (e & 255) >> 2, n = 4 * (ln >> 4) + (e & 3);
-      const float v = Wh[(size_t)(n < NH ? n : 0) * H + pt * 16 + (ln & 15)];
-      whF[e] = n < NH ? v : 0.f;
-    }
-    return;
-  }
-  b -= n_snap;
-  if (b >= n_rowwg) {  // dW_logits[D, H] tiles, one per wave
-    b -= n_rowwg;
-    // TW-wave workgroups over the linear tile index, so that tiles + row workgroups are about one per CU (a tile workgroup
-    // that shares its CU with another one finishes ~1 us late: 343 four-wave ones ended at 3.4 / 4.6 us)
-    const int tw = b * TW + wave, pt = fast_div(tw, ntH), qt = tw - pt * ntH;
-    // P = g read row-major in the fragments' row order (a second, fragment-order copy of g cost the forward launch more than
-    // these tiles gained), Q = hd in fragment order: 40 wave-level requests per tile instead of 64
-    if (pt * 16 < D) job_tn_halffrag<ADAM>(g, D, pt, D, hdF, qt, H, B >> 4, dWl, H, awl);
-    MV_SPAN_END(4, 2);
-    return;
-  }
-  const int row = b * TW + wave;
-  MV_STAMP(8);
-  // requests first: the row's 25 x 8 partials (lanes 0..ntH-1: two 16-byte vectors each), then the tables
-  f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(dzp + ((size_t)(row < B ? row : 0) * ntH + (lane < ntH ? lane : 0)) * 8);
-    const f32x4 a = src[0], c2 = src[1];
-    __builtin_amdgcn_sched_barrier(0);
-    if (lane < ntH) {
-      pa = a;
-      pb = c2;
-    }
-  }
-  // this lane's dual record (written by the forward launch): lane k owns the k-th active direction of the row.  Its
-  // component is found with a UNIFORM loop over the kernarg table (scalar loads, per-lane selects), so that the request
-  // travels with the partials above instead of behind the LDS tables.  (Measured: taking the whole descriptor through that
-  // loop -- no LDS tables, no barriers -- made the launch 1 us SLOWER: the scalar loads of the kernarg table are a dependent
-  // chain in front of everything else.)
-  constexpr int DS = DMAX + 2;
-  const int total = t.dir_off[t.n];
-  float du[DS];
-  int my_ci = 0, my_dir = 0;
-  {
-    const int gi = lane < total ? lane : 0;
-    int first = 0;
-    for (int ci = 0; ci < t.n; ++ci) {
-      const int lo = t.dir_off[ci], hi = t.dir_off[ci + 1];
-      const bool in = gi >= lo && gi < hi;
-      my_ci = in ? ci : my_ci;
-      my_dir = in ? gi - lo : my_dir;
-      first = in ? (int)t.first_dir[ci] : first;
-    }
-    const float* rec = duals + ((size_t)(row < B ? row : 0) * (NH + t.n) + first + my_dir) * DS;
-#pragma unroll
-    for (int i = 0; i < DS; ++i) du[i] = rec[i];
-  }
-  if (tid <= t.n) {
-    if (tid < t.n) desc_s[tid] = t.c[tid];
-    doff_s[tid] = t.dir_off[tid];
-    first_s[tid] = t.first_dir[tid < t.n ? tid : 0];
-  }
-  if (lane < 16) dh_s[wave][lane] = 0.f;
-  lds_barrier();
-  MV_STAMP(9);
-  // dz[j] = sum over the column tiles, in DPP-tree order (the same tree every step: deterministic)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    pa[j] = wave_sum(pa[j]);
-    pb[j] = wave_sum(pb[j]);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      dz_s[wave][j] = pa[j];
-      dz_s[wave][4 + j] = pb[j];
-    }
-  }
-  lds_barrier();
-  MV_STAMP(10);
-  // d(loss)/d(direction) = beta * d kl + <dz, d z>
-  for (int gi = lane; gi < total && row < B; gi += 64) {
-    if (gi >= 64) {
-      my_ci = 0;
-      while (gi >= doff_s[my_ci + 1]) ++my_ci;
-      my_dir = gi - doff_s[my_ci];
-      const float* rec = duals + ((size_t)row * (NH + t.n) + first_s[my_ci] + my_dir) * DS;
-#pragma unroll
-      for (int i = 0; i < DS; ++i) du[i] = rec[i];
-    }
-    const mvae_component_desc& c = desc_s[my_ci];
-    const int A = ambient_dim(c.kind, c.true_dim);
-    float gv = beta * du[0];
-#pragma unroll
-    for (int i = 0; i < DMAX + 1; ++i)
-      if (i < A) gv += dz_s[wave][c.z_col + i] * du[1 + i];
-    if (my_dir < c.true_dim) dh_s[wave][c.mean_col + my_dir] = gv;
-    else if (my_dir < c.true_dim + c.logvar_dim) dh_s[wave][c.logvar_col + (my_dir - c.true_dim)] = gv;
-    else drpart[(size_t)my_ci * B + row] = gv;
-  }
-  lds_barrier();
-  MV_STAMP(11);
-  if (lane < 16 && row < B) {
-    const float v = dh_s[wave][lane];  // zero past NH
-    if (lane < NH) dheads[(size_t)row * ldh + lane] = v;
-    dheads16[(size_t)row * 16 + lane] = v;          // A operand of launch 6's dh fragments
-    dheadsF[frag_off(row, lane, B >> 4)] = v;       // P operand of launch 6's dW_heads tiles
-  }
-  MV_STAMP(12);
-  MV_SPAN_END(4, 1);
-}
-
-// ---- 6': dW_e0 (+ b_e0) from rebuilt dh fragments, dW_heads, dW_d0, b_heads, b_d0 (+Adam) ; radius gradients (+SGD)
-// MBT = 8 (B <= 128) or 16 (B <= 256): row blocks held per lane
-template <bool ADAM, int MBT>
-__global__ __launch_bounds__(64 * kTileWaves) void k_enc_bwd2(CompTable t, const float* xF, const float* hF,
-                                                  const float* dheads16, const float* dheadsF, const float* dheads, int ldh,
-                                                  const float* whF, const float* dhdF, const float* zF, const float* drpart,
-                                                  float* G, float* P, int B, int H, int D, int NH, int Z, int n_small,
-                                                  int heads_on_idle, int64_t off_w_e0, int64_t off_b_e0, int64_t off_w_heads,
-                                                  int64_t off_b_heads, int64_t off_w_d0, int64_t off_b_d0, AdamArgs base,
-                                                  double curv_lr, int do_curv) {
-  __shared__ float red[4][16][17];
-  __shared__ f32x4 frag_s[MBT][64];  // the masked dh fragments of this workgroup's 16 columns, all row blocks
-  int b = blockIdx.x;
-  const int MB = B >> 4;
-  MV_SPAN_BEGIN(5);
-  auto at = [&](int64_t off) {
-    AdamArgs a = base;
-    a.p += off;
-    a.m += off;
-    a.v += off;
-    return a;
-  };
-  // Grid: 1 + n_small + tiles workgroups = 1 + 5 + 250 for the BASELINE shapes: exactly one per CU.
-  if (b == 0) {  // radius gradients (+ SGD) as in k_enc_bwd, then b_heads
-    job_radii<ADAM>(t, &red[0][0][0], drpart, G, P, B, curv_lr, do_curv);
-    __syncthreads();
-    job_colsum_opt<ADAM>(&red[0][0][0], dheads, ldh, B, NH, 0, G + off_b_heads, at(off_b_heads));  // NH <= 16: one block
-    MV_SPAN_END(5, 7);
-    return;
-  }
-  b -= 1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (b < n_small) {
-    // wave w, column tile tl = 5 b + w of H: the dW_d0 tile [16 rows tl, Z] = dhd^T z with b_d0's 16 entries (the column sums
-    // of its dhd fragments) and the dW_heads tile [NH, 16 columns tl] = dheads^T h; fragment-order operands.  (As two jobs
-    // one after the other these waves were the tail of the launch, 5.6 us; as ten workgroups the grid no longer fit one
-    // workgroup per CU and the last tile workgroups dispatched ended at 5.2 us.)
-    const int tl = b * kTileWaves + wave;
-    if (tl * 16 < H) {
-      if (heads_on_idle) {  // (dW_heads rides on the idle waves of the tile workgroups)
-        job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
-                                    at(off_b_d0));
-      } else if (MBT == 8) {  // both tiles requested before either is multiplied: the second round trip hides behind the first
-        FragJob<ADAM, true> j0;
-        FragJob<ADAM, false> j1;
-        const AdamArgs a0 = at(off_w_d0), b0 = at(off_b_d0), a1 = at(off_w_heads);
-        j0.request(dhdF, tl, H, zF, 0, Z, MB, Z, a0, b0);
-        j1.request(dheadsF, 0, NH, hF, tl, H, MB, H, a1, a1);
-        __builtin_amdgcn_sched_barrier(0);
-        j0.finish(H, Z, MB, G + off_w_d0, a0, G + off_b_d0, b0);
-        j1.finish(NH, H, MB, G + off_w_heads, a1, nullptr, a1);
-      } else {
-        job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
-                                    at(off_b_d0));
-        job_tn_frag<ADAM>(dheadsF, 0, NH, hF, tl, H, MB, G + off_w_heads, H, at(off_w_heads));
-      }
-    }
-    MV_SPAN_END(5, 3);
-    return;
-  }
-  b -= n_small;
-  {  // dW_e0[H, D] = dh^T x ; b_e0 = column sums of dh ; on the idle wave of a tile row: its dW_heads tile
-    const int ntDg = ((D >> 4) + kTileWaves - 1) / kTileWaves;
-    const int pt = fast_div(b, ntDg), qg = b - pt * ntDg;
-    const int qt = qg * kTileWaves + wave;
-    const bool have = qt * 16 < D;  // wave-uniform
-    const int i = lane & 15, q = lane >> 4;
-    // (uniform) the last tile group of a row of tiles has idle waves when D / 16 is not a multiple of 5.  The first of them
-    // adds up b_e0 for the workgroup's 16 columns and multiplies the dW_heads tile of those columns, dheads^T h: its Q
-    // operand is h's fragment (the same requests as a tile wave's x fragments, another base), its P operand dheads' one.
-    const bool idle_wave = heads_on_idle && !have && qt == (D >> 4);
-    // (on the idle wave, next to its dW_heads tile, the launch took 5.7 us against 5.2)
-    const bool bias_wave = qg == 0 && wave == 0;
-    // ---- requests.  First this wave's share of the dh fragments' operands (the workgroup meets on them): A = dheads16 rows
-    // of row blocks c = wave, wave + 5, ... (16 bytes per lane), B = W_heads[4 q + t][p0 + i] from launch 5's snapshot (this
-    // launch's dW_heads tiles update W_heads in place), mask = h's fragment.
-    constexpr int kPer = (MBT + kTileWaves - 1) / kTileWaves;
-    f32x4 da[kPer], hm[kPer];
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int c = wave + kTileWaves * u;
-      const int cc = c < MB ? c : 0;
-      da[u] = *reinterpret_cast<const f32x4*>(dheads16 + ((size_t)(16 * cc + i) << 4) + (q << 2));
-      hm[u] = reinterpret_cast<const f32x4*>(hF)[((size_t)(pt * MB + cc) << 6) + lane];
-    }
-    const f32x4 wb = reinterpret_cast<const f32x4*>(whF)[((size_t)pt << 6) + lane];  // launch 5's snapshot of W_heads
-    // the idle wave's P operand (the only requests behind a branch: the block ends with a wait for everything requested so
-    // far, which is exactly what the fragment phase below needs anyway)
-    f32x4 dv[MBT];
-#pragma unroll
-    for (int c = 0; c < MBT; ++c) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (idle_wave) {
-#pragma unroll
-      for (int c = 0; c < MBT; ++c) dv[c] = reinterpret_cast<const f32x4*>(dheadsF)[((size_t)(c < MB ? c : 0) << 6) + lane];
-    }
-    // Q operand and optimizer state, branch-free: tile wave = x's fragments of column tile qt and W_e0's tile (pt, qt);
-    // idle wave = h's fragments of column tile pt and W_heads' tile (0, pt)
-    const bool ok = idle_wave ? i < NH : have;
-    const size_t idx = idle_wave ? (size_t)(i < NH ? i : 0) * H + pt * 16 + (q << 2)
-                                 : (size_t)(pt * 16 + i) * D + (have ? qt : 0) * 16 + (q << 2);
-    const int64_t woff = idle_wave ? off_w_heads : off_w_e0;
-    const f32x4* qa = reinterpret_cast<const f32x4*>(idle_wave ? hF : xF) + ((size_t)(idle_wave ? pt : (have ? qt : 0)) * MB << 6) + lane;
-    f32x4 av[MBT];
-#pragma unroll
-    for (int c = 0; c < MBT; ++c) av[c] = qa[(size_t)(c < MB ? c : 0) << 6];
-    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
-    float neg_step = 0.f, bc2s = 1.f;
-    const int bcol = pt * 16 + i;
-    float bp = 0.f, bm = 0.f, bvv = 0.f;
-    if (ADAM) {
-      p0 = *reinterpret_cast<const f32x4*>(base.p + woff + idx);
-      m0 = *reinterpret_cast<const f32x4*>(base.m + woff + idx);
-      v0 = *reinterpret_cast<const f32x4*>(base.v + woff + idx);
-      neg_step = reinterpret_cast<const float*>(base.counters)[2];
-      bc2s = reinterpret_cast<const float*>(base.counters)[3];
-      // (every wave requests the bias column: under `if (bias_wave)` the compiler ends the block with a wait for ALL
-      // outstanding requests -- a full memory round trip in front of the fragment phase the five waves meet on)
-      bp = base.p[off_b_e0 + bcol];
-      bm = base.m[off_b_e0 + bcol];
-      bvv = base.v[off_b_e0 + bcol];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int c = wave + kTileWaves * u;
-      if (c < MB) {  // uniform
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d = mfma16(da[u][0], wb[0], d);
-        d = mfma16(da[u][1], wb[1], d);
-        d = mfma16(da[u][2], wb[2], d);
-        d = mfma16(da[u][3], wb[3], d);
-        // lane (column i, rows 4 q + r of block c): exactly the fragment position (q, i); ReLU mask from h
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = hm[u][r] > 0.f ? d[r] : 0.f;
-        frag_s[c][lane] = d;
-      }
-    }
-    lds_barrier();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, csum = acc;
-#pragma unroll
-    for (int c = 0; c < MBT; ++c) {
-      if (c < MB) {  // uniform
-        f32x4 bv = frag_s[c][lane];
-        if (bias_wave) csum += bv;
-        if (idle_wave) bv = dv[c];  // dheads' fragment instead of dh's
-        if (have || idle_wave) {
-          acc = mfma16(av[c][0], bv[0], acc);
-          acc2 = mfma16(av[c][1], bv[1], acc2);
-          acc = mfma16(av[c][2], bv[2], acc);
-          acc2 = mfma16(av[c][3], bv[3], acc2);
-        }
-      }
-    }
-    acc += acc2;
-    if (bias_wave) {
-      // b_e0[p0 + i] = sum over all rows of dh[:, p0 + i]: the lane's 4 MB values, then the four row quads q
-      float tsum = (csum[0] + csum[1]) + (csum[2] + csum[3]);
-      tsum += __shfl_xor(tsum, 16);
-      tsum += __shfl_xor(tsum, 32);
-      if (lane < 16) {
-        const int col = pt * 16 + lane;
-        G[off_b_e0 + col] = tsum;
-        if (ADAM) {  // (lanes 0..15: q == 0, so col == bcol)
-          adam1(bp, tsum, bm, bvv, neg_step, bc2s);
-          base.p[off_b_e0 + col] = bp;
-          base.m[off_b_e0 + col] = bm;
-          base.v[off_b_e0 + col] = bvv;
-        }
-      }
-    }
-    if (have || idle_wave) {
-      if (ADAM) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pp = p0[r], mm = m0[r], vv = v0[r];
-          adam1(pp, acc[r], mm, vv, neg_step, bc2s);
-          p0[r] = pp;
-          m0[r] = mm;
-          v0[r] = vv;
-        }
-      }
-      if (ok) {
-        store16_wt(G + woff, idx, acc);
-        if (ADAM) {
-          store16_wt(base.p + woff, idx, p0);
-          store16_wt(base.m + woff, idx, m0);
-          store16_wt(base.v + woff, idx, v0);
-        }
-      }
-    }
-    MV_SPAN_END(5, 1);
-  }
-}
-
-// =============================================================== the FOUR-launch step: launches 5' and 6' in one (k_bwd56)
-// What launch 5' did between launch 4 and launch 6' was small: add 25 partial products per row (dz), contract them with the
-// row's dual records (dheads), and -- independent of launch 4 -- the dW_logits tiles.  A launch costs ~4 us whatever it does
-// (DESIGN section 5), so:
-//   * dz arrives SUMMED: launch 4's tiles add their shares into 64-bit fixed-point accumulators with atomic adds (integer
-//     adds commute: the sum has the same bits in any arrival order; the forward launch zeroes them);
-//   * every workgroup of this launch rebuilds the dheads rows it needs from dz and the dual records -- which the forward
-//     launch now stores per HEAD COLUMN in the order these lanes read them (Rec4Args): lane (i, q) of the wave that owns row
-//     block c computes dheads[16 c + i][4 q .. 4 q + 3], which IS the A fragment of the dh product -- 4 NV + 1 wave-level
-//     requests per row block, no cross-wave dependency in front of the dh MFMAs;
-//   * the dW_logits tiles (+ Adam) ride on FIVE MORE WAVES of the same workgroups (W_logits was last read by launch 4); the
-//     five waves of the weight-gradient phase meet on an LDS counter, not on s_barrier, which would also wait for those.
-// Workgroup 0: radii (+ SGD, clip) and b_heads; workgroups 1 .. n_small: dW_d0 (+ b_d0) tiles; the rest: dW_e0 tiles as in
-// k_enc_bwd2.  1 + 5 + 250 workgroups of ten waves for the BASELINE shapes: one per CU.
+// ===================================================== the backward of the fused-forward shapes: launch 4 + ONE more (k_bwd56)
+// Models on the fused forward (NH <= 16, Z <= 8, B <= 256: BASELINE configs [0], [1], [2]) run the step in FOUR launches:
+// k_enc_fwd, k_fwd23, k_dec1_bwd<LITE 1>, k_bwd56.  What the generic launches 5 and 6 (k_latent_bwd, k_enc_bwd) do per batch
+// row -- load a row of dhd and W_d0 for dz, load W_heads and the row of h for dh = (dheads W_heads)[h > 0] -- and the launch
+// boundary between them (a launch costs ~4 us whatever it does) are replaced by:
+//   * dz arrives SUMMED: every dhd tile of launch 4 adds its share of dz = dhd W_d0 into 64-bit fixed-point accumulators with
+//     atomic adds (integer adds commute: the sum has the same bits in any arrival order; the forward launch zeroes them);
+//   * every workgroup of k_bwd56 rebuilds the dheads rows it needs from dz and the dual records -- which the forward launch
+//     stores per HEAD COLUMN in the order these lanes read them (Rec4Args): lane (i, q) of the wave that owns row block c
+//     computes dheads[16 c + i][4 q .. 4 q + 3], which IS the A fragment of the dh product -- 4 NV + 1 wave-level requests per
+//     row block, no cross-wave dependency in front of the dh MFMAs;
+//   * dh is never written: each dW_e0 workgroup rebuilds the fragments of dh it contracts with -- the MFMA D = dheads[16 rows][16]
+//     W_heads[16][16 columns], whose output lane layout IS the B-operand fragment of the weight-gradient MFMA -- masks them
+//     with h's fragment-order copy and shares them through LDS (their column sums are b_e0's gradient); W_heads is read from
+//     the snapshot short jobs of launch 4 write (this launch's dW_heads tiles update W_heads in place);
+//   * every batch contraction reads fragment-order operands (mvae_common.hpp: frag_off); only g is read row-major (a second,
+//     fragment-order copy of g cost the forward launch more than the tiles gained: 29.8 against 29.2 us per step);
+//   * the dW_logits tiles (+ Adam; W_logits was last read by launch 4) ride on FIVE MORE WAVES of the same workgroups.  They
+//     issue their requests only after the five main waves have issued theirs (an LDS counter; a CU's load path serves
+//     requests in issue order and the main waves carry the dependent chain), and the main waves meet on an LDS counter, not on
+//     s_barrier, which would also wait for the tile waves.
+// Workgroup 0: radii (+ SGD, clip) and b_heads; workgroups 1 .. n_small: dW_d0 (+ b_d0) tiles (and dW_heads where the rows of
+// tiles have no idle wave); the rest: 16 columns of dh x 5 x tiles each, dW_heads on the idle wave of the last tile group of
+// a row.  1 + 5 + 250 workgroups of ten waves for the BASELINE shapes: one per CU.
+// Measured (interleaved 2000-step runs, two boxes): 29.0-29.2 us per step against 31.0-31.2 with launches 5' + 6' (rounds 5's
+// k_latent_bwd2 / k_enc_bwd2, removed): launches 4.7 / 9.4 / 4.9 / 8.5 us against 4.7 / 9.4 / 4.8 / 4.75 + 5.2.
 constexpr int kW56 = 2 * kTileWaves;
 struct L56Args {
   const long long* dzfix;  // [B][8] fixed-point dz, then the overflow mark
   const float* recH;       // head-direction records (Rec4Args)
   const float* recR;       // radius-direction records
   const float* g;          // [B][D] row-major
-  const float* gF;         // g in fragment order, or NULL
   const float* hdF;        // hd in fragment order
   float* dheads;           // [B][ldh] (for observers; written by workgroup 0)
   float* drpart;           // [ncomp][B]     "
@@ -2375,20 +2043,25 @@ __device__ __forceinline__ void group_sync(int* ctr, int target) {
 }
 
 // dheads of the row blocks c = wave, wave + 5, ... of this wave (waves 0 .. 4): da[u] = dheads[16 c + i][4 q .. 4 q + 3] of lane
-// (i, q); also left in dh_s (every row of the batch once the five waves have met) and dz_s (dz as floats).
+// (i, q); also left in dh_s (every row of the batch once the five waves have met) and dz_s (dz as floats).  The blocks are
+// taken CH at a time (request(u0) ... finish(u0)): a pass holds CH x 4 NV record vectors per lane, and a ten-wave workgroup
+// has 168 registers -- one pass for the BASELINE shapes (B = 128, NV <= 2), more for B = 256 or records of three vectors.
 template <int NV, int MBT>
 struct DheadsJob {
   static constexpr int kPer = (MBT + kTileWaves - 1) / kTileWaves;
+  static constexpr int CH = NV >= 3 ? 1 : (kPer < 2 ? kPer : 2);
   static constexpr int AM = 4 * NV - 1;
   typedef long long i64x2 __attribute__((ext_vector_type(2)));
-  i64x2 zq[kPer];
-  f32x4 rv[kPer][4][NV];
+  i64x2 zq[CH];
+  f32x4 rv[CH][4][NV];
   unsigned mark;
-  __device__ __forceinline__ void request(const L56Args& a, int MB, int B, int wave, int lane) {
+  int zc[4], Aa[4];
+  __device__ __forceinline__ void request(const L56Args& a, int MB, int B, int wave, int lane, int u0 = 0,
+                                          const unsigned* mark_p = nullptr) {
     const int i = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int c = wave + kTileWaves * u;
+    for (int u = 0; u < CH; ++u) {
+      const int c = wave + kTileWaves * (u0 + u);
       const int cc = c < MB ? c : 0;
       zq[u] = *reinterpret_cast<const i64x2*>(a.dzfix + ((size_t)(16 * cc + i) << 3) + (q << 1));
 #pragma unroll
@@ -2397,13 +2070,13 @@ struct DheadsJob {
         for (int v = 0; v < NV; ++v)
           rv[u][tt][v] = reinterpret_cast<const f32x4*>(a.recH)[((size_t)((cc * 4 + tt) * NV + v) << 6) + lane];
     }
-    mark = *reinterpret_cast<const unsigned*>(a.dzfix + (size_t)B * 8);
+    if (u0 == 0) mark = mark_p ? *mark_p : *reinterpret_cast<const unsigned*>(a.dzfix + (size_t)B * 8);
   }
-  __device__ __forceinline__ void finish(const CompTable& t, const L56Args& a, int MB, int NH, int wave, int lane,
-                                         f32x4 (&da)[kPer], float (*dh_s)[16], float (*dz_s)[8]) {
-    const int i = lane & 15, q = lane >> 4;
-    // this lane's four head columns 4 q + tt: z column and ambient dimension of the component that owns each (A = 0: none)
-    int zc[4] = {0, 0, 0, 0}, Aa[4] = {0, 0, 0, 0};
+  // this lane's four head columns 4 q + tt: z column and ambient dimension of the component that owns each (A = 0: none)
+  __device__ __forceinline__ void tables(const CompTable& t, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) zc[tt] = Aa[tt] = 0;
     for (int ci = 0; ci < t.n; ++ci) {  // uniform loop, per-lane selects
       const mvae_component_desc c = t.c[ci];
       const int A = ambient_dim(c.kind, c.true_dim);
@@ -2416,10 +2089,15 @@ struct DheadsJob {
         Aa[tt] = in ? A : Aa[tt];
       }
     }
+  }
+  __device__ __forceinline__ void finish(const L56Args& a, int MB, int NH, int wave, int lane, f32x4 (&da)[kPer],
+                                         float (*dh_s)[16], float (*dz_s)[8], int u0 = 0) {
+    const int i = lane & 15, q = lane >> 4;
     const float nanv = __int_as_float(0x7fc00000);
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int c = wave + kTileWaves * u;
+    for (int u = 0; u < CH; ++u) {
+      if (u0 + u >= kPer) break;
+      const int c = wave + kTileWaves * (u0 + u);
       if (c < MB) {  // uniform
         const int row = 16 * c + i;
         float d0 = (float)((double)zq[u][0] * (1.0 / kDzScale)), d1 = (float)((double)zq[u][1] * (1.0 / kDzScale));
@@ -2443,27 +2121,42 @@ struct DheadsJob {
           }
           gv[tt] = (Aa[tt] > 0 && 4 * q + tt < NH) ? acc : 0.f;
         }
-        da[u] = gv;
+        da[u0 + u] = gv;
         *reinterpret_cast<f32x4*>(&dh_s[row][4 * q]) = gv;
       } else {
-        da[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        da[u0 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
+  }
+  // the passes after the first (their records are requested only now: a memory round trip each)
+  __device__ __forceinline__ void rest(const L56Args& a, int MB, int B, int NH, int wave, int lane, f32x4 (&da)[kPer],
+                                       float (*dh_s)[16], float (*dz_s)[8]) {
+#pragma unroll
+    for (int u0 = CH; u0 < kPer; u0 += CH) {
+      __builtin_amdgcn_sched_barrier(0);
+      request(a, MB, B, wave, lane, u0);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(a, MB, NH, wave, lane, da, dh_s, dz_s, u0);
     }
   }
 };
 
 template <int NV, bool ADAM, int MBT>
-__global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, const float* xF, const float* hF, const float* whF,
+__global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, const float* __restrict__ scal_p,
+                                                     const unsigned* __restrict__ mark_p, const float* xF, const float* hF, const float* whF,
                                                      const float* dhdF, const float* zF, float* G, float* P, int B, int H,
                                                      int D, int NH, int Z, int n_small, int heads_on_idle, int64_t off_w_e0,
                                                      int64_t off_b_e0, int64_t off_w_heads, int64_t off_b_heads,
                                                      int64_t off_w_d0, int64_t off_b_d0, AdamArgs base, double curv_lr,
                                                      int do_curv) {
+  // scal_p = {-lr/bc1, sqrt(bc2)} of this step (launch 1; counters[2..3]) and mark_p = the dz overflow mark: uniform values
+  // behind __restrict__ pointers, so that they are SCALAR loads -- as vector loads they were 3 of a wave's ~25 requests
   __shared__ float red[4][16][17];
   __shared__ f32x4 frag_s[MBT][64];  // the masked dh fragments of this workgroup's 16 columns, all row blocks
   __shared__ __attribute__((aligned(16))) float dh_s[MBT * 16][16];  // dheads of every batch row (zero past NH)
   __shared__ __attribute__((aligned(16))) float dz_s[MBT * 16][8];   // dz of every batch row
-  __shared__ int meet_s;
+  __shared__ int meet_s, gate_s;
+  const float scal[2] = {ADAM ? scal_p[0] : 0.f, ADAM ? scal_p[1] : 1.f};
   const int b = blockIdx.x;
   const int MB = B >> 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2484,7 +2177,7 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
     constexpr int kRI = (kRecRad * MBT * 16 + 64 * kW56 - 1) / (64 * kW56);
     DheadsJob<NV, MBT> dj;
     f32x4 da[kPer];
-    if (wave < kTileWaves) dj.request(a, MB, B, wave, lane);
+    if (wave < kTileWaves) dj.request(a, MB, B, wave, lane, 0, mark_p);
     f32x4 rr[kRI][NV];
     const int n_items = t.n * B;
 #pragma unroll
@@ -2502,11 +2195,15 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
       bp = base.p[off_b_heads + col];
       bm = base.m[off_b_heads + col];
       bv2 = base.v[off_b_heads + col];
-      neg_step = reinterpret_cast<const float*>(base.counters)[2];
-      bc2s = reinterpret_cast<const float*>(base.counters)[3];
+      neg_step = scal[0];
+      bc2s = scal[1];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (wave < kTileWaves) dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
+    if (wave < kTileWaves) {
+      dj.tables(t, lane);
+      dj.finish(a, MB, NH, wave, lane, da, dh_s, dz_s);
+      dj.rest(a, MB, B, NH, wave, lane, da, dh_s, dz_s);
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRI; ++k) {
@@ -2560,17 +2257,26 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
     MV_SPAN_END(5, 7);
     return;
   }
-  if (threadIdx.x == 0) meet_s = 0;
+  if (threadIdx.x == 0) meet_s = gate_s = 0;
   __syncthreads();  // (the only hardware barrier of these workgroups: all ten waves are at their first instructions)
+  auto open_gate = [&]() {  // a main wave has issued its requests
+    if (lane == 0) __hip_atomic_fetch_add(&gate_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
   if (wave >= kTileWaves) {
     // ---- dW_logits[D, H] tiles (+ Adam), one per wave: tile index over (workgroup - 1, wave - 5)
     const int ntH = H >> 4;
     const int tw = (b - 1) * kTileWaves + (wave - kTileWaves), pt = fast_div(tw, ntH), qt = tw - pt * ntH;
     if (pt * 16 < D) {
+      // The main waves' requests first: a CU's load path serves ~1 wave-level request per 36 cycles in issue order, and these
+      // tiles have slack -- issued from the first cycle they ended at 4.8 us of a 7.4 us launch while the main waves' operands
+      // queued behind their ~200 requests
+      // (measured: 29.2 against 29.5 us per step without the wait)
+      while (__hip_atomic_load(&gate_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kTileWaves) __builtin_amdgcn_s_sleep(4);
       const AdamArgs awl = at(a.off_w_logits);
-      if (a.gF) job_tn_frag<ADAM>(a.gF, pt, D, a.hdF, qt, H, MB, G + a.off_w_logits, H, awl);
-      else job_tn_halffrag<ADAM>(a.g, D, pt, D, a.hdF, qt, H, MB, G + a.off_w_logits, H, awl);
+      // P = g read row-major in the fragments' row order, Q = hd in fragment order: 40 wave-level requests per tile
+      job_tn_halffrag<ADAM>(a.g, D, pt, D, a.hdF, qt, H, MB, G + a.off_w_logits, H, awl, scal);
     }
+    MV_SPAN_END_T(5, 2, 64 * kTileWaves, 1024);
     return;
   }
   const int bs = b - 1;
@@ -2579,9 +2285,10 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
     // of its dhd fragments); without idle tile waves (D / 16 a multiple of 5) also the dW_heads tile [NH, 16 columns tl]
     const int tl = bs * kTileWaves + wave;
     const bool live = tl * 16 < H;  // uniform
+    open_gate();
     if (live)
       job_tn_frag_any<ADAM, true>(dhdF, nullptr, 0, tl, H, zF, 0, Z, MB, G + off_w_d0, Z, at(off_w_d0), G + off_b_d0,
-                                  at(off_b_d0));
+                                  at(off_b_d0), scal);
     if (!heads_on_idle) {  // (uniform; one job after the other: a rare shape, and both at once do not fit the registers)
       DheadsJob<NV, MBT> dj;
       f32x4 da[kPer];
@@ -2590,18 +2297,21 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
       float neg_step = 0.f, bc2s = 1.f;
       const bool okh = i < NH && live;
       const size_t idxh = (size_t)(i < NH ? i : 0) * H + (live ? tl : 0) * 16 + (q << 2);
-      dj.request(a, MB, B, wave, lane);
+      dj.request(a, MB, B, wave, lane, 0, mark_p);
 #pragma unroll
       for (int c = 0; c < MBT; ++c) hv[c] = reinterpret_cast<const f32x4*>(hF)[((size_t)((live ? tl : 0) * MB + (c < MB ? c : 0)) << 6) + lane];
-      if (ADAM) {
+      __builtin_amdgcn_sched_barrier(0);
+      dj.tables(t, lane);
+      dj.finish(a, MB, NH, wave, lane, da, dh_s, dz_s);
+      dj.rest(a, MB, B, NH, wave, lane, da, dh_s, dz_s);
+      if (ADAM) {  // (requested late: together with the records they do not fit the registers)
         p0 = *reinterpret_cast<const f32x4*>(base.p + off_w_heads + idxh);
         m0 = *reinterpret_cast<const f32x4*>(base.m + off_w_heads + idxh);
         v0 = *reinterpret_cast<const f32x4*>(base.v + off_w_heads + idxh);
-        neg_step = reinterpret_cast<const float*>(base.counters)[2];
-        bc2s = reinterpret_cast<const float*>(base.counters)[3];
+        neg_step = scal[0];
+        bc2s = scal[1];
       }
       __builtin_amdgcn_sched_barrier(0);
-      dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
       group_sync(&meet_s, kTileWaves);
       if (live) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
@@ -2650,7 +2360,8 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
     // the operands of the dh product (B = W_heads[4 q + t][p0 + i] from launch 4's snapshot: this launch's dW_heads tiles
     // update W_heads in place; mask = h's fragment), then the tile's own
     DheadsJob<NV, MBT> dj;
-    dj.request(a, MB, B, wave, lane);
+    MV_STAMP_B(40, MV_STAMP_BLK);
+    dj.request(a, MB, B, wave, lane, 0, mark_p);
     f32x4 da[kPer], hm[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
@@ -2666,27 +2377,47 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
                                  : (size_t)(pt * 16 + i) * D + (have ? qt : 0) * 16 + (q << 2);
     const int64_t woff = idle_wave ? off_w_heads : off_w_e0;
     const f32x4* qa = reinterpret_cast<const f32x4*>(idle_wave ? hF : xF) + ((size_t)(idle_wave ? pt : (have ? qt : 0)) * MB << 6) + lane;
+    // Wide records (NV >= 2) or sixteen row blocks: the records and the tile's Q fragments do not fit the 168 registers of a
+    // ten-wave workgroup together -- the tile's own operands are then requested once the dheads rows are done (their round
+    // trip overlaps the dh product and the meeting instead of the records' one)
+    constexpr bool kLateQ = NV >= 2 || MBT > 8;
     f32x4 av[MBT];
-#pragma unroll
-    for (int c = 0; c < MBT; ++c) av[c] = qa[(size_t)(c < MB ? c : 0) << 6];
     f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, m0 = p0, v0 = p0;
     float neg_step = 0.f, bc2s = 1.f;
     const int bcol = pt * 16 + i;
     float bp = 0.f, bm = 0.f, bvv = 0.f;
-    if (ADAM) {
-      p0 = *reinterpret_cast<const f32x4*>(base.p + woff + idx);
-      m0 = *reinterpret_cast<const f32x4*>(base.m + woff + idx);
-      v0 = *reinterpret_cast<const f32x4*>(base.v + woff + idx);
-      neg_step = reinterpret_cast<const float*>(base.counters)[2];
-      bc2s = reinterpret_cast<const float*>(base.counters)[3];
-      // (every wave requests the bias column: under `if (bias_wave)` the compiler ends the block with a wait for ALL
-      // outstanding requests -- a full memory round trip in front of the fragment phase the five waves meet on)
-      bp = base.p[off_b_e0 + bcol];
-      bm = base.m[off_b_e0 + bcol];
-      bvv = base.v[off_b_e0 + bcol];
-    }
+    auto request_tile = [&]() {
+#pragma unroll
+      for (int c = 0; c < MBT; ++c) av[c] = qa[(size_t)(c < MB ? c : 0) << 6];
+      if (ADAM) {
+        p0 = *reinterpret_cast<const f32x4*>(base.p + woff + idx);
+        m0 = *reinterpret_cast<const f32x4*>(base.m + woff + idx);
+        v0 = *reinterpret_cast<const f32x4*>(base.v + woff + idx);
+        neg_step = scal[0];
+        bc2s = scal[1];
+        // (the bias column: requested by every wave of the FIRST tile group of a row of tiles -- under `if (bias_wave)` the
+        // compiler ends the block with a wait for ALL outstanding requests, a full memory round trip in front of the
+        // fragment phase the five waves meet on; the other nine tile groups of the row do not request it at all)
+        if (qg == 0) {  // (uniform per workgroup)
+          bp = base.p[off_b_e0 + bcol];
+          bm = base.m[off_b_e0 + bcol];
+          bvv = base.v[off_b_e0 + bcol];
+        }
+      }
+    };
+    if (!kLateQ) request_tile();
+    open_gate();
     __builtin_amdgcn_sched_barrier(0);
-    dj.finish(t, a, MB, NH, wave, lane, da, dh_s, dz_s);
+    MV_STAMP_B(41, MV_STAMP_BLK);
+    dj.tables(t, lane);
+      dj.finish(a, MB, NH, wave, lane, da, dh_s, dz_s);
+      dj.rest(a, MB, B, NH, wave, lane, da, dh_s, dz_s);
+    MV_STAMP_B(42, MV_STAMP_BLK);
+    if (kLateQ) {
+      __builtin_amdgcn_sched_barrier(0);
+      request_tile();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int c = wave + kTileWaves * u;
@@ -2702,7 +2433,9 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
         frag_s[c][lane] = d;
       }
     }
+    MV_STAMP_B(43, MV_STAMP_BLK);
     group_sync(&meet_s, kTileWaves);
+    MV_STAMP_B(44, MV_STAMP_BLK);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, csum = acc;
 #pragma unroll
     for (int c = 0; c < MBT; ++c) {
@@ -2722,6 +2455,7 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
       }
     }
     acc += acc2;
+    MV_STAMP_B(45, MV_STAMP_BLK);
     if (bias_wave) {
       // b_e0[p0 + i] = sum over all rows of dh[:, p0 + i]: the lane's 4 MB values, then the four row quads q
       float tsum = (csum[0] + csum[1]) + (csum[2] + csum[3]);
@@ -2758,6 +2492,7 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
         }
       }
     }
+    MV_STAMP_B(46, MV_STAMP_BLK);
     MV_SPAN_END(5, 1);
   }
 }
@@ -2970,7 +2705,7 @@ extern "C" int mvae_step_kernel_path(const mvae_ctx* c) { return c ? latent_path
 // fused = single-GPU step (Adam/SGD in the gradient epilogues, no k_optim); otherwise gradients only.
 static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, bool fused, int do_curv,
                      int want_outputs, float* logits, float* concat_z, float* bce, float* kl, void* stream,
-                     hipEvent_t* ev, int parts = MVAE_STEP_HEAD | MVAE_STEP_TAIL) {
+                     hipEvent_t* ev) {
   // profile slot of the next launch (0 enc_fwd, 1 latent_fwd, 2 dec1_fwd | the fused 2+3, 3 dec1_bwd, 4 latent_bwd,
   // 5 enc_bwd); with `ev` != NULL the launch is bracketed by ev[2 ki] (start) / ev[2 ki + 1] (stop)
   int ki = 0;
@@ -2980,7 +2715,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, s, __VA_ARGS__);                                          \
   } while (0)
   if (!c || !x || !eps) return fail(MVAE_E_BADARG, "null pointer%s", "");
-  if ((parts & MVAE_STEP_HEAD) && c->feed.images && (c->feed.x == x || c->feed.eps == eps)) {
+  if (c->feed.images && (c->feed.x == x || c->feed.eps == eps)) {
     c->feed = FeedArgs{};  // launch 4 would overwrite what launches 4-6 read
     return fail(MVAE_E_BADARG, "mvae_set_next_batch_feed: x_next / eps_next are the buffers this step reads%s", "");
   }
@@ -3012,10 +2747,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // FULL: tile-aligned shapes and 16-byte aligned operands (true for every BASELINE MLP config at B = 128)
   const bool full = (B % 16 == 0) && (H % 16 == 0) && (D % 16 == 0) && aligned16(x) && aligned16(P + d.off_w_e0) &&
                     aligned16(P + d.off_w_logits) && aligned16(ws);
-  // The "lite" backward (k_latent_bwd2 / k_enc_bwd2, fragment-order operands): fused-forward shapes with B <= 256.
-  // MVAE_NO_LITE=1: the round-4 launches (A/B measurements).
+  // The four-launch step (k_dec1_bwd<LITE 1> + k_bwd56, fragment-order operands): fused-forward shapes with B <= 256.
+  // MVAE_NO_LITE=1: the generic backward launches (A/B measurements, and the other half of the lite-vs-generic parity test).
   const bool lite = full && !c->no_lite && latent_path(c, aligned16(x)) == MVAE_PATH_FUSED && !uses_blk_bwd(c, aligned16(x)) &&
-                    fast_b && NH <= 16 && Z <= 8 && B <= 256;
+                    fast_b && NH <= 16 && Z <= 8 && B <= 256 && d.ncomp <= kRecRad && c->rec_nv <= kRecVecMax;
   // the block backward (many small components) takes dz from partial products of launch 4's tiles too (z_dim 17 .. 64),
   // and its weight gradients from fragment-order operands (k_enc_bwd3)
   const bool dzp_blk = full && !c->no_lite && uses_blk_bwd(c, aligned16(x)) && Z > 16 && Z <= 64;
@@ -3027,12 +2762,10 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
         *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = dzp_blk ? ws + c->o_dhF : nullptr;
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
-  float *dzp = ws + c->o_dzp, *dheads16 = ws + c->o_dheads16, *whF = ws + c->o_whF;
-  // the four-launch step (k_bwd56 = launches 5' and 6' in one): MVAE_STEP5=1 keeps the two launches (A/B measurements)
-  const bool four = lite && !c->five_launch && d.ncomp <= kRecRad && c->rec_nv <= kRecVecMax;
-  float *recH = ws + c->o_recH, *recR = ws + c->o_recR, *gF = ws + c->o_gF;
+  float *dzp = ws + c->o_dzp, *whF = ws + c->o_whF;
+  float *recH = ws + c->o_recH, *recR = ws + c->o_recR;
   long long* dzfix = reinterpret_cast<long long*>(ws + c->o_dzfix);
-  if (parts & MVAE_STEP_HEAD) {  // launches 1-5
+  {
   ki = 0;
   if (full)
     STEP_LAUNCH(k_enc_fwd<true>, dim3(8 * ((c->nt_h + 7) / 8) * c->nt_b), dim3(512), 0, x, P + d.off_w_e0,
@@ -3062,7 +2795,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
               NH, Z, duals, zF, hdF, r4)
-    const Rec4Args r4 = {four ? recH : nullptr, recR, four ? dzfix : nullptr, (four && c->gf) ? gF : nullptr, c->rec_nv};
+    const Rec4Args r4 = {lite ? recH : nullptr, recR, lite ? dzfix : nullptr, c->rec_nv};
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
@@ -3133,9 +2866,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
-    const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, fr6 ? dzp : nullptr, P + d.off_w_d0, Z,
+    const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, dzp_blk ? dzp : nullptr, P + d.off_w_d0, Z,
                          z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0,
-                         four ? dzfix : nullptr, P + d.off_w_heads, whF, four ? 4 : 0, NH};
+                         lite ? dzfix : nullptr, P + d.off_w_heads, whF, lite ? 4 : 0, NH};
     const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
@@ -3165,24 +2898,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
                      hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
-    if (four) {
+    if (lite) {
       // (no launch 5: k_bwd56, the TAIL part, does its work)
-    } else if (lite) {
-      const int n_snap = 4;  // W_heads snapshot workgroups (1600 floats each for H = 400)
-      // seven waves per workgroup: 4 + 19 + 175 workgroups, one per CU (five: 275 workgroups, rows end 4.3 us / tiles 3.9; seven:
-      // 3.9 / 4.0 -- the step 30.79 -> 30.77 us, within the noise)
-      constexpr int tw5 = 7;
-      const int n_rowwg = (B + tw5 - 1) / tw5, n_tiles = (c->nt_d * c->nt_h + tw5 - 1) / tw5;
-#define LB2(DM, AD) LB2W(DM, AD, tw5)
-#define LB2W(DM, AD, TWV)                                                                                                  \
-  STEP_LAUNCH((k_latent_bwd2<DM, AD, TWV>), dim3(n_snap + n_rowwg + n_tiles), dim3(64 * TWV), 0, c->t, dzp, c->nt_h, c->ldh, dheads,     \
-              dheads16, dheadsF, drpart, g, hdF, G + d.off_w_logits, beta, B, H, D, NH, Z, n_rowwg,               \
-              at(d.off_w_logits), duals, P + d.off_w_heads, whF, n_snap)
-      const int bk = bucket_of(c->dmax);
-      if (fused) { if (bk == 2) LB2(2, true); else if (bk == 4) LB2(4, true); else LB2(8, true); }
-      else { if (bk == 2) LB2(2, false); else if (bk == 4) LB2(4, false); else LB2(8, false); }
-#undef LB2
-#undef LB2W
     } else if (uses_blk_bwd(c, aligned16(x))) {
       const int n_blk = c->nt_b * ((H + 63) / 64);
       const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
@@ -3207,7 +2924,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #undef LB
   }
   }
-  if (parts & MVAE_STEP_TAIL) {
+  {
     ki = 5;
     const int tw = kTileWaves;
     const int n_we0 = c->nt_h * ((c->nt_d + tw - 1) / tw), n_wh = ((NH + 15) / 16) * ((c->nt_h + tw - 1) / tw),
@@ -3215,12 +2932,14 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_be0 = (H + kColsPerBlock - 1) / kColsPerBlock, n_bh = (NH + kColsPerBlock - 1) / kColsPerBlock,
               n_bd0 = n_be0;
     const int grid = n_we0 + n_wh + n_wd0 + n_be0 + n_bh + n_bd0 + 1;
-    if (four) {
+    if (lite) {
       const int n_small = (c->nt_h + tw - 1) / tw;
       const int grid2 = 1 + n_small + n_we0;
-      const L56Args la = {dzfix, recH, recR, g, c->gf ? gF : nullptr, hdF, dheads, drpart, c->ldh, beta, d.off_w_logits};
+      const L56Args la = {dzfix, recH, recR, g, hdF, dheads, drpart, c->ldh, beta, d.off_w_logits};
+      const float* scal_p = reinterpret_cast<const float*>(d.step_count) + 2;
+      const unsigned* mark_p = reinterpret_cast<const unsigned*>(dzfix + (size_t)B * 8);
 #define B56(NVV, AD, MBT)                                                                                            \
-  STEP_LAUNCH((k_bwd56<NVV, AD, MBT>), dim3(grid2), dim3(64 * kW56), 0, c->t, la, xF, hF, whF, dhdF, zF, G, P, B, H, D, \
+  STEP_LAUNCH((k_bwd56<NVV, AD, MBT>), dim3(grid2), dim3(64 * kW56), 0, c->t, la, scal_p, mark_p, xF, hF, whF, dhdF, zF, G, P, B, H, D, \
               NH, Z, n_small, (c->nt_d % tw) != 0 ? 1 : 0, d.off_w_e0, d.off_b_e0, d.off_w_heads, d.off_b_heads,      \
               d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
 #define B56N(AD, MBT) do { if (c->rec_nv == 1) B56(1, AD, MBT); else if (c->rec_nv == 2) B56(2, AD, MBT); else B56(3, AD, MBT); } while (0)
@@ -3228,16 +2947,6 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       else { if (B <= 128) B56N(false, 8); else B56N(false, 16); }
 #undef B56N
 #undef B56
-    } else if (lite) {
-      const int n_small = (c->nt_h + tw - 1) / tw;
-      const int grid2 = 1 + n_small + n_we0;
-#define EB2(AD, MBT)                                                                                                 \
-  STEP_LAUNCH((k_enc_bwd2<AD, MBT>), dim3(grid2), dim3(64 * kTileWaves), 0, c->t, xF, hF, dheads16, dheadsF, dheads,  \
-              c->ldh, whF, dhdF, zF, drpart, G, P, B, H, D, NH, Z, n_small, (c->nt_d % tw) != 0 ? 1 : 0, d.off_w_e0, d.off_b_e0, d.off_w_heads,    \
-              d.off_b_heads, d.off_w_d0, d.off_b_d0, base, (double)d.curvature_lr, do_curv)
-      if (fused) { if (B <= 128) EB2(true, 8); else EB2(true, 16); }
-      else { if (B <= 128) EB2(false, 8); else EB2(false, 16); }
-#undef EB2
     } else if (dzp_blk) {
       // seven waves per workgroup: 49 x tiles of a dh column block = 7 x 7, and 1 + 11 + 18 + 175 workgroups for config [3] fit
       // one per CU (five-wave workgroups, 291 of them: 39.0 us per step against 37.8)
@@ -3292,12 +3001,6 @@ extern "C" int mvae_set_next_batch_feed(mvae_ctx* c, const uint8_t* images, cons
 extern "C" int mvae_step_forward_backward(mvae_ctx* c, const float* x, const float* eps, float beta, int want_outputs,
                                           float* logits, float* concat_z, float* bce, float* kl, void* stream) {
   return step_impl(c, x, eps, beta, false, 0, want_outputs, logits, concat_z, bce, kl, stream, nullptr);
-}
-
-extern "C" int mvae_step_forward_backward_parts(mvae_ctx* c, const float* x, const float* eps, float beta, int parts,
-                                                void* stream) {
-  if (!(parts & (MVAE_STEP_HEAD | MVAE_STEP_TAIL))) return fail(MVAE_E_BADARG, "parts must name HEAD and / or TAIL%s", "");
-  return step_impl(c, x, eps, beta, false, 0, 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, parts);
 }
 
 extern "C" int mvae_step_optimizer(mvae_ctx* c, int do_curvature_step, void* stream) {

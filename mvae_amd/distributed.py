@@ -5,10 +5,10 @@ parameters and the loss is a batch SUM (stats.py:200-202), so:
   * batch rows are split contiguously across ranks (`shard_rows`), every rank draws / receives its own eps rows;
   * parameters, optimizer state and radii are replicated;
   * ONE exchange per step: all-reduce(SUM) of the flat gradient buffer (P floats, 2.55 MB for h2,s2,e2) as ONE bucket
-    on the default route (librccl directly on the step's stream, mvae_amd/rccl.py), after the last backward launch;
-    then every rank applies the identical optimizer step.  (The torch.distributed route -- the agreed fall-back, and
-    MVAE_DP_EXCHANGE=allreduce -- splits it in two buckets by default (MVAE_DP_OVERLAP): the fc_logits half of the buffer is
-    final one launch before the rest, so its all-reduce is issued there and travels while the last backward launch runs);
+    (librccl directly on the step's stream, mvae_amd/rccl.py, by default; torch.distributed's all_reduce as the agreed
+    fall-back and for engines without a HIP device), after the last backward launch; then every rank applies the identical
+    optimizer step.  (Rounds 2-5 could split the exchange in two buckets -- fc_logits' half of the buffer was final one launch
+    before the rest; since the four-launch step produces every weight gradient in its last launch there is nothing to overlap);
   * the epoch >= 10 gate and the radius warm-up are functions of the epoch only: no communication;
   * statistics are summed across ranks only when somebody reads them (`reduce_stats`).
 `engine` is anything with `.grads` (flat tensor), `.stats`, `forward_backward(x, eps, beta)` and
@@ -89,12 +89,9 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 class DataParallelStep:
 
     def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False,
-                 overlap: Optional[bool] = None, exchange: Optional[str] = None) -> None:
+                 exchange: Optional[str] = None) -> None:
         """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
         exercises the collective, its graph capture and k_optim on a single GPU).
-        overlap: two-bucket exchange overlapped with the last backward launch (MVAE_DP_OVERLAP=1 / 0; default: off for the
-        direct RCCL route -- one all-reduce of the whole buffer after the backward pass, on the step's stream --, on for
-        torch.distributed's asynchronous all_reduce).
         exchange (MVAE_DP_EXCHANGE): "rccl" -- ncclAllReduce on librccl DIRECTLY, enqueued on the step's own streams
         (mvae_amd/rccl.py: no ProcessGroupNCCL, no watchdog thread, captured natively; the process group is only the side
         channel for the communicator id and may be gloo) -- the default for an engine on a HIP device; "allreduce" --
@@ -106,8 +103,6 @@ class DataParallelStep:
         self.engine = engine
         self.group = group
         self.always_exchange = bool(always_exchange)
-        env_overlap = os.environ.get("MVAE_DP_OVERLAP")
-        self.overlap = (env_overlap not in ("0", "")) if (overlap is None and env_overlap is not None) else overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         on_hip = getattr(getattr(engine, "grads", None), "is_cuda", False)
@@ -132,7 +127,6 @@ class DataParallelStep:
             from .rccl import FlatAllReduce, RcclUnavailable
             try:
                 self.rccl = FlatAllReduce(engine.device, group)
-                self._side = torch.cuda.Stream(device=engine.device)  # the exchange travels here while launch 6 runs
             except RcclUnavailable as e:
                 # EVERY rank is here (FlatAllReduce agrees on the outcome of each stage before going on, so a failure
                 # on one rank raises RcclUnavailable on all of them): the ranks fall back TOGETHER to torch.distributed's
@@ -141,12 +135,6 @@ class DataParallelStep:
                 self.exchange = "allreduce"
                 self.exchange_note = f"fallback from rccl: {e}"
                 self._fallback_group = self._make_fallback_group(engine.device)
-        if self.overlap is None:
-            # Default: on for torch.distributed's asynchronous all_reduce (the backend's own stream), OFF for the direct
-            # RCCL route, whose steps are captured: a kernel on a side stream between a fork and a join of a captured step
-            # costs ~20 us of cross-queue dependency on this runtime (measured at world 1 with half of k_optim on the side
-            # stream: 37.8 -> 58.6 us / step) against the <= 5.5 us of launch 6 the overlap can hide.
-            self.overlap = self.rccl is None
         self.steps_since_check = 0
 
     def _make_fallback_group(self, device):
@@ -218,40 +206,10 @@ class DataParallelStep:
             self.peer.optimizer_step(do_curvature_step, batch=x_local.shape[0])
             self.steps_since_check += 1
             return
+        eng.forward_backward(x_local, eps_local, beta)
         if self.rccl is not None:
-            main = torch.cuda.current_stream(eng.device)
-            if self.overlap and hasattr(eng, "forward_backward_part"):
-                # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5; its
-                # all-reduce is enqueued on the side stream behind an event and travels while launch 6 runs
-                off = eng.flat.off_w_logits
-                eng.forward_backward_part(x_local, eps_local, beta, eng.HEAD)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    self.rccl.all_reduce(eng.grads[off:])
-                eng.forward_backward_part(x_local, eps_local, beta, eng.TAIL)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    self.rccl.all_reduce(eng.grads[:off])
-                main.wait_stream(self._side)
-            else:
-                eng.forward_backward(x_local, eps_local, beta)
-                self.rccl.all_reduce(eng.grads)
-            eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
-            return
-        if self.overlap and hasattr(eng, "forward_backward_part"):
-            # bucket 1 = fc_logits.{weight,bias}: the LAST segment of the flat buffer, final after launch 5.  An async
-            # collective is ordered after the work already on the current stream and runs on the backend's own stream,
-            # so it overlaps launch 6, which is issued next; both buckets are waited for (stream-level) before the
-            # optimizer kernel.
-            off = eng.flat.off_w_logits
-            eng.forward_backward_part(x_local, eps_local, beta, eng.HEAD)
-            w1 = dist.all_reduce(eng.grads[off:], op=dist.ReduceOp.SUM, group=self._xgroup, async_op=True)
-            eng.forward_backward_part(x_local, eps_local, beta, eng.TAIL)
-            w2 = dist.all_reduce(eng.grads[:off], op=dist.ReduceOp.SUM, group=self._xgroup, async_op=True)
-            w1.wait()
-            w2.wait()
+            self.rccl.all_reduce(eng.grads)  # on the step's own stream: captured with the launches around it
         else:
-            eng.forward_backward(x_local, eps_local, beta)
             dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
 

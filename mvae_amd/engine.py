@@ -231,19 +231,6 @@ class StepEngine:
         self.grads_from_engine = True  # CurvatureOptimizer.step uses the flat gradient buffer as it is
         return out
 
-    HEAD, TAIL = 1, 2  # MVAE_STEP_HEAD / MVAE_STEP_TAIL
-
-    def forward_backward_part(self, x: Tensor, eps: Tensor, beta: float, part: int) -> None:
-        """forward_backward in two calls (mvae_step_forward_backward_parts): HEAD = launches 1-5, after which
-        `grads[flat.off_w_logits:]` (fc_logits, half of the buffer) is final; TAIL = launch 6 (the rest)."""
-        B = self._check_inputs(x, eps)
-        self._last_batch = B
-        check(load().mvae_step_forward_backward_parts(self._context(B), ptr(x), ptr(eps), float(beta), int(part),
-                                                      stream_ptr(self.device)))
-        # HEAD leaves half of the buffer stale; after TAIL the whole flat gradient buffer is the engine's, like after
-        # forward_backward(): CurvatureOptimizer.step then applies it as it is
-        self.grads_from_engine = int(part) == self.TAIL
-
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
         """The optimizer kernel is independent of the batch size; `batch` only selects which context's component table
         travels with the launch (default: the batch size of the last forward_backward, else any existing context, else

@@ -41,29 +41,6 @@ class OracleEngine:
         self.grads.copy_(torch.cat(flat))
         self.stats += torch.stack([out.bce.sum(), out.kl.sum(), out.elbo]).detach()
 
-    # the two-call surface of the overlapped exchange (StepEngine.forward_backward_part): HEAD leaves the LAST segment of
-    # the flat buffer final (here: the last named tensor onwards), TAIL the rest
-    HEAD, TAIL = 1, 2
-
-    class _Flat:
-        pass
-
-    @property
-    def flat(self):
-        f = OracleEngine._Flat()
-        f.off_w_logits = sum(self.sizes[:-2])  # fc_logits.weight, fc_logits.bias are the last two named tensors
-        return f
-
-    def forward_backward_part(self, x, eps, beta, part):
-        off = self.flat.off_w_logits
-        if part & self.HEAD:
-            keep = self.grads.clone()
-            self.forward_backward(x, eps, beta)
-            self._tail = self.grads[:off].clone()  # what launch 6 would still be computing
-            self.grads[:off] = keep[:off]
-        if part & self.TAIL:
-            self.grads[:off] = self._tail
-
     def optimizer_step(self, do_curv, batch=None):
         off = 0
         for n, k in zip(self.names, self.sizes):
@@ -85,7 +62,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, out_q, overlap=True):
+def _worker(rank, world, port, steps, out_q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -94,7 +71,7 @@ def _worker(rank, world, port, steps, out_q, overlap=True):
     xs = synthetic.binary_batches(steps, 64, 32)
     eps = synthetic.eps_batches(steps, 64, spec.total_true_dim)
     lo, hi = shard_rows(64, rank, world)
-    dp = DataParallelStep(OracleEngine(spec, state0), overlap=overlap)
+    dp = DataParallelStep(OracleEngine(spec, state0))
     assert spec.named_shapes()[-2][0] == "fc_logits.weight"
     dp.broadcast_state()
     for s in range(steps):
@@ -112,15 +89,14 @@ def test_shard_rows():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("overlap", [True, False])
-def test_data_parallel_world2_matches_single_process(overlap):
-    """overlap=True: the two-bucket exchange (fc_logits half all-reduced asynchronously between the two backward calls);
-    False: one all-reduce of the whole buffer.  Both must equal the single-process step."""
+def test_data_parallel_world2_matches_single_process():
+    """Two gloo ranks, each on half of the rows, one all-reduce of the flat gradient buffer per step: equal to the
+    single-process step on the whole batch."""
     steps, world = 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]

@@ -728,3 +728,89 @@ def test_cooperative_component_operators_vs_per_lane(dev, monkeypatch, model, sc
     for (dh, dr), (dhl, drl), nm in ((g1, g1l, "per-row KL weights"), (g2, g2l, "scalar KL weight")):
         assert_close(_cpu(dh), _cpu(dhl), 2e-4, "dheads, " + nm, atol_frac=2e-5)
         assert_close(_cpu(dr), _cpu(drl), 2e-4, "dradii, " + nm, atol_frac=2e-5)
+
+
+@pytest.mark.parametrize("model,fixed", [("e6", True), ("h2,s2,e2", False), ("6h2,6s2,6e2", False)])
+def test_fused_train_step_strict_vs_oracle(dev, model, fixed):
+    """The launches the benchmark times -- ONE fused `train_step` (optimizer in the gradient epilogues) from state0, BASELINE
+    configs [0], [1], [3] at full size -- against the oracle at the strict per-entry bar.  After the first Adam step from
+    zero moments m = 0.1 g and v = 0.001 g^2 are exact functions of the gradient, so comparing them (and the gradient buffer
+    the epilogues also store) holds every entry of every gradient to 1e-4 with no `bad_frac` allowance; the updated
+    parameters themselves sit on p - lr * sign-like(m / sqrt(v)), where rounding noise in g ~ 0 entries flips signs (which
+    is why the multi-step tests above use assert_close_after_adam).  Radii: SGD on the batch-summed gradient."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    B, H, D = 128, 400, 784
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=fixed)
+    ncomp = len(spec.components)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, D)[0]
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=1.0, epoch=12)
+    eng = StepEngine([(c.letter, c.true_dim) for c in spec.components], D, H, dev, radius_trainable=[not fixed] * ncomp)
+    eng.load_state(state0)
+    eng.train_step(x.to(dev), eps.to(dev), 1.0, not fixed)
+    torch.cuda.synchronize()
+    assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, "elbo")
+    mv, vv, gv, pv = eng.flat.views(eng.adam_m), eng.flat.views(eng.adam_v), eng.grad_views(), eng.param_views()
+    for n, p in orc.P.items():
+        if n.endswith("radius") or n.endswith("curvature"):
+            assert_close(_cpu(pv[n]), p.detach().numpy(), RTOL, f"{n} after the SGD step")
+            if not fixed:
+                assert_close(_cpu(gv[n]), p.grad.numpy(), RTOL, f"grad {n}")
+            continue
+        st = orc.adam.state[p]
+        assert_close(_cpu(gv[n]), p.grad.numpy(), RTOL, f"grad {n}", atol_frac=1e-4)
+        assert_close(_cpu(mv[n]), st["exp_avg"].numpy(), RTOL, f"adam m {n}", atol_frac=1e-4)
+        assert_close(_cpu(vv[n]), st["exp_avg_sq"].numpy(), 2 * RTOL, f"adam v {n}", atol_frac=2e-5)
+
+
+@pytest.mark.parametrize("model,B,H,D,path", [
+    # H: the fused forward stages W_logits for H <= 416 (one value inside, the limit, one past it)
+    ("h2,s2,e2", 128, 400, 784, "fused"), ("h2,s2,e2", 128, 416, 784, "fused"), ("h2,s2,e2", 128, 432, 784, "row"),
+    # B: multiples of 128 take the fused forward, B <= 256 the lite backward; 384 the fused forward with the round-4 backward
+    ("h2,s2,e2", 256, 400, 784, "fused"), ("h2,s2,e2", 384, 128, 96, "fused"), ("h2,s2,e2", 112, 128, 96, "row"),
+    # Z / NH: z_dim 8 and heads_dim 16 are the fused forward's limits (e4,s3 -> Z = 8, NH = 14; 4e2 -> NH = 16; h4,s4: Z = 10)
+    ("e4,s3", 128, 128, 96, "fused"), ("4e2", 128, 128, 96, "fused"), ("h4,s4", 128, 128, 96, None),
+    # D: 16-column tiles; 800 = no idle tile wave in k_bwd56; 776 is not a multiple of 16
+    ("h2,s2,e2", 128, 128, 800, "fused"), ("h2,s2,e2", 128, 128, 80, "fused"), ("h2,s2,e2", 128, 128, 776, "row"),
+    # components per wave: at most four of one kind on the fused forward (4e2 above fills the four slots)
+    ("5e1,s2", 128, 128, 96, None)])
+def test_fused_kernel_preconditions_shape_sweep(dev, model, B, H, D, path):
+    """Every host-side precondition of the fused kernels (latent_path / step_impl in csrc/mvae_step.hip) with one shape inside,
+    one ON and one PAST the documented limit: whichever kernels the shape is routed to, one fused train_step and one
+    gradients-only call agree with the oracle.  (The class of bug found in round 5: a shape let into a kernel whose staging
+    was sized for less.)"""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False)
+    ncomp = len(spec.components)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, D)[0]
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+    comps = [(c.letter, c.true_dim) for c in spec.components]
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * ncomp)
+    eng.load_state(state0)
+    if path is not None:
+        assert eng.kernel_path(B) == path
+    out = eng.forward_backward(x.to(dev), eps.to(dev), 0.7, want_outputs=True)
+    assert_close(_cpu(out["bce"]), ref.bce.detach().numpy(), RTOL, "bce rows")
+    assert_close(_cpu(out["concat_z"]), ref.concat_z.detach().numpy(), RTOL, "concat_z", atol_frac=1e-4)
+    for n, p in orc.P.items():
+        assert_close(_cpu(eng.grad_views()[n]), p.grad.numpy(), RTOL, f"grad {n} (gradients-only call)", atol_frac=1e-4)
+    eng2 = StepEngine(comps, D, H, dev, radius_trainable=[True] * ncomp)
+    eng2.load_state(state0)
+    eng2.train_step(x.to(dev), eps.to(dev), 0.7, True)
+    torch.cuda.synchronize()
+    assert_close(eng2.read_stats()["last"]["elbo"], float(ref.elbo), RTOL, "elbo")
+    mv = eng2.flat.views(eng2.adam_m)
+    for n, p in orc.P.items():
+        if n.endswith("radius") or n.endswith("curvature"):
+            assert_close(_cpu(eng2.param_views()[n]), p.detach().numpy(), RTOL, f"{n} after the SGD step")
+        else:
+            assert_close(_cpu(mv[n]), orc.adam.state[p]["exp_avg"].numpy(), RTOL, f"adam m {n} (fused step)", atol_frac=1e-4)

@@ -374,6 +374,65 @@ def test_fused_decoder_bce_rows_declines_other_shapes(dev):
                               torch.randn(30).to(dev), torch.rand(8, 30).to(dev)) is None      # D % 16 != 0
 
 
+def test_fused_decoder_bce_rows_declines_4gb_targets_at_the_c_abi(dev):
+    """The kernel addresses the targets with 32-bit byte offsets: a C caller (no Python wrapper in front) with x_rows * D * 4
+    >= 2^32 gets MVAE_E_UNSUPPORTED from the entry point itself, before any launch -- the call declines on the shape alone, so
+    small buffers stand in for the 4 GB of targets; one row less is accepted (rows = 0: nothing is launched)."""
+    from mvae_amd import _lib as L
+    lib = L.load()
+    Z, H, D = 6, 64, 784
+    t = lambda *shape: torch.zeros(*shape, device=dev)
+    z, w0, b0, wl, bl, x, out = t(64, Z), t(H, Z), t(H), t(D, H), t(D), t(64, D), t(64)
+    big = (1 << 32) // (D * 4) + 1
+    args = lambda rows, xr: (L.ptr(z), rows, Z, L.ptr(w0), L.ptr(b0), L.ptr(wl), L.ptr(bl), L.ptr(x), xr, H, D, L.ptr(out),
+                             L.stream_ptr(dev))
+    assert lib.mvae_decode_bce_rows(*args(64, big)) == L.MVAE_E_UNSUPPORTED
+    assert lib.mvae_decode_bce_rows(*args(0, big)) == 0          # rows == 0 returns before the shape checks
+    assert lib.mvae_decode_bce_rows(*args(64, 64)) == 0
+    torch.cuda.synchronize()
+
+
+def test_loglik_tail_all_minus_inf_column(dev):
+    """torch.logsumexp (vae.py:114,117) of a column whose n terms are all -inf is -inf, not exp(-inf + inf) = NaN: the reduce
+    kernels subtract 0 instead of an infinite maximum, as torch does."""
+    from mvae_amd import functional as Fn
+    n, B, Z, D, C = 40, 16, 6, 32, 2
+    gen = torch.Generator().manual_seed(3)
+    bce = torch.rand(n, B, generator=gen) * 10 + 100
+    lp, lq = torch.randn(C, n, B, generator=gen), torch.randn(C, n, B, generator=gen)
+    lp[:, :, 5] = -float("inf")  # log p(z) = -inf for every sample of batch column 5
+    z, x = torch.randn(n, B, Z, generator=gen), (torch.rand(B, D, generator=gen) < 0.3).float()
+    out = Fn.loglik_tail(bce.to(dev), lp.to(dev), lq.to(dev), z.to(dev), x.to(dev))
+    a = -bce.double() + lp.double().sum(0) - lq.double().sum(0)
+    ref = torch.logsumexp(a, dim=0) - np.log(n)
+    got = _cpu(out[0])
+    assert got[5] == -np.inf and ref[5] == -np.inf
+    keep = np.arange(B) != 5
+    assert_close(got[keep], ref.numpy()[keep], 1e-5, "log p(x), finite columns")
+    got2 = _cpu(Fn.loglik_reduce(bce.to(dev), lp.sum(0).to(dev), lq.sum(0).to(dev))[0])
+    assert got2[5] == -np.inf
+    assert_close(got2[keep], ref.numpy()[keep], 1e-5, "log p(x), finite columns (mvae_loglik_reduce)")
+
+
+@pytest.mark.parametrize("model", ["h2,s2,e2", "6h2,6s2,6e2"])
+def test_log_likelihood_full_size_vs_oracle(dev, model):
+    """ModelVAE.log_likelihood at the reference's evaluation size (n = 500 importance samples, B = 128, H = 400, D = 784:
+    64 000 decoded rows through mvae_decode_bce_rows, the component sums / logsumexp / covariance tail in two launches) --
+    the WHOLE call against oracle.model.log_likelihood (vae.py:82-123) at 1e-4."""
+    from mvae_amd import synthetic
+    from oracle import model as M
+    m, spec, state0 = _model(dev, model, 784, 400)
+    x = synthetic.binary_batches(1, 128, 784)[0]
+    eps = torch.randn(500, 128, spec.total_true_dim, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        lp, mi, cn = m.log_likelihood(x.to(dev), n=500, eps=eps.to(dev))
+        P = {k: v.detach().clone().float() for k, v in state0.items()}
+        rlp, rmi, rcn = M.log_likelihood(spec, P, x, eps)
+    assert_close(_cpu(lp), rlp.numpy(), RTOL, "log p(x)")
+    assert_close(_cpu(mi), rmi.numpy(), RTOL, "mi", atol_frac=1e-4)
+    assert_close(float(cn), float(rcn), 5 * RTOL, "cov_norm")
+
+
 @pytest.mark.parametrize("n,B,Z,D,C", [(500, 128, 6, 784, 3), (8, 32, 6, 32, 3), (37, 100, 12, 200, 5), (5, 4, 6, 3072, 3),
                                        (300, 1, 3, 17, 1), (50, 128, 48, 784, 18), (9, 16, 33, 48, 4)])
 def test_loglik_tail_equals_the_composed_operators(dev, n, B, Z, D, C):

@@ -62,16 +62,20 @@ for i in range(N):
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
     wv = [v[32 + j] for j in range(8)]
     wacc = wv if i == 0 else [a + b for a, b in zip(wacc, wv)]
+    k56 = [v[41 + j] - v[40 + j] for j in range(6)]
+    k56acc = k56 if i == 0 else [a + b for a, b in zip(k56acc, k56)]
 names = ["fwd:load+sync", "fwd:heads", "fwd:comps", "fwd:dec0", "bwd:load+sync", "bwd:dz", "bwd:dot", "bwd:dh",
          "enc_bwd tile:loads+mfma", "enc_bwd tile:adam+stores", "dec1_fwd tile:loads+mfma", "dec1_fwd tile:reduce",
          "dec1_fwd tile:epilogue", "fwd23: loads+heads mfma", "fwd23: heads reduce", "fwd23: heads_s/tables",
          "fwd23: components", "fwd23: hd", "fwd23: logits mfma", "fwd23: reduce"]
 for n, a in zip(names, acc): print(f"{n:16s} {a / N * 10:8.1f} ns")
 print("fwd23 per-wave time to the end of the heads MFMA (ns):", [round(a / N * 10) for a in wacc])
+print("k_bwd56 tile workgroup, wave 0 (ns): requests issued, dheads (waits for dz + records), dh fragments, meet, tile MFMAs, "
+      "Adam + stores:", [round(a / N * 10) for a in k56acc])
 KERNELS = ["enc_fwd", "latent_fwd", "dec1_fwd", "dec1_bwd", "latent_bwd", "enc_bwd"]
 KINDS = {(0, 1): "tiles", (1, 1): "main waves", (1, 2): "dual waves", (2, 1): "tiles", (2, 2): "dual workgroups", (3, 1): "dhd tiles",
          (3, 2): "db_logits", (3, 3): "statistics", (3, 4): "dual records", (4, 1): "rows", (4, 2): "dW_logits tiles", (4, 3): "statistics", (5, 1): "dW_e0 tiles",
-         (5, 2): "dW_heads", (5, 3): "dW_d0", (5, 4): "b_e0", (5, 5): "b_heads", (5, 6): "b_d0", (5, 7): "radii"}
+         (5, 2): "dW_logits waves (k_bwd56) | dW_heads", (5, 3): "dW_d0", (5, 4): "b_e0", (5, 5): "b_heads", (5, 6): "b_d0", (5, 7): "radii"}
 import numpy as np
 print("per launch: workgroup END time after the first workgroup's start, ns (median / latest over workgroups)")
 for (L, kind), v in sorted(spans.items()):
