@@ -1170,6 +1170,196 @@ __global__ __launch_bounds__(256, 2) void k_decode_bce_rows(const float* z, int6
   }
 }
 
+// ---- the same launch with 32 rows per wave on v_mfma_f32_32x32x2_f32.  k_decode_bce_rows above keeps a
+// wave's 16-row hidden block in registers and reads one B fragment (ds_read_b128) per four MFMAs; its counters say the loop is
+// bound by the non-MFMA issue slots (45 VALU + 25 ds_read_b128 per 100 MFMAs, LDS bank-conflict cycles 45 % of the LDS-active
+// ones) next to an MFMA pipe that is busy 73 % of the time.  Here a wave owns 32 rows: the A fragments of its [32][H] hidden
+// block are H / 2 registers per lane (200 for H = 400 -- one wave per SIMD, the 512-register budget), one B fragment feeds four
+// 32x32x2 MFMAs = twice the flops, a tile is 32 logits columns (half the barriers and loop overhead per flop), and the row
+// blocks of W_l sit in LDS with a row stride of H + 4 floats (one DMA piece never straddles a row): the 16 lanes a
+// ds_read_b128 serves together hit 16 different 4-bank groups.  K labelling: MFMA step (m, s) contracts k = 8 m + 4 h + s on
+// the half-wave h = lane >> 5 -- lane (j, h) reads W_l[col j][8 m + 4 h .. + 3] as ONE 16-byte vector for four steps, and the
+// hidden layer is computed straight into that order.  Output: lane (j = lane & 31, h) holds rows 8 (r >> 2) + 4 h + (r & 3),
+// r = 0 .. 15, of column j.
+template <int MCH, int ZP>  // H = 8 MCH ; z_dim in slices of ZP columns
+__global__ __launch_bounds__(256, 1) void k_decode_bce_rows32(const float* z, int64_t rows, int Z, const float* Wd0,
+                                                              const float* bd0, const float* Wl, const float* bl,
+                                                              const float* x, int64_t x_rows, int D, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int H = 8 * MCH, LDW = H + 4;        // LDS row stride of a W_l row (floats)
+  constexpr int RB = H * 4;                      // bytes per row
+  constexpr int NPC = (RB + 1023) / 1024;        // DMA pieces per row; the last one covers LASTL lanes
+  constexpr int LASTL = (RB - (NPC - 1) * 1024) / 16;
+  float* bt = dyn;                   // [2][32][LDW]
+  float* wd_s = dyn + 2 * 32 * LDW;  // [H][ZP] (zero past z_dim)
+  float* bd_s = wd_s + H * ZP;       // [H]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const int ntD = (D + 31) >> 5;
+  const unsigned lane16 = lane * 16;
+  // W_l's rows 32 nt .. 32 nt + 31 -> LDS buffer `buf` by LDS-DMA, row by row: wave w moves rows w, w + 4, ... (rows past D:
+  // the last row again -- their columns are masked in the epilogue)
+  auto request = [&](int nt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = wave + 4 * u;
+      const int gr = 32 * nt + r < D ? 32 * nt + r : D - 1;  // (scalar)
+      const char* src = reinterpret_cast<const char*>(Wl + (size_t)gr * H);
+      float* dst = bt + buf * (32 * LDW) + r * LDW;
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) {
+        if (pc + 1 < NPC || LASTL == 64) {
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + pc * 1024 + lane16),
+                                           (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+        } else if (lane < LASTL) {
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + pc * 1024 + lane16),
+                                           (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+        }
+      }
+    }
+  };
+  request(0, 0);
+  for (int e = tid; e < H; e += 256) bd_s[e] = bd0[e];
+  // hidden layer of this wave's 32 rows as A fragments: a[m][s] = relu(b_d0[k] + <z[row j], W_d0[k]>), k = 8 m + 4 h + s
+  f32x4 a[MCH];
+  const int64_t zrow = (r0 + j < rows ? r0 + j : rows - 1) * Z;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < MCH; ++m) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(bd_s + 8 * m + 4 * h);
+    asm volatile("" : "+v"(v));
+    a[m] = v;
+  }
+#ifdef MV_DBR32_NOPRO
+  for (int s0 = 0; s0 < 0; s0 += ZP) {
+#else
+  for (int s0 = 0; s0 < Z; s0 += ZP) {
+#endif
+    if (s0 > 0) __syncthreads();  // the previous slice has been consumed
+    float zr[ZP];
+#pragma unroll
+    for (int c = 0; c < ZP; ++c) {
+      const float v = z[zrow + (s0 + c < Z ? s0 + c : 0)];
+      zr[c] = s0 + c < Z ? v : 0.f;
+    }
+    for (int e0 = tid; e0 < H * ZP; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u < H * ZP ? e0 + 256 * u : 0;
+        const int k = e / ZP, c = e - k * ZP;
+        v[u] = Wd0[(size_t)k * Z + (s0 + c < Z ? s0 + c : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < H * ZP) wd_s[e] = s0 + (e % ZP) < Z ? v[u] : 0.f;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (first slice: the DMA is invisible to the compiler's LDS dependence tracking)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MCH; ++m) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 8 * m + 4 * h + s;
+        float v = a[m][s];
+#pragma unroll
+        for (int c4 = 0; c4 < ZP; c4 += 4) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wd_s + k * ZP + c4);
+          v = fmaf(zr[c4], w[0], v);
+          v = fmaf(zr[c4 + 1], w[1], v);
+          v = fmaf(zr[c4 + 2], w[2], v);
+          v = fmaf(zr[c4 + 3], w[3], v);
+        }
+        asm volatile("" : "+v"(v));  // (opaque to the SLP vectorizer, see k_decode_bce_rows)
+        a[m][s] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MCH; ++m)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float v = a[m][s];
+      v = v < 0.f ? 0.f : v;  // torch.relu: NaN propagates
+      asm volatile("" : "+v"(v));
+      a[m][s] = v;
+    }
+  // targets (x broadcast over the samples): row of output r = x row (r0 + 8 (r >> 2) + (r & 3) + 4 h) mod x_rows.  With
+  // x_rows a multiple of 32 (the estimator: x_rows = B = 128) a wave's 32 rows never wrap, so the row part is a SCALAR base per
+  // r and the lane contributes one fixed offset (4 h rows + its column) -- no per-lane offset array next to the 200 A registers
+  // (with one, the allocator parked the A fragments in AGPRs and fetched each with a v_accvgpr_read in front of its MFMA:
+  // next to the f32-input MFMA every VALU instruction is step time, and that was one per MFMA)
+  const int xr0 = (int)(r0 % x_rows);  // (uniform)
+  const unsigned hoff = (unsigned)(4 * h * D) * 4u;
+  float rs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+  for (int nt = 0; nt < ntD; ++nt) {
+    const int buf = nt & 1;
+    const int nts = __builtin_amdgcn_readfirstlane(nt);
+    if (nt + 1 < ntD) request(nts + 1, buf ^ 1);  // (uniform)
+    const int col = 32 * nts + j;
+    const bool cok = col < D;
+    const unsigned c4 = (unsigned)(cok ? col : D - 1) * 4u;
+    const float bias = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bl) + c4);
+    const unsigned lo = hoff + c4;
+    float tv[16];  // targets: requested here, first USED in the epilogue
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const char* xb = reinterpret_cast<const char*>(x + (size_t)(xr0 + 8 * (r >> 2) + (r & 3)) * D);  // (scalar)
+      tv[r] = *reinterpret_cast<const float*>(xb + lo);
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const float* brow = bt + buf * (32 * LDW) + j * LDW + 4 * h;
+    // B fragments one chunk (four MFMAs = 256 cycles) ahead
+    f32x4 bq = *reinterpret_cast<const f32x4*>(brow);
+#pragma unroll
+    for (int m0 = 0; m0 < MCH; ++m0) {
+      const f32x4 bn = *reinterpret_cast<const f32x4*>(brow + 8 * (m0 + 1 < MCH ? m0 + 1 : 0));
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef MV_DBR32_NOMMA
+      acc0[m0 & 15] += a[m0][0] * bq[0] + a[m0][2] * bq[2];
+      acc1[m0 & 15] += a[m0][1] * bq[1] + a[m0][3] * bq[3];
+#else
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m0][0], bq[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m0][1], bq[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m0][2], bq[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m0][3], bq[3], acc1, 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      bq = bn;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // F.binary_cross_entropy_with_logits: (1 - t) y + softplus(-y), as in k_decode_bce_rows
+      const float y = acc0[r] + acc1[r] + bias;
+#ifdef MV_DBR32_NOEPI
+      rs[r] += (1.f - tv[r]) * y;
+#else
+      const float e = __builtin_amdgcn_exp2f(fabsf(y) * -1.4426950408889634f);
+      const float l2 = __builtin_amdgcn_logf(1.f + e);
+      const float term = fmaf(l2, 0.6931471805599453f, fmaf(1.f - tv[r], y, -fminf(y, 0.f)));
+      rs[r] += cok ? term : 0.f;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next row block has landed (requested ~200 MFMAs ago)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float tot = row16_sum(rs[r]);
+    tot += __shfl_xor(tot, 16);  // the two 16-lane rows of a half-wave
+    const int64_t row = r0 + 8 * (r >> 2) + 4 * h + (r & 3);
+    if (j == 0 && row < rows) out[row] = tot;
+  }
+}
+
 extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const float* Wd0, const float* bd0, const float* Wl,
                                     const float* bl, const float* x, int64_t x_rows, int H, int D, float* out,
                                     void* stream) {
@@ -1183,6 +1373,36 @@ extern "C" int mvae_decode_bce_rows(const float* z, int64_t rows, int Z, const f
   // the kernel addresses the targets with 32-bit BYTE offsets (xo[r]): 4 GB of targets and more are declined here
   if ((uint64_t)x_rows * (uint64_t)D * 4ull >= (1ull << 32)) return MVAE_E_UNSUPPORTED;
   const int zp = Z <= 8 ? 8 : 16;
+  // MVAE_DBR32=1: 32 rows per wave on the 32x32x2 MFMA (k_decode_bce_rows32) for the reference's layer width.  Measured
+  // (round 6, tools/bench_decode_bce.py, interleaved): 377-385 us against 360-364 us for the 16-row kernel below -- kept for the
+  // A/B and its counter dump (profiles/r06_loglik_decoder32_pmc.txt), not the default
+  static const bool use32 = [] { const char* e = getenv("MVAE_DBR32"); return e && e[0] && e[0] != '0'; }();
+  if (use32 && nch == 25 && (x_rows & 31) == 0) {
+    const size_t lds32 = ((size_t)2 * 32 * (H + 4) + (size_t)H * zp + H) * sizeof(float);
+    const dim3 grid32((unsigned)((rows + 127) / 128));
+#define MV_DBR32(ZP_)                                                                                                \
+  do {                                                                                                               \
+    static std::atomic<bool> set_[kMaxDevices];                                                                      \
+    int dev_ = 0;                                                                                                    \
+    (void)hipGetDevice(&dev_);                                                                                       \
+    const bool tracked_ = dev_ >= 0 && dev_ < kMaxDevices;                                                           \
+    if (!(tracked_ && set_[dev_].load(std::memory_order_acquire))) {                                                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_bce_rows32<50, ZP_>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);                   \
+      if (e_ != hipSuccess) {                                                                                        \
+        (void)hipGetLastError();                                                                                     \
+        return MVAE_E_UNSUPPORTED;                                                                                   \
+      }                                                                                                              \
+      if (tracked_) set_[dev_].store(true, std::memory_order_release);                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((k_decode_bce_rows32<50, ZP_>), grid32, dim3(256), lds32, (hipStream_t)stream, z, rows, Z,    \
+                       Wd0, bd0, Wl, bl, x, x_rows, D, out);                                                         \
+  } while (0)
+    if (zp == 8) MV_DBR32(8); else MV_DBR32(16);
+#undef MV_DBR32
+    LAUNCH_CHECK("decode + bce rows launch (32-row waves)");
+    return 0;
+  }
   const size_t lds = ((size_t)2 * 16 * H + (size_t)H * zp + H) * sizeof(float);
   const dim3 grid((unsigned)((rows + 63) / 64));
 #define MV_DBR(NCH_, ZP_)                                                                                            \
