@@ -25,6 +25,8 @@
 #endif
 #include "mvae_common.hpp"
 #include "mvae_coop.hpp"
+#include <atomic>
+constexpr int kMaxDevices = 64;  // per-device "attribute set" marks of kernels that need more than 64 KB of dynamic LDS
 struct StatsArgs {  // job_step_stats outside launch 4; bce_part == NULL: not here
   const float* bce_part;
   const float* kl;
@@ -2782,13 +2784,17 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     const int n_main23 = ((c->nt_d + 1) / 2) * c->nt_b;  // no padding workgroups (see the kernel)
 #define LF23(DM)                                                                                                     \
   {                                                                                                                  \
-    static size_t lds_set = 0; /* more than 64 KB of dynamic LDS has to be allowed once per kernel */                \
-    if (lds > lds_set) {                                                                                             \
+    /* more than 64 KB of dynamic LDS has to be allowed once per kernel AND DEVICE (the attribute is per device) */   \
+    static std::atomic<size_t> lds_set[kMaxDevices];                                                                 \
+    int dev_ = 0;                                                                                                    \
+    (void)hipGetDevice(&dev_);                                                                                       \
+    const bool tracked_ = dev_ >= 0 && dev_ < kMaxDevices;                                                           \
+    if (!tracked_ || lds > lds_set[dev_].load(std::memory_order_acquire)) {                                          \
       auto kfn_ = &k_fwd23<DM>;                                                                                      \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn_),                                       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e_ != hipSuccess) return hip_fail(e_, "hipFuncSetAttribute(k_fwd23)");                                     \
-      lds_set = lds;                                                                                                 \
+      if (tracked_) lds_set[dev_].store(lds, std::memory_order_release);                                             \
     }                                                                                                                \
   }                                                                                                                  \
   STEP_LAUNCH((k_fwd23<DM>), dim3(n_main23 + c->nt_b + MV_PREFETCH_WGS), dim3(512), lds, c->t, h, P + d.off_w_heads,  \
