@@ -510,15 +510,17 @@ def test_wide_hidden_layer_vs_oracle(dev, H):
                                          ("6h2,6s2,6e2", 128, 400, 784), ("6h2,6s2,6e2", 256, 400, 784),
                                          ("3h2,s3,e2,p3,d2,u2,e2", 32, 128, 96), ("5e3,h4,2s2,e6", 16, 64, 48)])
 def test_lite_backward_vs_oracle_and_round4_launches(dev, model, B, H, D, monkeypatch):
-    """The "lite" backward of the fused-forward shapes (csrc/mvae_step.hip: k_latent_bwd2 / k_enc_bwd2 -- dz from the partial
-    products of launch 4's tiles, dh rebuilt per weight-gradient workgroup from a snapshot of W_heads, every batch contraction
-    on fragment-order operands) against the oracle (1e-4) and against the round-4 launches (MVAE_NO_LITE=1: same sums in another
-    order, 2e-5 of each tensor's scale), for: the BASELINE shapes, B = 256 (two fragment batches), z_dim 6 / 2 (scalar
-    epilogues), z_dim 4, H = 384 (launch 1's grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle
-    wave in a row of tiles: the small weight gradients share their waves), a small model, and the block-forward shapes (many
-    small components, BASELINE config [3]: dz from partial MFMA tiles of launch 4, dh / dhd / dheads / hd in fragment order only,
-    launch 6 = k_enc_bwd3 with the bias gradients as column sums of its fragments, the statistics job in launch 5; MVAE_NO_LITE=1
-    switches all of that off too); fused step and the gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
+    """The backward of the fused-forward shapes -- since round 6 the FOUR-launch step (csrc/mvae_step.hip: k_dec1_bwd<LITE 1> +
+    k_bwd56: dz as a fixed-point atomic sum of launch 4's tiles, dheads rebuilt per workgroup from dz and the per-head-column
+    dual records, dh rebuilt per weight-gradient workgroup from a snapshot of W_heads, the dW_logits tiles on five more waves,
+    every batch contraction on fragment-order operands) -- against the oracle (1e-4) and against the generic launches
+    (MVAE_NO_LITE=1: same sums in another order, 2e-5 of each tensor's scale), for: the BASELINE shapes, B = 256 (sixteen row
+    blocks: the records in passes), z_dim 6 / 2 (scalar epilogues; `e6`: records of two vectors), z_dim 4, H = 384 (launch 1's
+    grid has no padding workgroups: x's copy comes from launch 4), D = 800 (no idle wave in a row of tiles: the small workgroups
+    rebuild dheads too and take the dW_heads tiles), a small model, and the block-forward shapes (many small components,
+    BASELINE config [3]: dz from partial MFMA tiles of launch 4, dh / dhd / dheads / hd in fragment order only, launch 6 =
+    k_enc_bwd3, the statistics job in launch 5; MVAE_NO_LITE=1 switches all of that off too); fused step and the
+    gradients-only call; three consecutive steps (the snapshot of W_heads must be the pre-update one)."""
     from mvae_amd import synthetic
     from mvae_amd.engine import StepEngine
     from oracle import model as M
