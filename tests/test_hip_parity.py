@@ -816,3 +816,39 @@ def test_fused_kernel_preconditions_shape_sweep(dev, model, B, H, D, path):
             assert_close(_cpu(eng2.param_views()[n]), p.detach().numpy(), RTOL, f"{n} after the SGD step")
         else:
             assert_close(_cpu(mv[n]), orc.adam.state[p]["exp_avg"].numpy(), RTOL, f"adam m {n} (fused step)", atol_frac=1e-4)
+
+
+def test_dz_partial_out_of_fixed_point_range_poisons_the_step_and_recovers(dev):
+    """The four-launch step sums dz as 64-bit fixed point (2^-38 resolution, |partial| < 2^19).  A partial outside that range
+    (or not finite) cannot be represented: launch 4 sets the step's overflow mark instead and k_bwd56 turns dz into NaN, so the
+    gradients behind it (heads, encoder, radii) come out non-finite -- a diverged run poisons its statistics, it does not
+    continue on wrapped integers.  The mark is re-armed by the next forward launch: the same engine, back on sane weights,
+    steps exactly like a fresh one."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    B, H, D = 128, 400, 784
+    spec = M.Spec("h2,s2,e2", in_dim=D, h_dim=H, fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, B, D)[0].to(dev)
+    eps = synthetic.eps_batches(1, B, spec.total_true_dim)[0].to(dev)
+    comps = [(c.letter, c.true_dim) for c in spec.components]
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * 3)
+    bad = {k: v.clone() for k, v in state0.items()}
+    bad["fc_d0.weight"] = bad["fc_d0.weight"] * 1e9  # dz = dhd W_d0: partial products of ~1e9
+    eng.load_state(bad)
+    eng.forward_backward(x, eps, 1.0)
+    torch.cuda.synchronize()
+    g = eng.grad_views()
+    assert not np.isfinite(_cpu(g["fc_e0.weight"])).all(), "an unrepresentable dz must not yield finite encoder gradients"
+    assert not np.isfinite(_cpu(g["components.0.fc_mean.weight"])).all()
+    # back on sane weights: the mark does not stick
+    eng.load_state(state0)
+    eng.reset_optimizer()
+    eng.forward_backward(x, eps, 1.0)
+    fresh = StepEngine(comps, D, H, dev, radius_trainable=[True] * 3)
+    fresh.load_state(state0)
+    fresh.forward_backward(x, eps, 1.0)
+    torch.cuda.synchronize()
+    assert np.isfinite(_cpu(eng.grads)).all()
+    assert np.array_equal(_cpu(eng.grads), _cpu(fresh.grads)), "the recovered engine steps bit-identically to a fresh one"
