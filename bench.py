@@ -10,7 +10,7 @@ backward, Adam + SGD on the radii (+ gradient all-reduce when N > 1).  Inputs (b
 (mvae_amd/synthetic.py: MNIST-shaped stroke images, dynamically binarised) and resident in HBM before the timed
 region; weights are the synthetic init.
 Prints ONE JSON line on rank 0.  The top-level fields are configs[1]; at N = 1 the default invocation also times short
-legs of the other single-GPU BASELINE configs and reports them under "configs": {"e6", "prod36", "conv", "epoch_pipeline"}
+legs of the other single-GPU BASELINE configs and reports them under "configs": {"e6", "prod36", "conv", "epoch_pipeline", "epoch_pipeline_b100"}
 (configs[0], [3], [4]); `--no-extra-configs` skips them.
 """
 import argparse
@@ -479,7 +479,7 @@ def mlp_leg(model, fixed, steps, warmup, dev, repeats=5):
                                               "step_hbm_frac", "step_mfma_frac", "traffic", "traffic_step", "traffic_source")}}
 
 
-def epoch_pipeline_leg(dev, epochs=3):
+def epoch_pipeline_leg(dev, epochs=3, batch=None):
     """Scope row f-2 measured where the driver looks: whole training epochs of BASELINE configs[1] through the device-side
     input pipeline -- a 60000 x 784 uint8 synthetic set resident in HBM, batches gathered by a device permutation, dynamic
     binarisation and the eps draw (Philox) done by spare workgroups of the PREVIOUS step (mvae_set_next_batch_feed), steps
@@ -492,7 +492,8 @@ def epoch_pipeline_leg(dev, epochs=3):
     eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * len(comps), lr=1e-3)
     eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
     images = (torch.rand(60000, D, device=dev) ** 3 * 255).to(torch.uint8)
-    er = EpochRunner(eng, images, B, seed=1)
+    batch = B if batch is None else int(batch)  # (100: the reference CLI's default, mt/examples/run.py:32 -- buffers padded to 112 rows)
+    er = EpochRunner(eng, images, batch, seed=1)
     for _ in range(2):
         n = er.run_epoch(1.0, True)
     torch.cuda.synchronize()
@@ -504,7 +505,8 @@ def epoch_pipeline_leg(dev, epochs=3):
     stats = eng.read_stats()
     assert stats["sum"]["steps"] == (2 + epochs) * n, stats["sum"]["steps"]  # (capture warm-ups restore the statistics)
     assert stats["last"]["elbo"] == stats["last"]["elbo"], "non-finite ELBO"
-    return {"metric": f"ELBO-steps/sec (batch 128) MNIST {MODEL}, whole epochs through the device-side input pipeline",
+    return {"metric": f"ELBO-steps/sec (batch {batch}) MNIST {MODEL}, whole epochs through the device-side input pipeline",
+            "batch": batch, "buffer_rows": er.Bp, "kernel_path": eng.kernel_path(er.Bp),
             "value": n * epochs / dt, "unit": "ELBO-steps/sec", "ms_per_step": dt / (n * epochs) * 1e3,
             "steps": n * epochs, "epochs": epochs, "steps_per_epoch": n, "dtype": "f32",
             "workload": "60000 x 784 uint8 synthetic images in HBM; per step: gather by a device permutation + dynamic "
@@ -586,7 +588,8 @@ def configs_summary(line):
     out = {"fmt": "[value/s, ms, roofline frac]; median of timed_repeats repeats",
            "h2s2e2": row(line), "e6": row(c.get("e6")), "prod36": row(c.get("prod36")), "conv": row(c.get("conv")),
            "conv_f32_mfma": row(c.get("conv_f32_mfma")), "conv_split": row(c.get("conv_split_bf16_products")),
-           "epoch_pipeline": row(c.get("epoch_pipeline")), "loglik": row(c.get("loglik"), "ms_per_batch"),
+           "epoch_pipeline": row(c.get("epoch_pipeline")), "epoch_b100": row(c.get("epoch_pipeline_b100")),
+           "loglik": row(c.get("loglik"), "ms_per_batch"),
            "conv_mode": (c.get("conv") or {}).get("contraction_mode"),
            "timed_repeats": line["config"]["timed_repeats"],
            "first_repeat": round(line["config"]["first_repeat_value"], 1)}
@@ -852,6 +855,10 @@ def main():
             extra["epoch_pipeline"] = epoch_pipeline_leg(dev)
         except Exception as e:  # noqa: BLE001
             extra["epoch_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:  # the reference CLI's default batch size: padding rows keep it on the fused kernels
+            extra["epoch_pipeline_b100"] = epoch_pipeline_leg(dev, batch=100)
+        except Exception as e:  # noqa: BLE001
+            extra["epoch_pipeline_b100"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             extra["loglik"] = loglik_leg(dev)
         except Exception as e:  # noqa: BLE001

@@ -573,6 +573,15 @@ void mvae_destroy(mvae_ctx* ctx);
 /* Change which radius / curvature parameters are trained (Parameter.requires_grad toggles of the --universal schedule,
  * mt/examples/run.py:153-165).  trainable[ncomp], host pointer, copied; takes effect from the next step call. */
 int mvae_set_radius_trainable(mvae_ctx* ctx, const uint8_t* trainable);
+/* Padding rows.  The fused kernels want a batch that is a multiple of 16; the reference CLI's default is 100
+ * (mt/examples/run.py:32).  A caller rounds `batch` up to a multiple of 16 in mvae_create, keeps rows [valid_rows, batch) of
+ * every x / eps buffer finite (zeros) and declares them here: they then contribute no reconstruction term, no KL term, no
+ * gradient and no statistics (ModelVAE.train_step sums over the rows of the batch, vae.py:125-147), and
+ * mvae_set_next_batch_feed / the step's in-launch input pipeline prepare valid_rows rows per batch.  Only the four-launch
+ * step (mvae_step_kernel_path() == MVAE_PATH_FUSED, batch <= 256) masks: for any other model / shape the call returns
+ * MVAE_E_UNSUPPORTED (no message) and the caller creates a context for exactly valid_rows rows instead; a later step whose
+ * buffers' alignment takes it off the four-launch kernels fails with MVAE_E_UNSUPPORTED rather than sum padding rows. */
+int mvae_set_valid_rows(mvae_ctx* ctx, int valid_rows);
 
 /* forward -> ELBO -> backward: fills `grads` (all P entries are written, nothing accumulates) and adds this step's
  * bce / kl / elbo sums to `stats`.  x[B, D] (binarised or soft targets), eps[B, eps_dim] ~ N(0,1).

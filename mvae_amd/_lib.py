@@ -142,6 +142,7 @@ PROTOTYPES = {
     "mvae_slice_sums_defer": (C.c_int, [_I]),
     "mvae_slice_sums_flush": (C.c_int, [_P]),
     "mvae_step_kernel_path": (C.c_int, [_P]),
+    "mvae_set_valid_rows": (C.c_int, [_P, _I]),
     "mvae_peer_create": (C.c_int, [C.c_int64, _I, _I, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]),
     "mvae_peer_destroy": (None, [C.c_void_p]),
     "mvae_peer_export": (C.c_int, [_P, C.POINTER(C.c_uint8)]),

@@ -48,6 +48,7 @@ struct Rec4Args {
   float* recR;        // radius-direction records [B][kRecRad][NV] vectors
   long long* dzfix;   // [B][8] fixed-point sums of dz, then one unsigned: the overflow / non-finite mark
   int NV;             // vectors per record, (max ambient dim + 1 + 3) / 4
+  int Bv;             // valid rows (mvae_set_valid_rows): rows past it are padding -- no loss, no KL, no gradient
 };
 
 // ================================================================================================ the fused step
@@ -73,6 +74,7 @@ struct mvae_ctx {
   bool blk_fwd;          // block kernels in the forward launches as well (MVAE_BLK_FWD=0: per-row forward, A/B measurements)
   bool coop;             // large components (true dim >= 9): wave-cooperative kernels (MVAE_NO_COOP=1: off)
   FeedArgs feed;         // mvae_set_next_batch_feed: the batch launch 4 of the NEXT step prepares (images == NULL: none)
+  int valid_rows;        // mvae_set_valid_rows: rows [valid_rows, batch) of x / eps are PADDING (four-launch step only)
 };
 
 static int latent_path(const mvae_ctx* c, bool x_aligned);
@@ -212,6 +214,7 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
   const char* nc = getenv("MVAE_NO_COOP");
   c->coop = bucket_of(c->dmax) > 8 && coop_eligible(c->t) && !(nc && nc[0] && nc[0] != '0');
   carve(c, bucket_of(c->dmax));
+  c->valid_rows = desc->batch;
   // the only device access of create, and only for models that take the block kernels
   if (uses_blk_bwd(c, true) && (rc = upload_dirtab(c)) != 0) {
     delete c;
@@ -222,6 +225,25 @@ extern "C" int mvae_create(const mvae_model_desc* desc, mvae_ctx** out) {
 }
 
 extern "C" void mvae_destroy(mvae_ctx* ctx) { delete ctx; }
+
+// Rows [valid_rows, batch) of x / eps become PADDING: they contribute no reconstruction term, no KL term and no gradient, and
+// the device-side input pipeline prepares valid_rows rows per batch.  For batch sizes that are not a multiple of 16 (the
+// reference CLI's default is 100, mt/examples/run.py:32): the caller rounds the batch up, keeps the padding rows of its x / eps
+// buffers finite (zeros), and the step runs on the fused kernels instead of the one-row-per-workgroup ones (B = 100: 28.5
+// against 39.4 us per step).  Only the four-launch step masks; everything else declines.
+extern "C" int mvae_set_valid_rows(mvae_ctx* c, int valid_rows) {
+  if (!c) return fail(MVAE_E_BADARG, "null ctx%s", "");
+  const mvae_model_desc& d = c->d;
+  if (valid_rows < 1 || valid_rows > d.batch) return fail(MVAE_E_BADARG, "valid_rows outside [1, batch]%s (%lld)", "", valid_rows);
+  if (valid_rows < d.batch) {
+    const bool four = latent_path(c, true) == MVAE_PATH_FUSED && !uses_blk_bwd(c, true) && !c->no_lite && d.batch <= 256 &&
+                      d.ncomp <= kRecRad && c->rec_nv <= kRecVecMax;
+    if (!four) return MVAE_E_UNSUPPORTED;  // (quietly: the caller then steps on exactly valid_rows rows)
+  }
+  c->valid_rows = valid_rows;
+  c->feed = FeedArgs{};
+  return 0;
+}
 
 extern "C" int mvae_set_radius_trainable(mvae_ctx* c, const uint8_t* trainable) {
   if (!c || !trainable) return fail(MVAE_E_BADARG, "null ctx / trainable%s", "");
@@ -935,8 +957,9 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       comp_fwd_row<DMAX>(my_desc, heads_s[r], eps_s[r], rad_s, z_s[r], lead ? z + row * ldz : nullptr, &klv, nullptr,
                          nullptr, nullptr, nullptr);
       if (lead) {
-        kl[(size_t)my_ci * B + row] = klv;
-        if (kl_user) kl_user[(size_t)my_ci * B + row] = klv;
+        const float klm = (int)row < r4.Bv ? klv : 0.f;  // (padding rows carry no KL term)
+        kl[(size_t)my_ci * B + row] = klm;
+        if (kl_user) kl_user[(size_t)my_ci * B + row] = klm;
       }
     }
   } else {
@@ -990,6 +1013,10 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   if (lead && zF && tid < 64) {  // z in fragment order (one 16-column tile, zero past Z): launch 6's dW_d0 tiles
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < 8) v = f32x4{z_s[4 * q][i], z_s[4 * q + 1][i], z_s[4 * q + 2][i], z_s[4 * q + 3][i]};  // z_s is zero past Z
+    // (padding rows: zero -- their z need not be finite (the sphere's sample at eps = 0 is 0 / 0, spherical.py:87-88), and
+    // the batch contractions multiply it by a zero gradient)
+#pragma unroll
+    for (int r4i = 0; r4i < 4; ++r4i) v[r4i] = mt * 16 + 4 * q + r4i < r4.Bv ? v[r4i] : 0.f;
     store16_wt(zF, ((size_t)mt * 64 + tid) << 2, v);
   }
 
@@ -1057,7 +1084,9 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
       for (int tile = pt; tile < (H >> 4); tile += ntP) {
         const int ii = lane & 15, qq = lane >> 4;
         const float* src = hd_s + (4 * qq) * ld + tile * 16 + ii;
-        const f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
+        f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
+#pragma unroll
+        for (int r4i = 0; r4i < 4; ++r4i) v[r4i] = mt * 16 + 4 * qq + r4i < r4.Bv ? v[r4i] : 0.f;  // (padding rows: zero)
         reinterpret_cast<f32x4*>(hdF)[((size_t)(tile * MB + mt) << 6) + lane] = v;
       }
   }
@@ -1089,9 +1118,10 @@ __global__ __launch_bounds__(512) void k_fwd23(CompTable t, const float* h, cons
   loss += __shfl_xor(loss, 4, 16);
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
-  g[(size_t)m_ep * D + n_ep] = sig - tv;  // d(sum bce)/d(logit)
+  const bool vrow = m_ep < r4.Bv;  // (a padding row: no reconstruction term, and through g = 0 no gradient behind it)
+  g[(size_t)m_ep * D + n_ep] = vrow ? sig - tv : 0.f;  // d(sum bce)/d(logit)
   if (logits_user) logits_user[(size_t)m_ep * D + n_ep] = y;
-  if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = loss;
+  if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = vrow ? loss : 0.f;
   MV_TFLUSH(24, 8, 96);
   MV_SPAN_END(2, 1);
 }
@@ -2034,6 +2064,7 @@ struct L56Args {
   int ldh;
   float beta;
   int64_t off_w_logits;
+  int Bv;                  // valid rows: dheads / radius terms of the padding rows are zero
 };
 
 // the five main waves of a k_bwd56 workgroup meet here (s_barrier would wait for the tile waves as well)
@@ -2121,7 +2152,7 @@ struct DheadsJob {
             const float rk = rv[u][tt][(1 + k) >> 2][(1 + k) & 3];
             acc += k < Aa[tt] ? dzv * rk : 0.f;
           }
-          gv[tt] = (Aa[tt] > 0 && 4 * q + tt < NH) ? acc : 0.f;
+          gv[tt] = (Aa[tt] > 0 && 4 * q + tt < NH && row < a.Bv) ? acc : 0.f;  // (zero for padding rows)
         }
         da[u0 + u] = gv;
         *reinterpret_cast<f32x4*>(&dh_s[row][4 * q]) = gv;
@@ -2227,7 +2258,7 @@ __global__ __launch_bounds__(64 * kW56) void k_bwd56(CompTable t, L56Args a, con
           const float dzv = dz_s[row][zi < 8 ? zi : 7];
           acc += kk < A ? dzv * rr[k][(1 + kk) >> 2][(1 + kk) & 3] : 0.f;
         }
-        acc = on ? acc : 0.f;  // (the record of a fixed radius is not written)
+        acc = (on && row < a.Bv) ? acc : 0.f;  // (the record of a fixed radius is not written; padding rows: no term)
         drp_s[it] = acc;
         a.drpart[it] = acc;
       }
@@ -2679,10 +2710,12 @@ static int latent_path(const mvae_ctx* c, bool x_aligned) {
                     aligned16(P + d.off_w_logits) && aligned16(d.workspace);
   int max_slot = 0;
   for (int i = 0; i < c->t.n; ++i) max_slot = c->t.lane_of[i] > max_slot ? c->t.lane_of[i] : max_slot;
-  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for.  H <= 416: its staging of the two
+  // the fused forward (launches 2 + 3 in one, k_fwd23) for the shapes it was written for -- any batch size that is a multiple
+  // of 16 (up to round 5: multiples of 128 only; measured in round 6 with the four-launch step, us per step fused / per-row
+  // kernels: B = 16 27.1 / 31.5, 64 27.2 / 31.9, 112 28.2 / 33.4, 192 41.9 / 44.2).  H <= 416: its staging of the two
   // W_logits row blocks is sized for 32 x 416 floats (kWl = 13 vectors per thread) -- up to round 4 wider layers (H <= 512)
   // were let through and read LDS rows nobody had written
-  if (fast && full && H <= 416 && (B % 128 == 0) && (Z == 8 || Z == 4 || Z == 6 || Z == 2) && d.eps_dim <= 8 && d.ncomp <= 8 &&
+  if (fast && full && H <= 416 && (Z == 8 || Z == 4 || Z == 6 || Z == 2) && d.eps_dim <= 8 && d.ncomp <= 8 &&
       max_slot < 4 && aligned16(P + d.off_w_d0) &&
       bucket_of(c->dmax) <= 8 && !c->no_fwd23)
     return MVAE_PATH_FUSED;
@@ -2764,6 +2797,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
         *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = dzp_blk ? ws + c->o_dhF : nullptr;
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
+  if (c->valid_rows < B && !lite)
+    return fail(MVAE_E_UNSUPPORTED, "padding rows (mvae_set_valid_rows) need the four-launch step%s: this call's shape / alignment takes other kernels", "");
   float *dzp = ws + c->o_dzp, *whF = ws + c->o_whF;
   float *recH = ws + c->o_recH, *recR = ws + c->o_recR;
   long long* dzfix = reinterpret_cast<long long*>(ws + c->o_dzfix);
@@ -2801,7 +2836,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, P + d.off_w_logits, \
               P + d.off_b_logits, x, heads, c->ldh, z, c->ldz, concat_z, klw, kl, hd, g, bce_part, logits, B, H, D,   \
               NH, Z, duals, zF, hdF, r4)
-    const Rec4Args r4 = {lite ? recH : nullptr, recR, lite ? dzfix : nullptr, c->rec_nv};
+    const Rec4Args r4 = {lite ? recH : nullptr, recR, lite ? dzfix : nullptr, c->rec_nv, c->valid_rows};
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LF23(2); } else if (bk == 4) { LF23(4); } else { LF23(8); }
 #undef LF23
@@ -2941,7 +2976,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (lite) {
       const int n_small = (c->nt_h + tw - 1) / tw;
       const int grid2 = 1 + n_small + n_we0;
-      const L56Args la = {dzfix, recH, recR, g, hdF, dheads, drpart, c->ldh, beta, d.off_w_logits};
+      const L56Args la = {dzfix, recH, recR, g, hdF, dheads, drpart, c->ldh, beta, d.off_w_logits, c->valid_rows};
       const float* scal_p = reinterpret_cast<const float*>(d.step_count) + 2;
       const unsigned* mark_p = reinterpret_cast<const unsigned*>(dzfix + (size_t)B * 8);
 #define B56(NVV, AD, MBT)                                                                                            \
@@ -2993,11 +3028,13 @@ extern "C" int mvae_set_next_batch_feed(mvae_ctx* c, const uint8_t* images, cons
   if (!x_next || !eps_next || n_images < 1 || batches_per_epoch < 1 || train < 0 || train > 2)
     return fail(MVAE_E_BADARG, "null pointer / bad shape%s", "");
   const mvae_model_desc& d = c->d;
-  FeedArgs f = {images, perm, d.step_count, x_next, eps_next, (unsigned long long)seed, n_images, d.in_dim, d.batch,
+  // (with padding rows the batch of the data set is the VALID rows; rows past them are never written and stay what the caller
+  // made them -- zeros)
+  FeedArgs f = {images, perm, d.step_count, x_next, eps_next, (unsigned long long)seed, n_images, d.in_dim, c->valid_rows,
                 d.eps_dim, batches_per_epoch, train, 0};
   // two items (of four values) per thread of a 512-thread workgroup; the workgroups join launch 4's short jobs
   static const int per_thread = [] { const char* e = getenv("MVAE_FEED_ITEMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-  const int items = (d.batch * d.in_dim + 3) / 4 + (d.batch * d.eps_dim + 3) / 4;
+  const int items = (c->valid_rows * d.in_dim + 3) / 4 + (c->valid_rows * d.eps_dim + 3) / 4;
   f.n_wg = (items + 512 * per_thread - 1) / (512 * per_thread);
   if (f.n_wg > 128) f.n_wg = 128;
   c->feed = f;

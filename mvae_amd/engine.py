@@ -15,6 +15,7 @@ run all-reduces ONE contiguous gradient buffer.  nn.Parameters of the host-side 
 (state-dict keys and shapes are the reference's).
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -106,6 +107,7 @@ class StepEngine:
         self.counters = z(32, torch.int32)
         self.stats = z(3 * (4 + n))  # sums | last step | Kahan compensation of the sums
         self._ctx: Dict[int, Tuple[int, Tensor]] = {}
+        self._valid_rows: Dict[int, int] = {}  # physical batch -> valid rows (set_valid_rows); re-applied to rebuilt contexts
         self._last_batch: Optional[int] = None
         self.grads_from_engine = False  # the flat gradient buffer was filled by forward_backward(), not through p.grad
         # bumped whenever the contexts (workspace pointers, lr baked into kernel arguments) are rebuilt: anything that
@@ -203,7 +205,38 @@ class StepEngine:
         handle = C.c_void_p()
         check(load().mvae_create(C.byref(d), C.byref(handle)))
         self._ctx[batch] = (handle.value, ws)
+        if batch in self._valid_rows:
+            check(load().mvae_set_valid_rows(handle.value, self._valid_rows[batch]))
         return handle.value
+
+    # ---- padding rows (batch sizes that are not a multiple of 16, e.g. the reference CLI's default 100)
+    def set_valid_rows(self, batch: int, valid_rows: int) -> bool:
+        """Declare rows [valid_rows, batch) of every (x, eps) this engine is stepped on at physical batch size `batch` to be
+        PADDING (mvae_set_valid_rows): no loss, no KL, no gradient, no statistics from them; the in-step input pipeline
+        prepares `valid_rows` rows.  The caller keeps the padding rows finite (zeros).  False -- and nothing changed -- when
+        this model / shape does not take the four-launch step, the only one that masks."""
+        rc = int(load().mvae_set_valid_rows(self._context(int(batch)), int(valid_rows)))
+        if rc == _lib.MVAE_E_UNSUPPORTED:
+            return False
+        check(rc)
+        if int(valid_rows) == int(batch):
+            self._valid_rows.pop(int(batch), None)
+        else:
+            self._valid_rows[int(batch)] = int(valid_rows)
+        return True
+
+    def padded_rows(self, batch: int) -> int:
+        """The physical batch size to allocate (x, eps) buffers with so that a batch of `batch` rows runs on the fused
+        kernels: `batch` itself if it is a multiple of 16 or if padding is not available for this model (then the
+        one-row-per-workgroup kernels take the exact batch), else the next multiple of 16 with the rest declared padding."""
+        batch = int(batch)
+        if batch % 16 == 0 or os.environ.get("MVAE_NO_PAD_ROWS", "") not in ("", "0"):
+            return batch
+        padded = (batch + 15) // 16 * 16
+        cur = self._valid_rows.get(padded)
+        if padded > 256 or (cur is None and padded in self._ctx) or (cur is not None and cur != batch):
+            return batch  # (too large for the four-launch step, or that physical size is in use with another row count)
+        return padded if self.set_valid_rows(padded, batch) else batch
 
     # ---- the step
     def _check_inputs(self, x: Tensor, eps: Tensor) -> int:

@@ -192,8 +192,12 @@ class EpochRunner:
         if fold and not can_fold:
             raise ValueError("this engine has no in-step input preparation")
         self.fold = bool(fold)
+        # A batch size that is not a multiple of 16 (the reference CLI's default is 100) runs on the fused kernels with PADDING
+        # rows: the buffers get `Bp` rows, the pipeline fills the first B of them, the rest stay zero and are masked by the
+        # step (StepEngine.padded_rows / mvae_set_valid_rows).  Bp == B when the engine cannot mask.
+        self.Bp = eng.padded_rows(self.B) if (hasattr(eng, "padded_rows") and dp is None) else self.B
         # two (x, eps) pairs in alternation when the step prepares its successor's batch; `par` = the pair the next step reads
-        self._bufs = [(torch.zeros(self.B, self.D, device=dev), torch.zeros(self.B, self.E, device=dev))
+        self._bufs = [(torch.zeros(self.Bp, self.D, device=dev), torch.zeros(self.Bp, self.E, device=dev))
                       for _ in range(2 if self.fold else 1)]
         self.par = 0
         self.perm = torch.arange(self.N, device=dev, dtype=torch.int32)
@@ -211,11 +215,11 @@ class EpochRunner:
     @property
     def x(self) -> Tensor:
         """The batch the next step reads (after a step: the one prepared for its successor)."""
-        return self._bufs[self.par][0]
+        return self._bufs[self.par][0][:self.B]
 
     @property
     def eps(self) -> Tensor:
-        return self._bufs[self.par][1]
+        return self._bufs[self.par][1][:self.B]
 
     def _prepare(self, train: bool = True) -> None:
         """One mvae_prepare_batch launch: the batch at the cursor into the pair the next step reads."""
@@ -230,7 +234,7 @@ class EpochRunner:
         x, eps = self._bufs[self.par]
         if self.fold:
             nx, ne = self._bufs[self.par ^ 1]
-            self.eng.set_next_batch_feed(self.B, self.images, self.perm, self.seed, self.nb,
+            self.eng.set_next_batch_feed(self.Bp, self.images, self.perm, self.seed, self.nb,
                                          self.mode if train else (0 if self.mode == 1 else 2), nx, ne)
             self.par ^= 1
         else:
@@ -281,7 +285,7 @@ class EpochRunner:
                     dst.copy_(src)
                 self.par = par0
                 if self.fold:
-                    eng.set_next_batch_feed(self.B, None)  # a failed capture may leave the context armed
+                    eng.set_next_batch_feed(self.Bp, None)  # a failed capture may leave the context armed
             # every rank takes the same route (see StepRunner.__init__): any failure -> all run this key eagerly
             if self.dp is not None and agree_any(failed, self.dp.group, "epochrunner-capture"):
                 g = None

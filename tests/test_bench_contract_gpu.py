@@ -64,8 +64,11 @@ def test_bench_line_schema():
     assert list(d)[-1] == "configs_summary"
     cs = d["configs_summary"]
     assert len(json.dumps(cs)) <= 700, len(json.dumps(cs))
-    for key in ("h2s2e2", "e6", "prod36", "conv", "conv_f32_mfma", "conv_split", "epoch_pipeline", "loglik"):
+    for key in ("h2s2e2", "e6", "prod36", "conv", "conv_f32_mfma", "conv_split", "epoch_pipeline", "epoch_b100", "loglik"):
         assert cs[key] is not None and cs[key][0] > 0, (key, cs)
+    # the reference CLI's default batch size rides on the fused kernels through padding rows (112-row buffers)
+    b100 = d["configs"]["epoch_pipeline_b100"]
+    assert b100["batch"] == 100 and b100["buffer_rows"] == 112 and b100["kernel_path"] == "fused", b100
     assert abs(cs["h2s2e2"][0] - d["value"]) < 0.06 and cs["timed_repeats"] == 5
 
 

@@ -772,8 +772,10 @@ def test_fused_train_step_strict_vs_oracle(dev, model, fixed):
 @pytest.mark.parametrize("model,B,H,D,path", [
     # H: the fused forward stages W_logits for H <= 416 (one value inside, the limit, one past it)
     ("h2,s2,e2", 128, 400, 784, "fused"), ("h2,s2,e2", 128, 416, 784, "fused"), ("h2,s2,e2", 128, 432, 784, "row"),
-    # B: multiples of 128 take the fused forward, B <= 256 the lite backward; 384 the fused forward with the round-4 backward
-    ("h2,s2,e2", 256, 400, 784, "fused"), ("h2,s2,e2", 384, 128, 96, "fused"), ("h2,s2,e2", 112, 128, 96, "row"),
+    # B: multiples of 16 take the fused forward, B <= 256 the four-launch step; 384 the fused forward with the generic backward;
+    # 100 is not a multiple of 16: per-row kernels (or padding rows: test_padding_rows_vs_oracle)
+    ("h2,s2,e2", 256, 400, 784, "fused"), ("h2,s2,e2", 384, 128, 96, "fused"), ("h2,s2,e2", 112, 128, 96, "fused"),
+    ("h2,s2,e2", 16, 128, 96, "fused"), ("h2,s2,e2", 100, 128, 96, "row"),
     # Z / NH: z_dim 8 and heads_dim 16 are the fused forward's limits (e4,s3 -> Z = 8, NH = 14; 4e2 -> NH = 16; h4,s4: Z = 10)
     ("e4,s3", 128, 128, 96, "fused"), ("4e2", 128, 128, 96, "fused"), ("h4,s4", 128, 128, 96, None),
     # D: 16-column tiles; 800 = no idle tile wave in k_bwd56; 776 is not a multiple of 16
@@ -852,3 +854,71 @@ def test_dz_partial_out_of_fixed_point_range_poisons_the_step_and_recovers(dev):
     torch.cuda.synchronize()
     assert np.isfinite(_cpu(eng.grads)).all()
     assert np.array_equal(_cpu(eng.grads), _cpu(fresh.grads)), "the recovered engine steps bit-identically to a fresh one"
+
+
+@pytest.mark.parametrize("model,Bv,H,D", [("h2,s2,e2", 100, 400, 784), ("e6", 100, 400, 784), ("h2,s2,e2", 7, 128, 96),
+                                           ("s2,h2", 241, 128, 96)])
+@pytest.mark.parametrize("pad_fill", ["zeros", "finite garbage"])
+def test_padding_rows_vs_oracle(dev, model, Bv, H, D, pad_fill):
+    """Batch sizes that are not a multiple of 16 (the reference CLI's default is 100, mt/examples/run.py:32) on the fused
+    kernels: the batch is rounded up, rows [Bv, B) are PADDING (mvae_set_valid_rows) -- no reconstruction term, no KL, no
+    gradient, no statistics from them, whatever (finite) values they hold.  One gradients-only call and one fused step on
+    the padded buffers against the oracle on the Bv valid rows (1e-4), per-row outputs included."""
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from oracle import model as M
+    spec = M.Spec(model, in_dim=D, h_dim=H, fixed_curvature=False)
+    ncomp = len(spec.components)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    x = synthetic.binary_batches(1, Bv, D)[0]
+    eps = synthetic.eps_batches(1, Bv, spec.total_true_dim)[0]
+    orc = M.StepOracle(spec, state0)
+    ref = orc.train_step(x, eps, beta=0.7, epoch=12)
+    comps = [(c.letter, c.true_dim) for c in spec.components]
+
+    def padded(eng):
+        Bp = eng.padded_rows(Bv)
+        assert Bp == (Bv + 15) // 16 * 16, "this shape takes the four-launch step: padding is available"
+        assert eng.kernel_path(Bp) == "fused"
+        gen = torch.Generator().manual_seed(3)
+        xp, ep = torch.zeros(Bp, D), torch.zeros(Bp, spec.total_true_dim)
+        if pad_fill != "zeros":
+            xp[Bv:] = (torch.rand(Bp - Bv, D, generator=gen) < 0.5).float()
+            ep[Bv:] = torch.randn(Bp - Bv, spec.total_true_dim, generator=gen) * 3
+        xp[:Bv], ep[:Bv] = x, eps
+        return xp.to(dev), ep.to(dev)
+
+    eng = StepEngine(comps, D, H, dev, radius_trainable=[True] * ncomp)
+    eng.load_state(state0)
+    xp, ep = padded(eng)
+    out = eng.forward_backward(xp, ep, 0.7, want_outputs=True)
+    assert_close(_cpu(out["bce"])[:Bv], ref.bce.detach().numpy(), RTOL, "bce rows")
+    assert_close(_cpu(out["kl"])[:, :Bv], ref.kl.detach().numpy(), RTOL, "kl rows", atol_frac=1e-4)
+    assert not _cpu(out["bce"])[Bv:].any() and not _cpu(out["kl"])[:, Bv:].any(), "padding rows carry no loss terms"
+    assert_close(_cpu(out["concat_z"])[:Bv], ref.concat_z.detach().numpy(), RTOL, "concat_z", atol_frac=1e-4)
+    for n, p in orc.P.items():
+        assert_close(_cpu(eng.grad_views()[n]), p.grad.numpy(), RTOL, f"grad {n} (gradients-only call)", atol_frac=1e-4)
+    assert_close(eng.read_stats()["last"]["elbo"], float(ref.elbo.detach()), RTOL, "elbo")
+    eng2 = StepEngine(comps, D, H, dev, radius_trainable=[True] * ncomp)
+    eng2.load_state(state0)
+    xp, ep = padded(eng2)
+    eng2.train_step(xp, ep, 0.7, True)
+    torch.cuda.synchronize()
+    mv = eng2.flat.views(eng2.adam_m)
+    for n, p in orc.P.items():
+        if n.endswith("radius") or n.endswith("curvature"):
+            assert_close(_cpu(eng2.param_views()[n]), p.detach().numpy(), RTOL, f"{n} after the SGD step")
+        else:
+            assert_close(_cpu(mv[n]), orc.adam.state[p]["exp_avg"].numpy(), RTOL, f"adam m {n} (fused step)", atol_frac=1e-4)
+
+
+def test_padding_rows_declined_off_the_four_launch_step(dev):
+    """mvae_set_valid_rows only where the kernels mask: a model on the per-row kernels (H = 432), on the wave-cooperative ones
+    (`h40`) or on the block kernels (`6h2,6s2,6e2`) declines -- padded_rows() then returns the exact batch."""
+    from mvae_amd.engine import StepEngine
+    for comps, H in (([("h", 2), ("s", 2), ("e", 2)], 432), ([("h", 40)], 400), ([("h", 2)] * 6 + [("s", 2)] * 6 + [("e", 2)] * 6, 400)):
+        eng = StepEngine(comps, 784, H, dev, radius_trainable=[True] * len(comps))
+        assert eng.padded_rows(100) == 100
+        assert not eng.set_valid_rows(112, 100)
+    eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True] * 3)
+    assert eng.padded_rows(128) == 128 and eng.padded_rows(100) == 112 and eng.padded_rows(300) == 300

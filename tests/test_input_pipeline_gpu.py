@@ -274,3 +274,40 @@ def test_next_batch_feed_refuses_the_buffers_the_step_reads(dev):
     eng.train_step(x, eps, 1.0, False)  # the refused arming is gone
     torch.cuda.synchronize()
     assert int(eng.counters[0]) == 1
+
+
+def test_epoch_runner_at_the_reference_batch_size_pads_rows(dev, monkeypatch):
+    """`--batch_size 100` (the reference CLI's default, mt/examples/run.py:32) through the device-side pipeline: the buffers are
+    padded to 112 rows, the pipeline prepares 100 of them and the step masks the rest (four launches on the fused kernels
+    instead of the one-row-per-workgroup path).  Same permutation, same Philox items -> the same batches: after an epoch the
+    parameters and the epoch statistics agree with a runner that does not pad (MVAE_NO_PAD_ROWS=1) to float32 rounding."""
+    from helpers import assert_close, assert_close_after_adam
+    from mvae_amd import synthetic
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import EpochRunner
+    from oracle import model as M
+    spec = M.Spec("h2,s2,e2", in_dim=784, h_dim=400, fixed_curvature=False)
+    state0 = synthetic.synthetic_state(spec.named_shapes(), radius=2.0)
+    imgs = (synthetic.digits_like_batches(7, 100).reshape(-1, 784) * 255).to(torch.uint8).to(dev)[:650]  # 6 batches + a tail
+    res = {}
+    for mode in ("padded", "exact"):
+        if mode == "exact":
+            monkeypatch.setenv("MVAE_NO_PAD_ROWS", "1")
+        eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+        eng.load_state(state0)
+        er = EpochRunner(eng, imgs, 100, seed=5, graph_steps=3)
+        assert er.Bp == (112 if mode == "padded" else 100) and er.nb == 6
+        assert eng.kernel_path(er.Bp) == ("fused" if mode == "padded" else "row")
+        for _ in range(2):
+            er.run_epoch(0.8, True)
+        torch.cuda.synchronize()
+        assert tuple(er.x.shape) == (100, 784)
+        st = eng.read_stats()
+        res[mode] = ({n: t.detach().cpu().numpy().copy() for n, t in eng.param_views().items()}, st["sum"]["elbo"], st["sum"]["steps"])
+    assert res["padded"][2] == res["exact"][2] == 12
+    assert_close(res["padded"][1], res["exact"][1], 1e-4, "sum of the ELBO over two epochs")
+    for n, v in res["padded"][0].items():
+        if n.endswith("radius"):
+            assert_close(v, res["exact"][0][n], 2e-4, n)
+        else:
+            assert_close_after_adam(v, res["exact"][0][n], 1e-3, 12, f"param {n}: padded rows vs exact batch", bad_frac=2e-3)

@@ -11,7 +11,8 @@ comps = [("h", 2), ("s", 2), ("e", 2)]
 eng = StepEngine(comps, 784, 400, dev, radius_trainable=[True, True, False], lr=1e-3)
 eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
 images = (torch.rand(60000, 784, device=dev) ** 3 * 255).to(torch.uint8)
-er = EpochRunner(eng, images, 128, seed=1)
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 128  # (100 = the reference CLI's default: padded to 112 rows, MVAE_NO_PAD_ROWS=1: exact)
+er = EpochRunner(eng, images, BATCH, seed=1)
 for _ in range(2):
     n = er.run_epoch(1.0, True)
 torch.cuda.synchronize()
@@ -21,4 +22,5 @@ for _ in range(E):
     n = er.run_epoch(1.0, True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+print(f"batch {BATCH} (buffers of {er.Bp} rows, kernels: {eng.kernel_path(er.Bp)}): " if BATCH != 128 else "", end="")
 print(f"epoch of {n} steps: {dt / E * 1e3:.2f} ms = {n * E / dt:.0f} steps/s ({dt / E / n * 1e6:.1f} us/step)")
