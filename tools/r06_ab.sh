@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: ran against commits 1a5dcdb / 405fdfa, whose library still had the MVAE_STEP5 / MVAE_GF / MVAE_L56_GATE switches; kept as the record of the A/B behind DESIGN section 5)
 # round 6: the four-launch step (k_bwd56) against the five-launch lite step (MVAE_STEP5=1), with and without g's
 # fragment-order copy (MVAE_GF=1); parity tests first, then interleaved 2000-step bench runs.
 out=gpurun_out/r06ab

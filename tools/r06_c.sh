@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: ran against commits 1a5dcdb / 405fdfa, whose library still had the MVAE_STEP5 / MVAE_GF / MVAE_L56_GATE switches; kept as the record of the A/B behind DESIGN section 5)
 out=gpurun_out/r06c
 mkdir -p $out
 timeout 1200 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "lite_backward or strict or shape_sweep or fused_step" > $out/pytest_parity.log 2>&1
