@@ -578,7 +578,8 @@ int mvae_set_radius_trainable(mvae_ctx* ctx, const uint8_t* trainable);
  * every x / eps buffer finite (zeros) and declares them here: they then contribute no reconstruction term, no KL term, no
  * gradient and no statistics (ModelVAE.train_step sums over the rows of the batch, vae.py:125-147), and
  * mvae_set_next_batch_feed / the step's in-launch input pipeline prepare valid_rows rows per batch.  Only the four-launch
- * step (mvae_step_kernel_path() == MVAE_PATH_FUSED, batch <= 256) masks: for any other model / shape the call returns
+ * step (mvae_step_kernel_path() == MVAE_PATH_FUSED, batch <= 256) and the fragment-order block kernels (MVAE_PATH_BLOCK,
+ * z_dim 17 .. 64) mask: for any other model / shape the call returns
  * MVAE_E_UNSUPPORTED (no message) and the caller creates a context for exactly valid_rows rows instead; a later step whose
  * buffers' alignment takes it off the four-launch kernels fails with MVAE_E_UNSUPPORTED rather than sum padding rows. */
 int mvae_set_valid_rows(mvae_ctx* ctx, int valid_rows);

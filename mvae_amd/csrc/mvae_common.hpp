@@ -801,7 +801,8 @@ __device__ __forceinline__ void job_tn_halffrag(const float* Prow, int ldp, int 
 // x [B][N] -> its fragment-order copy, one column tile per workgroup (any block size that is a multiple of 64): thread
 // (block c, lane (i, q)) gathers its four batch rows and stores one 16-byte vector.
 // ncols > 0: columns past ncols (a ragged last tile) repeat the last column; they only reach outputs nobody stores.
-__device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, int MB, float* TF, int ncols = 0) {
+// nrows > 0: rows past nrows (padding rows, mvae_set_valid_rows) are stored as zeros.
+__device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, int MB, float* TF, int ncols = 0, int nrows = 0) {
   const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
   const int col = (ncols > 0 && 16 * nt + i >= ncols) ? ncols - 1 : 16 * nt + i;
   for (int c = threadIdx.x >> 6; c < MB; c += (int)(blockDim.x >> 6)) {
@@ -811,6 +812,10 @@ __device__ __forceinline__ void job_frag_copy(const float* T, int ld, int nt, in
     v[1] = src[(size_t)ld];
     v[2] = src[2 * (size_t)ld];
     v[3] = src[3 * (size_t)ld];
+    if (nrows > 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = 16 * c + 4 * q + t < nrows ? v[t] : 0.f;
+    }
     store16_wt(TF, (((size_t)(nt * MB + c) << 6) + lane) << 2, v);  // read by a later launch only
   }
 }

@@ -33,6 +33,7 @@ struct StatsArgs {  // job_step_stats outside launch 4; bce_part == NULL: not he
   float* bce_user;
   float* stats;
   int ncomp;
+  int valid_rows;  // mvae_set_valid_rows: rows past it are padding (k_latent_bwd_blk zeroes their derivative terms)
 };
 __device__ __forceinline__ void job_step_stats(float* sm, const float* bce_part, const float* kl, float* bce_user, float* stats,
                                                float beta, int B, int ntD, int ncomp);
@@ -238,7 +239,11 @@ extern "C" int mvae_set_valid_rows(mvae_ctx* c, int valid_rows) {
   if (valid_rows < d.batch) {
     const bool four = latent_path(c, true) == MVAE_PATH_FUSED && !uses_blk_bwd(c, true) && !c->no_lite && d.batch <= 256 &&
                       d.ncomp <= kRecRad && c->rec_nv <= kRecVecMax;
-    if (!four) return MVAE_E_UNSUPPORTED;  // (quietly: the caller then steps on exactly valid_rows rows)
+    // ... or the fragment-order block kernels (many small components, z_dim 17 .. 64, block forward on)
+    const bool blk = !c->no_lite && uses_blk_bwd(c, true) && d.z_dim > 16 && d.z_dim <= 64 &&
+                     latent_path(c, true) == MVAE_PATH_BLOCK && c->blk_fwd && (d.batch % 16 == 0) && (d.h_dim % 16 == 0) &&
+                     (d.in_dim % 16 == 0);
+    if (!four && !blk) return MVAE_E_UNSUPPORTED;  // (quietly: the caller then steps on exactly valid_rows rows)
   }
   c->valid_rows = valid_rows;
   c->feed = FeedArgs{};
@@ -1229,6 +1234,7 @@ struct FragArgs {
   const float* Wh;
   float* whF;
   int n_snap, NH;
+  int Bv;  // valid rows: z's fragment copy is zero past them (a padding row's z need not be finite)
 };
 struct DualArgs {
   const float* heads;
@@ -1514,7 +1520,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
     } else if (fb - fd.n_wg < fr.n_xf) {
       job_frag_copy(fr.x, D, fb - fd.n_wg, B >> 4, fr.xF);  // x in fragment order for launch 6's dW_e0 tiles
     } else if (fb - fd.n_wg - fr.n_xf < fr.n_zf) {
-      job_frag_copy(fr.z, fr.ldz, fb - fd.n_wg - fr.n_xf, B >> 4, fr.zF, fr.Z);
+      job_frag_copy(fr.z, fr.ldz, fb - fd.n_wg - fr.n_xf, B >> 4, fr.zF, fr.Z, fr.Bv);
     } else if (fb - fd.n_wg - fr.n_xf - fr.n_zf < fr.n_snap) {
       // whF[(pt * 64 + q * 16 + i) * 4 + t] = W_heads[4 q + t][16 pt + i] (0 past NH): the B fragments of k_bwd56's dh product
       const int sb = fb - fd.n_wg - fr.n_xf - fr.n_zf;
@@ -2797,8 +2803,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
         *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = dzp_blk ? ws + c->o_dhF : nullptr;
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
-  if (c->valid_rows < B && !lite)
-    return fail(MVAE_E_UNSUPPORTED, "padding rows (mvae_set_valid_rows) need the four-launch step%s: this call's shape / alignment takes other kernels", "");
+  if (c->valid_rows < B && !lite && !(dzp_blk && hdf_blk))
+    return fail(MVAE_E_UNSUPPORTED, "padding rows (mvae_set_valid_rows) need the four-launch step or the block kernels%s: this call's shape / alignment takes other kernels", "");
   float *dzp = ws + c->o_dzp, *whF = ws + c->o_whF;
   float *recH = ws + c->o_recH, *recR = ws + c->o_recR;
   long long* dzfix = reinterpret_cast<long long*>(ws + c->o_dzfix);
@@ -2845,7 +2851,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LHC(DM)                                                                                                      \
   STEP_LAUNCH((k_heads_comp<DM>), dim3(c->nt_b * c->gt.ng), dim3(512), 0, c->t, c->gt, h, P + d.off_w_heads,          \
               P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, heads, c->ldh, z, c->ldz, concat_z, klw, kl, B, H,  \
-              NH, Z)
+              NH, Z, c->valid_rows)
     const int bk = bucket_of(c->dmax);
     if (bk == 2) { LHC(2); } else if (bk == 4) { LHC(4); } else { LHC(8); }
 #undef LHC
@@ -2856,7 +2862,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   STEP_LAUNCH((k_fwd3m<DM>), dim3(n_dual3 + ((c->nt_d + 1) / 2) * c->nt_b), dim3(512), lds, c->t, c->gt, heads,       \
               c->ldh, eps, d.eps_dim, P + d.off_radii, NH, duals, n_dual3, z, c->ldz, P + d.off_w_d0, P + d.off_b_d0, \
               P + d.off_w_logits, P + d.off_b_logits, x, hd, g, bce_part, logits, B, H, D, Z,  \
-              hdF)
+              hdF, c->valid_rows)
     if (bk == 2) { LF3(2); } else if (bk == 4) { LF3(4); } else { LF3(8); }
 #undef LF3
   } else {
@@ -2909,7 +2915,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     c->feed = FeedArgs{};
     const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, dzp_blk ? dzp : nullptr, P + d.off_w_d0, Z,
                          z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0,
-                         lite ? dzfix : nullptr, P + d.off_w_heads, whF, lite ? 4 : 0, NH};
+                         lite ? dzfix : nullptr, P + d.off_w_heads, whF, lite ? 4 : 0, NH, c->valid_rows};
     const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
   STEP_LAUNCH((k_dec1_bwd<AD, FU, DU, LI>), dim3(n_dhd + n_short), dim3(512), 0, c->t, g, hd, P + d.off_w_logits, \
@@ -2945,7 +2951,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       const int n_blk = c->nt_b * ((H + 63) / 64);
       const size_t lds_b = Z <= 16 ? (size_t)H * Z * sizeof(float) : 0;
       const int4* dirtab = reinterpret_cast<const int4*>(ws + c->o_dirtab);
-      const StatsArgs sa = {hdf_blk ? bce_part : nullptr, klw, bce, d.stats, d.ncomp};  // (launch 4 skipped it: FragArgs::stats_later)
+      const StatsArgs sa = {hdf_blk ? bce_part : nullptr, klw, bce, d.stats, d.ncomp, c->valid_rows};  // (launch 4 skipped it: FragArgs::stats_later)
       const int n_tile_wg = hdf_blk ? (c->nt_d * c->nt_h + 7) / 8 : c->nt_d * ntHg5;
 #define LBB(DM, AD, TT)                                                                                               \
   STEP_LAUNCH((k_latent_bwd_blk<DM, AD, TT>), dim3(n_blk + n_tile_wg + (hdf_blk ? 1 : 0)), dim3(hdf_blk ? 512 : 256), lds_b, c->t, dirtab, dhd, P + d.off_w_d0, \

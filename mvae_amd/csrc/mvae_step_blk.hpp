@@ -70,7 +70,8 @@ template <int DMAX>
 __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, const float* h, const float* Wh,
                                                     const float* bh, const float* eps, int eps_ld, const float* radii,
                                                     float* heads, int ldh, float* z, int ldz, float* z_user, float* kl,
-                                                    float* kl_user, int B, int H, int NH, int Z) {
+                                                    float* kl_user, int B, int H, int NH, int Z, int Bv) {
+  // Bv: valid rows (mvae_set_valid_rows); rows past it are padding and carry no KL term
   __shared__ float red[kW8][16][17];
   __shared__ __attribute__((aligned(16))) float heads_s[16][16];
   __shared__ __attribute__((aligned(16))) float eps_s[16][16];
@@ -141,8 +142,9 @@ __global__ __launch_bounds__(512) void k_heads_comp(CompTable t, GroupTable gt, 
       float klv;
       comp_fwd_row<DMAX>(c, heads_s[r], eps_s[r], rad_s, z + row * ldz + z0, z_user ? z_user + row * Z + z0 : nullptr,
                          &klv, nullptr, nullptr, nullptr, nullptr);
-      kl[(size_t)(first + sl) * B + row] = klv;
-      if (kl_user) kl_user[(size_t)(first + sl) * B + row] = klv;
+      const float klm = (int)row < Bv ? klv : 0.f;
+      kl[(size_t)(first + sl) * B + row] = klm;
+      if (kl_user) kl_user[(size_t)(first + sl) * B + row] = klm;
     }
     MV_SPAN_END(1, 1);
     return;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
                                                int n_dual, const float* z, int ldz, const float* Wd0, const float* bd0,
                                                const float* Wl, const float* bl, const float* x, float* hd, float* g,
                                                float* bce_part, float* logits_user, int B, int H, int D, int Z,
-                                               float* hdF) {
+                                               float* hdF, int Bv) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // hd_s[16][H + 4]
   __shared__ float red[kW8][16][17];
   __shared__ float red2[kW8][16][17];
@@ -314,7 +316,10 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
       for (int e = tid; e < nchunks * 64; e += 512) {
         const int c = e >> 6, l = e & 63;
         const float* src = hd_s + (4 * (l >> 4)) * ld + 16 * c + (l & 15);
-        reinterpret_cast<f32x4*>(hdF)[((size_t)(c * MT + mt) << 6) + l] = f32x4{src[0], src[ld], src[2 * ld], src[3 * ld]};
+        f32x4 v = {src[0], src[ld], src[2 * ld], src[3 * ld]};
+#pragma unroll
+        for (int r4i = 0; r4i < 4; ++r4i) v[r4i] = mt * 16 + 4 * (l >> 4) + r4i < Bv ? v[r4i] : 0.f;  // (padding rows: zero)
+        reinterpret_cast<f32x4*>(hdF)[((size_t)(c * MT + mt) << 6) + l] = v;
       }
     } else {
       for (int e4 = tid; e4 < 4 * H; e4 += 512) {
@@ -368,9 +373,10 @@ __global__ __launch_bounds__(512) void k_fwd3m(CompTable t, GroupTable gt, const
   loss += __shfl_xor(loss, 4, 16);
   loss += __shfl_xor(loss, 2, 16);
   loss += __shfl_xor(loss, 1, 16);
-  g[(size_t)m_ep * D + n_ep] = sig - tv;
+  const bool vrow = m_ep < Bv;  // (a padding row: no reconstruction term, and through g = 0 no gradient behind it)
+  g[(size_t)m_ep * D + n_ep] = vrow ? sig - tv : 0.f;
   if (logits_user) logits_user[(size_t)m_ep * D + n_ep] = y;
-  if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = loss;
+  if ((tid & 15) == 0) bce_part[(size_t)nt_ep * B + m_ep] = vrow ? loss : 0.f;
   MV_SPAN_END(2, 1);
 }
 
@@ -653,6 +659,7 @@ __global__ __launch_bounds__(512) void k_latent_bwd_blk(CompTable t, const int4*
             const float pv = dz_s[r][zc + e < 68 ? zc + e : 67] * du[rd][rr][(1 + e) >> 1][(1 + e) & 1];
             gv += e < A ? pv : 0.f;
           }
+          gv = mt * 16 + r < sa.valid_rows ? gv : 0.f;  // (padding rows: no term)
           if (oc >= 0) dheads_s[r][oc] = gv;
           else if (s == 0) drpart[(size_t)(-oc - 1) * B + mt * 16 + r] = gv;
         }

@@ -857,7 +857,8 @@ def test_dz_partial_out_of_fixed_point_range_poisons_the_step_and_recovers(dev):
 
 
 @pytest.mark.parametrize("model,Bv,H,D", [("h2,s2,e2", 100, 400, 784), ("e6", 100, 400, 784), ("h2,s2,e2", 7, 128, 96),
-                                           ("s2,h2", 241, 128, 96)])
+                                           ("s2,h2", 241, 128, 96), ("6h2,6s2,6e2", 100, 400, 784),
+                                           ("5e3,h4,2s2,e6", 23, 64, 48)])
 @pytest.mark.parametrize("pad_fill", ["zeros", "finite garbage"])
 def test_padding_rows_vs_oracle(dev, model, Bv, H, D, pad_fill):
     """Batch sizes that are not a multiple of 16 (the reference CLI's default is 100, mt/examples/run.py:32) on the fused
@@ -878,8 +879,8 @@ def test_padding_rows_vs_oracle(dev, model, Bv, H, D, pad_fill):
 
     def padded(eng):
         Bp = eng.padded_rows(Bv)
-        assert Bp == (Bv + 15) // 16 * 16, "this shape takes the four-launch step: padding is available"
-        assert eng.kernel_path(Bp) == "fused"
+        assert Bp == (Bv + 15) // 16 * 16, "this shape takes the four-launch step or the block kernels: padding is available"
+        assert eng.kernel_path(Bp) == ("block" if len(comps) > 8 else "fused")
         gen = torch.Generator().manual_seed(3)
         xp, ep = torch.zeros(Bp, D), torch.zeros(Bp, spec.total_true_dim)
         if pad_fill != "zeros":
@@ -913,12 +914,14 @@ def test_padding_rows_vs_oracle(dev, model, Bv, H, D, pad_fill):
 
 
 def test_padding_rows_declined_off_the_four_launch_step(dev):
-    """mvae_set_valid_rows only where the kernels mask: a model on the per-row kernels (H = 432), on the wave-cooperative ones
-    (`h40`) or on the block kernels (`6h2,6s2,6e2`) declines -- padded_rows() then returns the exact batch."""
+    """mvae_set_valid_rows only where the kernels mask (the four-launch step and the fragment-order block kernels): a model on
+    the per-row kernels (H = 432) or on the wave-cooperative ones (`h40`) declines -- padded_rows() then returns the exact batch."""
     from mvae_amd.engine import StepEngine
-    for comps, H in (([("h", 2), ("s", 2), ("e", 2)], 432), ([("h", 40)], 400), ([("h", 2)] * 6 + [("s", 2)] * 6 + [("e", 2)] * 6, 400)):
+    for comps, H in (([("h", 2), ("s", 2), ("e", 2)], 432), ([("h", 40)], 400)):
         eng = StepEngine(comps, 784, H, dev, radius_trainable=[True] * len(comps))
         assert eng.padded_rows(100) == 100
         assert not eng.set_valid_rows(112, 100)
     eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True] * 3)
     assert eng.padded_rows(128) == 128 and eng.padded_rows(100) == 112 and eng.padded_rows(300) == 300
+    eng = StepEngine([("h", 2)] * 6 + [("s", 2)] * 6 + [("e", 2)] * 6, 784, 400, dev, radius_trainable=[True] * 18)
+    assert eng.padded_rows(100) == 112 and eng.kernel_path(112) == "block"
