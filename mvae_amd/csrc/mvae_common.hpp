@@ -1157,8 +1157,15 @@ __device__ __forceinline__ void feed_item(const FeedArgs& f, unsigned cursor, in
     float n[4];  // Box-Muller on two pairs
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float u1 = ((float)(r[2 * t] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
-      const float u2 = (float)(r[2 * t + 1] >> 8) * (1.0f / 16777216.0f);
+      // Both uniforms on the OPEN interval, (k + 1/2) 2^-23: with u1 in (0, 1] a pair is exactly (0, 0) whenever u1 = 1 --
+      // probability 2^-24 per pair, i.e. about once per 50 MNIST epochs -- and a sphere component whose eps is (0, 0) is
+      // 0 / 0 in the reference's formula (spherical.py:87-88 divides by |u| unclamped): the float32 CLI run went non-finite
+      // at a random epoch in 2 of 16 seeds, at exactly the batches tools/eps_zero_scan.py finds such a pair in.  (The reference draws
+      // float64 normals by default, where the same event has probability 2^-53.)  The half-step offset also keeps sin / cos
+      // off their exact zeros, so no single draw is exactly 0 either.
+      // (23 random bits: k + 1/2 is then exact in float32 -- with 24 bits the largest k + 1/2 rounds up to 2^24 and u1 is 1 again)
+      const float u1 = ((float)(r[2 * t] >> 9) + 0.5f) * (1.0f / 8388608.0f);      // (0, 1)
+      const float u2 = ((float)(r[2 * t + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
       const float rad = sqrtf(-2.0f * logf(u1));
       float sn, cs;
       sincosf(6.283185307179586f * u2, &sn, &cs);

@@ -77,6 +77,7 @@ class FusedPosterior:
         B = self.heads.shape[0]
         if eps is None:
             eps = torch.randn(tuple(shape) + (B, lay.eps_dim), device=self.heads.device, generator=self._generator)
+            eps.masked_fill_(eps == 0, 1e-10)  # (an all-zero eps is 0 / 0 on the sphere: see ModelVAE._eps)
         radii = self.component._radii_tensor()
         if len(shape) == 0 and not want_log_probs and torch.is_grad_enabled() and \
                 (self.heads.requires_grad or radii.requires_grad):

@@ -161,7 +161,11 @@ class ModelVAE(nn.Module):
         self._generator = torch.Generator(device=self.device).manual_seed(seed)
 
     def _eps(self, *lead: int) -> Tensor:
-        return torch.randn(*lead, self._need_engine().layout.eps_dim, device=self.device, generator=self._generator)
+        """The N(0, 1) draw behind every rsample of the step.  A float32 Box-Muller draw is EXACTLY zero with probability
+        ~2^-25 per pair, and a sphere component whose eps is all zeros is 0 / 0 in the reference's formula (spherical.py:87-88,
+        |u| unclamped; float64 draws, the reference's default, never get there): exact zeros are nudged to 1e-10."""
+        eps = torch.randn(*lead, self._need_engine().layout.eps_dim, device=self.device, generator=self._generator)
+        return eps.masked_fill_(eps == 0, 1e-10)
 
     # ---- reference API
     def encode(self, x: Tensor) -> Tensor:

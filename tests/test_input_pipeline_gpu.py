@@ -2,6 +2,7 @@
 as HIP-graph replays.  The RNG is Philox (no parity with torch's generator is intended): the tests are statistical and
 structural -- the semantics of ImageDynamicBinarization (image_reconstruction.py:44-53) and of N(0,1) draws."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -311,3 +312,30 @@ def test_epoch_runner_at_the_reference_batch_size_pads_rows(dev, monkeypatch):
             assert_close(v, res["exact"][0][n], 2e-4, n)
         else:
             assert_close_after_adam(v, res["exact"][0][n], 1e-3, 12, f"param {n}: padded rows vs exact batch", bad_frac=2e-3)
+
+
+def test_pipeline_eps_is_never_exactly_zero(dev):
+    """Round 6: with Box-Muller's first uniform on (0, 1] an eps PAIR is exactly (0, 0) with probability 2^-24, and a sphere
+    component whose eps is the zero vector is 0 / 0 in the reference's formula (spherical.py:87-88) -- the float32 CLI run went
+    non-finite at a random epoch (2 of 16 seeds within 100 epochs).  The two draws that did it (found by tools/eps_zero_scan.py in the
+    old stream: seed 8, batch 100, cursor 51138, row 50; seed 9, batch 128, cursor 16186, row 122 -- both the s2 component)
+    and a scan of 3000 batches: no entry of eps is exactly zero, and the draws are still standard normal."""
+    from mvae_amd.engine import StepEngine
+    from mvae_amd.runner import EpochRunner
+    os.environ.pop("MVAE_NO_PAD_ROWS", None)
+    images = (torch.rand(60000, 784, device=dev) * 255).to(torch.uint8)
+    for seed, B, cursors in ((8, 100, [51138] + list(range(1500))), (9, 128, [16186] + list(range(1500)))):
+        eng = StepEngine([("h", 2), ("s", 2), ("e", 2)], 784, 400, dev, radius_trainable=[True, True, False])
+        er = EpochRunner(eng, images, B, seed=seed, fold=False)
+        zeros, acc = 0, []
+        for cur in cursors:
+            eng.counters[8] = cur
+            er._prepare()
+            e = er.eps
+            zeros += int((e == 0).sum())
+            if cur < 200:
+                acc.append(e.clone())
+        assert zeros == 0, f"seed {seed}: {zeros} exactly-zero eps entries"
+        allv = torch.cat(acc).double()
+        assert abs(float(allv.mean())) < 0.01 and abs(float(allv.var()) - 1.0) < 0.02
+        assert float(allv.abs().max()) < 6.0
