@@ -401,8 +401,8 @@ def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
                 continue
             # a profile slot -> the kernels that can fill it (the fused / block / per-row / wave-cooperative paths)
             cands = {"enc_fwd": [["k_enc_fwd"]], "latent_dec1_fwd": [["k_fwd23"]],
-                     "latent_fwd": [["k_heads_comp"], ["k_latent_fwd", "k_duals_coop"], ["k_latent_fwd"]],
-                     "dec1_fwd": [["k_fwd3m"], ["k_dec1_fwd"]], "dec1_bwd": [["k_dec1_bwd"]],
+                     "latent_fwd": [["k_heads_comp"], ["k_latent_fwd"]],
+                     "dec1_fwd": [["k_fwd3m"], ["k_dec1_fwd_duals"], ["k_dec1_fwd"]], "dec1_bwd": [["k_dec1_bwd"]],
                      "latent_bwd": [["k_latent_bwd_blk"], ["k_latent_bwd"]],
                      "enc_bwd": [["k_enc_bwd3"], ["k_enc_bwd"]],
                      "latent_enc_bwd": [["k_bwd56"]]}

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
   // therefore runs HERE, on waves 4..7, next to the primal lanes of waves 0..3 (wave 4+w takes the components placed
   // on wave w), instead of on the critical path of launch 5, which only contracts the stored records with dz.
   // Record layout: duals[row][first_dir(ci) + dir][{d kl, d z_0 .. d z_{A-1}}].
-  if (COOP && tid >= 256) return;  // large components: the records come from k_duals_coop (one WAVE per (row, direction))
+  if (COOP && tid >= 256) return;  // large components: the records come from job_duals_coop (one WAVE per (row, direction), launch 3)
   if (!COOP && tid >= 256) {
     // as many barriers as the main path executes up to "heads_s final": 2 in the prologue, then 2 (register-resident
     // path) or 2 per round of the generic heads contraction + 1
@@ -633,10 +633,20 @@ __global__ __launch_bounds__(512) void k_latent_fwd(CompTable t, const float* h,
 // ---- forward-mode dual records of LARGE components: one WAVE per (row, active input direction) evaluates the component
 // over dual numbers in the lane-distributed form of mvae_coop.hpp and writes {d kl, d z_0 .. d z_{A-1}} -- what the dual
 // waves of k_latent_fwd produce with one lane per record, whose 41-entry vectors (h40) live in scratch memory there.
-__global__ __launch_bounds__(512) void k_duals_coop(CompTable t, const float* heads, int ldh, const float* eps, int eps_ld,
-                                                    const float* radii, float* duals, int NH, int DS, int ngroups) {
+// They have no consumer before launch 5, so they ride as extra workgroups BEHIND the tiles of launch 3 (k_dec1_fwd_duals):
+// one launch less (h40: 64.8 -> 61.3 us per step).  The records are throughput-bound (10 368 waves for h40, 13.8 us of the
+// whole chip): spreading them over launches 3 and 4 hides nothing (50 / 50: 62.7 us, 35 / 65: 61.7).
+struct CoopDualArgs {
+  const float* heads;
+  const float* eps;
+  const float* radii;
+  float* duals;
+  int ldh, eps_ld, NH, DS, ngroups, n_tile_wg;
+};
+__device__ __forceinline__ void job_duals_coop(const CompTable& t, const float* heads, int ldh, const float* eps, int eps_ld,
+                                               const float* radii, float* duals, int NH, int DS, int ngroups, int wg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = (int)blockIdx.x / ngroups, grp = (int)blockIdx.x - row * ngroups;
+  const int row = wg / ngroups, grp = wg - row * ngroups;
   const int gd = __builtin_amdgcn_readfirstlane(grp * 8 + wave);
   if (gd >= t.total_dirs) return;
   int ci = 0;
@@ -1161,9 +1171,9 @@ __device__ __forceinline__ void job_duals(const CompTable& t, const float* heads
 
 // ---- 3: output layer + BCE-with-logits + its gradient (512 threads)
 template <bool FULL>
-__global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
-                                                  float* g, float* bce_part, float* logits_user, int B, int H, int D) {
-  __shared__ float red[kW8][16][17];
+__device__ __forceinline__ void job_dec1_fwd_tile(float (*red)[16][17], const float* hd, const float* W, const float* b,
+                                                  const float* x, float* g, float* bce_part, float* logits_user, int B, int H,
+                                                  int D) {
   const int wave = threadIdx.x >> 6;
   int mt, nt;
   MV_SPAN_BEGIN(2);
@@ -1202,6 +1212,28 @@ __global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* 
   if ((threadIdx.x & 15) == 0 && m < B) bce_part[(size_t)nt * B + m] = loss;
   MV_TFLUSH(20, 4, 96);
   MV_SPAN_END(2, 1);
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(512) void k_dec1_fwd(const float* hd, const float* W, const float* b, const float* x,
+                                                  float* g, float* bce_part, float* logits_user, int B, int H, int D) {
+  __shared__ float red[kW8][16][17];
+  job_dec1_fwd_tile<FULL>(red, hd, W, b, x, g, bce_part, logits_user, B, H, D);
+}
+
+// Large components on the wave-cooperative kernels: the workgroups PAST the tiles compute the forward-mode dual records
+// (job_duals_coop) -- dispatched after the tiles, which are the short job with a consumer in the next launch.
+template <bool FULL>
+__global__ __launch_bounds__(512) void k_dec1_fwd_duals(const float* hd, const float* W, const float* b, const float* x,
+                                                        float* g, float* bce_part, float* logits_user, int B, int H, int D,
+                                                        CompTable t, CoopDualArgs cd) {
+  __shared__ float red[kW8][16][17];
+  if ((int)blockIdx.x >= cd.n_tile_wg) {
+    job_duals_coop(t, cd.heads, cd.ldh, cd.eps, cd.eps_ld, cd.radii, cd.duals, cd.NH, cd.DS, cd.ngroups,
+                   (int)blockIdx.x - cd.n_tile_wg);
+    return;
+  }
+  job_dec1_fwd_tile<FULL>(red, hd, W, b, x, g, bce_part, logits_user, B, H, D);
 }
 
 // ---- 4: dhd = (g W_logits) * [hd > 0] ; db_logits (+Adam) ; step statistics   (512 threads)
@@ -1395,6 +1427,7 @@ __global__ __launch_bounds__(512) void k_dec1_bwd(CompTable t, const float* g, c
   // share a CU, which costs a tile workgroup little when the other one is short, but made the statistics workgroup the
   // tail of the launch when it came last.
   int b = blockIdx.x;
+
   const int ntH = (H + 15) / 16, ntD = (D + 15) / 16;
   const int n_dual = DUAL > 0 ? da.n_dual : 0;
   const int n_short = (n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
@@ -2869,14 +2902,9 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   {
     ki = 1;
     const size_t lds = (((size_t)H + 3) & ~(size_t)3) * sizeof(float) + ((size_t)d.eps_dim + 4) * sizeof(float);
-    // large components (d >= 9; h, s, e only): the components of launch 2 one WAVE each, the dual records by one more
-    // launch of one wave per (row, direction) -- instead of one lane each over scratch-resident vectors
+    // large components (d >= 9): the components of launch 2 one WAVE each, the dual records one wave per (row, direction) as
+    // extra workgroups of launch 3 -- instead of one lane each over scratch-resident vectors
     const bool coop = c->coop;
-    hipEvent_t ev_stop = nullptr;
-    if (coop && ev) {  // one profile slot for the two launches: start event on the first, stop event on the second
-      ev_stop = ev[2 * ki + 1];
-      ev[2 * ki + 1] = nullptr;
-    }
 #define LF(DM, FA, CO)                                                                                               \
   STEP_LAUNCH((k_latent_fwd<DM, FA, CO>), dim3(B), dim3(CO ? 256 : 512), lds, c->t, h, P + d.off_w_heads,            \
                      P + d.off_b_heads, eps, d.eps_dim, P + d.off_radii, P + d.off_w_d0, P + d.off_b_d0, heads,      \
@@ -2884,25 +2912,25 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (coop) { if (fast) LF(2, true, true); else LF(2, false, true); }
     else if (fast) { DMAX_SWITCH(c->dmax, LF(DM, true, false)); } else { DMAX_SWITCH(c->dmax, LF(DM, false, false)); }
 #undef LF
-    if (coop) {
-      const int ngroups = (c->t.total_dirs + 7) / 8;
-      const int DSr = dual_stride(bucket_of(c->dmax));
-      if (ev) {
-        ev[2 * ki + 1] = ev_stop;
-        hipExtLaunchKernelGGL(k_duals_coop, dim3(B * ngroups), dim3(512), 0, s, nullptr, ev_stop, 0, c->t, heads, c->ldh,
-                              eps, d.eps_dim, P + d.off_radii, duals, NH, DSr, ngroups);
-      } else {
-        hipLaunchKernelGGL(k_duals_coop, dim3(B * ngroups), dim3(512), 0, s, c->t, heads, c->ldh, eps, d.eps_dim,
-                           P + d.off_radii, duals, NH, DSr, ngroups);
-      }
-    }
   }
   ki = 2;
-  if (full)
-    STEP_LAUNCH(k_dec1_fwd<true>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+  const int n_tile3 = 8 * ((c->nt_d + 7) / 8) * c->nt_b;
+  if (c->coop) {
+    // the dual records of the large components (one wave per (row, direction)) as extra workgroups behind launch 3's tiles
+    const int ngroups = (c->t.total_dirs + 7) / 8;
+    const CoopDualArgs cd = {heads, eps, P + d.off_radii, duals, c->ldh, d.eps_dim, NH, dual_stride(bucket_of(c->dmax)), ngroups,
+                             n_tile3};
+    if (full)
+      STEP_LAUNCH(k_dec1_fwd_duals<true>, dim3(n_tile3 + B * ngroups), dim3(512), 0, hd, P + d.off_w_logits,
+                  P + d.off_b_logits, x, g, bce_part, logits, B, H, D, c->t, cd);
+    else
+      STEP_LAUNCH(k_dec1_fwd_duals<false>, dim3(n_tile3 + B * ngroups), dim3(512), 0, hd, P + d.off_w_logits,
+                  P + d.off_b_logits, x, g, bce_part, logits, B, H, D, c->t, cd);
+  } else if (full)
+    STEP_LAUNCH(k_dec1_fwd<true>, dim3(n_tile3), dim3(512), 0, hd, P + d.off_w_logits,
                 P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
   else
-    STEP_LAUNCH(k_dec1_fwd<false>, dim3(8 * ((c->nt_d + 7) / 8) * c->nt_b), dim3(512), 0, hd, P + d.off_w_logits,
+    STEP_LAUNCH(k_dec1_fwd<false>, dim3(n_tile3), dim3(512), 0, hd, P + d.off_w_logits,
                 P + d.off_b_logits, x, g, bce_part, logits, B, H, D);
   }
   {
