@@ -674,9 +674,18 @@ void mvae_peer_destroy(mvae_peer* peer);
 int mvae_peer_export(mvae_peer* peer, uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
 int mvae_peer_import(mvae_peer* peer, int peer_rank, const uint8_t handle[MVAE_IPC_HANDLE_BYTES]);
 int mvae_peer_publish(mvae_peer* peer, const float* grads, void* stream);
-/* on != 0: two-shot form (before the first publish; the same on every rank).  publish then also adds the rank's OWN 1/world
- * slice of every slot (rank order) in place and raises a second flag; the optimizer launch reads slice j from rank j.
- * Same sums, same bits as the one-shot form; per xGMI link and step 2 n / world floats instead of n. */
+/* The form of the exchange (before the first publish; the same on every rank; anything else: MVAE_E_BADARG).
+ * on = 0: one-shot (above).
+ * on = 1: two-shot.  publish then also adds the rank's OWN 1/world slice of every slot (rank order) in place and raises a
+ *   second flag; the optimizer launch reads slice j from rank j.  Same sums, same bits as the one-shot form; per xGMI link
+ *   and step 2 n / world floats instead of n.
+ * on = 2: SHARDED OPTIMIZER on the same two rounds.  mvae_step_optimizer_peer becomes three launches: rank r adds slice r of
+ *   every slot (rank order), applies Adam to that slice with ITS slice of m and v (rank 0: clip + SGD of the radii, which
+ *   live in slice 0) and writes the new parameters to `params` and into its slot; second flag round; every rank copies the
+ *   other slices of the PARAMETERS out of their owners' slots.  Same parameters, bit for bit, as the other forms; the
+ *   optimizer's reads and writes per rank shrink with the world size.  `grads` then holds the summed gradient on the owner's
+ *   slice only, and adam_m / adam_v are valid on the owner only (slice r = floats [4 r s4, 4 (r + 1) s4),
+ *   s4 = max(16, ceil(n_params / 4 / world))). */
 int mvae_peer_set_two_shot(mvae_peer* peer, int on);
 int mvae_step_optimizer_peer(mvae_ctx* ctx, mvae_peer* peer, int do_curvature_step, void* stream);
 int mvae_peer_timeouts(mvae_peer* peer);

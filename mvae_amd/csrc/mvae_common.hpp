@@ -101,8 +101,12 @@ struct mvae_peer {
   int shm_fd = -1;
   char shm_name[128] = {};
   unsigned long long timeout_ticks = 0;      // wall_clock64 ticks (100 MHz) a rank waits for a peer before giving up
-  bool two_shot = false;                     // reduce-scatter + all-gather by direct reads instead of the one-shot sum
+  int mode = 0;  // 0: one-shot sum in the optimizer launch; 1: two-shot (reduce-scatter + all-gather of GRADIENTS by direct
+                 // reads); 2: sharded optimizer (reduce-scatter + Adam on the owned slice + all-gather of PARAMETERS)
 };
+// (mvae_peer.hip) sharded form, after the owner's optimizer launch: raise the second flag, wait for every peer's, copy
+// every other rank's slice of the updated parameters out of its slot
+int peer_gather_params(mvae_peer* p, float* params, hipStream_t s);
 
 // float4 per owned slice of the two-shot exchange (the radii region, 16 float4, stays inside slice 0)
 inline long long peer_slice4(const mvae_peer* p) {

@@ -174,7 +174,7 @@ extern "C" int mvae_peer_publish(mvae_peer* p, const float* grads, void* stream)
                      reinterpret_cast<float4*>(p->slots), n4, p->seq);
   hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, s, p->seq, p->flags_dev, p->world, p->rank,
                      p->timeout_ticks, 0);
-  if (p->two_shot) {
+  if (p->mode == 1) {
     PeerSrc ps{};
     for (int r = 0; r < p->world; ++r) ps.slot[r] = p->peer_slots[r];
     ps.seq = p->seq;
@@ -190,9 +190,42 @@ extern "C" int mvae_peer_publish(mvae_peer* p, const float* grads, void* stream)
   return 0;
 }
 
+// Sharded form, all-gather of PARAMETERS: slice j of rank j's slot holds the parameters rank j's optimizer launch has just
+// written there (in place of the gradients it summed); every rank copies the slices it does not own into its own buffer.
+__global__ __launch_bounds__(256) void k_peer_gather(PeerSrc ps, float* params, int rank) {
+  const size_t off4 = (size_t)(ps.seq[0] & 1) * (size_t)(ps.n / 4);
+  const long long n4 = ps.n / 4;
+  const long long lo = (long long)rank * ps.slice4, hi = lo + ps.slice4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    if (i >= lo && i < hi) continue;  // the owned slice: written by this rank's optimizer launch
+    int owner = (int)(i / ps.slice4);
+    owner = owner < ps.world ? owner : ps.world - 1;
+    reinterpret_cast<float4*>(params)[i] = reinterpret_cast<const float4*>(ps.slot[owner])[off4 + i];
+  }
+}
+
+int peer_gather_params(mvae_peer* p, float* params, hipStream_t s) {
+  hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, s, p->seq, p->flags_dev, p->world, p->rank, p->timeout_ticks, 1);
+  if (p->world > 1) {
+    PeerSrc ps{};
+    for (int r = 0; r < p->world; ++r) ps.slot[r] = p->peer_slots[r];
+    ps.seq = p->seq;
+    ps.n = p->n;
+    ps.world = p->world;
+    ps.slice4 = peer_slice4(p);
+    const long long n4 = p->n / 4;
+    const int gb = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_peer_gather, dim3(gb), dim3(256), 0, s, ps, params, p->rank);
+  }
+  LAUNCH_CHECK("peer parameter gather");
+  return 0;
+}
+
 extern "C" int mvae_peer_set_two_shot(mvae_peer* p, int on) {
   if (!p) return fail(MVAE_E_BADARG, "null pointer%s", "");
-  p->two_shot = on != 0;
+  if (on < 0 || on > 2) return fail(MVAE_E_BADARG, "exchange form must be 0 (one-shot), 1 (two-shot) or 2 (sharded optimizer)%s", "");
+  p->mode = on;
   return 0;
 }
 

@@ -2739,6 +2739,98 @@ __global__ __launch_bounds__(256) void k_optim(CompTable t, float* p, float* g, 
   }
 }
 
+// ---- 7', sharded form of the peer exchange (mvae_peer mode 2): the optimizer shrinks with the world size.  Rank r owns slice
+// r of the flat buffer: it adds that slice of EVERY rank's published gradients (rank order: the same sum, bit for bit, as
+// the other peer forms and -- at world 2 -- as an all-reduce), applies Adam with ITS slice of m and v, and writes the new
+// parameters both to its own buffer and INTO its slot, in place of the gradients it has just read (the only reader of slice
+// r of rank r's slot in this phase is rank r).  After the second flag round every rank copies the other slices out of
+// their owners' slots (k_peer_gather): the same bytes over the links as the two-shot form, 1 / world of the optimizer's
+// reads and writes, and no pass over the whole buffer on any rank.  Adam's moments are valid on the owner only.
+// Rank 0's slice holds the radii region: clip + SGD there as in k_optim, the region travels with slice 0.
+__global__ __launch_bounds__(256) void k_optim_shard(CompTable t, float* p, float* g, float* m, float* v, int n4,
+                                                     int* counters, double lr, double curv_lr, int do_curv, PeerSrc ps,
+                                                     int rank, float* own_slots) {
+  __shared__ float sh[2];
+  __shared__ float gsh[kMaxComp];
+  const int tid = threadIdx.x;
+  adam_consts(sh, counters, lr, 1);
+  const size_t slot_off = (size_t)(ps.seq[0] & 1) * (size_t)ps.n;
+  const bool radii_owner = rank == 0 && blockIdx.x == 0;
+  if (radii_owner && tid < t.n) {
+    float gv = ps.slot[0][slot_off + tid];
+    for (int r = 1; r < ps.world; ++r) gv += ps.slot[r][slot_off + tid];
+    g[tid] = gv;
+    gsh[tid] = gv;
+  }
+  __syncthreads();
+  const float neg_step = sh[0], bc2s = sh[1];
+  const long long lo4 = (long long)rank * ps.slice4 + (rank == 0 ? kRadiiRegion / 4 : 0);
+  long long hi4 = (long long)(rank + 1) * ps.slice4;
+  hi4 = hi4 < n4 ? hi4 : n4;
+  float4 pp[kOptU], gg[kOptU], mm[kOptU], vv[kOptU];
+  long long i4s[kOptU];
+#pragma unroll
+  for (int u = 0; u < kOptU; ++u) {
+    const long long i4 = lo4 + ((long long)u * gridDim.x + blockIdx.x) * 256 + tid;
+    i4s[u] = i4;
+    const long long ic = i4 < hi4 ? i4 : kRadiiRegion / 4;  // clamped request, masked at the store
+    pp[u] = reinterpret_cast<float4*>(p)[ic];
+    gg[u] = reinterpret_cast<const float4*>(ps.slot[0] + slot_off)[ic];
+    for (int r = 1; r < ps.world; ++r) {
+      const float4 o = reinterpret_cast<const float4*>(ps.slot[r] + slot_off)[ic];
+      gg[u].x += o.x;
+      gg[u].y += o.y;
+      gg[u].z += o.z;
+      gg[u].w += o.w;
+    }
+    mm[u] = reinterpret_cast<float4*>(m)[ic];
+    vv[u] = reinterpret_cast<float4*>(v)[ic];
+  }
+#pragma unroll
+  for (int u = 0; u < kOptU; ++u) {
+    const long long i4 = i4s[u];
+    if (i4 >= hi4) continue;
+    store16_wt(g, (size_t)i4 * 4, f32x4{gg[u].x, gg[u].y, gg[u].z, gg[u].w});  // the summed gradient, on its owner
+    adam1(pp[u].x, gg[u].x, mm[u].x, vv[u].x, neg_step, bc2s);
+    adam1(pp[u].y, gg[u].y, mm[u].y, vv[u].y, neg_step, bc2s);
+    adam1(pp[u].z, gg[u].z, mm[u].z, vv[u].z, neg_step, bc2s);
+    adam1(pp[u].w, gg[u].w, mm[u].w, vv[u].w, neg_step, bc2s);
+    const f32x4 pn{pp[u].x, pp[u].y, pp[u].z, pp[u].w};
+    store16_wt(p, (size_t)i4 * 4, pn);
+    store16_wt(own_slots + slot_off, (size_t)i4 * 4, pn);  // what the peers gather
+    store16_wt(m, (size_t)i4 * 4, f32x4{mm[u].x, mm[u].y, mm[u].z, mm[u].w});
+    store16_wt(v, (size_t)i4 * 4, f32x4{vv[u].x, vv[u].y, vv[u].z, vv[u].w});
+  }
+  if (radii_owner && tid < kRadiiRegion) {
+    float pv = p[tid];
+    if (tid < t.n && t.trainable[tid]) {
+      float gv = gsh[tid];
+      if (t.trainable[tid] & 2) {  // universal curvature: clipped after the reduction
+        gv *= clip_coef(t, gsh);
+        g[tid] = gv;
+      }
+      if (do_curv & 1) {
+        pv = pv + (float)(-curv_lr) * gv;  // SGD: param.add_(grad, alpha=-lr)
+        p[tid] = pv;
+      }
+    }
+    own_slots[slot_off + tid] = pv;  // the whole radii region travels with slice 0
+  }
+  if (tid == 0) {  // the last workgroup to arrive advances the step counter (as in k_optim)
+    constexpr int NG = 16;
+    const int grp = blockIdx.x % NG;
+    const int gsize = ((int)gridDim.x - grp + NG - 1) / NG;
+    if (atomicAdd(&counters[16 + grp], 1) == gsize - 1) {
+      counters[16 + grp] = 0;
+      const int ngroups = (int)gridDim.x < NG ? (int)gridDim.x : NG;
+      if (atomicAdd(&counters[1], 1) == ngroups - 1) {
+        counters[1] = 0;
+        counters[0] = counters[0] + 1;
+      }
+    }
+  }
+}
+
 // Which latent kernels the step takes (see MVAE_PATH_* in the header)
 static int latent_path(const mvae_ctx* c, bool x_aligned) {
   const mvae_model_desc& d = c->d;
@@ -3103,8 +3195,18 @@ extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_cur
   ps.seq = peer->seq;
   ps.n = peer->n;
   ps.world = peer->world;
-  ps.slice4 = peer->two_shot ? peer_slice4(peer) : 0;
+  ps.slice4 = peer->mode ? peer_slice4(peer) : 0;
   const int n4 = d.n_params / 4;
+  if (peer->mode == 2) {  // sharded optimizer: Adam on the owned slice, then the all-gather of parameters
+    const long long s4 = ps.slice4;
+    int sb = (int)((s4 + 256 * kOptU - 1) / (256 * kOptU));
+    sb = sb < 1 ? 1 : sb;
+    hipLaunchKernelGGL(k_optim_shard, dim3(sb), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
+                       d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, ps,
+                       peer->rank, peer->slots);
+    LAUNCH_CHECK("sharded peer optimizer launch");
+    return peer_gather_params(peer, d.params, (hipStream_t)stream);
+  }
   const int blocks = optim_blocks(n4);
   hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
                      d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, ps);

@@ -98,7 +98,9 @@ class DataParallelStep:
         torch.distributed's all_reduce (what an engine without a HIP device gets: the gloo tests on CPU); "peer" -- the
         one-shot peer-read reduction of mvae_amd/peer.py, fused into the optimizer launch, ranks of ONE node only;
         "peer2": its two-shot form (each rank reduces 1/world of the buffer, the optimizer reads every slice from its
-        owner)."""
+        owner); "peer3": the SHARDED optimizer on the same two rounds (each rank reduces its 1/world slice, applies Adam to
+        it, and the ranks gather the updated PARAMETERS: no pass over the whole buffer on any rank; Adam's moments live on
+        the slice's owner -- `gather_optimizer_state()`)."""
         import os
         self.engine = engine
         self.group = group
@@ -110,17 +112,17 @@ class DataParallelStep:
         one_device = _env_on("MVAE_DIST_ONE_DEVICE") or _env_on("MVAE_BENCH_ONE_DEVICE")
         self.exchange = exchange or os.environ.get("MVAE_DP_EXCHANGE", "") or \
             ("rccl" if (on_hip and not one_device) else "allreduce")
-        if self.exchange not in ("allreduce", "rccl", "peer", "peer2"):
+        if self.exchange not in ("allreduce", "rccl", "peer", "peer2", "peer3"):
             raise ValueError(f"unknown gradient exchange {self.exchange!r}")
         self.peer = None
         self.rccl = None
         active = self.world > 1 or self.always_exchange
-        if self.exchange in ("peer", "peer2") and active:
+        if self.exchange in ("peer", "peer2", "peer3") and active:
             if not hasattr(engine, "_context"):
                 raise ValueError("the peer-read exchange is fused into the MLP step's optimizer launch (StepEngine); "
                                  "other engines (ConvEngine) exchange through 'rccl' or 'allreduce'")
             from .peer import PeerExchange
-            self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2")
+            self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2", sharded=self.exchange == "peer3")
         self.exchange_note = ""   # why a route other than the requested one is in use (bench.py: config.exchange)
         self._fallback_group = None
         if self.exchange == "rccl" and active:
@@ -212,6 +214,29 @@ class DataParallelStep:
         else:
             dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
+
+    def owned_slice(self) -> Tuple[int, int]:
+        """[lo, hi) in floats of the flat buffers whose Adam moments THIS rank holds on the sharded route ("peer3"); the whole
+        buffer on every other route."""
+        n = int(self.engine.params.numel())
+        if self.peer is None or not getattr(self.peer, "sharded", False):
+            return 0, n
+        s4 = max(16, (n // 4 + self.world - 1) // self.world)  # peer_slice4 (csrc/mvae_common.hpp)
+        return min(n, 4 * s4 * self.rank), min(n, 4 * s4 * (self.rank + 1))
+
+    def gather_optimizer_state(self) -> None:
+        """Sharded route only: make adam_m / adam_v whole on every rank (each slice broadcast by its owner) -- before a
+        checkpoint of the optimizer state, or before switching to another route.  A no-op elsewhere."""
+        if self.peer is None or not getattr(self.peer, "sharded", False) or self.world == 1:
+            return
+        n = int(self.engine.params.numel())
+        s4 = max(16, (n // 4 + self.world - 1) // self.world)
+        for r in range(self.world):
+            lo, hi = min(n, 4 * s4 * r), min(n, 4 * s4 * (r + 1))
+            if hi > lo:
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                for t in (self.engine.adam_m, self.engine.adam_v):
+                    dist.broadcast(t[lo:hi], src=src, group=self.group)
 
     def reduce_stats(self) -> Tensor:
         """Global sums of the running statistics (one small all-reduce, when the host wants to log)."""

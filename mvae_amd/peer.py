@@ -24,9 +24,13 @@ IPC_HANDLE_BYTES = 64
 class PeerExchange:
 
     def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, timeout_seconds: float = 2.0,
-                 two_shot: bool = False) -> None:
+                 two_shot: bool = False, sharded: bool = False) -> None:
         """two_shot: every rank first reduces its own 1/world slice of all slots, the optimizer launch then reads each
-        slice from its owner (2 n / world floats per link and step instead of n; one more flag round per step)."""
+        slice from its owner (2 n / world floats per link and step instead of n; one more flag round per step).
+        sharded: the optimizer itself is sharded -- rank r sums slice r of every slot, applies Adam to it with ITS slice of
+        the moments (radii: rank 0), leaves the new parameters in its slot, and every rank gathers the other slices from their
+        owners: the two-shot form's bytes, 1 / world of the optimizer pass per rank.  Adam's m and v are then valid on the
+        owner only (`DataParallelStep.gather_optimizer_state()` before they are read as a whole)."""
         self.engine = engine
         # MVAE_PEER_TIMEOUT=<seconds>: the bound of a wait for a peer's flag.  Ranks that SHARE a device (the one-device
         # rehearsals of the node layout) are time-sliced: a spinning wait holds the GPU while its peer cannot run, and the
@@ -43,7 +47,8 @@ class PeerExchange:
         with torch.cuda.device(engine.device):
             check(load().mvae_peer_create(int(engine.grads.numel()), self.world, self.rank, name[0].encode(),
                                           float(timeout_seconds), C.byref(self._h)))
-            check(load().mvae_peer_set_two_shot(self._h, 1 if two_shot else 0))
+            check(load().mvae_peer_set_two_shot(self._h, 2 if sharded else (1 if two_shot else 0)))
+            self.sharded = bool(sharded)
             mine = (C.c_uint8 * IPC_HANDLE_BYTES)()
             check(load().mvae_peer_export(self._h, mine))
             handles = [None] * self.world
@@ -63,7 +68,8 @@ class PeerExchange:
         check(load().mvae_peer_publish(self._h, ptr(self.engine.grads), stream_ptr(self.engine.device)))
 
     def optimizer_step(self, do_curvature_step: bool, batch: Optional[int] = None) -> None:
-        """mvae_step_optimizer with g := sum over ranks of the published slots (rank order), also written to .grads."""
+        """mvae_step_optimizer with g := sum over ranks of the published slots (rank order), also written to .grads (sharded
+        form: on the owner's slice only)."""
         eng = self.engine
         if batch is None:
             batch = eng._last_batch if eng._last_batch is not None else (next(iter(eng._ctx)) if eng._ctx else 1)

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None, env=None):
+def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None, env=None, moments=False):
     import torch.distributed as dist
     os.environ.update(env or {})
     from mvae_amd import synthetic
@@ -63,7 +63,15 @@ def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cy
     torch.cuda.synchronize()
     total = dp.reduce_stats().cpu().numpy().copy()
     timeouts = dp.peer.timeouts() if dp.peer is not None else 0
-    q.put((rank, eng.params.cpu().numpy().copy(), total, timeouts, (dp.exchange, dp.exchange_note, dp.capturable)))
+    extra = None
+    if moments:  # Adam's moments: what the rank holds after the step, and after the sharded route's gather
+        lo_o, hi_o = dp.owned_slice()
+        own_m = eng.adam_m.cpu().numpy().copy()
+        dp.gather_optimizer_state()
+        torch.cuda.synchronize()
+        extra = ((lo_o, hi_o), own_m, eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy(),
+                 eng.grads.cpu().numpy().copy())
+    q.put((rank, eng.params.cpu().numpy().copy(), total, timeouts, (dp.exchange, dp.exchange_note, dp.capturable), extra))
     dist.barrier()
     if dp.peer is not None:
         dp.peer.close()
@@ -211,7 +219,8 @@ def _run_ranks(steps, world, **kw):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph_steps,exchange", [(0, "peer"), (3, "peer"), (0, "peer2"), (3, "peer2")])
+@pytest.mark.parametrize("graph_steps,exchange", [(0, "peer"), (3, "peer"), (0, "peer2"), (3, "peer2"), (0, "peer3"),
+                                                  (3, "peer3")])
 def test_peer_read_exchange_two_processes_one_device(graph_steps, exchange):
     """The one-shot peer-read reduction (mvae_peer_*: hipIpc-mapped gradient slots, host-coherent flags, the sum fused into
     the optimizer launch) with two PROCESSES sharing cuda:0: no wait times out, the ranks end bit-identical, and the result
@@ -220,7 +229,8 @@ def test_peer_read_exchange_two_processes_one_device(graph_steps, exchange):
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     steps, world = 6, 2
-    peer = _run_ranks(steps, world, exchange=exchange, graph_steps=graph_steps)  # "peer2": the two-shot form
+    # "peer2": the two-shot form; "peer3": the sharded optimizer (Adam on the owned slice, all-gather of parameters)
+    peer = _run_ranks(steps, world, exchange=exchange, graph_steps=graph_steps)
     assert peer[0][3] == 0 and peer[1][3] == 0, "a rank gave up waiting for its peer"
     assert np.array_equal(peer[0][1], peer[1][1]), "ranks diverged"
     ref = _run_ranks(steps, world, exchange="allreduce", cycle=graph_steps or None)  # a replay repeats its batches
@@ -253,7 +263,7 @@ def test_rccl_init_failure_falls_back_together(fake):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange", ["peer", "peer2"])
+@pytest.mark.parametrize("exchange", ["peer", "peer2", "peer3"])
 def test_peer_exchange_eight_processes_one_device(exchange):
     """The node-sized case, rehearsed on one device: EIGHT processes (the `--gpus 8` layout: one process per rank, hipIpc
     mappings and flags among 8 ranks, slots reused every second publish, 16 rows per rank) through HIP-graph replays: no
@@ -277,6 +287,38 @@ def test_peer_exchange_eight_processes_one_device(exchange):
         eng.train_step(xs[s % 3], eps[s % 3], 1.0, True)  # a replay repeats its three batches
     assert_close_after_adam(res[0][1], eng.params.cpu().numpy(), 1e-3, steps, "flat parameters, dp8 vs single process")
     np.testing.assert_allclose(res[0][2][:3], eng.stats.cpu().numpy()[:3], rtol=2e-4)
+
+
+@pytest.mark.timeout(900)
+def test_sharded_optimizer_moments_live_on_the_owner_and_gather_whole():
+    """The sharded peer route ("peer3": reduce-scatter -> Adam on the rank's own 1/world slice -> all-gather of PARAMETERS),
+    four processes on one device: the parameters equal the two-shot route's bit for bit (same rank-order sums, same Adam);
+    each rank's Adam moments moved on ITS slice only (elsewhere they are still the zeros of the start); after
+    `gather_optimizer_state()` every rank holds the moments the replicated optimizer of the two-shot route computed, bit for
+    bit; and the summed gradient is in `grads` on the owner's slice."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    steps, world = 4, 4
+    env = {"MVAE_PEER_TIMEOUT": "20"}
+    sh = _run_ranks(steps, world, exchange="peer3", env=env, moments=True)
+    ref = _run_ranks(steps, world, exchange="peer2", env=env, moments=True)
+    assert all(r[3] == 0 for r in sh + ref), "a rank gave up waiting for a peer"
+    n = sh[0][1].size
+    covered = np.zeros(n, dtype=bool)
+    for r in sh:
+        assert np.array_equal(r[1], ref[0][1]), f"rank {r[0]}: sharded parameters differ from the two-shot route's"
+        (lo, hi), own_m, m, v, g = r[5]
+        assert 0 <= lo <= hi <= n and not covered[lo:hi].any()
+        covered[lo:hi] = True
+        assert np.array_equal(own_m[lo:hi], ref[0][5][2][lo:hi]), "the owner's moments differ from the replicated optimizer's"
+        outside = np.ones(n, dtype=bool)
+        outside[lo:hi] = False
+        assert not own_m[outside].any(), "a rank moved moments outside its slice"
+        assert np.array_equal(m, ref[0][5][2]) and np.array_equal(v, ref[0][5][3]), "gathered moments differ"
+        lo_g = max(lo, 64)  # (the radii region of `grads` holds the clipped radius gradients on rank 0)
+        assert np.array_equal(g[lo_g:hi], ref[0][5][4][lo_g:hi]), "summed gradient on the owner's slice"
+    assert covered.all(), "the slices do not cover the buffer"
+    assert np.abs(ref[0][5][2]).max() > 0
 
 
 @pytest.mark.timeout(900)
