@@ -812,7 +812,8 @@ def main():
                                "MLP h_dim=400, " + ("global batch 128 split by rows" if strong else "batch 128 per GPU") +
                                ", epoch>=10 state",
                    "global_batch": B if strong else B * world, "parallelism": f"dp{world}" + ("(forced exchange)" if args.force_dp else ""),
-                   "exchange": ((runner.dp.exchange + (f" ({runner.dp.exchange_note})" if runner.dp.exchange_note else ""))
+                   "exchange": ((runner.dp.exchange + (" + sharded optimizer" if getattr(runner.dp, "shard", False) else "") +
+                                 (f" ({runner.dp.exchange_note})" if runner.dp.exchange_note else ""))
                                 if runner.dp is not None else "none (fused optimizer epilogues)"),
                    "ranks_identical": ranks_identical, "peer_timeouts": peer_timeouts,
                    "graph_steps": runner.gs,

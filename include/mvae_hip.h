@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 11
+#define MVAE_ABI_VERSION 12
 
 /* Manifold kinds = the letters of the model-string grammar (utils.py:30-38): e, h, s, p, d, u.
  * MVAE_PROJ_SPHERE: StereographicallyProjectedSphere (ops/spherical_projected.py).
@@ -689,6 +689,12 @@ int mvae_peer_publish(mvae_peer* peer, const float* grads, void* stream);
 int mvae_peer_set_two_shot(mvae_peer* peer, int on);
 int mvae_step_optimizer_peer(mvae_ctx* ctx, mvae_peer* peer, int do_curvature_step, void* stream);
 int mvae_peer_timeouts(mvae_peer* peer);
+/* The sharded optimizer for exchanges that leave the SUMMED gradient of the rank's slice in `grads` itself (an in-place
+ * reduce-scatter -- mvae_flat_reduce_scatter -- or a whole all-reduce): mvae_step_optimizer restricted to slice `rank` of
+ * `world` (float4 [rank s4, (rank + 1) s4), s4 = max(16, ceil(n_params / 4 / world)); the radii -- clip + SGD -- on rank 0,
+ * whose slice holds them).  The caller all-gathers `params` afterwards (mvae_flat_allgather); adam_m / adam_v are valid on
+ * the owner only.  Advances the step counter like mvae_step_optimizer.  New functionality. */
+int mvae_step_optimizer_slice(mvae_ctx* ctx, int rank, int world, int do_curvature_step, void* stream);
 
 /* ---- Flat all-reduce on librccl directly (data-parallel training; new functionality -- the reference is single-device,
  * SURVEY.md section 8b names this export).  One process per GPU; the SUM of the flat gradient buffer is the ONE exchange
@@ -708,6 +714,12 @@ int mvae_rccl_unique_id(uint8_t id[MVAE_RCCL_ID_BYTES]);
 int mvae_rccl_create(const uint8_t id[MVAE_RCCL_ID_BYTES], int rank, int world, mvae_rccl** out);
 void mvae_rccl_destroy(mvae_rccl* comm);
 int mvae_flat_allreduce(mvae_rccl* comm, float* buf, int64_t n, void* stream);
+/* The two halves of the all-reduce around mvae_step_optimizer_slice, both IN PLACE on the flat buffer: after the
+ * reduce-scatter rank r holds the sums of floats [r n / world, (r + 1) n / world) in that range of `buf` (the rest is
+ * unspecified); the all-gather hands every rank's range to everybody.  n % world != 0: MVAE_E_UNSUPPORTED (keep the
+ * replicated optimizer). */
+int mvae_flat_reduce_scatter(mvae_rccl* comm, float* buf, int64_t n, void* stream);
+int mvae_flat_allgather(mvae_rccl* comm, float* buf, int64_t n, void* stream);
 int mvae_flat_broadcast(mvae_rccl* comm, void* buf, int64_t n_words, int root, void* stream);
 int mvae_rccl_group(int begin);
 

@@ -10,4 +10,4 @@ Layers, bottom up:
 There is no CPU execution path: importing is free, running needs a HIP device and the built library.
 """
 __version__ = "0.1.0"
-ABI_VERSION = 10  # == MVAE_ABI_VERSION of include/mvae_hip.h, checked against the library at load time
+ABI_VERSION = 12  # == MVAE_ABI_VERSION of include/mvae_hip.h, checked against the library at load time

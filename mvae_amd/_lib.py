@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVAE_HIP_LIB") or os.path.join(HERE, "libmvae_hip.so")  # override: A/B builds
 
 EUCLIDEAN, HYPERBOLOID, SPHERE, POINCARE, PROJ_SPHERE, UNIVERSAL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 11
+ABI_VERSION = 12
 # return codes of the C ABI (include/mvae_hip.h)
 MVAE_OK, MVAE_E_BADARG, MVAE_E_UNSUPPORTED, MVAE_E_ALIGN, MVAE_E_SYSTEM = 0, -1, -2, -3, -4
 MAX_TRUE_DIM = 64
@@ -150,6 +150,7 @@ PROTOTYPES = {
     "mvae_peer_publish": (C.c_int, [_P, _P, _P]),
     "mvae_peer_set_two_shot": (C.c_int, [_P, _I]),
     "mvae_step_optimizer_peer": (C.c_int, [_P, _P, _I, _P]),
+    "mvae_step_optimizer_slice": (C.c_int, [_P, _I, _I, _I, _P]),
     "mvae_peer_timeouts": (C.c_int, [_P]),
     "mvae_step_profile": (C.c_int, [_P, _P, _P, _F, _I, _I, C.POINTER(C.c_float), _P]),
     "mvae_rccl_load": (C.c_int, [C.c_char_p]),
@@ -157,6 +158,8 @@ PROTOTYPES = {
     "mvae_rccl_create": (C.c_int, [C.POINTER(C.c_uint8), _I, _I, C.POINTER(C.c_void_p)]),
     "mvae_rccl_destroy": (None, [C.c_void_p]),
     "mvae_flat_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mvae_flat_reduce_scatter": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mvae_flat_allgather": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mvae_flat_broadcast": (C.c_int, [_P, _P, C.c_int64, _I, _P]),
     "mvae_rccl_group": (C.c_int, [_I]),
 }

@@ -29,6 +29,8 @@ struct RcclApi {
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -66,6 +68,8 @@ extern "C" int mvae_rccl_load(const char* path) {
   MV_SYM(CommAbort, "ncclCommAbort");
   MV_SYM(AllReduce, "ncclAllReduce");
   MV_SYM(Broadcast, "ncclBroadcast");
+  MV_SYM(ReduceScatter, "ncclReduceScatter");
+  MV_SYM(AllGather, "ncclAllGather");
   MV_SYM(GroupStart, "ncclGroupStart");
   MV_SYM(GroupEnd, "ncclGroupEnd");
   MV_SYM(GetErrorString, "ncclGetErrorString");
@@ -112,6 +116,30 @@ extern "C" int mvae_flat_allreduce(mvae_rccl* c, float* buf, int64_t n, void* st
   if (n == 0) return 0;
   ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
   if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+  return 0;
+}
+
+// The two halves of the all-reduce, for the SHARDED optimizer (mvae_step_optimizer_slice between them), both in place on the
+// flat buffer: after the reduce-scatter rank r holds the sums of floats [r n / world, (r + 1) n / world) in that range of
+// `buf` (the rest of `buf` is unspecified); the all-gather hands every rank's range of `buf` to everybody.  n must be a
+// multiple of the world size (MVAE_E_UNSUPPORTED otherwise: the caller keeps the replicated optimizer).
+extern "C" int mvae_flat_reduce_scatter(mvae_rccl* c, float* buf, int64_t n, void* stream) {
+  if (!c || !buf || n < 0) return fail(MVAE_E_BADARG, "null pointer / negative count%s", "");
+  if (n % c->world) return fail(MVAE_E_UNSUPPORTED, "reduce-scatter: the count must be a multiple of the world size%s", "");
+  if (n == 0) return 0;
+  const size_t cnt = (size_t)(n / c->world);
+  ncclResult_t r = g_rccl.ReduceScatter(buf, buf + (size_t)c->rank * cnt, cnt, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclReduceScatter");
+  return 0;
+}
+
+extern "C" int mvae_flat_allgather(mvae_rccl* c, float* buf, int64_t n, void* stream) {
+  if (!c || !buf || n < 0) return fail(MVAE_E_BADARG, "null pointer / negative count%s", "");
+  if (n % c->world) return fail(MVAE_E_UNSUPPORTED, "all-gather: the count must be a multiple of the world size%s", "");
+  if (n == 0) return 0;
+  const size_t cnt = (size_t)(n / c->world);
+  ncclResult_t r = g_rccl.AllGather(buf + (size_t)c->rank * cnt, buf, cnt, ncclFloat32, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
   return 0;
 }
 

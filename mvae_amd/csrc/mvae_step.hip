@@ -2754,7 +2754,7 @@ __global__ __launch_bounds__(256) void k_optim_shard(CompTable t, float* p, floa
   __shared__ float gsh[kMaxComp];
   const int tid = threadIdx.x;
   adam_consts(sh, counters, lr, 1);
-  const size_t slot_off = (size_t)(ps.seq[0] & 1) * (size_t)ps.n;
+  const size_t slot_off = ps.seq ? (size_t)(ps.seq[0] & 1) * (size_t)ps.n : 0;  // (no sequence word: one buffer, not a slot pair)
   const bool radii_owner = rank == 0 && blockIdx.x == 0;
   if (radii_owner && tid < t.n) {
     float gv = ps.slot[0][slot_off + tid];
@@ -2797,7 +2797,7 @@ __global__ __launch_bounds__(256) void k_optim_shard(CompTable t, float* p, floa
     adam1(pp[u].w, gg[u].w, mm[u].w, vv[u].w, neg_step, bc2s);
     const f32x4 pn{pp[u].x, pp[u].y, pp[u].z, pp[u].w};
     store16_wt(p, (size_t)i4 * 4, pn);
-    store16_wt(own_slots + slot_off, (size_t)i4 * 4, pn);  // what the peers gather
+    if (own_slots) store16_wt(own_slots + slot_off, (size_t)i4 * 4, pn);  // what the peers gather
     store16_wt(m, (size_t)i4 * 4, f32x4{mm[u].x, mm[u].y, mm[u].z, mm[u].w});
     store16_wt(v, (size_t)i4 * 4, f32x4{vv[u].x, vv[u].y, vv[u].z, vv[u].w});
   }
@@ -2814,7 +2814,7 @@ __global__ __launch_bounds__(256) void k_optim_shard(CompTable t, float* p, floa
         p[tid] = pv;
       }
     }
-    own_slots[slot_off + tid] = pv;  // the whole radii region travels with slice 0
+    if (own_slots) own_slots[slot_off + tid] = pv;  // the whole radii region travels with slice 0
   }
   if (tid == 0) {  // the last workgroup to arrive advances the step counter (as in k_optim)
     constexpr int NG = 16;
@@ -3211,6 +3211,30 @@ extern "C" int mvae_step_optimizer_peer(mvae_ctx* c, mvae_peer* peer, int do_cur
   hipLaunchKernelGGL(k_optim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m,
                      d.adam_v, n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, ps);
   LAUNCH_CHECK("peer optimizer launch");
+  return 0;
+}
+
+// The sharded optimizer for exchanges that leave the SUMMED gradient of the rank's slice in `grads` itself (a reduce-scatter in
+// place: mvae_flat_reduce_scatter, or a whole all-reduce): Adam on slice `rank` of `world` only, radii on rank 0; the caller
+// all-gathers `params` afterwards.  The slices are the peer route's: s4 = max(16, ceil(n_params / 4 / world)) float4 each.
+extern "C" int mvae_step_optimizer_slice(mvae_ctx* c, int rank, int world, int do_curvature_step, void* stream) {
+  if (!c) return fail(MVAE_E_BADARG, "null pointer%s", "");
+  if (world < 1 || rank < 0 || rank >= world) return fail(MVAE_E_BADARG, "rank must be in [0, world)%s", "");
+  const mvae_model_desc& d = c->d;
+  const int n4 = d.n_params / 4;
+  PeerSrc ps{};
+  ps.slot[0] = d.grads;
+  ps.seq = nullptr;
+  ps.n = d.n_params;
+  ps.world = 1;  // one source: the gradient is already summed
+  long long s4 = ((long long)n4 + world - 1) / world;
+  ps.slice4 = s4 < 16 ? 16 : s4;
+  int sb = (int)((ps.slice4 + 256 * kOptU - 1) / (256 * kOptU));
+  sb = sb < 1 ? 1 : sb;
+  hipLaunchKernelGGL(k_optim_shard, dim3(sb), dim3(256), 0, (hipStream_t)stream, c->t, d.params, d.grads, d.adam_m, d.adam_v,
+                     n4, d.step_count, (double)d.lr, (double)d.curvature_lr, do_curvature_step ? 1 : 0, ps, rank,
+                     (float*)nullptr);
+  LAUNCH_CHECK("sliced optimizer launch");
   return 0;
 }
 

@@ -89,7 +89,7 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 class DataParallelStep:
 
     def __init__(self, engine, group: Optional[dist.ProcessGroup] = None, always_exchange: bool = False,
-                 exchange: Optional[str] = None) -> None:
+                 exchange: Optional[str] = None, shard_optimizer: Optional[bool] = None) -> None:
         """always_exchange: take the gradients -> all-reduce -> optimizer route even at world size 1 (a diagnostic: it
         exercises the collective, its graph capture and k_optim on a single GPU).
         exchange (MVAE_DP_EXCHANGE): "rccl" -- ncclAllReduce on librccl DIRECTLY, enqueued on the step's own streams
@@ -100,7 +100,12 @@ class DataParallelStep:
         "peer2": its two-shot form (each rank reduces 1/world of the buffer, the optimizer reads every slice from its
         owner); "peer3": the SHARDED optimizer on the same two rounds (each rank reduces its 1/world slice, applies Adam to
         it, and the ranks gather the updated PARAMETERS: no pass over the whole buffer on any rank; Adam's moments live on
-        the slice's owner -- `gather_optimizer_state()`)."""
+        the slice's owner -- `gather_optimizer_state()`).
+        shard_optimizer (MVAE_DP_SHARD_OPTIMIZER=1; routes "rccl" and "allreduce", engines with `optimizer_step_slice`): the
+        all-reduce becomes reduce-scatter -> optimizer on the rank's own 1/world range -> all-gather of PARAMETERS
+        (librccl: ncclReduceScatter / ncclAllGather in place on the flat buffers; torch.distributed: all_reduce + one
+        broadcast per owner, gloo has no reduce-scatter).  The optimizer pass per rank shrinks with the world size; the
+        price on the RCCL route is two collectives where there was one -- off by default until a node has measured it."""
         import os
         self.engine = engine
         self.group = group
@@ -124,6 +129,9 @@ class DataParallelStep:
             from .peer import PeerExchange
             self.peer = PeerExchange(engine, group, two_shot=self.exchange == "peer2", sharded=self.exchange == "peer3")
         self.exchange_note = ""   # why a route other than the requested one is in use (bench.py: config.exchange)
+        want_shard = _env_on("MVAE_DP_SHARD_OPTIMIZER") if shard_optimizer is None else bool(shard_optimizer)
+        self.shard = bool(want_shard and active and self.exchange in ("rccl", "allreduce") and
+                          hasattr(engine, "optimizer_step_slice"))
         self._fallback_group = None
         if self.exchange == "rccl" and active:
             from .rccl import FlatAllReduce, RcclUnavailable
@@ -137,7 +145,18 @@ class DataParallelStep:
                 self.exchange = "allreduce"
                 self.exchange_note = f"fallback from rccl: {e}"
                 self._fallback_group = self._make_fallback_group(engine.device)
+        if self.shard and self.rccl is not None:
+            n = int(engine.params.numel())
+            lo, hi = engine.owned_range(0, self.world)
+            if n % self.world or (hi - lo) * self.world != n:  # ncclReduceScatter wants equal ranges = the optimizer's slices
+                self.shard = False
+                self.exchange_note += "; replicated optimizer (the flat buffer does not split evenly over the ranks)"
         self.steps_since_check = 0
+
+    @property
+    def sharded(self) -> bool:
+        """Whether Adam's moments live on the slice's owner only (the sharded peer route, or shard_optimizer)."""
+        return self.shard or (self.peer is not None and getattr(self.peer, "sharded", False))
 
     def _make_fallback_group(self, device):
         """Process group for the all_reduce fall-back when the direct RCCL route could not be set up: torch's own RCCL
@@ -209,6 +228,22 @@ class DataParallelStep:
             self.steps_since_check += 1
             return
         eng.forward_backward(x_local, eps_local, beta)
+        if self.shard:
+            # reduce-scatter -> optimizer on the owned range -> all-gather of parameters
+            if self.rccl is not None:
+                self.rccl.reduce_scatter(eng.grads)
+            else:  # (gloo has no reduce-scatter: the whole sum, of which the rank uses its range)
+                dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
+            eng.optimizer_step_slice(self.rank, self.world, do_curvature_step, batch=x_local.shape[0])
+            if self.rccl is not None:
+                self.rccl.all_gather(eng.params)
+            elif self.world > 1:
+                for r in range(self.world):
+                    lo, hi = eng.owned_range(r, self.world)
+                    if hi > lo:
+                        src = dist.get_global_rank(self._xgroup, r) if self._xgroup is not None else r
+                        dist.broadcast(eng.params[lo:hi], src=src, group=self._xgroup)
+            return
         if self.rccl is not None:
             self.rccl.all_reduce(eng.grads)  # on the step's own stream: captured with the launches around it
         else:
@@ -216,27 +251,26 @@ class DataParallelStep:
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
 
     def owned_slice(self) -> Tuple[int, int]:
-        """[lo, hi) in floats of the flat buffers whose Adam moments THIS rank holds on the sharded route ("peer3"); the whole
-        buffer on every other route."""
-        n = int(self.engine.params.numel())
-        if self.peer is None or not getattr(self.peer, "sharded", False):
-            return 0, n
-        s4 = max(16, (n // 4 + self.world - 1) // self.world)  # peer_slice4 (csrc/mvae_common.hpp)
-        return min(n, 4 * s4 * self.rank), min(n, 4 * s4 * (self.rank + 1))
+        """[lo, hi) in floats of the flat buffers whose Adam moments THIS rank holds on the sharded routes ("peer3",
+        shard_optimizer); the whole buffer on every other route."""
+        if not self.sharded:
+            return 0, int(self.engine.params.numel())
+        return self.engine.owned_range(self.rank, self.world)
 
     def gather_optimizer_state(self) -> None:
-        """Sharded route only: make adam_m / adam_v whole on every rank (each slice broadcast by its owner) -- before a
+        """Sharded routes only: make adam_m / adam_v whole on every rank (each range broadcast by its owner) -- before a
         checkpoint of the optimizer state, or before switching to another route.  A no-op elsewhere."""
-        if self.peer is None or not getattr(self.peer, "sharded", False) or self.world == 1:
+        if not self.sharded or self.world == 1:
             return
-        n = int(self.engine.params.numel())
-        s4 = max(16, (n // 4 + self.world - 1) // self.world)
         for r in range(self.world):
-            lo, hi = min(n, 4 * s4 * r), min(n, 4 * s4 * (r + 1))
+            lo, hi = self.engine.owned_range(r, self.world)
             if hi > lo:
-                src = dist.get_global_rank(self.group, r) if self.group is not None else r
                 for t in (self.engine.adam_m, self.engine.adam_v):
-                    dist.broadcast(t[lo:hi], src=src, group=self.group)
+                    if self.rccl is not None:
+                        self.rccl.broadcast(t[lo:hi], dist.get_global_rank(self.group, r) if self.group is not None else r)
+                    else:
+                        g = self._xgroup
+                        dist.broadcast(t[lo:hi], src=dist.get_global_rank(g, r) if g is not None else r, group=g)
 
     def reduce_stats(self) -> Tensor:
         """Global sums of the running statistics (one small all-reduce, when the host wants to log)."""

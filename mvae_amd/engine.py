@@ -274,6 +274,23 @@ class StepEngine:
         check(load().mvae_step_optimizer(ctx, 1 if do_curvature_step else 0, stream_ptr(self.device)))
         self.grads_from_engine = False
 
+    def owned_range(self, rank: int, world: int):
+        """[lo, hi) in floats of the flat buffers that the sharded optimizer forms give to `rank` of `world`
+        (peer_slice4, csrc/mvae_common.hpp: whole float4, at least the radii region)."""
+        n = int(self.params.numel())
+        s4 = max(16, (n // 4 + world - 1) // world)
+        return min(n, 4 * s4 * rank), min(n, 4 * s4 * (rank + 1))
+
+    def optimizer_step_slice(self, rank: int, world: int, do_curvature_step: bool, batch: Optional[int] = None) -> None:
+        """optimizer_step on `owned_range(rank, world)` only (radii: rank 0), for a data-parallel exchange that left the
+        SUMMED gradient of that range in `grads`; the caller all-gathers `params` afterwards.  Adam's moments move on the
+        owned range only."""
+        if batch is None:
+            batch = self._last_batch if self._last_batch is not None else (next(iter(self._ctx)) if self._ctx else 1)
+        check(load().mvae_step_optimizer_slice(self._context(batch), int(rank), int(world), 1 if do_curvature_step else 0,
+                                               stream_ptr(self.device)))
+        self.grads_from_engine = False
+
     def train_step(self, x: Tensor, eps: Tensor, beta: float = 1.0, do_curvature_step: bool = False) -> None:
         B = self._check_inputs(x, eps)
         self._last_batch = B

@@ -110,6 +110,17 @@ class FlatAllReduce:
         assert t.dtype == torch.float32 and t.is_contiguous()
         check(load().mvae_flat_allreduce(self._h, ptr(t), t.numel(), stream_ptr(t.device)))
 
+    def reduce_scatter(self, t: Tensor) -> None:
+        """In place: afterwards rank r holds the sums of t[r n / world : (r + 1) n / world] in that range of t (the rest of t
+        is unspecified).  t.numel() must be a multiple of the world size."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        check(load().mvae_flat_reduce_scatter(self._h, ptr(t), t.numel(), stream_ptr(t.device)))
+
+    def all_gather(self, t: Tensor) -> None:
+        """In place: every rank's range t[r n / world : (r + 1) n / world] reaches everybody."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        check(load().mvae_flat_allgather(self._h, ptr(t), t.numel(), stream_ptr(t.device)))
+
     def broadcast(self, t: Tensor, src: int = 0) -> None:
         """t of GLOBAL rank `src` (torch.distributed's convention, dist.broadcast) -> every rank of the group (float32 /
         int32 tensors, in place, current stream).  The communicator numbers its ranks inside the group."""

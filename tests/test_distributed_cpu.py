@@ -27,6 +27,10 @@ class OracleEngine:
         self.grads = torch.zeros(sum(self.sizes))
         self.stats = torch.zeros(3)
         self.params = torch.cat([self.orc.P[n].detach().reshape(-1) for n in self.names])
+        off = 0
+        for n, k in zip(self.names, self.sizes):  # the named parameters ARE ranges of the flat buffer (as in StepEngine)
+            self.orc.P[n].data = self.params[off:off + k].view_as(self.orc.P[n])
+            off += k
         self.adam_m = torch.zeros(1)
         self.adam_v = torch.zeros(1)
         self.counters = torch.zeros(1)
@@ -54,6 +58,22 @@ class OracleEngine:
                     o.step()
 
 
+    # ---- the sharded optimizer's surface (StepEngine.owned_range / optimizer_step_slice)
+    def owned_range(self, rank, world):
+        n = self.params.numel()
+        k = (n + world - 1) // world
+        return min(n, k * rank), min(n, k * (rank + 1))
+
+    def optimizer_step_slice(self, rank, world, do_curv, batch=None):
+        """The stand-in applies the whole step and then puts back everything OUTSIDE the rank's range: a rank ends with new
+        parameters on its own range only, so the all-gather that follows is what makes the ranks whole (and equal)."""
+        lo, hi = self.owned_range(rank, world)
+        old = self.params.clone()
+        self.optimizer_step(do_curv)
+        self.params[:lo] = old[:lo]
+        self.params[hi:] = old[hi:]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -62,7 +82,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, out_q):
+def _worker(rank, world, port, steps, out_q, shard=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -71,7 +91,8 @@ def _worker(rank, world, port, steps, out_q):
     xs = synthetic.binary_batches(steps, 64, 32)
     eps = synthetic.eps_batches(steps, 64, spec.total_true_dim)
     lo, hi = shard_rows(64, rank, world)
-    dp = DataParallelStep(OracleEngine(spec, state0))
+    dp = DataParallelStep(OracleEngine(spec, state0), shard_optimizer=shard)
+    assert dp.shard == shard and dp.sharded == shard
     assert spec.named_shapes()[-2][0] == "fc_logits.weight"
     dp.broadcast_state()
     for s in range(steps):
@@ -89,14 +110,16 @@ def test_shard_rows():
 
 
 @pytest.mark.timeout(300)
-def test_data_parallel_world2_matches_single_process():
+@pytest.mark.parametrize("shard", [False, True])
+def test_data_parallel_world2_matches_single_process(shard):
     """Two gloo ranks, each on half of the rows, one all-reduce of the flat gradient buffer per step: equal to the
-    single-process step on the whole batch."""
+    single-process step on the whole batch.  shard: the SHARDED optimizer route (sum -> optimizer on the rank's own range
+    -> all-gather of parameters): the same result, with each rank updating its own range only."""
     steps, world = 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q, shard)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]

@@ -22,7 +22,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None, env=None, moments=False):
+def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cycle=None, env=None, moments=False,
+            shard=False):
     import torch.distributed as dist
     os.environ.update(env or {})
     from mvae_amd import synthetic
@@ -36,7 +37,8 @@ def _worker(rank, world, port, steps, q, exchange="allreduce", graph_steps=0, cy
     xs = synthetic.digits_like_batches(steps, 128)
     eps = synthetic.eps_batches(steps, 128, 6)
     lo, hi = shard_rows(128, rank, world)
-    dp = DataParallelStep(eng, exchange=exchange)
+    dp = DataParallelStep(eng, exchange=exchange, shard_optimizer=shard)
+    assert dp.shard == bool(shard)
     dp.broadcast_state()
     xl, el = xs[:, lo:hi].contiguous().to(dev), eps[:, lo:hi].contiguous().to(dev)
     if graph_steps:  # the whole [forward/backward, publish + wait, peer-read optimizer] sequence replayed as a HIP graph
@@ -201,7 +203,7 @@ def test_two_rank_conv_step_equals_the_oracle():
     for n, t in lay.views(params).items():
         assert_close_after_adam(t.numpy(), orc.P[n].detach().numpy(), 1e-3, 1, "dp2 conv param " + n,
                                 max_steps_apart=2.0 if flips else 1.0, bad_frac=2e-3 if flips else 1e-4)
-    np.testing.assert_allclose(res[0][3][2], float(ref.elbo), rtol=1e-4)
+    np.testing.assert_allclose(res[0][3][2], float(ref.elbo.detach()), rtol=1e-4)
 
 
 def _run_ranks(steps, world, **kw):
@@ -319,6 +321,31 @@ def test_sharded_optimizer_moments_live_on_the_owner_and_gather_whole():
         assert np.array_equal(g[lo_g:hi], ref[0][5][4][lo_g:hi]), "summed gradient on the owner's slice"
     assert covered.all(), "the slices do not cover the buffer"
     assert np.abs(ref[0][5][2]).max() > 0
+
+
+@pytest.mark.timeout(900)
+def test_sharded_optimizer_on_the_all_reduce_route_two_processes():
+    """shard_optimizer on the host-collective routes (mvae_step_optimizer_slice: the sum -> Adam on the rank's own range ->
+    all-gather of parameters), two gloo ranks on one device with the real engine: the parameters equal the replicated
+    optimizer's bit for bit (same summed gradient, same Adam), the moments move on the owner's range only and
+    `gather_optimizer_state()` makes them equal to the replicated optimizer's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    steps, world = 4, 2
+    sh = _run_ranks(steps, world, exchange="allreduce", shard=True, moments=True)
+    ref = _run_ranks(steps, world, exchange="allreduce", moments=True)
+    n = sh[0][1].size
+    covered = np.zeros(n, dtype=bool)
+    for r in sh:
+        assert np.array_equal(r[1], ref[0][1]), f"rank {r[0]}: sharded parameters differ from the replicated optimizer's"
+        (lo, hi), own_m, m, v, _ = r[5]
+        covered[lo:hi] = True
+        outside = np.ones(n, dtype=bool)
+        outside[lo:hi] = False
+        assert np.array_equal(own_m[lo:hi], ref[0][5][2][lo:hi]) and not own_m[outside].any()
+        assert np.array_equal(m, ref[0][5][2]) and np.array_equal(v, ref[0][5][3]), "gathered moments differ"
+    assert covered.all() and ref[0][5][0] == (0, n)
+    np.testing.assert_allclose(sh[0][2][:3], ref[0][2][:3], rtol=1e-6)
 
 
 @pytest.mark.timeout(900)

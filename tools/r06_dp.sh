@@ -1,9 +1,9 @@
 #!/bin/bash
 # World-1 forced exchange (bench.py --force-dp) on every route: what one GPU can measure of the data-parallel tax.
 mkdir -p gpurun_out/r06dp; O=gpurun_out/r06dp; : > $O/summary.txt
-for ex in rccl peer peer2 peer3; do
+for ex in rccl rccl+shard peer3; do
   for rep in 1 2; do
-    MVAE_DP_EXCHANGE=$ex timeout 300 python bench.py --force-dp --no-cpu-baseline --no-extra-configs > $O/${ex}_$rep.json 2> $O/${ex}_$rep.err
+    MVAE_DP_EXCHANGE=${ex%+shard} MVAE_DP_SHARD_OPTIMIZER=$([ "$ex" = "rccl+shard" ] && echo 1 || echo 0) timeout 300 python bench.py --force-dp --no-cpu-baseline --no-extra-configs > $O/${ex}_$rep.json 2> $O/${ex}_$rep.err
     python - $O/${ex}_$rep.json $ex $rep <<'PY' >> gpurun_out/r06dp/summary.txt
 import json, sys
 try:
