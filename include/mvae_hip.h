@@ -609,6 +609,11 @@ int mvae_train_step(mvae_ctx* ctx, const float* x, const float* eps, float beta,
  * captured into a HIP graph and replayed for a whole epoch without host work. */
 int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E, uint64_t seed,
                        const int32_t* counters, int batches_per_epoch, int train, float* x, float* eps, void* stream);
+/* out[0 .. n) ~ N(0, 1) in ONE launch, never exactly 0 (both Box-Muller uniforms on the open interval; an all-zero eps row is
+ * 0 / 0 on a sphere component, spherical.py:87-88): the eps draw of an eager step and of log_likelihood's n x B samples
+ * (vae.py:90: rsample of n samples; here a Philox4x32-10 stream keyed by (seed, offset) -- item i of four values at counter
+ * (i, offset) -- so equal (seed, offset) give equal bits; the host layer takes both from the torch generator and advances it). */
+int mvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
 /* The same preparation WITHOUT a launch of its own ("fused into the step", scope row f-2): arms `ctx` so that the NEXT step
  * launched on it (mvae_train_step, mvae_step_forward_backward[_parts HEAD], mvae_step_profile) also prepares, on spare

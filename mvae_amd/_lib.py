@@ -137,6 +137,7 @@ PROTOTYPES = {
     "mvae_step_forward_backward": (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     "mvae_step_optimizer": (C.c_int, [_P, _I, _P]),
     "mvae_train_step": (C.c_int, [_P, _P, _P, _F, _I, _P]),
+    "mvae_randn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "mvae_prepare_batch": (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _I, _I, _P, _P, _P]),
     "mvae_set_next_batch_feed": (C.c_int, [_P, _P, _P, _I, C.c_uint64, _I, _I, _P, _P]),
     "mvae_slice_sums_defer": (C.c_int, [_I]),

@@ -1098,6 +1098,27 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Four N(0, 1) draws from four 32-bit words: Box-Muller on two pairs.
+// Both uniforms on the OPEN interval, (k + 1/2) 2^-23: with u1 in (0, 1] a pair is exactly (0, 0) whenever u1 = 1 --
+// probability 2^-24 per pair, i.e. about once per 50 MNIST epochs -- and a sphere component whose eps is (0, 0) is
+// 0 / 0 in the reference's formula (spherical.py:87-88 divides by |u| unclamped): the float32 CLI run went non-finite
+// at a random epoch in 2 of 16 seeds, at exactly the batches tools/eps_zero_scan.py finds such a pair in.  (The reference draws
+// float64 normals by default, where the same event has probability 2^-53.)  The half-step offset also keeps sin / cos
+// off their exact zeros, so no single draw is exactly 0 either.
+// (23 random bits: k + 1/2 is then exact in float32 -- with 24 bits the largest k + 1/2 rounds up to 2^24 and u1 is 1 again)
+__device__ __forceinline__ void box_muller4(const unsigned r[4], float n[4]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float u1 = ((float)(r[2 * t] >> 9) + 0.5f) * (1.0f / 8388608.0f);      // (0, 1)
+    const float u2 = ((float)(r[2 * t + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    n[2 * t] = rad * cs;
+    n[2 * t + 1] = rad * sn;
+  }
+}
+
 struct FeedArgs {
   const unsigned char* images;  // [n_images][D] uint8; NULL: no feed
   const int* perm;              // device permutation or NULL
@@ -1158,24 +1179,8 @@ __device__ __forceinline__ void feed_item(const FeedArgs& f, unsigned cursor, in
   } else {
     const int q = i - nx4;
     philox4x32_10((unsigned)q, cursor, 1u, 0u, k0, k1, r);  // stream 1: eps
-    float n[4];  // Box-Muller on two pairs
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // Both uniforms on the OPEN interval, (k + 1/2) 2^-23: with u1 in (0, 1] a pair is exactly (0, 0) whenever u1 = 1 --
-      // probability 2^-24 per pair, i.e. about once per 50 MNIST epochs -- and a sphere component whose eps is (0, 0) is
-      // 0 / 0 in the reference's formula (spherical.py:87-88 divides by |u| unclamped): the float32 CLI run went non-finite
-      // at a random epoch in 2 of 16 seeds, at exactly the batches tools/eps_zero_scan.py finds such a pair in.  (The reference draws
-      // float64 normals by default, where the same event has probability 2^-53.)  The half-step offset also keeps sin / cos
-      // off their exact zeros, so no single draw is exactly 0 either.
-      // (23 random bits: k + 1/2 is then exact in float32 -- with 24 bits the largest k + 1/2 rounds up to 2^24 and u1 is 1 again)
-      const float u1 = ((float)(r[2 * t] >> 9) + 0.5f) * (1.0f / 8388608.0f);      // (0, 1)
-      const float u2 = ((float)(r[2 * t + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);  // (0, 1)
-      const float rad = sqrtf(-2.0f * logf(u1));
-      float sn, cs;
-      sincosf(6.283185307179586f * u2, &sn, &cs);
-      n[2 * t] = rad * cs;
-      n[2 * t + 1] = rad * sn;
-    }
+    float n[4];
+    box_muller4(r, n);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       if (q * 4 + t < f.B * f.E) f.eps[q * 4 + t] = n[t];

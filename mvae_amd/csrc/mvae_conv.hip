@@ -2491,6 +2491,40 @@ __global__ __launch_bounds__(256) void k_prepare_batch(FeedArgs f) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) feed_item(f, cursor, i);
 }
 
+// out[0 .. n) ~ N(0, 1), never exactly 0 (box_muller4): the eps draw of an eager step / of log_likelihood's n x B samples in ONE
+// launch.  Counter-based: item i (four values) = Philox4x32-10 at counter (i lo, i hi, offset lo, offset hi), key = seed --
+// the same (seed, offset) gives the same bits on every launch geometry.
+__global__ __launch_bounds__(256) void k_randn(float* __restrict__ out, long long n, unsigned long long seed,
+                                               unsigned long long offset) {
+  const long long items = (n + 3) >> 2;
+  const bool vec = (((uintptr_t)out) & 15) == 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)((unsigned long long)i >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    float v[4];
+    box_muller4(r, v);
+    if (vec && i * 4 + 3 < n) {
+      *reinterpret_cast<f32x4*>(out + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (i * 4 + t < n) out[i * 4 + t] = v[t];
+    }
+  }
+}
+
+extern "C" int mvae_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  if (!out || n < 0) return fail(MVAE_E_BADARG, "null pointer / negative count%s", "");
+  if (n == 0) return 0;
+  const long long items = (n + 3) / 4;
+  const long long blocks = (items + 255) / 256;
+  hipLaunchKernelGGL(k_randn, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, out,
+                     (long long)n, (unsigned long long)seed, (unsigned long long)offset);
+  LAUNCH_CHECK("randn launch");
+  return 0;
+}
+
 extern "C" int mvae_prepare_batch(const uint8_t* images, const int32_t* perm, int n_images, int D, int B, int E,
                                   uint64_t seed, const int32_t* counters, int batches_per_epoch, int train, float* x,
                                   float* eps, void* stream) {

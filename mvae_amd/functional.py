@@ -646,3 +646,23 @@ def loglik_reduce(bce: Tensor, log_p: Tensor, log_q: Tensor):
     check(load().mvae_loglik_reduce(ptr(bce), ptr(log_p), ptr(log_q), ptr(log_px), ptr(mi), n, B,
                                     stream_ptr(bce.device)))
     return log_px, mi
+
+
+def randn_nonzero(shape, device, generator: Optional[torch.Generator] = None) -> Tensor:
+    """N(0, 1) draws of `shape` on the HIP device in ONE launch (mvae_randn), none of them exactly 0 -- what `torch.randn`
+    + a zero nudge did in three.  The Philox (seed, offset) pair comes from `generator` (default: the device's torch
+    generator) and the generator is advanced, so `torch.manual_seed` / `Generator.manual_seed` reproduce the draws like
+    they do torch's own; under stream capture (where a generator's host-side offset cannot be read) torch.randn + the
+    nudge are used instead."""
+    device = torch.device(device)
+    if torch.cuda.is_current_stream_capturing():
+        eps = torch.randn(*shape, device=device, generator=generator)
+        return eps.masked_fill_(eps == 0, 1e-10)
+    gen = generator if generator is not None else torch.cuda.default_generators[
+        device.index if device.index is not None else torch.cuda.current_device()]
+    seed, offset = int(gen.initial_seed()), int(gen.get_offset())
+    out = torch.empty(*shape, device=device, dtype=torch.float32)
+    gen.set_offset(offset + 4)  # (torch wants multiples of 4; one tick per call: the item index is part of the counter)
+    with torch.cuda.device(device):
+        check(load().mvae_randn(ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, offset, stream_ptr(device)))
+    return out

@@ -163,9 +163,9 @@ class ModelVAE(nn.Module):
     def _eps(self, *lead: int) -> Tensor:
         """The N(0, 1) draw behind every rsample of the step.  A float32 Box-Muller draw is EXACTLY zero with probability
         ~2^-25 per pair, and a sphere component whose eps is all zeros is 0 / 0 in the reference's formula (spherical.py:87-88,
-        |u| unclamped; float64 draws, the reference's default, never get there): exact zeros are nudged to 1e-10."""
-        eps = torch.randn(*lead, self._need_engine().layout.eps_dim, device=self.device, generator=self._generator)
-        return eps.masked_fill_(eps == 0, 1e-10)
+        |u| unclamped; float64 draws, the reference's default, never get there): the draw comes from `Fn.randn_nonzero`
+        (one launch, both Box-Muller uniforms on the open interval, seeded from the torch generator)."""
+        return Fn.randn_nonzero((*lead, self._need_engine().layout.eps_dim), self.device, self._generator)
 
     # ---- reference API
     def encode(self, x: Tensor) -> Tensor:

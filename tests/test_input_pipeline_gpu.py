@@ -339,3 +339,42 @@ def test_pipeline_eps_is_never_exactly_zero(dev):
         allv = torch.cat(acc).double()
         assert abs(float(allv.mean())) < 0.01 and abs(float(allv.var()) - 1.0) < 0.02
         assert float(allv.abs().max()) < 6.0
+
+
+def test_randn_nonzero_one_launch_draw(dev):
+    """`Fn.randn_nonzero` (mvae_randn: the eps draw of an eager step / of log_likelihood's samples in one launch): standard
+    normal (moments of 4 M draws, both tails), never exactly zero, any size and alignment, seeded from -- and advancing -- the
+    torch generator (re-seeding reproduces the draws, a second call continues the stream), and the same bits for the same
+    (seed, offset) through the C ABI whatever the buffer's alignment."""
+    import ctypes as C
+    from mvae_amd import functional as Fn
+    from mvae_amd._lib import check, load, ptr, stream_ptr
+    g = torch.Generator(device=dev).manual_seed(1234)
+    a = Fn.randn_nonzero((4, 1 << 20), dev, g)
+    b = Fn.randn_nonzero((4, 1 << 20), dev, g)
+    assert a.shape == (4, 1 << 20) and a.dtype == torch.float32 and not torch.equal(a, b)
+    v = torch.cat([a.flatten(), b.flatten()]).double()
+    assert int((v == 0).sum()) == 0 and bool(torch.isfinite(v).all())
+    m, s2 = float(v.mean()), float(v.var())
+    assert abs(m) < 2e-3 and abs(s2 - 1.0) < 3e-3, (m, s2)
+    assert abs(float((v ** 3).mean())) < 1e-2 and abs(float((v ** 4).mean()) - 3.0) < 3e-2
+    assert 4.5 < float(v.max()) < 6.5 and -6.5 < float(v.min()) < -4.5  # 8 M draws: both tails are populated
+    assert abs(float((v.abs() < 1.0).double().mean()) - 0.682689) < 1e-3
+    g.manual_seed(1234)
+    assert torch.equal(Fn.randn_nonzero((4, 1 << 20), dev, g), a) and torch.equal(Fn.randn_nonzero((4, 1 << 20), dev, g), b)
+    # the default generator: torch.manual_seed reproduces
+    torch.manual_seed(7)
+    c1 = Fn.randn_nonzero((3, 5, 7), dev)
+    torch.manual_seed(7)
+    assert torch.equal(Fn.randn_nonzero((3, 5, 7), dev), c1) and c1.shape == (3, 5, 7)
+    # C ABI: same (seed, offset) = same bits for an unaligned buffer and a ragged count; another offset = another stream
+    lib = load()
+    buf = torch.zeros(1003 + 1, device=dev)
+    check(lib.mvae_randn(ptr(buf[1:]), 1003, 99, 8, stream_ptr(dev)))
+    al = torch.zeros(1003, device=dev)
+    check(lib.mvae_randn(ptr(al), 1003, 99, 8, stream_ptr(dev)))
+    assert torch.equal(buf[1:], al) and float(buf[0]) == 0.0
+    other = torch.zeros(1003, device=dev)
+    check(lib.mvae_randn(ptr(other), 1003, 99, 12, stream_ptr(dev)))
+    assert not torch.equal(other, al)
+    assert lib.mvae_randn(None, 4, 0, 0, stream_ptr(dev)) != 0  # null pointer: MVAE_E_BADARG

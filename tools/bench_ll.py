@@ -25,8 +25,8 @@ for _ in range(3):
     out = m.log_likelihood(x, n=n)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10):
+for _ in range(50):
     out = m.log_likelihood(x, n=n)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 10
-print(f"log_likelihood {model} B=128 n={n}: {dt * 1e3:.2f} ms  (log_px mean {float(out[0].mean()):.3f})")
+dt = (time.perf_counter() - t0) / 50
+print(f"log_likelihood {model} B=128 n={n}: {dt * 1e3:.4f} ms  (log_px mean {float(out[0].mean()):.3f})")
