@@ -31,7 +31,7 @@ MODEL = "h2,s2,e2"
 B, D, H = 128, 784, 400
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
-ONE_GRAPH_MAX = 400  # a timed region of up to this many steps is captured as ONE graph (one replay)
+ONE_GRAPH_MAX = int(os.environ.get("MVAE_BENCH_ONE_GRAPH_MAX", "400"))  # a timed region of up to this many steps is captured as ONE graph (one replay)
 
 
 def algorithmic_per_launch(P, NH=12, Z=8, E=6):
@@ -515,10 +515,12 @@ def epoch_pipeline_leg(dev, epochs=3, batch=None):
             "baseline_config": "configs[1] with the reference's DataLoader + ImageDynamicBinarization replaced (SURVEY 8 f-2)"}
 
 
-def loglik_leg(dev, n=500, iters=10):
+def loglik_leg(dev, n=500, iters=40):
     """Scope row f-1 (ModelVAE.log_likelihood, vae.py:82-123) at the reference's evaluation setting: B = 128, n = 500
     importance samples, model h2,s2,e2, MLP h_dim 400 -- 64 000 decoded rows per batch.  MFMA-bound: the decoder's two
-    layers are 2 * 64000 * (Z*H + H*D) flops."""
+    layers are 2 * 64000 * (Z*H + H*D) flops.  A timed repeat is `iters` back-to-back calls between two synchronisations (the
+    reference evaluates a test set batch after batch, train.py: one call per batch): with 10 calls per repeat the start-up of
+    the first call (~100 us of host work before its decoder launch) was 2-3 % of the reported time per call."""
     from mvae_amd import functional as Fn, utils
     from mvae_amd.models import FeedForwardVAE
 
