@@ -232,7 +232,7 @@ class DataParallelStep:
             # reduce-scatter -> optimizer on the owned range -> all-gather of parameters
             if self.rccl is not None:
                 self.rccl.reduce_scatter(eng.grads)
-            else:  # (gloo has no reduce-scatter: the whole sum, of which the rank uses its range)
+            elif self.world > 1:  # (gloo has no reduce-scatter: the whole sum, of which the rank uses its range)
                 dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
             eng.optimizer_step_slice(self.rank, self.world, do_curvature_step, batch=x_local.shape[0])
             if self.rccl is not None:
@@ -246,7 +246,7 @@ class DataParallelStep:
             return
         if self.rccl is not None:
             self.rccl.all_reduce(eng.grads)  # on the step's own stream: captured with the launches around it
-        else:
+        elif self.world > 1:  # (world 1 with the exchange forced and no process group: the sum of one rank is the gradient)
             dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self._xgroup)
         eng.optimizer_step(do_curvature_step, batch=x_local.shape[0])
 

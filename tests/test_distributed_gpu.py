@@ -348,6 +348,57 @@ def test_sharded_optimizer_on_the_all_reduce_route_two_processes():
     np.testing.assert_allclose(sh[0][2][:3], ref[0][2][:3], rtol=1e-6)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("model", ["h2,s2,e2", "u2,u3,e2"])
+@pytest.mark.parametrize("route", ["peer3", "rccl+shard", "allreduce+shard"])
+def test_sharded_optimizer_world_one_equals_the_replicated_step(model, route):
+    """World size 1 with the exchange forced (one process, no rendezvous): the sharded optimizer launches -- the peer form
+    (k_optim_shard + flag rounds) and mvae_step_optimizer_slice behind librccl's reduce-scatter / all-gather or the
+    all_reduce stand-in -- give the parameters, moments and radii of forward_backward + optimizer_step bit for bit, for
+    learnable radii and for UNIVERSAL curvatures (whose gradients are clipped after the reduction: the clip lives on rank 0's
+    slice), with the curvature step on and off."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from mvae_amd import synthetic
+    from mvae_amd.distributed import DataParallelStep
+    from mvae_amd.engine import StepEngine
+    dev = torch.device("cuda:0")
+    comps = [(tok[0], int(tok[1:])) for tok in model.split(",")]
+    steps = 4
+    xs = synthetic.digits_like_batches(steps, 128).to(dev)
+
+    def fresh():
+        eng = StepEngine(comps, 784, 400, dev, radius_trainable=[k != "e" for k, _ in comps])
+        eng.load_state(synthetic.synthetic_state([(n, s) for n, _, s in eng.flat.entries], radius=2.0))
+        if "u" in model:  # universal components carry a curvature (either sign), not a radius
+            eng.set_radii(2.0)
+            eng.params[:len(comps)].copy_(torch.tensor([-0.3, 0.4, 0.0][:len(comps)], device=dev))
+        return eng
+
+    ref = fresh()
+    eps = synthetic.eps_batches(steps, 128, ref.layout.eps_dim).to(dev)
+    for s in range(steps):
+        ref.forward_backward(xs[s], eps[s], 1.0)
+        ref.optimizer_step(s % 2 == 0, batch=128)
+    eng = fresh()
+    ex, shard = (route.split("+")[0], True) if "+" in route else (route, False)
+    dp = DataParallelStep(eng, always_exchange=True, exchange=ex, shard_optimizer=shard)
+    if ex == "rccl" and dp.rccl is None:
+        pytest.skip("librccl could not be set up on this box: " + dp.exchange_note)
+    assert dp.sharded and dp.owned_slice() == (0, eng.params.numel())
+    for s in range(steps):
+        dp.train_step(xs[s], eps[s], 1.0, s % 2 == 0)
+    torch.cuda.synchronize()
+    if dp.peer is not None:
+        assert dp.peer.timeouts() == 0
+        dp.peer.close()
+    for name, a, b in (("params", eng.params, ref.params), ("adam_m", eng.adam_m, ref.adam_m), ("adam_v", eng.adam_v, ref.adam_v)):
+        assert torch.equal(a, b), f"{route} {model}: {name} differ from the replicated optimizer step"
+    assert int(eng.counters[0]) == int(ref.counters[0]) == steps
+    n = len(comps)
+    assert bool((eng.params[:n] != fresh().params[:n])[[k != "e" for k, _ in comps]].all()), "the curvature step did not move the radii"
+
+
 @pytest.mark.timeout(900)
 def test_bench_flow_eight_ranks_one_device():
     """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, 8 ranks), dry-run on ONE device over the
