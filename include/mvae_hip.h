@@ -373,6 +373,13 @@ int mvae_p3_supported(int form, int64_t M, int N, int K, int C);
 /* planes[j] (3 x n[j] bf16, plane stride n[j]) of src[j] (n[j] floats, a multiple of 4), up to 12 tensors in ONE launch:
  * the conv weights after the optimizer step, activations whose producer does not write planes. */
 int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream);
+/* The same planes, QUEUED: nothing is launched; the jobs (at most 4 ride, more are performed by the next flush) travel as extra
+ * workgroups of the next mvae_conv_latent_forward on this thread -- a latency-bound launch with memory bandwidth to spare --
+ * and any plane contraction issued before that performs them first, as does mvae_split3_planes_flush / the next
+ * mvae_split3_planes[_queue] call.  The sources and the planes must stay alive until then.  Host-side state per calling thread
+ * (graph-capturable).  MVAE_SPLIT_RIDE=0: the latent forward does not take them (they run at the first consumer). */
+int mvae_split3_planes_queue(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream);
+int mvae_split3_planes_flush(void* stream);
 /* Grouped launches: between mvae_p3_group(1, stream) and mvae_p3_group(0, stream) up to two plane contractions are queued
  * instead of launched; group(0) launches them -- a weight gradient (mvae_conv_k4s2p1_nhwc_wgrad_p3) and the backward-data of the
  * same layer (the other three entry points) as ONE kernel whose workgroups of the second start as those of the first finish --

@@ -101,6 +101,8 @@ PROTOTYPES = {
     "mvae_set_forward_kernel": (C.c_int, [_I]),
     "mvae_p3_supported": (C.c_int, [_I, _L, _I, _I, _I]),
     "mvae_split3_planes": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
+    "mvae_split3_planes_queue": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
+    "mvae_split3_planes_flush": (C.c_int, [_P]),
     "mvae_conv3_k4s2p1_nchw": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "mvae_conv3_k4s2p1_nchw_wgrad_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "mvae_conv3_k4s2p1_nchw_wgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -127,15 +127,18 @@ def _ps(planes: Optional[Tensor]) -> int:
     return 0 if planes is None else planes[0].numel()
 
 
-def _split_planes(tensors: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None) -> List[Tensor]:
-    """Planes of up to 12 f32 tensors ([rows, cols], element count a multiple of 4) in ONE launch (mvae_split3_planes)."""
+def _split_planes(tensors: Sequence[Tensor], outs: Optional[Sequence[Tensor]] = None, queue: bool = False) -> List[Tensor]:
+    """Planes of up to 12 f32 tensors ([rows, cols], element count a multiple of 4) in ONE launch (mvae_split3_planes).
+    queue: no launch of their own -- the jobs ride on the next fused latent forward as extra workgroups
+    (mvae_split3_planes_queue; whoever reads planes first performs them otherwise)."""
     n = len(tensors)
     if outs is None:
         outs = [_new_planes(t.shape[0], t.numel() // t.shape[0], t.device) for t in tensors]
     src = (C.c_void_p * n)(*[ptr(t) for t in tensors])
     dst = (C.c_void_p * n)(*[_pptr(o) for o in outs])
     cnt = (C.c_int64 * n)(*[t.numel() for t in tensors])
-    check(load().mvae_split3_planes(n, src, dst, cnt, stream_ptr(tensors[0].device)))
+    fn = load().mvae_split3_planes_queue if queue else load().mvae_split3_planes
+    check(fn(n, src, dst, cnt, stream_ptr(tensors[0].device)))
     return list(outs)
 
 
@@ -498,6 +501,7 @@ class ConvEngine:
         self._sw_epi_colsum = os.environ.get("MVAE_CONV_EPI_COLSUM", "1")
         self._sw_dt0_slices = os.environ.get("MVAE_CONV_DT0_SLICES", "1") != "0"
         self._sw_da1_implicit = os.environ.get("MVAE_CONV_DA1_IMPLICIT", "1") != "0"
+        self._sw_split_ride = os.environ.get("MVAE_SPLIT_RIDE", "1") != "0"  # weight planes ride on the latent forward
         # (Rounds 3-4 also carried a backward pass on three HIP streams -- weight gradients and bias sums forked onto side
         # streams --: same bits, measured slower in every form (1.08 -> 1.21 ms eager, no overlap inside a captured graph);
         # removed in round 5.)
@@ -597,6 +601,10 @@ class ConvEngine:
                 c["t0_p"] = _new_planes(B * 16, 128, self.device)  # written by the same launch
             ws = x.new_empty(int(load().mvae_conv_latent_workspace_floats(B, lay.n)))
             eps = eps.contiguous()
+            if planes and "W_p" not in c and self._sw_split_ride:
+                # the weight planes of the backward pass (contraction mode 2) as extra workgroups of the latent forward: a launch
+                # of one small workgroup per batch row that leaves the memory system idle (no k_split3 launch in the backward)
+                c["W_p"] = _split_planes([c["We1"], c["We2"], c["Wd1"], c["Wd2"]], queue=True)
             check(load().mvae_conv_latent_forward(lay.descs, lay.n, ptr(c["hflat"]), ptr(self.params[ow:ow + NH * H_DIM]),
                                                   ptr(self.params[ob:ob + NH]), ptr(eps), eps.shape[1],
                                                   ptr(self.params[:lay.n]), ptr(PV["d0.weight"]), ptr(PV["d0.bias"]),
@@ -701,6 +709,8 @@ class ConvEngine:
                 pass
             raise
         finally:
+            # (planes queued by the forward pass and never consumed -- an aborted pass: performed while their tensors are alive)
+            load().mvae_split3_planes_flush(stream_ptr(self.device))
             check(load().mvae_slice_sums_defer(0))
 
     def _loss_end(self, x, c, bce, beta, B, lay):

@@ -1265,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_colsum_batched(ColJobs jobs) { colsum_b
 
 // The queued column sums handed to a launch that can carry them as extra workgroups (the boundary layer's weight gradient,
 // mvae_edge.hip: the last launch of the backward pass before the flush, independent of them) instead of a launch of their own.
+bool p3_take_splitjobs(SplitJobs4* out);  // mvae_p3.hip
 bool p3_take_coljobs(ColJobs* out) {
   if (!g_defer || g_cols.njobs == 0) return false;
   *out = g_cols;
@@ -1997,7 +1998,13 @@ __global__ __launch_bounds__(256) void k_cl_latent_fwd(CompTable t, const float*
                                                        const float* __restrict__ b_d0, int Z, float* __restrict__ heads,
                                                        float* __restrict__ z, float* __restrict__ kl,
                                                        float* __restrict__ t0, bf16r* __restrict__ t0p, long long t0ps,
-                                                       int B) {
+                                                       int B, const SplitJobs4 ride) {
+  // workgroups past the batch rows carry queued plane splits (the weight planes of the backward pass: independent of this launch,
+  // which is one dependent chain per row and leaves the memory system idle)
+  if ((int)blockIdx.x >= B) {
+    split3_body(ride, (int)blockIdx.x - B, 256);
+    return;
+  }
   __shared__ float hp[16][17];
   __shared__ float heads_s[16], z_s[16];
   __shared__ float eps_s[16], rad_s[16];
@@ -2428,9 +2435,14 @@ extern "C" int mvae_conv_latent_forward(const mvae_component_desc* comps, int nc
   hipStream_t s = (hipStream_t)stream;
   const dim3 gridA(kClSlices, (unsigned)((B + 63) / 64));
   MV_CL_NN_SWITCH(NH, hipLaunchKernelGGL((k_cl_heads_part<NN>), gridA, dim3(256), 0, s, a2, W_heads, workspace, (int)B, NH));
-  MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_fwd<DM>), dim3((unsigned)B), dim3(256), 0, s, t, workspace,
-                                             b_heads, NH, eps, eps_ld, radii, W_d0, b_d0, Z, heads, z, kl, t0, t0_planes,
-                                             (long long)t0_ps, (int)B));
+  SplitJobs4 ride;
+  ride.njobs = 0;
+  ride.blk0[0] = 0;
+  static const bool no_ride = [] { const char* e = getenv("MVAE_SPLIT_RIDE"); return e && e[0] == '0'; }();
+  const int n_ride = (!no_ride && p3_take_splitjobs(&ride)) ? ride.blk0[ride.njobs] : 0;
+  MV_CL_DMAX_SWITCH(dmax, hipLaunchKernelGGL((k_cl_latent_fwd<DM>), dim3((unsigned)(B + n_ride)), dim3(256), 0, s, t, workspace,
+                                             b_heads, NH, eps, eps_ld, radii, W_d0, b_d0, Z, heads, z, kl, t0,
+                                             reinterpret_cast<bf16r*>(t0_planes), (long long)t0_ps, (int)B, ride));
   LAUNCH_CHECK("fused conv latent forward launch");
   return 0;
 }

@@ -672,41 +672,65 @@ __global__ __launch_bounds__(512) void k_gemm_p3_pair(const P3Args g1, const P3A
 }
 
 // ---- planes of an existing f32 tensor (weights after the optimizer step; activations whose producer does not emit them)
-constexpr int kMaxSplitJobs = 12;
-struct SplitJobs {
-  const float* src[kMaxSplitJobs];
-  bf16r* dst[kMaxSplitJobs];
-  long long n[kMaxSplitJobs];  // floats, a multiple of 4; planes at dst, dst + n, dst + 2 n
-  int blk0[kMaxSplitJobs + 1];
-  int njobs;
-};
-__global__ __launch_bounds__(256) void k_split3(const SplitJobs jobs) {
-  int j = 0;
-  while (j + 1 < jobs.njobs && (int)blockIdx.x >= jobs.blk0[j + 1]) ++j;  // uniform
-  const float* src = jobs.src[j];
-  bf16r* dst = jobs.dst[j];
-  const long long n = jobs.n[j], n4 = n >> 2;
-  const int nblk = jobs.blk0[j + 1] - jobs.blk0[j];
-  for (long long i = (long long)((int)blockIdx.x - jobs.blk0[j]) * 256 + threadIdx.x; i < n4; i += (long long)nblk * 256) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    store_planes4(dst, n, (size_t)i * 4, v[0], v[1], v[2], v[3]);
-  }
-}
+__global__ __launch_bounds__(256) void k_split3(const SplitJobs jobs) { split3_body(jobs, (int)blockIdx.x, 256); }
 
-extern "C" int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream) {
+static int split_jobs_build(SplitJobs* jobs, int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n) {
   if (njobs < 1 || njobs > kMaxSplitJobs || !src || !planes || !n) return fail(MVAE_E_BADARG, "1 .. 12 jobs%s", "");
-  SplitJobs jobs;
-  jobs.njobs = njobs;
-  jobs.blk0[0] = 0;
+  jobs->njobs = njobs;
+  jobs->blk0[0] = 0;
   for (int j = 0; j < njobs; ++j) {
     if (!src[j] || !planes[j] || n[j] < 4 || (n[j] & 3)) return fail(MVAE_E_BADARG, "null pointer / n not a multiple of 4%s", "");
     if (!aligned16(src[j]) || ((uintptr_t)planes[j] & 7)) return fail(MVAE_E_ALIGN, "mvae_split3_planes: 16-byte aligned source, 8-byte aligned planes%s", "");
-    jobs.src[j] = src[j];
-    jobs.dst[j] = planes[j];
-    jobs.n[j] = n[j];
+    jobs->src[j] = src[j];
+    jobs->dst[j] = reinterpret_cast<bf16r*>(planes[j]);
+    jobs->n[j] = n[j];
     const long long want = (n[j] / 4 + 256 * 4 - 1) / (256 * 4);  // ~4 vectors per thread
-    jobs.blk0[j + 1] = jobs.blk0[j] + (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    jobs->blk0[j + 1] = jobs->blk0[j] + (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   }
+  return 0;
+}
+
+// Queued planes: mvae_split3_planes_queue only records the jobs (host side, per calling thread); the next launch that can carry
+// them as extra workgroups takes them (p3_take_splitjobs: the conv latent forward -- a latency-bound launch of one small
+// workgroup per batch row, whose CUs have bandwidth to spare), and ANY plane contraction launched before that performs them
+// first (p3_flush_split), so a consumer never sees planes that were not written.
+static thread_local SplitJobs g_split;
+static thread_local bool g_split_pending = false;
+void p3_flush_split(hipStream_t s) {
+  if (!g_split_pending) return;
+  g_split_pending = false;
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)g_split.blk0[g_split.njobs]), dim3(256), 0, s, g_split);
+}
+bool p3_take_splitjobs(SplitJobs4* out) {
+  if (!g_split_pending || g_split.njobs > kRideSplitJobs) return false;
+  g_split_pending = false;
+  out->njobs = g_split.njobs;
+  for (int j = 0; j < g_split.njobs; ++j) {
+    out->src[j] = g_split.src[j];
+    out->dst[j] = g_split.dst[j];
+    out->n[j] = g_split.n[j];
+  }
+  for (int j = 0; j <= g_split.njobs; ++j) out->blk0[j] = g_split.blk0[j];
+  return true;
+}
+extern "C" int mvae_split3_planes_queue(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream) {
+  p3_flush_split((hipStream_t)stream);  // (a queue nobody took: performed now, in order)
+  int rc = split_jobs_build(&g_split, njobs, src, planes, n);
+  if (rc) return rc;
+  g_split_pending = true;
+  return 0;
+}
+extern "C" int mvae_split3_planes_flush(void* stream) {
+  p3_flush_split((hipStream_t)stream);
+  LAUNCH_CHECK("split3 planes launch");
+  return 0;
+}
+
+extern "C" int mvae_split3_planes(int njobs, const float* const* src, uint16_t* const* planes, const int64_t* n, void* stream) {
+  p3_flush_split((hipStream_t)stream);
+  SplitJobs jobs;
+  int rc = split_jobs_build(&jobs, njobs, src, planes, n);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_split3, dim3((unsigned)jobs.blk0[njobs]), dim3(256), 0, (hipStream_t)stream, jobs);
   LAUNCH_CHECK("split3 planes launch");
   return 0;
@@ -760,6 +784,7 @@ static thread_local P3Post g_p3_post[kP3PostMax];
 
 template <int BM, int BN, int WR, int AF, int BF, bool KALT>
 static void p3_single(const P3Args& a, dim3 grid, hipStream_t s) {
+  p3_flush_split(s);
   hipLaunchKernelGGL((k_gemm_p3<BM, BN, WR, AF, BF, MV_P3_STAGES, KALT>), grid, dim3(512), 0, s, a);
 }
 template <int BM, int BN, int WR, int AF, int BF, bool KALT>
@@ -789,6 +814,7 @@ static void p3_sum_deferrable_after(const float* part, float* out, int64_t n, in
 template <int BM2, int BN2, int WR2, int AF2, int BF2, bool KALT2>
 static void p3_launch_pair(const P3Queued& w, const P3Queued& d, hipStream_t s) {  // w: the weight gradient (P3_WGRAD)
   const int n1 = (int)(w.grid.x * w.grid.y * w.grid.z), n2 = (int)(d.grid.x * d.grid.y * d.grid.z);
+  p3_flush_split(s);
   hipLaunchKernelGGL((k_gemm_p3_pair<128, 128, 2, A_KM, B_G2, true, BM2, BN2, WR2, AF2, BF2, KALT2>), dim3((unsigned)(n1 + n2)),
                      dim3(512), 0, s, w.a, d.a, n1, (int)w.grid.x, (int)w.grid.y, (int)w.grid.z, (int)d.grid.x, (int)d.grid.y,
                      (int)d.grid.z);

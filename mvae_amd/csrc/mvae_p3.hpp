@@ -52,6 +52,39 @@ __device__ __forceinline__ void store_planes4(bf16r* planes, long long plane_str
 // flight; the 16 row groups meet in LDS and are added in group order: per column the same additions in the same order as
 // k_colsum_sliced.
 constexpr int kColSlice = 512;  // rows per slice of the tall column sums (mvae_colsum)
+// ---- planes of existing f32 tensors (mvae_split3_planes): the job list and the workgroup body, shared by the stand-alone launch
+// (k_split3, mvae_p3.hip) and by a launch that carries the jobs as extra workgroups (the conv latent forward, mvae_conv.hip)
+constexpr int kMaxSplitJobs = 12;
+struct SplitJobs {
+  const float* src[kMaxSplitJobs];
+  bf16r* dst[kMaxSplitJobs];
+  long long n[kMaxSplitJobs];  // floats, a multiple of 4; planes at dst, dst + n, dst + 2 n
+  int blk0[kMaxSplitJobs + 1];
+  int njobs;
+};
+constexpr int kRideSplitJobs = 4;  // what a carrying launch takes (the four channel-last weight matrices of the conv step)
+struct SplitJobs4 {
+  const float* src[kRideSplitJobs];
+  bf16r* dst[kRideSplitJobs];
+  long long n[kRideSplitJobs];
+  int blk0[kRideSplitJobs + 1];
+  int njobs;  // 0: nothing rides
+};
+template <class Jobs>
+__device__ __forceinline__ void split3_body(const Jobs& jobs, const int blk, const int nthreads) {
+  int j = 0;
+  while (j + 1 < jobs.njobs && blk >= jobs.blk0[j + 1]) ++j;  // uniform
+  const float* src = jobs.src[j];
+  bf16r* dst = jobs.dst[j];
+  const long long n = jobs.n[j], n4 = n >> 2;
+  const int nblk = jobs.blk0[j + 1] - jobs.blk0[j];
+  for (long long i = (long long)(blk - jobs.blk0[j]) * nthreads + threadIdx.x; i < n4; i += (long long)nblk * nthreads) {
+    typedef float split_f4 __attribute__((ext_vector_type(4)));  // (f32x4 of mvae_common.hpp is declared after this header)
+    const split_f4 v = reinterpret_cast<const split_f4*>(src)[i];
+    store_planes4(dst, n, (size_t)i * 4, v[0], v[1], v[2], v[3]);
+  }
+}
+
 constexpr int kMaxColJobs = 12;
 struct ColJobs {
   const float* G[kMaxColJobs];
