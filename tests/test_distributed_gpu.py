@@ -400,9 +400,10 @@ def test_sharded_optimizer_world_one_equals_the_replicated_step(model, route):
 
 
 @pytest.mark.timeout(900)
-def test_bench_flow_eight_ranks_one_device():
+@pytest.mark.parametrize("exchange", ["peer2", "peer3"])
+def test_bench_flow_eight_ranks_one_device(exchange):
     """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, 8 ranks), dry-run on ONE device over the
-    two-shot peer route: the flow -- rendezvous, capture of the exchange, barrier-bracketed timed region, max over ranks,
+    two-shot peer route / the sharded-optimizer peer route: the flow -- rendezvous, capture of the exchange, barrier-bracketed timed region, max over ranks,
     ONE JSON line from rank 0 -- completes, no wait times out and the ranks hold identical parameters afterwards."""
     import json
     import subprocess
@@ -410,7 +411,7 @@ def test_bench_flow_eight_ranks_one_device():
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MVAE_BENCH_BACKEND="gloo", MVAE_BENCH_ONE_DEVICE="1", MVAE_DP_EXCHANGE="peer2",
+    env = dict(os.environ, MVAE_BENCH_BACKEND="gloo", MVAE_BENCH_ONE_DEVICE="1", MVAE_DP_EXCHANGE=exchange,
                MVAE_PEER_TIMEOUT="20")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20",
@@ -420,7 +421,7 @@ def test_bench_flow_eight_ranks_one_device():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak" and d["config"]["exchange"] == "peer2"
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak" and d["config"]["exchange"] == exchange
     assert d["config"]["graph_replays"] == 1 and d["config"]["ranks_identical"] is True
     assert d["config"]["peer_timeouts"] == 0 and d["value"] > 0
 
