@@ -1583,7 +1583,8 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
                                                     const float* h, const float* Wh, float* dheads, float* dh,
                                                     float* drpart, const float* g, const float* hd, float* dWl,
                                                     float beta, int B, int H, int D, int NH, int Z, int n_rows,
-                                                    AdamArgs awl, const float* duals) {
+                                                    AdamArgs awl, const float* duals, const float* dzp, float* dheadsF,
+                                                    float* dhF) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // [H] dhd row | [1024] dz partials
   __shared__ float red[4][16][17];
   __shared__ float sh2[2];
@@ -1707,13 +1708,17 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
       const int c = tid + 256 * u;
       if (c < H) dhd_s[c] = dhd_r[u];
     }
-  } else {
+  } else if (!dzp) {
     for (int k = tid; k < H; k += 256) dhd_s[k] = dhd[row * H + k];
   }
   // generic 16-byte path of dz: thread (slice s2, column quad j4) owns rows c = s2, s2 + nslv, ... of W_d0; the
   // first 24 of them are requested here, ahead of the barrier (one round trip instead of one per 4 rows)
   constexpr int kDzB = 24;
-  const bool dz_vec = !FAST && (Z & 3) == 0 && aligned16(Wd0);
+  // dzp (generic shapes on tile-aligned sizes: the large components): dz arrives as the partial products of launch 4's dhd
+  // tiles -- [row block][tile][z tile][64][4], as for the block backward -- and the row adds its 25 partials in tile order
+  // instead of contracting its dhd row with the whole of W_d0 (H x Z floats per ROW: 65 KB of 4-byte requests for `h40`)
+  const bool use_dzp = !FAST && dzp != nullptr;
+  const bool dz_vec = !FAST && !use_dzp && (Z & 3) == 0 && aligned16(Wd0);
   const int nj4 = dz_vec ? (Z >> 2) : 1, nslv = 256 / (nj4 > 256 ? 256 : nj4);
   const int j4 = tid % nj4, s2 = tid / nj4;
   float4 wzv[kDzB];
@@ -1745,7 +1750,26 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
 
   // ---- dz[j] = sum_c dhd[c] W_d0[c][j]: thread (slice, j) accumulates a strided slice of c; wave 3 adds the slices
   // in slice order
-  {
+  if (use_dzp) {
+    const int ntH = (H + 15) >> 4, ZT = (Z + 15) >> 4;
+    const int mt = (int)(row >> 4), rr = (int)(row & 15);
+    for (int j = tid; j < Z; j += 256) {
+      const float* src = dzp + ((((size_t)mt * ntH) * ZT + (j >> 4)) * 64 + (rr >> 2) * 16 + (j & 15)) * 4 + (rr & 3);
+      const size_t stride = (size_t)ZT * 256;  // floats from one tile's record to the next tile's
+      float tot = 0.f;
+      int nt = 0;
+      for (; nt + 8 <= ntH; nt += 8) {  // eight requests in flight, added in tile order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(nt + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += v[u];
+      }
+      for (; nt < ntH; ++nt) tot += src[(size_t)nt * stride];
+      dz_s[j] = tot;
+    }
+    lds_barrier();
+  } else {
     float p = 0.f;
     if (zv) {
       // thread's flat vectors e4 = tid + 256 u: row c = e4 / (Z/4), columns 4 (e4 % (Z/4)) .. +3; the column half is the
@@ -1858,6 +1882,9 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
   lds_barrier();
   MV_STAMP(11);
   if (tid < NH) dheads[row * ldh + tid] = dheads_s[tid];
+  if (dheadsF) {  // (uniform; with dzp) fragment order, whole 16-column tiles, zero past NH: launch 6 is k_enc_bwd3
+    for (int c = tid; c < ((NH + 15) & ~15); c += 256) dheadsF[frag_off((int)row, c, B >> 4)] = c < NH ? dheads_s[c] : 0.f;
+  }
   // ---- dh = (dheads W_heads) * [h > 0]   (K = NH is small)
   if (zv) {
     if (tid < (H >> 2)) {
@@ -1921,7 +1948,15 @@ __global__ __launch_bounds__(64 * kTileWaves5) void k_latent_bwd(CompTable t, co
       tot.y = hmv.y > 0.f ? tot.y : 0.f;
       tot.z = hmv.z > 0.f ? tot.z : 0.f;
       tot.w = hmv.w > 0.f ? tot.w : 0.f;
-      *reinterpret_cast<float4*>(dh + row * H + 4 * tid) = tot;
+      if (dhF) {  // (uniform) fragment order only
+        const size_t o = frag_off((int)row, 4 * tid, B >> 4);  // columns 4 tid .. + 3 lie in one tile: 4 floats apart
+        dhF[o] = tot.x;
+        dhF[o + 4] = tot.y;
+        dhF[o + 8] = tot.z;
+        dhF[o + 12] = tot.w;
+      } else {
+        *reinterpret_cast<float4*>(dh + row * H + 4 * tid) = tot;
+      }
     }
   } else {
     for (int c = tid; c < H; c += 256) {
@@ -2920,12 +2955,15 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
   // the block backward (many small components) takes dz from partial products of launch 4's tiles too (z_dim 17 .. 64),
   // and its weight gradients from fragment-order operands (k_enc_bwd3)
   const bool dzp_blk = full && !c->no_lite && uses_blk_bwd(c, aligned16(x)) && Z > 16 && Z <= 64;
-  const bool fr6 = lite || dzp_blk;  // launch 6 reads fragment order
+  // ... and so does the generic per-row backward on tile-aligned shapes (the large components: `h40` contracted a dhd row with
+  // the 65 KB of W_d0 per batch ROW): k_dec1_bwd<LITE 2> with row-major dhd, k_latent_bwd adds the partials
+  const bool dzp_row = full && !c->no_lite && !lite && !dzp_blk && !fast_b && !uses_blk_bwd(c, aligned16(x)) && Z <= 64;
+  const bool fr6 = lite || dzp_blk || dzp_row;  // launch 6 reads fragment order
   // ... and with the block FORWARD (k_fwd3m) hd exists in fragment order only
   const bool hdf_blk = dzp_blk && latent_path(c, aligned16(x)) == MVAE_PATH_BLOCK && c->blk_fwd;
   float *hdF = (lite || hdf_blk) ? ws + c->o_hdF : nullptr, *xF = fr6 ? ws + c->o_xF : nullptr, *hF = fr6 ? ws + c->o_hF : nullptr,
         *dhdF = fr6 ? ws + c->o_dhdF : nullptr, *zF = fr6 ? ws + c->o_zF : nullptr,
-        *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = dzp_blk ? ws + c->o_dhF : nullptr;
+        *dheadsF = fr6 ? ws + c->o_dheadsF : nullptr, *dhF = (dzp_blk || dzp_row) ? ws + c->o_dhF : nullptr;
   // x's copy is written by the padding workgroups of launch 1's XCD-aware grid when it has any, else by short jobs of launch 4
   const bool xf_in_l1 = fr6 && (c->nt_h & 7) != 0;
   if (c->valid_rows < B && !lite && !(dzp_blk && hdf_blk))
@@ -3033,8 +3071,8 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
     if (fwd23 && duals_in_l4) da.n_dual = (B * c->t.total_dirs + 63) / 64;
     const FeedArgs fd = c->feed;  // one-shot: consumed by this step
     c->feed = FeedArgs{};
-    const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, dzp_blk ? dzp : nullptr, P + d.off_w_d0, Z,
-                         z, zF, c->ldz, dzp_blk ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0,
+    const FragArgs fr = {hdF, dhdF, x, xF, (fr6 && !xf_in_l1) ? c->nt_d : 0, (dzp_blk || dzp_row) ? dzp : nullptr, P + d.off_w_d0, Z,
+                         z, zF, c->ldz, (dzp_blk || dzp_row) ? (Z + 15) / 16 : 0, hdf_blk ? 1 : 0,
                          lite ? dzfix : nullptr, P + d.off_w_heads, whF, lite ? 4 : 0, NH, c->valid_rows};
     const int n_short = (da.n_dual + 1 + n_db + fd.n_wg + fr.n_xf + fr.n_zf + fr.n_snap + 7) & ~7;
 #define DBX(AD, FU, DU, LI)                                                                                    \
@@ -3044,7 +3082,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define DB(AD, FU, DU) DBX(AD, FU, DU, 0)
     if (lite) {
       if (fused) DBX(true, true, 0, 1); else DBX(false, true, 0, 1);
-    } else if (dzp_blk) {
+    } else if (dzp_blk || dzp_row) {
       if (fused) DBX(true, true, 0, 2); else DBX(false, true, 0, 2);
     } else
     if (fwd23 && duals_in_l4) {  // full && dmax bucket in {2, 4, 8}
@@ -3064,7 +3102,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
 #define LB(DM, FA, AD)                                                                                              \
   STEP_LAUNCH((k_latent_bwd<DM, FA, AD>), dim3(B + n_dwl), dim3(64 * kTileWaves5), lds, c->t, dhd, P + d.off_w_d0, \
                      c->ldh, h, P + d.off_w_heads, dheads, dh, drpart, g,                                           \
-                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals)
+                     hd, G + d.off_w_logits, beta, B, H, D, NH, Z, B, at(d.off_w_logits), duals, dzp_row ? dzp : nullptr, dzp_row ? dheadsF : nullptr, dzp_row ? dhF : nullptr)
     if (lite) {
       // (no launch 5: k_bwd56, the TAIL part, does its work)
     } else if (uses_blk_bwd(c, aligned16(x))) {
@@ -3114,7 +3152,7 @@ static int step_impl(mvae_ctx* c, const float* x, const float* eps, float beta, 
       else { if (B <= 128) B56N(false, 8); else B56N(false, 16); }
 #undef B56N
 #undef B56
-    } else if (dzp_blk) {
+    } else if (dzp_blk || dzp_row) {
       // seven waves per workgroup: 49 x tiles of a dh column block = 7 x 7, and 1 + 11 + 18 + 175 workgroups for config [3] fit
       // one per CU (five-wave workgroups, 291 of them: 39.0 us per step against 37.8)
       constexpr int w3 = 7;
