@@ -280,12 +280,19 @@ def conv_kernel_traffic(op):
             doc = json.load(open(path))
         except (OSError, ValueError):
             continue
+        note = ""
         if doc.get("source_hash") != cur:
-            stale = stale or os.path.basename(path)
-            continue
+            # another revision of the sources: still valid for the conv kernels when THEIR translation units and every header
+            # are byte-identical (mvae_amd.build.conv_file_hashes, recorded in the summary as `conv_file_hashes`)
+            from mvae_amd.build import conv_file_hashes
+            rec = doc.get("conv_file_hashes")
+            if not rec or rec != conv_file_hashes():
+                stale = stale or os.path.basename(path)
+                continue
+            note = f" (collected from source_hash {doc.get('source_hash')}; the conv translation units and all headers are unchanged)"
         k = doc.get("kernels", {}).get(op)
         if k and "traffic_bytes" in k:
-            return int(k["traffic_bytes"]), "profiles/" + os.path.basename(path)
+            return int(k["traffic_bytes"]), "profiles/" + os.path.basename(path) + note
     return None, (f"none: profiles/{stale} was recorded from another build of the kernels (source_hash mismatch)" if stale
                   else "none: no profiles/r*_conv_pmc_traffic.json")
 
@@ -388,15 +395,29 @@ def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
         suffix = tag[1 + len(digits):]
         return (int(digits or 0), 1 if suffix == "" else 0, suffix)
     stale = None
+    cur_isa = None  # machine-code fingerprints of this build's step kernels (computed only if a summary of another revision is met)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_order, reverse=True):
         name = os.path.basename(path)
+        if "_conv_" in name:  # (the conv engine's summaries: conv_kernel_traffic)
+            continue
         try:
             with open(path) as fh:
                 doc = json.load(fh)
-            if doc.get("source_hash") != cur:
-                stale = stale or name
-                continue
             kern = doc.get("configs", {}).get(pmc_config) if pmc_config else doc["kernels"]
+            same_code = None
+            if doc.get("source_hash") != cur:
+                # another revision of the sources: its counters still describe a launch whose MACHINE CODE is identical in this
+                # build (mvae_amd.build.kernel_isa: fingerprints of the disassembly, recorded in the summary next to source_hash)
+                rec = (doc.get("kernel_isa") or {}).get("hashes")
+                if rec and kern:
+                    if cur_isa is None:
+                        from mvae_amd.build import kernel_isa
+                        cur_isa = kernel_isa((doc.get("kernel_isa") or {}).get("unit", "mvae_step")) or {}
+                    same_code = {k for k in kern if rec.get(k) is not None and rec.get(k) == cur_isa.get(k)}
+                if not same_code:
+                    stale = stale or name
+                    continue
+                kern = {k: v for k, v in kern.items() if k in same_code}  # (a launch whose code changed raises KeyError below)
             if kern is None:
                 continue
             # a profile slot -> the kernels that can fill it (the fused / block / per-row / wave-cooperative paths)
@@ -412,9 +433,17 @@ def mlp_roofline(eng, prof, step_s, fixed, pmc_config=None):
                     if all(g in kern for g in group):
                         return sum(kern[g]["traffic_bytes"] for g in group)
                 raise KeyError(slot)
-            traffic = slot_bytes(dom)
-            traffic_step = sum(slot_bytes(k) for k in prof)
+            try:
+                t_dom, t_step = slot_bytes(dom), sum(slot_bytes(k) for k in prof)
+            except KeyError:
+                if same_code is not None:  # a launch of this step has other machine code than the summary's revision
+                    stale = stale or name
+                raise
+            traffic, traffic_step = t_dom, t_step
             traffic_src = "profiles/" + name + (f" [configs.{pmc_config}]" if pmc_config else "")
+            if same_code is not None:
+                traffic_src += (f" (collected from source_hash {doc.get('source_hash')}; the machine code of this step's "
+                                f"{len(prof)} launches is identical in this build: build.kernel_isa)")
             break
         except (OSError, KeyError, ValueError):
             continue

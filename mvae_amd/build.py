@@ -7,6 +7,7 @@ csrc/_obj/*.o and linked; a unit is recompiled only when it or a header is newer
                                                         written to libmvae_hip_timing.so)
 """
 import os
+from typing import Optional
 import shutil
 import subprocess
 import sys
@@ -38,6 +39,25 @@ def source_hash() -> str:
         with open(path, "rb") as fh:
             h.update(os.path.basename(path).encode() + b"\0" + fh.read() + b"\0")
     return h.hexdigest()[:16]
+
+
+CONV_UNITS = ("mvae_conv", "mvae_p3", "mvae_f32pp", "mvae_edge")
+
+
+def file_hashes(paths=None) -> dict:
+    """{file name: sha1 of its bytes} of the sources (default: all of DEPS).  The conv counter summaries record them: a conv
+    kernel's machine code depends on its own translation unit and the headers only (conv_source_hash)."""
+    import hashlib
+    out = {}
+    for path in (paths or DEPS):
+        with open(path, "rb") as fh:
+            out[os.path.basename(path)] = hashlib.sha1(fh.read()).hexdigest()[:16]
+    return out
+
+
+def conv_file_hashes() -> dict:
+    """file_hashes of what the conv engine's kernels are compiled from: the four conv translation units and every header."""
+    return file_hashes([os.path.join(CSRC, u + ".hip") for u in CONV_UNITS] + HEADERS)
 
 
 def lib_is_fresh(lib: str = LIB) -> bool:
@@ -86,3 +106,59 @@ def build(force: bool = False, verbose: bool = False, timing: bool = False) -> s
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))
+
+
+_LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _isa_of_elf(elf: str) -> dict:
+    """{kernel base name: fingerprint over the machine code of all of its instantiations} of one device ELF: per function
+    the disassembly's instruction text + encodings (addresses dropped), per base name the sorted (symbol, hash) pairs."""
+    import hashlib
+    import re
+    import subprocess
+    text = subprocess.check_output([os.path.join(_LLVM, "llvm-objdump"), "-d", elf], text=True)
+    per, name, buf = {}, None, []
+
+    def close():
+        if name:
+            per[name] = hashlib.sha256("".join(buf).encode()).hexdigest()[:16]
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            close()
+            name, buf = m.group(1), []
+        elif name:
+            t = line.split("//")
+            enc = t[1].split(":", 1)[1].strip() if len(t) > 1 and ":" in t[1] else ""
+            buf.append(t[0].strip() + "|" + enc + "\n")
+    close()
+    groups = {}
+    for sym, hsh in per.items():
+        m = re.match(r"^_Z(\d+)", sym)
+        base = sym[m.end():m.end() + int(m.group(1))] if m else sym
+        groups.setdefault(base, []).append(sym + ":" + hsh)
+    return {b: hashlib.sha256("\n".join(sorted(v)).encode()).hexdigest()[:16] for b, v in groups.items()}
+
+
+def kernel_isa(unit: str = "mvae_step", objdir: Optional[str] = None) -> Optional[dict]:
+    """Machine-code fingerprints of the kernels of one translation unit, taken from the object the library was linked from
+    (csrc/_obj/<unit>.o: its gfx950 code object is extracted and disassembled with the ROCm install's llvm tools).  Counter
+    files record them next to `source_hash`: a summary collected from ANOTHER revision of the sources still describes a
+    launch whose machine code is identical in this build (bench.py).  None when the object or the tools are missing."""
+    import subprocess
+    import tempfile
+    obj = os.path.join(objdir or os.path.join(CSRC, "_obj"), unit + ".o")
+    tools = [os.path.join(_LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(obj) or not all(os.path.exists(t) for t in tools):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fat, elf = os.path.join(d, "fat.bin"), os.path.join(d, "dev.elf")
+            subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, obj], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+            subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                   "--input=" + fat, "--output=" + elf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return _isa_of_elf(elf)
+    except (OSError, subprocess.CalledProcessError, ValueError):
+        return None

@@ -5,7 +5,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from mvae_amd.build import source_hash  # noqa: E402
+from mvae_amd.build import conv_file_hashes, kernel_isa, source_hash  # noqa: E402
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -86,7 +86,8 @@ if fetch and write:
                       "reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE taken as is "
                       "(uncalibrated per the guide). Both count L2<->fabric traffic, Infinity-Cache hits included, so "
                       "this is an upper bound on HBM bytes (the whole working set is ~12 MB and MALL-resident).",
-        "source_hash": source_hash(),  # bench.py refuses this summary once the kernels' sources change
+        "source_hash": source_hash(),  # bench.py refuses this summary once the kernels' sources change ...
+        "kernel_isa": {"unit": "mvae_step", "hashes": kernel_isa("mvae_step")},  # ... unless the launches' machine code did not
         "kernels": kernels}
     # the other kernel paths (tools/collect_profiles.sh step 3b): per-config kernel tables under "configs"
     rec["configs"] = {}
@@ -195,7 +196,7 @@ if os.path.exists(ct):
                          "as reported; both are L2<->fabric bytes, Infinity-Cache hits included (upper bound on HBM bytes)",
            "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): the fraction of SIMD cycles "
                              "with the matrix pipe busy (f32 MFMA 16x16x4: 32 cycles, bf16 16x16x32: 16 cycles per instruction)",
-           "source_hash": source_hash(), "kernels": kern}
+           "source_hash": source_hash(), "conv_file_hashes": conv_file_hashes(), "kernels": kern}
     with open(os.path.join(dst, f"{tag}_conv_pmc_traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
     print("wrote", f"{tag}_conv_pmc_traffic.json")
