@@ -109,6 +109,7 @@ if __name__ == "__main__":
 
 
 _LLVM = "/opt/rocm/lib/llvm/bin"
+_ISA_CACHE: dict = {}
 
 
 def _isa_of_elf(elf: str) -> dict:
@@ -152,6 +153,10 @@ def kernel_isa(unit: str = "mvae_step", objdir: Optional[str] = None) -> Optiona
     tools = [os.path.join(_LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
     if not os.path.exists(obj) or not all(os.path.exists(t) for t in tools):
         return None
+    key = (obj, os.path.getmtime(obj), os.path.getsize(obj))
+    if key in _ISA_CACHE:  # (~5 s per unit: once per process)
+        return _ISA_CACHE[key]
+    _ISA_CACHE[key] = None
     try:
         with tempfile.TemporaryDirectory() as d:
             fat, elf = os.path.join(d, "fat.bin"), os.path.join(d, "dev.elf")
@@ -159,6 +164,7 @@ def kernel_isa(unit: str = "mvae_step", objdir: Optional[str] = None) -> Optiona
                                   stderr=subprocess.DEVNULL)
             subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                    "--input=" + fat, "--output=" + elf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            return _isa_of_elf(elf)
+            _ISA_CACHE[key] = _isa_of_elf(elf)
+            return _ISA_CACHE[key]
     except (OSError, subprocess.CalledProcessError, ValueError):
         return None
