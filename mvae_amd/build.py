@@ -160,8 +160,9 @@ def kernel_isa(unit: str = "mvae_step", objdir: Optional[str] = None) -> Optiona
     try:
         with tempfile.TemporaryDirectory() as d:
             fat, elf = os.path.join(d, "fat.bin"), os.path.join(d, "dev.elf")
-            subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, obj], stdout=subprocess.DEVNULL,
-                                  stderr=subprocess.DEVNULL)
+            # (an explicit output file: without one llvm-objcopy rewrites its INPUT in place)
+            subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                    "--input=" + fat, "--output=" + elf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             _ISA_CACHE[key] = _isa_of_elf(elf)
