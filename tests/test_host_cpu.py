@@ -135,3 +135,67 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "/root/reference" not in src or f.endswith((".hip", ".hpp", ".py")) and \
                     not re.search(r"open\(.*/root/reference", src), f
+
+
+def test_counter_summaries_are_quoted_only_for_identical_machine_code(tmp_path, monkeypatch):
+    """bench.py quotes profiles/r*_pmc_traffic.json for the build it runs: same `source_hash`, or -- a summary of another
+    source revision -- identical machine code of every launch it is quoted for (`build.kernel_isa` fingerprints recorded in
+    the summary).  A changed kernel, a summary without fingerprints, or another revision's conv translation units: refused."""
+    import importlib.util
+    import json
+    import sys
+    from mvae_amd import build
+    isa = build.kernel_isa("mvae_step")
+    if isa is None:
+        pytest.skip("no csrc/_obj/mvae_step.o or no llvm tools: the fingerprints cannot be taken here")
+    for k in ("k_enc_fwd", "k_fwd23", "k_dec1_bwd", "k_bwd56"):
+        assert k in isa and len(isa[k]) == 16
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+
+    class _Flat:
+        def n_logical_params(self):
+            return 636000
+
+    class _Lay:
+        heads_dim, z_dim, eps_dim = 12, 8, 6
+
+    class _Eng:
+        layout, flat = _Lay(), _Flat()
+
+    prof = {"enc_fwd": 0.0046, "latent_fwd": 0.0, "dec1_fwd": 0.0093, "dec1_bwd": 0.0049, "latent_bwd": 0.0, "enc_bwd": 0.0083}
+    kern = {k: {"traffic_bytes": 1000 * (i + 1)} for i, k in enumerate(("k_enc_fwd", "k_fwd23", "k_dec1_bwd", "k_bwd56"))}
+
+    def line(doc):
+        with open(tmp_path / "profiles" / "r99_pmc_traffic.json", "w") as fh:
+            json.dump(doc, fh)
+        r = b.mlp_roofline(_Eng(), prof, 28.8e-6, False)
+        return r["traffic_step"], r["traffic_source"]
+
+    same = {"source_hash": build.source_hash(), "kernels": kern}
+    assert line(same) == (10000, "profiles/r99_pmc_traffic.json")
+    other = {"source_hash": "0" * 16, "kernels": kern}
+    step, src = line(other)  # another revision, no fingerprints: refused
+    assert step is None and "source_hash mismatch" in src
+    other["kernel_isa"] = {"unit": "mvae_step", "hashes": dict(isa)}
+    step, src = line(other)  # another revision, identical machine code: quoted, and the line says so
+    assert step == 10000 and "collected from source_hash " + "0" * 16 in src and "identical" in src
+    other["kernel_isa"]["hashes"]["k_bwd56"] = "f" * 16
+    step, src = line(other)  # one launch of the step has other machine code: refused
+    assert step is None and "source_hash mismatch" in src
+    # conv summaries: the conv translation units and every header byte-identical
+    ck = {"e2f": {"traffic_bytes": 123}}
+    with open(tmp_path / "profiles" / "r99_conv_pmc_traffic.json", "w") as fh:
+        json.dump({"source_hash": "0" * 16, "kernels": ck, "conv_file_hashes": build.conv_file_hashes()}, fh)
+    val, src = b.conv_kernel_traffic("e2f")
+    assert val == 123 and "unchanged" in src
+    bad = dict(build.conv_file_hashes(), **{"mvae_p3.hip": "0" * 16})
+    with open(tmp_path / "profiles" / "r99_conv_pmc_traffic.json", "w") as fh:
+        json.dump({"source_hash": "0" * 16, "kernels": ck, "conv_file_hashes": bad}, fh)
+    val, src = b.conv_kernel_traffic("e2f")
+    assert val is None and "source_hash mismatch" in src
